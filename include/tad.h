@@ -1,0 +1,199 @@
+/*
+ * tad.h — C ABI of libtad_mi355x.so, the MI355X (gfx950) throughput-anomaly-detection engine.
+ *
+ * This is the drop-in boundary for ONE path of antrea-io/theia: the Throughput Anomaly
+ * Detection job.  The reference has no FFI for it — the boundary there is a process boundary:
+ *   - pkg/controller/anomalydetector/controller.go:525-698 builds the job's argument vector
+ *     (--algo, --start_time, --end_time, --agg-flow, --pod-label, ... --id) and launches a
+ *     SparkApplication;
+ *   - plugins/anomaly-detection/anomaly_detection.py:647-710 (anomaly_detection) runs it:
+ *     ClickHouse GROUP BY (:507-614) -> per-key series + stddev_samp (:664-684) ->
+ *     EWMA / ARIMA / DBSCAN per key (:146-349) -> explode + keep anomalies (:352-421) ->
+ *     append to default.tadetector (:713-726).
+ * A cgo host (theia-manager) binds exactly the entry points below instead of launching Spark;
+ * INTEGRATION.md shows that binding.  Every struct is plain C: pointers, sizes, enums.  No
+ * callbacks, no retained caller pointers after return, no exceptions across the boundary.
+ *
+ * Strings never cross the boundary: the host dictionary-encodes the mode's key columns
+ * (anomaly_detection.py:109-137 DF_GROUP_COLUMNS / DF_AGG_GRP_COLUMNS_*) into dense uint64
+ * key ids and evaluates the string predicates of the SQL (:507-614); a row the predicates reject
+ * carries TAD_KEY_SKIP.
+ */
+#ifndef THEIA_TAD_H
+#define THEIA_TAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAD_ABI_VERSION 1
+#define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
+
+/* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
+enum {
+  TAD_OK = 0,
+  TAD_ERR_INVALID_ARGUMENT = -1, /* maps to the controller's illegal-argument FAILED state,
+                                    controller.go:505-514 */
+  TAD_ERR_NO_DEVICE = -2,        /* no gfx950 device / HIP runtime failure at create */
+  TAD_ERR_OUT_OF_MEMORY = -3,
+  TAD_ERR_HIP = -4,              /* a HIP call or kernel failed */
+  TAD_ERR_KEY_RANGE = -5,        /* a key id >= num_keys (and != TAD_KEY_SKIP) */
+  TAD_ERR_GRID_TOO_LARGE = -6,   /* num_keys x time-lattice does not fit the workspace limit */
+  TAD_ERR_BUSY = -7
+};
+
+/* --algo, controller.go:527-533 ("EWMA" | "ARIMA" | "DBSCAN"); anomaly_detection.py:697-709 */
+typedef enum { TAD_ALGO_EWMA = 0, TAD_ALGO_ARIMA = 1, TAD_ALGO_DBSCAN = 2 } tad_algo;
+
+/* --agg-flow, controller.go:560-620; anomaly_detection.py:617-628 (aggType literal).
+ * NONE  : per-connection keys, max(throughput)   (anomaly_detection.py:52-61)
+ * POD / SVC / EXTERNAL : sum(throughput)         (:63-106)                              */
+typedef enum { TAD_AGG_NONE = 0, TAD_AGG_POD = 1, TAD_AGG_SVC = 2, TAD_AGG_EXTERNAL = 3 } tad_agg_flow;
+
+/* Stage-0 aggregate over rows that share (key, flowEndSeconds). UInt64 semantics of ClickHouse:
+ * SUM wraps mod 2^64, MAX is unsigned (create_table.sh:74 `throughput UInt64`). */
+typedef enum { TAD_OP_AUTO = 0, TAD_OP_MAX = 1, TAD_OP_SUM = 2 } tad_value_op;
+
+typedef enum { TAD_MEM_HOST = 0, TAD_MEM_DEVICE = 1 } tad_mem;
+
+/* tad_job.flags */
+#define TAD_FLAG_EMIT_ALL_POINTS 1u /* result = every point (plotDF before the filter of :394),
+                                       with its verdict in tad_result.anomaly; for inspection/tests */
+
+typedef struct tad_engine tad_engine; /* opaque; one per GPU */
+
+typedef struct {
+  int32_t device;            /* HIP device ordinal */
+  void *stream;              /* hipStream_t to run on, or NULL: the engine creates its own */
+  uint64_t workspace_limit;  /* bytes of HBM the engine may use for its grid; 0 = 3/4 of free */
+} tad_engine_opts;
+
+/* Mirrors the job's argument vector (anomaly_detection.py:781-870). */
+typedef struct {
+  tad_algo algo;
+  tad_agg_flow agg_flow;
+  tad_value_op value_op;     /* AUTO: MAX for TAD_AGG_NONE, SUM otherwise */
+  int64_t start_time;        /* epoch seconds; 0 = unset. Row kept iff flow_start_s >= start_time
+                                (:581-583). Ignored when columns.flow_start_s is NULL. */
+  int64_t end_time;          /* epoch seconds; 0 = unset. Row kept iff flow_end_s < end_time (:584-586) */
+  double ewma_alpha;         /* 0 -> 0.5 (:157) */
+  double dbscan_eps;         /* 0 -> 250000000 (:342) */
+  int32_t dbscan_min_samples;/* 0 -> 4 (:342) */
+  int32_t arima_maxiter;     /* 0 -> 50 (statsmodels fit() default) */
+  uint32_t flags;            /* TAD_FLAG_* */
+  char id[64];               /* --id, echoed into the result (tadetector.id, :503) */
+} tad_job;
+
+/* One columnar batch of flow rows (the columns the SQL of :507-614 touches, after the host's
+ * dictionary encoding).  All arrays have n_rows entries; memory says where they live. */
+typedef struct {
+  uint64_t n_rows;
+  const uint64_t *key_id;       /* dense id of the row's key, < num_keys, or TAD_KEY_SKIP */
+  const uint64_t *key_id2;      /* optional (NULL): second key of the same row — pod mode's
+                                   UNION ALL of inbound + outbound (:556-565) */
+  const int64_t *flow_end_s;    /* flowEndSeconds, epoch seconds (DateTime) */
+  const int64_t *flow_start_s;  /* optional (NULL): flowStartSeconds for the start_time filter */
+  const uint64_t *value;        /* throughput (UInt64) — or any UInt64 column, e.g. octetDeltaCount */
+  uint64_t num_keys;            /* size of the key dictionary (ids are 0..num_keys-1) */
+  tad_mem memory;
+  /* Optional time lattice: flow_end_s = t0 + step*bucket, bucket < n_buckets.  n_buckets == 0:
+   * the engine derives (min, gcd of differences, max) itself with one extra pass over flow_end_s. */
+  int64_t t0;
+  int64_t step;
+  uint64_t n_buckets;
+} tad_columns;
+
+/* Per-run counters and stage timings (for CompletedStages/TotalStages-style progress and bench). */
+typedef struct {
+  uint64_t rows_in;        /* n_rows */
+  uint64_t rows_used;      /* rows that passed the filters (each key of a 2-key row counts) */
+  uint64_t n_keys;         /* keys with >= 1 point */
+  uint64_t n_points;       /* distinct (key, flowEndSeconds) points = P */
+  uint64_t n_anomalies;    /* A (0 => caller writes the sentinel row, :395-420) */
+  uint64_t keys_no_result; /* ARIMA keys that yield no rows (n<=3, x<=0, constant; :232-234,260-264) */
+  uint64_t kalman_steps;   /* ARIMA: filter time-steps over all likelihood evaluations */
+  uint64_t arima_fits;     /* ARIMA: number of (key,t) fits */
+  int64_t t0, step;        /* the time lattice used */
+  uint64_t n_buckets;
+  float ms_meta;           /* lattice derivation pass */
+  float ms_stage0;         /* grid clear + scatter aggregation kernel(s) */
+  float ms_scatter;        /* the scatter kernel alone (dominant kernel) */
+  float ms_detect;         /* per-key sigma + detector + compaction */
+  float ms_total;          /* device time of the whole run, HIP events on the engine stream */
+} tad_stats;
+
+/* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).
+ * Columns = what the mode-independent part of a tadetector row needs (create_table.sh:363-384):
+ * flowEndSeconds, throughputStandardDeviation, algoCalc, throughput; the host expands key_id
+ * back into the mode's string columns and adds aggType / algoType / id / anomaly="true". */
+typedef struct {
+  uint64_t n_rows;         /* rows in the arrays below: stats.n_anomalies, or stats.n_points with
+                              TAD_FLAG_EMIT_ALL_POINTS */
+  uint64_t *key_id;
+  int64_t *flow_end_s;
+  double *throughput;      /* float(x): correctly rounded uint64 -> double (:161) */
+  double *algo_calc;       /* EWMA value / ARIMA prediction / 0.0 for DBSCAN (:312-322) */
+  double *stddev;          /* the key's stddev_samp (:674-684) */
+  uint8_t *anomaly;        /* NULL unless TAD_FLAG_EMIT_ALL_POINTS: verdict per emitted point */
+  tad_mem memory;          /* where the arrays live (same as the request's out_memory) */
+  tad_stats stats;
+  char id[64];
+} tad_result;
+
+/* ---- engine life cycle ---- */
+int tad_abi_version(void);
+int tad_engine_create(const tad_engine_opts *opts, tad_engine **out);
+void tad_engine_destroy(tad_engine *e);
+/* Thread-safe; the returned string is owned by the engine (or static when e == NULL). */
+const char *tad_last_error(tad_engine *e);
+
+/* ---- the job: replaces the SparkApplication run (anomaly_detection.py:647-710) ----
+ * Callable from several OS threads (controller.go:199-201 runs 4 workers): runs on one engine
+ * serialise on an internal mutex.  out_memory selects host or device result arrays. */
+int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory,
+            tad_result **out);
+void tad_result_free(tad_engine *e, tad_result *r);
+/* Stage counter for Status.CompletedStages / TotalStages (controller.go:426-453); callable while
+ * tad_run executes on another thread. */
+int tad_progress(tad_engine *e, int32_t *done, int32_t *total);
+
+/* ---- per-series entry points: the reference's pure functions, one key, values in time order.
+ * Same device kernels as tad_run (a 1-key series table).  x, out arrays are HOST memory. ---- */
+/* calculate_ewma (:146-165): out[n]. */
+int tad_series_ewma(tad_engine *e, const uint64_t *x, uint64_t n, double alpha, double *out);
+/* calculate_ewma_anomaly (:168-212): verdict[n] in {0,1}. has_stddev == 0 models stddev None. */
+int tad_series_ewma_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, double alpha,
+                            int has_stddev, double stddev, uint8_t *verdict);
+/* stddev_samp over the series (:674-684). *has_stddev = 0 when n < 2 (Spark returns null). */
+int tad_series_stddev(tad_engine *e, const uint64_t *x, uint64_t n, int *has_stddev, double *stddev);
+/* calculate_dbscan_anomaly (:325-349): verdict[n] = (label == -1). */
+int tad_series_dbscan_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, double eps,
+                              int min_samples, uint8_t *verdict);
+/* calculate_arima (:215-264): out[n]; *has_result = 0 reproduces the `return None` cases. */
+int tad_series_arima(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int *has_result,
+                     double *out);
+/* calculate_arima_anomaly (:267-309): verdict[n]; *n_verdict = 1 and verdict[0] = 0 when ARIMA
+ * returned None (:284-287). */
+int tad_series_arima_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter,
+                             int has_stddev, double stddev, uint8_t *verdict, uint64_t *n_verdict);
+
+/* ---- deterministic synthetic flow table, generated straight into HBM ----
+ * Rows [first_row, first_row + n_rows) of the table (seed, num_keys, n_buckets); the three output
+ * arrays are DEVICE memory with n_rows entries.  Definition: theia_amd/csrc/tad_synth.hip. */
+int tad_synth_generate(tad_engine *e, uint64_t seed, uint64_t first_row, uint64_t n_rows,
+                       uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id,
+                       int64_t *flow_end_s, uint64_t *value);
+
+/* ---- device memory helpers for hosts without a HIP binding (cgo) ---- */
+int tad_device_alloc(tad_engine *e, uint64_t bytes, void **ptr);
+int tad_device_free(tad_engine *e, void *ptr);
+int tad_copy_to_device(tad_engine *e, void *dst, const void *src, uint64_t bytes);
+int tad_copy_to_host(tad_engine *e, void *dst, const void *src, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THEIA_TAD_H */

@@ -1,0 +1,243 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+(a) the reference's golden vectors, (b) outputs of the reference's own functions, (c) the CPU oracle
+on seeded tables, (d) size-independent properties at BASELINE.json's full size.
+
+Bar: integers and verdicts bit-exact; EWMA and stddev_samp bit-exact against the oracle (both
+evaluate the same sequential FP64 recurrences; BASELINE.json asks for 1e-6 relative)."""
+import numpy as np
+import pytest
+
+from oracle import tad_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SKIP = np.uint64(orc.MASK64)
+
+
+# ------------------------------------------------------------------ (a) reference golden vectors
+def test_series_ewma_equals_reference_golden_exactly(engine, golden):
+    # the reference asserts exact equality (anomaly_detection_test.py:252-258); so do we
+    got = engine.series_ewma(golden["throughput_list"])
+    assert got.tolist() == golden["expected_ewma_row_list"]
+
+
+def test_series_ewma_anomaly_equals_reference_golden(engine, golden):
+    got = engine.series_ewma_anomaly(golden["throughput_list"], golden["stddev"])
+    assert got.tolist() == golden["expected_anomaly_list_ewma"]
+    assert engine.series_ewma_anomaly(golden["throughput_list"], None).tolist() == [False] * 90   # stddev None (:198-201)
+
+
+def test_series_dbscan_anomaly_equals_reference_golden(engine, golden):
+    got = engine.series_dbscan_anomaly(golden["throughput_list"])
+    assert got.tolist() == golden["expected_dbscan_anomaly_list"]
+
+
+def test_series_stddev_equals_reference_constant_and_oracle_bits(engine, golden):
+    sd = engine.series_stddev(golden["throughput_list"])
+    assert abs(sd - golden["stddev"]) / golden["stddev"] < 1e-13        # test constant has 14 digits
+    assert sd == orc.stddev_samp_series(orc.u64_to_f64(golden["throughput_list"]))   # same recurrence -> same bits
+    assert engine.series_stddev([5]) is None and engine.series_stddev([]) is None
+
+
+# ------------------------------------------------------------------ (b) reference function outputs
+def test_series_functions_equal_reference_outputs(engine, ref_outputs):
+    for name, e in ref_outputs["series"].items():
+        x = e["x"]
+        sd = e["stddev_numpy_ddof1"]
+        assert engine.series_ewma(x).tolist() == e["ewma"], name
+        assert engine.series_ewma_anomaly(x, sd).tolist() == e["ewma_anomaly"], name
+        assert engine.series_ewma_anomaly(x, None if sd is None else sd / 2).tolist() == e["ewma_anomaly_half_sigma"], name
+        assert engine.series_dbscan_anomaly(x).tolist() == e["dbscan_anomaly"], name
+        mine = engine.series_stddev(x)
+        assert (mine is None) == (len(x) < 2), name
+        if mine is not None:
+            assert mine == orc.stddev_samp_series(orc.u64_to_f64(x)), name
+
+
+def test_series_long_dbscan_uses_fallback_kernel(engine):
+    rng = np.random.default_rng(5)
+    x = (4_000_000_000 + rng.integers(-900_000_000, 900_000_000, size=9000)).astype(np.uint64)
+    x[::1000] *= np.uint64(4)
+    assert (engine.series_dbscan_anomaly(x) == orc.dbscan_noise_1d(orc.u64_to_f64(x))).all()
+    assert engine.series_ewma(x).tolist() == orc.calculate_ewma(x.tolist())
+
+
+# ------------------------------------------------------------------ (c) whole job vs oracle
+def check_job(engine, algo, key, t, v, num_keys, agg_flow="svc", **kw):
+    okw = {k: kw[k] for k in ("key_id2", "flow_start_s", "start_time", "end_time") if k in kw}
+    want = orc.run_job(algo, key, t, v, agg_flow=agg_flow, **okw)
+    # every point, with verdicts (plotDF before the filter)
+    allp = engine.run(algo, key, t, v, num_keys, agg_flow=agg_flow, emit_all=True, **kw)
+    pk, pt, pv = want["points"]
+    assert allp.n_rows == want["n_points"] == allp.stats["n_points"]
+    assert allp.stats["n_keys"] == want["n_keys"]
+    assert (allp["key_id"] == pk).all() and (allp["flow_end_s"] == pt).all()
+    assert (allp["throughput"] == orc.u64_to_f64(pv)).all()          # integer aggregates, bit-exact
+    n = np.diff(want["ptr"])
+    assert (allp["stddev"] == np.repeat(want["sigma"], n)).all()       # same recurrence -> same bits
+    assert (allp["algo_calc"] == want["calc_all"]).all()               # EWMA bit-exact / DBSCAN 0.0
+    assert (allp["anomaly"].astype(bool) == want["anomaly_all"]).all()
+    assert allp.stats["n_anomalies"] == want["n_anomalies"]
+    # the job's real output: anomalous points only
+    res = engine.run(algo, key, t, v, num_keys, agg_flow=agg_flow, **kw)
+    assert res.n_rows == want["n_anomalies"] == res.stats["n_anomalies"]
+    for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+        assert (res[f] == want[f]).all(), f
+    return res, want
+
+
+@pytest.mark.parametrize("algo", ["EWMA", "DBSCAN"])
+@pytest.mark.parametrize("n_rows,K,T", [(1000, 7, 13), (100003, 100, 250), (1000000, 1000, 250), (300000, 3000, 100)])
+def test_job_synthetic_tables_match_oracle(engine, algo, n_rows, K, T):
+    k, t, v = orc.synth_rows(0, n_rows, K, T)
+    res, want = check_job(engine, algo, k, t, v, K, agg_flow="svc")
+    assert res.stats["rows_used"] == n_rows and res.stats["step"] == 60 and res.stats["t0"] == t.min()
+
+
+@pytest.mark.parametrize("algo", ["EWMA", "DBSCAN"])
+def test_job_max_mode_per_connection(engine, algo):
+    k, t, v = orc.synth_rows(0, 200000, 5000, 100)      # mode None: max(throughput), ~0.4 rows/point
+    check_job(engine, algo, k, t, v, 5000, agg_flow="")
+
+
+def test_job_uint64_wrap_and_huge_values(engine):
+    key = np.array([0, 0, 0, 1, 1, 2, 2, 2, 2, 2], dtype=np.uint64)
+    t = np.array([10, 10, 20, 10, 10, 5, 6, 7, 8, 9], dtype=np.int64)
+    v = np.array([2**63, 2**63 + 5, 7, 2**64 - 1, 2, 2**53 + 1, 2**53 + 3, 2**63 + 12345, 2**64 - 1, 1], dtype=np.uint64)
+    for agg in ("svc", ""):
+        for algo in ("EWMA", "DBSCAN"):
+            check_job(engine, algo, key, t, v, 3, agg_flow=agg)
+
+
+def test_job_filters_second_key_and_skip(engine):
+    rng = np.random.default_rng(11)
+    n = 50000
+    k, t, v = orc.synth_rows(0, n, 50, 40)
+    k2 = rng.integers(0, 50, size=n).astype(np.uint64)
+    k[rng.random(n) < 0.1] = SKIP
+    k2[rng.random(n) < 0.5] = SKIP
+    ts = t - rng.integers(0, 600, size=n)
+    start, end = int(orc.SYNTH_T_BASE + 60 * 3), int(orc.SYNTH_T_BASE + 60 * 30)
+    for algo in ("EWMA", "DBSCAN"):
+        check_job(engine, algo, k, t, v, 50, agg_flow="pod", key_id2=k2, flow_start_s=ts, start_time=start, end_time=end)
+        check_job(engine, algo, k, t, v, 50, agg_flow="pod", key_id2=k2)
+
+
+def test_job_irregular_timestamps_and_lattice_hints(engine):
+    rng = np.random.default_rng(2)
+    n = 20000
+    key = rng.integers(0, 20, size=n).astype(np.uint64)
+    t = (1_700_000_000 + rng.integers(0, 5000, size=n)).astype(np.int64)       # gcd 1: every second is a bucket
+    v = rng.integers(1, 2**40, size=n).astype(np.uint64)
+    res, _ = check_job(engine, "EWMA", key, t, v, 20)
+    assert res.stats["step"] == 1
+    t7 = (1_700_000_003 + 7 * rng.integers(0, 900, size=n)).astype(np.int64)   # step 7 from an odd origin
+    res, want = check_job(engine, "EWMA", key, t7, v, 20)
+    assert res.stats["step"] == 7
+    # a correct hint gives the same rows; a WRONG hint is detected and re-derived, never trusted
+    good = engine.run("EWMA", key, t7, v, 20, agg_flow="svc", lattice=(int(t7.min()), 7, int((t7.max() - t7.min()) // 7 + 1)))
+    bad = engine.run("EWMA", key, t7, v, 20, agg_flow="svc", lattice=(int(t7.min()) + 1, 60, 10))
+    for r in (good, bad):
+        assert (r["flow_end_s"] == want["flow_end_s"]).all() and (r["algo_calc"] == want["algo_calc"]).all()
+    # a single timestamp: one bucket
+    res, _ = check_job(engine, "DBSCAN", key, np.full(n, 1_700_000_000, dtype=np.int64), v, 20)
+    assert res.stats["n_buckets"] == 1
+
+
+def test_job_empty_and_degenerate_inputs(engine):
+    z = np.zeros(0, dtype=np.uint64)
+    for algo in ("EWMA", "DBSCAN"):
+        r = engine.run(algo, z, z.astype(np.int64), z, 10)
+        assert r.n_rows == 0 and r.stats["n_keys"] == 0 and r.stats["n_points"] == 0
+        r = engine.run(algo, np.full(5, SKIP), np.arange(5, dtype=np.int64), np.arange(5, dtype=np.uint64), 10)
+        assert r.n_rows == 0 and r.stats["rows_used"] == 0
+    # n_k in {1,2,3,4}: sigma null for n=1; DBSCAN flags every point of keys with < 4 points
+    key = np.repeat(np.arange(4, dtype=np.uint64), [1, 2, 3, 4])
+    t = np.concatenate([np.arange(n) for n in (1, 2, 3, 4)]).astype(np.int64) * 60
+    v = np.array([5, 1, 10**10, 3, 3, 3, 8, 8, 8, 8], dtype=np.uint64)
+    check_job(engine, "EWMA", key, t, v, 4)
+    res, _ = check_job(engine, "DBSCAN", key, t, v, 4)
+    assert res.n_rows == 6
+
+
+def test_job_rejects_bad_arguments(engine):
+    from theia_amd import TadError
+    k, t, v = orc.synth_rows(0, 1000, 10, 10)
+    with pytest.raises(TadError) as ei:
+        engine.run("EWMA", k, t, v, 5)                       # ids up to 9 but num_keys = 5
+    assert ei.value.code == -5
+    with pytest.raises(TadError) as ei:
+        engine.run("EWMA", k, t, v, 10, start_time=100, end_time=50)
+    assert ei.value.code == -1 and "EndInterval should be after StartInterval" in ei.value.message
+    with pytest.raises(TadError):
+        engine.run("KMEANS", k, t, v, 10)
+    small = type(engine)(device=0, workspace_limit=1 << 20)
+    with pytest.raises(TadError) as ei:
+        small.run("EWMA", *orc.synth_rows(0, 1000, 100000, 250), 100000)
+    assert ei.value.code == -6
+    small.close()
+
+
+def test_synth_generator_matches_numpy_definition(engine):
+    for first, n, K, T in [(0, 10000, 100, 250), (123457, 5001, 1000000, 100)]:
+        dk, dt, dv = engine.synth(first, n, K, T)
+        k, t, v = orc.synth_rows(first, n, K, T)
+        assert (dk.to_host() == k).all() and (dt.to_host() == t).all() and (dv.to_host() == v).all()
+
+
+def test_device_resident_inputs_and_outputs(engine):
+    n, K, T = 400000, 500, 250
+    dk, dt, dv = engine.synth(0, n, K, T)
+    k, t, v = orc.synth_rows(0, n, K, T)
+    want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+    res = engine.run("EWMA", dk, dt, dv, K, agg_flow="svc", out="device")
+    assert res.memory == "device" and res.n_rows == want["n_anomalies"]
+    for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+        assert (res[f] == want[f]).all(), f
+    assert engine.progress() == (4, 4)
+
+
+# ------------------------------------------------------------------ (d) full-size properties (BASELINE C2 / C4)
+@pytest.mark.parametrize("algo,N,K,T,agg", [("EWMA", 100_000_000, 100_000, 250, "svc"), ("DBSCAN", 100_000_000, 1_000_000, 100, "")])
+def test_full_size_properties(engine, algo, N, K, T, agg):
+    dk, dt, dv = engine.synth(0, N, K, T)
+    res = engine.run(algo, dk, dt, dv, K, agg_flow=agg, emit_all=True, out="device")
+    st = res.stats
+    assert st["rows_used"] == N and st["n_keys"] == K and st["step"] == 60 and st["n_buckets"] == T
+    assert st["n_points"] == res.n_rows <= K * T
+    h = res.to_host()
+    # (key, time) strictly increasing = sorted and duplicate-free
+    dkey = np.diff(h["key_id"].astype(np.int64))
+    dtime = np.diff(h["flow_end_s"])
+    assert ((dkey > 0) | ((dkey == 0) & (dtime > 0))).all()
+    # checksum of checksums: the synthetic values are < 2^40, so every aggregate is exact in f64
+    sample_rows = 4_000_000
+    if agg == "svc":
+        total = 0
+        for i in range(0, N, sample_rows):
+            total += int(engine.synth(i, sample_rows, K, T)[2].to_host().sum(dtype=np.uint64))
+        assert int(h["throughput"].astype(np.uint64).sum(dtype=np.uint64)) == total % 2**64
+    else:
+        assert h["throughput"].max() < 2.0**40 and h["throughput"].min() > 0
+    # verdict consistency, recomputed on the host from the emitted columns
+    if algo == "EWMA":
+        verdict = np.abs(h["throughput"] - h["algo_calc"]) > h["stddev"]
+        assert (verdict == h["anomaly"].astype(bool)).all()
+    # idempotence + the filtered output is exactly the flagged subset
+    res2 = engine.run(algo, dk, dt, dv, K, agg_flow=agg, out="device")
+    sel = h["anomaly"].astype(bool)
+    assert res2.n_rows == int(sel.sum()) == st["n_anomalies"]
+    h2 = res2.to_host()
+    for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+        assert (h2[f] == h[f][sel]).all(), f
+    # an oracle spot check on the first 200 keys of the full table
+    first = h["key_id"] < 200
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(h["key_id"][first].astype(np.int64), minlength=200))])
+    pvf = h["throughput"][first]
+    sig, has = orc.stddev_samp_all(pvf, ptr)
+    assert (np.repeat(sig, np.diff(ptr)) == h["stddev"][first]).all()
+    if algo == "EWMA":
+        assert (orc.ewma_all(pvf, ptr) == h["algo_calc"][first]).all()
+    else:
+        for a, b in zip(ptr[:-1], ptr[1:]):
+            assert (orc.dbscan_noise_1d(pvf[a:b]) == sel[first][a:b]).all()

@@ -1,0 +1,94 @@
+"""ctypes declarations for include/tad.h — field for field what a cgo `import "C"` block sees."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
+
+TAD_ABI_VERSION = 1
+TAD_KEY_SKIP = (1 << 64) - 1
+TAD_OK = 0
+TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
+TAD_ERR_KEY_RANGE, TAD_ERR_GRID_TOO_LARGE, TAD_ERR_BUSY = -5, -6, -7
+TAD_ALGO = {"EWMA": 0, "ARIMA": 1, "DBSCAN": 2}
+TAD_AGG = {"": 0, None: 0, "None": 0, "pod": 1, "svc": 2, "external": 3}
+TAD_OP = {"auto": 0, "max": 1, "sum": 2}
+TAD_MEM_HOST, TAD_MEM_DEVICE = 0, 1
+TAD_FLAG_EMIT_ALL_POINTS = 1
+
+
+class EngineOpts(C.Structure):
+    _fields_ = [("device", i32), ("stream", C.c_void_p), ("workspace_limit", u64)]
+
+
+class Job(C.Structure):
+    _fields_ = [("algo", C.c_int), ("agg_flow", C.c_int), ("value_op", C.c_int),
+                ("start_time", i64), ("end_time", i64), ("ewma_alpha", f64), ("dbscan_eps", f64),
+                ("dbscan_min_samples", i32), ("arima_maxiter", i32), ("flags", u32), ("id", C.c_char * 64)]
+
+
+class Columns(C.Structure):
+    _fields_ = [("n_rows", u64), ("key_id", C.c_void_p), ("key_id2", C.c_void_p),
+                ("flow_end_s", C.c_void_p), ("flow_start_s", C.c_void_p), ("value", C.c_void_p),
+                ("num_keys", u64), ("memory", C.c_int), ("t0", i64), ("step", i64), ("n_buckets", u64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rows_in", u64), ("rows_used", u64), ("n_keys", u64), ("n_points", u64),
+                ("n_anomalies", u64), ("keys_no_result", u64), ("kalman_steps", u64),
+                ("arima_fits", u64), ("t0", i64), ("step", i64), ("n_buckets", u64),
+                ("ms_meta", f32), ("ms_stage0", f32), ("ms_scatter", f32), ("ms_detect", f32),
+                ("ms_total", f32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_rows", u64), ("key_id", C.c_void_p), ("flow_end_s", C.c_void_p),
+                ("throughput", C.c_void_p), ("algo_calc", C.c_void_p), ("stddev", C.c_void_p),
+                ("anomaly", C.c_void_p), ("memory", C.c_int), ("stats", Stats), ("id", C.c_char * 64)]
+
+
+# every symbol include/tad.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "tad_abi_version": (C.c_int, []),
+    "tad_engine_create": (C.c_int, [C.POINTER(EngineOpts), C.POINTER(C.c_void_p)]),
+    "tad_engine_destroy": (None, [C.c_void_p]),
+    "tad_last_error": (C.c_char_p, [C.c_void_p]),
+    "tad_run": (C.c_int, [C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Result))]),
+    "tad_result_free": (None, [C.c_void_p, C.POINTER(Result)]),
+    "tad_progress": (C.c_int, [C.c_void_p, C.POINTER(i32), C.POINTER(i32)]),
+    "tad_series_ewma": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_void_p]),
+    "tad_series_ewma_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, f64, C.c_void_p]),
+    "tad_series_stddev": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.POINTER(C.c_int), C.POINTER(f64)]),
+    "tad_series_dbscan_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, C.c_void_p]),
+    "tad_series_arima": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "tad_series_arima_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.c_int, C.c_int, f64, C.c_void_p, C.POINTER(u64)]),
+    "tad_synth_generate": (C.c_int, [C.c_void_p, u64, u64, u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tad_device_alloc": (C.c_int, [C.c_void_p, u64, C.POINTER(C.c_void_p)]),
+    "tad_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tad_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64]),
+    "tad_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64]),
+}
+
+_lib = None
+
+
+def load_library(build_if_missing=True):
+    """dlopen theia_amd/lib/libtad_mi355x.so (building it in-tree first if needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise OSError("libtad_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _build.build_library()
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not export the header's symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tad_abi_version() != TAD_ABI_VERSION:
+        raise OSError("libtad_mi355x.so ABI %d != binding ABI %d" % (lib.tad_abi_version(), TAD_ABI_VERSION))
+    _lib = lib
+    return lib

@@ -1,0 +1,54 @@
+"""Build libtad_mi355x.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library is the product: HIP kernels + the C ABI of include/tad.h.  `-ffp-contract=off` is part
+of the numerics contract (EWMA / stddev_samp must round like the reference's Python floats).
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libtad_mi355x.so")
+SOURCES = ["tad_kernels.hip", "tad_stage0_part.hip", "tad_dbscan.hip", "tad_arima.hip", "tad_synth.hip", "tad_capi.cpp"]
+HEADERS = [os.path.join(CSRC, "tad_internal.h"), os.path.join(REPO_ROOT, "include", "tad.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libtad_mi355x.so")
+
+
+def sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in sources() + HEADERS)
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source into theia_amd/lib/libtad_mi355x.so. Returns the path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc()] + FLAGS + ["-I" + os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + sources()
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,779 @@
+// tad_capi.cpp — the C ABI of include/tad.h on top of the gfx950 kernels.  HIP only: there is no
+// CPU fallback in this library (the CPU oracle under oracle/ is test infrastructure and is never
+// linked or called from here).
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tad_internal.h"
+
+using namespace tad;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct FreeBlock {
+  void *p;
+  size_t cap;
+};
+
+thread_local std::string g_static_err;
+
+}  // namespace
+
+struct tad_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  uint64_t ws_limit = 0;
+  std::mutex mu;      // serialises runs on this engine (controller.go:199-201 has 4 workers)
+  std::mutex err_mu;  // protects err
+  std::string err;
+  std::atomic<int32_t> done{0}, total{0};
+  // grow-only device scratch
+  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux;
+  DevBuf in_key, in_key2, in_te, in_ts, in_val;
+  hipEvent_t ev[6] = {};
+  std::vector<FreeBlock> free_blocks;  // recycled device result blocks
+  MetaPartial *meta_host = nullptr;    // pinned
+  DevCounters *ctr_host = nullptr;     // pinned
+  unsigned long long *total_host = nullptr;  // pinned
+};
+
+namespace {
+
+constexpr int kMetaBlocks = 2048;
+
+int fail(tad_engine *e, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) {
+    std::lock_guard<std::mutex> lk(e->err_mu);
+    e->err = buf;
+  } else {
+    g_static_err = buf;
+  }
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                         \
+  do {                                                                                           \
+    hipError_t err__ = (call);                                                                   \
+    if (err__ != hipSuccess)                                                                     \
+      return fail((e), err__ == hipErrorOutOfMemory ? TAD_ERR_OUT_OF_MEMORY : TAD_ERR_HIP,       \
+                  "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
+  } while (0)
+
+int ensure(tad_engine *e, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return TAD_OK;
+  if (b.p) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t r = hipMalloc(&b.p, want);
+  if (r != hipSuccess) {
+    want = bytes;
+    r = hipMalloc(&b.p, want);
+  }
+  if (r != hipSuccess)
+    return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(r));
+  b.cap = want;
+  return TAD_OK;
+}
+
+Lattice make_lattice(int64_t t0, int64_t step, uint64_t nb) {
+  Lattice L;
+  L.t0 = t0;
+  L.step = step < 1 ? 1 : step;
+  L.nb = nb;
+  L.magic = 0;
+  if (L.step == 1) {
+    L.mode = 0;
+  } else {
+    // ceil(2^64 / step) = floor((2^64 - 1) / step) + 1 (step >= 2 never divides 2^64 - 1 + 1 exactly
+    // unless it is a power of two, for which floor((2^64-1)/step) + 1 = 2^64/step as well)
+    L.magic = UINT64_MAX / (uint64_t)L.step + 1;
+    // the multiply-high quotient is exact for dividends < 2^32 and divisors < 2^32
+    const bool small = (uint64_t)L.step < (1ull << 32) &&
+                       (nb == 0 || (nb - 1) <= (UINT32_MAX / (uint64_t)L.step));
+    L.mode = small ? 1 : 2;
+  }
+  return L;
+}
+
+uint64_t host_gcd(uint64_t a, uint64_t b) {
+  while (b) { uint64_t r = a % b; a = b; b = r; }
+  return a;
+}
+
+struct ResultBlock {
+  void *base = nullptr;
+  size_t cap = 0;
+};
+
+size_t result_bytes(uint64_t rows, bool with_anomaly) {
+  const uint64_t r = rows ? rows : 1;
+  return (size_t)r * 8 * 5 + (with_anomaly ? (size_t)((r + 15) & ~15ull) : 0);
+}
+
+void carve(void *base, uint64_t rows, bool with_anomaly, OutRows *o) {
+  const uint64_t r = rows ? rows : 1;
+  unsigned char *p = static_cast<unsigned char *>(base);
+  o->key_id = reinterpret_cast<unsigned long long *>(p); p += r * 8;
+  o->flow_end_s = reinterpret_cast<long long *>(p); p += r * 8;
+  o->throughput = reinterpret_cast<double *>(p); p += r * 8;
+  o->algo_calc = reinterpret_cast<double *>(p); p += r * 8;
+  o->stddev = reinterpret_cast<double *>(p); p += r * 8;
+  o->anomaly = with_anomaly ? p : nullptr;
+}
+
+int alloc_device_block(tad_engine *e, size_t bytes, ResultBlock *rb) {
+  for (size_t i = 0; i < e->free_blocks.size(); ++i) {
+    if (e->free_blocks[i].cap >= bytes && e->free_blocks[i].cap <= 2 * bytes + (1 << 20)) {
+      rb->base = e->free_blocks[i].p;
+      rb->cap = e->free_blocks[i].cap;
+      e->free_blocks.erase(e->free_blocks.begin() + i);
+      return TAD_OK;
+    }
+  }
+  void *p = nullptr;
+  hipError_t r = hipMalloc(&p, bytes);
+  if (r != hipSuccess) return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipMalloc(result, %zu) failed: %s", bytes, hipGetErrorString(r));
+  rb->base = p;
+  rb->cap = bytes;
+  return TAD_OK;
+}
+
+struct ResultPriv {  // lives right behind the public struct
+  tad_result pub;
+  void *block;
+  size_t block_cap;
+};
+
+}  // namespace
+
+extern "C" {
+
+int tad_abi_version(void) { return TAD_ABI_VERSION; }
+
+const char *tad_last_error(tad_engine *e) {
+  if (!e) return g_static_err.c_str();
+  std::lock_guard<std::mutex> lk(e->err_mu);
+  static thread_local std::string copy;
+  copy = e->err;
+  return copy.c_str();
+}
+
+int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
+  if (!out) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_engine_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t r = hipGetDeviceCount(&ndev);
+  if (r != hipSuccess || ndev == 0)
+    return fail(nullptr, TAD_ERR_NO_DEVICE, "no HIP device available (%s)", r != hipSuccess ? hipGetErrorString(r) : "count = 0");
+  const int dev = opts ? opts->device : 0;
+  if (dev < 0 || dev >= ndev) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "device %d out of range (have %d)", dev, ndev);
+  tad_engine *e = new (std::nothrow) tad_engine();
+  if (!e) return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
+  e->device = dev;
+  if (hipSetDevice(dev) != hipSuccess) { delete e; return fail(nullptr, TAD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", dev); }
+  if (opts && opts->stream) {
+    e->stream = static_cast<hipStream_t>(opts->stream);
+  } else {
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(nullptr, TAD_ERR_HIP, "hipStreamCreate failed"); }
+    e->own_stream = true;
+  }
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  e->ws_limit = (opts && opts->workspace_limit) ? opts->workspace_limit : (uint64_t)(free_b / 4 * 3);
+  for (auto &ev : e->ev) hipEventCreate(&ev);
+  hipHostMalloc(reinterpret_cast<void **>(&e->meta_host), sizeof(MetaPartial) * kMetaBlocks, hipHostMallocDefault);
+  hipHostMalloc(reinterpret_cast<void **>(&e->ctr_host), sizeof(DevCounters), hipHostMallocDefault);
+  hipHostMalloc(reinterpret_cast<void **>(&e->total_host), sizeof(unsigned long long), hipHostMallocDefault);
+  if (!e->meta_host || !e->ctr_host || !e->total_host) { tad_engine_destroy(e); return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "pinned host allocation failed"); }
+  *out = e;
+  return TAD_OK;
+}
+
+void tad_engine_destroy(tad_engine *e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+  for (DevBuf *b : bufs)
+    if (b->p) hipFree(b->p);
+  for (auto &fb : e->free_blocks) hipFree(fb.p);
+  for (auto &ev : e->ev)
+    if (ev) hipEventDestroy(ev);
+  if (e->meta_host) hipHostFree(e->meta_host);
+  if (e->ctr_host) hipHostFree(e->ctr_host);
+  if (e->total_host) hipHostFree(e->total_host);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int tad_progress(tad_engine *e, int32_t *done, int32_t *total) {
+  if (!e) return TAD_ERR_INVALID_ARGUMENT;
+  if (done) *done = e->done.load();
+  if (total) *total = e->total.load();
+  return TAD_OK;
+}
+
+void tad_result_free(tad_engine *e, tad_result *r) {
+  if (!r) return;
+  ResultPriv *rp = reinterpret_cast<ResultPriv *>(r);
+  if (rp->block) {
+    if (r->memory == TAD_MEM_DEVICE && e) {
+      std::lock_guard<std::mutex> lk(e->mu);
+      if (e->free_blocks.size() < 8) e->free_blocks.push_back({rp->block, rp->block_cap});
+      else { hipSetDevice(e->device); hipFree(rp->block); }
+    } else if (r->memory == TAD_MEM_DEVICE) {
+      hipFree(rp->block);
+    } else {
+      free(rp->block);
+    }
+  }
+  delete rp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the detector pipeline over a filled grid (shared by tad_run and the tad_series_* entry points)
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct JobParams {
+  tad_algo algo;
+  double alpha, eps;
+  int min_samples, maxiter;
+  bool all_points;
+};
+
+// Runs sigma + detector + scan on grid g.  On return *rows = number of rows emit will write.
+int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ctr, uint64_t *rows) {
+  hipStream_t s = e->stream;
+  int rc;
+  if ((rc = ensure(e, e->sigma, g.K * sizeof(double))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->n_pts, g.K * sizeof(uint32_t))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->n_anom, g.K * sizeof(uint32_t))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->off, (g.K + 1) * sizeof(unsigned long long))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->scan_scratch, scan_scratch_elems(g.K) * sizeof(unsigned long long))) != TAD_OK) return rc;
+  double *sigma = static_cast<double *>(e->sigma.p);
+  uint32_t *n_pts = static_cast<uint32_t *>(e->n_pts.p);
+  uint32_t *n_anom = static_cast<uint32_t *>(e->n_anom.p);
+  unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
+
+  const bool ewma = jp.algo == TAD_ALGO_EWMA;
+  launch_key_sigma(s, g, jp.alpha, ewma && !jp.all_points, sigma, n_pts, n_anom, ctr);
+  if (jp.algo == TAD_ALGO_DBSCAN) {
+    const size_t scratch = dbscan_long_scratch_bytes(g);
+    if (scratch == 0) {
+      if (launch_dbscan(s, g, jp.eps, jp.min_samples) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN tile selection failed");
+    } else {
+      if ((rc = ensure(e, e->aux, scratch)) != TAD_OK) return rc;
+      launch_dbscan_long(s, g, jp.eps, jp.min_samples, e->aux.p);
+    }
+  } else if (jp.algo == TAD_ALGO_ARIMA) {
+    if ((rc = ensure(e, e->calc, g.K * g.T * sizeof(double))) != TAD_OK) return rc;
+    const size_t wsb = arima_workspace_bytes(g);
+    if ((rc = ensure(e, e->aux, wsb)) != TAD_OK) return rc;
+    if (launch_arima(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, wsb) != 0)
+      return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
+  }
+  const uint32_t *cnt = n_anom;
+  if (jp.all_points && jp.algo != TAD_ALGO_ARIMA) cnt = n_pts;
+  else if (!ewma || jp.all_points) launch_count_flags(s, g, jp.all_points, n_anom);  // ARIMA all_points: skips no-result keys
+  launch_scan(s, cnt, off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
+  HIP_TRY(e, hipMemcpyAsync(e->total_host, off + g.K, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  HIP_TRY(e, hipGetLastError());
+  *rows = *e->total_host;
+  return TAD_OK;
+}
+
+void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows out) {
+  const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : 2);
+  launch_emit(e->stream, g, L, kind, jp.all_points, jp.alpha, static_cast<const double *>(e->sigma.p),
+              static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(e->calc.p),
+              static_cast<const unsigned long long *>(e->off.p), out);
+}
+
+int make_result(tad_engine *e, uint64_t rows, bool with_anomaly, tad_mem out_memory, ResultPriv **out, OutRows *dev_rows,
+                ResultBlock *dev_block) {
+  ResultPriv *rp = new (std::nothrow) ResultPriv();
+  if (!rp) return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
+  memset(rp, 0, sizeof *rp);
+  const size_t bytes = result_bytes(rows, with_anomaly);
+  int rc = alloc_device_block(e, bytes, dev_block);
+  if (rc != TAD_OK) { delete rp; return rc; }
+  carve(dev_block->base, rows, with_anomaly, dev_rows);
+  rp->pub.n_rows = rows;
+  rp->pub.memory = out_memory;
+  *out = rp;
+  return TAD_OK;
+}
+
+// after emit: hand the device block to the caller, or copy it to a host block
+int finish_result(tad_engine *e, ResultPriv *rp, uint64_t rows, bool with_anomaly, ResultBlock dev_block, OutRows dev_rows) {
+  if (rp->pub.memory == TAD_MEM_DEVICE) {
+    rp->block = dev_block.base;
+    rp->block_cap = dev_block.cap;
+    rp->pub.key_id = reinterpret_cast<uint64_t *>(dev_rows.key_id);
+    rp->pub.flow_end_s = reinterpret_cast<int64_t *>(dev_rows.flow_end_s);
+    rp->pub.throughput = dev_rows.throughput;
+    rp->pub.algo_calc = dev_rows.algo_calc;
+    rp->pub.stddev = dev_rows.stddev;
+    rp->pub.anomaly = dev_rows.anomaly;
+    return TAD_OK;
+  }
+  const size_t bytes = result_bytes(rows, with_anomaly);
+  void *h = malloc(bytes);
+  if (!h) { e->free_blocks.push_back({dev_block.base, dev_block.cap}); return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu result bytes", bytes); }
+  hipError_t r = hipMemcpyAsync(h, dev_block.base, bytes, hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+  e->free_blocks.push_back({dev_block.base, dev_block.cap});
+  if (r != hipSuccess) { free(h); return fail(e, TAD_ERR_HIP, "result copy failed: %s", hipGetErrorString(r)); }
+  OutRows ho;
+  carve(h, rows, with_anomaly, &ho);
+  rp->block = h;
+  rp->block_cap = bytes;
+  rp->pub.key_id = reinterpret_cast<uint64_t *>(ho.key_id);
+  rp->pub.flow_end_s = reinterpret_cast<int64_t *>(ho.flow_end_s);
+  rp->pub.throughput = ho.throughput;
+  rp->pub.algo_calc = ho.algo_calc;
+  rp->pub.stddev = ho.stddev;
+  rp->pub.anomaly = ho.anomaly;
+  return TAD_OK;
+}
+
+int stage_column(tad_engine *e, DevBuf &buf, const void *src, uint64_t n, tad_mem mem, const void **dev) {
+  if (!src) { *dev = nullptr; return TAD_OK; }
+  if (mem == TAD_MEM_DEVICE) { *dev = src; return TAD_OK; }
+  int rc = ensure(e, buf, n * 8);
+  if (rc != TAD_OK) return rc;
+  HIP_TRY(e, hipMemcpyAsync(buf.p, src, n * 8, hipMemcpyHostToDevice, e->stream));
+  *dev = buf.p;
+  return TAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out) {
+  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_run: engine is NULL");
+  if (!job || !cols || !out) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: job, cols and out must not be NULL");
+  *out = nullptr;
+  if (job->algo != TAD_ALGO_EWMA && job->algo != TAD_ALGO_ARIMA && job->algo != TAD_ALGO_DBSCAN)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: Throughput Anomaly DetectorQuerier type should be 'EWMA' or 'ARIMA' or 'DBSCAN'");
+  if (job->agg_flow < TAD_AGG_NONE || job->agg_flow > TAD_AGG_EXTERNAL)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: aggregated flow type should be 'pod' or 'external' or 'svc'");
+  if (job->start_time != 0 && job->end_time != 0 && job->end_time <= job->start_time)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: EndInterval should be after StartInterval");
+  if (cols->n_rows > 0 && (!cols->key_id || !cols->flow_end_s || !cols->value))
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: key_id, flow_end_s and value columns are required");
+  if (cols->n_rows > 0 && cols->num_keys == 0)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: num_keys is 0 but there are rows");
+  if (cols->n_buckets > 0 && cols->step < 1)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: lattice hint needs step >= 1");
+  if (job->ewma_alpha < 0.0 || job->ewma_alpha > 1.0 || job->dbscan_eps < 0.0 || job->dbscan_min_samples < 0 || job->arima_maxiter < 0)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: detector parameter out of range");
+
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  e->done.store(0);
+  e->total.store(4);
+
+  JobParams jp;
+  jp.algo = job->algo;
+  jp.alpha = job->ewma_alpha == 0.0 ? 0.5 : job->ewma_alpha;
+  jp.eps = job->dbscan_eps == 0.0 ? 250000000.0 : job->dbscan_eps;
+  jp.min_samples = job->dbscan_min_samples == 0 ? 4 : job->dbscan_min_samples;
+  jp.maxiter = job->arima_maxiter == 0 ? 50 : job->arima_maxiter;
+  jp.all_points = (job->flags & TAD_FLAG_EMIT_ALL_POINTS) != 0;
+  const bool op_max = job->value_op == TAD_OP_MAX || (job->value_op == TAD_OP_AUTO && job->agg_flow == TAD_AGG_NONE);
+  const uint64_t n = cols->n_rows;
+  const uint64_t K = cols->num_keys;
+  RowFilter rf{job->start_time, job->end_time};
+
+  int rc;
+  const void *d_key, *d_key2, *d_te, *d_ts, *d_val;
+  if ((rc = stage_column(e, e->in_key, cols->key_id, n, cols->memory, &d_key)) != TAD_OK) return rc;
+  if ((rc = stage_column(e, e->in_key2, cols->key_id2, n, cols->memory, &d_key2)) != TAD_OK) return rc;
+  if ((rc = stage_column(e, e->in_te, cols->flow_end_s, n, cols->memory, &d_te)) != TAD_OK) return rc;
+  if ((rc = stage_column(e, e->in_ts, cols->flow_start_s, n, cols->memory, &d_ts)) != TAD_OK) return rc;
+  if ((rc = stage_column(e, e->in_val, cols->value, n, cols->memory, &d_val)) != TAD_OK) return rc;
+
+  if ((rc = ensure(e, e->counters, sizeof(DevCounters))) != TAD_OK) return rc;
+  DevCounters *ctr = static_cast<DevCounters *>(e->counters.p);
+
+  HIP_TRY(e, hipEventRecord(e->ev[0], s));
+  // ---- time lattice ----
+  bool hinted = cols->n_buckets > 0;
+  Lattice L = make_lattice(cols->t0, hinted ? cols->step : 1, cols->n_buckets);
+  bool empty = (n == 0 || K == 0);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (!hinted && !empty) {
+      if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
+      int blocks = (int)((n + 255) / 256);
+      if (blocks > kMetaBlocks) blocks = kMetaBlocks;
+      launch_meta(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, rf,
+                  static_cast<MetaPartial *>(e->meta.p), blocks);
+      HIP_TRY(e, hipMemcpyAsync(e->meta_host, e->meta.p, sizeof(MetaPartial) * blocks, hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipStreamSynchronize(s));
+      int64_t tmin = 0, tmax = 0, tref = 0;
+      uint64_t g = 0, used = 0;
+      for (int b = 0; b < blocks; ++b) {
+        const MetaPartial &p = e->meta_host[b];
+        if (p.used == 0) continue;
+        if (used == 0) { tmin = p.tmin; tmax = p.tmax; tref = p.tref; g = p.g; }
+        else {
+          if (p.tmin < tmin) tmin = p.tmin;
+          if (p.tmax > tmax) tmax = p.tmax;
+          const uint64_t d = p.tref >= tref ? (uint64_t)p.tref - (uint64_t)tref : (uint64_t)tref - (uint64_t)p.tref;
+          g = host_gcd(host_gcd(g, p.g), d);
+        }
+        used += p.used;
+      }
+      if (used == 0) { empty = true; }
+      else {
+        const uint64_t span = (uint64_t)tmax - (uint64_t)tmin;
+        const uint64_t step = g == 0 ? 1 : g;
+        L = make_lattice(tmin, (int64_t)step, span / step + 1);
+      }
+    }
+    HIP_TRY(e, hipEventRecord(e->ev[1], s));
+    e->done.store(1);
+    if (empty) { L = make_lattice(0, 1, 0); }
+
+    // ---- Stage 0: clear + scatter ----
+    const uint64_t cells = empty ? 0 : K * L.nb;
+    if (!empty && L.nb != 0 && cells / L.nb != K) return fail(e, TAD_ERR_GRID_TOO_LARGE, "grid of %llu keys x %llu buckets overflows", (unsigned long long)K, (unsigned long long)L.nb);
+    const uint64_t need = cells * 9 + (jp.algo == TAD_ALGO_ARIMA ? cells * 8 : 0);
+    if (need > e->ws_limit)
+      return fail(e, TAD_ERR_GRID_TOO_LARGE,
+                  "dense point grid needs %llu bytes (%llu keys x %llu time buckets, step %lld s) > workspace limit %llu",
+                  (unsigned long long)need, (unsigned long long)K, (unsigned long long)L.nb, (long long)L.step, (unsigned long long)e->ws_limit);
+    if ((rc = ensure(e, e->grid_val, cells * 8)) != TAD_OK) return rc;
+    if ((rc = ensure(e, e->grid_flag, cells)) != TAD_OK) return rc;
+    Grid g{static_cast<unsigned long long *>(e->grid_val.p), static_cast<uint8_t *>(e->grid_flag.p), empty ? 0 : K, L.nb};
+    HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
+    if (cells) {
+      HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));
+      HIP_TRY(e, hipMemsetAsync(g.flag, 0, cells, s));
+    }
+    HIP_TRY(e, hipEventRecord(e->ev[2], s));
+    if (!empty)
+      launch_scatter(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
+                     (const uint64_t *)d_val, n, rf, L, g, op_max, ctr);
+    HIP_TRY(e, hipEventRecord(e->ev[3], s));
+    e->done.store(2);
+
+    // ---- Stage 1+2: sigma, detector, count, scan ----
+    uint64_t rows = 0;
+    if ((rc = detect_and_count(e, g, jp, ctr, &rows)) != TAD_OK) return rc;
+    const DevCounters c = *e->ctr_host;
+    if (c.err & DEV_ERR_KEY_RANGE)
+      return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
+    if (c.err & DEV_ERR_OFF_LATTICE) {
+      if (hinted && attempt == 0) { hinted = false; continue; }  // caller's lattice hint was wrong: derive it
+      return fail(e, TAD_ERR_HIP, "internal error: a row fell off the derived time lattice");
+    }
+    e->done.store(3);
+
+    // ---- Stage 3: emit ----
+    ResultPriv *rp = nullptr;
+    OutRows dev_rows;
+    ResultBlock dev_block;
+    if ((rc = make_result(e, rows, jp.all_points, out_memory, &rp, &dev_rows, &dev_block)) != TAD_OK) return rc;
+    if (rows) emit_rows(e, g, L, jp, dev_rows);
+    HIP_TRY(e, hipEventRecord(e->ev[4], s));
+    if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
+    HIP_TRY(e, hipStreamSynchronize(s));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { tad_result_free(nullptr, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
+
+    tad_stats &st = rp->pub.stats;
+    st.rows_in = n;
+    st.rows_used = c.rows_used;
+    st.n_keys = c.n_keys;
+    st.n_points = c.n_points;
+    st.keys_no_result = c.keys_no_result;
+    st.kalman_steps = c.kalman_steps;
+    st.arima_fits = c.arima_fits;
+    st.t0 = L.t0; st.step = L.step; st.n_buckets = L.nb;
+    st.n_anomalies = rows;
+    if (jp.all_points) {
+      // count verdicts host- or device-side? cheap: the emit kernel wrote them; count on the host copy if there is one
+      st.n_anomalies = 0;
+      if (rows) {
+        std::vector<uint8_t> tmp;
+        const uint8_t *a = rp->pub.anomaly;
+        if (out_memory == TAD_MEM_DEVICE) {
+          tmp.resize(rows);
+          HIP_TRY(e, hipMemcpy(tmp.data(), rp->pub.anomaly, rows, hipMemcpyDeviceToHost));
+          a = tmp.data();
+        }
+        for (uint64_t i = 0; i < rows; ++i) st.n_anomalies += a[i];
+      }
+    }
+    hipEventElapsedTime(&st.ms_meta, e->ev[0], e->ev[1]);
+    hipEventElapsedTime(&st.ms_stage0, e->ev[1], e->ev[3]);
+    hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
+    hipEventElapsedTime(&st.ms_detect, e->ev[3], e->ev[4]);
+    hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
+    strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
+    e->done.store(4);
+    *out = &rp->pub;
+    return TAD_OK;
+  }
+  return fail(e, TAD_ERR_HIP, "unreachable");
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-series entry points (a one-key table; same kernels)
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// Fill the engine's grid with one series: K = 1, T = n, every point present.
+int series_grid(tad_engine *e, const uint64_t *x, uint64_t n, Grid *g) {
+  int rc;
+  if ((rc = ensure(e, e->grid_val, (n ? n : 1) * 8)) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->grid_flag, n ? n : 1)) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->counters, sizeof(DevCounters))) != TAD_OK) return rc;
+  if (n) {
+    HIP_TRY(e, hipMemcpyAsync(e->grid_val.p, x, n * 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->grid_flag.p, FLAG_PRESENT, n, e->stream));
+  }
+  HIP_TRY(e, hipMemsetAsync(e->counters.p, 0, sizeof(DevCounters), e->stream));
+  g->val = static_cast<unsigned long long *>(e->grid_val.p);
+  g->flag = static_cast<uint8_t *>(e->grid_flag.p);
+  g->K = 1;
+  g->T = n;
+  return TAD_OK;
+}
+
+// Emit every point of a one-key grid with given sigma; copies verdicts / calc to the host.
+int series_emit_all(tad_engine *e, Grid g, const JobParams &jp, bool has_sigma, double sigma, double *calc_out, uint8_t *verdict_out) {
+  const uint64_t n = g.T;
+  int rc;
+  if ((rc = ensure(e, e->sigma, sizeof(double))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->n_pts, sizeof(uint32_t))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->off, 2 * sizeof(unsigned long long))) != TAD_OK) return rc;
+  const uint32_t npts = has_sigma ? (uint32_t)(n < 2 ? 2 : n) : (uint32_t)(n < 1 ? 0 : 1);  // n_pts >= 2 <=> sigma is defined
+  const unsigned long long off[2] = {0ull, (unsigned long long)n};
+  HIP_TRY(e, hipMemcpyAsync(e->sigma.p, &sigma, sizeof sigma, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->n_pts.p, &npts, sizeof npts, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->off.p, off, sizeof off, hipMemcpyHostToDevice, e->stream));
+  ResultBlock blk;
+  if ((rc = alloc_device_block(e, result_bytes(n, true), &blk)) != TAD_OK) return rc;
+  OutRows o;
+  carve(blk.base, n, true, &o);
+  JobParams all = jp;
+  all.all_points = true;
+  emit_rows(e, g, make_lattice(0, 1, n), all, o);
+  hipError_t r = hipSuccess;
+  if (calc_out && n) r = hipMemcpyAsync(calc_out, o.algo_calc, n * 8, hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess && verdict_out && n) r = hipMemcpyAsync(verdict_out, o.anomaly, n, hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+  e->free_blocks.push_back({blk.base, blk.cap});
+  if (r != hipSuccess) return fail(e, TAD_ERR_HIP, "series copy failed: %s", hipGetErrorString(r));
+  return TAD_OK;
+}
+
+JobParams series_params(tad_algo algo, double alpha, double eps, int min_samples, int maxiter) {
+  JobParams jp;
+  jp.algo = algo;
+  jp.alpha = alpha == 0.0 ? 0.5 : alpha;
+  jp.eps = eps == 0.0 ? 250000000.0 : eps;
+  jp.min_samples = min_samples == 0 ? 4 : min_samples;
+  jp.maxiter = maxiter == 0 ? 50 : maxiter;
+  jp.all_points = true;
+  return jp;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tad_series_ewma(tad_engine *e, const uint64_t *x, uint64_t n, double alpha, double *out) {
+  if (!e || (n && (!x || !out))) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_ewma: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  Grid g;
+  int rc = series_grid(e, x, n, &g);
+  if (rc != TAD_OK || n == 0) return rc;
+  return series_emit_all(e, g, series_params(TAD_ALGO_EWMA, alpha, 0, 0, 0), false, 0.0, out, nullptr);
+}
+
+int tad_series_ewma_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, double alpha, int has_stddev, double stddev,
+                            uint8_t *verdict) {
+  if (!e || (n && (!x || !verdict))) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_ewma_anomaly: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  Grid g;
+  int rc = series_grid(e, x, n, &g);
+  if (rc != TAD_OK || n == 0) return rc;
+  return series_emit_all(e, g, series_params(TAD_ALGO_EWMA, alpha, 0, 0, 0), has_stddev != 0, stddev, nullptr, verdict);
+}
+
+int tad_series_stddev(tad_engine *e, const uint64_t *x, uint64_t n, int *has_stddev, double *stddev) {
+  if (!e || !has_stddev || !stddev || (n && !x)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_stddev: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  *has_stddev = 0;
+  *stddev = 0.0;
+  Grid g;
+  int rc = series_grid(e, x, n, &g);
+  if (rc != TAD_OK || n == 0) return rc;
+  if ((rc = ensure(e, e->sigma, sizeof(double))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->n_pts, sizeof(uint32_t))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->n_anom, sizeof(uint32_t))) != TAD_OK) return rc;
+  launch_key_sigma(e->stream, g, 0.5, false, static_cast<double *>(e->sigma.p), static_cast<uint32_t *>(e->n_pts.p),
+                   static_cast<uint32_t *>(e->n_anom.p), static_cast<DevCounters *>(e->counters.p));
+  double sg = 0.0;
+  HIP_TRY(e, hipMemcpyAsync(&sg, e->sigma.p, sizeof sg, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  *has_stddev = n >= 2;
+  *stddev = sg;
+  return TAD_OK;
+}
+
+int tad_series_dbscan_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, double eps, int min_samples, uint8_t *verdict) {
+  if (!e || (n && (!x || !verdict)) || eps < 0.0 || min_samples < 0)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_dbscan_anomaly: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  Grid g;
+  int rc = series_grid(e, x, n, &g);
+  if (rc != TAD_OK || n == 0) return rc;
+  JobParams jp = series_params(TAD_ALGO_DBSCAN, 0, eps, min_samples, 0);
+  const size_t scratch = dbscan_long_scratch_bytes(g);
+  if (scratch == 0) {
+    if (launch_dbscan(e->stream, g, jp.eps, jp.min_samples) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN tile selection failed");
+  } else {
+    if ((rc = ensure(e, e->aux, scratch)) != TAD_OK) return rc;
+    launch_dbscan_long(e->stream, g, jp.eps, jp.min_samples, e->aux.p);
+  }
+  return series_emit_all(e, g, jp, false, 0.0, nullptr, verdict);
+}
+
+int tad_series_arima(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int *has_result, double *out) {
+  if (!e || !has_result || (n && (!x || !out)) || maxiter < 0) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima: bad arguments");
+  uint64_t nv = 0;
+  std::vector<uint8_t> verdict(n ? n : 1);
+  int rc = tad_series_arima_anomaly(e, x, n, maxiter, 0, 0.0, verdict.data(), &nv);
+  if (rc != TAD_OK) return rc;
+  // tad_series_arima_anomaly leaves the predictions in the engine's calc buffer
+  std::lock_guard<std::mutex> lk(e->mu);
+  *has_result = (nv == n && n > 3) ? 1 : 0;
+  if (*has_result) {
+    HIP_TRY(e, hipMemcpy(out, e->calc.p, n * 8, hipMemcpyDeviceToHost));
+  }
+  return TAD_OK;
+}
+
+int tad_series_arima_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
+                             uint8_t *verdict, uint64_t *n_verdict) {
+  if (!e || !n_verdict || !verdict || (n && !x) || maxiter < 0)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima_anomaly: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  *n_verdict = 1;
+  verdict[0] = 0;
+  if (n <= 3) return TAD_OK;  // anomaly_detection.py:232-234 -> None -> [False] (:284-287)
+  Grid g;
+  int rc = series_grid(e, x, n, &g);
+  if (rc != TAD_OK) return rc;
+  JobParams jp = series_params(TAD_ALGO_ARIMA, 0, 0, 0, maxiter);
+  if ((rc = ensure(e, e->sigma, sizeof(double))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->n_pts, sizeof(uint32_t))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->calc, n * sizeof(double))) != TAD_OK) return rc;
+  // sigma as given by the caller; n_pts >= 2 <=> sigma defined; n_pts carries the real length for ARIMA
+  const double sg = has_stddev ? stddev : __builtin_inf();  // no sigma -> no point can exceed it
+  const uint32_t npts = (uint32_t)n;
+  HIP_TRY(e, hipMemcpyAsync(e->sigma.p, &sg, sizeof sg, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->n_pts.p, &npts, sizeof npts, hipMemcpyHostToDevice, e->stream));
+  const size_t wsb = arima_workspace_bytes(g);
+  if ((rc = ensure(e, e->aux, wsb)) != TAD_OK) return rc;
+  DevCounters *ctr = static_cast<DevCounters *>(e->counters.p);
+  if (launch_arima(e->stream, g, static_cast<const double *>(e->sigma.p), static_cast<const uint32_t *>(e->n_pts.p), jp.maxiter,
+                   static_cast<double *>(e->calc.p), ctr, e->aux.p, wsb) != 0)
+    return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
+  HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
+  std::vector<uint8_t> flags(n);
+  HIP_TRY(e, hipMemcpyAsync(flags.data(), g.flag, n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  HIP_TRY(e, hipGetLastError());
+  if (e->ctr_host->keys_no_result) return TAD_OK;  // calculate_arima returned None
+  *n_verdict = n;
+  for (uint64_t i = 0; i < n; ++i) verdict[i] = (flags[i] & FLAG_ANOMALY) ? 1 : 0;
+  return TAD_OK;
+}
+
+int tad_synth_generate(tad_engine *e, uint64_t seed, uint64_t first_row, uint64_t n_rows, uint64_t num_keys,
+                       uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s, uint64_t *value) {
+  if (!e || num_keys == 0 || n_buckets == 0 || (n_rows && (!key_id || !flow_end_s || !value)))
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_synth_generate: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  launch_synth(e->stream, seed, first_row, n_rows, num_keys, n_buckets, key_id, flow_end_s, value);
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  HIP_TRY(e, hipGetLastError());
+  return TAD_OK;
+}
+
+int tad_device_alloc(tad_engine *e, uint64_t bytes, void **ptr) {
+  if (!e || !ptr) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_device_alloc: bad arguments");
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipError_t r = hipMalloc(ptr, bytes ? bytes : 1);
+  if (r != hipSuccess) return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(r));
+  return TAD_OK;
+}
+
+int tad_device_free(tad_engine *e, void *ptr) {
+  if (!e) return TAD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (ptr) HIP_TRY(e, hipFree(ptr));
+  return TAD_OK;
+}
+
+int tad_copy_to_device(tad_engine *e, void *dst, const void *src, uint64_t bytes) {
+  if (!e || (bytes && (!dst || !src))) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_copy_to_device: bad arguments");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return TAD_OK;
+}
+
+int tad_copy_to_host(tad_engine *e, void *dst, const void *src, uint64_t bytes) {
+  if (!e || (bytes && (!dst || !src))) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_copy_to_host: bad arguments");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  HIP_TRY(e, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return TAD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// tad_internal.h — shared between the C-ABI host code (tad_capi.cpp) and the gfx950 kernels.
+// Product code.  Nothing here may include or call anything under oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tad.h"
+
+namespace tad {
+
+// flowEndSeconds lattice: t = t0 + step * bucket, bucket < nb.
+struct Lattice {
+  int64_t t0;
+  int64_t step;
+  uint64_t nb;
+  uint64_t magic;  // ceil(2^64 / step): exact quotient for dividends < 2^32 (mode 1)
+  int mode;        // 0: step == 1, 1: multiply-high path ((tmax - t0) < 2^32), 2: 64-bit division
+};
+
+// The aggregated point grid, TIME-MAJOR: cell(bucket b, key k) = b * K + k.
+// Time-major so that "one lane = one key, walk the series sequentially" is a fully coalesced
+// access at every step (64 consecutive keys = 512 contiguous bytes).
+struct Grid {
+  unsigned long long *val;  // aggregated UInt64 value of the point
+  uint8_t *flag;            // bit0: point present, bit1: anomaly verdict (DBSCAN / ARIMA detectors)
+  uint64_t K;               // keys
+  uint64_t T;               // buckets
+};
+
+enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u };
+enum : uint8_t { FLAG_PRESENT = 1, FLAG_ANOMALY = 2 };
+
+// Per-block partial of the lattice-derivation pass.
+struct MetaPartial {
+  int64_t tmin, tmax, tref;
+  uint64_t g;     // gcd of |t - tref| over the rows this block kept
+  uint64_t used;  // rows kept
+};
+
+// Device-side counters of one run (one 64-byte block, zeroed per run).
+struct DevCounters {
+  unsigned long long rows_used;
+  unsigned long long n_keys;
+  unsigned long long n_points;
+  unsigned long long keys_no_result;
+  unsigned long long kalman_steps;
+  unsigned long long arima_fits;
+  uint32_t err;
+  uint32_t pad;
+};
+
+struct RowFilter {
+  int64_t start_time;  // 0 = unset
+  int64_t end_time;    // 0 = unset
+};
+
+struct OutRows {
+  unsigned long long *key_id;
+  long long *flow_end_s;
+  double *throughput;
+  double *algo_calc;
+  double *stddev;
+  uint8_t *anomaly;  // only with TAD_FLAG_EMIT_ALL_POINTS
+};
+
+// ---- launchers (tad_kernels.hip / tad_dbscan.hip / tad_arima.hip / tad_synth.hip) ----
+int launch_meta(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
+                const int64_t *t_start, uint64_t n, RowFilter f, MetaPartial *partials, int n_blocks);
+
+void launch_scatter(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
+                    const int64_t *t_start, const uint64_t *value, uint64_t n, RowFilter f,
+                    Lattice lat, Grid g, bool op_max, DevCounters *ctr);
+
+// per-key n / sigma (+ EWMA anomaly count when ewma != 0)
+void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, double *sigma,
+                      uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr);
+void launch_count_flags(hipStream_t s, Grid g, bool all_points, uint32_t *n_anom);
+// exclusive scan of cnt[K] into off[K], total in off[K]
+void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K,
+                 unsigned long long *scratch);
+size_t scan_scratch_elems(uint64_t K);
+// kind: 0 EWMA (recompute), 1 flags + calc array, 2 flags with calc = 0
+void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
+                 const double *sigma, const uint32_t *n_pts, const double *calc,
+                 const unsigned long long *off, OutRows out);
+// EWMA value for every present point into calc[T][K] (series entry points)
+void launch_ewma_values(hipStream_t s, Grid g, double alpha, double *calc);
+
+// DBSCAN: sets FLAG_ANOMALY on noise points.  Returns 0, or -1 if T is too large for the LDS tile.
+int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples);
+size_t dbscan_long_scratch_bytes(Grid g);  // 0 when the LDS tile kernel applies
+int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch);
+
+// ARIMA(1,1,1) walk-forward on Box-Cox data: calc[T][K] + FLAG_ANOMALY.
+int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter,
+                 double *calc, DevCounters *ctr, void *workspace, size_t workspace_bytes);
+size_t arima_workspace_bytes(Grid g);
+
+void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows,
+                  uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,
+                  uint64_t *value);
+
+}  // namespace tad

@@ -1,0 +1,267 @@
+"""TadEngine — Python host over the C ABI (include/tad.h).  Plumbing only: every number is computed
+by the HIP kernels in libtad_mi355x.so; there is no CPU fallback and no import of oracle/.
+
+Columns may be numpy arrays (host memory), torch CUDA tensors or DeviceArray objects (device
+memory).  torch is optional here: it is only touched when the caller hands in tensors.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+SYNTH_SEED = 0x7AD05EED
+
+
+class TadError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("tad error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+class DeviceArray:
+    """n 8-byte elements in HBM, owned by an engine (tad_device_alloc / tad_device_free)."""
+
+    def __init__(self, engine, n, dtype):
+        self.engine = engine
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        ptr = C.c_void_p()
+        engine._check(engine._lib.tad_device_alloc(engine._h, self.n * self.dtype.itemsize, C.byref(ptr)))
+        self.ptr = ptr.value
+
+    def to_host(self):
+        out = np.empty(self.n, dtype=self.dtype)
+        if self.n:
+            self.engine._check(self.engine._lib.tad_copy_to_host(self.engine._h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.engine._h is not None:
+            self.engine._lib.tad_device_free(self.engine._h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _as_column(x, dtype, n_expected=None):
+    """-> (pointer, n, is_device, keepalive)"""
+    if x is None:
+        return None, 0, None, None
+    if isinstance(x, DeviceArray):
+        return x.ptr, x.n, True, x
+    if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):  # torch tensor
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if x.element_size() != 8:
+            raise TypeError("tensor columns must be 8-byte integers")
+        if x.is_cuda:
+            return x.data_ptr(), x.numel(), True, x
+        x = x.numpy()
+    a = np.ascontiguousarray(x)
+    if a.dtype != np.dtype(dtype):
+        if a.dtype.kind in "iu" and a.dtype.itemsize == 8:
+            a = a.view(dtype)
+        else:
+            a = a.astype(dtype)
+    return a.ctypes.data, a.size, False, a
+
+
+class TadResult:
+    """Anomalous points ordered by (key_id, flow_end_s) + the run's counters and stage timings."""
+
+    FIELDS = (("key_id", np.uint64), ("flow_end_s", np.int64), ("throughput", np.float64),
+              ("algo_calc", np.float64), ("stddev", np.float64))
+
+    def __init__(self, engine, res_ptr):
+        self._engine = engine
+        self._ptr = res_ptr
+        r = res_ptr.contents
+        self.n_rows = int(r.n_rows)
+        self.memory = "device" if r.memory == capi.TAD_MEM_DEVICE else "host"
+        self.id = r.id.decode()
+        self.stats = {name: getattr(r.stats, name) for name, _ in capi.Stats._fields_}
+        self._host = None
+        if self.memory == "host":
+            self._host = self._copy_host(r, direct=True)
+            self.close()
+
+    def _copy_host(self, r, direct):
+        out = {}
+        n = self.n_rows
+        cols = list(self.FIELDS) + ([("anomaly", np.uint8)] if r.anomaly else [])
+        for name, dt in cols:
+            arr = np.empty(n, dtype=dt)
+            src = getattr(r, name)
+            if n:
+                if direct:
+                    C.memmove(arr.ctypes.data, src, arr.nbytes)
+                else:
+                    self._engine._check(self._engine._lib.tad_copy_to_host(self._engine._h, arr.ctypes.data, src, arr.nbytes))
+            out[name] = arr
+        return out
+
+    def device_pointers(self):
+        if self._ptr is None or self.memory != "device":
+            raise ValueError("no live device result")
+        r = self._ptr.contents
+        return {name: getattr(r, name) for name, _ in self.FIELDS + (("anomaly", np.uint8),)}
+
+    def to_host(self):
+        """dict of numpy arrays: key_id, flow_end_s, throughput, algo_calc, stddev (, anomaly)."""
+        if self._host is None:
+            self._host = self._copy_host(self._ptr.contents, direct=False)
+        return self._host
+
+    def __getitem__(self, name):
+        return self.to_host()[name]
+
+    def close(self):
+        if self._ptr is not None and self._engine._h is not None:
+            self._engine._lib.tad_result_free(self._engine._h, self._ptr)
+        self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TadEngine:
+    """One engine per GPU.  Thread-safe (runs serialise inside the library)."""
+
+    def __init__(self, device=0, stream=None, workspace_limit=0):
+        self._lib = capi.load_library()
+        self._h = None
+        opts = capi.EngineOpts(device=int(device), stream=C.c_void_p(stream) if stream else None,
+                               workspace_limit=int(workspace_limit))
+        h = C.c_void_p()
+        rc = self._lib.tad_engine_create(C.byref(opts), C.byref(h))
+        if rc != capi.TAD_OK:
+            raise TadError(rc, (self._lib.tad_last_error(None) or b"").decode())
+        self._h = h
+
+    # ---- plumbing ----
+    def _check(self, rc):
+        if rc != capi.TAD_OK:
+            raise TadError(rc, (self._lib.tad_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h is not None:
+            self._lib.tad_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def progress(self):
+        d, t = capi.i32(), capi.i32()
+        self._lib.tad_progress(self._h, C.byref(d), C.byref(t))
+        return d.value, t.value
+
+    # ---- the job (anomaly_detection.py:647-710) ----
+    def run(self, algo, key_id, flow_end_s, value, num_keys, agg_flow="", value_op="auto", key_id2=None,
+            flow_start_s=None, start_time=0, end_time=0, lattice=None, emit_all=False, out="host", job_id="",
+            alpha=0.0, eps=0.0, min_samples=0, maxiter=0):
+        if algo not in capi.TAD_ALGO:
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "algo must be EWMA, ARIMA or DBSCAN")
+        if agg_flow not in capi.TAD_AGG:
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "agg_flow must be '', pod, svc or external")
+        pk, n, dev, keep1 = _as_column(key_id, np.uint64)
+        pt, nt, dev_t, keep2 = _as_column(flow_end_s, np.int64)
+        pv, nv, dev_v, keep3 = _as_column(value, np.uint64)
+        pk2, nk2, dev_k2, keep4 = _as_column(key_id2, np.uint64)
+        ps, ns, dev_s, keep5 = _as_column(flow_start_s, np.int64)
+        for m, d in ((nt, dev_t), (nv, dev_v)) + (((nk2, dev_k2),) if key_id2 is not None else ()) + \
+                (((ns, dev_s),) if flow_start_s is not None else ()):
+            if m != n or d != dev:
+                raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "columns must have equal length and live in the same memory")
+        job = capi.Job(algo=capi.TAD_ALGO[algo], agg_flow=capi.TAD_AGG[agg_flow], value_op=capi.TAD_OP[value_op],
+                       start_time=int(start_time), end_time=int(end_time), ewma_alpha=float(alpha),
+                       dbscan_eps=float(eps), dbscan_min_samples=int(min_samples), arima_maxiter=int(maxiter),
+                       flags=capi.TAD_FLAG_EMIT_ALL_POINTS if emit_all else 0, id=job_id.encode()[:63])
+        cols = capi.Columns(n_rows=n, key_id=pk, key_id2=pk2, flow_end_s=pt, flow_start_s=ps, value=pv,
+                            num_keys=int(num_keys), memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
+        if lattice is not None:
+            cols.t0, cols.step, cols.n_buckets = int(lattice[0]), int(lattice[1]), int(lattice[2])
+        res = C.POINTER(capi.Result)()
+        rc = self._lib.tad_run(self._h, C.byref(job), C.byref(cols),
+                               capi.TAD_MEM_DEVICE if out == "device" else capi.TAD_MEM_HOST, C.byref(res))
+        del keep1, keep2, keep3, keep4, keep5
+        self._check(rc)
+        return TadResult(self, res)
+
+    # ---- the reference's per-series pure functions, on the GPU ----
+    @staticmethod
+    def _series(x):
+        a = np.ascontiguousarray(np.asarray([int(v) for v in x] if not isinstance(x, np.ndarray) else x, dtype=np.uint64))
+        return a
+
+    def series_ewma(self, x, alpha=0.0):
+        a = self._series(x)
+        out = np.empty(a.size, dtype=np.float64)
+        self._check(self._lib.tad_series_ewma(self._h, a.ctypes.data, a.size, float(alpha), out.ctypes.data))
+        return out
+
+    def series_ewma_anomaly(self, x, stddev, alpha=0.0):
+        a = self._series(x)
+        out = np.zeros(a.size, dtype=np.uint8)
+        self._check(self._lib.tad_series_ewma_anomaly(self._h, a.ctypes.data, a.size, float(alpha),
+                                                      0 if stddev is None else 1, 0.0 if stddev is None else float(stddev),
+                                                      out.ctypes.data))
+        return out.astype(bool)
+
+    def series_stddev(self, x):
+        a = self._series(x)
+        has, sd = C.c_int(), capi.f64()
+        self._check(self._lib.tad_series_stddev(self._h, a.ctypes.data, a.size, C.byref(has), C.byref(sd)))
+        return sd.value if has.value else None
+
+    def series_dbscan_anomaly(self, x, eps=0.0, min_samples=0):
+        a = self._series(x)
+        out = np.zeros(a.size, dtype=np.uint8)
+        self._check(self._lib.tad_series_dbscan_anomaly(self._h, a.ctypes.data, a.size, float(eps), int(min_samples), out.ctypes.data))
+        return out.astype(bool)
+
+    def series_arima(self, x, maxiter=0):
+        a = self._series(x)
+        out = np.empty(a.size, dtype=np.float64)
+        has = C.c_int()
+        self._check(self._lib.tad_series_arima(self._h, a.ctypes.data, a.size, int(maxiter), C.byref(has), out.ctypes.data))
+        return out if has.value else None
+
+    def series_arima_anomaly(self, x, stddev, maxiter=0):
+        a = self._series(x)
+        out = np.zeros(max(a.size, 1), dtype=np.uint8)
+        nv = capi.u64()
+        self._check(self._lib.tad_series_arima_anomaly(self._h, a.ctypes.data, a.size, int(maxiter),
+                                                       0 if stddev is None else 1, 0.0 if stddev is None else float(stddev),
+                                                       out.ctypes.data, C.byref(nv)))
+        return out[:nv.value].astype(bool)
+
+    # ---- synthetic table straight into HBM ----
+    def synth(self, first_row, n_rows, num_keys, n_buckets, seed=SYNTH_SEED, into=None):
+        """Returns (key_id, flow_end_s, value) as DeviceArray, or fills the 3 given torch CUDA tensors."""
+        if into is None:
+            cols = (DeviceArray(self, n_rows, np.uint64), DeviceArray(self, n_rows, np.int64), DeviceArray(self, n_rows, np.uint64))
+            ptrs = [c.ptr for c in cols]
+        else:
+            cols = into
+            ptrs = [t.data_ptr() for t in into]
+        self._check(self._lib.tad_synth_generate(self._h, int(seed), int(first_row), int(n_rows), int(num_keys), int(n_buckets), *ptrs))
+        return cols
