@@ -116,6 +116,9 @@ typedef struct {
   uint64_t keys_no_result; /* ARIMA keys that yield no rows (n<=3, x<=0, constant; :232-234,260-264) */
   uint64_t kalman_steps;   /* ARIMA: filter time-steps over all likelihood evaluations */
   uint64_t arima_fits;     /* ARIMA: number of (key,t) fits */
+  double pts_mean;         /* mean and sum of squared deviations (M2) of the aggregated point values of */
+  double pts_m2;           /* this shard: (n_points, mean, M2) triples Chan-merge across GPUs into the global
+                              mean / sigma the multi-GPU host reports (telemetry; the reference has none) */
   int64_t t0, step;        /* the time lattice used */
   uint64_t n_buckets;
   float ms_meta;           /* lattice derivation pass */

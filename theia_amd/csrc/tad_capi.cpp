@@ -41,13 +41,14 @@ struct tad_engine {
   std::string err;
   std::atomic<int32_t> done{0}, total{0};
   // grow-only device scratch
-  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux;
+  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2, moments;
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
   hipEvent_t ev[6] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
   DevCounters *ctr_host = nullptr;     // pinned
   unsigned long long *total_host = nullptr;  // pinned
+  Moments *moments_host = nullptr;           // pinned
 };
 
 namespace {
@@ -206,7 +207,8 @@ int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
   hipHostMalloc(reinterpret_cast<void **>(&e->meta_host), sizeof(MetaPartial) * kMetaBlocks, hipHostMallocDefault);
   hipHostMalloc(reinterpret_cast<void **>(&e->ctr_host), sizeof(DevCounters), hipHostMallocDefault);
   hipHostMalloc(reinterpret_cast<void **>(&e->total_host), sizeof(unsigned long long), hipHostMallocDefault);
-  if (!e->meta_host || !e->ctr_host || !e->total_host) { tad_engine_destroy(e); return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "pinned host allocation failed"); }
+  hipHostMalloc(reinterpret_cast<void **>(&e->moments_host), sizeof(Moments) * kMomentBlocks, hipHostMallocDefault);
+  if (!e->meta_host || !e->ctr_host || !e->total_host || !e->moments_host) { tad_engine_destroy(e); return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "pinned host allocation failed"); }
   *out = e;
   return TAD_OK;
 }
@@ -216,7 +218,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -225,6 +227,7 @@ void tad_engine_destroy(tad_engine *e) {
   if (e->meta_host) hipHostFree(e->meta_host);
   if (e->ctr_host) hipHostFree(e->ctr_host);
   if (e->total_host) hipHostFree(e->total_host);
+  if (e->moments_host) hipHostFree(e->moments_host);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -281,8 +284,14 @@ int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ct
   uint32_t *n_anom = static_cast<uint32_t *>(e->n_anom.p);
   unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
 
+  if ((rc = ensure(e, e->key_mean, g.K * sizeof(double))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->key_m2, g.K * sizeof(double))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->moments, kMomentBlocks * sizeof(Moments))) != TAD_OK) return rc;
   const bool ewma = jp.algo == TAD_ALGO_EWMA;
-  launch_key_sigma(s, g, jp.alpha, ewma && !jp.all_points, sigma, n_pts, n_anom, ctr);
+  launch_key_sigma(s, g, jp.alpha, ewma && !jp.all_points, sigma, n_pts, n_anom, ctr, static_cast<double *>(e->key_mean.p),
+                   static_cast<double *>(e->key_m2.p));
+  launch_moments(s, g.K, n_pts, static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
+                 static_cast<Moments *>(e->moments.p));
   if (jp.algo == TAD_ALGO_DBSCAN) {
     const size_t scratch = dbscan_long_scratch_bytes(g);
     if (scratch == 0) {
@@ -304,6 +313,7 @@ int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ct
   launch_scan(s, cnt, off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
   HIP_TRY(e, hipMemcpyAsync(e->total_host, off + g.K, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(e->moments_host, e->moments.p, kMomentBlocks * sizeof(Moments), hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipStreamSynchronize(s));
   HIP_TRY(e, hipGetLastError());
   *rows = *e->total_host;
@@ -522,6 +532,21 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     st.kalman_steps = c.kalman_steps;
     st.arima_fits = c.arima_fits;
     st.t0 = L.t0; st.step = L.step; st.n_buckets = L.nb;
+    {
+      double mn = 0.0, mean = 0.0, m2 = 0.0;  // Chan merge of the block partials, fixed order
+      if (g.K)
+        for (int b = 0; b < kMomentBlocks; ++b) {
+          const Moments &p = e->moments_host[b];
+          if (p.n == 0.0) continue;
+          if (mn == 0.0) { mn = p.n; mean = p.mean; m2 = p.m2; continue; }
+          const double nn = mn + p.n, d = p.mean - mean;
+          mean = mean + d * (p.n / nn);
+          m2 = m2 + p.m2 + d * d * (mn * p.n / nn);
+          mn = nn;
+        }
+      st.pts_mean = mean;
+      st.pts_m2 = m2;
+    }
     st.n_anomalies = rows;
     if (jp.all_points) {
       // count verdicts host- or device-side? cheap: the emit kernel wrote them; count on the host copy if there is one
@@ -652,7 +677,7 @@ int tad_series_stddev(tad_engine *e, const uint64_t *x, uint64_t n, int *has_std
   if ((rc = ensure(e, e->n_pts, sizeof(uint32_t))) != TAD_OK) return rc;
   if ((rc = ensure(e, e->n_anom, sizeof(uint32_t))) != TAD_OK) return rc;
   launch_key_sigma(e->stream, g, 0.5, false, static_cast<double *>(e->sigma.p), static_cast<uint32_t *>(e->n_pts.p),
-                   static_cast<uint32_t *>(e->n_anom.p), static_cast<DevCounters *>(e->counters.p));
+                   static_cast<uint32_t *>(e->n_anom.p), static_cast<DevCounters *>(e->counters.p), nullptr, nullptr);
   double sg = 0.0;
   HIP_TRY(e, hipMemcpyAsync(&sg, e->sigma.p, sizeof sg, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));

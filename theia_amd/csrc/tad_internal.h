@@ -73,7 +73,12 @@ void launch_scatter(hipStream_t s, const uint64_t *key, const uint64_t *key2, co
 
 // per-key n / sigma (+ EWMA anomaly count when ewma != 0)
 void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, double *sigma,
-                      uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr);
+                      uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2);
+// deterministic Chan merge of the per-key (n, mean, M2) into kMomentBlocks partials
+struct Moments { double n, mean, m2; };
+static constexpr int kMomentBlocks = 128;
+void launch_moments(hipStream_t s, uint64_t K, const uint32_t *n_pts, const double *key_mean,
+                    const double *key_m2, Moments *partials);
 void launch_count_flags(hipStream_t s, Grid g, bool all_points, uint32_t *n_anom);
 // exclusive scan of cnt[K] into off[K], total in off[K]
 void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K,

@@ -241,7 +241,8 @@ static constexpr int kUnroll = 8;
 template <bool EWMA_COUNT>
 __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, double *__restrict__ sigma,
                                                       uint32_t *__restrict__ n_pts,
-                                                      uint32_t *__restrict__ n_anom, DevCounters *ctr) {
+                                                      uint32_t *__restrict__ n_anom, DevCounters *ctr,
+                                                      double *__restrict__ key_mean, double *__restrict__ key_m2) {
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   unsigned long long my_pts = 0;
   unsigned my_key = 0;
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, doub
     const double sg = has_sigma ? sqrt(m2 / (cnt - 1.0)) : 0.0;
     sigma[k] = sg;
     n_pts[k] = n;
+    if (key_mean != nullptr) { key_mean[k] = avg; key_m2[k] = m2; }
     my_pts = n;
     my_key = n > 0;
     if (EWMA_COUNT) {
@@ -332,13 +334,59 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, doub
 }
 
 void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, double *sigma,
-                      uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr) {
+                      uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2) {
   if (g.K == 0) return;
   const int blocks = (int)((g.K + kBlock - 1) / kBlock);
   if (ewma_count)
-    hipLaunchKernelGGL((k_key_sigma<true>), dim3(blocks), dim3(kBlock), 0, s, g, alpha, sigma, n_pts, n_anom, ctr);
+    hipLaunchKernelGGL((k_key_sigma<true>), dim3(blocks), dim3(kBlock), 0, s, g, alpha, sigma, n_pts, n_anom, ctr, key_mean, key_m2);
   else
-    hipLaunchKernelGGL((k_key_sigma<false>), dim3(blocks), dim3(kBlock), 0, s, g, alpha, sigma, n_pts, n_anom, ctr);
+    hipLaunchKernelGGL((k_key_sigma<false>), dim3(blocks), dim3(kBlock), 0, s, g, alpha, sigma, n_pts, n_anom, ctr, key_mean, key_m2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_moments — Chan et al. pairwise merge of the per-key (n, mean, M2) triples in a FIXED order
+// (strided per thread, then a fixed shuffle tree), so a shard's moments do not depend on scheduling.
+// The host merges the kMomentBlocks partials, and the multi-GPU host merges shards the same way.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Moments chan_merge(Moments a, Moments b) {
+  if (b.n == 0.0) return a;
+  if (a.n == 0.0) return b;
+  Moments r;
+  r.n = a.n + b.n;
+  const double d = b.mean - a.mean;
+  r.mean = a.mean + d * (b.n / r.n);
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+  return r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_moments(uint64_t K, const uint32_t *__restrict__ n_pts,
+                                                    const double *__restrict__ key_mean,
+                                                    const double *__restrict__ key_m2,
+                                                    Moments *__restrict__ partials) {
+  Moments acc{0.0, 0.0, 0.0};
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < K; k += stride) {
+    Moments m{(double)n_pts[k], key_mean[k], key_m2[k]};
+    acc = chan_merge(acc, m);
+  }
+  for (int d = 1; d < 64; d <<= 1) {
+    Moments o{__shfl_xor(acc.n, d), __shfl_xor(acc.mean, d), __shfl_xor(acc.m2, d)};
+    // both partners must compute the same value: order the pair by lane
+    acc = (threadIdx.x & d) ? chan_merge(o, acc) : chan_merge(acc, o);
+  }
+  __shared__ Moments s_m[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Moments a = s_m[0];
+    for (int w = 1; w < kBlock / 64; ++w) a = chan_merge(a, s_m[w]);
+    partials[blockIdx.x] = a;
+  }
+}
+
+void launch_moments(hipStream_t s, uint64_t K, const uint32_t *n_pts, const double *key_mean,
+                    const double *key_m2, Moments *partials) {
+  hipLaunchKernelGGL(k_moments, dim3(kMomentBlocks), dim3(kBlock), 0, s, K, n_pts, key_mean, key_m2, partials);
 }
 
 // per-key count of points flagged by a detector kernel (DBSCAN / ARIMA), or of all points
