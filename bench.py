@@ -150,7 +150,7 @@ def main():
                        "algo": args.algo, "rows_per_gpu": n, "keys_per_gpu": K, "buckets": T,
                        "lattice": "hinted" if args.hint_lattice else "derived by the engine (extra pass over flow_end_s)",
                        "parallelism": "key-sharded x%d, no data-path collective; all-reduce of counters + all-gather of moments" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_scatter (Stage-0 GROUP BY)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_partition (Stage-0 v2, row partition pass)" if st["stage0_path"] == 2 else "k_scatter (Stage-0 v1, direct atomics)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": BYTES_PER_ROW * n, "avg_kernel_ms": scatter_ms},
             "pipeline": {"ms_meta": acc["ms_meta"] / steps, "ms_stage0_clear_plus_scatter": acc["ms_stage0"] / steps,

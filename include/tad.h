@@ -122,10 +122,12 @@ typedef struct {
   int64_t t0, step;        /* the time lattice used */
   uint64_t n_buckets;
   float ms_meta;           /* lattice derivation pass */
-  float ms_stage0;         /* grid clear + scatter aggregation kernel(s) */
-  float ms_scatter;        /* the scatter kernel alone (dominant kernel) */
+  float ms_stage0;         /* Stage 0 after the lattice pass: v1 grid clear + k_scatter; v2 offsets +
+                              k_partition + k_tile_aggregate */
+  float ms_scatter;        /* the dominant Stage-0 kernel alone: k_scatter (v1) or k_partition (v2) */
   float ms_detect;         /* per-key sigma + detector + compaction */
   float ms_total;          /* device time of the whole run, HIP events on the engine stream */
+  int32_t stage0_path;     /* 1 = direct atomic scatter, 2 = partition + LDS tiles */
 } tad_stats;
 
 /* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).

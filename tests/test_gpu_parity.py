@@ -9,9 +9,20 @@ import pytest
 
 from oracle import tad_oracle as orc
 
+import os
+
 pytestmark = pytest.mark.gpu
 
 SKIP = np.uint64(orc.MASK64)
+
+
+@pytest.fixture(autouse=True, params=["v1", "v2"])
+def stage0(request):
+    """Every test runs with both Stage-0 strategies: v1 = direct atomic scatter, v2 = partition + LDS
+    tiles (forced even on tiny inputs).  Both must give the reference's integers bit for bit."""
+    os.environ["TAD_STAGE0"] = request.param
+    yield request.param
+    os.environ.pop("TAD_STAGE0", None)
 
 
 # ------------------------------------------------------------------ (a) reference golden vectors
@@ -92,6 +103,7 @@ def test_job_synthetic_tables_match_oracle(engine, algo, n_rows, K, T):
     k, t, v = orc.synth_rows(0, n_rows, K, T)
     res, want = check_job(engine, algo, k, t, v, K, agg_flow="svc")
     assert res.stats["rows_used"] == n_rows and res.stats["step"] == 60 and res.stats["t0"] == t.min()
+    assert res.stats["stage0_path"] == (2 if os.environ["TAD_STAGE0"] == "v2" else 1)
 
 
 @pytest.mark.parametrize("algo", ["EWMA", "DBSCAN"])

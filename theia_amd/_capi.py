@@ -39,7 +39,7 @@ class Stats(C.Structure):
                 ("n_anomalies", u64), ("keys_no_result", u64), ("kalman_steps", u64),
                 ("arima_fits", u64), ("pts_mean", f64), ("pts_m2", f64), ("t0", i64), ("step", i64), ("n_buckets", u64),
                 ("ms_meta", f32), ("ms_stage0", f32), ("ms_scatter", f32), ("ms_detect", f32),
-                ("ms_total", f32)]
+                ("ms_total", f32), ("stage0_path", i32)]
 
 
 class Result(C.Structure):

@@ -43,7 +43,8 @@ struct tad_engine {
   // grow-only device scratch
   DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2, moments;
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
-  hipEvent_t ev[6] = {};
+  DevBuf binhist, part_cnt, part_start, part_offs, recs;  // Stage 0 v2
+  hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
   DevCounters *ctr_host = nullptr;     // pinned
@@ -218,7 +219,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->binhist, &e->part_cnt, &e->part_start, &e->part_offs, &e->recs, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -442,18 +443,34 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   bool hinted = cols->n_buckets > 0;
   Lattice L = make_lattice(cols->t0, hinted ? cols->step : 1, cols->n_buckets);
   bool empty = (n == 0 || K == 0);
+  // Stage 0 strategy: v2 (partition + LDS tiles) for big batches, v1 (direct atomics) otherwise / as fallback.
+  const char *s0env = getenv("TAD_STAGE0");
+  const bool force_v1 = s0env && !strcmp(s0env, "v1");
+  const bool force_v2 = s0env && !strcmp(s0env, "v2");
   for (int attempt = 0; attempt < 2; ++attempt) {
-    if (!hinted && !empty) {
-      if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
-      int blocks = (int)((n + 255) / 256);
-      if (blocks > kMetaBlocks) blocks = kMetaBlocks;
+    HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
+    PartPlan pl{};
+    bool v2 = !empty && !force_v1 && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, &pl);
+    if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
+    int meta_blocks = 0;
+    if (v2) {
+      // pass A: lattice partials + per-workgroup key-bin histogram in one read of the key/time columns
+      if ((rc = ensure(e, e->binhist, (size_t)pl.G * pl.nbins * 4)) != TAD_OK) return rc;
+      launch_meta_hist(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, K, rf,
+                       pl, static_cast<MetaPartial *>(e->meta.p), static_cast<uint32_t *>(e->binhist.p), ctr);
+      meta_blocks = pl.G;
+    } else if (!hinted && !empty) {
+      meta_blocks = (int)((n + 255) / 256);
+      if (meta_blocks > kMetaBlocks) meta_blocks = kMetaBlocks;
       launch_meta(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, rf,
-                  static_cast<MetaPartial *>(e->meta.p), blocks);
-      HIP_TRY(e, hipMemcpyAsync(e->meta_host, e->meta.p, sizeof(MetaPartial) * blocks, hipMemcpyDeviceToHost, s));
+                  static_cast<MetaPartial *>(e->meta.p), meta_blocks);
+    }
+    if (!hinted && !empty) {
+      HIP_TRY(e, hipMemcpyAsync(e->meta_host, e->meta.p, sizeof(MetaPartial) * meta_blocks, hipMemcpyDeviceToHost, s));
       HIP_TRY(e, hipStreamSynchronize(s));
       int64_t tmin = 0, tmax = 0, tref = 0;
       uint64_t g = 0, used = 0;
-      for (int b = 0; b < blocks; ++b) {
+      for (int b = 0; b < meta_blocks; ++b) {
         const MetaPartial &p = e->meta_host[b];
         if (p.used == 0) continue;
         if (used == 0) { tmin = p.tmin; tmax = p.tmax; tref = p.tref; g = p.g; }
@@ -474,9 +491,9 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     }
     HIP_TRY(e, hipEventRecord(e->ev[1], s));
     e->done.store(1);
-    if (empty) { L = make_lattice(0, 1, 0); }
+    if (empty) { L = make_lattice(0, 1, 0); v2 = false; }
 
-    // ---- Stage 0: clear + scatter ----
+    // ---- Stage 0: GROUP BY (key, flowEndSeconds) into the time-major point grid ----
     const uint64_t cells = empty ? 0 : K * L.nb;
     if (!empty && L.nb != 0 && cells / L.nb != K) return fail(e, TAD_ERR_GRID_TOO_LARGE, "grid of %llu keys x %llu buckets overflows", (unsigned long long)K, (unsigned long long)L.nb);
     const uint64_t need = cells * 9 + (jp.algo == TAD_ALGO_ARIMA ? cells * 8 : 0);
@@ -487,16 +504,37 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     if ((rc = ensure(e, e->grid_val, cells * 8)) != TAD_OK) return rc;
     if ((rc = ensure(e, e->grid_flag, cells)) != TAD_OK) return rc;
     Grid g{static_cast<unsigned long long *>(e->grid_val.p), static_cast<uint8_t *>(e->grid_flag.p), empty ? 0 : K, L.nb};
-    HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
-    if (cells) {
-      HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));
-      HIP_TRY(e, hipMemsetAsync(g.flag, 0, cells, s));
+    if (v2 && !part_plan_tiles(K, L.nb, d_key2 != nullptr, &pl)) v2 = false;  // tile does not fit LDS: direct scatter
+    if (v2) {
+      const uint64_t slots = n * (d_key2 ? 2 : 1);
+      if ((rc = ensure(e, e->part_cnt, (size_t)pl.nparts * 4)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->part_start, ((size_t)pl.nparts + 1) * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->part_offs, (size_t)pl.G * pl.nparts * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->scan_scratch, scan_scratch_elems(pl.nparts) * sizeof(unsigned long long))) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->recs, (size_t)slots * 16)) != TAD_OK) return rc;
+      uint32_t *part_cnt = static_cast<uint32_t *>(e->part_cnt.p);
+      unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
+      unsigned long long *offs = static_cast<unsigned long long *>(e->part_offs.p);
+      launch_part_counts(s, static_cast<const uint32_t *>(e->binhist.p), pl, part_cnt);
+      launch_scan(s, part_cnt, part_start, pl.nparts, static_cast<unsigned long long *>(e->scan_scratch.p));
+      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, part_start, offs);
+      HIP_TRY(e, hipEventRecord(e->ev[2], s));
+      launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
+                       (const uint64_t *)d_val, n, K, rf, L, pl, offs, e->recs.p, ctr);
+      HIP_TRY(e, hipEventRecord(e->ev[3], s));
+      launch_tile_aggregate(s, e->recs.p, part_start, pl, g, op_max);
+    } else {
+      if (cells) {
+        HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));
+        HIP_TRY(e, hipMemsetAsync(g.flag, 0, cells, s));
+      }
+      HIP_TRY(e, hipEventRecord(e->ev[2], s));
+      if (!empty)
+        launch_scatter(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
+                       (const uint64_t *)d_val, n, rf, L, g, op_max, ctr);
+      HIP_TRY(e, hipEventRecord(e->ev[3], s));
     }
-    HIP_TRY(e, hipEventRecord(e->ev[2], s));
-    if (!empty)
-      launch_scatter(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
-                     (const uint64_t *)d_val, n, rf, L, g, op_max, ctr);
-    HIP_TRY(e, hipEventRecord(e->ev[3], s));
+    HIP_TRY(e, hipEventRecord(e->ev[5], s));
     e->done.store(2);
 
     // ---- Stage 1+2: sigma, detector, count, scan ----
@@ -563,9 +601,10 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       }
     }
     hipEventElapsedTime(&st.ms_meta, e->ev[0], e->ev[1]);
-    hipEventElapsedTime(&st.ms_stage0, e->ev[1], e->ev[3]);
+    hipEventElapsedTime(&st.ms_stage0, e->ev[1], e->ev[5]);
     hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
-    hipEventElapsedTime(&st.ms_detect, e->ev[3], e->ev[4]);
+    hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
+    st.stage0_path = v2 ? 2 : 1;
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     e->done.store(4);

@@ -186,7 +186,7 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples) {
   if (!pick_tile(g.T, &KT, &Tp, &bytes)) return -1;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_dbscan_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_dbscan_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     attr_set = true;
   }
   const uint64_t blocks = (g.K + KT - 1) / KT;

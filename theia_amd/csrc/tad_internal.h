@@ -101,6 +101,31 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
                  double *calc, DevCounters *ctr, void *workspace, size_t workspace_bytes);
 size_t arima_workspace_bytes(Grid g);
 
+// ---- Stage 0 v2: partition rows by key range, aggregate tiles in LDS (tad_stage0_part.hip) ----
+struct PartPlan {
+  int shift_bin;       // pass-A histogram bin = key >> shift_bin
+  uint32_t nbins;
+  int G;               // workgroups of pass A and pass B (identical row chunking)
+  uint64_t chunk;      // rows per workgroup
+  int shift_part;      // partition = key >> shift_part ; KP = 1 << shift_part keys per tile
+  uint32_t KP, nparts, bins_per_part;
+  size_t agg_lds, part_lds;
+  int rpt;             // rows per thread per tile in pass B
+};
+bool part_plan_bins(uint64_t n, uint64_t K, PartPlan *pl);
+bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
+void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
+                      const int64_t *t_start, uint64_t n, uint64_t K, RowFilter f, const PartPlan &pl,
+                      MetaPartial *partials, uint32_t *binhist, DevCounters *ctr);
+void launch_part_counts(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *part_cnt);
+void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl,
+                         const unsigned long long *part_start, unsigned long long *offs);
+void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
+                      const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f,
+                      Lattice L, const PartPlan &pl, const unsigned long long *offs, void *recs, DevCounters *ctr);
+void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start,
+                           const PartPlan &pl, Grid g, bool op_max);
+
 void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                   uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,
                   uint64_t *value);
