@@ -1,0 +1,73 @@
+"""CPU tests: the ARIMA oracle (oracle/arima_oracle.py) against the reference's golden vectors.
+
+What the reference pins (anomaly_detection_test.py): the verdict list (:320-345, asserted) and the first
+five characters of each prediction (:261-283, asserted).  The full-precision list (:288-318) is never
+asserted and disagrees with the asserted one at 12 of 90 indices, so a 1e-6 match against statsmodels
+is not pinned by anything ("parity unpinned"); the distances are recorded here."""
+import numpy as np
+import pytest
+
+from oracle import arima_oracle as ao
+
+
+@pytest.fixture(scope="module")
+def golden_pred(golden):
+    return ao.calculate_arima(golden["throughput_list"])
+
+
+def test_arima_verdicts_equal_reference_golden(golden, golden_pred):
+    x, sd = golden["throughput_list"], golden["stddev"]
+    verdict = [abs(float(a) - p) > sd for a, p in zip(x, golden_pred)]
+    assert verdict == golden["expected_anomaly_list_arima"]
+    assert [i for i, b in enumerate(verdict) if b] == [58, 59, 60, 68]
+    assert ao.calculate_arima_anomaly(x, sd) == golden["expected_anomaly_list_arima"]
+
+
+def test_arima_values_against_both_reference_lists(golden, golden_pred):
+    five = [int(str(v)[:5]) for v in golden_pred]
+    hits = sum(a == b for a, b in zip(five, golden["expected_arima_row_list"]))
+    # the asserted and the unasserted reference lists agree with each other at only 78 of 90 indices
+    self_hits = sum(int(str(v)[:5]) == b for v, b in zip(golden["expanded_arima_row_list"], golden["expected_arima_row_list"]))
+    assert self_hits == 78
+    assert hits >= 75, hits                      # measured: 77 / 90
+    full = np.array(golden["expanded_arima_row_list"])
+    rel = np.abs(np.array(golden_pred) - full) / full
+    assert np.median(rel) < 1e-7 and np.percentile(rel, 90) < 1e-4 and rel.max() < 5e-3   # measured 1e-9 / 1.6e-5 / 1.9e-3
+    # the first three predictions are inv_boxcox(boxcox(x)) (:241,255-256)
+    assert np.allclose(golden_pred[:3], golden["throughput_list"][:3], rtol=1e-12)
+
+
+def test_none_cases():
+    assert ao.calculate_arima([1, 2, 3]) is None                 # len <= 3 (:232-234)
+    assert ao.calculate_arima([5, 5, 5, 5, 5]) is None           # constant -> boxcox raises (:260-264)
+    assert ao.calculate_arima([5, 0, 7, 9, 11]) is None          # non-positive -> boxcox raises
+    assert ao.calculate_arima_anomaly([1, 2, 3], 1.0) == [False]  # :284-287
+
+
+def test_boxcox_lambda_matches_scipy(golden):
+    from scipy import stats
+    x = np.array(golden["throughput_list"], dtype=np.float64)
+    assert abs(ao.boxcox_mle_lambda(x) - stats.boxcox(x)[1]) < 1e-6
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        x = rng.uniform(1e9, 5e9, size=40)
+        assert abs(ao.boxcox_mle_lambda(x) - stats.boxcox(x)[1]) < 1e-5 * max(1.0, abs(stats.boxcox(x)[1]))
+
+
+def test_c_kalman_equals_numpy_kalman():
+    rng = np.random.default_rng(0)
+    y = np.cumsum(rng.normal(size=80)) + 50
+    for p in [(0.3, -0.4, 1.2), (0.0, 0.0, 0.5), (-0.9, 0.8, 1e-4), (0.99, -0.99, 3.0)]:
+        a = ao.kalman_arima111(y, *p)
+        b = ao.kalman_fast(y, *p)
+        assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(a[1])
+
+
+def test_start_params_small_sample_paths():
+    # the ValueError fallbacks of _conditional_sum_squares for 3, 4 and 5 observations
+    for n in (3, 4, 5, 6, 7):
+        y = np.array([1.0, 1.5, 1.2, 1.9, 1.7, 2.4, 2.2])[:n]
+        phi, theta, var = ao.start_params(y)
+        assert abs(phi) < 1 and abs(theta) < 1 and var >= 1e-10
+        if n <= 4:
+            assert phi == 0.0 and theta == 0.0

@@ -1,6 +1,680 @@
-// tad_arima.hip — placeholder until the ARIMA(1,1,1) kernel lands (next milestone).
+// tad_arima.hip — ARIMA detector (anomaly_detection.py:215-309) on gfx950, FP64 throughout.
+//
+//   y, lam = scipy.stats.boxcox(x)                 (:239)   -> k_arima_prep  (one lane = one key)
+//   preds[0:3] = y[0:3]                            (:241)
+//   for t in 3..n-1: ARIMA(y[:t], (1,1,1)).fit().forecast()[0]   (:246-253) -> k_arima_fit (one lane = one fit)
+//   algoCalc = inv_boxcox(preds, lam)              (:256)
+//   anomaly  = |x - algoCalc| > stddev             (:306-307)
+//   n <= 3, x <= 0 or constant x -> None -> the key yields no rows  (:232-234, :260-264, :284-287)
+//
+// The fit restates statsmodels 0.14 SARIMAX/ARIMA (not in /root/reference; pinned in
+// plugins/anomaly-detection/requirements.txt:3):  state space Z=[1 1 0], T=[[1 1 0],[0 phi 1],[0 0 0]],
+// R=[0 1 theta]', approximate-diffuse (1e6) + stationary initial covariance, loglikelihood_burn = 1,
+// covariance frozen once ||P_t - P_{t+1}||_F^2 < 1e-19; start parameters by conditional sum of squares on
+// diff(y) with numpy-pinv semantics; phi = u/sqrt(1+u^2), theta = -u/sqrt(1+u^2), sigma2 = u^2;
+// objective -loglike/nobs minimised by L-BFGS-B (m = 10, factr = 1e7, pgtol = 1e-5, maxiter = 50, maxls = 20)
+// with forward-difference gradients (h = 1e-5) and the More'-Thuente line search (ftol 1e-3, gtol 0.9,
+// xtol 0.1) — the unconstrained path of L-BFGS-B 3.0, where the subspace step equals the two-loop
+// L-BFGS direction with H0 = (s'y / y'y) I.
+//
+// GPU mapping: there is no dense contraction here (3 parameters, 3 states): the work is ~200 sequential
+// likelihood evaluations per fit, each a sequential Kalman recursion over the history.  Parallelism is
+// across the P - 3K independent fits.  A wavefront takes 64 consecutive keys at the SAME series position,
+// so all lanes run Kalman loops of the same length; the optimiser is a per-lane state machine that asks
+// for exactly one likelihood evaluation per trip, so lanes in different optimiser phases (gradient
+// component, line-search trial, final forecast) still execute the expensive part in lockstep.
 #include "tad_internal.h"
+
+// helper functions are host+device so that tools/arima_trace.cpp can step through the same code on the CPU
+#define TAD_HD __host__ __device__
+
 namespace tad {
-size_t arima_workspace_bytes(Grid) { return 0; }
-int launch_arima(hipStream_t, Grid, const double *, const uint32_t *, int, double *, DevCounters *, void *, size_t) { return -1; }
+
+static constexpr double kDiffuse = 1e6;
+static constexpr double kConvTol = 1e-19;
+static constexpr double kLog2Pi = 1.8378770664093453;  // log(2*pi)
+static constexpr double kEpsMch = 2.220446049250313e-16;
+static constexpr int kLbfgsM = 10;
+
+TAD_HD inline bool tad_finite(double v) { return fabs(v) <= 1.7976931348623157e308; }  // false for NaN and +-inf
+
+struct ArimaWs {
+  double *xs;      // [T][K] compacted values (as double), position-major
+  double *lx;      // [T][K] log(x)
+  double *ys;      // [T][K] Box-Cox transformed
+  uint32_t *tpos;  // [T][K] bucket of the p-th point
+  double *lam;     // [K]
+  uint8_t *state;  // [K] 0 = ok, 1 = no result
+};
+
+// ------------------------------------------------------------------------------------------------
+// Box-Cox: llf of scipy 1.10.1 (_morestats.boxcox_llf), bracket() + Brent.optimize() of scipy.optimize
+// ------------------------------------------------------------------------------------------------
+TAD_HD double bc_neg_llf(double lmb, const double *xs, const double *lx, size_t stride, uint32_t n, double sumlog) {
+  // variance of x**lmb / lmb (population), two passes like numpy.var
+  double mean = 0.0;
+  if (lmb == 0.0) {
+    for (uint32_t i = 0; i < n; ++i) mean += lx[i * stride];
+    mean /= (double)n;
+    double s = 0.0;
+    for (uint32_t i = 0; i < n; ++i) { const double d = lx[i * stride] - mean; s += d * d; }
+    return -((lmb - 1.0) * sumlog - (double)n / 2.0 * log(s / (double)n));
+  }
+  for (uint32_t i = 0; i < n; ++i) mean += exp(lmb * lx[i * stride]) / lmb;
+  mean /= (double)n;
+  double s = 0.0;
+  for (uint32_t i = 0; i < n; ++i) { const double d = exp(lmb * lx[i * stride]) / lmb - mean; s += d * d; }
+  return -((lmb - 1.0) * sumlog - (double)n / 2.0 * log(s / (double)n));
+}
+
+// returns false when no valid bracket / not finite (scipy raises -> calculate_arima returns None)
+TAD_HD bool bc_mle_lambda(const double *xs, const double *lx, size_t stride, uint32_t n, double sumlog, double *lam_out) {
+#define BCF(l) bc_neg_llf((l), xs, lx, stride, n, sumlog)
+  const double gold = 1.618034, verysmall = 1e-21, grow_limit = 110.0;
+  double xa = -2.0, xb = 2.0;
+  double fa = BCF(xa), fb = BCF(xb);
+  if (fa < fb) { double t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
+  double xc = xb + gold * (xb - xa);
+  double fc = BCF(xc);
+  int iter = 0;
+  while (fc < fb) {
+    const double tmp1 = (xb - xa) * (fb - fc);
+    const double tmp2 = (xb - xc) * (fb - fa);
+    const double val = tmp2 - tmp1;
+    const double denom = fabs(val) < verysmall ? 2.0 * verysmall : 2.0 * val;
+    double w = xb - ((xb - xc) * tmp2 - (xb - xa) * tmp1) / denom;
+    const double wlim = xb + grow_limit * (xc - xb);
+    if (iter > 1000) return false;
+    iter++;
+    double fw;
+    if ((w - xc) * (xb - w) > 0.0) {
+      fw = BCF(w);
+      if (fw < fc) { xa = xb; xb = w; fa = fb; fb = fw; break; }
+      else if (fw > fb) { xc = w; fc = fw; break; }
+      w = xc + gold * (xc - xb);
+      fw = BCF(w);
+    } else if ((w - wlim) * (wlim - xc) >= 0.0) {
+      w = wlim;
+      fw = BCF(w);
+    } else if ((w - wlim) * (xc - w) > 0.0) {
+      fw = BCF(w);
+      if (fw < fc) {
+        xb = xc; xc = w; w = xc + gold * (xc - xb);
+        fb = fc; fc = fw; fw = BCF(w);
+      }
+    } else {
+      w = xc + gold * (xc - xb);
+      fw = BCF(w);
+    }
+    xa = xb; xb = xc; xc = w;
+    fa = fb; fb = fc; fc = fw;
+  }
+  const bool cond1 = (fb < fc && fb <= fa) || (fb < fa && fb <= fc);
+  const bool cond2 = (xa < xb && xb < xc) || (xc < xb && xb < xa);
+  const bool cond3 = tad_finite(xa) && tad_finite(xb) && tad_finite(xc);
+  if (!(cond1 && cond2 && cond3)) return false;
+  // Brent
+  const double tol = 1.48e-8, mintol = 1.0e-11, cg = 0.3819660;
+  double x = xb, w = xb, v = xb, fx = fb, fw = fb, fv = fb;
+  double a = xa < xc ? xa : xc, b = xa < xc ? xc : xa;
+  double deltax = 0.0, rat = 0.0;
+  for (int it = 0; it < 500; ++it) {
+    const double tol1 = tol * fabs(x) + mintol, tol2 = 2.0 * tol1, xmid = 0.5 * (a + b);
+    if (fabs(x - xmid) < (tol2 - 0.5 * (b - a))) break;
+    if (fabs(deltax) <= tol1) {
+      deltax = x >= xmid ? a - x : b - x;
+      rat = cg * deltax;
+    } else {
+      double tmp1 = (x - w) * (fx - fv);
+      double tmp2 = (x - v) * (fx - fw);
+      double p = (x - v) * tmp2 - (x - w) * tmp1;
+      tmp2 = 2.0 * (tmp2 - tmp1);
+      if (tmp2 > 0.0) p = -p;
+      tmp2 = fabs(tmp2);
+      const double dx_temp = deltax;
+      deltax = rat;
+      if (p > tmp2 * (a - x) && p < tmp2 * (b - x) && fabs(p) < fabs(0.5 * tmp2 * dx_temp)) {
+        rat = p * 1.0 / tmp2;
+        const double u = x + rat;
+        if ((u - a) < tol2 || (b - u) < tol2) rat = xmid - x >= 0 ? tol1 : -tol1;
+      } else {
+        deltax = x >= xmid ? a - x : b - x;
+        rat = cg * deltax;
+      }
+    }
+    const double u = fabs(rat) < tol1 ? (rat >= 0 ? x + tol1 : x - tol1) : x + rat;
+    const double fu = BCF(u);
+    if (fu > fx) {
+      if (u < x) a = u; else b = u;
+      if (fu <= fw || w == x) { v = w; w = u; fv = fw; fw = fu; }
+      else if (fu <= fv || v == x || v == w) { v = u; fv = fu; }
+    } else {
+      if (u >= x) a = x; else b = x;
+      v = w; w = x; x = u;
+      fv = fw; fw = fx; fx = fu;
+    }
+  }
+#undef BCF
+  *lam_out = x;
+  return tad_finite(x);
+}
+
+TAD_HD inline double inv_boxcox(double y, double lam) {
+  return lam == 0.0 ? exp(y) : exp(log1p(lam * y) / lam);  // scipy.special.inv_boxcox
+}
+
+// one lane = one key: compact the series, Box-Cox it, first three predictions
+__global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const double *__restrict__ sigma,
+                                                    double *__restrict__ calc, DevCounters *ctr) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned noresult = 0;
+  if (k < g.K) {
+    const size_t st = g.K;
+    double *xs = ws.xs + k, *lx = ws.lx + k, *ys = ws.ys + k;
+    uint32_t *tp = ws.tpos + k;
+    uint32_t n = 0;
+    bool nonpos = false, allsame = true;
+    double x0 = 0.0, sumlog = 0.0;
+    for (uint64_t t = 0; t < g.T; ++t) {
+      const uint64_t c = t * g.K + k;
+      if (g.flag[c] & FLAG_PRESENT) {
+        const double x = (double)g.val[c];
+        if (n == 0) x0 = x;
+        if (x != x0) allsame = false;
+        if (!(x > 0.0)) nonpos = true;
+        const double l = log(x);
+        xs[(size_t)n * st] = x;
+        lx[(size_t)n * st] = l;
+        tp[(size_t)n * st] = (uint32_t)t;
+        sumlog += l;
+        n++;
+      }
+    }
+    bool ok = n > 3 && !nonpos && !allsame;
+    double lam = 0.0;
+    if (ok) ok = bc_mle_lambda(xs, lx, st, n, sumlog, &lam);
+    ws.lam[k] = lam;
+    ws.state[k] = ok ? 0 : 1;
+    if (ok) {
+      const double sg = sigma[k];
+      for (uint32_t i = 0; i < n; ++i) {
+        const double l = lx[(size_t)i * st];
+        const double y = lam == 0.0 ? l : expm1(lam * l) / lam;  // scipy.special.boxcox
+        ys[(size_t)i * st] = y;
+        if (i < 3) {
+          const uint64_t c = (uint64_t)tp[(size_t)i * st] * g.K + k;
+          const double pred = inv_boxcox(y, lam);
+          calc[c] = pred;
+          if (fabs(xs[(size_t)i * st] - pred) > sg) g.flag[c] = FLAG_PRESENT | FLAG_ANOMALY;
+        }
+      }
+    } else if (n > 0) {
+      // calculate_arima returned None: arrays_zip/explode of a null array -> the key has no rows at all
+      for (uint32_t i = 0; i < n; ++i) g.flag[(uint64_t)tp[(size_t)i * st] * g.K + k] = 0;
+      noresult = 1;
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) noresult += __shfl_down(noresult, d);
+  if ((threadIdx.x & 63) == 0 && noresult) atomicAdd(&ctr->keys_no_result, (unsigned long long)noresult);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ARIMA(1,1,1) likelihood: conventional Kalman filter written out for the 3-state model
+// ------------------------------------------------------------------------------------------------
+struct KfOut {
+  double nll;       // -loglike / nobs
+  double forecast;  // Z a_{n+1|n}
+};
+
+TAD_HD KfOut arima_nll(const double u0, const double u1, const double u2, const double *__restrict__ y, size_t stride,
+                           uint32_t n) {
+  const double phi = u0 / sqrt(1.0 + u0 * u0);
+  const double theta = -(u1 / sqrt(1.0 + u1 * u1));
+  const double s2 = u2 * u2;
+  // predicted covariance (symmetric): p00 p01 p02 / p11 p12 / p22
+  double p00 = kDiffuse, p01 = 0.0, p02 = 0.0;
+  double p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
+  double p12 = theta * s2, p22 = theta * theta * s2;
+  const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  double llf = 0.0, F = 1.0, k0 = 0.0, k1 = 0.0, k2 = 0.0, cterm = 0.0;
+  bool conv = false;
+  for (uint32_t t = 0; t < n; ++t) {
+    const double v = y[(size_t)t * stride] - (a0 + a1);
+    double pz0 = 0.0, pz1 = 0.0, pz2 = 0.0;
+    if (!conv) {
+      pz0 = p00 + p01; pz1 = p01 + p11; pz2 = p02 + p12;
+      F = pz0 + pz1;
+      k0 = pz0 / F; k1 = pz1 / F; k2 = pz2 / F;
+      cterm = -0.5 * (kLog2Pi + log(F));
+    }
+    if (t >= 1) llf += cterm - 0.5 * v * v / F;
+    const double f0 = a0 + k0 * v, f1 = a1 + k1 * v, f2 = a2 + k2 * v;
+    a0 = f0 + f1;
+    a1 = phi * f1 + f2;
+    a2 = 0.0;
+    if (!conv) {
+      // filtered covariance P - K (PZ)'
+      const double c00 = p00 - k0 * pz0, c01 = p01 - k0 * pz1, c02 = p02 - k0 * pz2;
+      const double c11 = p11 - k1 * pz1, c12 = p12 - k1 * pz2, c22 = p22 - k2 * pz2;
+      // T C T' + R Q R'
+      const double n00 = c00 + 2.0 * c01 + c11;
+      const double n01 = phi * (c01 + c11) + (c02 + c12);
+      const double n11 = phi * (phi * c11 + c12) + (phi * c12 + c22) + q11;
+      const double n12 = q12, n22 = q22;
+      const double d00 = p00 - n00, d01 = p01 - n01, d02 = p02, d11 = p11 - n11, d12 = p12 - n12, d22 = p22 - n22;
+      const double dsq = d00 * d00 + 2.0 * (d01 * d01) + 2.0 * (d02 * d02) + d11 * d11 + 2.0 * (d12 * d12) + d22 * d22;
+      if (dsq < kConvTol) conv = true;
+      p00 = n00; p01 = n01; p02 = 0.0; p11 = n11; p12 = n12; p22 = n22;
+    }
+  }
+  KfOut o;
+  o.nll = -llf / (double)n;
+  o.forecast = a0 + a1;
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// start parameters (SARIMAX.start_params -> _conditional_sum_squares, k_ar = k_ma = 1), streaming
+// ------------------------------------------------------------------------------------------------
+struct Ls2 { double a, b; };
+
+// minimum-norm least squares of Y on two columns = numpy.linalg.pinv(X).dot(Y) with rcond 1e-15, via a
+// one-sided Jacobi rotation.  g11 g12 g22 are the Gram entries; the callback recomputes the rotated
+// column norms and projections from the data (second pass) so that small singular values keep accuracy.
+template <typename RowFn>
+TAD_HD Ls2 pinv2_solve(uint32_t rows, RowFn row) {
+  Ls2 r{0.0, 0.0};
+  if (rows == 0) return r;
+  double g11 = 0.0, g12 = 0.0, g22 = 0.0;
+  for (uint32_t i = 0; i < rows; ++i) { double c1, c2, yy; row(i, c1, c2, yy); g11 += c1 * c1; g12 += c1 * c2; g22 += c2 * c2; }
+  double cs = 1.0, sn = 0.0;
+  if (g12 != 0.0) {
+    const double zeta = (g22 - g11) / (2.0 * g12);
+    const double tn = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    cs = 1.0 / sqrt(1.0 + tn * tn);
+    sn = cs * tn;
+  }
+  double s1 = 0.0, s2 = 0.0, b1 = 0.0, b2 = 0.0;
+  for (uint32_t i = 0; i < rows; ++i) {
+    double c1, c2, yy; row(i, c1, c2, yy);
+    const double r1 = cs * c1 - sn * c2, r2 = sn * c1 + cs * c2;
+    s1 += r1 * r1; s2 += r2 * r2; b1 += r1 * yy; b2 += r2 * yy;
+  }
+  const double smax = sqrt(fmax(s1, s2));
+  const double cut = 1e-15 * smax;
+  const double w1 = sqrt(s1) > cut ? b1 / s1 : 0.0;
+  const double w2 = sqrt(s2) > cut ? b2 / s2 : 0.0;
+  r.a = cs * w1 + sn * w2;
+  r.b = -sn * w1 + cs * w2;
+  return r;
+}
+
+TAD_HD void arima_start_params(const double *__restrict__ y, size_t stride, uint32_t n, double *u) {
+  const uint32_t m = n - 1;  // number of first differences e_i = y[i+1] - y[i]
+  auto e = [&](uint32_t i) { return y[(size_t)(i + 1) * stride] - y[(size_t)i * stride]; };
+  double phi0 = 0.0, theta0 = 0.0, var0 = 0.0;
+  bool fallback = m <= 2 || m - 2 <= 1;  // lagmat(endog, 2) / lagmat(residuals, 1) raise ValueError
+  if (!fallback) {
+    // AR(2) by pinv-OLS: e_t on (e_{t-1}, e_{t-2}), t = 2..m-1
+    const Ls2 ar = pinv2_solve(m - 2, [&](uint32_t i, double &c1, double &c2, double &yy) { c1 = e(i + 1); c2 = e(i); yy = e(i + 2); });
+    auto res = [&](uint32_t j) { return e(j + 2) - (e(j + 1) * ar.a + e(j) * ar.b); };  // residual of t = j + 2
+    // ARMA(1,1) by pinv-OLS: e_t on (e_{t-1}, res_{t-1}), t = 3..m-1
+    const uint32_t rows = m - 3;
+    const Ls2 am = pinv2_solve(rows, [&](uint32_t i, double &c1, double &c2, double &yy) { c1 = e(i + 2); c2 = res(i); yy = e(i + 3); });
+    phi0 = am.a;
+    theta0 = am.b;
+    if (rows > 1) {
+      double s = 0.0;
+      for (uint32_t i = 1; i < rows; ++i) { const double r2 = e(i + 3) - (e(i + 2) * am.a + res(i) * am.b); s += r2 * r2; }
+      var0 = s / (double)(rows - 1);
+    } else {
+      double mean = 0.0;
+      for (uint32_t i = 0; i < m; ++i) mean += e(i);
+      mean /= (double)m;
+      double s = 0.0;
+      for (uint32_t i = 0; i < m; ++i) { const double d = e(i) - mean; s += d * d; }
+      var0 = s / (double)m;  // numpy.var(endog)
+    }
+  } else {
+    double mean = 0.0;
+    for (uint32_t i = 0; i < m; ++i) mean += e(i);
+    mean /= (double)m;
+    double s = 0.0;
+    for (uint32_t i = 0; i < m; ++i) { const double d = e(i) - mean; s += d * d; }
+    var0 = s / (double)(m + 1);  // mean of residuals[1:] = [0, e - mean(e)]
+  }
+  if (!(fabs(phi0) < 1.0)) phi0 = 0.0;      // non-stationary start -> zeros
+  if (!(fabs(theta0) < 1.0)) theta0 = 0.0;  // non-invertible start -> zeros
+  var0 = fmax(var0, 1e-10);
+  u[0] = phi0 / sqrt(1.0 - phi0 * phi0);
+  u[1] = -theta0 / sqrt(1.0 - theta0 * theta0);
+  u[2] = sqrt(var0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// More'-Thuente line search (MINPACK-2 dcsrch / dcstep), restated
+// ------------------------------------------------------------------------------------------------
+struct LineSearch {
+  double stx, fx, gx, sty, fy, gy, stmin, stmax, width, width1, finit, ginit, gtest;
+  bool brackt;
+  int stage;
+};
+enum { LS_FG = 0, LS_CONV = 1, LS_WARN = 2, LS_ERROR = 3 };
+
+TAD_HD void mt_step(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp, double fp,
+                        double dp, bool &brackt, double stpmin, double stpmax) {
+  const double sgnd = dp * (dx / fabs(dx));
+  double stpf;
+  if (fp > fx) {
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp < stx) gamma = -gamma;
+    const double p = (gamma - dx) + theta, q = ((gamma - dx) + gamma) + dp, r = p / q;
+    const double stpc = stx + r * (stp - stx);
+    const double stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+    stpf = fabs(stpc - stx) <= fabs(stpq - stx) ? stpc : stpc + (stpq - stpc) / 2.0;
+    brackt = true;
+  } else if (sgnd < 0.0) {
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dx, r = p / q;
+    const double stpc = stp + r * (stx - stp);
+    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    stpf = fabs(stpc - stp) > fabs(stpq - stp) ? stpc : stpq;
+    brackt = true;
+  } else if (fabs(dp) < fabs(dx)) {
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    double gamma = s * sqrt(fmax(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta, q = (gamma + (dx - dp)) + gamma, r = p / q;
+    double stpc;
+    if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx - stp);
+    else if (stp > stx) stpc = stpmax;
+    else stpc = stpmin;
+    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (brackt) {
+      stpf = fabs(stpc - stp) < fabs(stpq - stp) ? stpc : stpq;
+      if (stp > stx) stpf = fmin(stp + 0.66 * (sty - stp), stpf);
+      else stpf = fmax(stp + 0.66 * (sty - stp), stpf);
+    } else {
+      stpf = fabs(stpc - stp) > fabs(stpq - stp) ? stpc : stpq;
+      stpf = fmin(stpmax, stpf);
+      stpf = fmax(stpmin, stpf);
+    }
+  } else {
+    if (brackt) {
+      const double theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+      const double s = fmax(fabs(theta), fmax(fabs(dy), fabs(dp)));
+      double gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+      if (stp > sty) gamma = -gamma;
+      const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dy, r = p / q;
+      stpf = stp + r * (sty - stp);
+    } else if (stp > stx) stpf = stpmax;
+    else stpf = stpmin;
+  }
+  if (fp > fx) { sty = stp; fy = fp; dy = dp; }
+  else {
+    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+    stx = stp; fx = fp; dx = dp;
+  }
+  stp = stpf;
+}
+
+TAD_HD int mt_start(LineSearch &L, double stp, double f, double g, double stpmin, double stpmax) {
+  if (stp < stpmin || stp > stpmax || g >= 0.0) return LS_ERROR;
+  L.brackt = false; L.stage = 1; L.finit = f; L.ginit = g; L.gtest = 1e-3 * g;
+  L.width = stpmax - stpmin; L.width1 = L.width / 0.5;
+  L.stx = 0.0; L.fx = f; L.gx = g; L.sty = 0.0; L.fy = f; L.gy = g;
+  L.stmin = 0.0; L.stmax = stp + 4.0 * stp;
+  return LS_FG;
+}
+
+TAD_HD int mt_iterate(LineSearch &L, double &stp, double f, double g, double stpmin, double stpmax) {
+  const double ftol = 1e-3, gtol = 0.9, xtol = 0.1;
+  (void)ftol;
+  const double ftest = L.finit + stp * L.gtest;
+  if (L.stage == 1 && f <= ftest && g >= 0.0) L.stage = 2;
+  int task = LS_FG;
+  if (L.brackt && (stp <= L.stmin || stp >= L.stmax)) task = LS_WARN;
+  if (L.brackt && L.stmax - L.stmin <= xtol * L.stmax) task = LS_WARN;
+  if (stp == stpmax && f <= ftest && g <= L.gtest) task = LS_WARN;
+  if (stp == stpmin && (f > ftest || g >= L.gtest)) task = LS_WARN;
+  if (f <= ftest && fabs(g) <= gtol * (-L.ginit)) task = LS_CONV;
+  if (task != LS_FG) return task;
+  if (L.stage == 1 && f <= L.fx && f > ftest) {
+    const double fm = f - stp * L.gtest;
+    double fxm = L.fx - L.stx * L.gtest, fym = L.fy - L.sty * L.gtest;
+    const double gm = g - L.gtest;
+    double gxm = L.gx - L.gtest, gym = L.gy - L.gtest;
+    mt_step(L.stx, fxm, gxm, L.sty, fym, gym, stp, fm, gm, L.brackt, L.stmin, L.stmax);
+    L.fx = fxm + L.stx * L.gtest; L.fy = fym + L.sty * L.gtest;
+    L.gx = gxm + L.gtest; L.gy = gym + L.gtest;
+  } else {
+    mt_step(L.stx, L.fx, L.gx, L.sty, L.fy, L.gy, stp, f, g, L.brackt, L.stmin, L.stmax);
+  }
+  if (L.brackt) {
+    if (fabs(L.sty - L.stx) >= 0.66 * L.width1) stp = L.stx + 0.5 * (L.sty - L.stx);
+    L.width1 = L.width;
+    L.width = fabs(L.sty - L.stx);
+  }
+  if (L.brackt) { L.stmin = fmin(L.stx, L.sty); L.stmax = fmax(L.stx, L.sty); }
+  else { L.stmin = stp + 1.1 * (stp - L.stx); L.stmax = stp + 4.0 * (stp - L.stx); }
+  stp = fmax(stp, stpmin);
+  stp = fmin(stp, stpmax);
+  if ((L.brackt && (stp <= L.stmin || stp >= L.stmax)) || (L.brackt && L.stmax - L.stmin <= xtol * L.stmax)) stp = L.stx;
+  return LS_FG;
+}
+
+// ------------------------------------------------------------------------------------------------
+// L-BFGS-B 3.0, unconstrained path, as a per-lane state machine driven by (f, g) deliveries
+// ------------------------------------------------------------------------------------------------
+struct Lbfgs {
+  double x[3], g[3], f;
+  double d[3], t[3], r[3];  // search direction, iterate and gradient at the start of the line search
+  double fold, gd, gdold, stp, dnorm, dtd, theta;
+  double S[kLbfgsM][3], Y[kLbfgsM][3];
+  int col, head, iter, ifun, iback, nit;
+  bool in_ls, done;
+  LineSearch ls;
+};
+
+TAD_HD void lbfgs_direction(Lbfgs &o) {
+  if (o.col == 0) {
+    for (int i = 0; i < 3; ++i) o.d[i] = -o.g[i];  // Cauchy point with B = theta I, theta = 1
+    return;
+  }
+  double q[3] = {o.g[0], o.g[1], o.g[2]}, alpha[kLbfgsM];
+  for (int j = o.col - 1; j >= 0; --j) {
+    const int i = (o.head + j) % kLbfgsM;
+    const double sy = o.S[i][0] * o.Y[i][0] + o.S[i][1] * o.Y[i][1] + o.S[i][2] * o.Y[i][2];
+    alpha[j] = (o.S[i][0] * q[0] + o.S[i][1] * q[1] + o.S[i][2] * q[2]) / sy;
+    for (int c = 0; c < 3; ++c) q[c] -= alpha[j] * o.Y[i][c];
+  }
+  for (int c = 0; c < 3; ++c) q[c] /= o.theta;
+  for (int j = 0; j < o.col; ++j) {
+    const int i = (o.head + j) % kLbfgsM;
+    const double sy = o.S[i][0] * o.Y[i][0] + o.S[i][1] * o.Y[i][1] + o.S[i][2] * o.Y[i][2];
+    const double beta = (o.Y[i][0] * q[0] + o.Y[i][1] * q[1] + o.Y[i][2] * q[2]) / sy;
+    for (int c = 0; c < 3; ++c) q[c] += o.S[i][c] * (alpha[j] - beta);
+  }
+  for (int c = 0; c < 3; ++c) o.d[c] = -q[c];
+}
+
+// begin a line search from the current (x, f, g); sets the first trial point in x
+TAD_HD void lbfgs_begin_ls(Lbfgs &o) {
+  for (;;) {
+    lbfgs_direction(o);
+    o.dtd = o.d[0] * o.d[0] + o.d[1] * o.d[1] + o.d[2] * o.d[2];
+    o.dnorm = sqrt(o.dtd);
+    o.stp = o.iter == 0 ? fmin(1.0 / o.dnorm, 1e10) : 1.0;
+    for (int i = 0; i < 3; ++i) { o.t[i] = o.x[i]; o.r[i] = o.g[i]; }
+    o.fold = o.f;
+    o.ifun = 0;
+    o.iback = 0;
+    o.gd = o.g[0] * o.d[0] + o.g[1] * o.d[1] + o.g[2] * o.d[2];
+    o.gdold = o.gd;
+    int task = LS_ERROR;
+    if (o.gd < 0.0) task = mt_start(o.ls, o.stp, o.f, o.gd, 0.0, 1e10);
+    if (task == LS_FG) break;
+    // ascent direction / bad step: info != 0
+    if (o.col == 0) { o.done = true; return; }  // ABNORMAL_TERMINATION_IN_LNSRCH (x, f already the old iterate)
+    o.col = 0; o.head = 0; o.theta = 1.0;          // refresh the memory and restart with steepest descent
+  }
+  o.ifun = 1;
+  o.iback = 0;
+  for (int i = 0; i < 3; ++i) o.x[i] = o.stp == 1.0 ? o.t[i] + o.d[i] : o.stp * o.d[i] + o.t[i];
+  o.in_ls = true;
+}
+
+// (f, g) at o.x have just been delivered
+TAD_HD void lbfgs_deliver(Lbfgs &o, int maxiter) {
+  const double pgtol = 1e-5, factr = 1e7;
+  if (!o.in_ls) {  // first evaluation
+    const double sbg = fmax(fabs(o.g[0]), fmax(fabs(o.g[1]), fabs(o.g[2])));
+    if (sbg <= pgtol) { o.done = true; return; }
+    lbfgs_begin_ls(o);
+    return;
+  }
+  o.gd = o.g[0] * o.d[0] + o.g[1] * o.d[1] + o.g[2] * o.d[2];
+  const int task = mt_iterate(o.ls, o.stp, o.f, o.gd, 0.0, 1e10);
+  if (task == LS_FG) {
+    o.ifun++;
+    o.iback = o.ifun - 1;
+    if (o.iback >= 20) {  // maxls: give up on this direction
+      for (int i = 0; i < 3; ++i) { o.x[i] = o.t[i]; o.g[i] = o.r[i]; }
+      o.f = o.fold;
+      if (o.col == 0) { o.done = true; return; }
+      o.col = 0; o.head = 0; o.theta = 1.0;
+      o.in_ls = false;  // restart from the restored iterate
+      lbfgs_begin_ls(o);
+      return;
+    }
+    for (int i = 0; i < 3; ++i) o.x[i] = o.stp == 1.0 ? o.t[i] + o.d[i] : o.stp * o.d[i] + o.t[i];
+    return;  // evaluate the new trial point
+  }
+  // CONVERGENCE or WARNING: the trial point is the new iterate
+  o.iter++;
+  o.nit++;
+  if (o.nit >= maxiter) { o.done = true; return; }  // the driver stops (scipy: n_iterations >= maxiter)
+  const double sbg = fmax(fabs(o.g[0]), fmax(fabs(o.g[1]), fabs(o.g[2])));
+  if (sbg <= pgtol) { o.done = true; return; }
+  const double ddum0 = fmax(fabs(o.fold), fmax(fabs(o.f), 1.0));
+  if ((o.fold - o.f) <= kEpsMch * factr * ddum0) { o.done = true; return; }
+  // BFGS update
+  double rr = 0.0;
+  for (int i = 0; i < 3; ++i) { o.r[i] = o.g[i] - o.r[i]; rr += o.r[i] * o.r[i]; }
+  double dr, ddum;
+  if (o.stp == 1.0) { dr = o.gd - o.gdold; ddum = -o.gdold; }
+  else { dr = (o.gd - o.gdold) * o.stp; for (int i = 0; i < 3; ++i) o.d[i] *= o.stp; ddum = -o.gdold * o.stp; }
+  if (!(dr <= kEpsMch * ddum)) {
+    int slot;
+    if (o.col < kLbfgsM) { slot = (o.head + o.col) % kLbfgsM; o.col++; }
+    else { slot = o.head; o.head = (o.head + 1) % kLbfgsM; }
+    for (int i = 0; i < 3; ++i) { o.S[slot][i] = o.d[i]; o.Y[slot][i] = o.r[i]; }
+    o.theta = rr / dr;
+  }
+  o.in_ls = false;
+  lbfgs_begin_ls(o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_arima_fit — one lane = one (key, position) fit; a wavefront = 64 consecutive keys at one position
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_arima_fit(Grid g, ArimaWs ws, const double *__restrict__ sigma,
+                                                  const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,
+                                                  double *__restrict__ calc, DevCounters *ctr) {
+  const uint32_t kblocks = (uint32_t)((g.K + 63) / 64);
+  const uint32_t pb = blockIdx.x / kblocks;           // heaviest (longest history) positions first
+  const uint32_t p = pmax - 1 - pb;
+  const uint64_t k = (uint64_t)(blockIdx.x % kblocks) * 64 + threadIdx.x;
+  const bool active = k < g.K && ws.state[k] == 0 && n_pts[k] > p;
+  unsigned long long steps = 0, fits = 0;
+  if (__any(active)) {
+    const size_t st = g.K;
+    const double *y = ws.ys + (active ? k : 0);
+    Lbfgs o;
+    o.col = 0; o.head = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = !active;
+    o.f = 0.0;
+    if (active) arima_start_params(y, st, p, o.x);
+    else { o.x[0] = 0.0; o.x[1] = 0.0; o.x[2] = 1.0; }
+    int phase = 0;  // 0: f at x; 1..3: f at x + h e_i; 4: final forecast
+    double f0 = 0.0, forecast = 0.0;
+    bool finished = !active;
+    while (__any(!finished)) {
+      double xe0 = o.x[0], xe1 = o.x[1], xe2 = o.x[2], dx = 1.0;
+      if (phase >= 1 && phase <= 3) {
+        double *xe = phase == 1 ? &xe0 : (phase == 2 ? &xe1 : &xe2);
+        const double x0 = *xe;
+        *xe = x0 + 1e-5;
+        dx = *xe - x0;
+      }
+      const KfOut r = arima_nll(xe0, xe1, xe2, y, st, p);  // uniform trip count across the wave
+      if (!finished) {
+        steps += p;
+        if (phase == 4) {
+          forecast = r.forecast;
+          finished = true;
+        } else if (phase == 0) {
+          f0 = r.nll;
+          phase = 1;
+        } else {
+          o.g[phase - 1] = (r.nll - f0) / dx;
+          phase++;
+          if (phase == 4) {
+            o.f = f0;
+            lbfgs_deliver(o, maxiter);
+            phase = o.done ? 4 : 0;
+          }
+        }
+      }
+    }
+    if (active) {
+      fits = 1;
+      const double lam = ws.lam[k];
+      const uint64_t c = (uint64_t)ws.tpos[(size_t)p * st + k] * g.K + k;
+      const double pred = inv_boxcox(forecast, lam);
+      calc[c] = pred;
+      if (fabs(ws.xs[(size_t)p * st + k] - pred) > sigma[k]) g.flag[c] = FLAG_PRESENT | FLAG_ANOMALY;
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) { steps += __shfl_down(steps, d); fits += __shfl_down(fits, d); }
+  if (threadIdx.x == 0 && fits) {
+    atomicAdd(&ctr->kalman_steps, steps);
+    atomicAdd(&ctr->arima_fits, fits);
+  }
+}
+
+size_t arima_workspace_bytes(Grid g) {
+  const size_t cells = (size_t)g.K * g.T;
+  return cells * (8 + 8 + 8 + 4) + (size_t)g.K * 9 + 256;
+}
+
+int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc,
+                 DevCounters *ctr, void *workspace, size_t workspace_bytes) {
+  if (g.K == 0 || g.T == 0) return 0;
+  if (workspace_bytes < arima_workspace_bytes(g)) return -1;
+  const size_t cells = (size_t)g.K * g.T;
+  unsigned char *w = static_cast<unsigned char *>(workspace);
+  ArimaWs ws;
+  ws.xs = reinterpret_cast<double *>(w); w += cells * 8;
+  ws.lx = reinterpret_cast<double *>(w); w += cells * 8;
+  ws.ys = reinterpret_cast<double *>(w); w += cells * 8;
+  ws.lam = reinterpret_cast<double *>(w); w += (size_t)g.K * 8;
+  ws.tpos = reinterpret_cast<uint32_t *>(w); w += cells * 4;
+  ws.state = w;
+  hipLaunchKernelGGL(k_arima_prep, dim3((unsigned)((g.K + 255) / 256)), dim3(256), 0, s, g, ws, sigma, calc, ctr);
+  if (g.T > 3) {
+    const uint64_t kblocks = (g.K + 63) / 64;
+    const uint64_t blocks = kblocks * (g.T - 3);
+    if (blocks > 0x7FFFFFFFull) return -1;
+    hipLaunchKernelGGL(k_arima_fit, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, calc, ctr);
+  }
+  return 0;
+}
+
 }  // namespace tad
