@@ -1,0 +1,460 @@
+"""Host-side mirror of the reference job's interface for the Throughput Anomaly Detection path.
+
+Reference: /root/reference/plugins/anomaly-detection/anomaly_detection.py (cited below as `ref:`).
+Same function names, argument meaning and error behaviour as the reference module, so that the
+parity tests read like the reference's own (anomaly_detection_test.py) — but every number comes
+from the HIP kernels in libtad_mi355x.so through the C ABI (include/tad.h).  There is no CPU
+fallback here and nothing under oracle/ is imported: without the library or a GPU the compute
+entry points raise TadError / OSError.
+
+What stays on the host (as SURVEY.md §8b assigns it): the string work of the SQL the reference
+pushes into ClickHouse (ref:507-614) — evaluating the WHERE predicates on the string columns and
+dictionary-encoding the mode's key columns into dense uint64 ids — and the expansion of the
+engine's (key_id, flowEndSeconds, ...) result rows back into `tadetector` rows (ref:352-421,
+create_table.sh:363-384).  The engine sees integers only.
+
+Flow tables are dicts of equally long numpy arrays named like the ClickHouse columns
+(create_table.sh:31-85); DateTime columns are epoch seconds (int64).  `load_flows` reads such a
+table from .npz / .parquet / .csv.
+"""
+import getopt
+import json
+import logging
+import re
+import sys
+import time
+import uuid
+from datetime import datetime, timezone
+
+import numpy as np
+
+from . import _capi as capi
+from .engine import TadEngine, TadError
+
+logger = logging.getLogger("anomaly_detection")
+
+table_name = "default.flows"                      # ref:48
+RESULT_TABLE_NAME = "default.tadetector"          # ref:732
+VALID_ALGOS = ("EWMA", "ARIMA", "DBSCAN")         # ref:816
+VALID_AGG_FLOWS = ("", "pod", "external", "svc")  # controller.go:560-620
+MEANINGLESS_LABELS = ("pod-template-hash", "controller-revision-hash", "pod-template-generation")  # ref:139-143
+TIME_FORMAT = "%Y-%m-%d %H:%M:%S"                 # ref:833, pkg/controller/util.go:45
+
+# key columns per mode, in result-row order (ref:109-137)
+KEY_COLUMNS = {
+    "": ("sourceIP", "sourceTransportPort", "destinationIP", "destinationTransportPort", "protocolIdentifier",
+         "flowStartSeconds"),
+    "external": ("destinationIP",),           # flowType is part of the GROUP BY (ref:130-133) but constant 3 and dropped (ref:621)
+    "svc": ("destinationServicePortName",),
+    "pod": ("podNamespace", "podLabels", "direction"),
+    "podname": ("podNamespace", "podName", "direction"),
+}
+
+_engine = None
+
+
+def get_engine():
+    """The process-wide engine on HIP device 0 (created on first use)."""
+    global _engine
+    if _engine is None:
+        _engine = TadEngine(device=0)
+    return _engine
+
+
+def set_engine(engine):
+    global _engine
+    _engine = engine
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's pure per-series functions (ref:146-349), computed by the GPU kernels
+# ------------------------------------------------------------------------------------------------
+def _as_u64_list(values):
+    return np.asarray([int(v) for v in values], dtype=np.uint64)
+
+
+def calculate_ewma(throughput_list):
+    """ref:146-165 -> list of float, e_t = 0.5 e_{t-1} + 0.5 float(x_t), e_{-1} = 0."""
+    return get_engine().series_ewma(_as_u64_list(throughput_list)).tolist()
+
+
+def calculate_ewma_anomaly(throughput_row, stddev):
+    """ref:168-212 -> list of bool; stddev None -> all False."""
+    return get_engine().series_ewma_anomaly(_as_u64_list(throughput_row), stddev).tolist()
+
+
+def calculate_arima(throughputs):
+    """ref:215-264 -> list of float, or None (len <= 3, non-positive or constant data: Box-Cox raises)."""
+    out = get_engine().series_arima(_as_u64_list(throughputs))
+    return None if out is None else out.tolist()
+
+
+def calculate_arima_anomaly(throughput_row, stddev):
+    """ref:267-309 -> list of bool; [False] when calculate_arima returns None (ref:284-287)."""
+    return get_engine().series_arima_anomaly(_as_u64_list(throughput_row), stddev).tolist()
+
+
+def calculate_dbscan(throughput_list):
+    """ref:312-322: the algoCalc placeholder, 0.0 per point (no device work to do)."""
+    return [0.0] * len(throughput_list)
+
+
+def calculate_dbscan_anomaly(throughput_row, stddev=None):
+    """ref:325-349 -> list of bool (label == -1); stddev is ignored, as in the reference."""
+    return get_engine().series_dbscan_anomaly(_as_u64_list(throughput_row)).tolist()
+
+
+def remove_meaningless_labels(podLabels):
+    """ref:631-644: drop the controller-generated labels, re-serialise with sorted keys; bad JSON -> ""."""
+    try:
+        labels = json.loads(podLabels)
+        kept = {k: v for k, v in labels.items() if k not in MEANINGLESS_LABELS}
+    except Exception as exc:  # same catch-all as the reference
+        logger.error("Error %s: labels %s are not in json format", exc, podLabels)
+        return ""
+    return json.dumps(kept, sort_keys=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# Stage 0, host half: WHERE predicates + dictionary encoding (ref:507-614)
+# ------------------------------------------------------------------------------------------------
+def _epoch(ts):
+    """'YYYY-MM-DD hh:mm:ss' (UTC) -> epoch seconds; '' / None -> 0."""
+    if not ts:
+        return 0
+    return int(datetime.strptime(ts, TIME_FORMAT).replace(tzinfo=timezone.utc).timestamp())
+
+
+def _like_regex(pattern):
+    """ClickHouse LIKE pattern -> compiled case-insensitive regex (ilike, ref:518-521)."""
+    out, i = [], 0
+    while i < len(pattern):
+        c = pattern[i]
+        if c == "\\" and i + 1 < len(pattern):
+            out.append(re.escape(pattern[i + 1]))
+            i += 2
+            continue
+        out.append(".*" if c == "%" else "." if c == "_" else re.escape(c))
+        i += 1
+    return re.compile("^" + "".join(out) + "$", re.IGNORECASE | re.DOTALL)
+
+
+def _str_col(flows, name):
+    return np.asarray(flows[name]).astype(str)
+
+
+def _ilike_contains(col, needle):
+    rx = _like_regex("%" + needle + "%")
+    uniq, inv = np.unique(col, return_inverse=True)
+    hit = np.fromiter((rx.match(u) is not None for u in uniq), dtype=bool, count=uniq.size)
+    return hit[inv]
+
+
+class PreparedColumns:
+    """What tad_run needs for one job: the encoded columns + the dictionary to decode results."""
+
+    def __init__(self, mode, key_id, key_id2, flow_end_s, flow_start_s, value, key_table, start_time, end_time):
+        self.mode = mode                  # key of KEY_COLUMNS
+        self.key_id = key_id              # u64[N], TAD_KEY_SKIP where the predicates reject the row
+        self.key_id2 = key_id2            # pod mode: the row's outbound key (ref:556-565), else None
+        self.flow_end_s = flow_end_s      # i64[N]
+        self.flow_start_s = flow_start_s  # i64[N] or None (pod mode: the SQL has no time filter)
+        self.value = value                # u64[N] throughput
+        self.key_table = key_table        # dict column name -> array[num_keys]
+        self.start_time = start_time      # epoch seconds handed to the engine (0 = unset)
+        self.end_time = end_time
+
+    @property
+    def num_keys(self):
+        return len(next(iter(self.key_table.values()))) if self.key_table else 0
+
+
+def _factorize(columns):
+    """Rows of `columns` (list of equally long arrays) -> (codes int64[N], list of unique-value arrays)."""
+    import pandas as pd
+    n = len(columns[0])
+    if n == 0:
+        return np.zeros(0, dtype=np.int64), [np.asarray(c)[:0] for c in columns]
+    codes, uniques = pd.MultiIndex.from_arrays(columns).factorize() if len(columns) > 1 else pd.factorize(np.asarray(columns[0]))
+    if len(columns) > 1:
+        uniq_cols = [np.asarray(uniques.get_level_values(i)) for i in range(len(columns))]
+    else:
+        uniq_cols = [np.asarray(uniques)]
+    return np.asarray(codes, dtype=np.int64), uniq_cols
+
+
+def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_flow="", pod_label="", external_ip="",
+                    svc_port_name="", pod_name="", pod_namespace=""):
+    """The host half of generate_tad_sql_query (ref:507-614): same predicates, same GROUP BY keys."""
+    n = len(flows["flowEndSeconds"])
+    flow_end = np.asarray(flows["flowEndSeconds"], dtype=np.int64)
+    value = np.asarray(flows["throughput"], dtype=np.uint64)
+    skip = np.uint64(capi.TAD_KEY_SKIP)
+    keep = np.ones(n, dtype=bool)
+    if ns_ignore_list:  # ref:549-553, 576-580
+        ign = np.asarray(list(ns_ignore_list), dtype=str)
+        keep &= ~np.isin(_str_col(flows, "sourcePodNamespace"), ign) & ~np.isin(_str_col(flows, "destinationPodNamespace"), ign)
+
+    if agg_flow == "pod":
+        by_name = bool(pod_name) and not pod_label
+        ident = "PodName" if by_name else "PodLabels"
+        sides = []
+        for side, direction in (("destination", "inbound"), ("source", "outbound")):
+            col = _str_col(flows, side + ident)
+            ns = _str_col(flows, side + "PodNamespace")
+            if pod_label:                                      # ref:516-527
+                ok = _ilike_contains(col, pod_label)
+                if pod_namespace:
+                    ok &= ns == pod_namespace
+            elif pod_name:                                     # ref:528-543
+                ok = col == pod_name
+                if pod_namespace:
+                    ok &= ns == pod_namespace
+            else:                                              # ref:544-548
+                ok = col != ""
+            sides.append((ok & keep, ns, col, direction))
+        sel = [np.flatnonzero(s[0]) for s in sides]
+        codes, uniq = _factorize([np.concatenate([sides[i][1][sel[i]] for i in range(2)]),
+                                  np.concatenate([sides[i][2][sel[i]] for i in range(2)]),
+                                  np.concatenate([np.full(sel[i].size, sides[i][3]) for i in range(2)])])
+        key_id = np.full(n, skip, dtype=np.uint64)
+        key_id2 = np.full(n, skip, dtype=np.uint64)
+        key_id[sel[0]] = codes[:sel[0].size].astype(np.uint64)
+        key_id2[sel[1]] = codes[sel[0].size:].astype(np.uint64)
+        mode = "podname" if by_name else "pod"
+        table = dict(zip(KEY_COLUMNS[mode], uniq))
+        # the pod SQL carries no flowStartSeconds / flowEndSeconds predicate (ref:556-565)
+        return PreparedColumns(mode, key_id, key_id2, flow_end, None, value, table, 0, 0)
+
+    if agg_flow == "external":
+        keep &= np.asarray(flows["flowType"]).astype(np.int64) == 3      # ref:590
+        if external_ip:
+            keep &= _str_col(flows, "destinationIP") == external_ip      # ref:591-593
+        cols = [_str_col(flows, "destinationIP")]
+    elif agg_flow == "svc":
+        svc = _str_col(flows, "destinationServicePortName")
+        keep &= (svc == svc_port_name) if svc_port_name else (svc != "")  # ref:594-601
+        cols = [svc]
+    elif not agg_flow:
+        cols = [_str_col(flows, "sourceIP"), np.asarray(flows["sourceTransportPort"]).astype(np.int64),
+                _str_col(flows, "destinationIP"), np.asarray(flows["destinationTransportPort"]).astype(np.int64),
+                np.asarray(flows["protocolIdentifier"]).astype(np.int64), np.asarray(flows["flowStartSeconds"], dtype=np.int64)]
+    else:
+        raise ValueError("aggregated flow type should be 'pod' or 'external' or 'svc'")
+    sel = np.flatnonzero(keep)
+    codes, uniq = _factorize([c[sel] for c in cols])
+    key_id = np.full(n, skip, dtype=np.uint64)
+    key_id[sel] = codes.astype(np.uint64)
+    mode = agg_flow or ""
+    table = dict(zip(KEY_COLUMNS[mode], uniq))
+    flow_start = np.asarray(flows["flowStartSeconds"], dtype=np.int64) if start_time else None
+    return PreparedColumns(mode, key_id, None, flow_end, flow_start, value, table, _epoch(start_time), _epoch(end_time))
+
+
+# ------------------------------------------------------------------------------------------------
+# the job (ref:647-710) and the result rows (ref:352-421, 500-503)
+# ------------------------------------------------------------------------------------------------
+def _sentinel_row(algo_type, agg_flow, tad_id):
+    """ref:395-420: the single row written when no point is anomalous."""
+    return {
+        "sourceIP": "None", "sourceTransportPort": 0, "destinationIP": "None", "destinationTransportPort": 0,
+        "protocolIdentifier": 0, "flowStartSeconds": datetime.now().strftime(TIME_FORMAT),
+        "podNamespace": "None", "podLabels": "None", "podName": "None", "destinationServicePortName": "None",
+        "direction": "None", "flowEndSeconds": 0, "throughputStandardDeviation": 0,
+        "aggType": agg_flow if agg_flow else "None", "algoType": algo_type, "algoCalc": 0.0, "throughput": 0.0,
+        "anomaly": "NO ANOMALY DETECTED", "id": str(tad_id),
+    }
+
+
+def result_rows(prep, res, algo_type, agg_flow, tad_id):
+    """Engine result -> list of `tadetector` rows (only the mode's columns are set; ClickHouse defaults the rest)."""
+    if res.n_rows == 0:
+        return [_sentinel_row(algo_type, agg_flow, tad_id)]
+    host = res.to_host()
+    kid = host["key_id"].astype(np.int64)
+    cols = {}
+    for name in KEY_COLUMNS[prep.mode]:
+        vals = prep.key_table[name][kid]
+        if name == "podLabels":                       # ref:686-695: canonicalised AFTER the grouping
+            canon = {u: remove_meaningless_labels(u) for u in np.unique(vals)}
+            vals = np.asarray([canon[v] for v in vals], dtype=object)
+        cols[name] = vals.tolist()
+    agg_type = agg_flow if agg_flow else "None"       # ref:617-628
+    rows = []
+    for i in range(res.n_rows):
+        row = {name: cols[name][i] for name in cols}
+        row.update({
+            "flowEndSeconds": int(host["flow_end_s"][i]),
+            "throughputStandardDeviation": float(host["stddev"][i]),
+            "aggType": agg_type, "algoType": algo_type,
+            "algoCalc": float(host["algo_calc"][i]), "throughput": float(host["throughput"][i]),
+            "anomaly": "true", "id": str(tad_id),     # ref:500-503 (cast boolean to string, add id)
+        })
+        rows.append(row)
+    return rows
+
+
+def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_ignore_list, agg_flow=None,
+                      pod_label=None, external_ip=None, svc_port_name=None, pod_name=None, pod_namespace=None,
+                      engine=None):
+    """ref:647-710.  `flows` (a column dict, or a path for load_flows) stands where the reference has the
+    JDBC address.  Returns (stats dict, list of result rows)."""
+    if algo_type not in VALID_ALGOS:
+        raise ValueError("Algorithm should be in {}".format(" or ".join(VALID_ALGOS)))
+    agg_flow = agg_flow or ""
+    if agg_flow not in VALID_AGG_FLOWS:
+        raise ValueError("aggregated flow type should be 'pod' or 'external' or 'svc'")
+    if isinstance(flows, str):
+        flows = load_flows(flows)
+    prep = prepare_columns(flows, start_time or "", end_time or "", ns_ignore_list or (), agg_flow, pod_label or "",
+                           external_ip or "", svc_port_name or "", pod_name or "", pod_namespace or "")
+    eng = engine or get_engine()
+    res = eng.run(algo_type, prep.key_id, prep.flow_end_s, prep.value, max(prep.num_keys, 1), agg_flow=agg_flow,
+                  key_id2=prep.key_id2, flow_start_s=prep.flow_start_s, start_time=prep.start_time,
+                  end_time=prep.end_time, job_id=str(tad_id_input or ""))
+    return res.stats, result_rows(prep, res, algo_type, agg_flow, tad_id_input)
+
+
+RESULT_COLUMNS = ("sourceIP", "sourceTransportPort", "destinationIP", "destinationTransportPort", "protocolIdentifier",
+                  "flowStartSeconds", "podNamespace", "podLabels", "podName", "destinationServicePortName", "direction",
+                  "flowEndSeconds", "throughputStandardDeviation", "aggType", "algoType", "algoCalc", "throughput",
+                  "anomaly", "id")   # create_table.sh:363-384
+
+
+def write_anomaly_detection_result(result_rows_, destination, result_table_name=RESULT_TABLE_NAME, tad_id_input=None):
+    """ref:713-726.  Appends the rows as JSON lines (ClickHouse `FORMAT JSONEachRow` input) to `destination`
+    — a path or a file object; the ClickHouse transport itself is SURVEY.md §8f rank 1.  Returns the job id."""
+    tad_id = tad_id_input if tad_id_input else str(uuid.uuid4())
+    own = isinstance(destination, str)
+    fh = open(destination, "a") if own else destination
+    try:
+        for row in result_rows_:
+            out = {k: row[k] for k in RESULT_COLUMNS if k in row}
+            out["id"] = row.get("id") if row.get("id") not in (None, "None", "") else tad_id
+            fh.write(json.dumps(out) + "\n")
+    finally:
+        if own:
+            fh.close()
+    return tad_id
+
+
+def load_flows(path):
+    """.npz (numpy), .parquet / .csv (pyarrow) -> column dict; DateTime columns as epoch seconds."""
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=True) as z:
+            return {k: z[k] for k in z.files}
+    if path.endswith(".parquet"):
+        import pyarrow.parquet as pq
+        tbl = pq.read_table(path)
+    elif path.endswith(".csv"):
+        import pyarrow.csv as pcsv
+        tbl = pcsv.read_csv(path)
+    else:
+        raise ValueError("flows file must be .npz, .parquet or .csv")
+    out = {}
+    for name in tbl.column_names:
+        col = tbl.column(name)
+        if str(col.type).startswith("timestamp"):
+            out[name] = col.cast("timestamp[s]").cast("int64").to_numpy()
+        else:
+            out[name] = col.to_numpy(zero_copy_only=False)
+    return out
+
+
+HELP_MESSAGE = """
+    Start the Throughput Anomaly Detection job on the MI355X engine.
+        Options:
+        -h, --help: Show help message.
+        -a, --algo=EWMA: EWMA, ARIMA or DBSCAN.
+        -d, --db_jdbc_url=None: accepted for compatibility; the ClickHouse transport is not part of this engine.
+        -F, --flows=PATH: flow table (.npz / .parquet / .csv with the columns of default.flows).
+        -o, --out=PATH: where the tadetector rows are appended as JSON lines (default stdout).
+        -s, --start_time=None / -e, --end_time=None: 'YYYY-MM-DD hh:mm:ss' UTC.
+        -i, --id=None: job id (uuid); generated when missing.
+        -n, --ns_ignore_list=[]: JSON list of namespaces to ignore.
+        -f, --agg-flow=None: pod | external | svc.
+        -l, --pod-label, -N, --pod-name, -P, --pod-namespace, -x, --external-ip, -p, --svc-port-name.
+    """
+
+
+def main(argv=None):
+    """ref:729-900: same options, same exit codes (2 on a bad argument)."""
+    argv = sys.argv[1:] if argv is None else argv
+    try:
+        opts, _ = getopt.getopt(argv, "ha:d:s:e:i:n:f:l:x:p:N:P:F:o:",
+                                ["help", "algo=", "db_jdbc_url=", "start_time=", "end_time=", "id=", "ns_ignore_list=",
+                                 "agg-flow=", "pod-label=", "external-ip=", "svc-port-name=", "pod-name=",
+                                 "pod-namespace=", "flows=", "out="])
+    except getopt.GetoptError as exc:
+        logger.error("ERROR of getopt.getopt: %s", exc)
+        logger.info(HELP_MESSAGE)
+        sys.exit(2)
+    a = {"algo": "", "start": "", "end": "", "id": None, "ns": [], "agg": "", "label": "", "ip": "", "svc": "",
+         "name": "", "namespace": "", "flows": "", "out": ""}
+
+    def bad(msg):
+        logger.error(msg)
+        logger.info(HELP_MESSAGE)
+        sys.exit(2)
+
+    for opt, arg in opts:
+        if opt in ("-h", "--help"):
+            logger.info(HELP_MESSAGE)
+            sys.exit()
+        elif opt in ("-a", "--algo"):
+            if arg not in VALID_ALGOS:
+                bad("Algorithm should be in {}".format(" or ".join(VALID_ALGOS)))
+            a["algo"] = arg
+        elif opt in ("-d", "--db_jdbc_url"):
+            if not arg.startswith("jdbc:"):
+                bad("Please provide a valid JDBC url for ClickHouse database")
+        elif opt in ("-s", "--start_time", "-e", "--end_time"):
+            which = "start" if opt in ("-s", "--start_time") else "end"
+            try:
+                datetime.strptime(arg, TIME_FORMAT)
+            except ValueError:
+                bad("{}_time should be in 'YYYY-MM-DD hh:mm:ss' format.".format(which))
+            a[which] = arg
+        elif opt in ("-n", "--ns_ignore_list"):
+            lst = json.loads(arg)
+            if not isinstance(lst, list):
+                bad("ns_ignore_list should be a list.")
+            a["ns"] = lst
+        elif opt in ("-i", "--id"):
+            a["id"] = arg
+        elif opt in ("-f", "--agg-flow"):
+            a["agg"] = arg
+        elif opt in ("-l", "--pod-label"):
+            a["label"] = arg
+        elif opt in ("-N", "--pod-name"):
+            a["name"] = arg
+        elif opt in ("-P", "--pod-namespace"):
+            a["namespace"] = arg
+        elif opt in ("-x", "--external-ip"):
+            a["ip"] = arg
+        elif opt in ("-p", "--svc-port-name"):
+            a["svc"] = arg
+        elif opt in ("-F", "--flows"):
+            a["flows"] = arg
+        elif opt in ("-o", "--out"):
+            a["out"] = arg
+    if not a["flows"]:
+        bad("--flows is required: this engine does not open the ClickHouse connection itself")
+    tad_id = a["id"] or str(uuid.uuid4())
+    t0 = time.time()
+    logger.info("Script started at %s", datetime.now().strftime("%a, %d %B %Y %H:%M:%S"))
+    try:
+        _, rows = anomaly_detection(a["algo"] or "EWMA", a["flows"], a["start"], a["end"], tad_id, a["ns"], a["agg"],
+                                    a["label"], a["ip"], a["svc"], a["name"], a["namespace"])
+    except (TadError, ValueError) as exc:
+        logger.error("Anomaly Detection failed: %s", exc)
+        sys.exit(1)
+    t1 = time.time()
+    write_anomaly_detection_result(rows, a["out"] if a["out"] else sys.stdout, RESULT_TABLE_NAME, tad_id)
+    logger.info("Anomaly Detection completed, id: %s, in %s seconds ", tad_id, t1 - t0)
+    return tad_id
+
+
+if __name__ == "__main__":
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    main()
