@@ -72,3 +72,52 @@ def test_product_code_never_touches_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b|#include\s+\"[^\"]*oracle", txt, flags=re.M):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def _build_c_driver(tmp_path):
+    from theia_amd import build
+    build.build_library()
+    exe = tmp_path / "capi_driver"
+    lib_dir = os.path.join(ROOT, "theia_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "capi_driver.c"), "-L", lib_dir, "-ltad_mi355x",
+                           "-Wl,-rpath," + lib_dir, "-o", str(exe)])
+    return exe
+
+
+def test_plain_c_caller_compiles_against_the_header_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/tad.h is C (what cgo parses): a C11 translation unit must compile -Werror clean and link."""
+    exe = _build_c_driver(tmp_path)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_runs_the_job(tmp_path):
+    import numpy as np
+    from oracle import tad_oracle as orc
+    exe = _build_c_driver(tmp_path)
+    for algo in ("EWMA", "DBSCAN"):
+        r = subprocess.run([str(exe), algo], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        # the same table as tools/capi_driver.c builds
+        key, tend, val = [], [], []
+        for k in range(3):
+            for t in range(30):
+                for dup in range(2):
+                    key.append(k); tend.append(1660202814 + 60 * t)
+                    val.append(2000000000 + 1000 * t + dup + (30000000000 if t == 20 + k else 0))
+        want = orc.run_job(algo, np.array(key, dtype=np.uint64), np.array(tend), np.array(val, dtype=np.uint64), agg_flow="svc")
+        rows = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("row ")]
+        assert len(rows) == want["n_anomalies"] > 0
+        for i, f in enumerate(rows):
+            d = dict(x.split("=") for x in f[1:])
+            assert int(d["key"]) == int(want["key_id"][i]) and int(d["t"]) == int(want["flow_end_s"][i])
+            assert float(d["x"]) == want["throughput"][i] and float(d["calc"]) == want["algo_calc"][i] and float(d["sd"]) == want["stddev"][i]
+        assert "illegal algo -> -1: invalid request: Throughput Anomaly Detector algorithm type should be" in r.stdout

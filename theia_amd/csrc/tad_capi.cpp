@@ -395,9 +395,9 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   if (!job || !cols || !out) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: job, cols and out must not be NULL");
   *out = nullptr;
   if (job->algo != TAD_ALGO_EWMA && job->algo != TAD_ALGO_ARIMA && job->algo != TAD_ALGO_DBSCAN)
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: Throughput Anomaly DetectorQuerier type should be 'EWMA' or 'ARIMA' or 'DBSCAN'");
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: Throughput Anomaly Detector algorithm type should be 'EWMA' or 'ARIMA' or 'DBSCAN'");
   if (job->agg_flow < TAD_AGG_NONE || job->agg_flow > TAD_AGG_EXTERNAL)
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: aggregated flow type should be 'pod' or 'external' or 'svc'");
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: Throughput Anomaly Detector aggregated flow type should be 'pod' or 'external' or 'svc'");
   if (job->start_time != 0 && job->end_time != 0 && job->end_time <= job->start_time)
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: EndInterval should be after StartInterval");
   if (cols->n_rows > 0 && (!cols->key_id || !cols->flow_end_s || !cols->value))

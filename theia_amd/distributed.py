@@ -1,0 +1,177 @@
+"""Multi-GPU host logic of the Throughput Anomaly Detection path: one process per GPU, key-sharded.
+
+Why this shape: after Stage 0 everything is independent per flow key — sigma is per
+key (anomaly_detection.py:674-684) and every detector runs on one key's series (:440-484) — and the
+Stage-0 aggregates are associative integers.  So flow keys are hash-partitioned across the GPUs of a
+node, each rank runs the whole single-GPU job (tad_run) on the rows of ITS keys, and the data path
+needs no collective.  What does cross ranks (RCCL over xGMI with backend "nccl", gloo on CPU):
+
+  1. all-reduce(sum, int64[6])  {anomalies, keys, points, rows_used, keys_no_result, rows_in} — the
+     reference's global `ret_plot.count() == 0` decision for the sentinel row (:395) needs the
+     global anomaly count;
+  2. all-gather of the (n, mean, M2) moments of each shard's aggregated points, Chan-merged in rank
+     order on every rank — the job-wide mean / sigma telemetry BASELINE.json's north_star asks for
+     (the reference itself has no global sigma);
+  3. (only when rows arrive row-sharded instead of key-sharded) one all-to-all(v) of rows or partial
+     aggregates to the key owners: `exchange_rows`.  Re-aggregating partial sums / maxima with the
+     same operator is bit-exact (wrapping add and unsigned max are associative and commutative).
+
+Anomaly rows stay on the rank that produced them: each rank appends its own rows to `tadetector`
+(row order in that table is irrelevant, it is ORDER BY flowStartSeconds — create_table.sh:384); only
+the sentinel row is written by rank 0.  Nothing here computes detector numbers: `run_local` is the
+HIP engine (TadEngine.run); the tests substitute the oracle for it on CPU ranks.
+"""
+import numpy as np
+
+SKIP = np.uint64(0xFFFFFFFFFFFFFFFF)  # TAD_KEY_SKIP
+STAT_FIELDS = ("n_anomalies", "n_keys", "n_points", "rows_used", "keys_no_result", "rows_in")
+
+
+def owner_of(key_id, world):
+    """Rank that owns a key.  Key ids are dense dictionary codes (first-appearance order on the host), so
+    `id mod world` is already a uniform hash partition and keeps the local ids dense: local = id // world."""
+    return np.asarray(key_id, dtype=np.uint64) % np.uint64(world)
+
+
+def local_key(key_id, world):
+    return np.asarray(key_id, dtype=np.uint64) // np.uint64(world)
+
+
+def global_key(local_id, rank, world):
+    return np.asarray(local_id, dtype=np.uint64) * np.uint64(world) + np.uint64(rank)
+
+
+def num_local_keys(num_keys, rank, world):
+    return (int(num_keys) - rank + world - 1) // world if num_keys > rank else 0
+
+
+def shard_rows(rank, world, key_id, flow_end_s, value, key_id2=None, flow_start_s=None):
+    """Rows of the batch that rank `rank` must see, with LOCAL key ids.  A pod-mode row (two keys,
+    anomaly_detection.py:556-565) goes to the owner of each of its keys; the key the rank does not own is
+    masked with TAD_KEY_SKIP so that it is aggregated exactly once job-wide."""
+    key_id = np.asarray(key_id, dtype=np.uint64)
+    live1 = key_id != SKIP
+    mine1 = live1 & (owner_of(key_id, world) == rank)
+    if key_id2 is not None:
+        key_id2 = np.asarray(key_id2, dtype=np.uint64)
+        live2 = key_id2 != SKIP
+        mine2 = live2 & (owner_of(key_id2, world) == rank)
+    else:
+        mine2 = np.zeros(key_id.shape, dtype=bool)
+    sel = np.flatnonzero(mine1 | mine2)
+    out = {
+        "key_id": np.where(mine1[sel], local_key(key_id[sel], world), SKIP),
+        "flow_end_s": np.asarray(flow_end_s, dtype=np.int64)[sel],
+        "value": np.asarray(value, dtype=np.uint64)[sel],
+        "key_id2": None, "flow_start_s": None,
+    }
+    if key_id2 is not None:
+        out["key_id2"] = np.where(mine2[sel], local_key(key_id2[sel], world), SKIP)
+    if flow_start_s is not None:
+        out["flow_start_s"] = np.asarray(flow_start_s, dtype=np.int64)[sel]
+    return out
+
+
+def chan_merge(parts):
+    """[(n, mean, M2), ...] merged left to right (Chan et al.) -> (n, mean, M2).  Same formula and order as
+    the engine's k_moments / host merge, so every rank computes identical bits."""
+    mn, mean, m2 = 0.0, 0.0, 0.0
+    for bn, bmean, bm2 in parts:
+        if bn == 0:
+            continue
+        if mn == 0:
+            mn, mean, m2 = float(bn), float(bmean), float(bm2)
+            continue
+        nn = mn + bn
+        d = bmean - mean
+        mean = mean + d * (bn / nn)
+        m2 = m2 + bm2 + d * d * (mn * bn / nn)
+        mn = nn
+    return mn, mean, m2
+
+
+class JobReducer:
+    """Pre-allocated buffers for the per-job collectives (so that a bench step allocates nothing)."""
+
+    def __init__(self, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.counters = torch.zeros(len(STAT_FIELDS), dtype=torch.int64, device=device)
+        self.moments = torch.zeros(3, dtype=torch.float64, device=device)
+        self.gathered = [torch.zeros(3, dtype=torch.float64, device=device) for _ in range(self.world)]
+        self._stage_i = torch.zeros(len(STAT_FIELDS), dtype=torch.int64).pin_memory() if device is not None and str(device) != "cpu" else None
+        self._stage_f = torch.zeros(3, dtype=torch.float64).pin_memory() if self._stage_i is not None else None
+
+    def reduce(self, stats):
+        """stats: tad_stats of this rank's run -> dict of job-wide values (identical on every rank)."""
+        torch, dist = self.torch, self.dist
+        ints = [int(stats.get(f, 0)) for f in STAT_FIELDS]
+        flts = [float(stats.get("n_points", 0)), float(stats.get("pts_mean", 0.0)), float(stats.get("pts_m2", 0.0))]
+        if self._stage_i is not None:
+            self._stage_i.copy_(torch.tensor(ints, dtype=torch.int64))
+            self._stage_f.copy_(torch.tensor(flts, dtype=torch.float64))
+            self.counters.copy_(self._stage_i, non_blocking=True)
+            self.moments.copy_(self._stage_f, non_blocking=True)
+        else:
+            self.counters.copy_(torch.tensor(ints, dtype=torch.int64))
+            self.moments.copy_(torch.tensor(flts, dtype=torch.float64))
+        if self.world > 1:
+            dist.all_reduce(self.counters, group=self.group)            # 1. global counts (sentinel decision)
+            dist.all_gather(self.gathered, self.moments, group=self.group)  # 2. moments per shard
+            parts = [tuple(g.tolist()) for g in self.gathered]
+        else:
+            parts = [tuple(self.moments.tolist())]
+        tot = self.counters.tolist()
+        n, mean, m2 = chan_merge(parts)
+        out = dict(zip(STAT_FIELDS, (int(v) for v in tot)))
+        out["global_mean"] = mean if n > 0 else None
+        out["global_sigma"] = (m2 / (n - 1.0)) ** 0.5 if n > 1 else None
+        out["write_sentinel"] = out["n_anomalies"] == 0 and self.rank == 0     # anomaly_detection.py:395-420
+        return out
+
+
+def exchange_rows(cols, world, rank, group=None, device=None):
+    """Row-sharded ingest: every rank holds an arbitrary slice of the rows; ship each row (or each locally
+    pre-aggregated partial point) to the owner(s) of its key(s) with one all-to-all(v).  Returns the columns this rank
+    owns, with local key ids.  Payload: 3 (or 4, 5) int64 columns per row, bucketed by destination rank."""
+    import torch
+    import torch.distributed as dist
+    names = ["key_id", "flow_end_s", "value"] + [n for n in ("key_id2", "flow_start_s") if cols.get(n) is not None]
+    send_parts, send_counts = [], []
+    for dst in range(world):
+        part = shard_rows(dst, world, cols["key_id"], cols["flow_end_s"], cols["value"], cols.get("key_id2"), cols.get("flow_start_s"))
+        mat = np.stack([np.asarray(part[n]).view(np.int64) if part[n].dtype == np.uint64 else np.asarray(part[n], dtype=np.int64)
+                        for n in names], axis=1) if part["key_id"].size else np.zeros((0, len(names)), dtype=np.int64)
+        send_parts.append(mat)
+        send_counts.append(mat.shape[0])
+    send = torch.from_numpy(np.concatenate(send_parts, axis=0)).to(device or "cpu")
+    counts = torch.tensor(send_counts, dtype=torch.int64, device=device or "cpu")
+    recv_counts = torch.zeros(world, dtype=torch.int64, device=device or "cpu")
+    if world > 1:
+        dist.all_to_all_single(recv_counts, counts, group=group)
+    else:
+        recv_counts.copy_(counts)
+    rc = [int(c) for c in recv_counts.tolist()]
+    recv = torch.zeros((sum(rc), len(names)), dtype=torch.int64, device=device or "cpu")
+    if world > 1:
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=send_counts, group=group)
+    else:
+        recv.copy_(send)
+    got = recv.cpu().numpy()
+    out = {"key_id2": None, "flow_start_s": None}
+    for j, n in enumerate(names):
+        col = np.ascontiguousarray(got[:, j])
+        out[n] = col.view(np.uint64) if n in ("key_id", "key_id2", "value") else col
+    return out
+
+
+def run_sharded(run_local, algo, cols, num_keys, reducer, **job):
+    """cols: this rank's rows with LOCAL key ids (shard_rows / exchange_rows).  run_local(algo, key_id, flow_end_s,
+    value, num_local_keys, **job) -> object with .stats (TadEngine.run).  Returns (local result, job-wide stats)."""
+    nk = max(1, num_local_keys(num_keys, reducer.rank, reducer.world))
+    res = run_local(algo, cols["key_id"], cols["flow_end_s"], cols["value"], nk, key_id2=cols.get("key_id2"),
+                    flow_start_s=cols.get("flow_start_s"), **job)
+    return res, reducer.reduce(res.stats)
