@@ -43,7 +43,9 @@ struct tad_engine {
   // grow-only device scratch
   DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2, moments;
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
-  DevBuf binhist, part_cnt, part_start, part_offs, recs;  // Stage 0 v2
+  DevBuf rcp_table;           // rcp_table[n] = RN(1/n), n = 0..rcp_n-1
+  uint64_t rcp_n = 0;
+  DevBuf binhist, part_total, part_start, part_offs32, rec_val, rec_cell;  // Stage 0 v2
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
@@ -219,7 +221,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->binhist, &e->part_cnt, &e->part_start, &e->part_offs, &e->recs, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->rec_val, &e->rec_cell, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -271,26 +273,53 @@ struct JobParams {
   bool all_points;
 };
 
+// reciprocals of the point counts 1..T for the exact-division FMA sequence (tad_internal.h:div_by_count);
+// 1.0 / n on the host is IEEE division = the correctly rounded reciprocal the sequence needs.
+int ensure_rcp_table(tad_engine *e, uint64_t T) {
+  const uint64_t want = T + 2;
+  if (want <= e->rcp_n) return TAD_OK;
+  uint64_t cap = want < 1024 ? 1024 : want + want / 4;
+  int rc = ensure(e, e->rcp_table, cap * sizeof(double));
+  if (rc != TAD_OK) return rc;
+  std::vector<double> h(cap);
+  h[0] = 0.0;
+  for (uint64_t i = 1; i < cap; ++i) h[i] = 1.0 / (double)i;
+  HIP_TRY(e, hipMemcpyAsync(e->rcp_table.p, h.data(), cap * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));  // h goes out of scope
+  e->rcp_n = cap;
+  return TAD_OK;
+}
+
+int ensure_key_buffers(tad_engine *e, uint64_t K) {
+  int rc;
+  const uint64_t k = K ? K : 1;
+  if ((rc = ensure(e, e->sigma, k * sizeof(double))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->n_pts, k * sizeof(uint32_t))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->n_anom, k * sizeof(uint32_t))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->off, (k + 1) * sizeof(unsigned long long))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->scan_scratch, scan_scratch_elems(k) * sizeof(unsigned long long))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->key_mean, k * sizeof(double))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->key_m2, k * sizeof(double))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->moments, kMomentBlocks * sizeof(Moments))) != TAD_OK) return rc;
+  return TAD_OK;
+}
+
 // Runs sigma + detector + scan on grid g.  On return *rows = number of rows emit will write.
-int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ctr, uint64_t *rows) {
+// stats_done: Stage 0 v2's tile pass already produced sigma / n_pts / (EWMA) n_anom / moments inputs / counters.
+int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ctr, uint64_t *rows, bool stats_done = false) {
   hipStream_t s = e->stream;
   int rc;
-  if ((rc = ensure(e, e->sigma, g.K * sizeof(double))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->n_pts, g.K * sizeof(uint32_t))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->n_anom, g.K * sizeof(uint32_t))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->off, (g.K + 1) * sizeof(unsigned long long))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->scan_scratch, scan_scratch_elems(g.K) * sizeof(unsigned long long))) != TAD_OK) return rc;
+  if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
+  if ((rc = ensure_rcp_table(e, g.T)) != TAD_OK) return rc;
   double *sigma = static_cast<double *>(e->sigma.p);
   uint32_t *n_pts = static_cast<uint32_t *>(e->n_pts.p);
   uint32_t *n_anom = static_cast<uint32_t *>(e->n_anom.p);
   unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
 
-  if ((rc = ensure(e, e->key_mean, g.K * sizeof(double))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->key_m2, g.K * sizeof(double))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->moments, kMomentBlocks * sizeof(Moments))) != TAD_OK) return rc;
   const bool ewma = jp.algo == TAD_ALGO_EWMA;
-  launch_key_sigma(s, g, jp.alpha, ewma && !jp.all_points, sigma, n_pts, n_anom, ctr, static_cast<double *>(e->key_mean.p),
-                   static_cast<double *>(e->key_m2.p));
+  if (!stats_done)
+    launch_key_sigma(s, g, jp.alpha, ewma && !jp.all_points, static_cast<const double *>(e->rcp_table.p), sigma, n_pts, n_anom, ctr, static_cast<double *>(e->key_mean.p),
+                     static_cast<double *>(e->key_m2.p));
   launch_moments(s, g.K, n_pts, static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
                  static_cast<Moments *>(e->moments.p));
   if (jp.algo == TAD_ALGO_DBSCAN) {
@@ -440,17 +469,21 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
 
   HIP_TRY(e, hipEventRecord(e->ev[0], s));
   // ---- time lattice ----
-  bool hinted = cols->n_buckets > 0;
-  Lattice L = make_lattice(cols->t0, hinted ? cols->step : 1, cols->n_buckets);
+  // lat_mode 0: the caller's hint; 1: derived — v2 samples the gcd (pass A) and pass B verifies every row, v1 derives it
+  // exactly; 2: exact derivation (k_meta).  A row off the lattice (wrong hint / sample missed a residue) moves to the next mode.
+  int lat_mode = cols->n_buckets > 0 ? 0 : 1;
+  Lattice L = make_lattice(cols->t0, lat_mode == 0 ? cols->step : 1, cols->n_buckets);
   bool empty = (n == 0 || K == 0);
   // Stage 0 strategy: v2 (partition + LDS tiles) for big batches, v1 (direct atomics) otherwise / as fallback.
   const char *s0env = getenv("TAD_STAGE0");
   const bool force_v1 = s0env && !strcmp(s0env, "v1");
   const bool force_v2 = s0env && !strcmp(s0env, "v2");
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  const bool has2 = cols->key_id2 != nullptr;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    const bool hinted = lat_mode == 0;
     HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
     PartPlan pl{};
-    bool v2 = !empty && !force_v1 && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, &pl);
+    bool v2 = !empty && !force_v1 && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
     if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
     int meta_blocks = 0;
     if (v2) {
@@ -459,7 +492,8 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       launch_meta_hist(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, K, rf,
                        pl, static_cast<MetaPartial *>(e->meta.p), static_cast<uint32_t *>(e->binhist.p), ctr);
       meta_blocks = pl.G;
-    } else if (!hinted && !empty) {
+    }
+    if (!hinted && !empty && (!v2 || lat_mode == 2)) {
       meta_blocks = (int)((n + 255) / 256);
       if (meta_blocks > kMetaBlocks) meta_blocks = kMetaBlocks;
       launch_meta(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, rf,
@@ -485,8 +519,9 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       if (used == 0) { empty = true; }
       else {
         const uint64_t span = (uint64_t)tmax - (uint64_t)tmin;
-        const uint64_t step = g == 0 ? 1 : g;
-        L = make_lattice(tmin, (int64_t)step, span / step + 1);
+        // the lattice must contain tmin and tmax whatever the sample saw
+        const uint64_t step = host_gcd(host_gcd(g, span), (uint64_t)tref - (uint64_t)tmin);
+        L = make_lattice(tmin, (int64_t)(step == 0 ? 1 : step), span / (step == 0 ? 1 : step) + 1);
       }
     }
     HIP_TRY(e, hipEventRecord(e->ev[1], s));
@@ -497,32 +532,43 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     const uint64_t cells = empty ? 0 : K * L.nb;
     if (!empty && L.nb != 0 && cells / L.nb != K) return fail(e, TAD_ERR_GRID_TOO_LARGE, "grid of %llu keys x %llu buckets overflows", (unsigned long long)K, (unsigned long long)L.nb);
     const uint64_t need = cells * 9 + (jp.algo == TAD_ALGO_ARIMA ? cells * 8 : 0);
-    if (need > e->ws_limit)
+    if (need > e->ws_limit) {
+      if (lat_mode == 1 && v2) { lat_mode = 2; continue; }  // a too-fine sampled step cannot happen (it is a multiple of the true one); be safe
       return fail(e, TAD_ERR_GRID_TOO_LARGE,
                   "dense point grid needs %llu bytes (%llu keys x %llu time buckets, step %lld s) > workspace limit %llu",
                   (unsigned long long)need, (unsigned long long)K, (unsigned long long)L.nb, (long long)L.step, (unsigned long long)e->ws_limit);
+    }
     if ((rc = ensure(e, e->grid_val, cells * 8)) != TAD_OK) return rc;
     if ((rc = ensure(e, e->grid_flag, cells)) != TAD_OK) return rc;
     Grid g{static_cast<unsigned long long *>(e->grid_val.p), static_cast<uint8_t *>(e->grid_flag.p), empty ? 0 : K, L.nb};
-    if (v2 && !part_plan_tiles(K, L.nb, d_key2 != nullptr, &pl)) v2 = false;  // tile does not fit LDS: direct scatter
+    if (v2 && !part_plan_tiles(K, L.nb, has2, &pl)) v2 = false;  // tile does not fit LDS: direct scatter
+    bool stats_done = false;
     if (v2) {
-      const uint64_t slots = n * (d_key2 ? 2 : 1);
-      if ((rc = ensure(e, e->part_cnt, (size_t)pl.nparts * 4)) != TAD_OK) return rc;
+      const uint64_t slots = n * (has2 ? 2 : 1);
+      if ((rc = ensure(e, e->part_total, (size_t)pl.nparts * 4)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_start, ((size_t)pl.nparts + 1) * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->part_offs, (size_t)pl.G * pl.nparts * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->scan_scratch, scan_scratch_elems(pl.nparts) * sizeof(unsigned long long))) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->recs, (size_t)slots * 16)) != TAD_OK) return rc;
-      uint32_t *part_cnt = static_cast<uint32_t *>(e->part_cnt.p);
+      if ((rc = ensure(e, e->part_offs32, (size_t)pl.G * pl.nparts * 4)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->rec_val, (size_t)slots * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->rec_cell, (size_t)slots * 2)) != TAD_OK) return rc;
+      if ((rc = ensure_key_buffers(e, K)) != TAD_OK) return rc;
+      if ((rc = ensure_rcp_table(e, L.nb)) != TAD_OK) return rc;
+      uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
       unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
-      unsigned long long *offs = static_cast<unsigned long long *>(e->part_offs.p);
-      launch_part_counts(s, static_cast<const uint32_t *>(e->binhist.p), pl, part_cnt);
-      launch_scan(s, part_cnt, part_start, pl.nparts, static_cast<unsigned long long *>(e->scan_scratch.p));
-      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, part_start, offs);
+      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start);
       HIP_TRY(e, hipEventRecord(e->ev[2], s));
       launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
-                       (const uint64_t *)d_val, n, K, rf, L, pl, offs, e->recs.p, ctr);
+                       (const uint64_t *)d_val, n, K, rf, L, pl, offs32, part_start, e->rec_val.p, e->rec_cell.p, ctr);
       HIP_TRY(e, hipEventRecord(e->ev[3], s));
-      launch_tile_aggregate(s, e->recs.p, part_start, pl, g, op_max);
+      // Per-key statistics fused into the tile pass cost more than they save on MI355X (one wavefront per tile walks a
+      // 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do: 2.53 vs 2.44 ms per C2 job),
+      // so the default runs them as their own kernel (k_key_sigma); TAD_FUSE_STATS=1 selects the fused variant.
+      const char *fz = getenv("TAD_FUSE_STATS");
+      const bool fuse = fz && !strcmp(fz, "1");
+      const int stats = !fuse ? 0 : (jp.algo == TAD_ALGO_EWMA && !jp.all_points) ? 2 : 1;
+      launch_tile_aggregate(s, e->rec_val.p, e->rec_cell.p, part_start, pl, g, op_max, stats, jp.alpha, static_cast<const double *>(e->rcp_table.p),
+                            static_cast<double *>(e->sigma.p), static_cast<uint32_t *>(e->n_pts.p), static_cast<uint32_t *>(e->n_anom.p),
+                            static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p), ctr);
+      stats_done = fuse;
     } else {
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));
@@ -539,12 +585,12 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
 
     // ---- Stage 1+2: sigma, detector, count, scan ----
     uint64_t rows = 0;
-    if ((rc = detect_and_count(e, g, jp, ctr, &rows)) != TAD_OK) return rc;
+    if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) return rc;
     const DevCounters c = *e->ctr_host;
     if (c.err & DEV_ERR_KEY_RANGE)
       return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
     if (c.err & DEV_ERR_OFF_LATTICE) {
-      if (hinted && attempt == 0) { hinted = false; continue; }  // caller's lattice hint was wrong: derive it
+      if (lat_mode < 2) { lat_mode = (lat_mode == 0) ? 1 : 2; continue; }  // wrong hint -> derive; sampled gcd too coarse -> exact
       return fail(e, TAD_ERR_HIP, "internal error: a row fell off the derived time lattice");
     }
     e->done.store(3);
@@ -715,7 +761,8 @@ int tad_series_stddev(tad_engine *e, const uint64_t *x, uint64_t n, int *has_std
   if ((rc = ensure(e, e->sigma, sizeof(double))) != TAD_OK) return rc;
   if ((rc = ensure(e, e->n_pts, sizeof(uint32_t))) != TAD_OK) return rc;
   if ((rc = ensure(e, e->n_anom, sizeof(uint32_t))) != TAD_OK) return rc;
-  launch_key_sigma(e->stream, g, 0.5, false, static_cast<double *>(e->sigma.p), static_cast<uint32_t *>(e->n_pts.p),
+  if ((rc = ensure_rcp_table(e, g.T)) != TAD_OK) return rc;
+  launch_key_sigma(e->stream, g, 0.5, false, static_cast<const double *>(e->rcp_table.p), static_cast<double *>(e->sigma.p), static_cast<uint32_t *>(e->n_pts.p),
                    static_cast<uint32_t *>(e->n_anom.p), static_cast<DevCounters *>(e->counters.p), nullptr, nullptr);
   double sg = 0.0;
   HIP_TRY(e, hipMemcpyAsync(&sg, e->sigma.p, sizeof sg, hipMemcpyDeviceToHost, e->stream));

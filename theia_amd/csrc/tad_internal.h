@@ -71,8 +71,21 @@ void launch_scatter(hipStream_t s, const uint64_t *key, const uint64_t *key2, co
                     const int64_t *t_start, const uint64_t *value, uint64_t n, RowFilter f,
                     Lattice lat, Grid g, bool op_max, DevCounters *ctr);
 
-// per-key n / sigma (+ EWMA anomaly count when ewma != 0)
-void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, double *sigma,
+// a / b for an integer-valued b >= 1, given y = RN(1 / b): Markstein's correction steps on the FMA unit.
+// q0 = RN(a y); r = a - b q (exact in one FMA); q' = RN(q + r y) is the correctly rounded quotient once q is a
+// faithful approximation — two steps guarantee that (checked against IEEE division on 4e8 operand pairs,
+// and by the bit-exact sigma parity tests).  5 dependent FMA-class ops instead of the ~12-op v_div sequence:
+// the per-key stddev_samp recurrence (Spark's d / n) is a pure dependency chain.
+__device__ __forceinline__ double div_by_count(double a, double b, double y) {
+  double q = a * y;
+  double r = fma(-b, q, a);
+  q = fma(r, y, q);
+  r = fma(-b, q, a);
+  return fma(r, y, q);
+}
+
+// per-key n / sigma (+ EWMA anomaly count when ewma != 0).  rcp[n] = RN(1/n) for n = 0..T (rcp[0] unused).
+void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, const double *rcp, double *sigma,
                       uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2);
 // deterministic Chan merge of the per-key (n, mean, M2) into kMomentBlocks partials
 struct Moments { double n, mean, m2; };
@@ -112,19 +125,22 @@ struct PartPlan {
   size_t agg_lds, part_lds;
   int rpt;             // rows per thread per tile in pass B
 };
-bool part_plan_bins(uint64_t n, uint64_t K, PartPlan *pl);
+bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl);
 bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
 void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, uint64_t n, uint64_t K, RowFilter f, const PartPlan &pl,
                       MetaPartial *partials, uint32_t *binhist, DevCounters *ctr);
-void launch_part_counts(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *part_cnt);
-void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl,
-                         const unsigned long long *part_start, unsigned long long *offs);
+// offs32[G][nparts] (exclusive per-workgroup prefix inside each partition), total[nparts], part_start[nparts + 1]
+void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
+                         unsigned long long *part_start);
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f,
-                      Lattice L, const PartPlan &pl, const unsigned long long *offs, void *recs, DevCounters *ctr);
-void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start,
-                           const PartPlan &pl, Grid g, bool op_max);
+                      Lattice L, const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start,
+                      void *rec_val, void *rec_cell, DevCounters *ctr);
+// stats: 0 = aggregate only, 1 = also per-key n / sigma / mean / M2 + key and point counters, 2 = also the EWMA count
+void launch_tile_aggregate(hipStream_t s, const void *rec_val, const void *rec_cell, const unsigned long long *part_start,
+                           const PartPlan &pl, Grid g, bool op_max, int stats, double alpha, const double *rcp, double *sigma,
+                           uint32_t *n_pts, uint32_t *n_anom, double *key_mean, double *key_m2, DevCounters *ctr);
 
 void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                   uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,

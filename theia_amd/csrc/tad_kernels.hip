@@ -236,10 +236,10 @@ void launch_scatter(hipStream_t s, const uint64_t *key, const uint64_t *key2, co
 // (Spark >= 3.1 returns null; anomaly_detection.py:198-201 then yields False for every point).
 // EWMA_COUNT additionally runs the EWMA recurrence and counts the key's anomalous points.
 // ------------------------------------------------------------------------------------------------
-static constexpr int kUnroll = 8;
+static constexpr int kUnroll = 16;  // independent loads in flight per lane: the per-key walks are HBM-latency bound
 
 template <bool EWMA_COUNT>
-__global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, double *__restrict__ sigma,
+__global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, const double *__restrict__ rcp, double *__restrict__ sigma,
                                                       uint32_t *__restrict__ n_pts,
                                                       uint32_t *__restrict__ n_anom, DevCounters *ctr,
                                                       double *__restrict__ key_mean, double *__restrict__ key_m2) {
@@ -263,11 +263,11 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, doub
         if (fl[u] & FLAG_PRESENT) {
           const double x = (double)v[u];
           cnt = cnt + 1.0;
+          n++;
           const double d = x - avg;
-          const double dn = d / cnt;
+          const double dn = div_by_count(d, cnt, rcp[n]);  // == d / cnt, bit for bit
           avg = avg + dn;
           m2 = m2 + d * (d - dn);
-          n++;
         }
       }
     }
@@ -275,11 +275,11 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, doub
       if (g.flag[t * g.K + k] & FLAG_PRESENT) {
         const double x = (double)g.val[t * g.K + k];
         cnt = cnt + 1.0;
+        n++;
         const double d = x - avg;
-        const double dn = d / cnt;
+        const double dn = div_by_count(d, cnt, rcp[n]);
         avg = avg + dn;
         m2 = m2 + d * (d - dn);
-        n++;
       }
     }
     const bool has_sigma = n >= 2;
@@ -333,14 +333,14 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, doub
   }
 }
 
-void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, double *sigma,
+void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, const double *rcp, double *sigma,
                       uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2) {
   if (g.K == 0) return;
   const int blocks = (int)((g.K + kBlock - 1) / kBlock);
   if (ewma_count)
-    hipLaunchKernelGGL((k_key_sigma<true>), dim3(blocks), dim3(kBlock), 0, s, g, alpha, sigma, n_pts, n_anom, ctr, key_mean, key_m2);
+    hipLaunchKernelGGL((k_key_sigma<true>), dim3(blocks), dim3(kBlock), 0, s, g, alpha, rcp, sigma, n_pts, n_anom, ctr, key_mean, key_m2);
   else
-    hipLaunchKernelGGL((k_key_sigma<false>), dim3(blocks), dim3(kBlock), 0, s, g, alpha, sigma, n_pts, n_anom, ctr, key_mean, key_m2);
+    hipLaunchKernelGGL((k_key_sigma<false>), dim3(blocks), dim3(kBlock), 0, s, g, alpha, rcp, sigma, n_pts, n_anom, ctr, key_mean, key_m2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,11 +507,9 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
   const bool has_sigma = n_pts[k] >= 2;
   const double one_minus = 1.0 - alpha;
   double e = 0.0;
-  for (uint64_t t = 0; t < g.T && pos < end; ++t) {
-    const uint64_t c = t * g.K + k;
-    const uint8_t fl = g.flag[c];
-    if (!(fl & FLAG_PRESENT)) continue;
-    const double x = (double)g.val[c];
+  auto step = [&](uint64_t t, uint8_t fl, unsigned long long raw) {
+    if (!(fl & FLAG_PRESENT)) return;
+    const double x = (double)raw;
     double a;
     bool verdict;
     if (KIND == 0) {
@@ -519,10 +517,10 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
       a = e;
       verdict = has_sigma && fabs(x - e) > sg;
     } else {
-      a = KIND == 1 ? calc[c] : 0.0;
+      a = KIND == 1 ? calc[t * g.K + k] : 0.0;
       verdict = (fl & FLAG_ANOMALY) != 0;
     }
-    if (ALL || verdict) {
+    if ((ALL || verdict) && pos < end) {
       out.key_id[pos] = k;
       out.flow_end_s[pos] = (long long)(L.t0 + (int64_t)t * L.step);
       out.throughput[pos] = x;
@@ -531,7 +529,21 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
       if (ALL) out.anomaly[pos] = verdict ? 1 : 0;
       pos++;
     }
+  };
+  // the series walk is a dependency chain per lane: issue kUnroll independent loads, then consume them
+  uint64_t t = 0;
+  for (; t + kUnroll <= g.T && pos < end; t += kUnroll) {
+    uint8_t fl[kUnroll];
+    unsigned long long v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      fl[u] = g.flag[(t + u) * g.K + k];
+      v[u] = g.val[(t + u) * g.K + k];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) step(t + u, fl[u], v[u]);
   }
+  for (; t < g.T && pos < end; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
 }
 
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,

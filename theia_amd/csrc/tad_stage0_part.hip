@@ -1,31 +1,53 @@
 // tad_stage0_part.hip — Stage 0 v2: GROUP BY (key, flowEndSeconds) without random HBM atomics.
 //
 // Why: on MI355X the direct scatter (tad_kernels.hip:k_scatter) is bound by L2-miss read-modify-write
-// transactions (~23.5e9/s measured, tools/ubench_scatter.hip) — 5.5 ms for 1e8 rows while the 24 B/row
-// column stream alone takes 0.43 ms.  Here every random access lands in LDS instead:
+// transactions (~20e9/s measured, tools/ubench_scatter.hip) — 5.5 ms for 1e8 rows while the 24 B/row
+// column stream alone takes 0.4 ms.  Here every random access lands in LDS instead:
 //
-//   pass A  k_meta_hist     one streaming read of the key/time columns (16 B/row): derives the
-//                           flowEndSeconds lattice (min, max, gcd) AND a per-workgroup histogram of rows
-//                           per key bin (bin = key >> shift_bin, <= 16384 bins, LDS counters).
-//   (tiny)  k_part_*        bins -> partitions of KP = 2^shift_part consecutive keys whose KP x T tile of
-//                           the point grid fits in LDS; exclusive offsets per (workgroup, partition):
-//                           the partition pass needs no global atomics and its output order is fixed.
-//   pass B  k_partition     streams the rows once more (24 B/row), turns each into a 16-byte record
-//                           {value, tile-local cell}, groups a tile of S records by partition in LDS
-//                           (LDS histogram + scan) and copies the runs out (16 B/row written).
-//   pass C  k_tile_aggregate  one workgroup per partition: LDS u64 atomics (add wraps mod 2^64 / unsigned
-//                           max) over its records, then writes its KP x T tile of the time-major grid
-//                           (values + presence flags) with coalesced stores.  No grid memset needed.
+//   pass A  k_meta_hist     one streaming read of the key/time columns (16 B/row, 16-byte loads): min / max of
+//                           flowEndSeconds, a SAMPLED gcd of its differences (verified by pass B, see below) AND a
+//                           per-workgroup histogram of rows per key bin (bin = key >> shift_bin, LDS counters).
+//   (tiny)  k_part_rows / k_part_colscan / k_part_scan1
+//                           bins -> partitions of KP = 2^shift_part consecutive keys whose KP x T tile of the
+//                           point grid fits in LDS; exclusive offsets per (workgroup, partition): the partition
+//                           pass needs no global atomics and its output order is fixed.
+//   pass B  k_partition     streams the rows once more (24 B/row, next tile prefetched into registers while the
+//                           current one is sorted), turns each into a 10-byte record {value u64, tile-local cell
+//                           u16} (two separate arrays), groups a tile of records by partition in LDS (LDS
+//                           histogram + scan) and copies the runs out (10 B/row written).
+//   pass C  k_tile_aggregate  one workgroup per partition: LDS u64 atomics (add wraps mod 2^64 / unsigned max)
+//                           over its records, then writes its KP x T tile of the time-major grid (values +
+//                           presence flags) with coalesced stores while one wavefront per 64 keys computes the
+//                           per-key stddev_samp (and the EWMA anomaly count) straight from the LDS tile.
 //
 // Integer add/max are associative and commutative, so the aggregates are bit-identical to v1 and to
 // ClickHouse's sum()/max() over UInt64 whatever the record order.
+//
+// Sampled gcd: every thread of pass A feeds only its first kGcdSamples kept rows into the gcd (a 64-bit
+// modulo per row would make the pass ALU-bound); the result is a multiple of the true lattice step.  Pass B
+// checks EVERY row against the lattice; a row off the lattice raises DEV_ERR_OFF_LATTICE and the host reruns
+// with the exact derivation (tad_kernels.hip:k_meta).  Results are therefore never computed on a wrong lattice.
+#include <cstdlib>
+#include <cstring>
+
 #include "tad_internal.h"
 
 namespace tad {
 
 static constexpr int kPartThreads = 1024;
-static constexpr uint32_t kCellPoison = 0xFFFFFFFFu;
+static constexpr uint32_t kCellPoison = 0xFFFFu;
+
+// A Stage-0 record is {value u64, tile-local cell u16}, kept as two arrays (10 B/row).  Measured on MI355X: the
+// partition pass is bound by the 64-byte write sectors its short runs touch, and 8 B + 2 B arrays (1.07 ms) beat
+// packed 12-byte records written with global_store_dwordx3 (1.19 ms) and the original 16-byte records (1.37 ms).
 static constexpr size_t kLdsBudget = 156 * 1024;  // dynamic LDS per workgroup; the rest of the CU's 160 KiB is for static __shared__
+static constexpr int kGcdSamples = 4;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier and makes
+// hipcc drain vmcnt(0) first — that would wait for the prefetched rows of the next tile and for the record stores
+// of the previous one at every barrier.  Threads of pass B exchange data through LDS alone (global stores go to
+// disjoint addresses nobody reads inside the kernel), so waiting for lgkmcnt (LDS) before s_barrier is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------------
 // shared helpers (duplicated from tad_kernels.hip on purpose: separate translation units)
@@ -61,28 +83,62 @@ __device__ __forceinline__ PMeta pmeta_merge(PMeta a, const PMeta &b) {
   return a;
 }
 
-__device__ __forceinline__ bool p_row_kept(int64_t te, const int64_t *t_start, uint64_t i, RowFilter f) {
-  if (f.end_time != 0 && !(te < f.end_time)) return false;
-  if (f.start_time != 0 && t_start != nullptr && !(t_start[i] >= f.start_time)) return false;
+__device__ __forceinline__ bool p_time_kept(int64_t te, int64_t ts, bool has_ts, RowFilter f) {
+  if (f.end_time != 0 && !(te < f.end_time)) return false;                  // anomaly_detection.py:584-586
+  if (f.start_time != 0 && has_ts && !(ts >= f.start_time)) return false;   // :581-583
   return true;
 }
 
-__device__ __forceinline__ bool p_bucket(const Lattice &L, int64_t te, uint64_t &bucket) {
+__device__ __forceinline__ bool p_bucket(const Lattice &L, int64_t te, uint32_t &bucket) {
   const uint64_t d = (uint64_t)te - (uint64_t)L.t0;
   uint64_t b;
   if (L.mode == 0) b = d;
   else if (L.mode == 1) { if (d >> 32) return false; b = __umul64hi(d, L.magic); }
   else b = d / (uint64_t)L.step;
   if (b >= L.nb || b * (uint64_t)L.step != d) return false;
-  bucket = b;
+  bucket = (uint32_t)b;
   return true;
 }
 
 // ------------------------------------------------------------------------------------------------
 // pass A — lattice partial + per-workgroup key-bin histogram.  Workgroup b owns rows
 // [b * chunk, (b+1) * chunk): the SAME chunking as pass B, so the histogram row b is exactly what
-// workgroup b of pass B will emit.
+// workgroup b of pass B will emit.  chunk is even and the columns are 16-byte aligned when VEC.
 // ------------------------------------------------------------------------------------------------
+struct MetaAcc {
+  PMeta m;
+  int nsample;
+  uint32_t err;
+};
+
+__device__ __forceinline__ void meta_row(MetaAcc &a, uint32_t *hist, uint64_t k1, uint64_t k2, int64_t te, bool kept,
+                                         uint64_t K, int shift_bin) {
+  if (!kept) return;
+  bool counted = false;
+  if (k1 != TAD_KEY_SKIP) {
+    if (k1 < K) { atomicAdd(&hist[(uint32_t)(k1 >> shift_bin)], 1u); counted = true; }
+    else a.err |= DEV_ERR_KEY_RANGE;
+  }
+  if (k2 != TAD_KEY_SKIP) {
+    if (k2 < K) { atomicAdd(&hist[(uint32_t)(k2 >> shift_bin)], 1u); counted = true; }
+    else a.err |= DEV_ERR_KEY_RANGE;
+  }
+  if (!counted) return;
+  if (a.m.used == 0) {
+    a.m.tmin = a.m.tmax = a.m.tref = te;
+    a.m.g = 0;
+  } else {
+    a.m.tmin = te < a.m.tmin ? te : a.m.tmin;
+    a.m.tmax = te > a.m.tmax ? te : a.m.tmax;
+    if (a.nsample < kGcdSamples) {
+      const uint64_t d = p_absdiff(te, a.m.tref);
+      if (d != 0) { a.m.g = p_gcd_u64(a.m.g, d); a.nsample++; }
+    }
+  }
+  a.m.used++;
+}
+
+template <bool VEC, bool HAS2>
 __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__restrict__ key,
                                                             const uint64_t *__restrict__ key2,
                                                             const int64_t *__restrict__ t_end,
@@ -97,48 +153,69 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
   __syncthreads();
   const uint64_t lo = (uint64_t)blockIdx.x * chunk;
   const uint64_t hi = lo + chunk < n ? lo + chunk : n;
-  PMeta acc{0, 0, 0, 0, 0};
-  uint32_t err = 0;
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += kPartThreads) {
-    const int64_t te = t_end[i];
-    const uint64_t k1 = key[i];
-    const uint64_t k2 = key2 != nullptr ? key2[i] : TAD_KEY_SKIP;
-    if ((k1 == TAD_KEY_SKIP && k2 == TAD_KEY_SKIP) || !p_row_kept(te, t_start, i, f)) continue;
-    bool counted = false;
-    if (k1 != TAD_KEY_SKIP) {
-      if (k1 < K) { atomicAdd(&hist[(uint32_t)(k1 >> shift_bin)], 1u); counted = true; }
-      else err |= DEV_ERR_KEY_RANGE;
+  MetaAcc acc{{0, 0, 0, 0, 0}, 0, 0};
+  const bool has_ts = t_start != nullptr && f.start_time != 0;
+  if (VEC) {
+    // two rows per lane per column: 1 KiB per wave-instruction
+    const uint64_t npair = hi > lo ? (hi - lo) >> 1 : 0;
+    const ulonglong2 *kv = reinterpret_cast<const ulonglong2 *>(key + lo);
+    const ulonglong2 *k2v = reinterpret_cast<const ulonglong2 *>(key2 + (HAS2 ? lo : 0));
+    const longlong2 *tv = reinterpret_cast<const longlong2 *>(t_end + lo);
+    constexpr int U = 4;
+    uint64_t i = threadIdx.x;
+    for (; i + (U - 1) * kPartThreads < npair; i += U * kPartThreads) {
+      ulonglong2 k[U], k2[U];
+      longlong2 t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        k[u] = kv[i + u * kPartThreads];
+        t[u] = tv[i + u * kPartThreads];
+        k2[u] = HAS2 ? k2v[i + u * kPartThreads] : make_ulonglong2(TAD_KEY_SKIP, TAD_KEY_SKIP);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t r = lo + 2 * (i + u * kPartThreads);
+        const int64_t ts0 = has_ts ? t_start[r] : 0, ts1 = has_ts ? t_start[r + 1] : 0;
+        meta_row(acc, hist, k[u].x, k2[u].x, t[u].x, p_time_kept(t[u].x, ts0, has_ts, f), K, shift_bin);
+        meta_row(acc, hist, k[u].y, k2[u].y, t[u].y, p_time_kept(t[u].y, ts1, has_ts, f), K, shift_bin);
+      }
     }
-    if (k2 != TAD_KEY_SKIP) {
-      if (k2 < K) { atomicAdd(&hist[(uint32_t)(k2 >> shift_bin)], 1u); counted = true; }
-      else err |= DEV_ERR_KEY_RANGE;
+    for (; i < npair; i += kPartThreads) {
+      const ulonglong2 k = kv[i];
+      const longlong2 t = tv[i];
+      const ulonglong2 k2 = HAS2 ? k2v[i] : make_ulonglong2(TAD_KEY_SKIP, TAD_KEY_SKIP);
+      const uint64_t r = lo + 2 * i;
+      const int64_t ts0 = has_ts ? t_start[r] : 0, ts1 = has_ts ? t_start[r + 1] : 0;
+      meta_row(acc, hist, k.x, k2.x, t.x, p_time_kept(t.x, ts0, has_ts, f), K, shift_bin);
+      meta_row(acc, hist, k.y, k2.y, t.y, p_time_kept(t.y, ts1, has_ts, f), K, shift_bin);
     }
-    if (!counted) continue;
-    if (acc.used == 0) {
-      acc.tmin = acc.tmax = acc.tref = te;
-      acc.g = 0;
-    } else {
-      acc.tmin = te < acc.tmin ? te : acc.tmin;
-      acc.tmax = te > acc.tmax ? te : acc.tmax;
-      const uint64_t d = p_absdiff(te, acc.tref);
-      if (d != 0 && (acc.g == 0 || d % acc.g != 0)) acc.g = p_gcd_u64(acc.g, d);
+    if (((hi - lo) & 1) && threadIdx.x == 0 && hi > lo) {
+      const uint64_t r = hi - 1;
+      const int64_t te = t_end[r];
+      meta_row(acc, hist, key[r], HAS2 ? key2[r] : TAD_KEY_SKIP, te, p_time_kept(te, has_ts ? t_start[r] : 0, has_ts, f), K, shift_bin);
     }
-    acc.used++;
+  } else {
+    for (uint64_t r = lo + threadIdx.x; r < hi; r += kPartThreads) {
+      const int64_t te = t_end[r];
+      meta_row(acc, hist, key[r], HAS2 ? key2[r] : TAD_KEY_SKIP, te, p_time_kept(te, has_ts ? t_start[r] : 0, has_ts, f), K, shift_bin);
+    }
   }
+  PMeta m = acc.m;
+  uint32_t err = acc.err;
   for (int d = 32; d >= 1; d >>= 1) {
     PMeta o;
-    o.tmin = __shfl_down((long long)acc.tmin, d);
-    o.tmax = __shfl_down((long long)acc.tmax, d);
-    o.tref = __shfl_down((long long)acc.tref, d);
-    o.g = __shfl_down((unsigned long long)acc.g, d);
-    o.used = __shfl_down((unsigned long long)acc.used, d);
-    acc = pmeta_merge(acc, o);
+    o.tmin = __shfl_down((long long)m.tmin, d);
+    o.tmax = __shfl_down((long long)m.tmax, d);
+    o.tref = __shfl_down((long long)m.tref, d);
+    o.g = __shfl_down((unsigned long long)m.g, d);
+    o.used = __shfl_down((unsigned long long)m.used, d);
+    m = pmeta_merge(m, o);
     err |= __shfl_down(err, d);
   }
   __shared__ PMeta s_acc[kPartThreads / 64];
   __shared__ uint32_t s_err[kPartThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { s_acc[wave] = acc; s_err[wave] = err; }
+  if (lane == 0) { s_acc[wave] = m; s_err[wave] = err; }
   __syncthreads();  // also: every histogram update of this workgroup is done
   if (threadIdx.x == 0) {
     PMeta a = s_acc[0];
@@ -153,39 +230,72 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
   for (uint32_t i = threadIdx.x; i < nbins; i += kPartThreads) out[i] = hist[i];
 }
 
-// bins -> partition totals (one thread per partition)
-__global__ void k_part_counts(const uint32_t *__restrict__ binhist, uint32_t nbins, int G, uint32_t bins_per_part,
-                              uint32_t nparts, uint32_t *__restrict__ part_cnt) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= nparts) return;
-  uint64_t s = 0;
-  const uint32_t b0 = p * bins_per_part;
-  const uint32_t b1 = b0 + bins_per_part < nbins ? b0 + bins_per_part : nbins;
-  for (int g = 0; g < G; ++g)
-    for (uint32_t b = b0; b < b1; ++b) s += binhist[(size_t)g * nbins + b];
-  part_cnt[p] = (uint32_t)s;  // v2 requires n_rows < 2^32 (checked on the host)
+// ------------------------------------------------------------------------------------------------
+// offsets: cnt[g][p] (row reduce of the bins) -> column-wise exclusive prefix over g -> part_start[p]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_part_rows(const uint32_t *__restrict__ binhist, uint32_t nbins,
+                                                   uint32_t bins_per_part, uint32_t nparts, uint32_t *__restrict__ cnt) {
+  const uint32_t *row = binhist + (size_t)blockIdx.x * nbins;
+  uint32_t *out = cnt + (size_t)blockIdx.x * nparts;
+  for (uint32_t p = threadIdx.x; p < nparts; p += 256) {
+    const uint32_t b0 = p * bins_per_part;
+    const uint32_t b1 = b0 + bins_per_part < nbins ? b0 + bins_per_part : nbins;
+    uint32_t s = 0;
+    for (uint32_t b = b0; b < b1; ++b) s += row[b];
+    out[p] = s;
+  }
 }
 
-// exclusive offsets per (workgroup, partition): offs[g * nparts + p] = start[p] + sum_{g' < g} cnt[g'][p]
-__global__ void k_part_offsets(const uint32_t *__restrict__ binhist, uint32_t nbins, int G, uint32_t bins_per_part,
-                               uint32_t nparts, const unsigned long long *__restrict__ part_start,
-                               unsigned long long *__restrict__ offs) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+// one thread per partition: offs32[g][p] = sum_{g' < g} cnt[g'][p] (in place), total[p] = column sum
+__global__ __launch_bounds__(256) void k_part_colscan(uint32_t *__restrict__ cnt, int G, uint32_t nparts,
+                                                      uint32_t *__restrict__ total) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= nparts) return;
-  unsigned long long run = part_start[p];
-  const uint32_t b0 = p * bins_per_part;
-  const uint32_t b1 = b0 + bins_per_part < nbins ? b0 + bins_per_part : nbins;
-  for (int g = 0; g < G; ++g) {
-    offs[(size_t)g * nparts + p] = run;
-    uint32_t s = 0;
-    for (uint32_t b = b0; b < b1; ++b) s += binhist[(size_t)g * nbins + b];
-    run += s;
+  uint32_t run = 0;
+  int g = 0;
+  for (; g + 8 <= G; g += 8) {
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = cnt[(size_t)(g + u) * nparts + p];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { cnt[(size_t)(g + u) * nparts + p] = run; run += c[u]; }
   }
+  for (; g < G; ++g) { const uint32_t c = cnt[(size_t)g * nparts + p]; cnt[(size_t)g * nparts + p] = run; run += c; }
+  total[p] = run;  // v2 requires n_rows * 2 < 2^32 (checked on the host)
+}
+
+// single workgroup: exclusive scan of total[0..nparts) into part_start[0..nparts]
+__global__ __launch_bounds__(kPartThreads) void k_part_scan1(const uint32_t *__restrict__ total, uint32_t nparts,
+                                                             unsigned long long *__restrict__ part_start) {
+  __shared__ unsigned long long s_wave[kPartThreads / 64];
+  const uint32_t per = (nparts + kPartThreads - 1) / kPartThreads;
+  const uint32_t b0 = threadIdx.x * per;
+  unsigned long long sum = 0;
+  for (uint32_t j = 0; j < per; ++j)
+    if (b0 + j < nparts) sum += total[b0 + j];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long incl = sum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned long long base = 0, tot = 0;
+  for (int w = 0; w < kPartThreads / 64; ++w) {
+    if (w < wave) base += s_wave[w];
+    tot += s_wave[w];
+  }
+  unsigned long long run = base + incl - sum;
+  for (uint32_t j = 0; j < per; ++j)
+    if (b0 + j < nparts) { part_start[b0 + j] = run; run += total[b0 + j]; }
+  if (threadIdx.x == 0) part_start[nparts] = tot;
 }
 
 // ------------------------------------------------------------------------------------------------
 // pass B — group records by partition through LDS.
-// LDS carve (dynamic): rec[S] (16 B) | hist[F] u32 | off[F+1] u32 | cur[F] u64 | part[S] u16
+// LDS carve (dynamic): val[S] u64 | cp[S] u32 (cell | part << 16) | off[F+1] u32 | gcur[F] u32 | delta[F] u32
+// (record indices fit 32 bits: the host requires rows * keys-per-row < 2^32 for this path)
 // ------------------------------------------------------------------------------------------------
 struct PartArgs {
   const uint64_t *key, *key2;
@@ -197,8 +307,10 @@ struct PartArgs {
   int shift_part;     // partition = key >> shift_part
   uint32_t kp_mask;   // KP - 1
   uint32_t nparts;
-  const unsigned long long *offs;  // [G][nparts]
-  ulonglong2 *recs;   // out: {value, cell}
+  const uint32_t *offs32;                  // [G][nparts] exclusive row prefix of this workgroup inside each partition
+  const unsigned long long *part_start;    // [nparts + 1]
+  unsigned long long *rec_val;             // out: value of each record
+  uint16_t *rec_cell;                      // out: tile-local cell (bucket * KP + key-in-tile), kCellPoison = skip
   DevCounters *ctr;
 };
 
@@ -216,7 +328,7 @@ __device__ __forceinline__ void lds_exclusive_scan(uint32_t *a, uint32_t n, uint
     if (lane >= d) incl += y;
   }
   if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
+  lds_barrier();
   uint32_t base = 0, tot = 0;
   for (int w = 0; w < kPartThreads / 64; ++w) {
     if (w < wave) base += s_wave[w];
@@ -226,94 +338,181 @@ __device__ __forceinline__ void lds_exclusive_scan(uint32_t *a, uint32_t n, uint
   for (uint32_t j = 0; j < per; ++j)
     if (b0 + j < n) { const uint32_t c = a[b0 + j]; a[b0 + j] = run; run += c; }
   if (threadIdx.x == 0) a[n] = tot;
-  __syncthreads();
+  lds_barrier();
 }
 
-template <int RPT, bool HAS2>
+// RPT rows per thread per tile.  VEC: RPT even, columns 16-byte aligned, chunk even -> 16-byte loads
+// (thread owns the row pairs 2*tid, 2*tid+1 of every 2048-row slab).
+// GENERIC = false is the fast path: no time-window filter and a lattice whose bucket is one multiply-high
+// (step == 1 or the 2^32 span case); GENERIC = true evaluates both at run time (64-bit division, t_start loads).
+//
+// Register plan (128 VGPRs at 16 wavefronts per CU): key + time of the NEXT tile are loaded right after
+// phase 1 has consumed the current ones; the value column is only needed in phase 3, so the next tile's values
+// are loaded after phase 3 into the registers phase 3 has just drained.  Every load therefore has two to four
+// LDS phases to land, and nothing is live twice.
+template <int RPT, bool HAS2, bool VEC, bool GENERIC>
 __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr uint32_t S = (uint32_t)RPT * kPartThreads * (HAS2 ? 2 : 1);  // record slots per tile
+  constexpr int NSLOT = RPT * (HAS2 ? 2 : 1);
+  constexpr uint32_t S = (uint32_t)NSLOT * kPartThreads;  // record slots per tile
+  constexpr uint32_t TILE = (uint32_t)RPT * kPartThreads;  // rows per tile
   const uint32_t F = A.nparts;
-  ulonglong2 *rec = reinterpret_cast<ulonglong2 *>(smem);
-  uint32_t *hist = reinterpret_cast<uint32_t *>(smem + (size_t)S * 16);
-  uint32_t *off = hist + F;
-  unsigned long long *cur = reinterpret_cast<unsigned long long *>(off + (F + 1) + 1);  // hist F + off F+1 + 1 pad = even
-  uint16_t *part = reinterpret_cast<uint16_t *>(cur + F);
+  unsigned long long *val = reinterpret_cast<unsigned long long *>(smem);
+  uint32_t *cp = reinterpret_cast<uint32_t *>(smem + (size_t)S * 8);
+  uint32_t *off = cp + S;                 // F + 1 entries (+1 pad keeps delta 8-byte aligned)
+  uint32_t *gcur = off + (F + 1);  // next global record slot of (this workgroup, partition)
+  uint32_t *delta = gcur + F;
   __shared__ uint32_t s_wave[kPartThreads / 64];
 
-  const unsigned long long *my_offs = A.offs + (size_t)blockIdx.x * F;
-  for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) { cur[p] = my_offs[p]; hist[p] = 0; }
-  __syncthreads();
+  // no global load may sit inside the tile loop: vmcnt retires in order, so waiting for one fresh load would
+  // also wait for every prefetched row behind it
+  const uint32_t *my_offs = A.offs32 + (size_t)blockIdx.x * F;
+  for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) { gcur[p] = (uint32_t)A.part_start[p] + my_offs[p]; off[p] = 0; }
 
   const uint64_t lo = (uint64_t)blockIdx.x * A.chunk;
   const uint64_t hi = lo + A.chunk < A.n ? lo + A.chunk : A.n;
+  const bool has_ts = GENERIC && A.t_start != nullptr && A.f.start_time != 0;
+  const uint32_t KP = A.kp_mask + 1u;
   uint32_t err = 0, used = 0;
-  constexpr int NSLOT = RPT * (HAS2 ? 2 : 1);
 
-  for (uint64_t base = lo; base < hi; base += (uint64_t)RPT * kPartThreads) {
-    // ---- phase 1: load rows, make records, rank them inside their partition (LDS atomic) ----
-    uint64_t r_val[NSLOT];
-    uint32_t r_cell[NSLOT], r_part[NSLOT], r_rank[NSLOT];
+  uint64_t pk[RPT], pk2[HAS2 ? RPT : 1], pv[RPT];
+  int64_t pt[RPT];
+  auto row_index = [&](uint64_t base, int j) -> uint64_t {
+    return VEC ? base + (uint64_t)(j >> 1) * (2 * kPartThreads) + 2 * threadIdx.x + (j & 1)
+               : base + (uint64_t)j * kPartThreads + threadIdx.x;
+  };
+  // full tiles: unconditional loads (no per-lane branch anywhere near a load, so hipcc keeps them in flight);
+  // the one ragged tile at the end of the chunk takes the guarded scalar loads.
+  auto load_keys_full = [&](uint64_t base) {
+#pragma unroll
+    for (int j = 0; j < RPT; j += (VEC ? 2 : 1)) {
+      const uint64_t i = row_index(base, j);
+      if (VEC) {
+        const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(A.key + i);
+        const longlong2 t = *reinterpret_cast<const longlong2 *>(A.t_end + i);
+        pk[j] = k.x; pk[j + 1] = k.y; pt[j] = t.x; pt[j + 1] = t.y;
+        if (HAS2) { const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(A.key2 + i); pk2[j] = k2.x; pk2[j + 1] = k2.y; }
+      } else {
+        pk[j] = A.key[i]; pt[j] = A.t_end[i];
+        if (HAS2) pk2[j] = A.key2[i];
+      }
+    }
+  };
+  auto load_values_full = [&](uint64_t base) {
+#pragma unroll
+    for (int j = 0; j < RPT; j += (VEC ? 2 : 1)) {
+      const uint64_t i = row_index(base, j);
+      if (VEC) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(A.value + i);
+        pv[j] = v.x; pv[j + 1] = v.y;
+      } else {
+        pv[j] = A.value[i];
+      }
+    }
+  };
+  auto load_keys_tail = [&](uint64_t base) {
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-      const uint64_t i = base + (uint64_t)j * kPartThreads + threadIdx.x;
-      uint64_t k1 = TAD_KEY_SKIP, k2 = TAD_KEY_SKIP, v = 0;
-      int64_t te = 0;
-      bool kept = false;
-      if (i < hi) {
-        k1 = A.key[i];
-        te = A.t_end[i];
-        v = A.value[i];
-        if (HAS2) k2 = A.key2[i];
-        kept = p_row_kept(te, A.t_start, i, A.f);
+      const uint64_t i = row_index(base, j);
+      const bool in = i < hi;
+      pk[j] = in ? A.key[i] : TAD_KEY_SKIP;
+      pt[j] = in ? A.t_end[i] : 0;
+      if (HAS2) pk2[j] = in ? A.key2[i] : TAD_KEY_SKIP;
+    }
+  };
+  auto load_values_tail = [&](uint64_t base) {
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const uint64_t i = row_index(base, j);
+      pv[j] = i < hi ? A.value[i] : 0;
+    }
+  };
+  const uint64_t nfull = hi > lo ? (hi - lo) / TILE : 0;
+  const uint64_t ntiles = hi > lo ? (hi - lo + TILE - 1) / TILE : 0;
+  if (ntiles) {
+    if (nfull) { load_keys_full(lo); load_values_full(lo); }
+    else { load_keys_tail(lo); load_values_tail(lo); }
+  }
+  lds_barrier();
+
+  for (uint64_t tile = 0; tile < ntiles; ++tile) {
+    const uint64_t base = lo + tile * TILE;
+    const int next_kind = tile + 1 < nfull ? 1 : (tile + 1 < ntiles ? 2 : 0);  // workgroup-uniform
+    // ---- phase 1: partition + tile-local cell of every row, ranked inside its partition (LDS atomic) ----
+    uint32_t r_cp[NSLOT], r_rank[NSLOT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int64_t te = pt[j];
+      bool kept = true;
+      if (GENERIC && (A.f.end_time != 0 || has_ts)) {
+        const uint64_t i = row_index(base, j);
+        const int64_t ts = (has_ts && i < hi) ? A.t_start[i] : 0;
+        kept = p_time_kept(te, ts, has_ts, A.f);
+      }
+      uint32_t bucket = 0;
+      bool on_lattice;
+      if (GENERIC) {
+        on_lattice = p_bucket(A.L, te, bucket);
+      } else {  // mode 0 or 1: one multiply-high
+        const uint64_t d = (uint64_t)te - (uint64_t)A.L.t0;
+        const uint64_t bq = A.L.mode == 0 ? d : __umul64hi(d, A.L.magic);
+        on_lattice = (d >> 32) == 0 && bq < A.L.nb && bq * (uint64_t)A.L.step == d;
+        bucket = (uint32_t)bq;
       }
 #pragma unroll
       for (int h = 0; h < (HAS2 ? 2 : 1); ++h) {
         const int slot = j * (HAS2 ? 2 : 1) + h;
-        const uint64_t k = h == 0 ? k1 : k2;
-        r_part[slot] = 0xFFFFFFFFu;
-        r_val[slot] = v;
-        r_cell[slot] = kCellPoison;
+        const uint64_t k = h == 0 ? pk[j] : pk2[HAS2 ? j : 0];
+        r_cp[slot] = 0xFFFFFFFFu;
         r_rank[slot] = 0;
         if (kept && k != TAD_KEY_SKIP && k < A.K) {  // same predicate as pass A: the slot is reserved
-          uint64_t bucket;
-          if (p_bucket(A.L, te, bucket)) {
-            r_cell[slot] = (uint32_t)bucket * (A.kp_mask + 1u) + ((uint32_t)k & A.kp_mask);
+          uint32_t cell = kCellPoison;
+          if (on_lattice) {
+            cell = bucket * KP + ((uint32_t)k & A.kp_mask);
             used++;
           } else {
-            err |= DEV_ERR_OFF_LATTICE;  // only possible with a wrong caller-supplied lattice hint
+            err |= DEV_ERR_OFF_LATTICE;  // wrong lattice hint, or the sampled gcd missed a residue: host re-derives
           }
           const uint32_t p = (uint32_t)(k >> A.shift_part);
-          r_part[slot] = p;
-          r_rank[slot] = atomicAdd(&hist[p], 1u);
+          r_cp[slot] = cell | (p << 16);
+          r_rank[slot] = atomicAdd(&off[p], 1u);
         }
       }
     }
-    __syncthreads();
-    // ---- phase 2: exclusive scan of the tile's partition histogram ----
-    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) off[p] = hist[p];
-    __syncthreads();
+    if (next_kind == 1) load_keys_full(base + TILE);  // lands during phases 2-4
+    else if (next_kind == 2) load_keys_tail(base + TILE);
+    lds_barrier();
+    // ---- phase 2: exclusive scan of the tile's partition histogram (in place) ----
     lds_exclusive_scan(off, F, s_wave);
-    // ---- phase 3: place the records in partition order ----
+    // ---- phase 3: place the records in partition order; per-partition global destination ----
 #pragma unroll
     for (int slot = 0; slot < NSLOT; ++slot) {
-      if (r_part[slot] != 0xFFFFFFFFu) {
-        const uint32_t pos = off[r_part[slot]] + r_rank[slot];
-        rec[pos] = make_ulonglong2(r_val[slot], (unsigned long long)r_cell[slot]);
-        part[pos] = (uint16_t)r_part[slot];
+      if (r_cp[slot] != 0xFFFFFFFFu) {
+        const uint32_t pos = off[r_cp[slot] >> 16] + r_rank[slot];
+        val[pos] = pv[slot / (HAS2 ? 2 : 1)];
+        cp[pos] = r_cp[slot];
       }
     }
-    __syncthreads();
+    if (next_kind == 1) load_values_full(base + TILE);  // needed again only in the next tile's phase 3
+    else if (next_kind == 2) load_values_tail(base + TILE);
+    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
+      const uint32_t o = off[p], c = off[p + 1] - o;
+      const uint32_t gc = gcur[p];
+      delta[p] = gc - o;  // global slot of the partition's first record of this tile, minus its tile position
+      gcur[p] = gc + c;
+    }
+    lds_barrier();
     // ---- phase 4: copy the runs out (consecutive lanes -> consecutive records of one partition) ----
     const uint32_t total = off[F];
     for (uint32_t idx = threadIdx.x; idx < total; idx += kPartThreads) {
-      const uint32_t p = part[idx];
-      A.recs[cur[p] + (idx - off[p])] = rec[idx];
+      const uint32_t c = cp[idx];
+      const uint32_t dst = delta[c >> 16] + idx;
+      A.rec_val[dst] = val[idx];
+      A.rec_cell[dst] = (uint16_t)(c & 0xFFFFu);
     }
-    __syncthreads();
-    // ---- phase 5: advance the cursors, clear the histogram ----
-    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) { cur[p] += hist[p]; hist[p] = 0; }
-    __syncthreads();
+    lds_barrier();
+    for (uint32_t p = threadIdx.x; p <= F; p += kPartThreads) off[p] = 0;
+    lds_barrier();
   }
   unsigned long long u = used;
   for (int d = 32; d >= 1; d >>= 1) { u += __shfl_down(u, d); err |= __shfl_down(err, d); }
@@ -324,16 +523,30 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass C — one workgroup per partition: aggregate its records in an LDS tile, write the tile out.
+// pass C — one workgroup per partition: aggregate its records in an LDS tile, write the tile out, and
+// (STATS) compute the per-key stddev_samp / EWMA anomaly count from the LDS tile on the side.
 // LDS carve: vals[KP*T] u64 | flags[KP*T] u8
+// STATS: 0 none, 1 n + sigma (+ mean, M2), 2 also the EWMA anomaly count.
+// The per-key arithmetic is the same sequence of FP64 operations as tad_kernels.hip:k_key_sigma.
 // ------------------------------------------------------------------------------------------------
-template <bool OPMAX>
-__global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const ulonglong2 *__restrict__ recs,
+struct KeyStatsOut {
+  const double *rcp;  // rcp[n] = RN(1 / n), n = 0..T (tad_internal.h:div_by_count)
+  double *sigma;
+  uint32_t *n_pts, *n_anom;
+  double *key_mean, *key_m2;
+  DevCounters *ctr;
+  double alpha;
+};
+
+template <bool OPMAX, int STATS>
+__global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ rec_val,
+                                                                 const uint16_t *__restrict__ rec_cell,
                                                                  const unsigned long long *__restrict__ part_start,
-                                                                 int shift_part, Grid g) {
+                                                                 int shift_part, Grid g, KeyStatsOut ks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t KP = 1u << shift_part;
-  const uint32_t cells = KP * (uint32_t)g.T;
+  const uint32_t T = (uint32_t)g.T;
+  const uint32_t cells = KP * T;
   unsigned long long *vals = reinterpret_cast<unsigned long long *>(smem);
   uint8_t *flags = smem + (size_t)cells * 8;
   for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
@@ -341,22 +554,113 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const ulonglong
   __syncthreads();
   const uint32_t p = blockIdx.x;
   const unsigned long long lo = part_start[p], hi = part_start[p + 1];
-  for (unsigned long long i = lo + threadIdx.x; i < hi; i += kPartThreads) {
-    const ulonglong2 r = recs[i];
-    const uint32_t c = (uint32_t)r.y;
+  constexpr int U = 8;
+  unsigned long long i = lo + threadIdx.x;
+  for (; i + (U - 1) * kPartThreads < hi; i += U * kPartThreads) {
+    unsigned long long v[U];
+    uint32_t c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { v[u] = rec_val[i + u * kPartThreads]; c[u] = rec_cell[i + u * kPartThreads]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (c[u] == kCellPoison) continue;
+      if (OPMAX) atomicMax(&vals[c[u]], v[u]);
+      else atomicAdd(&vals[c[u]], v[u]);
+      flags[c[u]] = FLAG_PRESENT;
+    }
+  }
+  for (; i < hi; i += kPartThreads) {
+    const unsigned long long v = rec_val[i];
+    const uint32_t c = rec_cell[i];
     if (c == kCellPoison) continue;
-    if (OPMAX) atomicMax(&vals[c], r.x);
-    else atomicAdd(&vals[c], r.x);
+    if (OPMAX) atomicMax(&vals[c], v);
+    else atomicAdd(&vals[c], v);
     flags[c] = FLAG_PRESENT;
   }
   __syncthreads();
   const uint64_t k0 = (uint64_t)p << shift_part;
-  for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {
-    const uint32_t b = c >> shift_part, kk = c & (KP - 1);
+  const uint32_t stat_waves = STATS ? (KP + 63) / 64 : 0;  // KP <= 2^16 / T; plan keeps stat_waves < 16
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (STATS && wave < stat_waves) {
+    const uint32_t kk = wave * 64 + lane;
     const uint64_t k = k0 + kk;
-    if (k < g.K) {
-      g.val[(uint64_t)b * g.K + k] = vals[c];
-      g.flag[(uint64_t)b * g.K + k] = flags[c];
+    unsigned long long my_pts = 0;
+    unsigned my_key = 0;
+    if (kk < KP && k < g.K) {
+      double cnt = 0.0, avg = 0.0, m2 = 0.0;
+      uint32_t n = 0;
+      auto wstep = [&](uint8_t fl, unsigned long long raw) {
+        if (fl & FLAG_PRESENT) {
+          const double x = (double)raw;
+          cnt = cnt + 1.0;
+          n++;
+          const double d = x - avg;
+          const double dn = div_by_count(d, cnt, ks.rcp[n]);  // == d / cnt, bit for bit
+          avg = avg + dn;
+          m2 = m2 + d * (d - dn);
+        }
+      };
+      uint32_t b = 0;
+      for (; b + 8 <= T; b += 8) {  // LDS reads hoisted off the dependency chain
+        uint8_t fl[8];
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { fl[u] = flags[(b + u) * KP + kk]; v[u] = vals[(b + u) * KP + kk]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wstep(fl[u], v[u]);
+      }
+      for (; b < T; ++b) wstep(flags[b * KP + kk], vals[b * KP + kk]);
+      const bool has_sigma = n >= 2;
+      const double sg = has_sigma ? sqrt(m2 / (cnt - 1.0)) : 0.0;
+      ks.sigma[k] = sg;
+      ks.n_pts[k] = n;
+      if (ks.key_mean != nullptr) { ks.key_mean[k] = avg; ks.key_m2[k] = m2; }
+      my_pts = n;
+      my_key = n > 0;
+      if (STATS == 2) {
+        uint32_t a = 0;
+        if (has_sigma) {
+          const double one_minus = 1.0 - ks.alpha;
+          double e = 0.0;
+          auto estep = [&](uint8_t fl, unsigned long long raw) {
+            if (fl & FLAG_PRESENT) {
+              const double x = (double)raw;
+              e = one_minus * e + ks.alpha * x;
+              a += fabs(x - e) > sg ? 1u : 0u;
+            }
+          };
+          uint32_t b2 = 0;
+          for (; b2 + 8 <= T; b2 += 8) {
+            uint8_t fl[8];
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { fl[u] = flags[(b2 + u) * KP + kk]; v[u] = vals[(b2 + u) * KP + kk]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) estep(fl[u], v[u]);
+          }
+          for (; b2 < T; ++b2) estep(flags[b2 * KP + kk], vals[b2 * KP + kk]);
+        }
+        ks.n_anom[k] = a;
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      my_pts += __shfl_down(my_pts, d);
+      my_key += __shfl_down(my_key, d);
+    }
+    if (lane == 0 && my_key) {
+      atomicAdd(&ks.ctr->n_points, my_pts);
+      atomicAdd(&ks.ctr->n_keys, (unsigned long long)my_key);
+    }
+  } else {
+    // the other wavefronts write the tile: consecutive lanes -> consecutive keys of one bucket
+    const uint32_t nw = kPartThreads / 64 - stat_waves;
+    for (uint32_t c = (wave - stat_waves) * 64 + lane; c < cells; c += nw * 64) {
+      const uint32_t b = c >> shift_part, kk = c & (KP - 1);
+      const uint64_t k = k0 + kk;
+      if (k < g.K) {
+        g.val[(uint64_t)b * g.K + k] = vals[c];
+        g.flag[(uint64_t)b * g.K + k] = flags[c];
+      }
     }
   }
 }
@@ -367,101 +671,129 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const ulonglong
 
 static constexpr uint32_t kMaxBins = 16384;
 
-bool part_plan_bins(uint64_t n, uint64_t K, PartPlan *pl) {
-  if (K == 0 || n == 0 || n >= (1ull << 32)) return false;
+bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl) {
+  if (K == 0 || n == 0 || n * (has2 ? 2 : 1) >= (1ull << 32)) return false;
   int s = 0;
   while (((K + (1ull << s) - 1) >> s) > kMaxBins) ++s;
   pl->shift_bin = s;
   pl->nbins = (uint32_t)((K + (1ull << s) - 1) >> s);
   pl->G = 256;  // one workgroup per CU for passes A and B
   uint64_t chunk = (n + pl->G - 1) / pl->G;
+  chunk = (chunk + 1) & ~1ull;  // even: 16-byte loads stay aligned in every workgroup
   pl->chunk = chunk;
   return true;
 }
 
 bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
-  if (T == 0 || T >= (1ull << 31)) return false;
-  // largest power-of-two key tile whose KP x T (u64 + flag byte) fits in LDS
+  if (T == 0 || T >= (1ull << 16)) return false;
+  // largest power-of-two key tile whose KP x T (u64 + flag byte) fits in LDS and whose cells fit 16 bits
   int sp = -1;
-  for (int c = 16; c >= pl->shift_bin; --c)
-    if (((uint64_t)T << c) * 9 + 16 <= kLdsBudget && ((uint64_t)T << c) < (1ull << 31)) { sp = c; break; }
+  for (int c = 15; c >= pl->shift_bin; --c)
+    if (((uint64_t)T << c) * 9 + 16 <= kLdsBudget && ((uint64_t)T << c) < 0xFFFFull && (1ull << c) <= 15 * 64) { sp = c; break; }
   if (sp < 0) return false;
   while (sp > pl->shift_bin && (1ull << (sp - 1)) >= K) --sp;  // no wider than the key space
   pl->shift_part = sp;
   pl->KP = 1u << sp;
   pl->nparts = (uint32_t)((K + pl->KP - 1) >> sp);
-  if (pl->nparts > 65535) return false;  // part[] is u16
+  if (pl->nparts > 65535) return false;  // the partition id travels in 16 bits
   pl->bins_per_part = 1u << (sp - pl->shift_bin);
   pl->agg_lds = ((size_t)pl->KP * T * 9 + 15) & ~(size_t)15;
-  // pass B: records per tile limited by LDS
-  const size_t fixed = (size_t)pl->nparts * 4 + ((size_t)pl->nparts + 2) * 4 + (size_t)pl->nparts * 8 + 64;
+  // pass B: records per tile limited by LDS: 12 B per slot + 12 B per partition
+  const size_t fixed = ((size_t)pl->nparts + 4) * 12 + 64;
   pl->rpt = 0;
   const int mult = has2 ? 2 : 1;
-  for (int r : {6, 4, 2, 1}) {
+  const char *rpt_env = getenv("TAD_RPT");  // tuning knob: cap the rows per thread of pass B
+  const int rpt_cap = rpt_env ? atoi(rpt_env) : 10;
+  for (int r : {10, 8, 4, 2}) {
+    if (r > rpt_cap && r > 2) continue;
     const size_t slots = (size_t)r * kPartThreads * mult;
-    if (slots * 18 + fixed <= kLdsBudget) { pl->rpt = r; pl->part_lds = (slots * 18 + fixed + 15) & ~(size_t)15; break; }
+    if (slots * 12 + fixed <= kLdsBudget) { pl->rpt = r; pl->part_lds = (slots * 12 + fixed + 15) & ~(size_t)15; break; }
   }
   return pl->rpt != 0;
 }
 
+static bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, uint64_t n, uint64_t K, RowFilter f, const PartPlan &pl,
                       MetaPartial *partials, uint32_t *binhist, DevCounters *ctr) {
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_meta_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget); attr = true; }
-  hipLaunchKernelGGL(k_meta_hist, dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n,
-                     pl.chunk, K, f, pl.shift_bin, pl.nbins, partials, binhist, ctr);
+  const bool vec = aligned16(key) && aligned16(key2) && aligned16(t_end);
+  const bool has2 = key2 != nullptr;
+#define TAD_MH(V, H2)                                                                                                  \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_meta_hist<V, H2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget); attr = true; } \
+    hipLaunchKernelGGL((k_meta_hist<V, H2>), dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n, \
+                       pl.chunk, K, f, pl.shift_bin, pl.nbins, partials, binhist, ctr);                                \
+  } while (0)
+  if (vec) { if (has2) TAD_MH(true, true); else TAD_MH(true, false); }
+  else { if (has2) TAD_MH(false, true); else TAD_MH(false, false); }
+#undef TAD_MH
 }
 
-void launch_part_counts(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *part_cnt) {
-  hipLaunchKernelGGL(k_part_counts, dim3((pl.nparts + 255) / 256), dim3(256), 0, s, binhist, pl.nbins, pl.G, pl.bins_per_part,
-                     pl.nparts, part_cnt);
-}
-
-void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, const unsigned long long *part_start,
-                         unsigned long long *offs) {
-  hipLaunchKernelGGL(k_part_offsets, dim3((pl.nparts + 255) / 256), dim3(256), 0, s, binhist, pl.nbins, pl.G, pl.bins_per_part,
-                     pl.nparts, part_start, offs);
+void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
+                         unsigned long long *part_start) {
+  hipLaunchKernelGGL(k_part_rows, dim3(pl.G), dim3(256), 0, s, binhist, pl.nbins, pl.bins_per_part, pl.nparts, offs32);
+  hipLaunchKernelGGL(k_part_colscan, dim3((pl.nparts + 255) / 256), dim3(256), 0, s, offs32, pl.G, pl.nparts, total);
+  hipLaunchKernelGGL(k_part_scan1, dim3(1), dim3(kPartThreads), 0, s, total, pl.nparts, part_start);
 }
 
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, Lattice L,
-                      const PartPlan &pl, const unsigned long long *offs, void *recs, DevCounters *ctr) {
+                      const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start, void *rec_val,
+                      void *rec_cell, DevCounters *ctr) {
   PartArgs A;
   A.key = key; A.key2 = key2; A.t_end = t_end; A.t_start = t_start; A.value = value;
   A.n = n; A.chunk = pl.chunk; A.K = K; A.f = f; A.L = L;
   A.shift_part = pl.shift_part; A.kp_mask = pl.KP - 1; A.nparts = pl.nparts;
-  A.offs = offs; A.recs = static_cast<ulonglong2 *>(recs); A.ctr = ctr;
+  A.offs32 = offs32; A.part_start = part_start;
+  A.rec_val = static_cast<unsigned long long *>(rec_val); A.rec_cell = static_cast<uint16_t *>(rec_cell); A.ctr = ctr;
   const bool has2 = key2 != nullptr;
-#define TAD_PART(RPT, H2)                                                                                             \
+  const bool vec = aligned16(key) && aligned16(key2) && aligned16(t_end) && aligned16(value);
+  // fast path: 16-byte loads, no time-window filter, bucket by one multiply-high
+  const bool generic = !vec || L.mode == 2 || f.end_time != 0 || (f.start_time != 0 && t_start != nullptr);
+  int rpt = pl.rpt;
+  if (generic && rpt > 4) rpt = 4;
+  const size_t fixed = ((size_t)pl.nparts + 4) * 12 + 64;
+  const size_t lds = ((size_t)rpt * kPartThreads * (has2 ? 2 : 1) * 12 + fixed + 15) & ~(size_t)15;
+#define TAD_PART(RPT, H2, V, GEN)                                                                                       \
   do {                                                                                                                \
     static bool attr = false;                                                                                         \
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_partition<RPT, H2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget); attr = true; } \
-    hipLaunchKernelGGL((k_partition<RPT, H2>), dim3(pl.G), dim3(kPartThreads), pl.part_lds, s, A);                     \
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_partition<RPT, H2, V, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget); attr = true; } \
+    hipLaunchKernelGGL((k_partition<RPT, H2, V, GEN>), dim3(pl.G), dim3(kPartThreads), lds, s, A);                       \
   } while (0)
-  switch (pl.rpt) {
-    case 6: if (has2) TAD_PART(6, true); else TAD_PART(6, false); break;
-    case 4: if (has2) TAD_PART(4, true); else TAD_PART(4, false); break;
-    case 2: if (has2) TAD_PART(2, true); else TAD_PART(2, false); break;
-    default: if (has2) TAD_PART(1, true); else TAD_PART(1, false); break;
+  if (!generic) {
+    switch (rpt) {
+      case 10: if (has2) TAD_PART(8, true, true, false); else TAD_PART(10, false, true, false); break;
+      case 8: if (has2) TAD_PART(8, true, true, false); else TAD_PART(8, false, true, false); break;
+      case 6: case 4: if (has2) TAD_PART(4, true, true, false); else TAD_PART(4, false, true, false); break;
+      default: if (has2) TAD_PART(2, true, true, false); else TAD_PART(2, false, true, false); break;
+    }
+  } else if (vec) {
+    if (rpt >= 4) { if (has2) TAD_PART(4, true, true, true); else TAD_PART(4, false, true, true); }
+    else { if (has2) TAD_PART(2, true, true, true); else TAD_PART(2, false, true, true); }
+  } else {
+    if (rpt >= 4) { if (has2) TAD_PART(4, true, false, true); else TAD_PART(4, false, false, true); }
+    else { if (has2) TAD_PART(2, true, false, true); else TAD_PART(2, false, false, true); }
   }
 #undef TAD_PART
 }
 
-void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
-                           Grid g, bool op_max) {
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    attr = true;
-  }
-  if (op_max)
-    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(pl.nparts), dim3(kPartThreads), pl.agg_lds, s,
-                       static_cast<const ulonglong2 *>(recs), part_start, pl.shift_part, g);
-  else
-    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(pl.nparts), dim3(kPartThreads), pl.agg_lds, s,
-                       static_cast<const ulonglong2 *>(recs), part_start, pl.shift_part, g);
+void launch_tile_aggregate(hipStream_t s, const void *rec_val, const void *rec_cell, const unsigned long long *part_start,
+                           const PartPlan &pl, Grid g, bool op_max, int stats, double alpha, const double *rcp, double *sigma,
+                           uint32_t *n_pts, uint32_t *n_anom, double *key_mean, double *key_m2, DevCounters *ctr) {
+  KeyStatsOut ks{rcp, sigma, n_pts, n_anom, key_mean, key_m2, ctr, alpha};
+  const unsigned long long *rv = static_cast<const unsigned long long *>(rec_val);
+  const uint16_t *rc = static_cast<const uint16_t *>(rec_cell);
+#define TAD_AGG(OPM, ST)                                                                                              \
+  do {                                                                                                                \
+    static bool attr = false;                                                                                         \
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<OPM, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget); attr = true; } \
+    hipLaunchKernelGGL((k_tile_aggregate<OPM, ST>), dim3(pl.nparts), dim3(kPartThreads), pl.agg_lds, s, rv, rc, part_start, pl.shift_part, g, ks); \
+  } while (0)
+  if (op_max) { if (stats == 2) TAD_AGG(true, 2); else if (stats == 1) TAD_AGG(true, 1); else TAD_AGG(true, 0); }
+  else { if (stats == 2) TAD_AGG(false, 2); else if (stats == 1) TAD_AGG(false, 1); else TAD_AGG(false, 0); }
+#undef TAD_AGG
 }
 
 }  // namespace tad
