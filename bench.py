@@ -12,10 +12,13 @@ N>1 (torchrun, one rank per GPU): weak scaling — every rank owns the key shard
 per step one RCCL all-reduce of [anomalies, keys, points, rows] (the global `count() == 0` sentinel
 decision, anomaly_detection.py:395) and one all-gather of the (n, mean, M2) moments (global sigma).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the Stage-0 scatter):
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (Stage-0 pass B, k_partition):
 achieved = 24 B/row x rows per launch / the kernel's average duration measured with HIP events on the
-engine's stream (tad_stats.ms_scatter).  `cpu_baseline` = the oracle (numpy port of the reference
-job) timed on this box's host cores on a bounded sample.
+engine's stream (tad_stats.ms_scatter); `traffic` = that kernel's HBM bytes per launch from the committed
+rocprofv3 PMC passes (profiles/pmc_latest.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE;
+separate --pmc runs of this same command).  `cpu_baseline` = the oracle (numpy port of the reference
+job) timed on this box's host cores on a bounded sample.  The ARIMA line adds `arima`: fits/s and the
+FP64 flop rate from the engine's Kalman-step counter (60 flop per 3-state predict+update).
 """
 import argparse
 import json
@@ -27,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
+FLOP_PER_KALMAN_STEP = 60
 BYTES_PER_ROW = 24      # key_id u64 + flow_end_s i64 + value u64, read once
 BYTES_PER_ANOMALY = 40  # key_id, flow_end_s, throughput, algo_calc, stddev
 
@@ -43,6 +48,18 @@ def cpu_baseline(algo, rows, keys, buckets, agg):
             "sample": "%s, %d rows / %d keys / %d buckets of the same synthetic table (same rows-per-key as the GPU "
                       "workload), numpy oracle single process, %.1f s" % (algo, rows, keys, buckets, dt),
             "anomalies": int(r["n_anomalies"])}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            d = json.load(f)
+        k = d["kernels"][kernel]
+        return {"bytes": k["fetch_bytes"] + k["write_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
+                "source": d["source"]}
+    except Exception:
+        return None
 
 
 def main():
@@ -63,6 +80,7 @@ def main():
     import torch
     import torch.distributed as dist
     from theia_amd import TadEngine
+    from theia_amd import distributed as td
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -84,30 +102,24 @@ def main():
     eng.synth(rank * n, n, K, T, into=(key, tend, val))
     lattice = (1660202814, 60, T) if args.hint_lattice else None
 
-    counters = torch.zeros(4, dtype=torch.int64, device=dev)
-    moments = torch.zeros(3, dtype=torch.float64, device=dev)
-    gathered = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+    reducer = td.JobReducer(device=dev if world > 1 else None)
 
     def step():
         res = eng.run(args.algo, key, tend, val, K, agg_flow=args.agg, lattice=lattice, out="device")
         st = res.stats
-        if world > 1:
-            counters.copy_(torch.tensor([st["n_anomalies"], st["n_keys"], st["n_points"], st["rows_used"]], dtype=torch.int64))
-            moments.copy_(torch.tensor([float(st["n_points"]), st["pts_mean"], st["pts_m2"]], dtype=torch.float64))
-            dist.all_reduce(counters)                 # RCCL over xGMI: the global sentinel decision
-            dist.all_gather(gathered, moments)        # (n, mean, M2) per shard -> Chan merge below
+        glob = reducer.reduce(st) if world > 1 else None   # RCCL over xGMI: counters all-reduce + moments all-gather
         res.close()
-        return st
+        return st, glob
 
     for _ in range(args.warmup):
-        st = step()
+        st, glob = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     acc = {"ms_meta": 0.0, "ms_stage0": 0.0, "ms_scatter": 0.0, "ms_detect": 0.0, "ms_total": 0.0}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st = step()
+        st, glob = step()
         for f in acc:
             acc[f] += st[f]
     torch.cuda.synchronize()
@@ -118,20 +130,9 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        g_counts = [int(x) for x in counters.tolist()]
-        mn, mean, m2 = 0.0, 0.0, 0.0
-        for g in gathered:
-            bn, bmean, bm2 = (float(x) for x in g.tolist())
-            if bn == 0:
-                continue
-            if mn == 0:
-                mn, mean, m2 = bn, bmean, bm2
-                continue
-            nn, d = mn + bn, bmean - mean
-            mean, m2, mn = mean + d * bn / nn, m2 + bm2 + d * d * mn * bn / nn, nn
     else:
-        g_counts = [st["n_anomalies"], st["n_keys"], st["n_points"], st["rows_used"]]
-        mn, mean, m2 = float(st["n_points"]), st["pts_mean"], st["pts_m2"]
+        glob = td.JobReducer().reduce(st)
+    g_counts = [glob["n_anomalies"], glob["n_keys"], glob["n_points"], glob["rows_used"]]
 
     if rank == 0:
         steps = args.steps
@@ -143,7 +144,7 @@ def main():
             "metric": "flow-records/sec", "value": world * n * steps / dt, "unit": "flow-records/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 aggregates / f64 detectors", "data": "synthetic",
+            "dtype": "u64 (aggregates) + f64 (detectors)", "data": "synthetic",
             "config": {"workload": "%s detector, %d rows / %d flow keys / %d time buckets per GPU, sum(throughput) (agg_flow=%s), "
                                    "deterministic synthetic flow table (SURVEY.md 8d), inputs and outputs resident in HBM"
                                    % (args.algo, n, K, T, args.agg),
@@ -157,8 +158,16 @@ def main():
                          "ms_detect_and_emit": acc["ms_detect"] / steps, "ms_device_total": acc["ms_total"] / steps,
                          "hbm_frac_whole_job": (BYTES_PER_ROW * n + BYTES_PER_ANOMALY * A) / (acc["ms_total"] / steps * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "result": {"anomalies": g_counts[0], "keys": g_counts[1], "points": g_counts[2], "rows_used": g_counts[3],
-                       "global_mean": mean, "global_sigma": (m2 / (mn - 1)) ** 0.5 if mn > 1 else None},
+                       "global_mean": glob["global_mean"], "global_sigma": glob["global_sigma"]},
         }
+        out["roofline"]["traffic"] = pmc_traffic("k_partition" if st["stage0_path"] == 2 else "k_scatter")
+        if args.algo == "ARIMA":
+            sec = acc["ms_detect"] / steps * 1e-3
+            flops = FLOP_PER_KALMAN_STEP * st["kalman_steps"]
+            out["arima"] = {"fits_per_launch": st["arima_fits"], "kalman_steps_per_launch": st["kalman_steps"],
+                            "fits_per_s": st["arima_fits"] / sec, "bound": "fp64 vector ALU / dependency latency",
+                            "achieved_tflops": flops / sec / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                            "frac": flops / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "ms_detect": acc["ms_detect"] / steps}
         if world == 1 and not args.no_cpu_baseline:
             crow = min(args.cpu_rows, n)
             ckeys = max(1, int(K * crow / n))
