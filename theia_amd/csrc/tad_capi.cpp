@@ -45,7 +45,7 @@ struct tad_engine {
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
   DevBuf rcp_table;           // rcp_table[n] = RN(1/n), n = 0..rcp_n-1
   uint64_t rcp_n = 0;
-  DevBuf binhist, part_total, part_start, part_offs32, rec_val, rec_cell;  // Stage 0 v2
+  DevBuf binhist, part_total, part_start, part_offs32, recs, ovf;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
@@ -57,6 +57,7 @@ struct tad_engine {
 namespace {
 
 constexpr int kMetaBlocks = 2048;
+constexpr uint32_t kOverflowCap = 1u << 20;  // Stage 0 v2: rows with a value >= 2^49 per run before falling back to v1
 
 int fail(tad_engine *e, int code, const char *fmt, ...) {
   char buf[512];
@@ -221,7 +222,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->rec_val, &e->rec_cell, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -479,11 +480,12 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   const bool force_v1 = s0env && !strcmp(s0env, "v1");
   const bool force_v2 = s0env && !strcmp(s0env, "v2");
   const bool has2 = cols->key_id2 != nullptr;
-  for (int attempt = 0; attempt < 3; ++attempt) {
+  bool force_v1_retry = false;
+  for (int attempt = 0; attempt < 4; ++attempt) {
     const bool hinted = lat_mode == 0;
     HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
     PartPlan pl{};
-    bool v2 = !empty && !force_v1 && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
+    bool v2 = !empty && !force_v1 && !force_v1_retry && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
     if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
     int meta_blocks = 0;
     if (v2) {
@@ -548,8 +550,11 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       if ((rc = ensure(e, e->part_total, (size_t)pl.nparts * 4)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_start, ((size_t)pl.nparts + 1) * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_offs32, (size_t)pl.G * pl.nparts * 4)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->rec_val, (size_t)slots * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->rec_cell, (size_t)slots * 2)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->ovf, 16 + (size_t)kOverflowCap * sizeof(OverflowRec))) != TAD_OK) return rc;
+      unsigned long long *ovf_count = static_cast<unsigned long long *>(e->ovf.p);
+      OverflowRec *ovf = reinterpret_cast<OverflowRec *>(static_cast<unsigned char *>(e->ovf.p) + 16);
+      HIP_TRY(e, hipMemsetAsync(ovf_count, 0, 8, s));
       if ((rc = ensure_key_buffers(e, K)) != TAD_OK) return rc;
       if ((rc = ensure_rcp_table(e, L.nb)) != TAD_OK) return rc;
       uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
@@ -557,18 +562,11 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start);
       HIP_TRY(e, hipEventRecord(e->ev[2], s));
       launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
-                       (const uint64_t *)d_val, n, K, rf, L, pl, offs32, part_start, e->rec_val.p, e->rec_cell.p, ctr);
+                       (const uint64_t *)d_val, n, K, rf, L, pl, offs32, part_start, e->recs.p, ovf, ovf_count, kOverflowCap, ctr);
       HIP_TRY(e, hipEventRecord(e->ev[3], s));
-      // Per-key statistics fused into the tile pass cost more than they save on MI355X (one wavefront per tile walks a
-      // 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do: 2.53 vs 2.44 ms per C2 job),
-      // so the default runs them as their own kernel (k_key_sigma); TAD_FUSE_STATS=1 selects the fused variant.
-      const char *fz = getenv("TAD_FUSE_STATS");
-      const bool fuse = fz && !strcmp(fz, "1");
-      const int stats = !fuse ? 0 : (jp.algo == TAD_ALGO_EWMA && !jp.all_points) ? 2 : 1;
-      launch_tile_aggregate(s, e->rec_val.p, e->rec_cell.p, part_start, pl, g, op_max, stats, jp.alpha, static_cast<const double *>(e->rcp_table.p),
-                            static_cast<double *>(e->sigma.p), static_cast<uint32_t *>(e->n_pts.p), static_cast<uint32_t *>(e->n_anom.p),
-                            static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p), ctr);
-      stats_done = fuse;
+      // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
+      // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
+      launch_tile_aggregate(s, e->recs.p, part_start, pl, g, op_max, ovf, ovf_count, kOverflowCap);
     } else {
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));
@@ -589,6 +587,10 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     const DevCounters c = *e->ctr_host;
     if (c.err & DEV_ERR_KEY_RANGE)
       return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
+    if (c.err & DEV_ERR_OVERFLOW_LIST) {  // more than kOverflowCap values >= 2^49: the packed records do not pay off, use v1
+      if (!force_v1_retry) { force_v1_retry = true; continue; }
+      return fail(e, TAD_ERR_HIP, "internal error: overflow list full on the v1 path");
+    }
     if (c.err & DEV_ERR_OFF_LATTICE) {
       if (lat_mode < 2) { lat_mode = (lat_mode == 0) ? 1 : 2; continue; }  // wrong hint -> derive; sampled gcd too coarse -> exact
       return fail(e, TAD_ERR_HIP, "internal error: a row fell off the derived time lattice");

@@ -27,7 +27,7 @@ struct Grid {
   uint64_t T;               // buckets
 };
 
-enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u };
+enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u };
 enum : uint8_t { FLAG_PRESENT = 1, FLAG_ANOMALY = 2 };
 
 // Per-block partial of the lattice-derivation pass.
@@ -115,6 +115,10 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
 size_t arima_workspace_bytes(Grid g);
 
 // ---- Stage 0 v2: partition rows by key range, aggregate tiles in LDS (tad_stage0_part.hip) ----
+struct OverflowRec {  // a row whose value needs more than 49 bits: applied to the grid after the tile pass
+  unsigned long long val;
+  unsigned long long gcell;  // bucket * K + key
+};
 struct PartPlan {
   int shift_bin;       // pass-A histogram bin = key >> shift_bin
   uint32_t nbins;
@@ -136,11 +140,9 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f,
                       Lattice L, const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start,
-                      void *rec_val, void *rec_cell, DevCounters *ctr);
-// stats: 0 = aggregate only, 1 = also per-key n / sigma / mean / M2 + key and point counters, 2 = also the EWMA count
-void launch_tile_aggregate(hipStream_t s, const void *rec_val, const void *rec_cell, const unsigned long long *part_start,
-                           const PartPlan &pl, Grid g, bool op_max, int stats, double alpha, const double *rcp, double *sigma,
-                           uint32_t *n_pts, uint32_t *n_anom, double *key_mean, double *key_m2, DevCounters *ctr);
+                      void *recs, OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr);
+void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
+                           Grid g, bool op_max, const OverflowRec *ovf, const unsigned long long *ovf_count, uint32_t ovf_cap);
 
 void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                   uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,

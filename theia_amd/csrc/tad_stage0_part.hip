@@ -35,11 +35,16 @@
 namespace tad {
 
 static constexpr int kPartThreads = 1024;
-static constexpr uint32_t kCellPoison = 0xFFFFu;
 
-// A Stage-0 record is {value u64, tile-local cell u16}, kept as two arrays (10 B/row).  Measured on MI355X: the
-// partition pass is bound by the 64-byte write sectors its short runs touch, and 8 B + 2 B arrays (1.07 ms) beat
-// packed 12-byte records written with global_store_dwordx3 (1.19 ms) and the original 16-byte records (1.37 ms).
+// A Stage-0 record is ONE 64-bit word: value << 15 | tile-local cell (15 bits; 0x7FFF = no cell).  Measured on MI355X
+// the partition pass is bound by the 64-byte write sectors its short per-partition runs touch, so bytes per record
+// are what matters: 8-byte records beat {u64 value, u16 cell} arrays (10 B), packed 12-byte and the original 16-byte
+// records.  A value >= 2^49 does not fit: it goes, with its GLOBAL cell, to a small overflow list (global atomic
+// append) that k_apply_overflow folds into the grid after the tile pass — same associative integer operator, so the
+// aggregates stay bit-exact for the full UInt64 range.  If the list overflows the host falls back to Stage 0 v1.
+static constexpr uint32_t kCellBits = 15;
+static constexpr uint32_t kCellNone = 0x7FFFu;
+static constexpr unsigned long long kValueLimit = 1ull << (64 - kCellBits);
 static constexpr size_t kLdsBudget = 156 * 1024;  // dynamic LDS per workgroup; the rest of the CU's 160 KiB is for static __shared__
 static constexpr int kGcdSamples = 4;
 
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scan1(const uint32_t *__r
 
 // ------------------------------------------------------------------------------------------------
 // pass B — group records by partition through LDS.
-// LDS carve (dynamic): val[S] u64 | cp[S] u32 (cell | part << 16) | off[F+1] u32 | gcur[F] u32 | delta[F] u32
+// LDS carve (dynamic): rec[S] u64 | part[S] u16 | off[F+1] u32 | gcur[F] u32 | delta[F] u32
 // (record indices fit 32 bits: the host requires rows * keys-per-row < 2^32 for this path)
 // ------------------------------------------------------------------------------------------------
 struct PartArgs {
@@ -309,8 +314,10 @@ struct PartArgs {
   uint32_t nparts;
   const uint32_t *offs32;                  // [G][nparts] exclusive row prefix of this workgroup inside each partition
   const unsigned long long *part_start;    // [nparts + 1]
-  unsigned long long *rec_val;             // out: value of each record
-  uint16_t *rec_cell;                      // out: tile-local cell (bucket * KP + key-in-tile), kCellPoison = skip
+  unsigned long long *recs;                // out: value << 15 | tile-local cell (bucket * KP + key-in-tile)
+  OverflowRec *ovf;                        // out: records whose value needs more than 49 bits
+  unsigned long long *ovf_count;
+  uint32_t ovf_cap;
   DevCounters *ctr;
 };
 
@@ -357,9 +364,9 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
   constexpr uint32_t S = (uint32_t)NSLOT * kPartThreads;  // record slots per tile
   constexpr uint32_t TILE = (uint32_t)RPT * kPartThreads;  // rows per tile
   const uint32_t F = A.nparts;
-  unsigned long long *val = reinterpret_cast<unsigned long long *>(smem);
-  uint32_t *cp = reinterpret_cast<uint32_t *>(smem + (size_t)S * 8);
-  uint32_t *off = cp + S;                 // F + 1 entries (+1 pad keeps delta 8-byte aligned)
+  unsigned long long *rec = reinterpret_cast<unsigned long long *>(smem);
+  uint16_t *part = reinterpret_cast<uint16_t *>(smem + (size_t)S * 8);
+  uint32_t *off = reinterpret_cast<uint32_t *>(smem + (size_t)S * 10);  // F + 1 entries
   uint32_t *gcur = off + (F + 1);  // next global record slot of (this workgroup, partition)
   uint32_t *delta = gcur + F;
   __shared__ uint32_t s_wave[kPartThreads / 64];
@@ -466,10 +473,16 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
         r_cp[slot] = 0xFFFFFFFFu;
         r_rank[slot] = 0;
         if (kept && k != TAD_KEY_SKIP && k < A.K) {  // same predicate as pass A: the slot is reserved
-          uint32_t cell = kCellPoison;
+          uint32_t cell = kCellNone;
           if (on_lattice) {
-            cell = bucket * KP + ((uint32_t)k & A.kp_mask);
             used++;
+            if (pv[j] < kValueLimit) {
+              cell = bucket * KP + ((uint32_t)k & A.kp_mask);
+            } else {  // rare: the value needs more than 49 bits -> overflow list, the stream slot stays empty
+              const unsigned long long o = atomicAdd(A.ovf_count, 1ull);
+              if (o < A.ovf_cap) { A.ovf[o].val = pv[j]; A.ovf[o].gcell = (unsigned long long)bucket * A.K + k; }
+              else err |= DEV_ERR_OVERFLOW_LIST;
+            }
           } else {
             err |= DEV_ERR_OFF_LATTICE;  // wrong lattice hint, or the sampled gcd missed a residue: host re-derives
           }
@@ -489,8 +502,8 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     for (int slot = 0; slot < NSLOT; ++slot) {
       if (r_cp[slot] != 0xFFFFFFFFu) {
         const uint32_t pos = off[r_cp[slot] >> 16] + r_rank[slot];
-        val[pos] = pv[slot / (HAS2 ? 2 : 1)];
-        cp[pos] = r_cp[slot];
+        rec[pos] = (pv[slot / (HAS2 ? 2 : 1)] << kCellBits) | (r_cp[slot] & kCellNone);
+        part[pos] = (uint16_t)(r_cp[slot] >> 16);
       }
     }
     if (next_kind == 1) load_values_full(base + TILE);  // needed again only in the next tile's phase 3
@@ -505,10 +518,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     // ---- phase 4: copy the runs out (consecutive lanes -> consecutive records of one partition) ----
     const uint32_t total = off[F];
     for (uint32_t idx = threadIdx.x; idx < total; idx += kPartThreads) {
-      const uint32_t c = cp[idx];
-      const uint32_t dst = delta[c >> 16] + idx;
-      A.rec_val[dst] = val[idx];
-      A.rec_cell[dst] = (uint16_t)(c & 0xFFFFu);
+      A.recs[delta[part[idx]] + idx] = rec[idx];
     }
     lds_barrier();
     for (uint32_t p = threadIdx.x; p <= F; p += kPartThreads) off[p] = 0;
@@ -523,26 +533,13 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass C — one workgroup per partition: aggregate its records in an LDS tile, write the tile out, and
-// (STATS) compute the per-key stddev_samp / EWMA anomaly count from the LDS tile on the side.
+// pass C — one workgroup per partition: aggregate its records in an LDS tile, write the tile out.
 // LDS carve: vals[KP*T] u64 | flags[KP*T] u8
-// STATS: 0 none, 1 n + sigma (+ mean, M2), 2 also the EWMA anomaly count.
-// The per-key arithmetic is the same sequence of FP64 operations as tad_kernels.hip:k_key_sigma.
 // ------------------------------------------------------------------------------------------------
-struct KeyStatsOut {
-  const double *rcp;  // rcp[n] = RN(1 / n), n = 0..T (tad_internal.h:div_by_count)
-  double *sigma;
-  uint32_t *n_pts, *n_anom;
-  double *key_mean, *key_m2;
-  DevCounters *ctr;
-  double alpha;
-};
-
-template <bool OPMAX, int STATS>
-__global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ rec_val,
-                                                                 const uint16_t *__restrict__ rec_cell,
+template <bool OPMAX>
+__global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
-                                                                 int shift_part, Grid g, KeyStatsOut ks) {
+                                                                 int shift_part, Grid g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t KP = 1u << shift_part;
   const uint32_t T = (uint32_t)g.T;
@@ -554,114 +551,47 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
   __syncthreads();
   const uint32_t p = blockIdx.x;
   const unsigned long long lo = part_start[p], hi = part_start[p + 1];
-  constexpr int U = 8;
-  unsigned long long i = lo + threadIdx.x;
-  for (; i + (U - 1) * kPartThreads < hi; i += U * kPartThreads) {
-    unsigned long long v[U];
-    uint32_t c[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) { v[u] = rec_val[i + u * kPartThreads]; c[u] = rec_cell[i + u * kPartThreads]; }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (c[u] == kCellPoison) continue;
-      if (OPMAX) atomicMax(&vals[c[u]], v[u]);
-      else atomicAdd(&vals[c[u]], v[u]);
-      flags[c[u]] = FLAG_PRESENT;
-    }
-  }
-  for (; i < hi; i += kPartThreads) {
-    const unsigned long long v = rec_val[i];
-    const uint32_t c = rec_cell[i];
-    if (c == kCellPoison) continue;
+  auto apply = [&](unsigned long long r) {
+    const uint32_t c = (uint32_t)r & kCellNone;
+    if (c == kCellNone) return;
+    const unsigned long long v = r >> kCellBits;
     if (OPMAX) atomicMax(&vals[c], v);
     else atomicAdd(&vals[c], v);
     flags[c] = FLAG_PRESENT;
+  };
+  constexpr int U = 8;
+  unsigned long long i = lo + threadIdx.x;
+  for (; i + (U - 1) * kPartThreads < hi; i += U * kPartThreads) {
+    unsigned long long r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = recs[i + u * kPartThreads];
+#pragma unroll
+    for (int u = 0; u < U; ++u) apply(r[u]);
   }
+  for (; i < hi; i += kPartThreads) apply(recs[i]);
   __syncthreads();
   const uint64_t k0 = (uint64_t)p << shift_part;
-  const uint32_t stat_waves = STATS ? (KP + 63) / 64 : 0;  // KP <= 2^16 / T; plan keeps stat_waves < 16
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (STATS && wave < stat_waves) {
-    const uint32_t kk = wave * 64 + lane;
+  for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
+    const uint32_t b = c >> shift_part, kk = c & (KP - 1);
     const uint64_t k = k0 + kk;
-    unsigned long long my_pts = 0;
-    unsigned my_key = 0;
-    if (kk < KP && k < g.K) {
-      double cnt = 0.0, avg = 0.0, m2 = 0.0;
-      uint32_t n = 0;
-      auto wstep = [&](uint8_t fl, unsigned long long raw) {
-        if (fl & FLAG_PRESENT) {
-          const double x = (double)raw;
-          cnt = cnt + 1.0;
-          n++;
-          const double d = x - avg;
-          const double dn = div_by_count(d, cnt, ks.rcp[n]);  // == d / cnt, bit for bit
-          avg = avg + dn;
-          m2 = m2 + d * (d - dn);
-        }
-      };
-      uint32_t b = 0;
-      for (; b + 8 <= T; b += 8) {  // LDS reads hoisted off the dependency chain
-        uint8_t fl[8];
-        unsigned long long v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { fl[u] = flags[(b + u) * KP + kk]; v[u] = vals[(b + u) * KP + kk]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wstep(fl[u], v[u]);
-      }
-      for (; b < T; ++b) wstep(flags[b * KP + kk], vals[b * KP + kk]);
-      const bool has_sigma = n >= 2;
-      const double sg = has_sigma ? sqrt(m2 / (cnt - 1.0)) : 0.0;
-      ks.sigma[k] = sg;
-      ks.n_pts[k] = n;
-      if (ks.key_mean != nullptr) { ks.key_mean[k] = avg; ks.key_m2[k] = m2; }
-      my_pts = n;
-      my_key = n > 0;
-      if (STATS == 2) {
-        uint32_t a = 0;
-        if (has_sigma) {
-          const double one_minus = 1.0 - ks.alpha;
-          double e = 0.0;
-          auto estep = [&](uint8_t fl, unsigned long long raw) {
-            if (fl & FLAG_PRESENT) {
-              const double x = (double)raw;
-              e = one_minus * e + ks.alpha * x;
-              a += fabs(x - e) > sg ? 1u : 0u;
-            }
-          };
-          uint32_t b2 = 0;
-          for (; b2 + 8 <= T; b2 += 8) {
-            uint8_t fl[8];
-            unsigned long long v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { fl[u] = flags[(b2 + u) * KP + kk]; v[u] = vals[(b2 + u) * KP + kk]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) estep(fl[u], v[u]);
-          }
-          for (; b2 < T; ++b2) estep(flags[b2 * KP + kk], vals[b2 * KP + kk]);
-        }
-        ks.n_anom[k] = a;
-      }
+    if (k < g.K) {
+      g.val[(uint64_t)b * g.K + k] = vals[c];
+      g.flag[(uint64_t)b * g.K + k] = flags[c];
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-      my_pts += __shfl_down(my_pts, d);
-      my_key += __shfl_down(my_key, d);
-    }
-    if (lane == 0 && my_key) {
-      atomicAdd(&ks.ctr->n_points, my_pts);
-      atomicAdd(&ks.ctr->n_keys, (unsigned long long)my_key);
-    }
-  } else {
-    // the other wavefronts write the tile: consecutive lanes -> consecutive keys of one bucket
-    const uint32_t nw = kPartThreads / 64 - stat_waves;
-    for (uint32_t c = (wave - stat_waves) * 64 + lane; c < cells; c += nw * 64) {
-      const uint32_t b = c >> shift_part, kk = c & (KP - 1);
-      const uint64_t k = k0 + kk;
-      if (k < g.K) {
-        g.val[(uint64_t)b * g.K + k] = vals[c];
-        g.flag[(uint64_t)b * g.K + k] = flags[c];
-      }
-    }
+  }
+}
+
+// records whose value did not fit the packed form: fold them into the finished grid (agent-scope integer atomics)
+template <bool OPMAX>
+__global__ __launch_bounds__(256) void k_apply_overflow(const OverflowRec *__restrict__ ovf,
+                                                        const unsigned long long *__restrict__ ovf_count, uint32_t cap, Grid g) {
+  unsigned long long n = *ovf_count;
+  if (n > cap) n = cap;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+    const OverflowRec r = ovf[i];
+    if (OPMAX) __hip_atomic_fetch_max(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_add(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g.flag[r.gcell] = FLAG_PRESENT;
   }
 }
 
@@ -689,7 +619,7 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   // largest power-of-two key tile whose KP x T (u64 + flag byte) fits in LDS and whose cells fit 16 bits
   int sp = -1;
   for (int c = 15; c >= pl->shift_bin; --c)
-    if (((uint64_t)T << c) * 9 + 16 <= kLdsBudget && ((uint64_t)T << c) < 0xFFFFull && (1ull << c) <= 15 * 64) { sp = c; break; }
+    if (((uint64_t)T << c) * 9 + 16 <= kLdsBudget && ((uint64_t)T << c) < (uint64_t)kCellNone) { sp = c; break; }
   if (sp < 0) return false;
   while (sp > pl->shift_bin && (1ull << (sp - 1)) >= K) --sp;  // no wider than the key space
   pl->shift_part = sp;
@@ -698,16 +628,16 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   if (pl->nparts > 65535) return false;  // the partition id travels in 16 bits
   pl->bins_per_part = 1u << (sp - pl->shift_bin);
   pl->agg_lds = ((size_t)pl->KP * T * 9 + 15) & ~(size_t)15;
-  // pass B: records per tile limited by LDS: 12 B per slot + 12 B per partition
+  // pass B: records per tile limited by LDS: 10 B per slot + 12 B per partition
   const size_t fixed = ((size_t)pl->nparts + 4) * 12 + 64;
   pl->rpt = 0;
   const int mult = has2 ? 2 : 1;
   const char *rpt_env = getenv("TAD_RPT");  // tuning knob: cap the rows per thread of pass B
-  const int rpt_cap = rpt_env ? atoi(rpt_env) : 10;
-  for (int r : {10, 8, 4, 2}) {
+  const int rpt_cap = rpt_env ? atoi(rpt_env) : 10;  // 12 spills registers at 1024 threads (measured slower)
+  for (int r : {12, 10, 8, 4, 2}) {
     if (r > rpt_cap && r > 2) continue;
     const size_t slots = (size_t)r * kPartThreads * mult;
-    if (slots * 12 + fixed <= kLdsBudget) { pl->rpt = r; pl->part_lds = (slots * 12 + fixed + 15) & ~(size_t)15; break; }
+    if (slots * 10 + fixed <= kLdsBudget) { pl->rpt = r; pl->part_lds = (slots * 10 + fixed + 15) & ~(size_t)15; break; }
   }
   return pl->rpt != 0;
 }
@@ -740,14 +670,15 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
 
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, Lattice L,
-                      const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start, void *rec_val,
-                      void *rec_cell, DevCounters *ctr) {
+                      const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start, void *recs,
+                      OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr) {
   PartArgs A;
   A.key = key; A.key2 = key2; A.t_end = t_end; A.t_start = t_start; A.value = value;
   A.n = n; A.chunk = pl.chunk; A.K = K; A.f = f; A.L = L;
   A.shift_part = pl.shift_part; A.kp_mask = pl.KP - 1; A.nparts = pl.nparts;
   A.offs32 = offs32; A.part_start = part_start;
-  A.rec_val = static_cast<unsigned long long *>(rec_val); A.rec_cell = static_cast<uint16_t *>(rec_cell); A.ctr = ctr;
+  A.recs = static_cast<unsigned long long *>(recs); A.ctr = ctr;
+  A.ovf = ovf; A.ovf_count = ovf_count; A.ovf_cap = ovf_cap;
   const bool has2 = key2 != nullptr;
   const bool vec = aligned16(key) && aligned16(key2) && aligned16(t_end) && aligned16(value);
   // fast path: 16-byte loads, no time-window filter, bucket by one multiply-high
@@ -755,7 +686,7 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   int rpt = pl.rpt;
   if (generic && rpt > 4) rpt = 4;
   const size_t fixed = ((size_t)pl.nparts + 4) * 12 + 64;
-  const size_t lds = ((size_t)rpt * kPartThreads * (has2 ? 2 : 1) * 12 + fixed + 15) & ~(size_t)15;
+  const size_t lds = ((size_t)rpt * kPartThreads * (has2 ? 2 : 1) * 10 + fixed + 15) & ~(size_t)15;
 #define TAD_PART(RPT, H2, V, GEN)                                                                                       \
   do {                                                                                                                \
     static bool attr = false;                                                                                         \
@@ -764,6 +695,7 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   } while (0)
   if (!generic) {
     switch (rpt) {
+      case 12: if (has2) TAD_PART(8, true, true, false); else TAD_PART(12, false, true, false); break;
       case 10: if (has2) TAD_PART(8, true, true, false); else TAD_PART(10, false, true, false); break;
       case 8: if (has2) TAD_PART(8, true, true, false); else TAD_PART(8, false, true, false); break;
       case 6: case 4: if (has2) TAD_PART(4, true, true, false); else TAD_PART(4, false, true, false); break;
@@ -779,21 +711,22 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 #undef TAD_PART
 }
 
-void launch_tile_aggregate(hipStream_t s, const void *rec_val, const void *rec_cell, const unsigned long long *part_start,
-                           const PartPlan &pl, Grid g, bool op_max, int stats, double alpha, const double *rcp, double *sigma,
-                           uint32_t *n_pts, uint32_t *n_anom, double *key_mean, double *key_m2, DevCounters *ctr) {
-  KeyStatsOut ks{rcp, sigma, n_pts, n_anom, key_mean, key_m2, ctr, alpha};
-  const unsigned long long *rv = static_cast<const unsigned long long *>(rec_val);
-  const uint16_t *rc = static_cast<const uint16_t *>(rec_cell);
-#define TAD_AGG(OPM, ST)                                                                                              \
-  do {                                                                                                                \
-    static bool attr = false;                                                                                         \
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<OPM, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget); attr = true; } \
-    hipLaunchKernelGGL((k_tile_aggregate<OPM, ST>), dim3(pl.nparts), dim3(kPartThreads), pl.agg_lds, s, rv, rc, part_start, pl.shift_part, g, ks); \
-  } while (0)
-  if (op_max) { if (stats == 2) TAD_AGG(true, 2); else if (stats == 1) TAD_AGG(true, 1); else TAD_AGG(true, 0); }
-  else { if (stats == 2) TAD_AGG(false, 2); else if (stats == 1) TAD_AGG(false, 1); else TAD_AGG(false, 0); }
-#undef TAD_AGG
+void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
+                           Grid g, bool op_max, const OverflowRec *ovf, const unsigned long long *ovf_count, uint32_t ovf_cap) {
+  const unsigned long long *rr = static_cast<const unsigned long long *>(recs);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    attr = true;
+  }
+  if (op_max) {
+    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(pl.nparts), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, pl.shift_part, g);
+    hipLaunchKernelGGL((k_apply_overflow<true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
+  } else {
+    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(pl.nparts), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, pl.shift_part, g);
+    hipLaunchKernelGGL((k_apply_overflow<false>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
+  }
 }
 
 }  // namespace tad
