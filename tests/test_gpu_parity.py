@@ -121,6 +121,47 @@ def test_job_uint64_wrap_and_huge_values(engine):
             check_job(engine, algo, key, t, v, 3, agg_flow=agg)
 
 
+def test_job_values_beyond_the_packed_record_range(engine, stage0):
+    # Stage-0 v2 packs value << 15 | cell into one word; values >= 2^49 take the overflow list.  Mixed table:
+    # ~2 % of the rows carry 2^49 .. 2^64-1 (sums wrap), the rest are ordinary.
+    rng = np.random.default_rng(23)
+    k, t, v = orc.synth_rows(0, 120000, 300, 60)
+    big = rng.random(v.size) < 0.02
+    v = np.where(big, rng.integers(2**49, 2**64 - 1, size=v.size, dtype=np.uint64), v)
+    for agg in ("svc", ""):
+        check_job(engine, "EWMA", k, t, v, 300, agg_flow=agg)
+        check_job(engine, "DBSCAN", k, t, v, 300, agg_flow=agg)
+
+
+def test_job_overflow_list_full_falls_back_to_direct_scatter(engine, stage0):
+    # more than 2^20 rows with a value >= 2^49: the overflow list fills up, the engine reruns Stage 0 with v1
+    n = (1 << 20) + 4096
+    k, t, _ = orc.synth_rows(0, n, 64, 32)
+    v = (np.uint64(2**60) + np.arange(n, dtype=np.uint64)).astype(np.uint64)
+    want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+    res = engine.run("EWMA", k, t, v, 64, agg_flow="svc")
+    assert res.stats["stage0_path"] == 1
+    assert res.n_rows == want["n_anomalies"]
+    for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+        assert (res[f] == want[f]).all(), f
+
+
+def test_job_sampled_gcd_too_coarse_is_detected_and_rederived(engine, stage0):
+    # Stage-0 v2 derives the lattice step from a SAMPLE of the time differences (the first rows of every thread)
+    # and verifies every row in the partition pass.  One row 60 s off a 120 s lattice, placed where no thread
+    # samples it: the sampled step (120) is wrong, the engine must notice and derive the exact one (60).
+    n = 4_200_000
+    k, t, v = orc.synth_rows(0, n, 500, 40)
+    t = orc.SYNTH_T_BASE + 2 * (t - orc.SYNTH_T_BASE)        # every row on the 120 s lattice
+    t[12000] += 60                                           # ... except this one
+    want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+    res = engine.run("EWMA", k, t, v, 500, agg_flow="svc")
+    assert res.stats["step"] == 60 and res.stats["t0"] == t.min()
+    assert res.n_rows == want["n_anomalies"]
+    for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+        assert (res[f] == want[f]).all(), f
+
+
 def test_job_filters_second_key_and_skip(engine):
     rng = np.random.default_rng(11)
     n = 50000
