@@ -162,6 +162,20 @@ def test_job_sampled_gcd_too_coarse_is_detected_and_rederived(engine, stage0):
         assert (res[f] == want[f]).all(), f
 
 
+def test_job_sampled_time_range_too_narrow_is_detected_and_rederived(engine, stage0):
+    # Stage-0 v2 also SAMPLES the time column for (min, max): one iteration in eight plus both ends of every
+    # workgroup's chunk.  The latest timestamp of this table sits in an unsampled stretch of workgroup 0's chunk.
+    n = 7_000_000
+    k, t, v = orc.synth_rows(0, n, 400, 30)
+    t[10000] = t.max() + 60 * 5
+    want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+    res = engine.run("EWMA", k, t, v, 400, agg_flow="svc")
+    assert res.stats["n_buckets"] == 35 and res.stats["step"] == 60 and res.stats["t0"] == t.min()
+    assert res.n_rows == want["n_anomalies"]
+    for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+        assert (res[f] == want[f]).all(), f
+
+
 def test_job_filters_second_key_and_skip(engine):
     rng = np.random.default_rng(11)
     n = 50000

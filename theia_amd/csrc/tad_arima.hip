@@ -221,6 +221,23 @@ __global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const do
 // ------------------------------------------------------------------------------------------------
 // ARIMA(1,1,1) likelihood: conventional Kalman filter written out for the 3-state model
 // ------------------------------------------------------------------------------------------------
+// a / b with b's reciprocal y = RN(1 / b) already at hand: Markstein's FMA correction (tad_internal.h:div_by_count)
+// returns the correctly rounded quotient, i.e. the bits of the IEEE division (checked on 6e8 random operand pairs,
+// including all-ones and power-of-two significands).  The filter divides four numbers by the same F in every
+// step; this turns four ~25-instruction divisions into one division and four 5-FMA sequences.  Outside a generous
+// exponent window (overflow / underflow of the intermediates) it falls back to the division itself.
+TAD_HD inline double div_shared(double a, double b, double y, bool b_ok) {
+  const double aa = fabs(a);
+  if (b_ok && aa < 1e140 && (aa > 1e-140 || a == 0.0)) {
+    double q = a * y;
+    double r = fma(-b, q, a);
+    q = fma(r, y, q);
+    r = fma(-b, q, a);
+    return fma(r, y, q);
+  }
+  return a / b;
+}
+
 struct KfOut {
   double nll;       // -loglike / nobs
   double forecast;  // Z a_{n+1|n}
@@ -237,18 +254,20 @@ TAD_HD KfOut arima_nll(const double u0, const double u1, const double u2, const 
   double p12 = theta * s2, p22 = theta * theta * s2;
   const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  double llf = 0.0, F = 1.0, k0 = 0.0, k1 = 0.0, k2 = 0.0, cterm = 0.0;
-  bool conv = false;
+  double llf = 0.0, F = 1.0, k0 = 0.0, k1 = 0.0, k2 = 0.0, cterm = 0.0, invF = 1.0;
+  bool conv = false, F_ok = true;
   for (uint32_t t = 0; t < n; ++t) {
     const double v = y[(size_t)t * stride] - (a0 + a1);
     double pz0 = 0.0, pz1 = 0.0, pz2 = 0.0;
     if (!conv) {
       pz0 = p00 + p01; pz1 = p01 + p11; pz2 = p02 + p12;
       F = pz0 + pz1;
-      k0 = pz0 / F; k1 = pz1 / F; k2 = pz2 / F;
+      F_ok = F > 1e-100 && F < 1e100;
+      invF = 1.0 / F;
+      k0 = div_shared(pz0, F, invF, F_ok); k1 = div_shared(pz1, F, invF, F_ok); k2 = div_shared(pz2, F, invF, F_ok);  // == pz / F
       cterm = -0.5 * (kLog2Pi + log(F));
     }
-    if (t >= 1) llf += cterm - 0.5 * v * v / F;
+    if (t >= 1) llf += cterm - div_shared(0.5 * v * v, F, invF, F_ok);  // == 0.5 * v * v / F
     const double f0 = a0 + k0 * v, f1 = a1 + k1 * v, f2 = a2 + k2 * v;
     a0 = f0 + f1;
     a1 = phi * f1 + f2;

@@ -4,8 +4,9 @@
 // transactions (~20e9/s measured, tools/ubench_scatter.hip) — 5.5 ms for 1e8 rows while the 24 B/row
 // column stream alone takes 0.4 ms.  Here every random access lands in LDS instead:
 //
-//   pass A  k_meta_hist     one streaming read of the key/time columns (16 B/row, 16-byte loads): min / max of
-//                           flowEndSeconds, a SAMPLED gcd of its differences (verified by pass B, see below) AND a
+//   pass A  k_meta_hist     one streaming read of the key column (8 B/row, 16-byte loads) and of a SAMPLE of the time
+//                           column: min / max of flowEndSeconds and gcd of its differences over the sample (verified
+//                           on every row by pass B, see below) AND a
 //                           per-workgroup histogram of rows per key bin (bin = key >> shift_bin, LDS counters).
 //   (tiny)  k_part_rows / k_part_colscan / k_part_scan1
 //                           bins -> partitions of KP = 2^shift_part consecutive keys whose KP x T tile of the
@@ -23,10 +24,12 @@
 // Integer add/max are associative and commutative, so the aggregates are bit-identical to v1 and to
 // ClickHouse's sum()/max() over UInt64 whatever the record order.
 //
-// Sampled gcd: every thread of pass A feeds only its first kGcdSamples kept rows into the gcd (a 64-bit
-// modulo per row would make the pass ALU-bound); the result is a multiple of the true lattice step.  Pass B
-// checks EVERY row against the lattice; a row off the lattice raises DEV_ERR_OFF_LATTICE and the host reruns
-// with the exact derivation (tad_kernels.hip:k_meta).  Results are therefore never computed on a wrong lattice.
+// Sampled lattice: every thread of pass A feeds only its first kGcdSamples kept rows into the gcd (a 64-bit
+// modulo per row would make the pass ALU-bound) and, when no time-window filter is set, reads the time column
+// for one iteration in eight plus both ends of its chunk.  The sampled step is a multiple of the true one and the
+// sampled [min, max] lies inside the true range.  Pass B checks EVERY row against the lattice; a row off it
+// (between lattice points, or outside the range) raises DEV_ERR_OFF_LATTICE and the host reruns with the exact
+// derivation over all rows (tad_kernels.hip:k_meta).  Results are therefore never computed on a wrong lattice.
 #include <cstdlib>
 #include <cstring>
 
@@ -143,6 +146,18 @@ __device__ __forceinline__ void meta_row(MetaAcc &a, uint32_t *hist, uint64_t k1
   a.m.used++;
 }
 
+// a row whose time is not sampled: histogram only
+__device__ __forceinline__ void hist_row(MetaAcc &a, uint32_t *hist, uint64_t k1, uint64_t k2, uint64_t K, int shift_bin) {
+  if (k1 != TAD_KEY_SKIP) {
+    if (k1 < K) atomicAdd(&hist[(uint32_t)(k1 >> shift_bin)], 1u);
+    else a.err |= DEV_ERR_KEY_RANGE;
+  }
+  if (k2 != TAD_KEY_SKIP) {
+    if (k2 < K) atomicAdd(&hist[(uint32_t)(k2 >> shift_bin)], 1u);
+    else a.err |= DEV_ERR_KEY_RANGE;
+  }
+}
+
 template <bool VEC, bool HAS2>
 __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__restrict__ key,
                                                             const uint64_t *__restrict__ key2,
@@ -167,22 +182,37 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
     const ulonglong2 *k2v = reinterpret_cast<const ulonglong2 *>(key2 + (HAS2 ? lo : 0));
     const longlong2 *tv = reinterpret_cast<const longlong2 *>(t_end + lo);
     constexpr int U = 4;
+    // Without a time-window filter the time column is only needed for (min, max, sampled gcd): read it for one
+    // iteration in eight plus both ends of the chunk (time-ordered tables have their extremes there) and let the
+    // partition pass, which checks every row against the lattice, catch a missed extreme (-> exact re-derivation).
+    const bool sample_t = f.end_time == 0 && !has_ts;
     uint64_t i = threadIdx.x;
-    for (; i + (U - 1) * kPartThreads < npair; i += U * kPartThreads) {
+    uint32_t it = 0;
+    for (; i + (U - 1) * kPartThreads < npair; i += U * kPartThreads, ++it) {
+      const bool with_t = !sample_t || (it & 7) == 0 || (i - threadIdx.x) + 2 * U * kPartThreads >= npair;  // workgroup-uniform
       ulonglong2 k[U], k2[U];
       longlong2 t[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         k[u] = kv[i + u * kPartThreads];
-        t[u] = tv[i + u * kPartThreads];
         k2[u] = HAS2 ? k2v[i + u * kPartThreads] : make_ulonglong2(TAD_KEY_SKIP, TAD_KEY_SKIP);
       }
+      if (with_t) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint64_t r = lo + 2 * (i + u * kPartThreads);
-        const int64_t ts0 = has_ts ? t_start[r] : 0, ts1 = has_ts ? t_start[r + 1] : 0;
-        meta_row(acc, hist, k[u].x, k2[u].x, t[u].x, p_time_kept(t[u].x, ts0, has_ts, f), K, shift_bin);
-        meta_row(acc, hist, k[u].y, k2[u].y, t[u].y, p_time_kept(t[u].y, ts1, has_ts, f), K, shift_bin);
+        for (int u = 0; u < U; ++u) t[u] = tv[i + u * kPartThreads];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint64_t r = lo + 2 * (i + u * kPartThreads);
+          const int64_t ts0 = has_ts ? t_start[r] : 0, ts1 = has_ts ? t_start[r + 1] : 0;
+          meta_row(acc, hist, k[u].x, k2[u].x, t[u].x, p_time_kept(t[u].x, ts0, has_ts, f), K, shift_bin);
+          meta_row(acc, hist, k[u].y, k2[u].y, t[u].y, p_time_kept(t[u].y, ts1, has_ts, f), K, shift_bin);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          hist_row(acc, hist, k[u].x, k2[u].x, K, shift_bin);
+          hist_row(acc, hist, k[u].y, k2[u].y, K, shift_bin);
+        }
       }
     }
     for (; i < npair; i += kPartThreads) {
