@@ -10,7 +10,7 @@ tail -6 $O/pytest_gpu.log | head -3
 timeout 300 python bench.py > $O/bench_ewma_c2.json 2> $O/bench_ewma_c2.err; head -c 600 $O/bench_ewma_c2.json; echo
 timeout 300 python bench.py --algo DBSCAN --keys 1000000 --buckets 100 --agg "" --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_dbscan_c4.json 2> $O/bench_dbscan_c4.err
 if [ "$2" = "full" ]; then
-timeout 600 python bench.py --algo ARIMA --steps 1 --warmup 1 --cpu-rows 3000 > $O/bench_arima_c3.json 2> $O/bench_arima_c3.err
+timeout 600 python bench.py --algo ARIMA --steps 1 --warmup 1 --cpu-rows 40000 > $O/bench_arima_c3.json 2> $O/bench_arima_c3.err
 fi
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -o ewma -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_kt.log 2>&1
