@@ -187,6 +187,57 @@ func (e *Engine) Run(job Job, cols Columns) ([]Row, Stats, error) {
 	return rows, st, nil
 }
 
+// Point is one aggregated (key, flowEndSeconds) point of Stage 0 (tad_aggregate): the GROUP BY the reference pushes
+// into ClickHouse, with the full UInt64 aggregate.  Row-sharded ingest across several GPUs aggregates each slice
+// with Aggregate, routes the points to the engine that owns the key, and calls Run on the partial points.
+type Point struct {
+	KeyID    uint64
+	FlowEndS int64
+	Value    uint64
+}
+
+func (e *Engine) Aggregate(job Job, cols Columns) ([]Point, error) {
+	var cj C.tad_job
+	cj.agg_flow = C.tad_agg_flow(job.AggFlow)
+	cj.value_op = C.TAD_OP_AUTO
+	cj.start_time = C.int64_t(job.StartTime)
+	cj.end_time = C.int64_t(job.EndTime)
+	var cc C.tad_columns
+	n := len(cols.KeyID)
+	cc.n_rows = C.uint64_t(n)
+	cc.num_keys = C.uint64_t(cols.NumKeys)
+	cc.memory = C.TAD_MEM_HOST
+	bufs := []unsafe.Pointer{cColumn(cols.KeyID), cColumn(cols.KeyID2), cColumn(cols.FlowEndS), cColumn(cols.FlowStartS), cColumn(cols.Value)}
+	defer func() {
+		for _, p := range bufs {
+			if p != nil {
+				C.free(p)
+			}
+		}
+	}()
+	cc.key_id = (*C.uint64_t)(bufs[0])
+	cc.key_id2 = (*C.uint64_t)(bufs[1])
+	cc.flow_end_s = (*C.int64_t)(bufs[2])
+	cc.flow_start_s = (*C.int64_t)(bufs[3])
+	cc.value = (*C.uint64_t)(bufs[4])
+	var pts *C.tad_points
+	if rc := C.tad_aggregate(e.h, &cj, &cc, C.TAD_MEM_HOST, &pts); rc != C.TAD_OK {
+		return nil, fmt.Errorf("tad_aggregate: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	defer C.tad_points_free(e.h, pts)
+	m := int(pts.n_points)
+	out := make([]Point, m)
+	if m > 0 {
+		k := unsafe.Slice((*uint64)(unsafe.Pointer(pts.key_id)), m)
+		t := unsafe.Slice((*int64)(unsafe.Pointer(pts.flow_end_s)), m)
+		v := unsafe.Slice((*uint64)(unsafe.Pointer(pts.value)), m)
+		for i := range out {
+			out[i] = Point{k[i], t[i], v[i]}
+		}
+	}
+	return out, nil
+}
+
 // Progress feeds Status.CompletedStages / TotalStages (controller.go:426-453).
 func (e *Engine) Progress() (done, total int) {
 	var d, t C.int32_t

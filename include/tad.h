@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 1
+#define TAD_ABI_VERSION 2
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -161,6 +161,22 @@ const char *tad_last_error(tad_engine *e);
 int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory,
             tad_result **out);
 void tad_result_free(tad_engine *e, tad_result *r);
+/* ---- Stage 0 alone: the GROUP BY the reference pushes into ClickHouse (anomaly_detection.py:507-614) ----
+ * Aggregated points ordered by (key_id, flow_end_s); value keeps the full UInt64 (sum wraps, max unsigned).
+ * Used by row-sharded multi-GPU ingest: every GPU pre-aggregates its slice of the rows, the partial points travel to
+ * the key owners (one all-to-all), and tad_run over the partials with the same value_op gives bit-identical
+ * aggregates (integer add / max are associative).  job->algo and the detector parameters are ignored. */
+typedef struct {
+  uint64_t n_points;
+  uint64_t *key_id;
+  int64_t *flow_end_s;
+  uint64_t *value;
+  tad_mem memory;
+  tad_stats stats;       /* rows_in, rows_used, n_keys, n_points, lattice, stage timings */
+} tad_points;
+int tad_aggregate(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_points **out);
+void tad_points_free(tad_engine *e, tad_points *p);
+
 /* Stage counter for Status.CompletedStages / TotalStages (controller.go:426-453); callable while
  * tad_run executes on another thread. */
 int tad_progress(tad_engine *e, int32_t *done, int32_t *total);

@@ -20,7 +20,8 @@ def declared_functions():
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for must in ("tad_engine_create", "tad_run", "tad_result_free", "tad_progress", "tad_last_error",
-                 "tad_engine_destroy", "tad_series_ewma", "tad_series_dbscan_anomaly", "tad_series_arima"):
+                 "tad_engine_destroy", "tad_series_ewma", "tad_series_dbscan_anomaly", "tad_series_arima", "tad_aggregate",
+                 "tad_points_free"):
         assert must in names
 
 
@@ -38,12 +39,12 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 def test_ctypes_struct_layout_matches_the_c_compiler(tmp_path):
     from theia_amd import _capi
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include "tad.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
-                    'sizeof(tad_engine_opts),sizeof(tad_job),sizeof(tad_columns),sizeof(tad_stats),sizeof(tad_result));return 0;}\n')
+    prog.write_text('#include <stdio.h>\n#include "tad.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                    'sizeof(tad_engine_opts),sizeof(tad_job),sizeof(tad_columns),sizeof(tad_stats),sizeof(tad_result),sizeof(tad_points));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    mine = [ctypes.sizeof(c) for c in (_capi.EngineOpts, _capi.Job, _capi.Columns, _capi.Stats, _capi.Result)]
+    mine = [ctypes.sizeof(c) for c in (_capi.EngineOpts, _capi.Job, _capi.Columns, _capi.Stats, _capi.Result, _capi.Points)]
     assert sizes == mine
 
 

@@ -176,6 +176,40 @@ def test_job_sampled_time_range_too_narrow_is_detected_and_rederived(engine, sta
         assert (res[f] == want[f]).all(), f
 
 
+@pytest.mark.parametrize("agg", ["svc", ""])
+def test_job_hot_key_partition_is_split_across_workgroups(engine, stage0, agg):
+    # half of the rows carry one key: its Stage-0 partition holds > 2^17 records and is aggregated by several
+    # workgroups that merge with integer atomics (sum and max) -- still bit-exact
+    rng = np.random.default_rng(17)
+    k, t, v = orc.synth_rows(0, 700000, 300, 64)
+    k = np.where(rng.random(k.size) < 0.5, np.uint64(7), k)
+    v = np.where(rng.random(v.size) < 0.001, rng.integers(2**50, 2**64 - 1, size=v.size, dtype=np.uint64), v)
+    check_job(engine, "EWMA", k, t, v, 300, agg_flow=agg)
+
+
+@pytest.mark.parametrize("op", ["sum", "max"])
+def test_aggregate_points_and_reaggregation_of_partials(engine, op):
+    # tad_aggregate = Stage 0 alone.  (1) its points equal the oracle's GROUP BY bit for bit (values as uint64, wrap
+    # included); (2) the row-sharded multi-GPU recipe: aggregate two halves of the rows separately, concatenate the
+    # partial points, run the job on them with the same operator -> identical to the job on all rows.
+    rng = np.random.default_rng(3)
+    k, t, v = orc.synth_rows(0, 150000, 200, 50)
+    v = np.where(rng.random(v.size) < 0.01, rng.integers(2**62, 2**64 - 1, size=v.size, dtype=np.uint64), v)
+    agg = "svc" if op == "sum" else ""
+    pts = engine.aggregate(k, t, v, 200, agg_flow=agg)
+    pk, pt, pv = orc.stage0(k, t, v, op)
+    assert pts.n_points == pk.size and (pts["key_id"] == pk).all() and (pts["flow_end_s"] == pt).all() and (pts["value"] == pv).all()
+    half = k.size // 2
+    a = engine.aggregate(k[:half], t[:half], v[:half], 200, agg_flow=agg)
+    b = engine.aggregate(k[half:], t[half:], v[half:], 200, agg_flow=agg)
+    ck, ct, cv = (np.concatenate([a[f], b[f]]) for f in ("key_id", "flow_end_s", "value"))
+    whole = engine.run("EWMA", k, t, v, 200, agg_flow=agg, emit_all=True)
+    parts = engine.run("EWMA", ck, ct, cv, 200, agg_flow=agg, emit_all=True)
+    assert whole.n_rows == parts.n_rows
+    for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev", "anomaly"):
+        assert (whole[f] == parts[f]).all(), f
+
+
 def test_job_filters_second_key_and_skip(engine):
     rng = np.random.default_rng(11)
     n = 50000

@@ -6,7 +6,7 @@ from . import build as _build
 
 u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
 
-TAD_ABI_VERSION = 1
+TAD_ABI_VERSION = 2
 TAD_KEY_SKIP = (1 << 64) - 1
 TAD_OK = 0
 TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
@@ -48,6 +48,11 @@ class Result(C.Structure):
                 ("anomaly", C.c_void_p), ("memory", C.c_int), ("stats", Stats), ("id", C.c_char * 64)]
 
 
+class Points(C.Structure):
+    _fields_ = [("n_points", u64), ("key_id", C.c_void_p), ("flow_end_s", C.c_void_p), ("value", C.c_void_p),
+                ("memory", C.c_int), ("stats", Stats)]
+
+
 # every symbol include/tad.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "tad_abi_version": (C.c_int, []),
@@ -56,6 +61,8 @@ SYMBOLS = {
     "tad_last_error": (C.c_char_p, [C.c_void_p]),
     "tad_run": (C.c_int, [C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Result))]),
     "tad_result_free": (None, [C.c_void_p, C.POINTER(Result)]),
+    "tad_aggregate": (C.c_int, [C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Points))]),
+    "tad_points_free": (None, [C.c_void_p, C.POINTER(Points)]),
     "tad_progress": (C.c_int, [C.c_void_p, C.POINTER(i32), C.POINTER(i32)]),
     "tad_series_ewma": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_void_p]),
     "tad_series_ewma_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, f64, C.c_void_p]),

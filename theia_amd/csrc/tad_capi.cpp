@@ -45,7 +45,7 @@ struct tad_engine {
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
   DevBuf rcp_table;           // rcp_table[n] = RN(1/n), n = 0..rcp_n-1
   uint64_t rcp_n = 0;
-  DevBuf binhist, part_total, part_start, part_offs32, recs, ovf;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
+  DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
@@ -222,7 +222,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -420,11 +420,24 @@ int stage_column(tad_engine *e, DevBuf &buf, const void *src, uint64_t n, tad_me
 
 extern "C" {
 
-int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out) {
+}  // extern "C"
+
+namespace {
+
+struct PointsPriv {  // tad_points + its storage
+  tad_points pub;
+  void *block;
+  size_t block_cap;
+};
+
+// The job (points_out == nullptr) or Stage 0 alone (points_out != nullptr).
+int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out) {
+  const bool points_mode = points_out != nullptr;
   if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_run: engine is NULL");
-  if (!job || !cols || !out) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: job, cols and out must not be NULL");
-  *out = nullptr;
-  if (job->algo != TAD_ALGO_EWMA && job->algo != TAD_ALGO_ARIMA && job->algo != TAD_ALGO_DBSCAN)
+  if (!job || !cols || (!out && !points_out)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: job, cols and out must not be NULL");
+  if (out) *out = nullptr;
+  if (points_out) *points_out = nullptr;
+  if (!points_mode && job->algo != TAD_ALGO_EWMA && job->algo != TAD_ALGO_ARIMA && job->algo != TAD_ALGO_DBSCAN)
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: Throughput Anomaly Detector algorithm type should be 'EWMA' or 'ARIMA' or 'DBSCAN'");
   if (job->agg_flow < TAD_AGG_NONE || job->agg_flow > TAD_AGG_EXTERNAL)
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: Throughput Anomaly Detector aggregated flow type should be 'pod' or 'external' or 'svc'");
@@ -566,7 +579,8 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       HIP_TRY(e, hipEventRecord(e->ev[3], s));
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
-      launch_tile_aggregate(s, e->recs.p, part_start, pl, g, op_max, ovf, ovf_count, kOverflowCap);
+      if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
+      launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap);
     } else {
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));
@@ -583,7 +597,25 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
 
     // ---- Stage 1+2: sigma, detector, count, scan ----
     uint64_t rows = 0;
-    if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) return rc;
+    if (points_mode) {   // every present point: counts = n_pts
+      if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
+      if ((rc = ensure_rcp_table(e, g.T)) != TAD_OK) return rc;
+      launch_key_sigma(s, g, 0.5, false, static_cast<const double *>(e->rcp_table.p), static_cast<double *>(e->sigma.p),
+                       static_cast<uint32_t *>(e->n_pts.p), static_cast<uint32_t *>(e->n_anom.p), ctr, static_cast<double *>(e->key_mean.p),
+                       static_cast<double *>(e->key_m2.p));
+      launch_moments(s, g.K, static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(e->key_mean.p),
+                     static_cast<const double *>(e->key_m2.p), static_cast<Moments *>(e->moments.p));
+      unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
+      launch_scan(s, static_cast<const uint32_t *>(e->n_pts.p), off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
+      HIP_TRY(e, hipMemcpyAsync(e->total_host, off + g.K, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipMemcpyAsync(e->moments_host, e->moments.p, kMomentBlocks * sizeof(Moments), hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipStreamSynchronize(s));
+      HIP_TRY(e, hipGetLastError());
+      rows = *e->total_host;
+    } else if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) {
+      return rc;
+    }
     const DevCounters c = *e->ctr_host;
     if (c.err & DEV_ERR_KEY_RANGE)
       return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
@@ -596,6 +628,67 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       return fail(e, TAD_ERR_HIP, "internal error: a row fell off the derived time lattice");
     }
     e->done.store(3);
+
+    if (points_mode) {
+      PointsPriv *pp = new (std::nothrow) PointsPriv();
+      if (!pp) return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
+      memset(pp, 0, sizeof *pp);
+      const uint64_t r = rows ? rows : 1;
+      const size_t bytes = (size_t)r * 24;
+      ResultBlock blk;
+      if ((rc = alloc_device_block(e, bytes, &blk)) != TAD_OK) { delete pp; return rc; }
+      unsigned char *d = static_cast<unsigned char *>(blk.base);
+      if (rows)
+        launch_emit_points(s, g, L, static_cast<const unsigned long long *>(e->off.p), reinterpret_cast<unsigned long long *>(d),
+                           reinterpret_cast<long long *>(d + r * 8), reinterpret_cast<unsigned long long *>(d + r * 16));
+      HIP_TRY(e, hipEventRecord(e->ev[4], s));
+      unsigned char *base = d;
+      if (out_memory == TAD_MEM_HOST) {
+        void *h = malloc(bytes);
+        if (!h) { e->free_blocks.push_back({blk.base, blk.cap}); delete pp; return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu bytes of points", bytes); }
+        hipError_t hr = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
+        if (hr == hipSuccess) hr = hipStreamSynchronize(s);
+        e->free_blocks.push_back({blk.base, blk.cap});
+        if (hr != hipSuccess) { free(h); delete pp; return fail(e, TAD_ERR_HIP, "points copy failed: %s", hipGetErrorString(hr)); }
+        base = static_cast<unsigned char *>(h);
+        pp->block = h; pp->block_cap = bytes;
+      } else {
+        HIP_TRY(e, hipStreamSynchronize(s));
+        pp->block = blk.base; pp->block_cap = blk.cap;
+      }
+      HIP_TRY(e, hipGetLastError());
+      pp->pub.n_points = rows;
+      pp->pub.key_id = reinterpret_cast<uint64_t *>(base);
+      pp->pub.flow_end_s = reinterpret_cast<int64_t *>(base + r * 8);
+      pp->pub.value = reinterpret_cast<uint64_t *>(base + r * 16);
+      pp->pub.memory = out_memory;
+      tad_stats &st = pp->pub.stats;
+      st.rows_in = n; st.rows_used = c.rows_used; st.n_keys = c.n_keys; st.n_points = c.n_points;
+      st.t0 = L.t0; st.step = L.step; st.n_buckets = L.nb;
+      {
+        double mn = 0.0, mean = 0.0, m2 = 0.0;
+        if (g.K)
+          for (int b = 0; b < kMomentBlocks; ++b) {
+            const Moments &p = e->moments_host[b];
+            if (p.n == 0.0) continue;
+            if (mn == 0.0) { mn = p.n; mean = p.mean; m2 = p.m2; continue; }
+            const double nn = mn + p.n, dd = p.mean - mean;
+            mean = mean + dd * (p.n / nn);
+            m2 = m2 + p.m2 + dd * dd * (mn * p.n / nn);
+            mn = nn;
+          }
+        st.pts_mean = mean; st.pts_m2 = m2;
+      }
+      hipEventElapsedTime(&st.ms_meta, e->ev[0], e->ev[1]);
+      hipEventElapsedTime(&st.ms_stage0, e->ev[1], e->ev[5]);
+      hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
+      hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
+      hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
+      st.stage0_path = v2 ? 2 : 1;
+      e->done.store(4);
+      *points_out = &pp->pub;
+      return TAD_OK;
+    }
 
     // ---- Stage 3: emit ----
     ResultPriv *rp = nullptr;
@@ -660,6 +753,37 @@ int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     return TAD_OK;
   }
   return fail(e, TAD_ERR_HIP, "unreachable");
+}
+
+}  // namespace
+
+extern "C" {
+
+int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out) {
+  if (e && !out) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: job, cols and out must not be NULL");
+  return run_job(e, job, cols, out_memory, out, nullptr);
+}
+
+int tad_aggregate(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_points **out) {
+  if (e && !out) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_aggregate: job, cols and out must not be NULL");
+  return run_job(e, job, cols, out_memory, nullptr, out);
+}
+
+void tad_points_free(tad_engine *e, tad_points *p) {
+  if (!p) return;
+  PointsPriv *pp = reinterpret_cast<PointsPriv *>(p);
+  if (pp->block) {
+    if (p->memory == TAD_MEM_DEVICE && e) {
+      std::lock_guard<std::mutex> lk(e->mu);
+      if (e->free_blocks.size() < 8) e->free_blocks.push_back({pp->block, pp->block_cap});
+      else { hipSetDevice(e->device); hipFree(pp->block); }
+    } else if (p->memory == TAD_MEM_DEVICE) {
+      hipFree(pp->block);
+    } else {
+      free(pp->block);
+    }
+  }
+  delete pp;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -101,6 +101,8 @@ size_t scan_scratch_elems(uint64_t K);
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
                  const unsigned long long *off, OutRows out);
+void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long long *off, unsigned long long *out_key,
+                        long long *out_t, unsigned long long *out_val);
 // EWMA value for every present point into calc[T][K] (series entry points)
 void launch_ewma_values(hipStream_t s, Grid g, double alpha, double *calc);
 
@@ -141,8 +143,11 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f,
                       Lattice L, const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start,
                       void *recs, OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr);
+// slots = record slots of the run (rows x keys per row); slice_mem = slice_table_bytes(slots, pl) bytes of device scratch
+size_t slice_table_bytes(uint64_t slots, const PartPlan &pl);
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
-                           Grid g, bool op_max, const OverflowRec *ovf, const unsigned long long *ovf_count, uint32_t ovf_cap);
+                           uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
+                           const unsigned long long *ovf_count, uint32_t ovf_cap);
 
 void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                   uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,

@@ -561,6 +561,41 @@ void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, 
 #undef TAD_LAUNCH_EMIT
 }
 
+// every present point with its raw UInt64 aggregate, in (key, time) order (tad_aggregate)
+__global__ __launch_bounds__(kBlock) void k_emit_points(Grid g, Lattice L, const unsigned long long *__restrict__ off,
+                                                        unsigned long long *__restrict__ out_key, long long *__restrict__ out_t,
+                                                        unsigned long long *__restrict__ out_val) {
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= g.K) return;
+  unsigned long long pos = off[k];
+  const unsigned long long end = off[k + 1];
+  auto step = [&](uint64_t t, uint8_t fl, unsigned long long raw) {
+    if ((fl & FLAG_PRESENT) && pos < end) {
+      out_key[pos] = k;
+      out_t[pos] = (long long)(L.t0 + (int64_t)t * L.step);
+      out_val[pos] = raw;
+      pos++;
+    }
+  };
+  uint64_t t = 0;
+  for (; t + kUnroll <= g.T && pos < end; t += kUnroll) {
+    uint8_t fl[kUnroll];
+    unsigned long long v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) { fl[u] = g.flag[(t + u) * g.K + k]; v[u] = g.val[(t + u) * g.K + k]; }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) step(t + u, fl[u], v[u]);
+  }
+  for (; t < g.T && pos < end; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
+}
+
+void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long long *off, unsigned long long *out_key,
+                        long long *out_t, unsigned long long *out_val) {
+  if (g.K == 0) return;
+  const int blocks = (int)((g.K + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_emit_points, dim3(blocks), dim3(kBlock), 0, s, g, lat, off, out_key, out_t, out_val);
+}
+
 // EWMA value of every present point (tad_series_ewma = calculate_ewma, :146-165)
 __global__ __launch_bounds__(kBlock) void k_ewma_values(Grid g, double alpha, double *__restrict__ calc) {
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;

@@ -563,24 +563,95 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass C — one workgroup per partition: aggregate its records in an LDS tile, write the tile out.
+// pass C — aggregate the records of a partition in an LDS tile, write the tile out.
 // LDS carve: vals[KP*T] u64 | flags[KP*T] u8
+//
+// Work unit = a SLICE of at most kSliceRecords records of one partition, so that a partition swollen by a hot key
+// (real flow tables have heavy hitters: one key with half the rows made this pass 30x slower when it was one
+// workgroup per partition) is spread over many CUs.  A partition with one slice — every partition of a uniform
+// table — stores its tile directly; the slices of a split partition merge into the (pre-zeroed) grid tile with
+// agent-scope integer atomics, which commute, so the aggregates are bit-exact either way.
 // ------------------------------------------------------------------------------------------------
+static constexpr uint32_t kSliceRecords = 1u << 17;
+
+struct SliceTable {
+  uint32_t *slice_part;          // [max_slices] partition of each slice
+  uint32_t *slice_first;         // [nparts] index of the partition's first slice
+  uint32_t *n_slices;            // [1]
+};
+
+// single workgroup: nsl[p] = max(1, ceil(cnt[p] / kSliceRecords)); exclusive scan -> slice_first; fill slice_part
+__global__ __launch_bounds__(kPartThreads) void k_build_slices(const unsigned long long *__restrict__ part_start, uint32_t nparts,
+                                                               SliceTable st) {
+  __shared__ uint32_t s_wave[kPartThreads / 64];
+  const uint32_t per = (nparts + kPartThreads - 1) / kPartThreads;
+  const uint32_t b0 = threadIdx.x * per;
+  auto nsl = [&](uint32_t p) -> uint32_t {
+    const unsigned long long c = part_start[p + 1] - part_start[p];
+    const uint32_t k = (uint32_t)((c + kSliceRecords - 1) / kSliceRecords);
+    return k ? k : 1u;
+  };
+  uint32_t sum = 0;
+  for (uint32_t j = 0; j < per; ++j)
+    if (b0 + j < nparts) sum += nsl(b0 + j);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = sum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < kPartThreads / 64; ++w) {
+    if (w < wave) base += s_wave[w];
+    tot += s_wave[w];
+  }
+  uint32_t run = base + incl - sum;
+  for (uint32_t j = 0; j < per; ++j) {
+    const uint32_t p = b0 + j;
+    if (p < nparts) {
+      const uint32_t k = nsl(p);
+      st.slice_first[p] = run;
+      for (uint32_t i = 0; i < k; ++i) st.slice_part[run + i] = p;
+      run += k;
+    }
+  }
+  if (threadIdx.x == 0) *st.n_slices = tot;
+}
+
 template <bool OPMAX>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
-                                                                 int shift_part, Grid g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+                                                                 SliceTable st, int shift_part, uint32_t nparts, Grid g, int phase) {
+  const uint32_t s_idx = blockIdx.x;
+  if (s_idx >= *st.n_slices) return;
+  const uint32_t p = st.slice_part[s_idx];
+  const uint32_t first = st.slice_first[p];
+  const uint32_t nsl = (p + 1 < nparts ? st.slice_first[p + 1] : *st.n_slices) - first;
+  const bool split = nsl > 1;
   const uint32_t KP = 1u << shift_part;
   const uint32_t T = (uint32_t)g.T;
   const uint32_t cells = KP * T;
+  const uint64_t k0 = (uint64_t)p << shift_part;
+  if (phase == 0) {  // pre-zero the grid tile of every split partition (first slice does it)
+    if (!split || s_idx != first) return;
+    for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {
+      const uint32_t b = c >> shift_part, kk = c & (KP - 1);
+      const uint64_t k = k0 + kk;
+      if (k < g.K) { g.val[(uint64_t)b * g.K + k] = 0ull; g.flag[(uint64_t)b * g.K + k] = 0; }
+    }
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *vals = reinterpret_cast<unsigned long long *>(smem);
   uint8_t *flags = smem + (size_t)cells * 8;
   for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
   for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
   __syncthreads();
-  const uint32_t p = blockIdx.x;
-  const unsigned long long lo = part_start[p], hi = part_start[p + 1];
+  const unsigned long long plo = part_start[p], phi = part_start[p + 1];
+  const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * kSliceRecords;
+  const unsigned long long hi = lo + kSliceRecords < phi ? lo + kSliceRecords : phi;
   auto apply = [&](unsigned long long r) {
     const uint32_t c = (uint32_t)r & kCellNone;
     if (c == kCellNone) return;
@@ -600,13 +671,18 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
   }
   for (; i < hi; i += kPartThreads) apply(recs[i]);
   __syncthreads();
-  const uint64_t k0 = (uint64_t)p << shift_part;
   for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
     const uint32_t b = c >> shift_part, kk = c & (KP - 1);
     const uint64_t k = k0 + kk;
-    if (k < g.K) {
-      g.val[(uint64_t)b * g.K + k] = vals[c];
-      g.flag[(uint64_t)b * g.K + k] = flags[c];
+    if (k >= g.K) continue;
+    const uint64_t gc = (uint64_t)b * g.K + k;
+    if (!split) {
+      g.val[gc] = vals[c];
+      g.flag[gc] = flags[c];
+    } else if (flags[c]) {
+      if (OPMAX) __hip_atomic_fetch_max(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_fetch_add(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g.flag[gc] = FLAG_PRESENT;
     }
   }
 }
@@ -741,20 +817,35 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 #undef TAD_PART
 }
 
+size_t slice_table_bytes(uint64_t slots, const PartPlan &pl) {
+  const size_t max_slices = (size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1;
+  return (max_slices + pl.nparts + 4) * sizeof(uint32_t);
+}
+
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
-                           Grid g, bool op_max, const OverflowRec *ovf, const unsigned long long *ovf_count, uint32_t ovf_cap) {
+                           uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
+                           const unsigned long long *ovf_count, uint32_t ovf_cap) {
   const unsigned long long *rr = static_cast<const unsigned long long *>(recs);
+  const uint32_t max_slices = (uint32_t)((size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1);
+  SliceTable st;
+  st.slice_part = static_cast<uint32_t *>(slice_mem);
+  st.slice_first = st.slice_part + max_slices;
+  st.n_slices = st.slice_first + pl.nparts;
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     attr = true;
   }
+  hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st);
+  const bool may_split = max_slices > pl.nparts + 1 || slots > kSliceRecords;  // some partition could exceed one slice
   if (op_max) {
-    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(pl.nparts), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, pl.shift_part, g);
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, pl.shift_part, pl.nparts, g, 0);
+    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, pl.shift_part, pl.nparts, g, 1);
     hipLaunchKernelGGL((k_apply_overflow<true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
   } else {
-    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(pl.nparts), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, pl.shift_part, g);
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, pl.shift_part, pl.nparts, g, 0);
+    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, pl.shift_part, pl.nparts, g, 1);
     hipLaunchKernelGGL((k_apply_overflow<false>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
   }
 }

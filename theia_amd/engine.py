@@ -133,6 +133,62 @@ class TadResult:
             pass
 
 
+class TadPoints:
+    """Stage-0 output (tad_aggregate): aggregated points ordered by (key_id, flow_end_s), values as raw uint64."""
+
+    FIELDS = (("key_id", np.uint64), ("flow_end_s", np.int64), ("value", np.uint64))
+
+    def __init__(self, engine, ptr):
+        self._engine = engine
+        self._ptr = ptr
+        p = ptr.contents
+        self.n_points = int(p.n_points)
+        self.memory = "device" if p.memory == capi.TAD_MEM_DEVICE else "host"
+        self.stats = {name: getattr(p.stats, name) for name, _ in capi.Stats._fields_}
+        self._host = None
+        if self.memory == "host":
+            self._host = self._copy(direct=True)
+            self.close()
+
+    def _copy(self, direct):
+        p = self._ptr.contents
+        out = {}
+        for name, dt in self.FIELDS:
+            arr = np.empty(self.n_points, dtype=dt)
+            if self.n_points:
+                if direct:
+                    C.memmove(arr.ctypes.data, getattr(p, name), arr.nbytes)
+                else:
+                    self._engine._check(self._engine._lib.tad_copy_to_host(self._engine._h, arr.ctypes.data, getattr(p, name), arr.nbytes))
+            out[name] = arr
+        return out
+
+    def device_pointers(self):
+        if self._ptr is None or self.memory != "device":
+            raise ValueError("no live device points")
+        p = self._ptr.contents
+        return {name: getattr(p, name) for name, _ in self.FIELDS}
+
+    def to_host(self):
+        if self._host is None:
+            self._host = self._copy(direct=False)
+        return self._host
+
+    def __getitem__(self, name):
+        return self.to_host()[name]
+
+    def close(self):
+        if self._ptr is not None and self._engine._h is not None:
+            self._engine._lib.tad_points_free(self._engine._h, self._ptr)
+        self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TadEngine:
     """One engine per GPU.  Thread-safe (runs serialise inside the library)."""
 
@@ -205,6 +261,33 @@ class TadEngine:
         del keep1, keep2, keep3, keep4, keep5
         self._check(rc)
         return TadResult(self, res)
+
+    # ---- Stage 0 alone: the GROUP BY (anomaly_detection.py:507-614) ----
+    def aggregate(self, key_id, flow_end_s, value, num_keys, agg_flow="", value_op="auto", key_id2=None, flow_start_s=None,
+                  start_time=0, end_time=0, lattice=None, out="host"):
+        if agg_flow not in capi.TAD_AGG:
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "agg_flow must be '', pod, svc or external")
+        pk, n, dev, keep1 = _as_column(key_id, np.uint64)
+        pt, nt, dev_t, keep2 = _as_column(flow_end_s, np.int64)
+        pv, nv, dev_v, keep3 = _as_column(value, np.uint64)
+        pk2, nk2, dev_k2, keep4 = _as_column(key_id2, np.uint64)
+        ps, ns, dev_s, keep5 = _as_column(flow_start_s, np.int64)
+        for m, d in ((nt, dev_t), (nv, dev_v)) + (((nk2, dev_k2),) if key_id2 is not None else ()) + \
+                (((ns, dev_s),) if flow_start_s is not None else ()):
+            if m != n or d != dev:
+                raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "columns must have equal length and live in the same memory")
+        job = capi.Job(algo=0, agg_flow=capi.TAD_AGG[agg_flow], value_op=capi.TAD_OP[value_op],
+                       start_time=int(start_time), end_time=int(end_time))
+        cols = capi.Columns(n_rows=n, key_id=pk, key_id2=pk2, flow_end_s=pt, flow_start_s=ps, value=pv,
+                            num_keys=int(num_keys), memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
+        if lattice is not None:
+            cols.t0, cols.step, cols.n_buckets = int(lattice[0]), int(lattice[1]), int(lattice[2])
+        res = C.POINTER(capi.Points)()
+        rc = self._lib.tad_aggregate(self._h, C.byref(job), C.byref(cols),
+                                     capi.TAD_MEM_DEVICE if out == "device" else capi.TAD_MEM_HOST, C.byref(res))
+        del keep1, keep2, keep3, keep4, keep5
+        self._check(rc)
+        return TadPoints(self, res)
 
     # ---- the reference's per-series pure functions, on the GPU ----
     @staticmethod
