@@ -176,6 +176,15 @@ def test_job_sampled_time_range_too_narrow_is_detected_and_rederived(engine, sta
         assert (res[f] == want[f]).all(), f
 
 
+@pytest.mark.parametrize("n_rows,K,T", [(1_500_000, 40_000, 2000), (300_000, 50, 20_000), (2_000_000, 300_000, 100)])
+def test_job_wide_grids_take_several_rounds_per_partition(engine, stage0, n_rows, K, T):
+    # grids whose KP x T block does not fit one LDS tile (many buckets) or that would need more than 2048 partitions
+    # (many keys): Stage-0 v2 widens the key block and walks the partition's records in several bucket rounds
+    k, t, v = orc.synth_rows(0, n_rows, K, T)
+    res, want = check_job(engine, "EWMA", k, t, v, K, agg_flow="svc")
+    assert res.stats["stage0_path"] == (2 if stage0 == "v2" else 1)
+
+
 @pytest.mark.parametrize("agg", ["svc", ""])
 def test_job_hot_key_partition_is_split_across_workgroups(engine, stage0, agg):
     # half of the rows carry one key: its Stage-0 partition holds > 2^17 records and is aggregated by several

@@ -130,6 +130,8 @@ struct PartPlan {
   uint32_t KP, nparts, bins_per_part;
   size_t agg_lds, part_lds;
   int rpt;             // rows per thread per tile in pass B
+  int cell_bits;       // record = value << cell_bits | partition-local cell
+  uint32_t tb, n_chunks;  // pass C: buckets per LDS round, rounds per partition
 };
 bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl);
 bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);

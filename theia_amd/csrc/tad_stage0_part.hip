@@ -39,15 +39,17 @@ namespace tad {
 
 static constexpr int kPartThreads = 1024;
 
-// A Stage-0 record is ONE 64-bit word: value << 15 | tile-local cell (15 bits; 0x7FFF = no cell).  Measured on MI355X
+// A Stage-0 record is ONE 64-bit word: value << cell_bits | partition-local cell (all ones = no cell).  Measured on MI355X
 // the partition pass is bound by the 64-byte write sectors its short per-partition runs touch, so bytes per record
 // are what matters: 8-byte records beat {u64 value, u16 cell} arrays (10 B), packed 12-byte and the original 16-byte
-// records.  A value >= 2^49 does not fit: it goes, with its GLOBAL cell, to a small overflow list (global atomic
+// records.  A value >= 2^(64 - cell_bits) does not fit: it goes, with its GLOBAL cell, to a small overflow list (global atomic
 // append) that k_apply_overflow folds into the grid after the tile pass — same associative integer operator, so the
 // aggregates stay bit-exact for the full UInt64 range.  If the list overflows the host falls back to Stage 0 v1.
-static constexpr uint32_t kCellBits = 15;
-static constexpr uint32_t kCellNone = 0x7FFFu;
-static constexpr unsigned long long kValueLimit = 1ull << (64 - kCellBits);
+// The cell field is cell_bits wide (15 .. kMaxCellBits, chosen by the plan from KP x T); the all-ones cell means
+// "no cell" (row off the lattice, or its value went to the overflow list).
+static constexpr int kMinCellBits = 15, kMaxCellBits = 24;
+static constexpr uint32_t kTileCells = 17000;   // cells of one LDS tile of pass C: 9 B per cell within kLdsBudget
+static constexpr uint32_t kMaxParts = 2048;     // partitions of pass B: 12 B of LDS each, and >= ~5 records per run per tile
 static constexpr size_t kLdsBudget = 156 * 1024;  // dynamic LDS per workgroup; the rest of the CU's 160 KiB is for static __shared__
 static constexpr int kGcdSamples = 4;
 
@@ -341,6 +343,7 @@ struct PartArgs {
   Lattice L;
   int shift_part;     // partition = key >> shift_part
   uint32_t kp_mask;   // KP - 1
+  int cell_bits;      // record = value << cell_bits | cell
   uint32_t nparts;
   const uint32_t *offs32;                  // [G][nparts] exclusive row prefix of this workgroup inside each partition
   const unsigned long long *part_start;    // [nparts + 1]
@@ -410,6 +413,8 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
   const uint64_t hi = lo + A.chunk < A.n ? lo + A.chunk : A.n;
   const bool has_ts = GENERIC && A.t_start != nullptr && A.f.start_time != 0;
   const uint32_t KP = A.kp_mask + 1u;
+  const uint32_t cell_none = (1u << A.cell_bits) - 1u;
+  const unsigned long long value_limit = 1ull << (64 - A.cell_bits);
   uint32_t err = 0, used = 0;
 
   uint64_t pk[RPT], pk2[HAS2 ? RPT : 1], pv[RPT];
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     const uint64_t base = lo + tile * TILE;
     const int next_kind = tile + 1 < nfull ? 1 : (tile + 1 < ntiles ? 2 : 0);  // workgroup-uniform
     // ---- phase 1: partition + tile-local cell of every row, ranked inside its partition (LDS atomic) ----
-    uint32_t r_cp[NSLOT], r_rank[NSLOT];
+    uint32_t r_cell[NSLOT], r_pr[NSLOT];  // cell; partition << 16 | rank (rank < S <= 2^14... stored in 16 bits)
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
       const int64_t te = pt[j];
@@ -500,13 +505,13 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
       for (int h = 0; h < (HAS2 ? 2 : 1); ++h) {
         const int slot = j * (HAS2 ? 2 : 1) + h;
         const uint64_t k = h == 0 ? pk[j] : pk2[HAS2 ? j : 0];
-        r_cp[slot] = 0xFFFFFFFFu;
-        r_rank[slot] = 0;
+        r_cell[slot] = cell_none;
+        r_pr[slot] = 0xFFFFFFFFu;
         if (kept && k != TAD_KEY_SKIP && k < A.K) {  // same predicate as pass A: the slot is reserved
-          uint32_t cell = kCellNone;
+          uint32_t cell = cell_none;
           if (on_lattice) {
             used++;
-            if (pv[j] < kValueLimit) {
+            if (pv[j] < value_limit) {
               cell = bucket * KP + ((uint32_t)k & A.kp_mask);
             } else {  // rare: the value needs more than 49 bits -> overflow list, the stream slot stays empty
               const unsigned long long o = atomicAdd(A.ovf_count, 1ull);
@@ -517,8 +522,8 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
             err |= DEV_ERR_OFF_LATTICE;  // wrong lattice hint, or the sampled gcd missed a residue: host re-derives
           }
           const uint32_t p = (uint32_t)(k >> A.shift_part);
-          r_cp[slot] = cell | (p << 16);
-          r_rank[slot] = atomicAdd(&off[p], 1u);
+          r_cell[slot] = cell;
+          r_pr[slot] = (p << 16) | atomicAdd(&off[p], 1u);
         }
       }
     }
@@ -530,10 +535,10 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     // ---- phase 3: place the records in partition order; per-partition global destination ----
 #pragma unroll
     for (int slot = 0; slot < NSLOT; ++slot) {
-      if (r_cp[slot] != 0xFFFFFFFFu) {
-        const uint32_t pos = off[r_cp[slot] >> 16] + r_rank[slot];
-        rec[pos] = (pv[slot / (HAS2 ? 2 : 1)] << kCellBits) | (r_cp[slot] & kCellNone);
-        part[pos] = (uint16_t)(r_cp[slot] >> 16);
+      if (r_pr[slot] != 0xFFFFFFFFu) {
+        const uint32_t pos = off[r_pr[slot] >> 16] + (r_pr[slot] & 0xFFFFu);
+        rec[pos] = (pv[slot / (HAS2 ? 2 : 1)] << A.cell_bits) | r_cell[slot];
+        part[pos] = (uint16_t)(r_pr[slot] >> 16);
       }
     }
     if (next_kind == 1) load_values_full(base + TILE);  // needed again only in the next tile's phase 3
@@ -620,69 +625,91 @@ __global__ __launch_bounds__(kPartThreads) void k_build_slices(const unsigned lo
   if (threadIdx.x == 0) *st.n_slices = tot;
 }
 
+// Geometry of pass C, decided by the plan: a partition is KP = 2^shift_part keys x T buckets; its cells are processed
+// in n_chunks rounds of TB buckets (TB * KP <= kTileCells cells per LDS tile).  n_chunks == 1 whenever the whole
+// KP x T tile fits (C2); wide grids (many keys and/or many buckets) take larger key blocks — so that pass B keeps a
+// few thousand partitions at most — and several rounds over the partition's records, which are L2 / MALL resident
+// after the first round (a partition holds a few hundred KB of records).
+struct TileGeom {
+  int shift_part;
+  int cell_bits;
+  uint32_t nparts;
+  uint32_t tb;        // buckets per round
+  uint32_t n_chunks;  // ceil(T / tb)
+};
+
 template <bool OPMAX>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
-                                                                 SliceTable st, int shift_part, uint32_t nparts, Grid g, int phase) {
+                                                                 SliceTable st, TileGeom tg, Grid g, int phase) {
   const uint32_t s_idx = blockIdx.x;
   if (s_idx >= *st.n_slices) return;
   const uint32_t p = st.slice_part[s_idx];
   const uint32_t first = st.slice_first[p];
-  const uint32_t nsl = (p + 1 < nparts ? st.slice_first[p + 1] : *st.n_slices) - first;
+  const uint32_t nsl = (p + 1 < tg.nparts ? st.slice_first[p + 1] : *st.n_slices) - first;
   const bool split = nsl > 1;
+  const int shift_part = tg.shift_part;
   const uint32_t KP = 1u << shift_part;
   const uint32_t T = (uint32_t)g.T;
-  const uint32_t cells = KP * T;
   const uint64_t k0 = (uint64_t)p << shift_part;
   if (phase == 0) {  // pre-zero the grid tile of every split partition (first slice does it)
     if (!split || s_idx != first) return;
-    for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {
-      const uint32_t b = c >> shift_part, kk = c & (KP - 1);
-      const uint64_t k = k0 + kk;
-      if (k < g.K) { g.val[(uint64_t)b * g.K + k] = 0ull; g.flag[(uint64_t)b * g.K + k] = 0; }
+    const uint64_t cells_all = (uint64_t)KP * T;
+    for (uint64_t c = threadIdx.x; c < cells_all; c += kPartThreads) {
+      const uint64_t b = c >> shift_part, k = k0 + (c & (KP - 1));
+      if (k < g.K) { g.val[b * g.K + k] = 0ull; g.flag[b * g.K + k] = 0; }
     }
     return;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long *vals = reinterpret_cast<unsigned long long *>(smem);
-  uint8_t *flags = smem + (size_t)cells * 8;
-  for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
-  for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
-  __syncthreads();
+  const uint32_t cell_none = (1u << tg.cell_bits) - 1u;
   const unsigned long long plo = part_start[p], phi = part_start[p + 1];
   const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * kSliceRecords;
   const unsigned long long hi = lo + kSliceRecords < phi ? lo + kSliceRecords : phi;
-  auto apply = [&](unsigned long long r) {
-    const uint32_t c = (uint32_t)r & kCellNone;
-    if (c == kCellNone) return;
-    const unsigned long long v = r >> kCellBits;
-    if (OPMAX) atomicMax(&vals[c], v);
-    else atomicAdd(&vals[c], v);
-    flags[c] = FLAG_PRESENT;
-  };
-  constexpr int U = 8;
-  unsigned long long i = lo + threadIdx.x;
-  for (; i + (U - 1) * kPartThreads < hi; i += U * kPartThreads) {
-    unsigned long long r[U];
+  for (uint32_t chunk = 0; chunk < tg.n_chunks; ++chunk) {
+    const uint32_t b_lo = chunk * tg.tb;
+    const uint32_t nb = b_lo + tg.tb <= T ? tg.tb : T - b_lo;
+    const uint32_t cells = nb << shift_part;
+    const uint32_t c_lo = b_lo << shift_part;  // first partition-local cell of this round
+    unsigned long long *vals = reinterpret_cast<unsigned long long *>(smem);
+    uint8_t *flags = smem + (size_t)(tg.tb << shift_part) * 8;
+    if (chunk) __syncthreads();  // the previous round's tile has been written out
+    for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
+    for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
+    __syncthreads();
+    auto apply = [&](unsigned long long r) {
+      const uint32_t cg = (uint32_t)r & cell_none;
+      const uint32_t c = cg - c_lo;  // wraps for cells before this round: the unsigned compare rejects them
+      if (cg == cell_none || c >= cells) return;
+      const unsigned long long v = r >> tg.cell_bits;
+      if (OPMAX) atomicMax(&vals[c], v);
+      else atomicAdd(&vals[c], v);
+      flags[c] = FLAG_PRESENT;
+    };
+    constexpr int U = 8;
+    unsigned long long i = lo + threadIdx.x;
+    for (; i + (U - 1) * kPartThreads < hi; i += U * kPartThreads) {
+      unsigned long long r[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) r[u] = recs[i + u * kPartThreads];
+      for (int u = 0; u < U; ++u) r[u] = recs[i + u * kPartThreads];
 #pragma unroll
-    for (int u = 0; u < U; ++u) apply(r[u]);
-  }
-  for (; i < hi; i += kPartThreads) apply(recs[i]);
-  __syncthreads();
-  for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
-    const uint32_t b = c >> shift_part, kk = c & (KP - 1);
-    const uint64_t k = k0 + kk;
-    if (k >= g.K) continue;
-    const uint64_t gc = (uint64_t)b * g.K + k;
-    if (!split) {
-      g.val[gc] = vals[c];
-      g.flag[gc] = flags[c];
-    } else if (flags[c]) {
-      if (OPMAX) __hip_atomic_fetch_max(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else __hip_atomic_fetch_add(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      g.flag[gc] = FLAG_PRESENT;
+      for (int u = 0; u < U; ++u) apply(r[u]);
+    }
+    for (; i < hi; i += kPartThreads) apply(recs[i]);
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
+      const uint32_t b = b_lo + (c >> shift_part), kk = c & (KP - 1);
+      const uint64_t k = k0 + kk;
+      if (k >= g.K) continue;
+      const uint64_t gc = (uint64_t)b * g.K + k;
+      if (!split) {
+        g.val[gc] = vals[c];
+        g.flag[gc] = flags[c];
+      } else if (flags[c]) {
+        if (OPMAX) __hip_atomic_fetch_max(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g.flag[gc] = FLAG_PRESENT;
+      }
     }
   }
 }
@@ -722,18 +749,29 @@ bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl) {
 
 bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   if (T == 0 || T >= (1ull << 16)) return false;
-  // largest power-of-two key tile whose KP x T (u64 + flag byte) fits in LDS and whose cells fit 16 bits
-  int sp = -1;
-  for (int c = 15; c >= pl->shift_bin; --c)
-    if (((uint64_t)T << c) * 9 + 16 <= kLdsBudget && ((uint64_t)T << c) < (uint64_t)kCellNone) { sp = c; break; }
-  if (sp < 0) return false;
+  // Key block: as small as keeps the partition count <= kMaxParts (few partitions = long runs in pass B), but not
+  // smaller than the largest block whose whole KP x T tile fits one LDS tile (then pass C needs a single round).
+  int sp_fit = -1;
+  for (int c = 13; c >= 0; --c)
+    if (((uint64_t)T << c) <= kTileCells) { sp_fit = c; break; }
+  int sp = sp_fit >= pl->shift_bin ? sp_fit : pl->shift_bin;
+  while (((K + (1ull << sp) - 1) >> sp) > kMaxParts && sp < 13) ++sp;
+  if (((K + (1ull << sp) - 1) >> sp) > kMaxParts) return false;
   while (sp > pl->shift_bin && (1ull << (sp - 1)) >= K) --sp;  // no wider than the key space
+  if ((1ull << sp) > kTileCells) return false;                 // one bucket of the block must fit a tile
   pl->shift_part = sp;
   pl->KP = 1u << sp;
   pl->nparts = (uint32_t)((K + pl->KP - 1) >> sp);
-  if (pl->nparts > 65535) return false;  // the partition id travels in 16 bits
   pl->bins_per_part = 1u << (sp - pl->shift_bin);
-  pl->agg_lds = ((size_t)pl->KP * T * 9 + 15) & ~(size_t)15;
+  const uint64_t cells_all = (uint64_t)pl->KP * T;
+  int cb = kMinCellBits;
+  while (cb < kMaxCellBits && (1ull << cb) - 1 <= cells_all) ++cb;   // all-ones is reserved
+  if ((1ull << cb) - 1 <= cells_all) return false;
+  pl->cell_bits = cb;
+  pl->tb = (uint32_t)(kTileCells >> sp);
+  if (pl->tb > T) pl->tb = (uint32_t)T;
+  pl->n_chunks = (uint32_t)((T + pl->tb - 1) / pl->tb);
+  pl->agg_lds = ((size_t)pl->tb * pl->KP * 9 + 15) & ~(size_t)15;
   // pass B: records per tile limited by LDS: 10 B per slot + 12 B per partition
   const size_t fixed = ((size_t)pl->nparts + 4) * 12 + 64;
   pl->rpt = 0;
@@ -781,7 +819,7 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   PartArgs A;
   A.key = key; A.key2 = key2; A.t_end = t_end; A.t_start = t_start; A.value = value;
   A.n = n; A.chunk = pl.chunk; A.K = K; A.f = f; A.L = L;
-  A.shift_part = pl.shift_part; A.kp_mask = pl.KP - 1; A.nparts = pl.nparts;
+  A.shift_part = pl.shift_part; A.kp_mask = pl.KP - 1; A.nparts = pl.nparts; A.cell_bits = pl.cell_bits;
   A.offs32 = offs32; A.part_start = part_start;
   A.recs = static_cast<unsigned long long *>(recs); A.ctr = ctr;
   A.ovf = ovf; A.ovf_count = ovf_count; A.ovf_cap = ovf_cap;
@@ -838,14 +876,15 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
     attr = true;
   }
   hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st);
-  const bool may_split = max_slices > pl.nparts + 1 || slots > kSliceRecords;  // some partition could exceed one slice
+  const bool may_split = slots > kSliceRecords;  // some partition could exceed one slice
+  TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks};
   if (op_max) {
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, pl.shift_part, pl.nparts, g, 0);
-    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, pl.shift_part, pl.nparts, g, 1);
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0);
+    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1);
     hipLaunchKernelGGL((k_apply_overflow<true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
   } else {
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, pl.shift_part, pl.nparts, g, 0);
-    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, pl.shift_part, pl.nparts, g, 1);
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0);
+    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1);
     hipLaunchKernelGGL((k_apply_overflow<false>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
   }
 }
