@@ -12,6 +12,8 @@
 // wavefront then owns one key at a time: it compacts the present points of the row (ballot +
 // popcount prefix), and runs the pair tests with lanes = points i and an LDS-broadcast x_j stream
 // — the O(n^2) compares never leave LDS/registers.
+#include <cstdlib>
+
 #include "tad_internal.h"
 
 namespace tad {
@@ -34,9 +36,10 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_tile(Grid g, double eps, in
 
   // ---- stage the tile: global (time-major, coalesced over keys) -> LDS (key-major rows) ----
   const uint64_t total = (uint64_t)KT * T;
+  const int kt_shift = __builtin_ctz((unsigned)KT);  // KT is a power of two
   for (uint64_t e = threadIdx.x; e < total; e += kDbBlock) {
-    const uint64_t t = e / KT;
-    const int kk = (int)(e % KT);
+    const uint64_t t = e >> kt_shift;
+    const int kk = (int)(e & (uint64_t)(KT - 1));
     uint8_t f = 0;
     double x = 0.0;
     if (kk < kt) {
@@ -160,8 +163,15 @@ static bool pick_tile(uint64_t T, int *KT, int *Tp, size_t *bytes) {
   const int tp = (int)(T | 1);  // odd row stride (in doubles): conflict-free transposed LDS writes
   auto need = [&](int kt) { return (size_t)kt * tp * 8 + (size_t)kDbWaves * T * 4 + (size_t)kt * T; };
   int kt = 0;
-  if (need(64) <= 64 * 1024) kt = 64;        // two or more workgroups per CU
-  else if (need(32) <= 80 * 1024) kt = 32;   // two workgroups per CU
+  // occupancy first: the pair loops are latency-bound (LDS broadcast reads), so aim at >= 4 workgroups (16 wavefronts)
+  // per CU; 16 keys still give 128-byte coalesced segments when the tile is staged from the time-major grid
+  const char *kt_env = getenv("TAD_DB_KT");  // tuning knob
+  const int kt_force = kt_env ? atoi(kt_env) : 0;
+  if (kt_force > 0 && (kt_force & (kt_force - 1)) == 0 && need(kt_force) <= 150 * 1024) kt = kt_force;
+  else if (need(64) <= 20 * 1024) kt = 64;   // measured at C4 (T = 100): 64 keys 1.96 ms, 32 keys 1.1 ms, 16 / 8 keys 0.95 ms
+  else if (need(32) <= 20 * 1024) kt = 32;
+  else if (need(16) <= 40 * 1024) kt = 16;
+  else if (need(8) <= 40 * 1024) kt = 8;
   else {
     for (int c = 64; c >= 1; c >>= 1)
       if (need(c) <= 150 * 1024) { kt = c; break; }
