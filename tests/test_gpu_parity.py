@@ -307,6 +307,39 @@ def test_device_resident_inputs_and_outputs(engine):
     assert engine.progress() == (4, 4)
 
 
+def test_concurrent_runs_from_four_threads(engine):
+    # controller.go:199-201 runs 4 workers; cgo pins an OS thread per call.  Runs on one engine serialise inside the
+    # library: four threads with different jobs must each get exactly their own result.
+    import threading
+    jobs = []
+    for i, algo in enumerate(["EWMA", "DBSCAN", "EWMA", "DBSCAN"]):
+        k, t, v = orc.synth_rows(1000 * i, 60000 + 7000 * i, 50 + 10 * i, 40)
+        jobs.append((algo, k, t, v, 50 + 10 * i, orc.run_job(algo, k, t, v, agg_flow="svc")))
+    out = [None] * 4
+    errs = []
+
+    def work(i):
+        try:
+            algo, k, t, v, K, _ = jobs[i]
+            for _ in range(3):
+                out[i] = engine.run(algo, k, t, v, K, agg_flow="svc", job_id="job-%d" % i)
+                assert engine.progress()[1] == 4
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    for i in range(4):
+        want = jobs[i][5]
+        assert out[i].id == "job-%d" % i and out[i].n_rows == want["n_anomalies"]
+        for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+            assert (out[i][f] == want[f]).all(), (i, f)
+
+
 # ------------------------------------------------------------------ (d) full-size properties (BASELINE C2 / C4)
 @pytest.mark.parametrize("algo,N,K,T,agg", [("EWMA", 100_000_000, 100_000, 250, "svc"), ("DBSCAN", 100_000_000, 1_000_000, 100, "")])
 def test_full_size_properties(engine, algo, N, K, T, agg):

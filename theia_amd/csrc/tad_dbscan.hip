@@ -194,11 +194,7 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples) {
   int KT, Tp;
   size_t bytes;
   if (!pick_tile(g.T, &KT, &Tp, &bytes)) return -1;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_dbscan_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    attr_set = true;
-  }
+  allow_big_lds(reinterpret_cast<const void *>(k_dbscan_tile), 152 * 1024);
   const uint64_t blocks = (g.K + KT - 1) / KT;
   hipLaunchKernelGGL(k_dbscan_tile, dim3((unsigned)blocks), dim3(kDbBlock), bytes, s, g, eps, min_samples, KT, Tp);
   return 0;

@@ -63,6 +63,13 @@ struct OutRows {
   uint8_t *anomaly;  // only with TAD_FLAG_EMIT_ALL_POINTS
 };
 
+// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute is per (function, device) in the HIP runtime and a
+// process may hold one engine per GPU (the Go controller does), so it is set — a cheap host call — before every
+// launch for the current device instead of being cached in a process-wide flag.
+inline void allow_big_lds(const void *kernel, size_t bytes) {
+  hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 // ---- launchers (tad_kernels.hip / tad_dbscan.hip / tad_arima.hip / tad_synth.hip) ----
 int launch_meta(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                 const int64_t *t_start, uint64_t n, RowFilter f, MetaPartial *partials, int n_blocks);

@@ -795,8 +795,7 @@ void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   const bool has2 = key2 != nullptr;
 #define TAD_MH(V, H2)                                                                                                  \
   do {                                                                                                                 \
-    static bool attr = false;                                                                                          \
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_meta_hist<V, H2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget); attr = true; } \
+    allow_big_lds(reinterpret_cast<const void *>(k_meta_hist<V, H2>), kLdsBudget);                                     \
     hipLaunchKernelGGL((k_meta_hist<V, H2>), dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n, \
                        pl.chunk, K, f, pl.shift_bin, pl.nbins, partials, binhist, ctr);                                \
   } while (0)
@@ -833,8 +832,7 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   const size_t lds = ((size_t)rpt * kPartThreads * (has2 ? 2 : 1) * 10 + fixed + 15) & ~(size_t)15;
 #define TAD_PART(RPT, H2, V, GEN)                                                                                       \
   do {                                                                                                                \
-    static bool attr = false;                                                                                         \
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_partition<RPT, H2, V, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget); attr = true; } \
+    allow_big_lds(reinterpret_cast<const void *>(k_partition<RPT, H2, V, GEN>), kLdsBudget);                           \
     hipLaunchKernelGGL((k_partition<RPT, H2, V, GEN>), dim3(pl.G), dim3(kPartThreads), lds, s, A);                       \
   } while (0)
   if (!generic) {
@@ -869,12 +867,7 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   st.slice_part = static_cast<uint32_t *>(slice_mem);
   st.slice_first = st.slice_part + max_slices;
   st.n_slices = st.slice_first + pl.nparts;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_aggregate<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
-    attr = true;
-  }
+  allow_big_lds(reinterpret_cast<const void *>(op_max ? k_tile_aggregate<true> : k_tile_aggregate<false>), kLdsBudget);
   hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st);
   const bool may_split = slots > kSliceRecords;  // some partition could exceed one slice
   TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks};
