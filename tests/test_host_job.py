@@ -73,6 +73,14 @@ def test_host_half_matches_string_oracle(case, algo):
         assert g == w
 
 
+def test_generate_tad_sql_query_equals_the_reference_goldens(golden):
+    # the reference's own parametrised test (anomaly_detection_test.py:46-195): 12 argument tuples -> exact SQL strings
+    assert len(golden["sql_cases"]) == 12
+    for case in golden["sql_cases"]:
+        start, end, ns, agg, label, ip, svc, name, namespace = case["args"]
+        assert ad.generate_tad_sql_query(start, end, ns, agg, label, ip, svc, name, namespace) == case["sql"], case["args"]
+
+
 def test_sentinel_row_when_nothing_is_anomalous():
     flows = jo.synth_flows(300)
     flows["throughput"] = np.full(300, 1000, dtype=np.uint64)     # constant: sigma 0, |x - e| > 0 only in EWMA warm-up

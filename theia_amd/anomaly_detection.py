@@ -116,6 +116,68 @@ def remove_meaningless_labels(podLabels):
 
 
 # ------------------------------------------------------------------------------------------------
+# The SQL of the reference job (ref:507-614), for a host that lets ClickHouse evaluate the WHERE clause and stream
+# the raw columns (or, as the reference does, the aggregated points).  String-identical to the reference's
+# generate_tad_sql_query — pinned by its 12 golden queries (anomaly_detection_test.py:46-195) in tests/test_host_job.py.
+# prepare_columns below evaluates the same predicates on a column dict.
+# ------------------------------------------------------------------------------------------------
+_SELECT = {   # mode -> (select list, group-by columns)
+    "": ("sourceIP, sourceTransportPort, destinationIP, destinationTransportPort, protocolIdentifier, flowStartSeconds, "
+         "flowEndSeconds, max(throughput)",
+         "sourceIP, sourceTransportPort, destinationIP, destinationTransportPort, protocolIdentifier, flowStartSeconds"),
+    "external": ("destinationIP, flowType, flowEndSeconds, sum(throughput)", "destinationIP, flowType"),
+    "svc": ("destinationServicePortName, flowEndSeconds, sum(throughput)", "destinationServicePortName"),
+}
+
+
+def _quoted_list(names):
+    return ", ".join("'{}'".format(x) for x in names)
+
+
+def generate_tad_sql_query(start_time, end_time, ns_ignore_list, agg_flow=None, pod_label=None, external_ip=None,
+                           svc_port_name=None, pod_name=None, pod_namespace=None):
+    ns_clause = ""
+    if ns_ignore_list:
+        ns_clause = "sourcePodNamespace NOT IN ({0}) AND destinationPodNamespace NOT IN ({0})".format(_quoted_list(ns_ignore_list))
+    if agg_flow == "pod":
+        ident, out = ("PodName", "podName") if (pod_name and not pod_label) else ("PodLabels", "podLabels")
+        halves = []
+        for side, direction in (("destination", "inbound"), ("source", "outbound")):
+            if pod_label:
+                cond = "ilike({}PodLabels, '%{}%')".format(side, pod_label) + (" " if side == "destination" else "")
+            elif pod_name:
+                cond = "{}PodName = '{}'".format(side, pod_name)
+            else:
+                cond = "{}PodLabels <> ''".format(side) + (" " if side == "destination" else "")
+            if (pod_label or pod_name) and pod_namespace:
+                cond += " AND {}PodNamespace = '{}'".format(side, pod_namespace)
+            halves.append("(SELECT {side}PodNamespace AS podNamespace, {side}{ident} AS {out}, '{direction}' AS direction, "
+                          "flowEndSeconds, sum(throughput) FROM {table} WHERE {cond} {ext} GROUP BY podNamespace, {out}, "
+                          "direction, flowEndSeconds)".format(side=side, ident=ident, out=out, direction=direction,
+                                                              table=table_name, cond=cond,
+                                                              ext=("AND " + ns_clause) if ns_clause else ""))
+        return "SELECT * FROM " + halves[0] + " UNION ALL " + halves[1] + " "
+    mode = agg_flow if agg_flow in ("external", "svc") else ""
+    select, group = _SELECT[mode]
+    where = [ns_clause] if ns_clause else []
+    if start_time:
+        where.append("flowStartSeconds >= '{}'".format(start_time))
+    if end_time:
+        where.append("flowEndSeconds < '{}'".format(end_time))
+    if mode == "external":
+        where.append("flowType = 3")
+        if external_ip:
+            where.append("destinationIP = '{}'".format(external_ip))
+    elif mode == "svc":
+        where.append("destinationServicePortName = '{}'".format(svc_port_name) if svc_port_name
+                     else "destinationServicePortName <> ''")
+    sql = "SELECT {} FROM {} ".format(select, table_name)
+    if where:
+        sql += "WHERE " + " AND ".join(where) + " "
+    return sql + "GROUP BY {}, flowEndSeconds ".format(group)
+
+
+# ------------------------------------------------------------------------------------------------
 # Stage 0, host half: WHERE predicates + dictionary encoding (ref:507-614)
 # ------------------------------------------------------------------------------------------------
 def _epoch(ts):
