@@ -9,8 +9,8 @@ Workload at N=1 = BASELINE.json configs[1]: EWMA on 1e8 rows / 1e5 flow keys / 2
 sum(throughput) (mode svc), the deterministic synthetic table of SURVEY.md §8d.
 N>1 (torchrun, one rank per GPU): weak scaling — every rank owns the key shard `key mod N == rank`
 (1e8 rows / 1e5 keys per rank, pre-sharded by key as SURVEY.md §8e allows), no data-path collective;
-per step one RCCL all-reduce of [anomalies, keys, points, rows] (the global `count() == 0` sentinel
-decision, anomaly_detection.py:395) and one all-gather of the (n, mean, M2) moments (global sigma).
+per step ONE RCCL all-gather of 9 doubles per rank: the counters [anomalies, keys, points, rows, ...] (the global
+`count() == 0` sentinel decision, anomaly_detection.py:395) and the (n, mean, M2) moments (global sigma).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (Stage-0 pass B, k_partition):
 achieved = 24 B/row x rows per launch / the kernel's average duration measured with HIP events on the
@@ -113,7 +113,7 @@ def main():
     def step():
         res = eng.run(args.algo, key, tend, val, K, agg_flow=args.agg, lattice=lattice, out="device")
         st = res.stats
-        glob = reducer.reduce(st) if world > 1 else None   # RCCL over xGMI: counters all-reduce + moments all-gather
+        glob = reducer.reduce(st) if world > 1 else None   # RCCL over xGMI: one 9-double all-gather (counters + moments)
         res.close()
         return st, glob
 
@@ -156,7 +156,7 @@ def main():
                                    % (args.algo, n, K, T, args.agg),
                        "algo": args.algo, "rows_per_gpu": n, "keys_per_gpu": K, "buckets": T,
                        "lattice": "hinted" if args.hint_lattice else "derived by the engine (extra pass over flow_end_s)",
-                       "parallelism": "key-sharded x%d, no data-path collective; all-reduce of counters + all-gather of moments" % world},
+                       "parallelism": "key-sharded x%d, no data-path collective; one 9-double all-gather per job (counters + moments)" % world},
             "roofline": {"bound": "hbm", "kernel": "k_partition (Stage-0 v2, row partition pass)" if st["stage0_path"] == 2 else "k_scatter (Stage-0 v1, direct atomics)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": BYTES_PER_ROW * n, "avg_kernel_ms": scatter_ms},
