@@ -85,7 +85,7 @@ def load_library(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    path = os.environ.get("TAD_LIBRARY_PATH") or _build.LIB_PATH   # override: A/B two builds of the library
     if not os.path.exists(path):
         if not build_if_missing:
             raise OSError("libtad_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
