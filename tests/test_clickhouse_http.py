@@ -1,0 +1,195 @@
+"""The ClickHouse HTTP transport (theia_amd/clickhouse.py) against an in-process server that speaks the two formats it
+uses: `SELECT ... FORMAT ArrowStream` out, `INSERT ... FORMAT JSONEachRow` in.  CPU tests cover the transport, the
+SQL it sends and the raw-rows / pushdown equivalence of the host half; the GPU test runs the CLI end to end."""
+import base64
+import io
+import json
+import threading
+import urllib.parse
+from http.server import BaseHTTPRequestHandler, HTTPServer
+
+import numpy as np
+import pandas as pd
+import pyarrow as pa
+import pyarrow.ipc as ipc
+import pytest
+
+from oracle import job_oracle as jo
+from oracle import tad_oracle as orc
+from theia_amd import anomaly_detection as ad
+from theia_amd import clickhouse as ch
+
+from test_host_job import FakeResult, canon, oracle_middle
+
+
+class FakeClickHouse:
+    """Answers a SELECT by looking the SQL text up in `responses` (exact match), records INSERTed rows."""
+
+    def __init__(self):
+        self.responses = {}
+        self.queries, self.inserted, self.auth = [], [], []
+        owner = self
+
+        class Handler(BaseHTTPRequestHandler):
+            def log_message(self, *a):
+                pass
+
+            def do_POST(self):
+                body = self.rfile.read(int(self.headers.get("Content-Length", 0)))
+                params = urllib.parse.parse_qs(urllib.parse.urlparse(self.path).query)
+                owner.auth.append(self.headers.get("Authorization"))
+                if "query" in params and params["query"][0].startswith("INSERT INTO"):
+                    owner.inserted.append((params["query"][0], [json.loads(l) for l in body.decode().splitlines() if l]))
+                    self.send_response(200); self.end_headers(); return
+                sql = body.decode()
+                owner.queries.append(sql)
+                assert sql.endswith(" FORMAT ArrowStream")
+                key = sql[: -len(" FORMAT ArrowStream")]
+                known = {k.rstrip(): v for k, v in owner.responses.items()}   # the client strips the SQL's trailing blank
+                if key not in known:
+                    self.send_response(404); self.end_headers(); self.wfile.write(b"unknown query"); return
+                table = known[key]
+                sink = io.BytesIO()
+                with ipc.new_stream(sink, table.schema) as w:
+                    w.write_table(table)
+                self.send_response(200); self.end_headers(); self.wfile.write(sink.getvalue())
+
+        self.httpd = HTTPServer(("127.0.0.1", 0), Handler)
+        self.url = "http://127.0.0.1:%d" % self.httpd.server_address[1]
+        self.thread = threading.Thread(target=self.httpd.serve_forever, daemon=True)
+        self.thread.start()
+
+    def close(self):
+        self.httpd.shutdown()
+
+
+def arrow_table(cols):
+    """column dict -> Arrow table typed the way ClickHouse types default.flows (create_table.sh:31-85)."""
+    arrays = {}
+    for name, v in cols.items():
+        v = np.asarray(v)
+        if name.endswith("Seconds"):
+            arrays[name] = pa.array(v.astype("datetime64[s]"), pa.timestamp("s"))      # DateTime
+        elif name in ("throughput", "max(throughput)", "sum(throughput)"):
+            arrays[name] = pa.array(v.astype(np.uint64), pa.uint64())
+        elif v.dtype.kind in "iu":
+            arrays[name] = pa.array(v.astype(np.uint16), pa.uint16())
+        else:
+            arrays[name] = pa.array(v.astype(str).tolist(), pa.string())
+    return pa.table(arrays)
+
+
+@pytest.fixture()
+def server():
+    s = FakeClickHouse()
+    yield s
+    s.close()
+
+
+KW = dict(start_time="", end_time="", ns_ignore_list=(), agg_flow="", pod_label="", external_ip="", svc_port_name="",
+          pod_name="", pod_namespace="")
+CASES = [dict(agg_flow="svc"), dict(agg_flow="external", external_ip="52.1.1.2"), dict(agg_flow="", end_time="2022-08-11 08:00:00"),
+         dict(agg_flow="pod", pod_label="app1"), dict(agg_flow="pod", pod_name="pod-2", pod_namespace="flow-visibility"),
+         dict(agg_flow="pod", ns_ignore_list=["kube-system"])]
+
+
+def test_jdbc_url_and_basic_auth(server, monkeypatch):
+    assert ch.jdbc_to_http("jdbc:clickhouse://clickhouse-clickhouse.flow-visibility.svc:8123") == \
+        "http://clickhouse-clickhouse.flow-visibility.svc:8123"
+    with pytest.raises(ValueError):
+        ch.jdbc_to_http("mysql://x")
+    monkeypatch.setenv("CH_USERNAME", "u1")
+    monkeypatch.setenv("CH_PASSWORD", "p1")          # controller.go:649-658: credentials arrive in the environment
+    server.responses["SELECT 1"] = pa.table({"1": pa.array([1], pa.uint8())})
+    out = ch.ClickHouseHTTP(server.url).query_columns("SELECT 1")
+    assert out["1"].tolist() == [1]
+    assert server.auth[-1] == "Basic " + base64.b64encode(b"u1:p1").decode()
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join("%s=%s" % kv for kv in c.items()))
+def test_raw_rows_and_pushdown_reads_give_the_same_job(server, case):
+    flows = jo.synth_flows(5000)
+    kw = dict(KW); kw.update(case)
+    args = (kw["start_time"], kw["end_time"], list(kw["ns_ignore_list"]), kw["agg_flow"], kw["pod_label"], kw["external_ip"],
+            kw["svc_port_name"], kw["pod_name"], kw["pod_namespace"])
+    client = ch.ClickHouseHTTP(server.url, user="", password="")
+    # raw rows: the server ignores the WHERE clause (it returns every row of the requested columns); the host applies
+    # the same predicates again, so the result cannot depend on how much ClickHouse filtered
+    sql_rows = ch.rows_query(*args)
+    want_cols = sql_rows[len("SELECT "):sql_rows.index(" FROM ")].split(", ")
+    server.responses[sql_rows] = arrow_table({c: flows[c] for c in want_cols})
+    got_flows = ch.fetch_flows(client, *args)
+    prep = ad.prepare_columns(got_flows, **kw)
+    rows_raw = ad.result_rows(prep, FakeResult(oracle_middle(prep, "EWMA", kw["agg_flow"])), "EWMA", kw["agg_flow"], "j")
+    # pushdown: the reference SQL, answered with what that SQL computes (pandas restatement in the oracle)
+    sql_push = ad.generate_tad_sql_query(*args)
+    pts, keys = jo.stage0_sql(pd.DataFrame({k: np.asarray(v) for k, v in flows.items()}), *args[:2], args[2], *args[3:])
+    agg_name = "max(throughput)" if kw["agg_flow"] == "" else "sum(throughput)"
+    cols = {k: pts[k].to_numpy() for k in keys}
+    cols["flowEndSeconds"] = pts["flowEndSeconds"].to_numpy()
+    cols[agg_name] = pts["v"].to_numpy()
+    if kw["agg_flow"] == "external":
+        cols["flowType"] = np.full(len(pts), 3)
+    server.responses[sql_push] = arrow_table(cols)
+    pushed = ch.fetch_points(client, sql_push, kw["agg_flow"], kw["pod_name"])
+    kw2 = dict(kw, start_time="", end_time="", ns_ignore_list=())
+    prep2 = ad.prepare_columns(pushed, **kw2)
+    rows_push = ad.result_rows(prep2, FakeResult(oracle_middle(prep2, "EWMA", kw["agg_flow"])), "EWMA", kw["agg_flow"], "j")
+    want = jo.run(flows, "EWMA", tad_id="j", **kw)
+    for r in want:
+        sd = r["throughputStandardDeviation"]
+        r["throughputStandardDeviation"] = 0.0 if sd is None else float(sd)
+    assert canon(rows_raw) == canon(want)
+    assert canon(rows_push) == canon(want)
+    assert "WHERE" in sql_rows or not any(args[:3]) and kw["agg_flow"] == ""
+
+
+def test_rows_query_where_clause():
+    q = ch.rows_query("2022-01-01 00:00:00", "2022-01-02 00:00:00", ["a", "b"], "svc", "", "", "http", "", "")
+    assert q == ("SELECT destinationServicePortName, flowStartSeconds, flowEndSeconds, throughput, sourcePodNamespace, "
+                 "destinationPodNamespace FROM default.flows WHERE sourcePodNamespace NOT IN ('a', 'b') AND "
+                 "destinationPodNamespace NOT IN ('a', 'b') AND flowStartSeconds >= '2022-01-01 00:00:00' AND "
+                 "flowEndSeconds < '2022-01-02 00:00:00' AND destinationServicePortName = 'http'")
+    q = ch.rows_query("2022-01-01 00:00:00", "", [], "pod", "", "", "", "p1", "ns1")
+    assert "flowStartSeconds >=" not in q        # the pod SQL carries no time window (anomaly_detection.py:556-565)
+    assert "(destinationPodName = 'p1' AND destinationPodNamespace = 'ns1') OR (sourcePodName = 'p1' AND sourcePodNamespace = 'ns1')" in q
+
+
+def test_insert_rows_json_each_row(server):
+    client = ch.ClickHouseHTTP(server.url, user="", password="")
+    rows = [ad._db_row({"destinationServicePortName": "s", "flowEndSeconds": 1660202814, "throughputStandardDeviation": 1.5,
+                        "aggType": "svc", "algoType": "EWMA", "algoCalc": 2.0, "throughput": 9.0, "anomaly": "true", "id": "x"})]
+    assert client.insert_rows(rows) == 1
+    q, got = server.inserted[-1]
+    assert q == "INSERT INTO default.tadetector FORMAT JSONEachRow"
+    assert got[0]["flowEndSeconds"] == "2022-08-11 07:26:54" and got[0]["id"] == "x"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pushdown", [False, True])
+def test_cli_against_clickhouse_http(engine, server, pushdown):
+    ad.set_engine(engine)
+    try:
+        flows = jo.synth_flows(4000)
+        args = ("", "", [], "svc", "", "", "", "", "")
+        if pushdown:
+            sql = ad.generate_tad_sql_query(*args)
+            pts, keys = jo.stage0_sql(pd.DataFrame({k: np.asarray(v) for k, v in flows.items()}), "", "", [], "svc")
+            server.responses[sql] = arrow_table({"destinationServicePortName": pts["destinationServicePortName"].to_numpy(),
+                                                 "flowEndSeconds": pts["flowEndSeconds"].to_numpy(), "sum(throughput)": pts["v"].to_numpy()})
+        else:
+            sql = ch.rows_query(*args)
+            cols = sql[len("SELECT "):sql.index(" FROM ")].split(", ")
+            server.responses[sql] = arrow_table({c: flows[c] for c in cols})
+        argv = ["--algo", "EWMA", "--agg-flow", "svc", "--id", "c-1", "--db_jdbc_url", server.url] + (["--pushdown-groupby"] if pushdown else [])
+        assert ad.main(argv) == "c-1"
+        want = jo.run(flows, "EWMA", tad_id="c-1", agg_flow="svc")
+        q, got = server.inserted[-1]
+        assert q == "INSERT INTO default.tadetector FORMAT JSONEachRow" and len(got) == len(want)
+        key = lambda r: (r["destinationServicePortName"], r["flowEndSeconds"] if isinstance(r["flowEndSeconds"], str) else
+                         ad._db_row(r)["flowEndSeconds"])
+        w = {key(r): r for r in want}
+        for r in got:
+            assert w[key(r)]["algoCalc"] == r["algoCalc"] and w[key(r)]["throughput"] == r["throughput"]
+    finally:
+        ad.set_engine(None)

@@ -119,7 +119,7 @@ def test_prepare_columns_key_ids_are_dense_and_rejected_rows_are_skipped():
 
 def test_cli_rejects_bad_arguments_with_exit_code_2():
     for argv in (["--algo", "LSTM"], ["--start_time", "yesterday"], ["--end_time", "2022-13-01 00:00:00"],
-                 ["--ns_ignore_list", '{"a": 1}'], ["--bogus"], ["--algo", "EWMA"]):   # last: no --flows
+                 ["--ns_ignore_list", '{"a": 1}'], ["--bogus"], ["--flows", "x.npz"], ["--db_jdbc_url", "ftp://x"]):   # no --algo; bad url
         with pytest.raises(SystemExit) as exc:
             ad.main(argv)
         assert exc.value.code == 2

@@ -358,9 +358,11 @@ def result_rows(prep, res, algo_type, agg_flow, tad_id):
 
 def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_ignore_list, agg_flow=None,
                       pod_label=None, external_ip=None, svc_port_name=None, pod_name=None, pod_namespace=None,
-                      engine=None):
-    """ref:647-710.  `flows` (a column dict, or a path for load_flows) stands where the reference has the
-    JDBC address.  Returns (stats dict, list of result rows)."""
+                      engine=None, pushdown=False):
+    """ref:647-710.  `flows` stands where the reference has the JDBC address: a column dict, a path for load_flows,
+    or a theia_amd.clickhouse.ClickHouseHTTP client (then the rows come over ClickHouse's HTTP interface as Arrow
+    batches; pushdown=True lets ClickHouse run the reference's GROUP BY and ships aggregated points instead).
+    Returns (stats dict, list of result rows)."""
     if algo_type not in VALID_ALGOS:
         raise ValueError("Algorithm should be in {}".format(" or ".join(VALID_ALGOS)))
     agg_flow = agg_flow or ""
@@ -368,6 +370,15 @@ def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_i
         raise ValueError("aggregated flow type should be 'pod' or 'external' or 'svc'")
     if isinstance(flows, str):
         flows = load_flows(flows)
+    elif hasattr(flows, "query_columns"):   # ClickHouse over HTTP (ref:651-662 reads through JDBC)
+        from . import clickhouse as ch
+        args = (start_time or "", end_time or "", list(ns_ignore_list or ()), agg_flow, pod_label or "", external_ip or "",
+                svc_port_name or "", pod_name or "", pod_namespace or "")
+        if pushdown:
+            flows = ch.fetch_points(flows, generate_tad_sql_query(*args), agg_flow, pod_name or "")
+            start_time, end_time, ns_ignore_list = "", "", ()   # ClickHouse has applied them already
+        else:
+            flows = ch.fetch_flows(flows, *args)
     prep = prepare_columns(flows, start_time or "", end_time or "", ns_ignore_list or (), agg_flow, pod_label or "",
                            external_ip or "", svc_port_name or "", pod_name or "", pod_namespace or "")
     eng = engine or get_engine()
@@ -400,6 +411,16 @@ def write_anomaly_detection_result(result_rows_, destination, result_table_name=
     return tad_id
 
 
+def _db_row(row):
+    """A result row as ClickHouse's JSONEachRow wants it: DateTime columns as 'YYYY-MM-DD hh:mm:ss' (UTC)."""
+    out = {k: row[k] for k in RESULT_COLUMNS if k in row}
+    for col in ("flowEndSeconds", "flowStartSeconds"):
+        v = out.get(col)
+        if isinstance(v, (int, np.integer)):
+            out[col] = datetime.fromtimestamp(int(v), tz=timezone.utc).strftime(TIME_FORMAT)
+    return out
+
+
 def load_flows(path):
     """.npz (numpy), .parquet / .csv (pyarrow) -> column dict; DateTime columns as epoch seconds."""
     if path.endswith(".npz"):
@@ -428,9 +449,12 @@ HELP_MESSAGE = """
         Options:
         -h, --help: Show help message.
         -a, --algo=EWMA: EWMA, ARIMA or DBSCAN.
-        -d, --db_jdbc_url=None: accepted for compatibility; the ClickHouse transport is not part of this engine.
-        -F, --flows=PATH: flow table (.npz / .parquet / .csv with the columns of default.flows).
-        -o, --out=PATH: where the tadetector rows are appended as JSON lines (default stdout).
+        -d, --db_jdbc_url=URL: ClickHouse (jdbc:clickhouse://host:8123 or http://host:8123); flow records are read
+            and results appended over its HTTP interface with CH_USERNAME / CH_PASSWORD.  Default
+            jdbc:clickhouse://clickhouse-clickhouse.flow-visibility.svc:8123 when --flows is not given.
+        -G, --pushdown-groupby: let ClickHouse run the GROUP BY (the reference's SQL) and ship aggregated points.
+        -F, --flows=PATH: read the flow table from a file instead (.npz / .parquet / .csv, columns of default.flows).
+        -o, --out=PATH: append the tadetector rows as JSON lines to PATH instead of inserting them ('-' = stdout).
         -s, --start_time=None / -e, --end_time=None: 'YYYY-MM-DD hh:mm:ss' UTC.
         -i, --id=None: job id (uuid); generated when missing.
         -n, --ns_ignore_list=[]: JSON list of namespaces to ignore.
@@ -443,16 +467,16 @@ def main(argv=None):
     """ref:729-900: same options, same exit codes (2 on a bad argument)."""
     argv = sys.argv[1:] if argv is None else argv
     try:
-        opts, _ = getopt.getopt(argv, "ha:d:s:e:i:n:f:l:x:p:N:P:F:o:",
+        opts, _ = getopt.getopt(argv, "ha:d:s:e:i:n:f:l:x:p:N:P:F:o:G",
                                 ["help", "algo=", "db_jdbc_url=", "start_time=", "end_time=", "id=", "ns_ignore_list=",
-                                 "agg-flow=", "pod-label=", "external-ip=", "svc-port-name=", "pod-name=",
-                                 "pod-namespace=", "flows=", "out="])
+                                 "ns-ignore-list=", "agg-flow=", "pod-label=", "external-ip=", "svc-port-name=", "pod-name=",
+                                 "pod-namespace=", "flows=", "out=", "pushdown-groupby"])
     except getopt.GetoptError as exc:
         logger.error("ERROR of getopt.getopt: %s", exc)
         logger.info(HELP_MESSAGE)
         sys.exit(2)
     a = {"algo": "", "start": "", "end": "", "id": None, "ns": [], "agg": "", "label": "", "ip": "", "svc": "",
-         "name": "", "namespace": "", "flows": "", "out": ""}
+         "name": "", "namespace": "", "flows": "", "out": "", "db": "", "pushdown": False}
 
     def bad(msg):
         logger.error(msg)
@@ -468,8 +492,11 @@ def main(argv=None):
                 bad("Algorithm should be in {}".format(" or ".join(VALID_ALGOS)))
             a["algo"] = arg
         elif opt in ("-d", "--db_jdbc_url"):
-            if not arg.startswith("jdbc:"):
+            if not (arg.startswith("jdbc:") or arg.startswith("http://") or arg.startswith("https://")):
                 bad("Please provide a valid JDBC url for ClickHouse database")
+            a["db"] = arg
+        elif opt in ("-G", "--pushdown-groupby"):
+            a["pushdown"] = True
         elif opt in ("-s", "--start_time", "-e", "--end_time"):
             which = "start" if opt in ("-s", "--start_time") else "end"
             try:
@@ -477,7 +504,7 @@ def main(argv=None):
             except ValueError:
                 bad("{}_time should be in 'YYYY-MM-DD hh:mm:ss' format.".format(which))
             a[which] = arg
-        elif opt in ("-n", "--ns_ignore_list"):
+        elif opt in ("-n", "--ns_ignore_list", "--ns-ignore-list"):   # the controller passes --ns-ignore-list (controller.go:548)
             lst = json.loads(arg)
             if not isinstance(lst, list):
                 bad("ns_ignore_list should be a list.")
@@ -500,19 +527,26 @@ def main(argv=None):
             a["flows"] = arg
         elif opt in ("-o", "--out"):
             a["out"] = arg
-    if not a["flows"]:
-        bad("--flows is required: this engine does not open the ClickHouse connection itself")
+    if not a["algo"]:
+        bad("Algorithm should be in {}".format(" or ".join(VALID_ALGOS)))
     tad_id = a["id"] or str(uuid.uuid4())
+    client = None
+    if not a["flows"] or (a["db"] and not a["out"]):
+        from . import clickhouse as ch
+        client = ch.ClickHouseHTTP(a["db"] or ch.DEFAULT_JDBC_URL)
     t0 = time.time()
     logger.info("Script started at %s", datetime.now().strftime("%a, %d %B %Y %H:%M:%S"))
     try:
-        _, rows = anomaly_detection(a["algo"] or "EWMA", a["flows"], a["start"], a["end"], tad_id, a["ns"], a["agg"],
-                                    a["label"], a["ip"], a["svc"], a["name"], a["namespace"])
-    except (TadError, ValueError) as exc:
+        _, rows = anomaly_detection(a["algo"], a["flows"] or client, a["start"], a["end"], tad_id, a["ns"], a["agg"],
+                                    a["label"], a["ip"], a["svc"], a["name"], a["namespace"], pushdown=a["pushdown"])
+    except (TadError, ValueError, OSError) as exc:
         logger.error("Anomaly Detection failed: %s", exc)
         sys.exit(1)
     t1 = time.time()
-    write_anomaly_detection_result(rows, a["out"] if a["out"] else sys.stdout, RESULT_TABLE_NAME, tad_id)
+    if a["out"] or client is None:
+        write_anomaly_detection_result(rows, sys.stdout if a["out"] in ("", "-") else a["out"], RESULT_TABLE_NAME, tad_id)
+    else:   # ref:713-726: append to default.tadetector
+        client.insert_rows([_db_row(r) for r in rows], RESULT_TABLE_NAME)
     logger.info("Anomaly Detection completed, id: %s, in %s seconds ", tad_id, t1 - t0)
     return tad_id
 

@@ -1,0 +1,181 @@
+"""ClickHouse transport for the Throughput Anomaly Detection host.
+
+The reference job reads `default.flows` and appends to `default.tadetector` through Spark's JDBC source over one
+connection (anomaly_detection.py:651-662, 713-726; URL `jdbc:clickhouse://clickhouse-clickhouse.flow-visibility.svc:8123`,
+:730-731; credentials in CH_USERNAME / CH_PASSWORD, controller.go:649-658).  Port 8123 is ClickHouse's HTTP interface,
+which speaks columnar formats directly: this module POSTs the query with `FORMAT ArrowStream` and hands the Arrow
+record batches to numpy without a row-by-row decode, and appends results with `INSERT ... FORMAT JSONEachRow`.
+Only the standard library (urllib) and pyarrow are used.
+
+Two ways to read (both end in the same numbers):
+  * raw rows  — SELECT of the mode's key columns, flowEndSeconds, flowStartSeconds, throughput with the WHERE clause
+    of the reference SQL; the GPU engine does the GROUP BY (Stage 0).  `rows_query`.
+  * pushdown  — the reference's own SQL (generate_tad_sql_query): ClickHouse aggregates, the engine receives points.
+    Re-aggregating points with the same operator is the identity, so tad_run works unchanged on them.
+
+Not verified against a live ClickHouse server (none in the build image): tests/test_clickhouse_http.py runs it
+against an in-process HTTP server that speaks the same two formats.
+"""
+import base64
+import io
+import json
+import os
+import urllib.parse
+import urllib.request
+
+import numpy as np
+
+DEFAULT_JDBC_URL = "jdbc:clickhouse://clickhouse-clickhouse.flow-visibility.svc:8123"   # anomaly_detection.py:730-731
+FLOWS_TABLE = "default.flows"
+RESULT_TABLE = "default.tadetector"
+
+
+def jdbc_to_http(url):
+    """'jdbc:clickhouse://host:8123[/db]' -> 'http://host:8123'; http(s) URLs pass through."""
+    if url.startswith("jdbc:clickhouse://"):
+        rest = url[len("jdbc:clickhouse://"):]
+        return "http://" + rest.split("/", 1)[0]
+    if url.startswith("http://") or url.startswith("https://"):
+        return url.rstrip("/")
+    raise ValueError("Please provide a valid JDBC url for ClickHouse database")   # anomaly_detection.py:823-829
+
+
+class ClickHouseHTTP:
+    def __init__(self, url=DEFAULT_JDBC_URL, user=None, password=None, timeout=600):
+        self.base = jdbc_to_http(url)
+        self.user = user if user is not None else os.getenv("CH_USERNAME")
+        self.password = password if password is not None else os.getenv("CH_PASSWORD")
+        self.timeout = timeout
+
+    def _post(self, params, body):
+        req = urllib.request.Request(self.base + "/?" + urllib.parse.urlencode(params), data=body, method="POST")
+        if self.user:
+            token = base64.b64encode(("%s:%s" % (self.user, self.password or "")).encode()).decode()
+            req.add_header("Authorization", "Basic " + token)
+        with urllib.request.urlopen(req, timeout=self.timeout) as resp:
+            return resp.read()
+
+    def query_columns(self, sql):
+        """Run a SELECT, return {column name: numpy array}.  DateTime -> int64 epoch seconds, String -> str."""
+        import pyarrow as pa
+        import pyarrow.ipc as ipc
+        raw = self._post({"output_format_arrow_string_as_string": 1}, (sql.rstrip() + " FORMAT ArrowStream").encode())
+        if not raw:
+            return {}
+        table = ipc.open_stream(io.BytesIO(raw)).read_all()
+        out = {}
+        for name in table.column_names:
+            col = table.column(name)
+            t = col.type
+            if pa.types.is_timestamp(t):
+                out[name] = col.cast(pa.timestamp("s")).cast(pa.int64()).to_numpy()
+            elif pa.types.is_binary(t) or pa.types.is_large_binary(t):
+                out[name] = np.asarray([b.decode() if b is not None else "" for b in col.to_pylist()], dtype=object).astype(str)
+            elif pa.types.is_string(t) or pa.types.is_large_string(t):
+                out[name] = np.asarray(col.to_pylist(), dtype=object).astype(str)
+            else:
+                out[name] = col.to_numpy(zero_copy_only=False)
+        return out
+
+    def insert_rows(self, rows, table=RESULT_TABLE):
+        """Append dict rows (INSERT ... FORMAT JSONEachRow); columns a row lacks take the table defaults."""
+        if not rows:
+            return 0
+        body = "\n".join(json.dumps(r) for r in rows).encode()
+        self._post({"query": "INSERT INTO %s FORMAT JSONEachRow" % table, "date_time_input_format": "best_effort"}, body)
+        return len(rows)
+
+
+# raw columns each mode needs (create_table.sh:31-85)
+_RAW_COLUMNS = {
+    "": ["sourceIP", "sourceTransportPort", "destinationIP", "destinationTransportPort", "protocolIdentifier",
+         "flowStartSeconds", "flowEndSeconds", "throughput", "sourcePodNamespace", "destinationPodNamespace"],
+    "external": ["destinationIP", "flowType", "flowStartSeconds", "flowEndSeconds", "throughput", "sourcePodNamespace",
+                 "destinationPodNamespace"],
+    "svc": ["destinationServicePortName", "flowStartSeconds", "flowEndSeconds", "throughput", "sourcePodNamespace",
+            "destinationPodNamespace"],
+    "pod": ["sourcePodNamespace", "destinationPodNamespace", "sourcePodLabels", "destinationPodLabels", "sourcePodName",
+            "destinationPodName", "flowStartSeconds", "flowEndSeconds", "throughput"],
+}
+
+
+def rows_query(start_time, end_time, ns_ignore_list, agg_flow=None, pod_label=None, external_ip=None, svc_port_name=None,
+               pod_name=None, pod_namespace=None):
+    """SELECT of the raw rows the job needs: the WHERE clause of the reference SQL (anomaly_detection.py:507-614) without
+    its GROUP BY.  Pod mode keeps a row if EITHER side passes its condition (the UNION ALL of :556-565 reads each
+    side separately); the host applies the per-side predicates again when it builds the two keys."""
+    mode = agg_flow if agg_flow in ("pod", "external", "svc") else ""
+    where = []
+    if ns_ignore_list:
+        quoted = ", ".join("'{}'".format(x) for x in ns_ignore_list)
+        where.append("sourcePodNamespace NOT IN ({0}) AND destinationPodNamespace NOT IN ({0})".format(quoted))
+    if mode == "pod":
+        sides = []
+        for side in ("destination", "source"):
+            if pod_label:
+                cond = "ilike({}PodLabels, '%{}%')".format(side, pod_label)
+            elif pod_name:
+                cond = "{}PodName = '{}'".format(side, pod_name)
+            else:
+                cond = "{}PodLabels <> ''".format(side)
+            if (pod_label or pod_name) and pod_namespace:
+                cond = "({} AND {}PodNamespace = '{}')".format(cond, side, pod_namespace)
+            sides.append(cond)
+        where.append("(" + " OR ".join(sides) + ")")   # the pod SQL has no time-window predicate (:556-565)
+    else:
+        if start_time:
+            where.append("flowStartSeconds >= '{}'".format(start_time))
+        if end_time:
+            where.append("flowEndSeconds < '{}'".format(end_time))
+        if mode == "external":
+            where.append("flowType = 3")
+            if external_ip:
+                where.append("destinationIP = '{}'".format(external_ip))
+        elif mode == "svc":
+            where.append("destinationServicePortName = '{}'".format(svc_port_name) if svc_port_name
+                         else "destinationServicePortName <> ''")
+    sql = "SELECT {} FROM {}".format(", ".join(_RAW_COLUMNS[mode]), FLOWS_TABLE)
+    if where:
+        sql += " WHERE " + " AND ".join(where)
+    return sql
+
+
+def fetch_flows(client, start_time="", end_time="", ns_ignore_list=(), agg_flow="", pod_label="", external_ip="",
+                svc_port_name="", pod_name="", pod_namespace=""):
+    """Raw-rows read: the column dict theia_amd.anomaly_detection.prepare_columns expects."""
+    flows = client.query_columns(rows_query(start_time, end_time, list(ns_ignore_list), agg_flow, pod_label, external_ip,
+                                            svc_port_name, pod_name, pod_namespace))
+    if not flows:   # empty result: ArrowStream carries no batch
+        mode = agg_flow if agg_flow in ("pod", "external", "svc") else ""
+        flows = {c: np.zeros(0, dtype=np.int64 if c.endswith("Seconds") or c in ("flowType", "throughput") else str)
+                 for c in _RAW_COLUMNS[mode]}
+    if "throughput" in flows:
+        flows["throughput"] = np.asarray(flows["throughput"]).astype(np.uint64)
+    return flows
+
+
+def fetch_points(client, sql, agg_flow="", pod_name=""):
+    """Pushdown read: run the reference's GROUP BY SQL, return the aggregated points as a column dict shaped like raw
+    rows, so that prepare_columns / tad_run treat them as (already aggregated) rows.  The aggregate column
+    `max(throughput)` / `sum(throughput)` becomes `throughput`."""
+    cols = client.query_columns(sql)
+    for agg in ("max(throughput)", "sum(throughput)"):
+        if agg in cols:
+            cols["throughput"] = np.asarray(cols.pop(agg)).astype(np.uint64)
+    if agg_flow == "pod" and cols:
+        # the SQL already produced (podNamespace, podLabels | podName, direction): present them as the inbound /
+        # outbound halves prepare_columns looks for, a row belonging to exactly one half
+        ident = "podName" if "podName" in cols else "podLabels"
+        inbound = np.asarray(cols["direction"]).astype(str) == "inbound"
+        ns, idv = np.asarray(cols["podNamespace"]).astype(str), np.asarray(cols[ident]).astype(str)
+        tail = ident[3:]   # Name | Labels
+        miss = "\x00not-this-side"   # never equals a pod name, never matches a label pattern ... and is not ''
+        cols["destinationPodNamespace"] = np.where(inbound, ns, "")
+        cols["sourcePodNamespace"] = np.where(inbound, "", ns)
+        cols["destinationPod" + tail] = np.where(inbound, idv, miss if tail == "Name" else "")
+        cols["sourcePod" + tail] = np.where(inbound, miss if tail == "Name" else "", idv)
+        other = "Labels" if tail == "Name" else "Name"
+        cols["destinationPod" + other] = np.full(ns.size, "")
+        cols["sourcePod" + other] = np.full(ns.size, "")
+        cols["flowStartSeconds"] = np.asarray(cols["flowEndSeconds"], dtype=np.int64)
+    return cols
