@@ -238,6 +238,45 @@ void launch_scatter(hipStream_t s, const uint64_t *key, const uint64_t *key2, co
 // ------------------------------------------------------------------------------------------------
 static constexpr int kUnroll = 16;  // independent loads in flight per lane: the per-key walks are HBM-latency bound
 
+// Walk one key's column of the time-major grid in time order, calling step(t, flag, raw_value) for every bucket.
+// The walk is a dependency chain per lane fed by HBM: it is software-pipelined — the loads of chunk c+1 are
+// issued before chunk c is consumed, in fixed numbers (the last chunk re-loads itself) so that hipcc can wait with
+// vmcnt(N > 0) instead of draining the pipe.  kWalkChunk buckets = 2 loads each; two chunks stay in flight.
+static constexpr int kWalkChunk = 8;
+
+template <typename Step>
+__device__ __forceinline__ void walk_series(const Grid &g, uint64_t k, Step step) {
+  const uint64_t T = g.T;
+  const uint64_t nfull = T / kWalkChunk;
+  uint8_t fa[kWalkChunk], fb[kWalkChunk];
+  unsigned long long va[kWalkChunk], vb[kWalkChunk];
+  auto load = [&](uint64_t c, uint8_t *f, unsigned long long *v) {
+#pragma unroll
+    for (int u = 0; u < kWalkChunk; ++u) {
+      const uint64_t cell = (c * kWalkChunk + u) * g.K + k;
+      f[u] = g.flag[cell];
+      v[u] = g.val[cell];
+    }
+  };
+  if (nfull) {
+    load(0, fa, va);
+    uint64_t c = 0;
+    for (; c + 2 <= nfull; c += 2) {
+      load(c + 1, fb, vb);
+#pragma unroll
+      for (int u = 0; u < kWalkChunk; ++u) step(c * kWalkChunk + u, fa[u], va[u]);
+      load(c + 2 < nfull ? c + 2 : c + 1, fa, va);   // past the end: a redundant in-bounds reload keeps the count fixed
+#pragma unroll
+      for (int u = 0; u < kWalkChunk; ++u) step((c + 1) * kWalkChunk + u, fb[u], vb[u]);
+    }
+    if (c < nfull) {
+#pragma unroll
+      for (int u = 0; u < kWalkChunk; ++u) step(c * kWalkChunk + u, fa[u], va[u]);
+    }
+  }
+  for (uint64_t t = nfull * kWalkChunk; t < T; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
+}
+
 template <bool EWMA_COUNT>
 __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, const double *__restrict__ rcp, double *__restrict__ sigma,
                                                       uint32_t *__restrict__ n_pts,
@@ -249,39 +288,17 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, cons
   if (k < g.K) {
     double cnt = 0.0, avg = 0.0, m2 = 0.0;
     uint32_t n = 0;
-    uint64_t t = 0;
-    for (; t + kUnroll <= g.T; t += kUnroll) {
-      uint8_t fl[kUnroll];
-      unsigned long long v[kUnroll];
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        fl[u] = g.flag[(t + u) * g.K + k];
-        v[u] = g.val[(t + u) * g.K + k];
-      }
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        if (fl[u] & FLAG_PRESENT) {
-          const double x = (double)v[u];
-          cnt = cnt + 1.0;
-          n++;
-          const double d = x - avg;
-          const double dn = div_by_count(d, cnt, rcp[n]);  // == d / cnt, bit for bit
-          avg = avg + dn;
-          m2 = m2 + d * (d - dn);
-        }
-      }
-    }
-    for (; t < g.T; ++t) {
-      if (g.flag[t * g.K + k] & FLAG_PRESENT) {
-        const double x = (double)g.val[t * g.K + k];
+    walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
+      if (fl & FLAG_PRESENT) {
+        const double x = (double)raw;
         cnt = cnt + 1.0;
         n++;
         const double d = x - avg;
-        const double dn = div_by_count(d, cnt, rcp[n]);
+        const double dn = div_by_count(d, cnt, rcp[n]);  // == d / cnt, bit for bit
         avg = avg + dn;
         m2 = m2 + d * (d - dn);
       }
-    }
+    });
     const bool has_sigma = n >= 2;
     const double sg = has_sigma ? sqrt(m2 / (cnt - 1.0)) : 0.0;
     sigma[k] = sg;
@@ -294,31 +311,13 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, cons
       if (has_sigma) {
         const double one_minus = 1.0 - alpha;
         double e = 0.0;
-        uint64_t t2 = 0;
-        for (; t2 + kUnroll <= g.T; t2 += kUnroll) {
-          uint8_t fl[kUnroll];
-          unsigned long long v[kUnroll];
-#pragma unroll
-          for (int u = 0; u < kUnroll; ++u) {
-            fl[u] = g.flag[(t2 + u) * g.K + k];
-            v[u] = g.val[(t2 + u) * g.K + k];
-          }
-#pragma unroll
-          for (int u = 0; u < kUnroll; ++u) {
-            if (fl[u] & FLAG_PRESENT) {
-              const double x = (double)v[u];
-              e = one_minus * e + alpha * x;
-              a += fabs(x - e) > sg ? 1u : 0u;
-            }
-          }
-        }
-        for (; t2 < g.T; ++t2) {
-          if (g.flag[t2 * g.K + k] & FLAG_PRESENT) {
-            const double x = (double)g.val[t2 * g.K + k];
+        walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
+          if (fl & FLAG_PRESENT) {
+            const double x = (double)raw;
             e = one_minus * e + alpha * x;
             a += fabs(x - e) > sg ? 1u : 0u;
           }
-        }
+        });
       }
       n_anom[k] = a;
     }
@@ -530,20 +529,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
       pos++;
     }
   };
-  // the series walk is a dependency chain per lane: issue kUnroll independent loads, then consume them
-  uint64_t t = 0;
-  for (; t + kUnroll <= g.T && pos < end; t += kUnroll) {
-    uint8_t fl[kUnroll];
-    unsigned long long v[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      fl[u] = g.flag[(t + u) * g.K + k];
-      v[u] = g.val[(t + u) * g.K + k];
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) step(t + u, fl[u], v[u]);
-  }
-  for (; t < g.T && pos < end; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
+  walk_series(g, k, step);
 }
 
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
