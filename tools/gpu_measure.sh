@@ -7,6 +7,7 @@ mkdir -p $O
 cd $R
 ( time timeout 900 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -6 $O/pytest_gpu.log | head -3
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) 2>&1 | tail -2
 timeout 300 python bench.py > $O/bench_ewma_c2.json 2> $O/bench_ewma_c2.err; head -c 600 $O/bench_ewma_c2.json; echo
 timeout 300 python bench.py --algo DBSCAN --keys 1000000 --buckets 100 --agg "" --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_dbscan_c4.json 2> $O/bench_dbscan_c4.err
 if [ "$2" = "full" ]; then
