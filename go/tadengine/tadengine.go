@@ -35,6 +35,7 @@ const (
 	EWMA   Algo = C.TAD_ALGO_EWMA
 	ARIMA  Algo = C.TAD_ALGO_ARIMA
 	DBSCAN Algo = C.TAD_ALGO_DBSCAN
+	Drop   Algo = C.TAD_ALGO_DROP // abnormal-traffic-drop detector (snowflake/udfs/udfs/drop_detection)
 )
 
 type AggFlow int

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 2
+#define TAD_ABI_VERSION 3
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -46,7 +46,11 @@ enum {
 };
 
 /* --algo, controller.go:527-533 ("EWMA" | "ARIMA" | "DBSCAN"); anomaly_detection.py:697-709 */
-typedef enum { TAD_ALGO_EWMA = 0, TAD_ALGO_ARIMA = 1, TAD_ALGO_DBSCAN = 2 } tad_algo;
+/* TAD_ALGO_DROP: the abnormal-traffic-drop detector of the reference's Snowflake backend
+ * (snowflake/udfs/udfs/drop_detection/drop_detection_udf.py:42-56): per key mean / sample std of the aggregated counts,
+ * anomaly outside mean +- drop_nsigma * std, keys with fewer than drop_min_samples points yield nothing.
+ * Result rows: throughput = the count, algo_calc = the key's mean, stddev = its std. */
+typedef enum { TAD_ALGO_EWMA = 0, TAD_ALGO_ARIMA = 1, TAD_ALGO_DBSCAN = 2, TAD_ALGO_DROP = 3 } tad_algo;
 
 /* --agg-flow, controller.go:560-620; anomaly_detection.py:617-628 (aggType literal).
  * NONE  : per-connection keys, max(throughput)   (anomaly_detection.py:52-61)
@@ -83,6 +87,8 @@ typedef struct {
   double dbscan_eps;         /* 0 -> 250000000 (:342) */
   int32_t dbscan_min_samples;/* 0 -> 4 (:342) */
   int32_t arima_maxiter;     /* 0 -> 50 (statsmodels fit() default) */
+  double drop_nsigma;        /* 0 -> 3 (drop_detection_udf.py:49-50) */
+  int32_t drop_min_samples;  /* 0 -> 3 (:44) */
   uint32_t flags;            /* TAD_FLAG_* */
   char id[64];               /* --id, echoed into the result (tadetector.id, :503) */
 } tad_job;
@@ -193,6 +199,9 @@ int tad_series_stddev(tad_engine *e, const uint64_t *x, uint64_t n, int *has_std
 /* calculate_dbscan_anomaly (:325-349): verdict[n] = (label == -1). */
 int tad_series_dbscan_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, double eps,
                               int min_samples, uint8_t *verdict);
+/* DropDetection.end_partition (drop_detection_udf.py:42-56) on one partition: *has_result = 0 when n < min_samples. */
+int tad_series_drop(tad_engine *e, const uint64_t *x, uint64_t n, double nsigma, int min_samples, int *has_result,
+                    double *mean, double *stddev, uint8_t *verdict);
 /* calculate_arima (:215-264): out[n]; *has_result = 0 reproduces the `return None` cases. */
 int tad_series_arima(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int *has_result,
                      double *out);

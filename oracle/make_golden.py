@@ -50,8 +50,43 @@ def seeded_series():
     return out
 
 
+def drop_golden():
+    """tests/golden/drop_outputs.json: the reference drop-detection UDF (snowflake/udfs/udfs/drop_detection/
+    drop_detection_udf.py) executed from where it lies on its own test data (drop_detection_udf_test.py:7-128) and on
+    seeded series."""
+    import ast
+    from oracle import drop_oracle as dro
+    udf = dro.load_reference_udf()
+    test_src = open(os.path.join(os.path.dirname(dro.UDF_FILE), "drop_detection_udf_test.py")).read()
+    tree = ast.parse(test_src)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef)][0]
+    consts = {t.targets[0].id: ast.literal_eval(t.value) for t in cls.body if isinstance(t, ast.Assign)}
+    rng = np.random.default_rng(20230117)
+    series = {"reference_test": [int(r[3]) for r in consts["aggregated_flows"]]}
+    for n in (2, 3, 4, 7, 8, 9, 20, 31, 127, 128, 129, 300, 1000):
+        v = rng.poisson(6.0, size=n).astype(np.int64)
+        if n >= 7:
+            v[rng.integers(0, n)] += int(rng.integers(50, 400))
+        series["poisson_n%d" % n] = [int(x) for x in v]
+    big = rng.integers(2**33, 2**34, size=200)
+    big[77] = 2**44 + 12345                       # sums of squares far beyond 2^53: the float arithmetic order matters
+    series["big_counts"] = [int(x) for x in big]
+    series["constant"] = [5] * 10
+    out = {"source": dro.UDF_FILE, "expected_result": consts["expected_result"], "detection_id": consts["detection_id"], "series": {}}
+    for name, xs in series.items():
+        d = udf.DropDetection()
+        for i, x in enumerate(xs):
+            next(d.process("initial", "det-1", "ns/pod", "ingress", "day-%04d" % i, x))
+        rows = list(d.end_partition())
+        out["series"][name] = {"x": xs, "rows": [[r[5], r[6], r[7], int(r[8])] for r in rows]}   # avg, std, date, number
+    with open(os.path.join(OUT_DIR, "drop_outputs.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote drop_outputs.json:", {k: len(v["rows"]) for k, v in out["series"].items()})
+
+
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
+    drop_golden()
     ad = ref_loader.load_reference_job()
     t = ref_loader.load_reference_tests()
 

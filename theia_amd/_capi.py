@@ -6,12 +6,12 @@ from . import build as _build
 
 u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
 
-TAD_ABI_VERSION = 2
+TAD_ABI_VERSION = 3
 TAD_KEY_SKIP = (1 << 64) - 1
 TAD_OK = 0
 TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
 TAD_ERR_KEY_RANGE, TAD_ERR_GRID_TOO_LARGE, TAD_ERR_BUSY = -5, -6, -7
-TAD_ALGO = {"EWMA": 0, "ARIMA": 1, "DBSCAN": 2}
+TAD_ALGO = {"EWMA": 0, "ARIMA": 1, "DBSCAN": 2, "DROP": 3}
 TAD_AGG = {"": 0, None: 0, "None": 0, "pod": 1, "svc": 2, "external": 3}
 TAD_OP = {"auto": 0, "max": 1, "sum": 2}
 TAD_MEM_HOST, TAD_MEM_DEVICE = 0, 1
@@ -25,7 +25,8 @@ class EngineOpts(C.Structure):
 class Job(C.Structure):
     _fields_ = [("algo", C.c_int), ("agg_flow", C.c_int), ("value_op", C.c_int),
                 ("start_time", i64), ("end_time", i64), ("ewma_alpha", f64), ("dbscan_eps", f64),
-                ("dbscan_min_samples", i32), ("arima_maxiter", i32), ("flags", u32), ("id", C.c_char * 64)]
+                ("dbscan_min_samples", i32), ("arima_maxiter", i32), ("drop_nsigma", f64), ("drop_min_samples", i32),
+                ("flags", u32), ("id", C.c_char * 64)]
 
 
 class Columns(C.Structure):
@@ -68,6 +69,7 @@ SYMBOLS = {
     "tad_series_ewma_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, f64, C.c_void_p]),
     "tad_series_stddev": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.POINTER(C.c_int), C.POINTER(f64)]),
     "tad_series_dbscan_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, C.c_void_p]),
+    "tad_series_drop": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, C.POINTER(C.c_int), C.POINTER(f64), C.POINTER(f64), C.c_void_p]),
     "tad_series_arima": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "tad_series_arima_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.c_int, C.c_int, f64, C.c_void_p, C.POINTER(u64)]),
     "tad_synth_generate": (C.c_int, [C.c_void_p, u64, u64, u64, u64, u64, C.c_void_p, C.c_void_p, C.c_void_p]),

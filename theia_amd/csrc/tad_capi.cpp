@@ -271,6 +271,8 @@ struct JobParams {
   tad_algo algo;
   double alpha, eps;
   int min_samples, maxiter;
+  double drop_nsigma;
+  int drop_min_samples;
   bool all_points;
 };
 
@@ -318,7 +320,12 @@ int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ct
   unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
 
   const bool ewma = jp.algo == TAD_ALGO_EWMA;
-  if (!stats_done)
+  const bool drop = jp.algo == TAD_ALGO_DROP;
+  if (drop) {   // mean / std / verdicts / counters in one kernel (pandas' pairwise arithmetic, not Spark's streaming update)
+    if ((rc = ensure(e, e->calc, (g.K * g.T ? g.K * g.T : 1) * sizeof(double))) != TAD_OK) return rc;
+    launch_drop(s, g, jp.drop_nsigma, jp.drop_min_samples, static_cast<double *>(e->calc.p), sigma, n_pts,
+                static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p), ctr);
+  } else if (!stats_done)
     launch_key_sigma(s, g, jp.alpha, ewma && !jp.all_points, static_cast<const double *>(e->rcp_table.p), sigma, n_pts, n_anom, ctr, static_cast<double *>(e->key_mean.p),
                      static_cast<double *>(e->key_m2.p));
   launch_moments(s, g.K, n_pts, static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
@@ -339,8 +346,8 @@ int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ct
       return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
   }
   const uint32_t *cnt = n_anom;
-  if (jp.all_points && jp.algo != TAD_ALGO_ARIMA) cnt = n_pts;
-  else if (!ewma || jp.all_points) launch_count_flags(s, g, jp.all_points, n_anom);  // ARIMA all_points: skips no-result keys
+  if (jp.all_points && jp.algo != TAD_ALGO_ARIMA && !drop) cnt = n_pts;
+  else if (!ewma || jp.all_points) launch_count_flags(s, g, jp.all_points, n_anom);  // ARIMA / DROP all_points: skips no-result keys
   launch_scan(s, cnt, off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
   HIP_TRY(e, hipMemcpyAsync(e->total_host, off + g.K, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
@@ -352,9 +359,9 @@ int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ct
 }
 
 void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows out) {
-  const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : 2);
+  const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : (jp.algo == TAD_ALGO_DROP ? 3 : 2));
   launch_emit(e->stream, g, L, kind, jp.all_points, jp.alpha, static_cast<const double *>(e->sigma.p),
-              static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(e->calc.p),
+              static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(kind == 3 ? e->key_mean.p : e->calc.p),
               static_cast<const unsigned long long *>(e->off.p), out);
 }
 
@@ -437,7 +444,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   if (!job || !cols || (!out && !points_out)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: job, cols and out must not be NULL");
   if (out) *out = nullptr;
   if (points_out) *points_out = nullptr;
-  if (!points_mode && job->algo != TAD_ALGO_EWMA && job->algo != TAD_ALGO_ARIMA && job->algo != TAD_ALGO_DBSCAN)
+  if (!points_mode && job->algo != TAD_ALGO_EWMA && job->algo != TAD_ALGO_ARIMA && job->algo != TAD_ALGO_DBSCAN && job->algo != TAD_ALGO_DROP)
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: Throughput Anomaly Detector algorithm type should be 'EWMA' or 'ARIMA' or 'DBSCAN'");
   if (job->agg_flow < TAD_AGG_NONE || job->agg_flow > TAD_AGG_EXTERNAL)
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "invalid request: Throughput Anomaly Detector aggregated flow type should be 'pod' or 'external' or 'svc'");
@@ -449,7 +456,8 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: num_keys is 0 but there are rows");
   if (cols->n_buckets > 0 && cols->step < 1)
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: lattice hint needs step >= 1");
-  if (job->ewma_alpha < 0.0 || job->ewma_alpha > 1.0 || job->dbscan_eps < 0.0 || job->dbscan_min_samples < 0 || job->arima_maxiter < 0)
+  if (job->ewma_alpha < 0.0 || job->ewma_alpha > 1.0 || job->dbscan_eps < 0.0 || job->dbscan_min_samples < 0 || job->arima_maxiter < 0 ||
+      job->drop_nsigma < 0.0 || job->drop_min_samples < 0)
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: detector parameter out of range");
 
   std::lock_guard<std::mutex> lk(e->mu);
@@ -464,6 +472,8 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   jp.eps = job->dbscan_eps == 0.0 ? 250000000.0 : job->dbscan_eps;
   jp.min_samples = job->dbscan_min_samples == 0 ? 4 : job->dbscan_min_samples;
   jp.maxiter = job->arima_maxiter == 0 ? 50 : job->arima_maxiter;
+  jp.drop_nsigma = job->drop_nsigma == 0.0 ? 3.0 : job->drop_nsigma;
+  jp.drop_min_samples = job->drop_min_samples == 0 ? 3 : job->drop_min_samples;
   jp.all_points = (job->flags & TAD_FLAG_EMIT_ALL_POINTS) != 0;
   const bool op_max = job->value_op == TAD_OP_MAX || (job->value_op == TAD_OP_AUTO && job->agg_flow == TAD_AGG_NONE);
   const uint64_t n = cols->n_rows;
@@ -546,7 +556,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     // ---- Stage 0: GROUP BY (key, flowEndSeconds) into the time-major point grid ----
     const uint64_t cells = empty ? 0 : K * L.nb;
     if (!empty && L.nb != 0 && cells / L.nb != K) return fail(e, TAD_ERR_GRID_TOO_LARGE, "grid of %llu keys x %llu buckets overflows", (unsigned long long)K, (unsigned long long)L.nb);
-    const uint64_t need = cells * 9 + (jp.algo == TAD_ALGO_ARIMA ? cells * 8 : 0);
+    const uint64_t need = cells * 9 + ((jp.algo == TAD_ALGO_ARIMA || jp.algo == TAD_ALGO_DROP) ? cells * 8 : 0);
     if (need > e->ws_limit) {
       if (lat_mode == 1 && v2) { lat_mode = 2; continue; }  // a too-fine sampled step cannot happen (it is a multiple of the true one); be safe
       return fail(e, TAD_ERR_GRID_TOO_LARGE,
@@ -846,6 +856,8 @@ JobParams series_params(tad_algo algo, double alpha, double eps, int min_samples
   jp.eps = eps == 0.0 ? 250000000.0 : eps;
   jp.min_samples = min_samples == 0 ? 4 : min_samples;
   jp.maxiter = maxiter == 0 ? 50 : maxiter;
+  jp.drop_nsigma = 3.0;
+  jp.drop_min_samples = 3;
   jp.all_points = true;
   return jp;
 }
@@ -915,6 +927,36 @@ int tad_series_dbscan_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, doub
     launch_dbscan_long(e->stream, g, jp.eps, jp.min_samples, e->aux.p);
   }
   return series_emit_all(e, g, jp, false, 0.0, nullptr, verdict);
+}
+
+int tad_series_drop(tad_engine *e, const uint64_t *x, uint64_t n, double nsigma, int min_samples, int *has_result,
+                    double *mean, double *stddev, uint8_t *verdict) {
+  if (!e || !has_result || !mean || !stddev || (n && (!x || !verdict)) || nsigma < 0.0 || min_samples < 0)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_drop: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  *has_result = 0;
+  *mean = 0.0;
+  *stddev = 0.0;
+  const int ms = min_samples == 0 ? 3 : min_samples;
+  if (n == 0 || n < (uint64_t)ms || n < 2) return TAD_OK;   // drop_detection_udf.py:44-45
+  Grid g;
+  int rc = series_grid(e, x, n, &g);
+  if (rc != TAD_OK) return rc;
+  if ((rc = ensure_key_buffers(e, 1)) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->calc, n * sizeof(double))) != TAD_OK) return rc;
+  launch_drop(e->stream, g, nsigma == 0.0 ? 3.0 : nsigma, ms, static_cast<double *>(e->calc.p), static_cast<double *>(e->sigma.p),
+              static_cast<uint32_t *>(e->n_pts.p), static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p),
+              static_cast<DevCounters *>(e->counters.p));
+  std::vector<uint8_t> flags(n);
+  HIP_TRY(e, hipMemcpyAsync(mean, e->key_mean.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(stddev, e->sigma.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(flags.data(), g.flag, n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  HIP_TRY(e, hipGetLastError());
+  *has_result = 1;
+  for (uint64_t i = 0; i < n; ++i) verdict[i] = (flags[i] & FLAG_ANOMALY) ? 1 : 0;
+  return TAD_OK;
 }
 
 int tad_series_arima(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int *has_result, double *out) {

@@ -104,7 +104,7 @@ void launch_count_flags(hipStream_t s, Grid g, bool all_points, uint32_t *n_anom
 void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K,
                  unsigned long long *scratch);
 size_t scan_scratch_elems(uint64_t K);
-// kind: 0 EWMA (recompute), 1 flags + calc array, 2 flags with calc = 0
+// kind: 0 EWMA (recompute), 1 flags + calc array, 2 flags with calc = 0, 3 flags with calc = per-key value calc[k]
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
                  const unsigned long long *off, OutRows out);
@@ -117,6 +117,10 @@ void launch_ewma_values(hipStream_t s, Grid g, double alpha, double *calc);
 int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples);
 size_t dbscan_long_scratch_bytes(Grid g);  // 0 when the LDS tile kernel applies
 int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch);
+
+// drop detector (tad_drop.hip): sigma / n_pts / key_mean / key_m2 / counters + FLAG_ANOMALY; ws = K * T doubles
+void launch_drop(hipStream_t s, Grid g, double n_sigma, int min_samples, double *ws, double *sigma, uint32_t *n_pts,
+                 double *key_mean, double *key_m2, DevCounters *ctr);
 
 // ARIMA(1,1,1) walk-forward on Box-Cox data: calc[T][K] + FLAG_ANOMALY.
 int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter,

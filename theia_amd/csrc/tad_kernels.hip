@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
       a = e;
       verdict = has_sigma && fabs(x - e) > sg;
     } else {
-      a = KIND == 1 ? calc[t * g.K + k] : 0.0;
+      a = KIND == 1 ? calc[t * g.K + k] : (KIND == 3 ? calc[k] : 0.0);
       verdict = (fl & FLAG_ANOMALY) != 0;
     }
     if ((ALL || verdict) && pos < end) {
@@ -540,9 +540,9 @@ void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, 
 #define TAD_LAUNCH_EMIT(KIND, ALL) \
   hipLaunchKernelGGL((k_emit<KIND, ALL>), dim3(blocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out)
   if (all_points) {
-    if (kind == 0) TAD_LAUNCH_EMIT(0, true); else if (kind == 1) TAD_LAUNCH_EMIT(1, true); else TAD_LAUNCH_EMIT(2, true);
+    if (kind == 0) TAD_LAUNCH_EMIT(0, true); else if (kind == 1) TAD_LAUNCH_EMIT(1, true); else if (kind == 3) TAD_LAUNCH_EMIT(3, true); else TAD_LAUNCH_EMIT(2, true);
   } else {
-    if (kind == 0) TAD_LAUNCH_EMIT(0, false); else if (kind == 1) TAD_LAUNCH_EMIT(1, false); else TAD_LAUNCH_EMIT(2, false);
+    if (kind == 0) TAD_LAUNCH_EMIT(0, false); else if (kind == 1) TAD_LAUNCH_EMIT(1, false); else if (kind == 3) TAD_LAUNCH_EMIT(3, false); else TAD_LAUNCH_EMIT(2, false);
   }
 #undef TAD_LAUNCH_EMIT
 }

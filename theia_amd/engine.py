@@ -233,9 +233,9 @@ class TadEngine:
     # ---- the job (anomaly_detection.py:647-710) ----
     def run(self, algo, key_id, flow_end_s, value, num_keys, agg_flow="", value_op="auto", key_id2=None,
             flow_start_s=None, start_time=0, end_time=0, lattice=None, emit_all=False, out="host", job_id="",
-            alpha=0.0, eps=0.0, min_samples=0, maxiter=0):
+            alpha=0.0, eps=0.0, min_samples=0, maxiter=0, drop_nsigma=0.0, drop_min_samples=0):
         if algo not in capi.TAD_ALGO:
-            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "algo must be EWMA, ARIMA or DBSCAN")
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "algo must be EWMA, ARIMA, DBSCAN or DROP")
         if agg_flow not in capi.TAD_AGG:
             raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "agg_flow must be '', pod, svc or external")
         pk, n, dev, keep1 = _as_column(key_id, np.uint64)
@@ -250,6 +250,7 @@ class TadEngine:
         job = capi.Job(algo=capi.TAD_ALGO[algo], agg_flow=capi.TAD_AGG[agg_flow], value_op=capi.TAD_OP[value_op],
                        start_time=int(start_time), end_time=int(end_time), ewma_alpha=float(alpha),
                        dbscan_eps=float(eps), dbscan_min_samples=int(min_samples), arima_maxiter=int(maxiter),
+                       drop_nsigma=float(drop_nsigma), drop_min_samples=int(drop_min_samples),
                        flags=capi.TAD_FLAG_EMIT_ALL_POINTS if emit_all else 0, id=job_id.encode()[:63])
         cols = capi.Columns(n_rows=n, key_id=pk, key_id2=pk2, flow_end_s=pt, flow_start_s=ps, value=pv,
                             num_keys=int(num_keys), memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
@@ -320,6 +321,15 @@ class TadEngine:
         out = np.zeros(a.size, dtype=np.uint8)
         self._check(self._lib.tad_series_dbscan_anomaly(self._h, a.ctypes.data, a.size, float(eps), int(min_samples), out.ctypes.data))
         return out.astype(bool)
+
+    def series_drop(self, x, nsigma=0.0, min_samples=0):
+        """DropDetection.end_partition on one partition -> None (too few samples) or (mean, std, verdict bool[n])."""
+        a = self._series(x)
+        out = np.zeros(max(a.size, 1), dtype=np.uint8)
+        has, mean, sd = C.c_int(), capi.f64(), capi.f64()
+        self._check(self._lib.tad_series_drop(self._h, a.ctypes.data, a.size, float(nsigma), int(min_samples), C.byref(has),
+                                              C.byref(mean), C.byref(sd), out.ctypes.data))
+        return (mean.value, sd.value, out[:a.size].astype(bool)) if has.value else None
 
     def series_arima(self, x, maxiter=0):
         a = self._series(x)
