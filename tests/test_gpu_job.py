@@ -98,3 +98,42 @@ def test_cli_end_to_end(engine, tmp_path):
     rows = [json.loads(line) for line in open(out)]
     want = jo.run(flows, "EWMA", tad_id="cli-1", agg_flow="svc")
     assert len(rows) == len(want) and all(r["id"] == "cli-1" and r["anomaly"] == "true" for r in rows)
+
+
+# ---- (c) the reference's e2e check (test/e2e/throughputanomalydetection_test.go:191-221, 262-300) ----
+E2E_RESULT_MAP = {   # first five characters of the throughput of every emitted row must be one of these, per algorithm
+    "ARIMA": {"4.005", "1.000", "5.000", "2.500", "5.002", "2.003", "2.002"},
+    "EWMA": {"4.004", "4.005", "4.006", "5.000", "2.002", "2.003", "2.500"},
+    "DBSCAN": {"1.000", "1.005", "5.000", "3.260", "2.058", "5.002", "5.027", "2.500", "1.029", "1.630"},
+}
+
+
+def e2e_flows(golden):
+    """addFakeRecordforTAD (throughputanomalydetection_test.go:398-470): 90 rows of ONE connection, one per minute."""
+    x = np.array(golden["throughput_list"], dtype=np.uint64)
+    n = x.size
+    const = lambda v: np.full(n, v)
+    return {
+        "flowStartSeconds": const(1660199214).astype(np.int64), "flowEndSeconds": (1660202814 + 60 * np.arange(n)).astype(np.int64),
+        "sourceIP": const("10.10.1.25"), "destinationIP": const("10.10.1.33"), "sourceTransportPort": const(58076),
+        "destinationTransportPort": const(5201), "protocolIdentifier": const(6),
+        "sourcePodNamespace": const("test_namespace"), "sourcePodName": const("test_podName"),
+        "destinationPodName": const("test_podName"), "destinationPodNamespace": const("test_namespace"),
+        "sourcePodLabels": const("{test_key:test_value}"), "destinationPodLabels": const("{test_key:test_value}"),
+        "destinationServicePortName": const("test_serviceportname"), "flowType": const(3), "throughput": x,
+    }
+
+
+@pytest.mark.parametrize("algo", ["EWMA", "DBSCAN", "ARIMA"])
+@pytest.mark.parametrize("mode", ["", "podname", "podlabel", "external", "svc"])
+def test_e2e_result_map(engine, golden, algo, mode):
+    flows = e2e_flows(golden)
+    kw = {"": {}, "podname": dict(agg_flow="pod", pod_name="test_podName"), "podlabel": dict(agg_flow="pod", pod_label="test_key"),
+          "external": dict(agg_flow="external"), "svc": dict(agg_flow="svc")}[mode]
+    _, rows = ad.anomaly_detection(algo, flows, "", "", "e2e", [], kw.get("agg_flow", ""), kw.get("pod_label"), None, None,
+                                   kw.get("pod_name"))
+    assert len(rows) >= 3 and all(r["anomaly"] == "true" for r in rows)
+    for r in rows:
+        # pod modes aggregate the inbound and the outbound half of every flow separately: same series twice
+        assert ("%e" % r["throughput"])[:5] in E2E_RESULT_MAP[algo], r
+    assert len({len(r) for r in rows}) == 1      # one row shape per aggregation mode
