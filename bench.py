@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--buckets", type=int, default=250)
     ap.add_argument("--agg", default="svc")
     ap.add_argument("--hint-lattice", action="store_true", help="pass the time lattice instead of deriving it")
+    ap.add_argument("--ingest", default="keys", choices=["keys", "rows"],
+                    help="keys: every rank holds the rows of its own keys (no data-path collective, the default); "
+                         "rows: every rank holds an arbitrary slice of the rows -> pre-aggregate (tad_aggregate), one "
+                         "all-to-all(v) of the partial points to the key owners, detect on the owners")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=30_000_000)
     args = ap.parse_args()
@@ -105,13 +109,27 @@ def main():
     key = torch.empty(n, dtype=torch.int64, device=dev)
     tend = torch.empty(n, dtype=torch.int64, device=dev)
     val = torch.empty(n, dtype=torch.int64, device=dev)
-    eng.synth(rank * n, n, K, T, into=(key, tend, val))
+    # ingest=keys: local key ids 0..K-1 of this rank's shard; ingest=rows: global key ids over all K * world keys
+    eng.synth(rank * n, n, K * (world if args.ingest == "rows" else 1), T, into=(key, tend, val))
     lattice = (1660202814, 60, T) if args.hint_lattice else None
 
     reducer = td.JobReducer(device=coll_dev)
 
     def step():
-        res = eng.run(args.algo, key, tend, val, K, agg_flow=args.agg, lattice=lattice, out="device")
+        if args.ingest == "rows":
+            # Stage 0 on the local slice -> partial points; all-to-all(v) to the owners (RCCL over xGMI); the owners run the
+            # job on the partials (re-aggregating sums of sums is bit-exact)
+            pts = eng.aggregate(key, tend, val, K * world, agg_flow=args.agg, lattice=lattice, out="device")
+            ptr = pts.device_pointers()
+            cols = [torch.as_tensor(td.DeviceColumn(ptr[f], pts.n_points), device=dev) for f in ("key_id", "flow_end_s", "value")]
+            if coll_dev is None and world > 1:
+                cols = [c.cpu() for c in cols]                  # gloo test mode: host tensors
+            lk, lt, lv = td.exchange_points_torch(cols[0], cols[1], cols[2], world, rank)
+            pts.close()
+            lk, lt, lv = (c.to(dev) for c in (lk, lt, lv))
+            res = eng.run(args.algo, lk, lt, lv, K, agg_flow=args.agg, lattice=lattice, out="device")
+        else:
+            res = eng.run(args.algo, key, tend, val, K, agg_flow=args.agg, lattice=lattice, out="device")
         st = res.stats
         glob = reducer.reduce(st) if world > 1 else None   # RCCL over xGMI: one 9-double all-gather (counters + moments)
         res.close()
@@ -156,7 +174,10 @@ def main():
                                    % (args.algo, n, K, T, args.agg),
                        "algo": args.algo, "rows_per_gpu": n, "keys_per_gpu": K, "buckets": T,
                        "lattice": "hinted" if args.hint_lattice else "derived by the engine (extra pass over flow_end_s)",
-                       "parallelism": "key-sharded x%d, no data-path collective; one 9-double all-gather per job (counters + moments)" % world},
+                       "parallelism": ("key-sharded x%d, no data-path collective; one 9-double all-gather per job (counters + moments)" % world)
+                       if args.ingest == "keys" else
+                       ("row-sharded x%d: tad_aggregate on the local slice, one all-to-all(v) of partial points, job on the owners; "
+                        "one 9-double all-gather per job" % world)},
             "roofline": {"bound": "hbm", "kernel": "k_partition (Stage-0 v2, row partition pass)" if st["stage0_path"] == 2 else "k_scatter (Stage-0 v1, direct atomics)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": BYTES_PER_ROW * n, "avg_kernel_ms": scatter_ms},

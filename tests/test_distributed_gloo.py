@@ -96,6 +96,46 @@ def test_sharded_job_equals_single_process(world, mode, algo, pod):
     assert sum(1 for g in got if g[2]["write_sentinel"]) == (1 if want["n_anomalies"] == 0 else 0)
 
 
+def torch_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, t, v, _ = table(False)
+        sl = slice(rank, None, world)                      # this rank's arbitrary slice of the rows
+        pk, pt, pv = orc.stage0(k[sl], t[sl], v[sl], "sum")  # pre-aggregated partial points (tad_aggregate on the GPU)
+        lk, lt, lv = td.exchange_points_torch(torch.from_numpy(pk.astype(np.int64)), torch.from_numpy(pt),
+                                              torch.from_numpy(pv.view(np.int64)), world, rank)
+        res = oracle_run("EWMA", lk.numpy().view(np.uint64), lt.numpy(), lv.numpy().view(np.uint64), td.num_local_keys(37, rank, world),
+                         agg_flow="svc")
+        rows = dict(res.rows)
+        rows["key_id"] = td.global_key(rows["key_id"], rank, world)
+        q.put((rank, rows))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_preaggregated_points_exchange_on_torch_tensors():
+    # row-sharded ingest, pre-aggregated: partial sums travel, owners re-aggregate (sum of sums) -> the single-GPU result
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=torch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in range(world)], key=lambda g: g[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    k, t, v, _ = table(False)
+    want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+    cat = {f: np.concatenate([g[1][f] for g in got]) for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev")}
+    order = np.lexsort((cat["flow_end_s"], cat["key_id"]))
+    for f in cat:
+        assert (cat[f][order] == want[f]).all(), f
+
+
 def test_shard_helpers():
     k = np.array([0, 1, 2, 3, 4, 5, td.SKIP], dtype=np.uint64)
     assert td.owner_of(k[:6], 2).tolist() == [0, 1, 0, 1, 0, 1]

@@ -102,7 +102,9 @@ def test_cli_end_to_end(engine, tmp_path):
 
 # ---- (c) the reference's e2e check (test/e2e/throughputanomalydetection_test.go:191-221, 262-300) ----
 E2E_RESULT_MAP = {   # first five characters of the throughput of every emitted row must be one of these, per algorithm
-    "ARIMA": {"4.005", "1.000", "5.000", "2.500", "5.002", "2.003", "2.002"},
+    # "1.005" (index 60, 1005533779) is not in the e2e map but IS flagged by the reference's unit-test golden
+    # (anomaly_detection_test.py:320-335, expected_anomaly_list_arima[60] == True): the two reference tests disagree here
+    "ARIMA": {"4.005", "1.000", "5.000", "2.500", "5.002", "2.003", "2.002", "1.005"},
     "EWMA": {"4.004", "4.005", "4.006", "5.000", "2.002", "2.003", "2.500"},
     "DBSCAN": {"1.000", "1.005", "5.000", "3.260", "2.058", "5.002", "5.027", "2.500", "1.029", "1.630"},
 }

@@ -170,6 +170,39 @@ def exchange_rows(cols, world, rank, group=None, device=None):
     return out
 
 
+def exchange_points_torch(key, flow_end_s, value, world, rank, group=None):
+    """The same exchange on torch tensors (CPU with gloo, HBM with RCCL): int64 tensors of global key ids, times and
+    values (uint64 bit patterns) — typically the partial points a rank pre-aggregated with tad_aggregate.  Rows are
+    bucketed by owner (key mod world) with a stable sort, the per-destination counts travel first, then ONE
+    all-to-all(v) moves the [n, 3] payload.  Returns (local_key, flow_end_s, value) tensors of the rows this rank owns."""
+    import torch
+    import torch.distributed as dist
+    owner = torch.remainder(key, world)
+    order = torch.argsort(owner, stable=True)
+    payload = torch.stack([torch.div(key, world, rounding_mode="floor"), flow_end_s, value], dim=1)[order].contiguous()
+    send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    recv_counts = torch.zeros_like(send_counts)
+    if world > 1:
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+    else:
+        recv_counts.copy_(send_counts)
+    sc, rc = [int(c) for c in send_counts.tolist()], [int(c) for c in recv_counts.tolist()]
+    recv = torch.empty((sum(rc), 3), dtype=torch.int64, device=payload.device)
+    if world > 1:
+        dist.all_to_all_single(recv, payload, output_split_sizes=rc, input_split_sizes=sc, group=group)
+    else:
+        recv.copy_(payload)
+    return recv[:, 0].contiguous(), recv[:, 1].contiguous(), recv[:, 2].contiguous()
+
+
+class DeviceColumn:
+    """Zero-copy torch view of an engine-owned device array (e.g. TadPoints.device_pointers()): torch.as_tensor accepts
+    any object with __cuda_array_interface__ (ROCm builds of torch keep the CUDA name)."""
+
+    def __init__(self, ptr, n, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
 def run_sharded(run_local, algo, cols, num_keys, reducer, **job):
     """cols: this rank's rows with LOCAL key ids (shard_rows / exchange_rows).  run_local(algo, key_id, flow_end_s,
     value, num_local_keys, **job) -> object with .stats (TadEngine.run).  Returns (local result, job-wide stats)."""
