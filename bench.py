@@ -77,6 +77,9 @@ def main():
                     help="keys: every rank holds the rows of its own keys (no data-path collective, the default); "
                          "rows: every rank holds an arbitrary slice of the rows -> pre-aggregate (tad_aggregate), one "
                          "all-to-all(v) of the partial points to the key owners, detect on the owners")
+    ap.add_argument("--host-input", action="store_true",
+                    help="hand the columns over as pinned HOST buffers (tad_columns.memory = TAD_MEM_HOST): the PCIe-inclusive "
+                         "rate DESIGN.md quotes; never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=30_000_000)
     args = ap.parse_args()
@@ -114,6 +117,8 @@ def main():
     lattice = (1660202814, 60, T) if args.hint_lattice else None
 
     reducer = td.JobReducer(device=coll_dev)
+    if args.host_input:
+        hkey, htend, hval = (x.cpu().pin_memory() for x in (key, tend, val))
 
     def step():
         if args.ingest == "rows":
@@ -128,6 +133,8 @@ def main():
             pts.close()
             lk, lt, lv = (c.to(dev) for c in (lk, lt, lv))
             res = eng.run(args.algo, lk, lt, lv, K, agg_flow=args.agg, lattice=lattice, out="device")
+        elif args.host_input:
+            res = eng.run(args.algo, hkey, htend, hval, K, agg_flow=args.agg, lattice=lattice, out="host")
         else:
             res = eng.run(args.algo, key, tend, val, K, agg_flow=args.agg, lattice=lattice, out="device")
         st = res.stats
@@ -170,8 +177,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 (aggregates) + f64 (detectors)", "data": "synthetic",
             "config": {"workload": "%s detector, %d rows / %d flow keys / %d time buckets per GPU, sum(throughput) (agg_flow=%s), "
-                                   "deterministic synthetic flow table (SURVEY.md 8d), inputs and outputs resident in HBM"
-                                   % (args.algo, n, K, T, args.agg),
+                                   "deterministic synthetic flow table (SURVEY.md 8d), %s"
+                                   % (args.algo, n, K, T, args.agg, "inputs in pinned HOST memory, results copied back (PCIe-inclusive)"
+                                      if args.host_input else "inputs and outputs resident in HBM"),
                        "algo": args.algo, "rows_per_gpu": n, "keys_per_gpu": K, "buckets": T,
                        "lattice": "hinted" if args.hint_lattice else "derived by the engine (extra pass over flow_end_s)",
                        "parallelism": ("key-sharded x%d, no data-path collective; one 9-double all-gather per job (counters + moments)" % world)
