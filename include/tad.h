@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 3
+#define TAD_ABI_VERSION 4
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -182,6 +182,24 @@ typedef struct {
 } tad_points;
 int tad_aggregate(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_points **out);
 void tad_points_free(tad_engine *e, tad_points *p);
+
+/* ---- streaming EWMA: per-key running state kept in HBM between batches ----
+ * The batch job re-reads the whole window and judges every point against the stddev_samp of the WHOLE series
+ * (anomaly_detection.py:664-684, 168-212).  A long-running detector appends: tad_state holds, per key, Spark's streaming
+ * moments (n, avg, m2 — the same update as the batch job), the last EWMA value and the last
+ * flowEndSeconds seen.  tad_run_stream aggregates ONE new batch (Stage 0 as in tad_run), continues both recurrences over
+ * the key's new points in time order and emits the points with |x - ewma| > stddev_samp(points seen so far, this one
+ * included) — the running sigma, the only one an append-only detector can know.  After the last batch the state equals
+ * what the batch job computes over the concatenated table bit for bit (same operations in the same order): n, avg, m2
+ * give its stddev_samp, ewma its last EWMA value.  A row not newer than its key's last_t is rejected
+ * (TAD_ERR_INVALID_ARGUMENT) and the state is left untouched.  job->algo must be TAD_ALGO_EWMA. */
+typedef struct tad_state tad_state;
+int tad_state_create(tad_engine *e, uint64_t num_keys, tad_state **out);
+void tad_state_destroy(tad_engine *e, tad_state *s);
+/* copies the state to HOST arrays of num_keys entries each (any may be NULL) */
+int tad_state_export(tad_engine *e, const tad_state *s, uint32_t *n, double *avg, double *m2, double *ewma, int64_t *last_t);
+int tad_run_stream(tad_engine *e, tad_state *s, const tad_job *job, const tad_columns *cols, tad_mem out_memory,
+                   tad_result **out);
 
 /* Stage counter for Status.CompletedStages / TotalStages (controller.go:426-453); callable while
  * tad_run executes on another thread. */

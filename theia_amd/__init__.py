@@ -10,6 +10,6 @@ Product layout:
 There is no CPU fallback: every compute entry point goes through the HIP library and fails
 loudly if it (or a GPU) is missing.
 """
-from .engine import TadEngine, TadError, TadPoints, TadResult  # noqa: F401
+from .engine import TadEngine, TadError, TadPoints, TadResult, TadState  # noqa: F401
 
-__all__ = ["TadEngine", "TadError", "TadPoints", "TadResult"]
+__all__ = ["TadEngine", "TadError", "TadPoints", "TadResult", "TadState"]

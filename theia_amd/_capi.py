@@ -6,7 +6,7 @@ from . import build as _build
 
 u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
 
-TAD_ABI_VERSION = 3
+TAD_ABI_VERSION = 4
 TAD_KEY_SKIP = (1 << 64) - 1
 TAD_OK = 0
 TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
@@ -62,6 +62,10 @@ SYMBOLS = {
     "tad_last_error": (C.c_char_p, [C.c_void_p]),
     "tad_run": (C.c_int, [C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Result))]),
     "tad_result_free": (None, [C.c_void_p, C.POINTER(Result)]),
+    "tad_state_create": (C.c_int, [C.c_void_p, u64, C.POINTER(C.c_void_p)]),
+    "tad_state_destroy": (None, [C.c_void_p, C.c_void_p]),
+    "tad_state_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tad_run_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Result))]),
     "tad_aggregate": (C.c_int, [C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Points))]),
     "tad_points_free": (None, [C.c_void_p, C.POINTER(Points)]),
     "tad_progress": (C.c_int, [C.c_void_p, C.POINTER(i32), C.POINTER(i32)]),

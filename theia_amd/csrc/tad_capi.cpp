@@ -54,6 +54,14 @@ struct tad_engine {
   Moments *moments_host = nullptr;           // pinned
 };
 
+// per-key running state of the streaming EWMA detector: two copies (the count pass writes the candidate next state,
+// it becomes current only when the batch succeeds)
+struct tad_state {
+  uint64_t K = 0;
+  void *block[2] = {nullptr, nullptr};
+  int cur = 0;
+};
+
 namespace {
 
 constexpr int kMetaBlocks = 2048;
@@ -437,9 +445,29 @@ struct PointsPriv {  // tad_points + its storage
   size_t block_cap;
 };
 
-// The job (points_out == nullptr) or Stage 0 alone (points_out != nullptr).
-int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out) {
+size_t state_bytes(uint64_t K) { return (size_t)K * (4 + 8 * 4 + 1) + 64; }
+
+StreamState state_view(const tad_state *st, int which) {
+  unsigned char *b = static_cast<unsigned char *>(st->block[which]);
+  StreamState v;
+  v.avg = reinterpret_cast<double *>(b);
+  v.m2 = v.avg + st->K;
+  v.ewma = v.m2 + st->K;
+  v.last_t = reinterpret_cast<long long *>(v.ewma + st->K);
+  v.n = reinterpret_cast<uint32_t *>(v.last_t + st->K);
+  v.seen = reinterpret_cast<unsigned char *>(v.n + st->K);
+  return v;
+}
+
+// The job (points_out == nullptr), Stage 0 alone (points_out != nullptr), or one streaming batch (stream != nullptr).
+int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
+            tad_state *stream = nullptr) {
   const bool points_mode = points_out != nullptr;
+  if (stream && e && job && cols) {
+    if (job->algo != TAD_ALGO_EWMA) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: only the EWMA detector has a streaming form");
+    if (cols->num_keys > stream->K) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: batch has %llu keys, the state only %llu",
+                                                (unsigned long long)cols->num_keys, (unsigned long long)stream->K);
+  }
   if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_run: engine is NULL");
   if (!job || !cols || (!out && !points_out)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: job, cols and out must not be NULL");
   if (out) *out = nullptr;
@@ -623,12 +651,26 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       HIP_TRY(e, hipStreamSynchronize(s));
       HIP_TRY(e, hipGetLastError());
       rows = *e->total_host;
+    } else if (stream) {   // continue the per-key recurrences from the stored state; the next state stays a candidate
+      if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
+      launch_stream(s, g, L, jp.alpha, jp.all_points, false, state_view(stream, stream->cur), state_view(stream, stream->cur ^ 1),
+                    static_cast<uint32_t *>(e->n_anom.p), nullptr, OutRows{}, ctr);
+      unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
+      launch_scan(s, static_cast<const uint32_t *>(e->n_anom.p), off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
+      HIP_TRY(e, hipMemcpyAsync(e->total_host, off + g.K, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipStreamSynchronize(s));
+      HIP_TRY(e, hipGetLastError());
+      rows = *e->total_host;
+      for (int b = 0; b < kMomentBlocks; ++b) e->moments_host[b] = Moments{0.0, 0.0, 0.0};
     } else if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) {
       return rc;
     }
     const DevCounters c = *e->ctr_host;
     if (c.err & DEV_ERR_KEY_RANGE)
       return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
+    if (c.err & DEV_ERR_LATE_ROW)
+      return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: a row is not newer than the last flowEndSeconds of its key's state; state unchanged");
     if (c.err & DEV_ERR_OVERFLOW_LIST) {  // more than kOverflowCap values >= 2^49: the packed records do not pay off, use v1
       if (!force_v1_retry) { force_v1_retry = true; continue; }
       return fail(e, TAD_ERR_HIP, "internal error: overflow list full on the v1 path");
@@ -705,7 +747,11 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     OutRows dev_rows;
     ResultBlock dev_block;
     if ((rc = make_result(e, rows, jp.all_points, out_memory, &rp, &dev_rows, &dev_block)) != TAD_OK) return rc;
-    if (rows) emit_rows(e, g, L, jp, dev_rows);
+    if (rows && stream)
+      launch_stream(s, g, L, jp.alpha, jp.all_points, true, state_view(stream, stream->cur), state_view(stream, stream->cur ^ 1),
+                    nullptr, static_cast<const unsigned long long *>(e->off.p), dev_rows, ctr);
+    else if (rows)
+      emit_rows(e, g, L, jp, dev_rows);
     HIP_TRY(e, hipEventRecord(e->ev[4], s));
     if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
     HIP_TRY(e, hipStreamSynchronize(s));
@@ -758,6 +804,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     st.stage0_path = v2 ? 2 : 1;
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
+    if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)
     e->done.store(4);
     *out = &rp->pub;
     return TAD_OK;
@@ -772,6 +819,55 @@ extern "C" {
 int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out) {
   if (e && !out) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: job, cols and out must not be NULL");
   return run_job(e, job, cols, out_memory, out, nullptr);
+}
+
+int tad_run_stream(tad_engine *e, tad_state *st, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out) {
+  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: engine is NULL");
+  if (!st || !out) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: state and out must not be NULL");
+  return run_job(e, job, cols, out_memory, out, nullptr, st);
+}
+
+int tad_state_create(tad_engine *e, uint64_t num_keys, tad_state **out) {
+  if (!e || !out || num_keys == 0) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_state_create: bad arguments");
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  tad_state *st = new (std::nothrow) tad_state();
+  if (!st) return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
+  st->K = num_keys;
+  for (int i = 0; i < 2; ++i) {
+    hipError_t r = hipMalloc(&st->block[i], state_bytes(num_keys));
+    if (r == hipSuccess) r = hipMemsetAsync(st->block[i], 0, state_bytes(num_keys), e->stream);   // n = 0, avg = m2 = ewma = 0, unseen
+    if (r != hipSuccess) {
+      for (int j = 0; j <= i; ++j) if (st->block[j]) hipFree(st->block[j]);
+      delete st;
+      return fail(e, TAD_ERR_OUT_OF_MEMORY, "tad_state_create: %s", hipGetErrorString(r));
+    }
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  *out = st;
+  return TAD_OK;
+}
+
+void tad_state_destroy(tad_engine *e, tad_state *st) {
+  if (!st) return;
+  if (e) { std::lock_guard<std::mutex> lk(e->mu); hipSetDevice(e->device); hipStreamSynchronize(e->stream); }
+  for (int i = 0; i < 2; ++i) if (st->block[i]) hipFree(st->block[i]);
+  delete st;
+}
+
+int tad_state_export(tad_engine *e, const tad_state *st, uint32_t *n, double *avg, double *m2, double *ewma, int64_t *last_t) {
+  if (!e || !st) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_state_export: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  const StreamState v = state_view(st, st->cur);
+  if (n) HIP_TRY(e, hipMemcpy(n, v.n, st->K * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (avg) HIP_TRY(e, hipMemcpy(avg, v.avg, st->K * sizeof(double), hipMemcpyDeviceToHost));
+  if (m2) HIP_TRY(e, hipMemcpy(m2, v.m2, st->K * sizeof(double), hipMemcpyDeviceToHost));
+  if (ewma) HIP_TRY(e, hipMemcpy(ewma, v.ewma, st->K * sizeof(double), hipMemcpyDeviceToHost));
+  if (last_t) HIP_TRY(e, hipMemcpy(last_t, v.last_t, st->K * sizeof(long long), hipMemcpyDeviceToHost));
+  return TAD_OK;
 }
 
 int tad_aggregate(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_points **out) {

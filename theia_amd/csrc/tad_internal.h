@@ -27,7 +27,7 @@ struct Grid {
   uint64_t T;               // buckets
 };
 
-enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u };
+enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u, DEV_ERR_LATE_ROW = 8u };
 enum : uint8_t { FLAG_PRESENT = 1, FLAG_ANOMALY = 2 };
 
 // Per-block partial of the lattice-derivation pass.
@@ -110,6 +110,17 @@ void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, 
                  const unsigned long long *off, OutRows out);
 void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long long *off, unsigned long long *out_key,
                         long long *out_t, unsigned long long *out_val);
+// streaming EWMA: per-key running state (tad_state); k_stream continues the recurrences over the new grid
+struct StreamState {
+  uint32_t *n;
+  double *avg, *m2, *ewma;
+  long long *last_t;
+  unsigned char *seen;  // 0 until the key has seen a point
+};
+// emit == false: next = updated state, n_anom[k] = anomalies among the new points (or all new points), late rows flagged;
+// emit == true: rows written from the OLD state `cur` at off[] (next is not touched)
+void launch_stream(hipStream_t s, Grid g, Lattice lat, double alpha, bool all_points, bool emit, StreamState cur, StreamState next,
+                   uint32_t *n_anom, const unsigned long long *off, OutRows out, DevCounters *ctr);
 // EWMA value for every present point into calc[T][K] (series entry points)
 void launch_ewma_values(hipStream_t s, Grid g, double alpha, double *calc);
 

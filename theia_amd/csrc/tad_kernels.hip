@@ -582,6 +582,89 @@ void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long 
   hipLaunchKernelGGL(k_emit_points, dim3(blocks), dim3(kBlock), 0, s, g, lat, off, out_key, out_t, out_val);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_stream — streaming EWMA (include/tad.h: tad_run_stream).  One lane = one key: continue Spark's moment update and the
+// EWMA recurrence from the key's stored state over its new points; verdict against the RUNNING stddev_samp.
+// EMIT = false counts (and produces the next state), EMIT = true replays from the old state and writes the rows.
+// The division stays a division here (n grows without bound, no reciprocal table); it rounds like div_by_count.
+// ------------------------------------------------------------------------------------------------
+template <bool EMIT, bool ALL>
+__global__ __launch_bounds__(kBlock) void k_stream(Grid g, Lattice L, double alpha, StreamState cur, StreamState next,
+                                                   uint32_t *__restrict__ n_anom, const unsigned long long *__restrict__ off,
+                                                   OutRows out, DevCounters *ctr) {
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long my_pts = 0;
+  unsigned my_key = 0;
+  uint32_t err = 0;
+  if (k < g.K) {
+    uint32_t n = cur.n[k];
+    double cnt = (double)n, avg = cur.avg[k], m2 = cur.m2[k], e = cur.ewma[k];
+    long long last_t = cur.last_t[k];
+    bool seen = cur.seen[k] != 0;
+    const double one_minus = 1.0 - alpha;
+    unsigned long long pos = EMIT ? off[k] : 0ull;
+    uint32_t a = 0, fresh = 0;
+    walk_series(g, k, [&](uint64_t t, uint8_t fl, unsigned long long raw) {
+      if (!(fl & FLAG_PRESENT)) return;
+      const long long ts = (long long)(L.t0 + (int64_t)t * L.step);
+      if (seen && ts <= last_t) { err |= DEV_ERR_LATE_ROW; return; }
+      const double x = (double)raw;
+      cnt = cnt + 1.0;
+      n++;
+      const double d = x - avg;
+      const double dn = d / cnt;
+      avg = avg + dn;
+      m2 = m2 + d * (d - dn);
+      e = one_minus * e + alpha * x;
+      const bool has_sigma = n >= 2;
+      const double sg = has_sigma ? sqrt(m2 / (cnt - 1.0)) : 0.0;
+      const bool verdict = has_sigma && fabs(x - e) > sg;
+      last_t = ts;
+      seen = true;
+      fresh++;
+      if (ALL || verdict) {
+        if (EMIT) {
+          out.key_id[pos] = k;
+          out.flow_end_s[pos] = ts;
+          out.throughput[pos] = x;
+          out.algo_calc[pos] = e;
+          out.stddev[pos] = sg;
+          if (ALL) out.anomaly[pos] = verdict ? 1 : 0;
+          pos++;
+        }
+        a++;
+      }
+    });
+    if (!EMIT) {
+      next.n[k] = n; next.avg[k] = avg; next.m2[k] = m2; next.ewma[k] = e; next.last_t[k] = last_t; next.seen[k] = seen ? 1 : 0;
+      n_anom[k] = a;
+      my_pts = fresh;
+      my_key = fresh > 0;
+    }
+  }
+  if (!EMIT) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      my_pts += __shfl_down(my_pts, d);
+      my_key += __shfl_down(my_key, d);
+      err |= __shfl_down(err, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (my_key) { atomicAdd(&ctr->n_points, my_pts); atomicAdd(&ctr->n_keys, (unsigned long long)my_key); }
+      if (err) atomicOr(&ctr->err, err);
+    }
+  }
+}
+
+void launch_stream(hipStream_t s, Grid g, Lattice lat, double alpha, bool all_points, bool emit, StreamState cur, StreamState next,
+                   uint32_t *n_anom, const unsigned long long *off, OutRows out, DevCounters *ctr) {
+  if (g.K == 0) return;
+  const int blocks = (int)((g.K + kBlock - 1) / kBlock);
+#define TAD_STREAM(E, A) hipLaunchKernelGGL((k_stream<E, A>), dim3(blocks), dim3(kBlock), 0, s, g, lat, alpha, cur, next, n_anom, off, out, ctr)
+  if (emit) { if (all_points) TAD_STREAM(true, true); else TAD_STREAM(true, false); }
+  else { if (all_points) TAD_STREAM(false, true); else TAD_STREAM(false, false); }
+#undef TAD_STREAM
+}
+
 // EWMA value of every present point (tad_series_ewma = calculate_ewma, :146-165)
 __global__ __launch_bounds__(kBlock) void k_ewma_values(Grid g, double alpha, double *__restrict__ calc) {
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;

@@ -189,6 +189,36 @@ class TadPoints:
             pass
 
 
+class TadState:
+    """Per-key running state of the streaming EWMA detector (tad_state), resident in HBM."""
+
+    def __init__(self, engine, num_keys):
+        self._engine = engine
+        self.num_keys = int(num_keys)
+        h = C.c_void_p()
+        engine._check(engine._lib.tad_state_create(engine._h, self.num_keys, C.byref(h)))
+        self._h = h
+
+    def export(self):
+        """dict of numpy arrays: n, avg, m2, ewma, last_t (one entry per key)."""
+        K = self.num_keys
+        out = {"n": np.zeros(K, np.uint32), "avg": np.zeros(K), "m2": np.zeros(K), "ewma": np.zeros(K), "last_t": np.zeros(K, np.int64)}
+        self._engine._check(self._engine._lib.tad_state_export(self._engine._h, self._h, *(out[f].ctypes.data for f in
+                                                                                             ("n", "avg", "m2", "ewma", "last_t"))))
+        return out
+
+    def close(self):
+        if self._h is not None and self._engine._h is not None:
+            self._engine._lib.tad_state_destroy(self._engine._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TadEngine:
     """One engine per GPU.  Thread-safe (runs serialise inside the library)."""
 
@@ -260,6 +290,30 @@ class TadEngine:
         rc = self._lib.tad_run(self._h, C.byref(job), C.byref(cols),
                                capi.TAD_MEM_DEVICE if out == "device" else capi.TAD_MEM_HOST, C.byref(res))
         del keep1, keep2, keep3, keep4, keep5
+        self._check(rc)
+        return TadResult(self, res)
+
+    # ---- streaming EWMA: one new batch against the per-key running state ----
+    def state_create(self, num_keys):
+        return TadState(self, num_keys)
+
+    def run_stream(self, state, key_id, flow_end_s, value, agg_flow="", value_op="auto", lattice=None, emit_all=False, out="host",
+                   alpha=0.0, job_id=""):
+        pk, n, dev, keep1 = _as_column(key_id, np.uint64)
+        pt, nt, dev_t, keep2 = _as_column(flow_end_s, np.int64)
+        pv, nv, dev_v, keep3 = _as_column(value, np.uint64)
+        if nt != n or nv != n or dev_t != dev or dev_v != dev:
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "columns must have equal length and live in the same memory")
+        job = capi.Job(algo=capi.TAD_ALGO["EWMA"], agg_flow=capi.TAD_AGG[agg_flow], value_op=capi.TAD_OP[value_op], ewma_alpha=float(alpha),
+                       flags=capi.TAD_FLAG_EMIT_ALL_POINTS if emit_all else 0, id=job_id.encode()[:63])
+        cols = capi.Columns(n_rows=n, key_id=pk, flow_end_s=pt, value=pv, num_keys=state.num_keys,
+                            memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
+        if lattice is not None:
+            cols.t0, cols.step, cols.n_buckets = int(lattice[0]), int(lattice[1]), int(lattice[2])
+        res = C.POINTER(capi.Result)()
+        rc = self._lib.tad_run_stream(self._h, state._h, C.byref(job), C.byref(cols),
+                                      capi.TAD_MEM_DEVICE if out == "device" else capi.TAD_MEM_HOST, C.byref(res))
+        del keep1, keep2, keep3
         self._check(rc)
         return TadResult(self, res)
 
