@@ -39,7 +39,11 @@ class FakeClickHouse:
                 params = urllib.parse.parse_qs(urllib.parse.urlparse(self.path).query)
                 owner.auth.append(self.headers.get("Authorization"))
                 if "query" in params and params["query"][0].startswith("INSERT INTO"):
-                    owner.inserted.append((params["query"][0], [json.loads(l) for l in body.decode().splitlines() if l]))
+                    if params["query"][0].endswith("FORMAT ArrowStream"):
+                        rows = ipc.open_stream(io.BytesIO(body)).read_all().to_pylist()
+                    else:
+                        rows = [json.loads(l) for l in body.decode().splitlines() if l]
+                    owner.inserted.append((params["query"][0], rows))
                     self.send_response(200); self.end_headers(); return
                 sql = body.decode()
                 owner.queries.append(sql)
@@ -155,6 +159,20 @@ def test_rows_query_where_clause():
     assert "(destinationPodName = 'p1' AND destinationPodNamespace = 'ns1') OR (sourcePodName = 'p1' AND sourcePodNamespace = 'ns1')" in q
 
 
+def test_insert_columns_arrow(server):
+    client = ch.ClickHouseHTTP(server.url, user="", password="")
+    flows = jo.synth_flows(3000)
+    prep = ad.prepare_columns(flows, agg_flow="", **{k: v for k, v in KW.items() if k != "agg_flow"})
+    mid = oracle_middle(prep, "EWMA", "")
+    cols = ad.result_columns(prep, FakeResult(mid), "EWMA", "", "col-1")
+    rows = ad.result_rows(prep, FakeResult(mid), "EWMA", "", "col-1")
+    assert client.insert_columns(cols) == len(rows) > 0
+    q, got = server.inserted[-1]
+    assert q.startswith("INSERT INTO default.tadetector (sourceIP, sourceTransportPort, destinationIP") and q.endswith("FORMAT ArrowStream")
+    assert canon([{k: (int(v) if k in ("flowEndSeconds", "flowStartSeconds", "sourceTransportPort", "destinationTransportPort",
+                                          "protocolIdentifier") else v) for k, v in r.items()} for r in got]) == canon(rows)
+
+
 def test_insert_rows_json_each_row(server):
     client = ch.ClickHouseHTTP(server.url, user="", password="")
     rows = [ad._db_row({"destinationServicePortName": "s", "flowEndSeconds": 1660202814, "throughputStandardDeviation": 1.5,
@@ -185,11 +203,12 @@ def test_cli_against_clickhouse_http(engine, server, pushdown):
         assert ad.main(argv) == "c-1"
         want = jo.run(flows, "EWMA", tad_id="c-1", agg_flow="svc")
         q, got = server.inserted[-1]
-        assert q == "INSERT INTO default.tadetector FORMAT JSONEachRow" and len(got) == len(want)
-        key = lambda r: (r["destinationServicePortName"], r["flowEndSeconds"] if isinstance(r["flowEndSeconds"], str) else
-                         ad._db_row(r)["flowEndSeconds"])
+        assert q == ("INSERT INTO default.tadetector (destinationServicePortName, flowEndSeconds, throughputStandardDeviation, "
+                     "aggType, algoType, algoCalc, throughput, anomaly, id) FORMAT ArrowStream") and len(got) == len(want)
+        key = lambda r: (r["destinationServicePortName"], int(r["flowEndSeconds"]))
         w = {key(r): r for r in want}
         for r in got:
             assert w[key(r)]["algoCalc"] == r["algoCalc"] and w[key(r)]["throughput"] == r["throughput"]
+            assert r["anomaly"] == "true" and r["id"] == "c-1" and r["aggType"] == "svc"
     finally:
         ad.set_engine(None)

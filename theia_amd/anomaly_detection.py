@@ -356,13 +356,40 @@ def result_rows(prep, res, algo_type, agg_flow, tad_id):
     return rows
 
 
+def result_columns(prep, res, algo_type, agg_flow, tad_id):
+    """Engine result -> the `tadetector` rows as COLUMNS (dict name -> numpy array), vectorised: what the Arrow insert of
+    theia_amd.clickhouse takes for large outputs.  Same content as result_rows (which builds one dict per row)."""
+    if res.n_rows == 0:
+        row = _sentinel_row(algo_type, agg_flow, tad_id)
+        return {k: np.asarray([v]) for k, v in row.items()}
+    host = res.to_host()
+    kid = host["key_id"].astype(np.int64)
+    n = res.n_rows
+    cols = {}
+    for name in KEY_COLUMNS[prep.mode]:
+        vals = np.asarray(prep.key_table[name])[kid]
+        if name == "podLabels":
+            uniq, inv = np.unique(vals.astype(str), return_inverse=True)
+            vals = np.asarray([remove_meaningless_labels(u) for u in uniq], dtype=object)[inv]
+        cols[name] = vals
+    cols["flowEndSeconds"] = host["flow_end_s"]
+    cols["throughputStandardDeviation"] = host["stddev"]
+    cols["aggType"] = np.full(n, agg_flow if agg_flow else "None", dtype=object)
+    cols["algoType"] = np.full(n, algo_type, dtype=object)
+    cols["algoCalc"] = host["algo_calc"]
+    cols["throughput"] = host["throughput"]
+    cols["anomaly"] = np.full(n, "true", dtype=object)
+    cols["id"] = np.full(n, str(tad_id), dtype=object)
+    return cols
+
+
 def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_ignore_list, agg_flow=None,
                       pod_label=None, external_ip=None, svc_port_name=None, pod_name=None, pod_namespace=None,
-                      engine=None, pushdown=False):
+                      engine=None, pushdown=False, columnar=False):
     """ref:647-710.  `flows` stands where the reference has the JDBC address: a column dict, a path for load_flows,
     or a theia_amd.clickhouse.ClickHouseHTTP client (then the rows come over ClickHouse's HTTP interface as Arrow
     batches; pushdown=True lets ClickHouse run the reference's GROUP BY and ships aggregated points instead).
-    Returns (stats dict, list of result rows)."""
+    Returns (stats dict, list of result rows) — or, with columnar=True, (stats dict, dict of result columns)."""
     if algo_type not in VALID_ALGOS:
         raise ValueError("Algorithm should be in {}".format(" or ".join(VALID_ALGOS)))
     agg_flow = agg_flow or ""
@@ -385,6 +412,8 @@ def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_i
     res = eng.run(algo_type, prep.key_id, prep.flow_end_s, prep.value, max(prep.num_keys, 1), agg_flow=agg_flow,
                   key_id2=prep.key_id2, flow_start_s=prep.flow_start_s, start_time=prep.start_time,
                   end_time=prep.end_time, job_id=str(tad_id_input or ""))
+    if columnar:
+        return res.stats, result_columns(prep, res, algo_type, agg_flow, tad_id_input)
     return res.stats, result_rows(prep, res, algo_type, agg_flow, tad_id_input)
 
 
@@ -536,17 +565,21 @@ def main(argv=None):
         client = ch.ClickHouseHTTP(a["db"] or ch.DEFAULT_JDBC_URL)
     t0 = time.time()
     logger.info("Script started at %s", datetime.now().strftime("%a, %d %B %Y %H:%M:%S"))
+    to_db = client is not None and not a["out"]
     try:
         _, rows = anomaly_detection(a["algo"], a["flows"] or client, a["start"], a["end"], tad_id, a["ns"], a["agg"],
-                                    a["label"], a["ip"], a["svc"], a["name"], a["namespace"], pushdown=a["pushdown"])
+                                    a["label"], a["ip"], a["svc"], a["name"], a["namespace"], pushdown=a["pushdown"], columnar=to_db)
     except (TadError, ValueError, OSError) as exc:
         logger.error("Anomaly Detection failed: %s", exc)
         sys.exit(1)
     t1 = time.time()
     if a["out"] or client is None:
         write_anomaly_detection_result(rows, sys.stdout if a["out"] in ("", "-") else a["out"], RESULT_TABLE_NAME, tad_id)
-    else:   # ref:713-726: append to default.tadetector
-        client.insert_rows([_db_row(r) for r in rows], RESULT_TABLE_NAME)
+    else:   # ref:713-726: append to default.tadetector — columnar (Arrow) insert, no per-row work on the host
+        if len(rows["anomaly"]) == 1 and rows["anomaly"][0] != "true":   # the sentinel row: its DateTime fields are text
+            client.insert_rows([_db_row({k: (v[0].item() if hasattr(v[0], "item") else v[0]) for k, v in rows.items()})], RESULT_TABLE_NAME)
+        else:
+            client.insert_columns(rows, RESULT_TABLE_NAME)
     logger.info("Anomaly Detection completed, id: %s, in %s seconds ", tad_id, t1 - t0)
     return tad_id
 

@@ -4,7 +4,8 @@ The reference job reads `default.flows` and appends to `default.tadetector` thro
 connection (anomaly_detection.py:651-662, 713-726; URL `jdbc:clickhouse://clickhouse-clickhouse.flow-visibility.svc:8123`,
 :730-731; credentials in CH_USERNAME / CH_PASSWORD, controller.go:649-658).  Port 8123 is ClickHouse's HTTP interface,
 which speaks columnar formats directly: this module POSTs the query with `FORMAT ArrowStream` and hands the Arrow
-record batches to numpy without a row-by-row decode, and appends results with `INSERT ... FORMAT JSONEachRow`.
+record batches to numpy without a row-by-row decode, and appends results with `INSERT ... FORMAT ArrowStream` (column
+dicts; `FORMAT JSONEachRow` for the few-row case such as the sentinel row).
 Only the standard library (urllib) and pyarrow are used.
 
 Two ways to read (both end in the same numbers):
@@ -84,6 +85,34 @@ class ClickHouseHTTP:
         body = "\n".join(json.dumps(r) for r in rows).encode()
         self._post({"query": "INSERT INTO %s FORMAT JSONEachRow" % table, "date_time_input_format": "best_effort"}, body)
         return len(rows)
+
+    def insert_columns(self, columns, table=RESULT_TABLE):
+        """Append a column dict (INSERT ... FORMAT ArrowStream): the result columns go out the way the flow columns came
+        in.  DateTime columns (flowEndSeconds / flowStartSeconds) travel as UInt32 epoch seconds, which ClickHouse accepts
+        for DateTime; columns the dict lacks take the table defaults."""
+        import pyarrow as pa
+        import pyarrow.ipc as ipc
+        if not columns:
+            return 0
+        n = len(next(iter(columns.values())))
+        arrays = {}
+        for name, v in columns.items():
+            v = np.asarray(v)
+            if name in ("flowEndSeconds", "flowStartSeconds") and v.dtype.kind in "iu":
+                arrays[name] = pa.array(v.astype(np.uint32), pa.uint32())
+            elif v.dtype.kind == "f":
+                arrays[name] = pa.array(v.astype(np.float64), pa.float64())
+            elif v.dtype.kind in "iu":
+                arrays[name] = pa.array(v.astype(np.uint16), pa.uint16())     # ports / protocolIdentifier (create_table.sh:364-368)
+            else:
+                arrays[name] = pa.array([str(x) for x in v.tolist()], pa.string())
+        table_ = pa.table(arrays)
+        sink = io.BytesIO()
+        with ipc.new_stream(sink, table_.schema) as w:
+            w.write_table(table_)
+        cols = ", ".join(table_.column_names)
+        self._post({"query": "INSERT INTO %s (%s) FORMAT ArrowStream" % (table, cols)}, sink.getvalue())
+        return n
 
 
 # raw columns each mode needs (create_table.sh:31-85)
