@@ -157,3 +157,45 @@ def test_sentinel_decision_single_rank():
     red = td.JobReducer()
     out = red.reduce({"n_anomalies": 0, "n_keys": 3, "n_points": 10, "pts_mean": 2.0, "pts_m2": 9.0})
     assert out["write_sentinel"] and out["global_sigma"] == 1.0
+
+
+def pipelined_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        red = td.JobReducer()
+        outs, pending = [], None
+        for job in range(5):        # job j on rank r reports counters that identify (j, r); collected one job late
+            stats = {"n_anomalies": 10 * job + rank, "n_keys": 100 + job, "n_points": 1000 * (rank + 1), "rows_used": job,
+                     "keys_no_result": 0, "rows_in": 7, "pts_mean": float(job + rank), "pts_m2": float(job)}
+            nxt = red.start(stats)
+            if pending is not None:
+                outs.append(pending.result())
+            pending = nxt
+        outs.append(pending.result())
+        q.put((rank, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_reducer_keeps_jobs_apart():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=pipelined_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for job in range(5):
+        for r in range(world):
+            o = got[r][job]
+            assert o["n_anomalies"] == sum(10 * job + x for x in range(world)) and o["n_keys"] == world * (100 + job)
+            assert o["n_points"] == sum(1000 * (x + 1) for x in range(world)) and o["rows_used"] == world * job
+            n, mean, m2 = td.chan_merge([(1000.0 * (x + 1), float(job + x), float(job)) for x in range(world)])
+            assert o["global_mean"] == mean and o["global_sigma"] == (m2 / (n - 1.0)) ** 0.5
+        assert {k: v for k, v in got[0][job].items() if k != "write_sentinel"} == {k: v for k, v in got[1][job].items() if k != "write_sentinel"}

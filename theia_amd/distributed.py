@@ -96,9 +96,34 @@ class JobReducer:
     One all-gather of 9 doubles per rank — the six counters (exact in float64 below 2^53) and the shard's
     (n, mean, M2) — replaces an all-reduce plus an all-gather: per-job collectives are latency-bound (a C2 job
     takes under 2 ms), so one hop instead of two.  Every rank then sums the counters and Chan-merges the moments in
-    rank order, which gives identical bits everywhere."""
+    rank order, which gives identical bits everywhere.
+
+    `start(stats)` launches the all-gather asynchronously and returns a handle; `handle.result()` waits for it.  A host
+    that runs jobs back to back starts job i's collective, runs job i+1 on the engine's stream, then collects job i's
+    result: the collective's latency hides behind the next job (two buffer sets alternate; a handle must be collected
+    before the second start after it).  `reduce(stats)` = start + result."""
 
     WIDTH = len(STAT_FIELDS) + 3
+
+    class Pending:
+        def __init__(self, owner, slot, work):
+            self.owner, self.slot, self.work = owner, slot, work
+
+        def result(self):
+            o = self.owner
+            if self.work is not None:
+                self.work.wait()
+            if o.world > 1:
+                rows = o.gathered[self.slot].view(o.world, o.WIDTH).tolist()
+            else:
+                rows = [o.payload[self.slot].tolist()]
+            nf = len(STAT_FIELDS)
+            out = {f: int(sum(int(r[i]) for r in rows)) for i, f in enumerate(STAT_FIELDS)}
+            n, mean, m2 = chan_merge([tuple(r[nf:nf + 3]) for r in rows])
+            out["global_mean"] = mean if n > 0 else None
+            out["global_sigma"] = (m2 / (n - 1.0)) ** 0.5 if n > 1 else None
+            out["write_sentinel"] = out["n_anomalies"] == 0 and o.rank == 0     # anomaly_detection.py:395-420
+            return out
 
     def __init__(self, device=None, group=None):
         import torch
@@ -107,32 +132,30 @@ class JobReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         on_gpu = device is not None and str(device) != "cpu"
-        self.payload = torch.zeros(self.WIDTH, dtype=torch.float64, device=device)
-        self.gathered = torch.zeros(self.world * self.WIDTH, dtype=torch.float64, device=device)
-        self._stage = torch.zeros(self.WIDTH, dtype=torch.float64).pin_memory() if on_gpu else None
+        self.payload = [torch.zeros(self.WIDTH, dtype=torch.float64, device=device) for _ in range(2)]
+        self.gathered = [torch.zeros(self.world * self.WIDTH, dtype=torch.float64, device=device) for _ in range(2)]
+        self._stage = [torch.zeros(self.WIDTH, dtype=torch.float64).pin_memory() for _ in range(2)] if on_gpu else None
+        self._next = 0
 
-    def reduce(self, stats):
-        """stats: tad_stats of this rank's run -> dict of job-wide values (identical on every rank)."""
+    def start(self, stats):
+        """stats: tad_stats of this rank's run -> Pending (the all-gather is in flight)."""
         torch, dist = self.torch, self.dist
+        slot, self._next = self._next, self._next ^ 1
         vals = [float(int(stats.get(f, 0))) for f in STAT_FIELDS] + \
                [float(stats.get("n_points", 0)), float(stats.get("pts_mean", 0.0)), float(stats.get("pts_m2", 0.0))]
         if self._stage is not None:
-            self._stage.copy_(torch.tensor(vals, dtype=torch.float64))
-            self.payload.copy_(self._stage, non_blocking=True)
+            self._stage[slot].copy_(torch.tensor(vals, dtype=torch.float64))
+            self.payload[slot].copy_(self._stage[slot], non_blocking=True)
         else:
-            self.payload.copy_(torch.tensor(vals, dtype=torch.float64))
+            self.payload[slot].copy_(torch.tensor(vals, dtype=torch.float64))
+        work = None
         if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered, self.payload, group=self.group)
-            rows = self.gathered.view(self.world, self.WIDTH).tolist()
-        else:
-            rows = [self.payload.tolist()]
-        nf = len(STAT_FIELDS)
-        out = {f: int(sum(int(r[i]) for r in rows)) for i, f in enumerate(STAT_FIELDS)}
-        n, mean, m2 = chan_merge([tuple(r[nf:nf + 3]) for r in rows])
-        out["global_mean"] = mean if n > 0 else None
-        out["global_sigma"] = (m2 / (n - 1.0)) ** 0.5 if n > 1 else None
-        out["write_sentinel"] = out["n_anomalies"] == 0 and self.rank == 0     # anomaly_detection.py:395-420
-        return out
+            work = dist.all_gather_into_tensor(self.gathered[slot], self.payload[slot], group=self.group, async_op=True)
+        return JobReducer.Pending(self, slot, work)
+
+    def reduce(self, stats):
+        """stats: tad_stats of this rank's run -> dict of job-wide values (identical on every rank)."""
+        return self.start(stats).result()
 
 
 def exchange_rows(cols, world, rank, group=None, device=None):
