@@ -219,7 +219,7 @@ def main():
                        if args.ingest == "keys" else
                        ("row-sharded x%d: tad_aggregate on the local slice, one all-to-all(v) of partial points, job on the owners; "
                         "one 9-double all-gather per job" % world)},
-            "roofline": {"bound": "hbm", "kernel": "k_partition (Stage-0 v2, row partition pass)" if st["stage0_path"] == 2 else "k_scatter (Stage-0 v1, direct atomics)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": {2: "k_partition (Stage-0 v2, row partition pass, sort-by-tile)", 3: "k_partition_wc (Stage-0 v2, row partition pass, write-combining)"}.get(st["stage0_path"], "k_scatter (Stage-0 v1, direct atomics)"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": BYTES_PER_ROW * n, "avg_kernel_ms": scatter_ms},
             "pipeline": {"ms_meta": acc["ms_meta"] / steps, "ms_stage0_clear_plus_scatter": acc["ms_stage0"] / steps,
@@ -229,7 +229,7 @@ def main():
                        "global_mean": glob["global_mean"], "global_sigma": glob["global_sigma"]},
         }
         if (n, K, T, args.algo) == (100_000_000, 100_000, 250, "EWMA"):   # the PMC passes were taken on this workload
-            out["roofline"]["traffic"] = pmc_traffic("k_partition" if st["stage0_path"] == 2 else "k_scatter")
+            out["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(st["stage0_path"], "k_scatter"))
         if args.algo == "ARIMA":
             sec = acc["ms_detect"] / steps * 1e-3
             flops = FLOP_PER_KALMAN_STEP * st["kalman_steps"]

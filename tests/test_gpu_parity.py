@@ -16,13 +16,16 @@ pytestmark = pytest.mark.gpu
 SKIP = np.uint64(orc.MASK64)
 
 
-@pytest.fixture(autouse=True, params=["v1", "v2"])
+@pytest.fixture(autouse=True, params=["v1", "v2", "v2wc"])
 def stage0(request):
-    """Every test runs with both Stage-0 strategies: v1 = direct atomic scatter, v2 = partition + LDS
-    tiles (forced even on tiny inputs).  Both must give the reference's integers bit for bit."""
-    os.environ["TAD_STAGE0"] = request.param
+    """Every test runs with every Stage-0 strategy: v1 = direct atomic scatter, v2 = partition + LDS tiles (forced
+    even on tiny inputs) with the sort-by-tile partition pass, v2wc = v2 with the write-combining partition pass.
+    All must give the reference's integers bit for bit."""
+    os.environ["TAD_STAGE0"] = request.param[:2]
+    os.environ["TAD_PARTB"] = "wc" if request.param == "v2wc" else "sort"
     yield request.param
     os.environ.pop("TAD_STAGE0", None)
+    os.environ.pop("TAD_PARTB", None)
 
 
 # ------------------------------------------------------------------ (a) reference golden vectors
@@ -99,11 +102,11 @@ def check_job(engine, algo, key, t, v, num_keys, agg_flow="svc", **kw):
 
 @pytest.mark.parametrize("algo", ["EWMA", "DBSCAN"])
 @pytest.mark.parametrize("n_rows,K,T", [(1000, 7, 13), (100003, 100, 250), (1000000, 1000, 250), (300000, 3000, 100)])
-def test_job_synthetic_tables_match_oracle(engine, algo, n_rows, K, T):
+def test_job_synthetic_tables_match_oracle(engine, stage0, algo, n_rows, K, T):
     k, t, v = orc.synth_rows(0, n_rows, K, T)
     res, want = check_job(engine, algo, k, t, v, K, agg_flow="svc")
     assert res.stats["rows_used"] == n_rows and res.stats["step"] == 60 and res.stats["t0"] == t.min()
-    assert res.stats["stage0_path"] == (2 if os.environ["TAD_STAGE0"] == "v2" else 1)
+    assert res.stats["stage0_path"] == {"v1": 1, "v2": 2, "v2wc": 3}[stage0]
 
 
 @pytest.mark.parametrize("algo", ["EWMA", "DBSCAN"])
@@ -182,7 +185,7 @@ def test_job_wide_grids_take_several_rounds_per_partition(engine, stage0, n_rows
     # (many keys): Stage-0 v2 widens the key block and walks the partition's records in several bucket rounds
     k, t, v = orc.synth_rows(0, n_rows, K, T)
     res, want = check_job(engine, "EWMA", k, t, v, K, agg_flow="svc")
-    assert res.stats["stage0_path"] == (2 if stage0 == "v2" else 1)
+    assert res.stats["stage0_path"] in ((1,) if stage0 == "v1" else (2,) if stage0 == "v2" else (2, 3))   # wc needs >= 9 queue slots per partition in LDS
 
 
 @pytest.mark.parametrize("agg", ["svc", ""])

@@ -43,7 +43,9 @@ def test_random_job(engine, seed):
         kw["start_time"] = int(t0 + step * (T // 4))
         kw["end_time"] = int(t0 + step * max(1, (3 * T) // 4) + 1)
     os.environ["TAD_STAGE0"] = str(rng.choice(["v1", "v2"]))
+    os.environ["TAD_PARTB"] = str(rng.choice(["sort", "wc"]))
     try:
         check_job(engine, algo, key, t, v, K, agg_flow=agg, **kw)
     finally:
         os.environ.pop("TAD_STAGE0", None)
+        os.environ.pop("TAD_PARTB", None)

@@ -597,7 +597,8 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     if (v2 && !part_plan_tiles(K, L.nb, has2, &pl)) v2 = false;  // tile does not fit LDS: direct scatter
     bool stats_done = false;
     if (v2) {
-      const uint64_t slots = n * (has2 ? 2 : 1);
+      part_plan_wc(n * (has2 ? 2 : 1), columns_aligned16(d_key, d_key2, d_te, d_val), has2, &pl);
+      const uint64_t slots = n * (has2 ? 2 : 1) + pl.pad_slots;
       if ((rc = ensure(e, e->part_total, (size_t)pl.nparts * 4)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_start, ((size_t)pl.nparts + 1) * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_offs32, (size_t)pl.G * pl.nparts * 4)) != TAD_OK) return rc;
@@ -736,7 +737,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
       hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
       hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
-      st.stage0_path = v2 ? 2 : 1;
+      st.stage0_path = v2 ? (pl.wc_cap ? 3 : 2) : 1;
       e->done.store(4);
       *points_out = &pp->pub;
       return TAD_OK;
@@ -801,7 +802,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     hipEventElapsedTime(&st.ms_stage0, e->ev[1], e->ev[5]);
     hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
     hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
-    st.stage0_path = v2 ? 2 : 1;
+    st.stage0_path = v2 ? (pl.wc_cap ? 3 : 2) : 1;
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)

@@ -154,7 +154,13 @@ struct PartPlan {
   int rpt;             // rows per thread per tile in pass B
   int cell_bits;       // record = value << cell_bits | partition-local cell
   uint32_t tb, n_chunks;  // pass C: buckets per LDS round, rounds per partition
+  uint32_t wc_cap;        // write-combining pass B: queue slots per partition (0 = use the sort-by-tile pass B)
+  uint32_t wc_sec, wc_rpt;  // wc: records per emitted piece (8 or 16), rows per thread per tile (2 or 4)
+  uint64_t pad_slots;     // wc: upper bound of the filler slots (regions rounded up to whole 64-byte sectors)
 };
+// decide whether pass B runs as the write-combining variant (sets wc_cap / pad_slots; needs 16-byte aligned columns)
+void part_plan_wc(uint64_t slots, bool aligned, bool has2, PartPlan *pl);
+bool columns_aligned16(const void *key, const void *key2, const void *t_end, const void *value);
 bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl);
 bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
 void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,

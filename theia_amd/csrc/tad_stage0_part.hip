@@ -12,14 +12,17 @@
 //                           bins -> partitions of KP = 2^shift_part consecutive keys whose KP x T tile of the
 //                           point grid fits in LDS; exclusive offsets per (workgroup, partition): the partition
 //                           pass needs no global atomics and its output order is fixed.
-//   pass B  k_partition     streams the rows once more (24 B/row, next tile prefetched into registers while the
-//                           current one is sorted), turns each into a 10-byte record {value u64, tile-local cell
-//                           u16} (two separate arrays), groups a tile of records by partition in LDS (LDS
-//                           histogram + scan) and copies the runs out (10 B/row written).
+//   pass B  k_partition_wc  streams the rows once more (24 B/row, two register sets of prefetched rows), turns each into
+//                           an 8-byte record (value << cell_bits | tile-local cell) and appends it to its partition's
+//                           queue in LDS; after every tile each queue that holds a whole 64-byte sector (or 128-byte line,
+//                           when there are few enough partitions) emits it with ONE store instruction of 8 / 16
+//                           consecutive lanes.  Nothing but whole aligned sectors ever goes to HBM: the memory system's
+//                           price for short unaligned runs is what bounded the earlier sort-by-tile pass
+//                           (k_partition: LDS histogram + scan per 10240-row tile, runs of ~7 records copied out; still
+//                           used when the queues do not fit LDS or the runs are long anyway; tools/ubench_runs.hip).
 //   pass C  k_tile_aggregate  one workgroup per partition: LDS u64 atomics (add wraps mod 2^64 / unsigned max)
 //                           over its records, then writes its KP x T tile of the time-major grid (values +
-//                           presence flags) with coalesced stores while one wavefront per 64 keys computes the
-//                           per-key stddev_samp (and the EWMA anomaly count) straight from the LDS tile.
+//                           presence flags) with coalesced stores.
 //
 // Integer add/max are associative and commutative, so the aggregates are bit-identical to v1 and to
 // ClickHouse's sum()/max() over UInt64 whatever the record order.
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
 // offsets: cnt[g][p] (row reduce of the bins) -> column-wise exclusive prefix over g -> part_start[p]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_part_rows(const uint32_t *__restrict__ binhist, uint32_t nbins,
-                                                   uint32_t bins_per_part, uint32_t nparts, uint32_t *__restrict__ cnt) {
+                                                   uint32_t bins_per_part, uint32_t nparts, uint32_t *__restrict__ cnt,
+                                                   uint32_t round_mask) {
   const uint32_t *row = binhist + (size_t)blockIdx.x * nbins;
   uint32_t *out = cnt + (size_t)blockIdx.x * nparts;
   for (uint32_t p = threadIdx.x; p < nparts; p += 256) {
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void k_part_rows(const uint32_t *__restrict__ 
     const uint32_t b1 = b0 + bins_per_part < nbins ? b0 + bins_per_part : nbins;
     uint32_t s = 0;
     for (uint32_t b = b0; b < b1; ++b) s += row[b];
-    out[p] = s;
+    out[p] = (s + round_mask) & ~round_mask;  // write-combining pass B: every (workgroup, partition) region is whole sectors
   }
 }
 
@@ -568,6 +572,195 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// pass B, write-combining variant.  Measured (tools/ubench_runs.hip): what k_partition pays for is not the sort but
+// the memory system's handling of ~7-record runs at arbitrary alignment (1.05-1.11 ms for the bare address pattern),
+// while runs of 8 records on 64-byte boundaries cost 0.82 ms and whole 128-byte lines run at streaming speed.  So this
+// variant never writes a partial sector: every (workgroup, partition) region starts on a 64-byte boundary (k_part_rows
+// rounds the counts up to 8), records are appended to a per-partition queue of `cap` (9..12) slots in LDS, and after
+// each tile every queue holding >= 8 records emits exactly one aligned 8-record sector (8 consecutive lanes, one
+// store instruction) and slides its remainder down.  A record that finds its queue full goes straight to the END of
+// the region (downward cursor, rare); at the end of the kernel the leftovers (< 8 per partition) and `no cell`
+// fillers close the gap, so pass C reads the same contiguous partitions as before and skips the fillers.
+// LDS: q[F * cap] u64 | cnt[F] | gcur[F] | gend[F] u32 | jobs[F] u16.  Tiles are small (RPT rows per thread, 2 * RPT
+// with a second key), two register sets alternate so that every load has more than a tile to land.
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t kWcSector = 8;  // records per 64-byte sector (the smaller of the two emit sizes)
+static constexpr bool kWcDefault = true;   // measured: k_partition 0.99 -> 0.71 ms at C2, same box (TAD_PARTB=sort selects the old pass)
+
+// SEC = records per emitted piece: 8 (one 64-byte sector) when LDS leaves only 9..12 queue slots per partition, 16 (one
+// whole 128-byte line — streaming speed in the micro-benchmark) when there are few enough partitions for >= 22 slots.
+template <int RPT, int SEC, bool HAS2, bool GENERIC>
+__global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint32_t cap, int G) {
+  static_assert(RPT == 2 || RPT == 4, "rows per thread: one or two 16-byte loads per column");
+  static_assert(SEC == 8 || SEC == 16, "emit one 64-byte sector or one 128-byte line");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint32_t TILE = (uint32_t)RPT * kPartThreads;
+  const uint32_t F = A.nparts;
+  unsigned long long *q = reinterpret_cast<unsigned long long *>(smem);
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + (size_t)F * cap * 8);
+  uint32_t *gcur = cnt + F;   // next sector of (this workgroup, partition), upward
+  uint32_t *gend = gcur + F;  // end of the region / first spilled record, downward
+  uint16_t *jobs = reinterpret_cast<uint16_t *>(gend + F);
+  __shared__ uint32_t s_njobs;
+
+  {
+    const uint32_t *my = A.offs32 + (size_t)blockIdx.x * F;
+    const uint32_t *nx = A.offs32 + (size_t)(blockIdx.x + 1) * F;
+    const bool last = (int)blockIdx.x + 1 == G;
+    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
+      const uint32_t ps = (uint32_t)A.part_start[p];
+      cnt[p] = 0;
+      gcur[p] = ps + my[p];
+      gend[p] = last ? (uint32_t)A.part_start[p + 1] : ps + nx[p];
+    }
+    if (threadIdx.x == 0) s_njobs = 0;
+  }
+
+  const uint64_t lo = (uint64_t)blockIdx.x * A.chunk;
+  const uint64_t hi = lo + A.chunk < A.n ? lo + A.chunk : A.n;
+  const bool has_ts = GENERIC && A.t_start != nullptr && A.f.start_time != 0;
+  const uint32_t KP = A.kp_mask + 1u;
+  const uint32_t cell_none = (1u << A.cell_bits) - 1u;
+  const unsigned long long value_limit = 1ull << (64 - A.cell_bits);
+  uint32_t err = 0, used = 0;
+  const uint64_t nfull = hi > lo ? (hi - lo) / TILE : 0;
+  const uint64_t ntiles = hi > lo ? (hi - lo + TILE - 1) / TILE : 0;
+
+  struct Rows { uint64_t k[RPT], k2[HAS2 ? RPT : 1], v[RPT]; int64_t t[RPT]; };
+  auto row_index = [&](uint64_t base, int j) -> uint64_t { return base + (uint64_t)(j >> 1) * (2 * kPartThreads) + 2 * threadIdx.x + (j & 1); };
+  auto load_tile = [&](Rows &r, uint64_t tile) {  // workgroup-uniform branches only
+    const uint64_t base = lo + tile * TILE;
+    if (tile < nfull) {
+#pragma unroll
+      for (int j = 0; j < RPT; j += 2) {
+        const uint64_t i = row_index(base, j);
+        const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(A.key + i);
+        const longlong2 t = *reinterpret_cast<const longlong2 *>(A.t_end + i);
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(A.value + i);
+        r.k[j] = k.x; r.k[j + 1] = k.y; r.t[j] = t.x; r.t[j + 1] = t.y; r.v[j] = v.x; r.v[j + 1] = v.y;
+        if (HAS2) { const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(A.key2 + i); r.k2[j] = k2.x; r.k2[j + 1] = k2.y; }
+      }
+    } else if (tile < ntiles) {
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        const uint64_t i = row_index(base, j);
+        const bool in = i < hi;
+        r.k[j] = in ? A.key[i] : TAD_KEY_SKIP;
+        r.t[j] = in ? A.t_end[i] : 0;
+        r.v[j] = in ? A.value[i] : 0;
+        if (HAS2) r.k2[j] = in ? A.key2[i] : TAD_KEY_SKIP;
+      }
+    }
+  };
+
+  auto process = [&](Rows &r, uint64_t tile) {
+    const uint64_t base = lo + tile * TILE;
+    // ---- append: every record joins its partition's queue (LDS), or spills to the end of the region ----
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int64_t te = r.t[j];
+      bool kept = true;
+      if (GENERIC && (A.f.end_time != 0 || has_ts)) {
+        const uint64_t i = row_index(base, j);
+        const int64_t ts = (has_ts && i < hi) ? A.t_start[i] : 0;
+        kept = p_time_kept(te, ts, has_ts, A.f);
+      }
+      uint32_t bucket = 0;
+      bool on_lattice;
+      if (GENERIC) {
+        on_lattice = p_bucket(A.L, te, bucket);
+      } else {
+        const uint64_t d = (uint64_t)te - (uint64_t)A.L.t0;
+        const uint64_t bq = A.L.mode == 0 ? d : __umul64hi(d, A.L.magic);
+        on_lattice = (d >> 32) == 0 && bq < A.L.nb && bq * (uint64_t)A.L.step == d;
+        bucket = (uint32_t)bq;
+      }
+#pragma unroll
+      for (int h = 0; h < (HAS2 ? 2 : 1); ++h) {
+        const uint64_t k = h == 0 ? r.k[j] : r.k2[HAS2 ? j : 0];
+        if (kept && k != TAD_KEY_SKIP && k < A.K) {  // same predicate as pass A: the slot is reserved
+          uint32_t cell = cell_none;
+          if (on_lattice) {
+            used++;
+            if (r.v[j] < value_limit) {
+              cell = bucket * KP + ((uint32_t)k & A.kp_mask);
+            } else {
+              const unsigned long long o = atomicAdd(A.ovf_count, 1ull);
+              if (o < A.ovf_cap) { A.ovf[o].val = r.v[j]; A.ovf[o].gcell = (unsigned long long)bucket * A.K + k; }
+              else err |= DEV_ERR_OVERFLOW_LIST;
+            }
+          } else {
+            err |= DEV_ERR_OFF_LATTICE;
+          }
+          const uint32_t p = (uint32_t)(k >> A.shift_part);
+          const unsigned long long rec = (r.v[j] << A.cell_bits) | cell;
+          const uint32_t pos = atomicAdd(&cnt[p], 1u);
+          if (pos < cap) q[p * cap + pos] = rec;
+          else A.recs[atomicSub(&gend[p], 1u) - 1u] = rec;  // queue full (a burst, or a hot key): top of the region
+        }
+      }
+    }
+    load_tile(r, tile + 2);  // this register set is free again: lands during the rest of this tile and the whole next one
+    lds_barrier();
+    // ---- which queues can emit a sector ----
+    for (uint32_t p0 = 0; p0 < F; p0 += kPartThreads) {  // workgroup-uniform trip count: the ballot below needs whole wavefronts
+      const uint32_t p = p0 + threadIdx.x;
+      uint32_t c = p < F ? cnt[p] : 0u;
+      if (c > cap) { c = cap; cnt[p] = cap; }
+      const bool emit = c >= (uint32_t)SEC;
+      const unsigned long long m = __ballot(emit);  // one LDS atomic per wavefront instead of one per queue
+      if (m) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(&s_njobs, (uint32_t)__popcll(m));
+        first = __shfl(first, 0);
+        if (emit) jobs[first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
+      }
+    }
+    lds_barrier();
+    // ---- emit: SEC consecutive lanes write the queue's whole aligned pieces (one store instruction each); the remainder
+    // slides down to the front of the queue ----
+    const uint32_t nj = s_njobs;
+    for (uint32_t j = threadIdx.x / SEC; j < nj; j += kPartThreads / SEC) {
+      const uint32_t p = jobs[j], sl = threadIdx.x & (SEC - 1u);
+      const uint32_t c = cnt[p], g = gcur[p];
+      unsigned long long *qp = q + p * cap;
+      const uint32_t whole = c & ~(uint32_t)(SEC - 1);
+      for (uint32_t o = 0; o < whole; o += SEC) A.recs[g + o + sl] = qp[o + sl];
+      const bool mv = whole + sl < c;
+      const unsigned long long tail = mv ? qp[whole + sl] : 0ull;
+      if (mv) qp[sl] = tail;  // (one wavefront, LDS in order: every lane has read before any lane writes)
+      if (sl == 0) { cnt[p] = c - whole; gcur[p] = g + whole; }
+    }
+    lds_barrier();
+    if (threadIdx.x == 0) s_njobs = 0;  // next used after the next tile's first barrier
+  };
+
+  Rows R0, R1;
+  load_tile(R0, 0);
+  load_tile(R1, 1);
+  lds_barrier();
+  for (uint64_t tile = 0; tile < ntiles; tile += 2) {
+    process(R0, tile);
+    if (tile + 1 < ntiles) process(R1, tile + 1);
+  }
+  // ---- close the regions: leftovers, then `no cell` fillers up to the spilled records ----
+  for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
+    const uint32_t c = cnt[p] < cap ? cnt[p] : cap;
+    uint32_t g = gcur[p];
+    const uint32_t e = gend[p];
+    for (uint32_t i = 0; i < c; ++i) A.recs[g + i] = q[p * cap + i];
+    for (g += c; g < e; ++g) A.recs[g] = ~0ull;
+  }
+  unsigned long long u = used;
+  for (int d = 32; d >= 1; d >>= 1) { u += __shfl_down(u, d); err |= __shfl_down(err, d); }
+  if ((threadIdx.x & 63) == 0) {
+    if (u) atomicAdd(&A.ctr->rows_used, u);
+    if (err) atomicOr(&A.ctr->err, err);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pass C — aggregate the records of a partition in an LDS tile, write the tile out.
 // LDS carve: vals[KP*T] u64 | flags[KP*T] u8
 //
@@ -755,6 +948,7 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   for (int c = 13; c >= 0; --c)
     if (((uint64_t)T << c) <= kTileCells) { sp_fit = c; break; }
   int sp = sp_fit >= pl->shift_bin ? sp_fit : pl->shift_bin;
+  if (const char *e = getenv("TAD_KP_SHIFT_MIN")) { const int v = atoi(e); if (v > sp && v <= 13) sp = v; }  // tuning knob: wider key blocks
   while (((K + (1ull << sp) - 1) >> sp) > kMaxParts && sp < 13) ++sp;
   if (((K + (1ull << sp) - 1) >> sp) > kMaxParts) return false;
   while (sp > pl->shift_bin && (1ull << (sp - 1)) >= K) --sp;  // no wider than the key space
@@ -788,6 +982,47 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
 
 static bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+bool columns_aligned16(const void *key, const void *key2, const void *t_end, const void *value) {
+  return aligned16(key) && aligned16(key2) && aligned16(t_end) && aligned16(value);
+}
+
+// write-combining pass B: F * (8 * cap + 14) bytes of LDS.  With >= 28 slots per partition the queues emit whole
+// 128-byte lines (16 records), with 9..21 slots 64-byte sectors; below 9 slots (more than ~1800 partitions) and for
+// tables with so few partitions that the sort-by-tile pass already writes long runs, the old pass runs.
+// TAD_PARTB=sort / =wc overrides the choice, TAD_WC_SEC / TAD_WC_RPT the emit size and rows per thread.
+void part_plan_wc(uint64_t slots, bool aligned, bool has2, PartPlan *pl) {
+  pl->wc_cap = 0;
+  pl->wc_sec = 0;
+  pl->wc_rpt = 0;
+  pl->pad_slots = 0;
+  const char *env = getenv("TAD_PARTB");
+  if (env && !strcmp(env, "sort")) return;
+  if (!aligned || pl->nparts == 0) return;
+  const size_t per = kLdsBudget / pl->nparts;
+  if (per < 14 + 8 * 9) return;
+  uint32_t cap = (uint32_t)((per - 14) / 8);
+  if (cap > 64) cap = 64;
+  uint32_t sec = cap >= 22 ? 16 : 8;   // 15 leftovers + room for a tile's arrivals
+  if (const char *e = getenv("TAD_WC_SEC")) { const int v = atoi(e); if (v == 8 || (v == 16 && cap >= 20)) sec = (uint32_t)v; }
+  if (sec == 8 && cap > 16) cap = 16;
+  // the sort-by-tile pass writes runs of (tile slots / partitions) records: long runs beat 64-byte sectors
+  const bool forced = env && !strcmp(env, "wc");
+  if (!forced && !kWcDefault) return;
+  if (!forced && sec == 8 && (uint64_t)pl->rpt * kPartThreads * (has2 ? 2 : 1) / pl->nparts >= 24) return;
+  // few, large partitions: a tile brings more records per partition than a queue can take (and the sort pass writes long runs)
+  if (!forced && 2.0 * kPartThreads * (has2 ? 2 : 1) / (double)pl->nparts > 0.5 * (double)(cap - (sec - 1))) return;
+  // rows per thread: 4 when a queue holding SEC - 1 leftovers still has room for twice the expected arrivals of a tile
+  const double lam4 = 4.0 * kPartThreads * (has2 ? 2 : 1) / (double)pl->nparts;
+  uint32_t rpt = !has2 && (double)(cap - (sec - 1)) >= 2.0 * lam4 + 4.0 ? 4 : 2;
+  if (const char *e = getenv("TAD_WC_RPT")) { const int v = atoi(e); if (v == 2 || (v == 4 && !has2)) rpt = (uint32_t)v; }
+  const uint64_t pad = (uint64_t)(sec - 1) * pl->G * pl->nparts;
+  if (slots + pad >= (1ull << 32)) return;
+  pl->wc_cap = cap;
+  pl->wc_sec = sec;
+  pl->wc_rpt = rpt;
+  pl->pad_slots = pad;
+}
+
 void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, uint64_t n, uint64_t K, RowFilter f, const PartPlan &pl,
                       MetaPartial *partials, uint32_t *binhist, DevCounters *ctr) {
@@ -806,7 +1041,8 @@ void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
                          unsigned long long *part_start) {
-  hipLaunchKernelGGL(k_part_rows, dim3(pl.G), dim3(256), 0, s, binhist, pl.nbins, pl.bins_per_part, pl.nparts, offs32);
+  hipLaunchKernelGGL(k_part_rows, dim3(pl.G), dim3(256), 0, s, binhist, pl.nbins, pl.bins_per_part, pl.nparts, offs32,
+                     pl.wc_cap ? pl.wc_sec - 1u : 0u);
   hipLaunchKernelGGL(k_part_colscan, dim3((pl.nparts + 255) / 256), dim3(256), 0, s, offs32, pl.G, pl.nparts, total);
   hipLaunchKernelGGL(k_part_scan1, dim3(1), dim3(kPartThreads), 0, s, total, pl.nparts, part_start);
 }
@@ -826,6 +1062,21 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   const bool vec = aligned16(key) && aligned16(key2) && aligned16(t_end) && aligned16(value);
   // fast path: 16-byte loads, no time-window filter, bucket by one multiply-high
   const bool generic = !vec || L.mode == 2 || f.end_time != 0 || (f.start_time != 0 && t_start != nullptr);
+  if (pl.wc_cap) {  // write-combining variant (the plan checked the alignment)
+    const size_t wlds = ((size_t)pl.nparts * (8 * (size_t)pl.wc_cap + 14) + 15) & ~(size_t)15;
+#define TAD_WC(RPT, SEC, H2, GEN)                                                                                       \
+  do {                                                                                                                \
+    allow_big_lds(reinterpret_cast<const void *>(k_partition_wc<RPT, SEC, H2, GEN>), kLdsBudget);                      \
+    hipLaunchKernelGGL((k_partition_wc<RPT, SEC, H2, GEN>), dim3(pl.G), dim3(kPartThreads), wlds, s, A, pl.wc_cap, pl.G); \
+  } while (0)
+#define TAD_WC_SEC(RPT, H2, GEN) do { if (pl.wc_sec == 16) TAD_WC(RPT, 16, H2, GEN); else TAD_WC(RPT, 8, H2, GEN); } while (0)
+    if (pl.wc_rpt == 4 && !has2) { if (generic) TAD_WC_SEC(4, false, true); else TAD_WC_SEC(4, false, false); }
+    else if (has2) { if (generic) TAD_WC_SEC(2, true, true); else TAD_WC_SEC(2, true, false); }
+    else { if (generic) TAD_WC_SEC(2, false, true); else TAD_WC_SEC(2, false, false); }
+#undef TAD_WC_SEC
+#undef TAD_WC
+    return;
+  }
   int rpt = pl.rpt;
   if (generic && rpt > 4) rpt = 4;
   const size_t fixed = ((size_t)pl.nparts + 4) * 12 + 64;
