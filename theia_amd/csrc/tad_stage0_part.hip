@@ -829,13 +829,24 @@ struct TileGeom {
   uint32_t nparts;
   uint32_t tb;        // buckets per round
   uint32_t n_chunks;  // ceil(T / tb)
+  uint32_t par_rounds;  // 1: every round of a slice is its own workgroup (grid = slices x rounds), see k_tile_aggregate
 };
 
 template <bool OPMAX>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
                                                                  SliceTable st, TileGeom tg, Grid g, int phase) {
-  const uint32_t s_idx = blockIdx.x;
+  // Rounds as workgroups: a partition whose KP x T block needs R > 1 LDS tiles is read by R workgroups, one per bucket
+  // round, instead of R times by one.  The R workgroups of a slice get block ids x + 8 * (R * j + r): the same XCD
+  // (blocks are dealt round-robin over the 8 XCDs) and adjacent in dispatch order, so they stream the same records at
+  // the same time and all but the first reader hit that XCD's L2.
+  uint32_t s_idx = blockIdx.x, r_lo = 0, r_hi = tg.n_chunks;
+  if (phase != 0 && tg.par_rounds && tg.n_chunks > 1) {
+    const uint32_t x = blockIdx.x & 7u, y = blockIdx.x >> 3;
+    r_lo = y % tg.n_chunks;
+    r_hi = r_lo + 1;
+    s_idx = (y / tg.n_chunks) * 8u + x;
+  }
   if (s_idx >= *st.n_slices) return;
   const uint32_t p = st.slice_part[s_idx];
   const uint32_t first = st.slice_first[p];
@@ -859,14 +870,14 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
   const unsigned long long plo = part_start[p], phi = part_start[p + 1];
   const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * kSliceRecords;
   const unsigned long long hi = lo + kSliceRecords < phi ? lo + kSliceRecords : phi;
-  for (uint32_t chunk = 0; chunk < tg.n_chunks; ++chunk) {
+  for (uint32_t chunk = r_lo; chunk < r_hi; ++chunk) {
     const uint32_t b_lo = chunk * tg.tb;
     const uint32_t nb = b_lo + tg.tb <= T ? tg.tb : T - b_lo;
     const uint32_t cells = nb << shift_part;
     const uint32_t c_lo = b_lo << shift_part;  // first partition-local cell of this round
     unsigned long long *vals = reinterpret_cast<unsigned long long *>(smem);
     uint8_t *flags = smem + (size_t)(tg.tb << shift_part) * 8;
-    if (chunk) __syncthreads();  // the previous round's tile has been written out
+    if (chunk != r_lo) __syncthreads();  // the previous round's tile has been written out
     for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
     for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
     __syncthreads();
@@ -952,6 +963,21 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   while (((K + (1ull << sp) - 1) >> sp) > kMaxParts && sp < 13) ++sp;
   if (((K + (1ull << sp) - 1) >> sp) > kMaxParts) return false;
   while (sp > pl->shift_bin && (1ull << (sp - 1)) >= K) --sp;  // no wider than the key space
+  // Whole 128-byte lines from the write-combining pass B need >= 22 queue slots per partition in LDS (part_plan_wc):
+  // widen the key block until the partitions are few enough, if pass C then needs at most twice the bucket rounds
+  // (they run as parallel workgroups sharing an XCD's L2, k_tile_aggregate) and no more than 4.  C2: 1563 partitions of
+  // 64 keys -> 782 of 128 keys, 2 rounds: partition pass 0.715 -> 0.59 ms, pass C 0.26 -> 0.29 ms.
+  {
+    const char *wide_env = getenv("TAD_WIDE_KP");
+    auto parts_of = [&](int c) { return (K + (1ull << c) - 1) >> c; };
+    auto rounds_of = [&](int c) { const uint64_t tb = kTileCells >> c; return tb ? (T + tb - 1) / tb : (uint64_t)1 << 30; };
+    const uint64_t line_parts = kLdsBudget / (8 * 22 + 14);
+    if (!(wide_env && atoi(wide_env) == 0) && parts_of(sp) > line_parts) {
+      int c = sp;
+      while (c < 13 && parts_of(c) > line_parts) ++c;
+      if (parts_of(c) <= line_parts && (1ull << c) <= kTileCells && rounds_of(c) <= 2 * rounds_of(sp) && rounds_of(c) <= 4) sp = c;
+    }
+  }
   if ((1ull << sp) > kTileCells) return false;                 // one bucket of the block must fit a tile
   pl->shift_part = sp;
   pl->KP = 1u << sp;
@@ -1121,14 +1147,17 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   allow_big_lds(reinterpret_cast<const void *>(op_max ? k_tile_aggregate<true> : k_tile_aggregate<false>), kLdsBudget);
   hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st);
   const bool may_split = slots > kSliceRecords;  // some partition could exceed one slice
-  TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks};
+  const char *pr_env = getenv("TAD_PAR_ROUNDS");
+  const uint32_t par = pl.n_chunks > 1 && !(pr_env && atoi(pr_env) == 0) ? 1u : 0u;
+  TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par};
+  const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
   if (op_max) {
     if (may_split) hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0);
-    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1);
+    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1);
     hipLaunchKernelGGL((k_apply_overflow<true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
   } else {
     if (may_split) hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0);
-    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1);
+    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1);
     hipLaunchKernelGGL((k_apply_overflow<false>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
   }
 }
