@@ -140,13 +140,14 @@ struct ResultBlock {
   size_t cap = 0;
 };
 
+// every column starts on a 32-byte boundary (stride = rows rounded up to 4): k_emit stores four rows at a time
 size_t result_bytes(uint64_t rows, bool with_anomaly) {
-  const uint64_t r = rows ? rows : 1;
+  const uint64_t r = ((rows ? rows : 1) + 3) & ~3ull;
   return (size_t)r * 8 * 5 + (with_anomaly ? (size_t)((r + 15) & ~15ull) : 0);
 }
 
 void carve(void *base, uint64_t rows, bool with_anomaly, OutRows *o) {
-  const uint64_t r = rows ? rows : 1;
+  const uint64_t r = ((rows ? rows : 1) + 3) & ~3ull;
   unsigned char *p = static_cast<unsigned char *>(base);
   o->key_id = reinterpret_cast<unsigned long long *>(p); p += r * 8;
   o->flow_end_s = reinterpret_cast<long long *>(p); p += r * 8;
