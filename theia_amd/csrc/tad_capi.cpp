@@ -45,8 +45,6 @@ struct tad_engine {
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
   DevBuf rcp_table;           // rcp_table[n] = RN(1/n), n = 0..rcp_n-1
   uint64_t rcp_n = 0;
-  DevBuf seg_e, seg_cum;      // EWMA checkpoints per (time segment, key) for the segmented emit
-  SegCkpt seg;                // valid for the job in flight when seg.e != nullptr
   DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
@@ -233,7 +231,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->seg_e, &e->seg_cum, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -336,20 +334,9 @@ int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ct
     if ((rc = ensure(e, e->calc, (g.K * g.T ? g.K * g.T : 1) * sizeof(double))) != TAD_OK) return rc;
     launch_drop(s, g, jp.drop_nsigma, jp.drop_min_samples, static_cast<double *>(e->calc.p), sigma, n_pts,
                 static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p), ctr);
-  } else if (!stats_done) {
-    e->seg = SegCkpt{};
-    if (ewma && !jp.all_points && g.T >= 64 && g.K) {   // the count walk leaves EWMA checkpoints for a 4-lanes-per-key emit
-      const uint32_t seg_len = (uint32_t)((((g.T + kEmitSegs - 1) / kEmitSegs) + 7) & ~7ull);
-      if ((rc = ensure(e, e->seg_e, (size_t)kEmitSegs * g.K * sizeof(double))) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->seg_cum, (size_t)kEmitSegs * g.K * sizeof(uint32_t))) != TAD_OK) return rc;
-      e->seg.e = static_cast<double *>(e->seg_e.p);
-      e->seg.cum = static_cast<uint32_t *>(e->seg_cum.p);
-      e->seg.seg_len = seg_len;
-      e->seg.n_segs = (uint32_t)((g.T + seg_len - 1) / seg_len);
-    }
+  } else if (!stats_done)
     launch_key_sigma(s, g, jp.alpha, ewma && !jp.all_points, static_cast<const double *>(e->rcp_table.p), sigma, n_pts, n_anom, ctr, static_cast<double *>(e->key_mean.p),
-                     static_cast<double *>(e->key_m2.p), e->seg);
-  }
+                     static_cast<double *>(e->key_m2.p));
   launch_moments(s, g.K, n_pts, static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
                  static_cast<Moments *>(e->moments.p));
   if (jp.algo == TAD_ALGO_DBSCAN) {
@@ -384,7 +371,7 @@ void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows ou
   const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : (jp.algo == TAD_ALGO_DROP ? 3 : 2));
   launch_emit(e->stream, g, L, kind, jp.all_points, jp.alpha, static_cast<const double *>(e->sigma.p),
               static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(kind == 3 ? e->key_mean.p : e->calc.p),
-              static_cast<const unsigned long long *>(e->off.p), out, kind == 0 && !jp.all_points ? e->seg : SegCkpt{});
+              static_cast<const unsigned long long *>(e->off.p), out);
 }
 
 int make_result(tad_engine *e, uint64_t rows, bool with_anomaly, tad_mem out_memory, ResultPriv **out, OutRows *dev_rows,

@@ -54,14 +54,6 @@ struct RowFilter {
   int64_t end_time;    // 0 = unset
 };
 
-// EWMA checkpoints at the start of every time segment (written by the count walk, read by the segmented emit)
-struct SegCkpt {
-  double *e = nullptr;      // [n_segs][K] EWMA state before the segment's first step
-  uint32_t *cum = nullptr;  // [n_segs][K] anomalies of the key before the segment
-  uint32_t seg_len = 0, n_segs = 0;
-};
-static constexpr uint32_t kEmitSegs = 4;
-
 struct OutRows {
   unsigned long long *key_id;
   long long *flow_end_s;
@@ -101,7 +93,7 @@ __device__ __forceinline__ double div_by_count(double a, double b, double y) {
 
 // per-key n / sigma (+ EWMA anomaly count when ewma != 0).  rcp[n] = RN(1/n) for n = 0..T (rcp[0] unused).
 void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, const double *rcp, double *sigma,
-                      uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2, SegCkpt sc = SegCkpt{});
+                      uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2);
 // deterministic Chan merge of the per-key (n, mean, M2) into kMomentBlocks partials
 struct Moments { double n, mean, m2; };
 static constexpr int kMomentBlocks = 128;
@@ -115,7 +107,7 @@ size_t scan_scratch_elems(uint64_t K);
 // kind: 0 EWMA (recompute), 1 flags + calc array, 2 flags with calc = 0, 3 flags with calc = per-key value calc[k]
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
-                 const unsigned long long *off, OutRows out, SegCkpt sc = SegCkpt{});
+                 const unsigned long long *off, OutRows out);
 void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long long *off, unsigned long long *out_key,
                         long long *out_t, unsigned long long *out_val);
 // streaming EWMA: per-key running state (tad_state); k_stream continues the recurrences over the new grid

@@ -245,14 +245,15 @@ static constexpr int kUnroll = 16;  // independent loads in flight per lane: the
 static constexpr int kWalkChunk = 8;
 
 template <typename Step>
-__device__ __forceinline__ void walk_range(const Grid &g, uint64_t k, uint64_t t0, uint64_t t1, Step step) {
-  const uint64_t nfull = (t1 - t0) / kWalkChunk;
+__device__ __forceinline__ void walk_series(const Grid &g, uint64_t k, Step step) {
+  const uint64_t T = g.T;
+  const uint64_t nfull = T / kWalkChunk;
   uint8_t fa[kWalkChunk], fb[kWalkChunk];
   unsigned long long va[kWalkChunk], vb[kWalkChunk];
   auto load = [&](uint64_t c, uint8_t *f, unsigned long long *v) {
 #pragma unroll
     for (int u = 0; u < kWalkChunk; ++u) {
-      const uint64_t cell = (t0 + c * kWalkChunk + u) * g.K + k;
+      const uint64_t cell = (c * kWalkChunk + u) * g.K + k;
       f[u] = g.flag[cell];
       v[u] = g.val[cell];
     }
@@ -263,30 +264,27 @@ __device__ __forceinline__ void walk_range(const Grid &g, uint64_t k, uint64_t t
     for (; c + 2 <= nfull; c += 2) {
       load(c + 1, fb, vb);
 #pragma unroll
-      for (int u = 0; u < kWalkChunk; ++u) step(t0 + c * kWalkChunk + u, fa[u], va[u]);
+      for (int u = 0; u < kWalkChunk; ++u) step(c * kWalkChunk + u, fa[u], va[u]);
       load(c + 2 < nfull ? c + 2 : c + 1, fa, va);   // past the end: a redundant in-bounds reload keeps the count fixed
 #pragma unroll
-      for (int u = 0; u < kWalkChunk; ++u) step(t0 + (c + 1) * kWalkChunk + u, fb[u], vb[u]);
+      for (int u = 0; u < kWalkChunk; ++u) step((c + 1) * kWalkChunk + u, fb[u], vb[u]);
     }
     if (c < nfull) {
 #pragma unroll
-      for (int u = 0; u < kWalkChunk; ++u) step(t0 + c * kWalkChunk + u, fa[u], va[u]);
+      for (int u = 0; u < kWalkChunk; ++u) step(c * kWalkChunk + u, fa[u], va[u]);
     }
   }
-  for (uint64_t t = t0 + nfull * kWalkChunk; t < t1; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
+  for (uint64_t t = nfull * kWalkChunk; t < T; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
 }
-
-template <typename Step>
-__device__ __forceinline__ void walk_series(const Grid &g, uint64_t k, Step step) { walk_range(g, k, 0, g.T, step); }
 
 // RCP_LDS: the reciprocal table (T + 1 doubles) is copied to LDS first.  A table lookup from global memory inside the
 // step would be a vector-memory load YOUNGER than the prefetched chunk of the walk, and vmcnt retires in order: waiting
-// for it waits for the whole prefetch, which serialises the walk into one memory round trip per chunk.
+// for it waits for the whole prefetch, which serialises the walk into one memory round trip per chunk (127 -> 101 us).
 template <bool EWMA_COUNT, bool RCP_LDS>
 __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, const double *__restrict__ rcp_g, double *__restrict__ sigma,
                                                       uint32_t *__restrict__ n_pts,
                                                       uint32_t *__restrict__ n_anom, DevCounters *ctr,
-                                                      double *__restrict__ key_mean, double *__restrict__ key_m2, SegCkpt sc) {
+                                                      double *__restrict__ key_mean, double *__restrict__ key_m2) {
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_rcp[];
   const double *rcp = rcp_g;
@@ -324,15 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, cons
       if (has_sigma) {
         const double one_minus = 1.0 - alpha;
         double e = 0.0;
-        uint64_t next_b = sc.e ? 0 : ~0ull;  // checkpoints for the segmented emit: EWMA state and anomaly count at every segment start
-        uint32_t seg = 0;
-        walk_series(g, k, [&](uint64_t t, uint8_t fl, unsigned long long raw) {
-          if (t == next_b) {  // wave-uniform
-            sc.e[(uint64_t)seg * g.K + k] = e;
-            sc.cum[(uint64_t)seg * g.K + k] = a;
-            seg++;
-            next_b += sc.seg_len;
-          }
+        walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
           if (fl & FLAG_PRESENT) {
             const double x = (double)raw;
             e = one_minus * e + alpha * x;
@@ -354,12 +344,12 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, cons
 }
 
 void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, const double *rcp, double *sigma,
-                      uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2, SegCkpt sc) {
+                      uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2) {
   if (g.K == 0) return;
   const int blocks = (int)((g.K + kBlock - 1) / kBlock);
   const size_t lds = (size_t)(g.T + 1) * 8;
   const bool in_lds = lds <= 32768;
-#define TAD_KS(EC, RL) hipLaunchKernelGGL((k_key_sigma<EC, RL>), dim3(blocks), dim3(kBlock), RL ? lds : 0, s, g, alpha, rcp, sigma, n_pts, n_anom, ctr, key_mean, key_m2, sc)
+#define TAD_KS(EC, RL) hipLaunchKernelGGL((k_key_sigma<EC, RL>), dim3(blocks), dim3(kBlock), RL ? lds : 0, s, g, alpha, rcp, sigma, n_pts, n_anom, ctr, key_mean, key_m2)
   if (ewma_count) { if (in_lds) TAD_KS(true, true); else TAD_KS(true, false); }
   else { if (in_lds) TAD_KS(false, true); else TAD_KS(false, false); }
 #undef TAD_KS
@@ -514,15 +504,21 @@ void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, ui
 // KIND 1: verdict bits + calc[] written by a detector kernel (ARIMA);
 // KIND 2: verdict bits, algoCalc = 0.0 (DBSCAN placeholder, :312-322).
 // ------------------------------------------------------------------------------------------------
-// rows of key k with t in [t0, t1), written at [pos, end); e0 = EWMA state at t0 (KIND 0)
 template <int KIND, bool ALL>
-__device__ __forceinline__ void emit_key(const Grid &g, const Lattice &L, double alpha, uint64_t k, const double *__restrict__ sigma,
-                                         const uint32_t *__restrict__ n_pts, const double *__restrict__ calc, unsigned long long pos,
-                                         const unsigned long long end, double e0, uint64_t t0, uint64_t t1, const OutRows &out) {
+__global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha,
+                                                 const double *__restrict__ sigma,
+                                                 const uint32_t *__restrict__ n_pts,
+                                                 const double *__restrict__ calc,
+                                                 const unsigned long long *__restrict__ off, OutRows out) {
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= g.K) return;
+  unsigned long long pos = off[k];
+  const unsigned long long end = off[k + 1];
+  if (pos == end) return;
   const double sg = sigma[k];
   const bool has_sigma = n_pts[k] >= 2;
   const double one_minus = 1.0 - alpha;
-  double e = e0;
+  double e = 0.0;
   // Every scattered 8-byte store is its own write transaction on this memory system (k_emit wrote 280 MB for 81 MB of
   // rows), so rows are buffered four at a time per lane and stored as aligned 16-byte pairs.
   long long bt[4];
@@ -579,54 +575,17 @@ __device__ __forceinline__ void emit_key(const Grid &g, const Lattice &L, double
       }
     }
   };
-  walk_range(g, k, t0, t1, step);
+  walk_series(g, k, step);
 #pragma unroll
   for (int i = 0; i < 3; ++i)   // tail of the segment: fewer than four buffered rows
     if (i < nb) write_row(pos + i, bt[i], bx[i], ba[i], ALL && bv[i] != 0);
 }
 
-template <int KIND, bool ALL>
-__global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha,
-                                                 const double *__restrict__ sigma,
-                                                 const uint32_t *__restrict__ n_pts,
-                                                 const double *__restrict__ calc,
-                                                 const unsigned long long *__restrict__ off, OutRows out) {
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= g.K) return;
-  const unsigned long long pos = off[k];
-  const unsigned long long end = off[k + 1];
-  if (pos == end) return;
-  emit_key<KIND, ALL>(g, L, alpha, k, sigma, n_pts, calc, pos, end, 0.0, 0, g.T, out);
-}
-
-// EWMA rows with kEmitSegs lanes per key: lane (k, j) continues the recurrence from the checkpoint the count walk left at
-// the start of segment j (same operations in the same order: the same bits) and owns the rows [off[k] + cum[j], off[k] +
-// cum[j + 1]).  One lane per key leaves 6 wavefronts per CU at 1e5 keys, far too few to hide the walk's memory latency.
-__global__ __launch_bounds__(kBlock) void k_emit_seg(Grid g, Lattice L, double alpha, const double *__restrict__ sigma,
-                                                     const uint32_t *__restrict__ n_pts,
-                                                     const unsigned long long *__restrict__ off, SegCkpt sc, OutRows out) {
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const uint32_t j = blockIdx.y;
-  if (k >= g.K) return;
-  const unsigned long long base = off[k], endk = off[k + 1];
-  if (base == endk) return;
-  const unsigned long long pos = base + sc.cum[(uint64_t)j * g.K + k];
-  const unsigned long long end = j + 1 < sc.n_segs ? base + sc.cum[(uint64_t)(j + 1) * g.K + k] : endk;
-  if (pos == end) return;
-  const uint64_t t0 = (uint64_t)j * sc.seg_len;
-  const uint64_t t1 = t0 + sc.seg_len < g.T ? t0 + sc.seg_len : g.T;
-  emit_key<0, false>(g, L, alpha, k, sigma, n_pts, nullptr, pos, end, sc.e[(uint64_t)j * g.K + k], t0, t1, out);
-}
-
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
-                 const unsigned long long *off, OutRows out, SegCkpt sc) {
+                 const unsigned long long *off, OutRows out) {
   if (g.K == 0) return;
   const int blocks = (int)((g.K + kBlock - 1) / kBlock);
-  if (kind == 0 && !all_points && sc.e != nullptr) {
-    hipLaunchKernelGGL(k_emit_seg, dim3(blocks, sc.n_segs), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, off, sc, out);
-    return;
-  }
 #define TAD_LAUNCH_EMIT(KIND, ALL) \
   hipLaunchKernelGGL((k_emit<KIND, ALL>), dim3(blocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out)
   if (all_points) {
