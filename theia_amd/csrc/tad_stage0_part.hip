@@ -351,8 +351,8 @@ struct PartArgs {
   uint32_t nparts;
   const uint32_t *offs32;                  // [G][nparts] exclusive row prefix of this workgroup inside each partition
   const unsigned long long *part_start;    // [nparts + 1]
-  unsigned long long *recs;                // out: value << 15 | tile-local cell (bucket * KP + key-in-tile)
-  OverflowRec *ovf;                        // out: records whose value needs more than 49 bits
+  unsigned long long *recs;                // out: value << cell_bits | tile-local cell (bucket * KP + key-in-tile)
+  OverflowRec *ovf;                        // out: records whose value needs more than 64 - cell_bits bits
   unsigned long long *ovf_count;
   uint32_t ovf_cap;
   DevCounters *ctr;
