@@ -584,7 +584,6 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
 // LDS: q[F * cap] u64 | cnt[F] | gcur[F] | gend[F] u32 | jobs[F] u16.  Tiles are small (RPT rows per thread, 2 * RPT
 // with a second key), two register sets alternate so that every load has more than a tile to land.
 // ------------------------------------------------------------------------------------------------
-static constexpr uint32_t kWcSector = 8;  // records per 64-byte sector (the smaller of the two emit sizes)
 static constexpr bool kWcDefault = true;   // measured: k_partition 0.99 -> 0.71 ms at C2, same box (TAD_PARTB=sort selects the old pass)
 
 // SEC = records per emitted piece: 8 (one 64-byte sector) when LDS leaves only 9..12 queue slots per partition, 16 (one
