@@ -252,3 +252,76 @@ def calculate_arima_anomaly(throughput_row, stddev, maxiter=50):
         return [False] * len(pred)
     s = float(stddev)
     return [abs(float(x) - p) > s for x, p in zip(throughput_row, pred)]
+
+
+# ------------------------------------------------------------------------------------------------
+# the fixed-arithmetic restatement (oracle/arima_exact.c): what the GPU path is held to bit for bit
+# ------------------------------------------------------------------------------------------------
+_xlib = None
+
+
+def _load_exact():
+    global _xlib
+    if _xlib is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libarima_exact.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/_build/libarima_exact.so is missing: run `make -C oracle` (or __graft_entry__.build())")
+        lib = ctypes.CDLL(path)
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.arima_exact_series.restype = ctypes.c_int
+        lib.arima_exact_series.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.arima_exact_nll.restype = ctypes.c_double
+        lib.arima_exact_nll.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
+        lib.arima_exact_start_params.restype = None
+        lib.arima_exact_start_params.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+        lib.arima_exact_fit_forecast.restype = ctypes.c_double
+        lib.arima_exact_fit_forecast.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int]
+        lib.arima_exact_boxcox_lambda.restype = ctypes.c_int
+        lib.arima_exact_boxcox_lambda.argtypes = [ctypes.c_void_p, ctypes.c_long, dp]
+        for fn in ("log", "exp", "expm1", "log1p"):
+            f = getattr(lib, "arima_exact_" + fn)
+            f.restype = ctypes.c_double
+            f.argtypes = [ctypes.c_double]
+        _xlib = lib
+    return _xlib
+
+
+def calculate_arima_exact(throughputs, maxiter=50, counters=None):
+    """calculate_arima (anomaly_detection.py:215-264) in the fixed arithmetic of oracle/arima_exact.c.
+    Returns list[float] (length n) or None."""
+    lib = _load_exact()
+    x = np.ascontiguousarray([float(v) for v in throughputs], dtype=np.float64)
+    pred = np.empty(max(x.size, 1), dtype=np.float64)
+    info = np.zeros(4, dtype=np.float64)
+    rc = lib.arima_exact_series(x.ctypes.data, x.size, int(maxiter), pred.ctypes.data, info.ctypes.data)
+    if rc < 0:
+        raise MemoryError("arima_exact_series")
+    if counters is not None and rc == 1:
+        counters["lambda"] = float(info[0])
+        counters["kalman_steps"] = counters.get("kalman_steps", 0) + int(info[1])
+        counters["fits"] = counters.get("fits", 0) + int(info[2])
+        counters["iterations"] = counters.get("iterations", 0) + int(info[3])
+    return [float(v) for v in pred[:x.size]] if rc == 1 else None
+
+
+def calculate_arima_anomaly_exact(throughput_row, stddev, maxiter=50):
+    """anomaly_detection.py:267-309 on top of calculate_arima_exact."""
+    pred = calculate_arima_exact(throughput_row, maxiter)
+    if pred is None:
+        return [False]
+    if stddev is None:
+        return [False] * len(pred)
+    s = float(stddev)
+    return [abs(float(x) - p) > s for x, p in zip(throughput_row, pred)]
+
+
+def kalman_exact(y, phi, theta, sigma2, counters=None):
+    """(loglike with burn 1, forecast) from the fixed-arithmetic filter, signature of kalman_arima111."""
+    lib = _load_exact()
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    u = untransform_params(phi, theta, sigma2)
+    fc = ctypes.c_double()
+    nll = lib.arima_exact_nll(y.ctypes.data, y.size, float(u[0]), float(u[1]), float(u[2]), ctypes.byref(fc))
+    if counters is not None:
+        counters["kalman_steps"] = counters.get("kalman_steps", 0) + y.size
+    return -nll * y.size, fc.value

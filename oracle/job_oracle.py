@@ -112,7 +112,7 @@ def run(flows, algo, start_time="", end_time="", ns_ignore_list=(), agg_flow="",
     rows = []
     agg_type = agg_flow if agg_flow else "None"
     if arima_fn is None and algo == "ARIMA":
-        from .arima_oracle import calculate_arima as arima_fn
+        from .arima_oracle import calculate_arima_exact as arima_fn   # the fixed-arithmetic restatement
     for key_vals, grp in (pts.groupby(keys, sort=True) if len(pts) else []):
         grp = grp.sort_values("flowEndSeconds")
         if not isinstance(key_vals, tuple):

@@ -257,6 +257,7 @@ def run_job(algo, key_id, flow_end_s, value, op=None, agg_flow="", key_id2=None,
     sig_pt = np.repeat(sigma, n)
     has_pt = np.repeat(has_sigma, n)
     keys_no_result = 0
+    arima_counters, arima_results = {}, None
     if algo == "EWMA":
         calc = ewma_all(pvf, ptr, alpha) if pk.size else np.zeros(0)
         with np.errstate(invalid="ignore"):
@@ -268,11 +269,16 @@ def run_job(algo, key_id, flow_end_s, value, op=None, agg_flow="", key_id2=None,
             anomaly[a:b] = dbscan_noise_1d(pvf[a:b], eps, min_samples)
     elif algo == "ARIMA":
         if arima_fn is None:
-            from oracle.arima_oracle import calculate_arima as arima_fn
+            from oracle.arima_oracle import calculate_arima_exact as arima_fn   # the fixed-arithmetic restatement
         calc = np.zeros(pk.size)
         anomaly = np.zeros(pk.size, dtype=bool)
+        arima_results = []
         for k, (a, b) in enumerate(zip(ptr[:-1], ptr[1:])):
-            pred = arima_fn(pv[a:b])
+            try:
+                pred = arima_fn(pv[a:b], counters=arima_counters)
+            except TypeError:         # a plain callable(series) was passed in
+                pred = arima_fn(pv[a:b])
+            arima_results.append(pred)
             if pred is None:          # :284-287 + arrays_zip/explode of a null array: no rows
                 keys_no_result += 1
                 continue
@@ -289,4 +295,5 @@ def run_job(algo, key_id, flow_end_s, value, op=None, agg_flow="", key_id2=None,
         # everything, for deeper comparisons
         "points": (pk, pt, pv), "sigma": sigma, "has_sigma": has_sigma, "keys": keys, "ptr": ptr,
         "calc_all": calc, "anomaly_all": anomaly,
+        "arima_results": arima_results, "kalman_steps": int(arima_counters.get("kalman_steps", 0)),
     }

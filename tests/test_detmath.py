@@ -1,0 +1,42 @@
+"""CPU: accuracy of the deterministic transcendental functions (theia_amd/csrc/tad_detmath.h, the ONE source shared by
+the device code and oracle/arima_exact.c) against numpy's long-double functions.  Determinism across host and device is
+what the bit-identical GPU parity tests (tests/test_gpu_arima.py) demonstrate; this file pins that the functions are
+also CORRECT to within a few ulp, so that sharing them cannot hide an error."""
+import numpy as np
+import pytest
+
+from oracle import arima_oracle as ao
+
+pytestmark = pytest.mark.skipif(np.finfo(np.longdouble).eps >= np.finfo(np.float64).eps, reason="needs an extended long double")
+
+
+def ulp_err(fn_name, ref_fn, x):
+    lib = ao._load_exact()
+    f = getattr(lib, "arima_exact_" + fn_name)
+    got = np.array([f(float(v)) for v in x])
+    ref = ref_fn(x.astype(np.longdouble))
+    ulp = np.spacing(np.abs(ref.astype(np.float64))).astype(np.longdouble)
+    return np.abs((got.astype(np.longdouble) - ref) / ulp).astype(np.float64)
+
+
+@pytest.mark.parametrize("name,ref,bound,gens", [
+    ("log", np.log, 1.0, [lambda r: np.exp(r.uniform(-700, 700, 20000)), lambda r: r.uniform(0.5, 2, 20000), lambda r: r.uniform(1e-10, 1e12, 20000)]),
+    ("exp", np.exp, 1.0, [lambda r: r.uniform(-700, 700, 20000), lambda r: r.uniform(-2, 2, 20000), lambda r: r.uniform(-1e-3, 1e-3, 20000)]),
+    ("expm1", np.expm1, 4.0, [lambda r: r.uniform(-50, 50, 20000), lambda r: r.uniform(-1, 1, 20000), lambda r: r.uniform(-1e-5, 1e-5, 20000)]),
+    ("log1p", np.log1p, 4.0, [lambda r: r.uniform(-0.999, 50, 20000), lambda r: r.uniform(-1e-5, 1e-5, 20000), lambda r: np.exp(r.uniform(-40, 40, 20000))]),
+])
+def test_accuracy_in_ulp(name, ref, bound, gens):
+    rng = np.random.default_rng(5)
+    for g in gens:
+        assert ulp_err(name, ref, g(rng)).max() < bound
+
+
+def test_special_values():
+    lib = ao._load_exact()
+    log, exp = lib.arima_exact_log, lib.arima_exact_exp
+    assert log(0.0) == -np.inf and log(-0.0) == -np.inf and np.isnan(log(-1.0)) and log(np.inf) == np.inf and np.isnan(log(np.nan))
+    assert log(1.0) == 0.0 and abs(log(5e-324) - np.log(5e-324)) < 1e-12 and abs(log(2.0 ** -1022) - np.log(2.0 ** -1022)) < 1e-12
+    assert exp(0.0) == 1.0 and exp(-746.0) == 0.0 and exp(710.0) == np.inf and exp(-np.inf) == 0.0 and np.isnan(exp(np.nan))
+    assert exp(-745.0) == 5e-324 and abs(exp(709.7) / np.exp(709.7) - 1.0) < 1e-15
+    assert lib.arima_exact_expm1(0.0) == 0.0 and lib.arima_exact_expm1(-1e3) == -1.0 and lib.arima_exact_log1p(0.0) == 0.0
+    assert lib.arima_exact_log1p(-1.0) == -np.inf and np.isnan(lib.arima_exact_log1p(-2.0))

@@ -36,7 +36,7 @@ def test_calculate_arima(golden):
     got = ad.calculate_arima(golden["throughput_list"])
     five = [int(str(v)[:5]) for v in got]                                # :276-283 compares the first 5 characters
     hits = sum(a == b for a, b in zip(five, golden["expected_arima_row_list"]))
-    assert hits >= 75        # the reference's own two golden lists agree at 78/90; oracle: 76/90
+    assert hits >= 76        # measured 78; the reference's own two golden lists agree with each other at 78/90
     assert ad.calculate_arima([1, 2, 3]) is None                         # :232-234
 
 
@@ -77,15 +77,9 @@ def test_job_arima_rows_match_oracle_verdicts(engine):
     flows = jo.synth_flows(1500, n_buckets=24)
     stats, got = ad.anomaly_detection("ARIMA", flows, "", "", "a-1", [], "svc")
     want = jo.run(flows, "ARIMA", tad_id="a-1", agg_flow="svc")
-    key = lambda r: (r["destinationServicePortName"], r["flowEndSeconds"])
-    g, w = {key(r): r for r in got}, {key(r): r for r in want}
-    common = set(g) & set(w)
-    # verdicts sit on |x - pred| > sigma; predictions agree to ~1e-6 except on flat likelihoods (tests/test_gpu_arima.py)
-    assert len(common) >= 0.9 * max(len(g), len(w)) and abs(len(g) - len(w)) <= max(2, len(w) // 20)
-    rel = [abs(g[k]["algoCalc"] - w[k]["algoCalc"]) / abs(w[k]["algoCalc"]) for k in common]
-    assert np.median(rel) < 1e-6
-    for k in common:
-        assert g[k]["throughput"] == w[k]["throughput"] and g[k]["throughputStandardDeviation"] == w[k]["throughputStandardDeviation"]
+    # same arithmetic contract on both sides (tests/test_gpu_arima.py): the row SETS are equal, every column bit for bit
+    assert canon(got) == canon(want)
+    assert stats["n_anomalies"] == len(got)
 
 
 def test_cli_end_to_end(engine, tmp_path):

@@ -71,3 +71,62 @@ def test_start_params_small_sample_paths():
         assert abs(phi) < 1 and abs(theta) < 1 and var >= 1e-10
         if n <= 4:
             assert phi == 0.0 and theta == 0.0
+
+
+# ---- the fixed-arithmetic restatement (oracle/arima_exact.c), the checker the GPU path is held to bit for bit ----
+@pytest.fixture(scope="module")
+def golden_exact(golden):
+    return ao.calculate_arima_exact(golden["throughput_list"])
+
+
+def test_exact_verdicts_equal_reference_golden(golden, golden_exact):
+    x, sd = golden["throughput_list"], golden["stddev"]
+    verdict = [abs(float(a) - p) > sd for a, p in zip(x, golden_exact)]
+    assert verdict == golden["expected_anomaly_list_arima"]                       # anomaly_detection_test.py:320-345
+    assert ao.calculate_arima_anomaly_exact(x, sd) == golden["expected_anomaly_list_arima"]
+
+
+def test_exact_values_against_both_reference_lists(golden, golden_exact):
+    five = [int(str(v)[:5]) for v in golden_exact]
+    hits = sum(a == b for a, b in zip(five, golden["expected_arima_row_list"]))   # :261-283, first five characters
+    assert hits >= 76, hits                       # measured 78 / 90 — as many as the reference's own two lists share
+    full = np.array(golden["expanded_arima_row_list"])                            # :288-318, never asserted by the reference
+    rel = np.abs(np.array(golden_exact) - full) / full
+    assert np.median(rel) < 1e-7 and np.percentile(rel, 90) < 1e-4 and rel.max() < 5e-3   # measured 3.4e-10 / 2.5e-5 / 1.9e-3
+    assert np.allclose(golden_exact[:3], golden["throughput_list"][:3], rtol=1e-12)
+
+
+def test_exact_agrees_with_scipy_driven_restatement(golden, golden_pred, golden_exact):
+    """Same model, same optimiser settings; scipy's L-BFGS-B (compact-matrix subspace step) vs the two-loop recursion and
+    glibc vs tad_detmath.h differ in the last bits, which the loosely stopped optimiser amplifies on flat likelihoods."""
+    rel = np.abs(np.array(golden_exact) - np.array(golden_pred)) / np.abs(np.array(golden_pred))
+    assert np.median(rel) < 1e-8 and (rel <= 1e-6).sum() >= 60 and rel.max() < 5e-3       # measured 9e-11, 72 / 90, 1.6e-4
+
+
+def test_exact_pieces_against_the_numpy_restatement(golden):
+    lib = ao._load_exact()
+    x = np.array(golden["throughput_list"], dtype=np.float64)
+    import ctypes
+    lam = ctypes.c_double()
+    assert lib.arima_exact_boxcox_lambda(x.ctypes.data, x.size, ctypes.byref(lam)) == 1
+    assert abs(lam.value - ao.boxcox_mle_lambda(x)) < 1e-6
+    y = np.ascontiguousarray(ao.boxcox_transform(x, lam.value))
+    for n in (4, 5, 6, 7, 30, 90):
+        u = np.zeros(3)
+        lib.arima_exact_start_params(y.ctypes.data, n, u.ctypes.data)
+        want = ao.untransform_params(*ao.start_params(y[:n]))
+        assert np.allclose(u, want, rtol=1e-7, atol=1e-9), (n, u, want)
+    rng = np.random.default_rng(0)
+    ys = np.cumsum(rng.normal(size=80)) + 50
+    for p in [(0.3, -0.4, 1.2), (0.0, 0.0, 0.5), (-0.9, 0.8, 1e-4), (0.99, -0.99, 3.0)]:
+        a = ao.kalman_arima111(ys, *p)
+        b = ao.kalman_exact(ys, *p)
+        # (sigma2 = 1e-4 next to the 1e6 diffuse prior: P - K F K' cancels ten digits, whatever the formulation)
+        assert abs(a[0] - b[0]) <= 1e-8 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-8 * abs(a[1])
+
+
+def test_exact_none_cases():
+    assert ao.calculate_arima_exact([1, 2, 3]) is None
+    assert ao.calculate_arima_exact([5, 5, 5, 5, 5]) is None
+    assert ao.calculate_arima_exact([5, 0, 7, 9, 11]) is None
+    assert ao.calculate_arima_anomaly_exact([1, 2, 3], 1.0) == [False]

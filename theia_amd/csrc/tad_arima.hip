@@ -10,7 +10,7 @@
 // The fit restates statsmodels 0.14 SARIMAX/ARIMA (not in /root/reference; pinned in
 // plugins/anomaly-detection/requirements.txt:3):  state space Z=[1 1 0], T=[[1 1 0],[0 phi 1],[0 0 0]],
 // R=[0 1 theta]', approximate-diffuse (1e6) + stationary initial covariance, loglikelihood_burn = 1,
-// covariance frozen once ||P_t - P_{t+1}||_F^2 < 1e-19; start parameters by conditional sum of squares on
+// covariance frozen once ||P_t - P_{t+1}||_F^2 < 1e-19 (arithmetic contract: see arima_nll); start parameters by conditional sum of squares on
 // diff(y) with numpy-pinv semantics; phi = u/sqrt(1+u^2), theta = -u/sqrt(1+u^2), sigma2 = u^2;
 // objective -loglike/nobs minimised by L-BFGS-B (m = 10, factr = 1e7, pgtol = 1e-5, maxiter = 50, maxls = 20)
 // with forward-difference gradients (h = 1e-5) and the More'-Thuente line search (ftol 1e-3, gtol 0.9,
@@ -24,6 +24,7 @@
 // for exactly one likelihood evaluation per trip, so lanes in different optimiser phases (gradient
 // component, line-search trial, final forecast) still execute the expensive part in lockstep.
 #include "tad_internal.h"
+#include "tad_detmath.h"
 
 // helper functions are host+device so that tools/arima_trace.cpp can step through the same code on the CPU
 #define TAD_HD __host__ __device__
@@ -58,13 +59,13 @@ TAD_HD double bc_neg_llf(double lmb, const double *xs, const double *lx, size_t 
     mean /= (double)n;
     double s = 0.0;
     for (uint32_t i = 0; i < n; ++i) { const double d = lx[i * stride] - mean; s += d * d; }
-    return -((lmb - 1.0) * sumlog - (double)n / 2.0 * log(s / (double)n));
+    return -((lmb - 1.0) * sumlog - (double)n / 2.0 * tad_det_log(s / (double)n));
   }
-  for (uint32_t i = 0; i < n; ++i) mean += exp(lmb * lx[i * stride]) / lmb;
+  for (uint32_t i = 0; i < n; ++i) mean += tad_det_exp(lmb * lx[i * stride]) / lmb;
   mean /= (double)n;
   double s = 0.0;
-  for (uint32_t i = 0; i < n; ++i) { const double d = exp(lmb * lx[i * stride]) / lmb - mean; s += d * d; }
-  return -((lmb - 1.0) * sumlog - (double)n / 2.0 * log(s / (double)n));
+  for (uint32_t i = 0; i < n; ++i) { const double d = tad_det_exp(lmb * lx[i * stride]) / lmb - mean; s += d * d; }
+  return -((lmb - 1.0) * sumlog - (double)n / 2.0 * tad_det_log(s / (double)n));
 }
 
 // returns false when no valid bracket / not finite (scipy raises -> calculate_arima returns None)
@@ -160,7 +161,7 @@ TAD_HD bool bc_mle_lambda(const double *xs, const double *lx, size_t stride, uin
 }
 
 TAD_HD inline double inv_boxcox(double y, double lam) {
-  return lam == 0.0 ? exp(y) : exp(log1p(lam * y) / lam);  // scipy.special.inv_boxcox
+  return lam == 0.0 ? tad_det_exp(y) : tad_det_exp(tad_det_log1p(lam * y) / lam);  // scipy.special.inv_boxcox
 }
 
 // one lane = one key: compact the series, Box-Cox it, first three predictions
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const do
         if (n == 0) x0 = x;
         if (x != x0) allsame = false;
         if (!(x > 0.0)) nonpos = true;
-        const double l = log(x);
+        const double l = tad_det_log(x);
         xs[(size_t)n * st] = x;
         lx[(size_t)n * st] = l;
         tp[(size_t)n * st] = (uint32_t)t;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const do
       const double sg = sigma[k];
       for (uint32_t i = 0; i < n; ++i) {
         const double l = lx[(size_t)i * st];
-        const double y = lam == 0.0 ? l : expm1(lam * l) / lam;  // scipy.special.boxcox
+        const double y = lam == 0.0 ? l : tad_det_expm1(lam * l) / lam;  // scipy.special.boxcox
         ys[(size_t)i * st] = y;
         if (i < 3) {
           const uint64_t c = (uint64_t)tp[(size_t)i * st] * g.K + k;
@@ -221,22 +222,22 @@ __global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const do
 // ------------------------------------------------------------------------------------------------
 // ARIMA(1,1,1) likelihood: conventional Kalman filter written out for the 3-state model
 // ------------------------------------------------------------------------------------------------
-// a / b with b's reciprocal y = RN(1 / b) already at hand: Markstein's FMA correction (tad_internal.h:div_by_count)
-// returns the correctly rounded quotient, i.e. the bits of the IEEE division (checked on 6e8 random operand pairs,
-// including all-ones and power-of-two significands).  The filter divides four numbers by the same F in every
-// step; this turns four ~25-instruction divisions into one division and four 5-FMA sequences.  Outside a generous
-// exponent window (overflow / underflow of the intermediates) it falls back to the division itself.
-TAD_HD inline double div_shared(double a, double b, double y, bool b_ok) {
-  const double aa = fabs(a);
-  if (b_ok && aa < 1e140 && (aa > 1e-140 || a == 0.0)) {
-    double q = a * y;
-    double r = fma(-b, q, a);
-    q = fma(r, y, q);
-    r = fma(-b, q, a);
-    return fma(r, y, q);
-  }
-  return a / b;
-}
+// Arithmetic contract of the likelihood (fixed operation order, no FMA contraction, tad_detmath.h for the one
+// transcendental) — oracle/arima_exact.c evaluates the same expressions in the same order on the host, which is what
+// makes the optimiser trajectories, and so every prediction, coincide bit for bit.  Restated after statsmodels'
+// conventional filter (_kalman_filter / _conventional: forecast error v, tmp2 = F^-1 v, a_t|t = a + P Z' tmp2,
+// P_t|t = P - P Z' (F^-1 Z) P, loglike_obs = -0.5 (log 2 pi + log F + v tmp2)), i.e. with the RECIPROCAL of F:
+//   v = y_t - (a0 + a1);  pz = P Z' = (p00 + p01, p01 + p11, q12);  F = pz0 + pz1;  r = 1 / F;  w = r v
+//   a_t|t = a + pz w;  a' = T a_t|t;  g = pz r;  C = P - g pz';  P' = T C T' + R Q R'
+// Structure used: P[0][2] = 0, P[1][2] = q12 = s2 theta and P[2][2] = q22 = s2 theta^2 hold from t = 0 on, so only p00,
+// p01, p11 evolve.  sum_t log F_t is one log of the running product of the F_t (mantissa renormalised every step, the
+// exponents summed as integers) plus, once the covariance has converged (||P_t - P_t+1||_F^2 < 1e-19: F, r, pz frozen),
+// (number of converged steps) x log F — one `log` per evaluation instead of one per step.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TAD_WAVE_ALL(c) __all(c)
+#else
+#define TAD_WAVE_ALL(c) (c)
+#endif
 
 struct KfOut {
   double nll;       // -loglike / nobs
@@ -244,49 +245,63 @@ struct KfOut {
 };
 
 TAD_HD KfOut arima_nll(const double u0, const double u1, const double u2, const double *__restrict__ y, size_t stride,
-                           uint32_t n) {
+                       uint32_t n) {
   const double phi = u0 / sqrt(1.0 + u0 * u0);
   const double theta = -(u1 / sqrt(1.0 + u1 * u1));
   const double s2 = u2 * u2;
-  // predicted covariance (symmetric): p00 p01 p02 / p11 p12 / p22
-  double p00 = kDiffuse, p01 = 0.0, p02 = 0.0;
-  double p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
-  double p12 = theta * s2, p22 = theta * theta * s2;
   const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  double llf = 0.0, F = 1.0, k0 = 0.0, k1 = 0.0, k2 = 0.0, cterm = 0.0, invF = 1.0;
-  bool conv = false, F_ok = true;
-  for (uint32_t t = 0; t < n; ++t) {
+  double p00 = kDiffuse, p01 = 0.0;
+  double p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
+  double a0 = 0.0, a1 = 0.0;
+  double F = 1.0, rF = 1.0, pz0 = 0.0, pz1 = 0.0;
+  double prod = 1.0, q = 0.0;
+  int esum = 0;
+  uint32_t nconv = 0, t = 0;
+  bool conv = false;
+  // phase 1: some lane of the wavefront still updates its covariance (on the host: this series does)
+  while (t < n && !TAD_WAVE_ALL(conv)) {
     const double v = y[(size_t)t * stride] - (a0 + a1);
-    double pz0 = 0.0, pz1 = 0.0, pz2 = 0.0;
     if (!conv) {
-      pz0 = p00 + p01; pz1 = p01 + p11; pz2 = p02 + p12;
+      pz0 = p00 + p01; pz1 = p01 + p11;
       F = pz0 + pz1;
-      F_ok = F > 1e-100 && F < 1e100;
-      invF = 1.0 / F;
-      k0 = div_shared(pz0, F, invF, F_ok); k1 = div_shared(pz1, F, invF, F_ok); k2 = div_shared(pz2, F, invF, F_ok);  // == pz / F
-      cterm = -0.5 * (kLog2Pi + log(F));
+      rF = 1.0 / F;
     }
-    if (t >= 1) llf += cterm - div_shared(0.5 * v * v, F, invF, F_ok);  // == 0.5 * v * v / F
-    const double f0 = a0 + k0 * v, f1 = a1 + k1 * v, f2 = a2 + k2 * v;
+    const double w = rF * v;
+    if (t >= 1) {
+      q += v * w;
+      if (!conv) { int e; prod = tad_det_frexp(prod * F, &e); esum += e; }
+      else nconv++;
+    }
+    const double f0 = a0 + pz0 * w, f1 = a1 + pz1 * w, f2 = q12 * w;
     a0 = f0 + f1;
     a1 = phi * f1 + f2;
-    a2 = 0.0;
     if (!conv) {
-      // filtered covariance P - K (PZ)'
-      const double c00 = p00 - k0 * pz0, c01 = p01 - k0 * pz1, c02 = p02 - k0 * pz2;
-      const double c11 = p11 - k1 * pz1, c12 = p12 - k1 * pz2, c22 = p22 - k2 * pz2;
-      // T C T' + R Q R'
+      const double g0 = pz0 * rF, g1 = pz1 * rF, g2 = q12 * rF;
+      const double c00 = p00 - g0 * pz0, c01 = p01 - g0 * pz1, c02 = -(g0 * q12);
+      const double c11 = p11 - g1 * pz1, c12 = q12 - g1 * q12, c22 = q22 - g2 * q12;
       const double n00 = c00 + 2.0 * c01 + c11;
       const double n01 = phi * (c01 + c11) + (c02 + c12);
       const double n11 = phi * (phi * c11 + c12) + (phi * c12 + c22) + q11;
-      const double n12 = q12, n22 = q22;
-      const double d00 = p00 - n00, d01 = p01 - n01, d02 = p02, d11 = p11 - n11, d12 = p12 - n12, d22 = p22 - n22;
-      const double dsq = d00 * d00 + 2.0 * (d01 * d01) + 2.0 * (d02 * d02) + d11 * d11 + 2.0 * (d12 * d12) + d22 * d22;
-      if (dsq < kConvTol) conv = true;
-      p00 = n00; p01 = n01; p02 = 0.0; p11 = n11; p12 = n12; p22 = n22;
+      const double d00 = p00 - n00, d01 = p01 - n01, d11 = p11 - n11;
+      const double dsq = d00 * d00 + 2.0 * (d01 * d01) + d11 * d11;
+      conv = dsq < kConvTol;
+      p00 = n00; p01 = n01; p11 = n11;
     }
+    ++t;
   }
+  // phase 2: steady state
+  nconv += n - t;
+  for (; t < n; ++t) {
+    const double v = y[(size_t)t * stride] - (a0 + a1);
+    const double w = rF * v;
+    q += v * w;
+    const double f0 = a0 + pz0 * w, f1 = a1 + pz1 * w, f2 = q12 * w;
+    a0 = f0 + f1;
+    a1 = phi * f1 + f2;
+  }
+  double sumlog = tad_det_log(prod) + (double)esum * TAD_DM_LN2;
+  if (nconv) sumlog += (double)nconv * tad_det_log(F);
+  const double llf = -0.5 * ((double)(n - 1) * kLog2Pi + sumlog) - 0.5 * q;
   KfOut o;
   o.nll = -llf / (double)n;
   o.forecast = a0 + a1;

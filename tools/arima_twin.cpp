@@ -1,0 +1,49 @@
+// tools/arima_twin.cpp — debugging aid (not product, not oracle): the HOST instantiation of the __host__ __device__
+// functions of theia_amd/csrc/tad_arima.hip, driven like k_arima_prep / k_arima_fit drive them on the GPU, exported
+// for ctypes.  Used on a machine without a GPU to check that the device source and oracle/arima_exact.c follow the
+// same arithmetic contract bit for bit before spending GPU time (tools/arima_twin_check.py).
+//   hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -fPIC -shared -Iinclude -Itheia_amd/csrc tools/arima_twin.cpp -o /tmp/libarima_twin.so
+#include <vector>
+#include "../theia_amd/csrc/tad_arima.hip"
+using namespace tad;
+
+static double twin_fit(const double *y, uint32_t p, int maxiter, unsigned long long *steps) {
+  Lbfgs o;
+  o.col = 0; o.head = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false; o.f = 0.0;
+  arima_start_params(y, 1, p, o.x);
+  int phase = 0;
+  double f0 = 0.0;
+  for (;;) {
+    double xe[3] = {o.x[0], o.x[1], o.x[2]}, dx = 1.0;
+    if (phase >= 1 && phase <= 3) { const double x0 = xe[phase - 1]; xe[phase - 1] = x0 + 1e-5; dx = xe[phase - 1] - x0; }
+    const KfOut r = arima_nll(xe[0], xe[1], xe[2], y, 1, p);
+    *steps += p;
+    if (phase == 4) return r.forecast;
+    if (phase == 0) { f0 = r.nll; phase = 1; continue; }
+    o.g[phase - 1] = (r.nll - f0) / dx;
+    phase++;
+    if (phase == 4) { o.f = f0; lbfgs_deliver(o, maxiter); phase = o.done ? 4 : 0; }
+  }
+}
+
+extern "C" int twin_series(const double *x, long n, int maxiter, double *pred, double *info) {
+  std::vector<double> lx(n), y(n);
+  bool nonpos = false, allsame = true;
+  double sumlog = 0.0;
+  for (long i = 0; i < n; ++i) {
+    if (x[i] != x[0]) allsame = false;
+    if (!(x[i] > 0.0)) nonpos = true;
+    lx[i] = tad_det_log(x[i]);
+    sumlog += lx[i];
+  }
+  bool ok = n > 3 && !nonpos && !allsame;
+  double lam = 0.0;
+  if (ok) ok = bc_mle_lambda(x, lx.data(), 1, (uint32_t)n, sumlog, &lam);
+  if (!ok) return 0;
+  unsigned long long steps = 0;
+  for (long i = 0; i < n; ++i) y[i] = lam == 0.0 ? lx[i] : tad_det_expm1(lam * lx[i]) / lam;
+  for (long i = 0; i < 3; ++i) pred[i] = inv_boxcox(y[i], lam);
+  for (long i = 3; i < n; ++i) pred[i] = inv_boxcox(twin_fit(y.data(), (uint32_t)i, maxiter, &steps), lam);
+  if (info) { info[0] = lam; info[1] = (double)steps; }
+  return 1;
+}
