@@ -192,7 +192,9 @@ void tad_points_free(tad_engine *e, tad_points *p);
  * included) — the running sigma, the only one an append-only detector can know.  After the last batch the state equals
  * what the batch job computes over the concatenated table bit for bit (same operations in the same order): n, avg, m2
  * give its stddev_samp, ewma its last EWMA value.  A row not newer than its key's last_t is rejected
- * (TAD_ERR_INVALID_ARGUMENT) and the state is left untouched.  job->algo must be TAD_ALGO_EWMA. */
+ * (TAD_ERR_INVALID_ARGUMENT) and the state is left untouched.  job->algo must be TAD_ALGO_EWMA, and cols->num_keys must
+ * EQUAL the num_keys the state was created with (a batch addresses the state's whole key space; keys without rows in
+ * the batch keep their state) — anything else is TAD_ERR_INVALID_ARGUMENT. */
 typedef struct tad_state tad_state;
 int tad_state_create(tad_engine *e, uint64_t num_keys, tad_state **out);
 void tad_state_destroy(tad_engine *e, tad_state *s);

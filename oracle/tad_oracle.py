@@ -297,3 +297,68 @@ def run_job(algo, key_id, flow_end_s, value, op=None, agg_flow="", key_id2=None,
         "calc_all": calc, "anomaly_all": anomaly,
         "arima_results": arima_results, "kalman_steps": int(arima_counters.get("kalman_steps", 0)),
     }
+
+
+# ----------------------------------------------------------------------------------------------
+# Full-size helpers (BASELINE C2 / C4 tables, 1e8 rows): the same semantics as stage0 / dbscan_noise_1d by a
+# DIFFERENT, faster route, for the per-point parity tests at the benchmarked sizes (tests/test_gpu_fullsize.py).
+# tests/test_oracle.py checks them against stage0 / dbscan_noise_1d on small inputs.
+# ----------------------------------------------------------------------------------------------
+def stage0_dense(key_id, flow_end_s, value, op, num_keys, t0, step, n_buckets):
+    """GROUP BY (key, flowEndSeconds) on a dense lattice without sorting.  sum: the 64-bit values are split into 32-bit
+    halves whose per-cell float64 bincount sums are exact (< 2^53 for < 2^21 rows per cell) and recombined mod 2^64;
+    max: numpy.maximum.at on uint64.  Returns the points in (key, t) order like stage0."""
+    key_id = np.asarray(key_id, dtype=U64)
+    t = np.asarray(flow_end_s, dtype=np.int64)
+    v = np.asarray(value, dtype=U64)
+    bucket = (t - np.int64(t0)) // np.int64(step)
+    assert ((t - np.int64(t0)) % np.int64(step) == 0).all() and (bucket >= 0).all() and (bucket < n_buckets).all()
+    cell = key_id.astype(np.int64) * np.int64(n_buckets) + bucket
+    ncell = int(num_keys) * int(n_buckets)
+    cnt = np.bincount(cell, minlength=ncell)
+    assert cnt.max() < (1 << 21)
+    if op == "sum":
+        lo = np.bincount(cell, weights=(v & U64(0xFFFFFFFF)).astype(np.float64), minlength=ncell)
+        hi = np.bincount(cell, weights=(v >> U64(32)).astype(np.float64), minlength=ncell)
+        with np.errstate(over="ignore"):
+            agg = (hi.astype(U64) << U64(32)) + lo.astype(U64)        # wraps mod 2^64 like ClickHouse's UInt64 sum
+    elif op == "max":
+        agg = np.zeros(ncell, dtype=U64)
+        np.maximum.at(agg, cell, v)
+    else:
+        raise ValueError(op)
+    present = np.flatnonzero(cnt)
+    pk = (present // n_buckets).astype(U64)
+    pt = np.int64(t0) + np.int64(step) * (present % n_buckets)
+    return pk, pt, agg[present]
+
+
+def dbscan_noise_all(pv_f64, ptr, eps=250000000.0, min_samples=4, chunk=4096):
+    """dbscan_noise_1d for every key at once: padded [keys, maxn] matrix, pairwise tests in chunks of keys."""
+    mat, valid, n = _padded(pv_f64, ptr)
+    out = np.zeros_like(valid)
+    for a in range(0, mat.shape[0], chunk):
+        m, ok = mat[a:a + chunk], valid[a:a + chunk]
+        near = (np.abs(m[:, :, None] - m[:, None, :]) <= eps) & ok[:, :, None] & ok[:, None, :]
+        core = near.sum(axis=2) >= min_samples
+        reach = (near & core[:, None, :]).any(axis=2)
+        out[a:a + chunk] = ~(core | reach)
+    return out[valid]
+
+
+def _synth_chunk(args):
+    return synth_rows(*args)
+
+
+def synth_rows_parallel(n_rows, num_keys, n_buckets, procs=None, chunk=5_000_000):
+    """synth_rows(0, n_rows, ...) generated by a process pool (the 1e8-row tables take ~50 s on one core)."""
+    import concurrent.futures as cf
+    import os
+    jobs = [(i, min(chunk, n_rows - i), num_keys, n_buckets) for i in range(0, n_rows, chunk)]
+    procs = procs or min(len(jobs), max(1, (os.cpu_count() or 1) - 2), 32)
+    if procs <= 1:
+        parts = [synth_rows(*j) for j in jobs]
+    else:
+        with cf.ProcessPoolExecutor(procs) as ex:
+            parts = list(ex.map(_synth_chunk, jobs))
+    return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))

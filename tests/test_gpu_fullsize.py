@@ -1,0 +1,122 @@
+"""GPU: per-point parity at the BENCHMARKED sizes (BASELINE.json configs[1..3]; VERDICT r1 "next" #2).
+
+The Stage-0 plan the bench line runs (C2: 782 partitions of 128 keys, 128-byte lines, two parallel bucket rounds) is
+only ever chosen at full size, so here the numpy oracle runs on the COMPLETE 1e8-row tables and every point, sigma,
+EWMA value, DBSCAN / EWMA / ARIMA verdict is compared bit for bit:
+  C2  EWMA,   1e8 rows / 1e5 keys / 250 buckets, sum   — all 2.45e7 points
+  C3  ARIMA,  the same table                            — every prediction and verdict of 200 sampled keys (~4.9e4 fits)
+  C4  DBSCAN, 1e8 rows / 1e6 keys / 100 buckets, max   — all points
+The oracle side uses oracle.tad_oracle.stage0_dense / dbscan_noise_all (a different route to the same semantics as
+stage0 / dbscan_noise_1d, checked against them in tests/test_oracle.py) so that the whole module runs in a few minutes."""
+import numpy as np
+import pytest
+
+from oracle import arima_oracle as ao
+from oracle import tad_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_points(N, K, T, op):
+    k, t, v = orc.synth_rows_parallel(N, K, T)
+    pk, pt, pv = orc.stage0_dense(k, t, v, op, K, orc.SYNTH_T_BASE, orc.SYNTH_T_STEP, T)
+    return (k, t, v), (pk, pt, pv)
+
+
+def device_table(engine, rows, N, K, T):
+    """the device-resident table the bench uses (tad_synth_generate) — and it must be the oracle's table"""
+    dk, dt, dv = engine.synth(0, N, K, T)
+    for d, h in zip((dk, dt, dv), rows):
+        assert (d.to_host() == h).all()
+    return dk, dt, dv
+
+
+@pytest.fixture(scope="module")
+def c2(engine):
+    N, K, T = 100_000_000, 100_000, 250
+    rows, pts = oracle_points(N, K, T, "sum")
+    dev = device_table(engine, rows, N, K, T)
+    del rows
+    return dict(N=N, K=K, T=T, dev=dev, pts=pts)
+
+
+def check_points(h, pk, pt, pv, sigma, ptr):
+    assert h["key_id"].size == pk.size
+    assert (h["key_id"] == pk).all() and (h["flow_end_s"] == pt).all()
+    assert (h["throughput"] == orc.u64_to_f64(pv)).all()                 # integer aggregates, bit-exact
+    assert (h["stddev"] == np.repeat(sigma, np.diff(ptr))).all()          # stddev_samp per key, bit-exact
+
+
+def test_c2_ewma_every_point(engine, c2):
+    pk, pt, pv = c2["pts"]
+    dk, dt, dv = c2["dev"]
+    res = engine.run("EWMA", dk, dt, dv, c2["K"], agg_flow="svc", emit_all=True, out="device")
+    st = res.stats
+    assert st["stage0_path"] == 3                                         # the write-combining partition pass of the bench line
+    assert st["rows_used"] == c2["N"] and st["n_keys"] == c2["K"] and st["n_points"] == pk.size == res.n_rows
+    h = res.to_host()
+    keys, ptr = orc.series_offsets(pk)
+    pvf = orc.u64_to_f64(pv)
+    sigma, has = orc.stddev_samp_all(pvf, ptr)
+    check_points(h, pk, pt, pv, sigma, ptr)
+    calc = orc.ewma_all(pvf, ptr)
+    assert (h["algo_calc"] == calc).all()                                 # EWMA, bit-exact
+    verdict = np.repeat(has, np.diff(ptr)) & (np.abs(pvf - calc) > np.repeat(sigma, np.diff(ptr)))
+    assert (h["anomaly"].astype(bool) == verdict).all()
+    # the filtered job (what the bench times) emits exactly the flagged rows
+    res2 = engine.run("EWMA", dk, dt, dv, c2["K"], agg_flow="svc", out="device")
+    assert res2.stats["stage0_path"] == 3 and res2.n_rows == int(verdict.sum())
+    h2 = res2.to_host()
+    for f, want in (("key_id", pk), ("flow_end_s", pt), ("throughput", pvf), ("algo_calc", calc)):
+        assert (h2[f] == want[verdict]).all(), f
+
+
+def test_c3_arima_sampled_keys_of_the_full_table(engine, c2):
+    pk, pt, pv = c2["pts"]
+    dk, dt, dv = c2["dev"]
+    res = engine.run("ARIMA", dk, dt, dv, c2["K"], agg_flow="svc", emit_all=True, out="device")
+    st = res.stats
+    assert st["n_points"] == pk.size and st["arima_fits"] == pk.size - 3 * c2["K"] and st["keys_no_result"] == 0
+    h = res.to_host()
+    assert (h["key_id"] == pk).all() and (h["flow_end_s"] == pt).all()
+    keys, ptr = orc.series_offsets(pk)
+    pvf = orc.u64_to_f64(pv)
+    rng = np.random.default_rng(3)
+    sample = np.sort(rng.choice(c2["K"], size=200, replace=False))
+    checked = 0
+    for kk in sample:
+        a, b = ptr[kk], ptr[kk + 1]
+        want = np.array(ao.calculate_arima_exact(pv[a:b]))
+        got = h["algo_calc"][a:b]
+        fin = np.isfinite(want)
+        assert (np.isfinite(got) == fin).all()
+        assert (got[fin].view(np.uint64) == want[fin].view(np.uint64)).all(), int(kk)      # every prediction, bit for bit
+        sd = orc.stddev_samp_series(pvf[a:b])
+        assert sd == h["stddev"][a]
+        with np.errstate(invalid="ignore"):
+            assert (h["anomaly"][a:b].astype(bool) == (np.abs(pvf[a:b] - want) > sd)).all()       # zero verdict flips
+        checked += b - a
+    assert checked > 45000
+
+
+def test_c4_dbscan_every_point(engine):
+    N, K, T = 100_000_000, 1_000_000, 100
+    rows, (pk, pt, pv) = oracle_points(N, K, T, "max")
+    dk, dt, dv = device_table(engine, rows, N, K, T)
+    del rows
+    res = engine.run("DBSCAN", dk, dt, dv, K, agg_flow="", emit_all=True, out="device")      # mode None: max(throughput)
+    st = res.stats
+    assert st["stage0_path"] in (2, 3)
+    assert st["rows_used"] == N and st["n_keys"] == K and st["n_points"] == pk.size == res.n_rows
+    h = res.to_host()
+    keys, ptr = orc.series_offsets(pk)
+    pvf = orc.u64_to_f64(pv)
+    sigma, has = orc.stddev_samp_all(pvf, ptr)
+    check_points(h, pk, pt, pv, sigma, ptr)
+    assert (h["algo_calc"] == 0.0).all()
+    noise = orc.dbscan_noise_all(pvf, ptr)
+    assert (h["anomaly"].astype(bool) == noise).all()
+    res2 = engine.run("DBSCAN", dk, dt, dv, K, agg_flow="", out="device")
+    assert res2.n_rows == int(noise.sum())
+    h2 = res2.to_host()
+    assert (h2["key_id"] == pk[noise]).all() and (h2["flow_end_s"] == pt[noise]).all() and (h2["throughput"] == pvf[noise]).all()

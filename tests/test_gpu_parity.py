@@ -179,6 +179,26 @@ def test_job_sampled_time_range_too_narrow_is_detected_and_rederived(engine, sta
         assert (res[f] == want[f]).all(), f
 
 
+def test_job_sparse_live_rows_in_an_unsampled_stretch(engine, stage0):
+    # prepare_columns hands over ALL rows and marks the rejected ones TAD_KEY_SKIP.  Stage-0 v2 samples the time column
+    # (one iteration in eight + both ends of every chunk): here every live row sits in an unsampled stretch of a 7e6-row
+    # table.  The sampled pass sees no live row; the engine must not believe it (it used to return the empty result).
+    n = 7_000_000
+    k, t, v = orc.synth_rows(0, n, 400, 30)
+    live = np.zeros(n, dtype=bool)
+    live[10000:10010] = True
+    live[3_000_011:3_000_019] = True
+    k = np.where(live, k, orc.KEY_SKIP)
+    want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+    assert want["n_points"] >= 15
+    allp = engine.run("EWMA", k, t, v, 400, agg_flow="svc", emit_all=True)
+    assert allp.stats["rows_used"] == 18 and allp.n_rows == want["n_points"]
+    assert (allp["key_id"] == want["points"][0]).all() and (allp["flow_end_s"] == want["points"][1]).all()
+    assert (allp["algo_calc"] == want["calc_all"]).all()
+    res = engine.run("EWMA", k, t, v, 400, agg_flow="svc")
+    assert res.n_rows == want["n_anomalies"] and (res["key_id"] == want["key_id"]).all()
+
+
 @pytest.mark.parametrize("n_rows,K,T", [(1_500_000, 40_000, 2000), (300_000, 50, 20_000), (2_000_000, 300_000, 100)])
 def test_job_wide_grids_take_several_rounds_per_partition(engine, stage0, n_rows, K, T):
     # grids whose KP x T block does not fit one LDS tile (many buckets) or that would need more than 2048 partitions
@@ -314,6 +334,10 @@ def test_concurrent_runs_from_four_threads(engine):
     # controller.go:199-201 runs 4 workers; cgo pins an OS thread per call.  Runs on one engine serialise inside the
     # library: four threads with different jobs must each get exactly their own result.
     import threading
+    from oracle import arima_oracle as ao
+    series = [(orc.synth_rows(77 * i, 40, 1, 40)[2]) for i in range(4)]
+    series_want = [ao.calculate_arima_exact(x) for x in series]
+    series_got = [None] * 4
     jobs = []
     for i, algo in enumerate(["EWMA", "DBSCAN", "EWMA", "DBSCAN"]):
         k, t, v = orc.synth_rows(1000 * i, 60000 + 7000 * i, 50 + 10 * i, 40)
@@ -327,6 +351,8 @@ def test_concurrent_runs_from_four_threads(engine):
             for _ in range(3):
                 out[i] = engine.run(algo, k, t, v, K, agg_flow="svc", job_id="job-%d" % i)
                 assert engine.progress()[1] == 4
+                # the per-series entry points share the engine's buffers: tad_series_arima must return ITS predictions
+                series_got[i] = engine.series_arima(series[i])
         except Exception as exc:  # noqa: BLE001
             errs.append(exc)
 
@@ -337,6 +363,7 @@ def test_concurrent_runs_from_four_threads(engine):
         th.join()
     assert not errs, errs
     for i in range(4):
+        assert np.array_equal(np.asarray(series_got[i]), np.asarray(series_want[i]), equal_nan=True), i
         want = jobs[i][5]
         assert out[i].id == "job-%d" % i and out[i].n_rows == want["n_anomalies"]
         for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):

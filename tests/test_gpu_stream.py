@@ -62,3 +62,18 @@ def test_late_row_is_rejected_and_state_kept(engine):
     res = engine.run_stream(st, k[:10], t[:10] + 60 * 100, v[:10], agg_flow="svc", emit_all=True)
     assert res.n_rows == np.unique(np.stack([k[:10].astype(np.int64), t[:10]]), axis=1).shape[1]
     st.close()
+
+
+def test_batch_must_declare_the_states_key_space(engine):
+    # a batch that declared fewer keys than the state holds would flip the double buffer with the other keys' candidate
+    # state unwritten (tad.h: cols->num_keys must equal the state's num_keys)
+    k, t, v = orc.synth_rows(0, 5000, 20, 50)
+    st = engine.state_create(20)
+    engine.run_stream(st, k, t, v, agg_flow="svc")
+    before = st.export()
+    for bad in (10, 21):
+        with pytest.raises(TadError) as ei:
+            engine.run_stream(st, k[:0], t[:0], v[:0], agg_flow="svc", num_keys=bad)
+        assert ei.value.code == -1 and "must be equal" in ei.value.message
+    assert all((st.export()[f] == before[f]).all() for f in before)
+    st.close()

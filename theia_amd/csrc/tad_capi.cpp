@@ -466,8 +466,10 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   const bool points_mode = points_out != nullptr;
   if (stream && e && job && cols) {
     if (job->algo != TAD_ALGO_EWMA) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: only the EWMA detector has a streaming form");
-    if (cols->num_keys > stream->K) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: batch has %llu keys, the state only %llu",
-                                                (unsigned long long)cols->num_keys, (unsigned long long)stream->K);
+    // k_stream writes the candidate state for keys < cols->num_keys and the double buffer flips as a whole: a batch
+    // that declares fewer keys than the state holds would drop the others' state
+    if (cols->num_keys != stream->K) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: batch declares %llu keys, the state holds %llu (they must be equal)",
+                                                 (unsigned long long)cols->num_keys, (unsigned long long)stream->K);
   }
   if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_run: engine is NULL");
   if (!job || !cols || (!out && !points_out)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: job, cols and out must not be NULL");
@@ -533,7 +535,9 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   const bool force_v2 = s0env && !strcmp(s0env, "v2");
   const bool has2 = cols->key_id2 != nullptr;
   bool force_v1_retry = false;
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  // retries: wrong hint -> derive (0 -> 1); sampled lattice too coarse / saw no live row -> exact (1 -> 2); overflow list
+  // full -> Stage 0 v1.  Each transition happens at most once, so 5 attempts cover every path.
+  for (int attempt = 0; attempt < 6; ++attempt) {
     const bool hinted = lat_mode == 0;
     HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
     PartPlan pl{};
@@ -569,6 +573,12 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
           g = host_gcd(host_gcd(g, p.g), d);
         }
         used += p.used;
+      }
+      if (used == 0 && v2 && lat_mode == 1) {
+        // pass A only SAMPLES the time column: every live row (not TAD_KEY_SKIP, inside the time window) may sit in an
+        // unsampled stretch of a big, mostly filtered table.  "No live row" is only believed from the exact pass.
+        lat_mode = 2;
+        continue;
       }
       if (used == 0) { empty = true; }
       else {
@@ -754,10 +764,17 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
                     nullptr, static_cast<const unsigned long long *>(e->off.p), dev_rows, ctr);
     else if (rows)
       emit_rows(e, g, L, jp, dev_rows);
-    HIP_TRY(e, hipEventRecord(e->ev[4], s));
+    {
+      const hipError_t er = hipEventRecord(e->ev[4], s);
+      if (er != hipSuccess) {
+        e->free_blocks.push_back({dev_block.base, dev_block.cap});
+        delete rp;
+        return fail(e, TAD_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er));
+      }
+    }
     if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
-    HIP_TRY(e, hipStreamSynchronize(s));
-    hipError_t le = hipGetLastError();
+    hipError_t le = hipStreamSynchronize(s);
+    if (le == hipSuccess) le = hipGetLastError();
     if (le != hipSuccess) { tad_result_free(nullptr, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
 
     tad_stats &st = rp->pub.stats;
@@ -811,7 +828,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     *out = &rp->pub;
     return TAD_OK;
   }
-  return fail(e, TAD_ERR_HIP, "unreachable");
+  return fail(e, TAD_ERR_HIP, "internal error: Stage 0 did not settle on a lattice / strategy after 6 attempts");
 }
 
 }  // namespace
@@ -1057,26 +1074,13 @@ int tad_series_drop(tad_engine *e, const uint64_t *x, uint64_t n, double nsigma,
   return TAD_OK;
 }
 
-int tad_series_arima(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int *has_result, double *out) {
-  if (!e || !has_result || (n && (!x || !out)) || maxiter < 0) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima: bad arguments");
-  uint64_t nv = 0;
-  std::vector<uint8_t> verdict(n ? n : 1);
-  int rc = tad_series_arima_anomaly(e, x, n, maxiter, 0, 0.0, verdict.data(), &nv);
-  if (rc != TAD_OK) return rc;
-  // tad_series_arima_anomaly leaves the predictions in the engine's calc buffer
-  std::lock_guard<std::mutex> lk(e->mu);
-  *has_result = (nv == n && n > 3) ? 1 : 0;
-  if (*has_result) {
-    HIP_TRY(e, hipMemcpy(out, e->calc.p, n * 8, hipMemcpyDeviceToHost));
-  }
-  return TAD_OK;
-}
+}  // extern "C"
 
-int tad_series_arima_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
-                             uint8_t *verdict, uint64_t *n_verdict) {
-  if (!e || !n_verdict || !verdict || (n && !x) || maxiter < 0)
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima_anomaly: bad arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+namespace {
+
+// calculate_arima / calculate_arima_anomaly on one series; the caller holds e->mu.  pred_out (n doubles) may be NULL.
+int series_arima_locked(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
+                        uint8_t *verdict, uint64_t *n_verdict, double *pred_out) {
   HIP_TRY(e, hipSetDevice(e->device));
   *n_verdict = 1;
   verdict[0] = 0;
@@ -1088,7 +1092,7 @@ int tad_series_arima_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, int m
   if ((rc = ensure(e, e->sigma, sizeof(double))) != TAD_OK) return rc;
   if ((rc = ensure(e, e->n_pts, sizeof(uint32_t))) != TAD_OK) return rc;
   if ((rc = ensure(e, e->calc, n * sizeof(double))) != TAD_OK) return rc;
-  // sigma as given by the caller; n_pts >= 2 <=> sigma defined; n_pts carries the real length for ARIMA
+  // sigma as given by the caller; n_pts carries the real length for ARIMA
   const double sg = has_stddev ? stddev : __builtin_inf();  // no sigma -> no point can exceed it
   const uint32_t npts = (uint32_t)n;
   HIP_TRY(e, hipMemcpyAsync(e->sigma.p, &sg, sizeof sg, hipMemcpyHostToDevice, e->stream));
@@ -1102,12 +1106,39 @@ int tad_series_arima_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, int m
   HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
   std::vector<uint8_t> flags(n);
   HIP_TRY(e, hipMemcpyAsync(flags.data(), g.flag, n, hipMemcpyDeviceToHost, e->stream));
+  if (pred_out) HIP_TRY(e, hipMemcpyAsync(pred_out, e->calc.p, n * 8, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   HIP_TRY(e, hipGetLastError());
   if (e->ctr_host->keys_no_result) return TAD_OK;  // calculate_arima returned None
   *n_verdict = n;
   for (uint64_t i = 0; i < n; ++i) verdict[i] = (flags[i] & FLAG_ANOMALY) ? 1 : 0;
   return TAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tad_series_arima(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int *has_result, double *out) {
+  if (!e || !has_result || (n && (!x || !out)) || maxiter < 0) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima: bad arguments");
+  uint64_t nv = 0;
+  std::vector<uint8_t> verdict(n ? n : 1);
+  std::vector<double> pred(n ? n : 1);
+  // ONE critical section: the predictions are read from the engine's calc buffer before any other thread can run
+  std::lock_guard<std::mutex> lk(e->mu);
+  const int rc = series_arima_locked(e, x, n, maxiter, 0, 0.0, verdict.data(), &nv, pred.data());
+  if (rc != TAD_OK) return rc;
+  *has_result = (nv == n && n > 3) ? 1 : 0;
+  if (*has_result) memcpy(out, pred.data(), n * 8);
+  return TAD_OK;
+}
+
+int tad_series_arima_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
+                             uint8_t *verdict, uint64_t *n_verdict) {
+  if (!e || !n_verdict || !verdict || (n && !x) || maxiter < 0)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima_anomaly: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  return series_arima_locked(e, x, n, maxiter, has_stddev, stddev, verdict, n_verdict, nullptr);
 }
 
 int tad_synth_generate(tad_engine *e, uint64_t seed, uint64_t first_row, uint64_t n_rows, uint64_t num_keys,

@@ -298,7 +298,7 @@ class TadEngine:
         return TadState(self, num_keys)
 
     def run_stream(self, state, key_id, flow_end_s, value, agg_flow="", value_op="auto", lattice=None, emit_all=False, out="host",
-                   alpha=0.0, job_id=""):
+                   alpha=0.0, job_id="", num_keys=None):
         pk, n, dev, keep1 = _as_column(key_id, np.uint64)
         pt, nt, dev_t, keep2 = _as_column(flow_end_s, np.int64)
         pv, nv, dev_v, keep3 = _as_column(value, np.uint64)
@@ -306,7 +306,7 @@ class TadEngine:
             raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "columns must have equal length and live in the same memory")
         job = capi.Job(algo=capi.TAD_ALGO["EWMA"], agg_flow=capi.TAD_AGG[agg_flow], value_op=capi.TAD_OP[value_op], ewma_alpha=float(alpha),
                        flags=capi.TAD_FLAG_EMIT_ALL_POINTS if emit_all else 0, id=job_id.encode()[:63])
-        cols = capi.Columns(n_rows=n, key_id=pk, flow_end_s=pt, value=pv, num_keys=state.num_keys,
+        cols = capi.Columns(n_rows=n, key_id=pk, flow_end_s=pt, value=pv, num_keys=state.num_keys if num_keys is None else int(num_keys),
                             memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
         if lattice is not None:
             cols.t0, cols.step, cols.n_buckets = int(lattice[0]), int(lattice[1]), int(lattice[2])
