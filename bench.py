@@ -5,19 +5,25 @@ One "step" = one full job (tad_run through the C ABI) over one synthetic batch t
 resident in HBM: Stage-0 GROUP BY (key, flowEndSeconds) -> per-key stddev_samp -> detector ->
 compaction of the anomalous points into device-resident result columns.
 
-Workload at N=1 = BASELINE.json configs[1]: EWMA on 1e8 rows / 1e5 flow keys / 250 time buckets,
-sum(throughput) (mode svc), the deterministic synthetic table of SURVEY.md §8d.
+Workload at N=1 (`--config c2`, the default) = BASELINE.json configs[1]: EWMA on 1e8 rows / 1e5 flow keys / 250 time
+buckets, sum(throughput) (mode svc), the deterministic synthetic table of SURVEY.md §8d.  The same JSON line carries
+`other_configs`: C4 (configs[3]: DBSCAN, 1e6 keys x 100 buckets, max(throughput) = mode None) and C3 (configs[2]: ARIMA
+on the C2 table), each timed the same way (W warm-up steps, K timed steps bracketed by synchronisation) with its own
+roofline — so that those rates are measured by whoever runs this file, not quoted.
 N>1 (torchrun, one rank per GPU): weak scaling — every rank owns the key shard `key mod N == rank`
 (1e8 rows / 1e5 keys per rank, pre-sharded by key as SURVEY.md §8e allows), no data-path collective;
 per step ONE RCCL all-gather of 9 doubles per rank: the counters [anomalies, keys, points, rows, ...] (the global
 `count() == 0` sentinel decision, anomaly_detection.py:395) and the (n, mean, M2) moments (global sigma).
+`--config c5` = BASELINE.json configs[4]: the 1e9-row / 1e6-key table split over the N ranks (1e9/N rows, 1e6/N keys
+per rank — strong scaling), one step = the EWMA job THEN the ARIMA job on the rank's shard; `--ingest rows` makes every
+rank start from an arbitrary row slice and ship partial points to the key owners with one all-to-all(v) first.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (Stage-0 pass B, k_partition):
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (Stage-0 pass B, the row partition pass):
 achieved = 24 B/row x rows per launch / the kernel's average duration measured with HIP events on the
 engine's stream (tad_stats.ms_scatter); `traffic` = that kernel's HBM bytes per launch from the committed
 rocprofv3 PMC passes (profiles/pmc_latest.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE;
 separate --pmc runs of this same command).  `cpu_baseline` = the oracle (numpy port of the reference
-job) timed on this box's host cores on a bounded sample.  The ARIMA line adds `arima`: fits/s and the
+job) timed on this box's host cores on a bounded sample.  ARIMA lines add `arima`: fits/s and the
 FP64 flop rate from the engine's Kalman-step counter (60 flop per 3-state predict+update).
 """
 import argparse
@@ -35,25 +41,37 @@ FLOP_PER_KALMAN_STEP = 60
 BYTES_PER_ROW = 24      # key_id u64 + flow_end_s i64 + value u64, read once
 BYTES_PER_ANOMALY = 40  # key_id, flow_end_s, throughput, algo_calc, stddev
 
+CONFIGS = {   # BASELINE.json configs[1..4]
+    "c2": dict(algos=("EWMA",), rows=100_000_000, keys=100_000, buckets=250, agg="svc"),
+    "c3": dict(algos=("ARIMA",), rows=100_000_000, keys=100_000, buckets=250, agg="svc"),
+    "c4": dict(algos=("DBSCAN",), rows=100_000_000, keys=1_000_000, buckets=100, agg=""),
+    "c5": dict(algos=("EWMA", "ARIMA"), rows=1_000_000_000, keys=1_000_000, buckets=250, agg="svc"),   # totals, split over the ranks
+}
+STAGE0_KERNEL = {2: "k_partition (Stage-0 v2, row partition pass, sort-by-tile)",
+                 3: "k_partition_wc (Stage-0 v2, row partition pass, write-combining)"}
 
-def cpu_baseline(algo, rows, keys, buckets, agg):
-    """The oracle (numpy restatement of the reference job) on a bounded sample of the same workload, in its own process
-    (oracle/cpu_bench.py): one process, and key-sharded over all host cores the way Spark local[*] runs the per-key
-    UDFs.  `value` is the faster of the two, `cores` the processes it used."""
+
+def cpu_baseline(algo, rows, keys, buckets, agg, single_rows=0):
+    """The oracle (numpy restatement of the reference job; ARIMA: oracle/arima_exact.c) on a bounded sample of the same
+    workload, in its own process (oracle/cpu_bench.py): one process, and key-sharded over ALL host cores the way Spark
+    local[*] runs the per-key UDFs (two-phase shuffle through shared memory, timed).  `value` is the faster of the two,
+    `cores` the processes it used.  kind "port": the reference's PySpark job cannot run here (no JVM / pyspark /
+    statsmodels in the image) — a GPU-over-numpy ratio says nothing about kernel quality; the roofline fractions do."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--algo", algo, "--rows", str(rows), "--keys", str(keys),
            "--buckets", str(buckets), "--agg", agg]
-    if algo == "ARIMA":
-        cmd += ["--skip-single"] if (os.cpu_count() or 1) > 1 else []
-    r = json.loads(subprocess.run(cmd, check=True, capture_output=True, timeout=900, text=True).stdout.strip().splitlines()[-1])
-    single = rows / r["single_s"] if "single_s" in r else None
+    if single_rows and single_rows < rows:
+        cmd += ["--single-rows", str(single_rows)]
+    r = json.loads(subprocess.run(cmd, check=True, capture_output=True, timeout=1200, text=True).stdout.strip().splitlines()[-1])
+    single = r["single_rows"] / r["single_s"] if "single_s" in r else None
     multi = rows / r["multi_s"] if "multi_s" in r else None
     use_multi = multi is not None and (single is None or multi > single)
     out = {"value": multi if use_multi else single, "unit": "flow-records/s", "cores": r["procs"] if use_multi else 1, "kind": "port",
            "sample": "%s, %d rows / %d keys / %d buckets of the same synthetic table (same rows-per-key as the GPU workload), numpy "
-                     "oracle; %s" % (algo, rows, keys, buckets,
-                                     "key-sharded over %d processes (rows with key mod P == w per worker, selection timed), %.1f s"
-                                     % (r["procs"], r["multi_s"]) if use_multi else "single process, %.1f s" % r["single_s"]),
+                     "oracle; %s" % (algo, rows if use_multi else r["single_rows"], keys, buckets,
+                                     "key-sharded over %d processes = all host cores (two-phase shuffle by key mod P through shared "
+                                     "memory %.2f s + per-shard jobs, both timed), %.1f s" % (r["procs"], r["shuffle_s"], r["multi_s"])
+                                     if use_multi else "single process, %.1f s" % r["single_s"]),
            "host_cores": r["host_cores"], "anomalies": r.get("multi_anomalies", r.get("single_anomalies"))}
     # the reference job evaluates its lineage twice (the `.count()` action of anomaly_detection.py:395, then the JDBC
     # write, :713-726; SURVEY.md 3.2): `value` is the de-duplicated (1x) rate, this is the as-written one
@@ -63,6 +81,16 @@ def cpu_baseline(algo, rows, keys, buckets, agg):
     if multi is not None:
         out["all_cores_value"] = multi
     return out
+
+
+def cpu_sample(algo, rows, keys, cores):
+    """(rows, keys, single_rows) of the bounded CPU sample: ~10-30 s of host work, same rows-per-key as the workload."""
+    rpk = max(1, rows // keys)
+    if algo == "ARIMA":        # ~22 keys/s per core (245 fits of ~125 points each per key)
+        ck = min(keys, max(8, 12 * cores))
+        return ck * rpk, ck, min(ck, 24) * rpk
+    cr = rows if cores >= 64 else min(rows, 30_000_000)     # the full table on a many-core host (a few seconds there)
+    return cr, max(1, cr // rpk), min(cr, 20_000_000)
 
 
 def pmc_traffic(kernel):
@@ -82,11 +110,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--algo", default="EWMA", choices=["EWMA", "DBSCAN", "ARIMA"])
-    ap.add_argument("--rows", type=int, default=100_000_000)
-    ap.add_argument("--keys", type=int, default=100_000)
-    ap.add_argument("--buckets", type=int, default=250)
-    ap.add_argument("--agg", default="svc")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json config; --algo/--rows/--keys/--buckets/--agg override it")
+    ap.add_argument("--algo", default=None, choices=["EWMA", "DBSCAN", "ARIMA"])
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU")
+    ap.add_argument("--keys", type=int, default=None, help="keys per GPU")
+    ap.add_argument("--buckets", type=int, default=None)
+    ap.add_argument("--agg", default=None)
     ap.add_argument("--hint-lattice", action="store_true", help="pass the time lattice instead of deriving it")
     ap.add_argument("--ingest", default="keys", choices=["keys", "rows"],
                     help="keys: every rank holds the rows of its own keys (no data-path collective, the default); "
@@ -96,7 +125,8 @@ def main():
                     help="hand the columns over as pinned HOST buffers (tad_columns.memory = TAD_MEM_HOST): the PCIe-inclusive "
                          "rate DESIGN.md quotes; never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=30_000_000)
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU sample (0 = chosen from the host's core count)")
     args = ap.parse_args()
 
     import torch
@@ -121,126 +151,196 @@ def main():
             dist.init_process_group(backend)
     coll_dev = dev if (world > 1 and backend == "nccl") else None
 
+    cfg = dict(CONFIGS[args.config])
+    strong = args.config == "c5"
+    if strong:      # the fixed 1e9-row / 1e6-key table split over the ranks
+        cfg["rows"], cfg["keys"] = cfg["rows"] // world, cfg["keys"] // world
+    if args.algo:
+        cfg["algos"] = (args.algo,)
+    for f in ("rows", "keys", "buckets", "agg"):
+        if getattr(args, f) is not None:
+            cfg[f] = getattr(args, f)
+    headline_is_c2 = (args.config == "c2" and not args.algo and all(getattr(args, f) is None for f in ("rows", "keys", "buckets", "agg")))
+
     eng = TadEngine(device=dev.index)
-    n, K, T = args.rows, args.keys, args.buckets
-    # rank r's shard: its own 1e8 rows of the table, local key ids 0..K-1 (global key = local * world + rank)
-    key = torch.empty(n, dtype=torch.int64, device=dev)
-    tend = torch.empty(n, dtype=torch.int64, device=dev)
-    val = torch.empty(n, dtype=torch.int64, device=dev)
-    # ingest=keys: local key ids 0..K-1 of this rank's shard; ingest=rows: global key ids over all K * world keys
-    eng.synth(rank * n, n, K * (world if args.ingest == "rows" else 1), T, into=(key, tend, val))
-    lattice = (1660202814, 60, T) if args.hint_lattice else None
-
     reducer = td.JobReducer(device=coll_dev)
-    if args.host_input:
-        hkey, htend, hval = (x.cpu().pin_memory() for x in (key, tend, val))
 
-    def step():
-        if args.ingest == "rows":
-            # Stage 0 on the local slice -> partial points; all-to-all(v) to the owners (RCCL over xGMI); the owners run the
-            # job on the partials (re-aggregating sums of sums is bit-exact)
-            pts = eng.aggregate(key, tend, val, K * world, agg_flow=args.agg, lattice=lattice, out="device")
-            ptr = pts.device_pointers()
-            cols = [torch.as_tensor(td.DeviceColumn(ptr[f], pts.n_points), device=dev) for f in ("key_id", "flow_end_s", "value")]
-            if coll_dev is None and world > 1:
-                cols = [c.cpu() for c in cols]                  # gloo test mode: host tensors
-            lk, lt, lv = td.exchange_points_torch(cols[0], cols[1], cols[2], world, rank)
-            pts.close()
-            lk, lt, lv = (c.to(dev) for c in (lk, lt, lv))
-            res = eng.run(args.algo, lk, lt, lv, K, agg_flow=args.agg, lattice=lattice, out="device")
-        elif args.host_input:
-            res = eng.run(args.algo, hkey, htend, hval, K, agg_flow=args.agg, lattice=lattice, out="host")
-        else:
-            res = eng.run(args.algo, key, tend, val, K, agg_flow=args.agg, lattice=lattice, out="device")
-        st = res.stats
-        # RCCL over xGMI: one 9-double all-gather (counters + moments) per job, started now and collected after the NEXT
-        # job has been issued, so its latency hides behind that job; the last one is collected inside the timed region
+    def make_table(n, K, T, ingest):
+        key = torch.empty(n, dtype=torch.int64, device=dev)
+        tend = torch.empty(n, dtype=torch.int64, device=dev)
+        val = torch.empty(n, dtype=torch.int64, device=dev)
+        # ingest=keys: local key ids 0..K-1 of this rank's shard (global key = local * world + rank);
+        # ingest=rows: an arbitrary slice of the rows, global key ids over all K * world keys
+        eng.synth(rank * n, n, K * (world if ingest == "rows" else 1), T, into=(key, tend, val))
+        return key, tend, val
+
+    def run_config(algos, n, K, T, agg, steps, warmup, ingest="keys", host_input=False, hint=False):
+        """W warm-up steps, then exactly `steps` timed steps between synchronisation points; one step = one job per algo."""
+        key, tend, val = make_table(n, K, T, ingest)
+        lattice = (1660202814, 60, T) if hint else None
+        if host_input:
+            hkey, htend, hval = (x.cpu().pin_memory() for x in (key, tend, val))
+        pending = [None]
+
+        def one_job(algo, k_, t_, v_):
+            if host_input:
+                return eng.run(algo, hkey, htend, hval, K, agg_flow=agg, lattice=lattice, out="host")
+            return eng.run(algo, k_, t_, v_, K, agg_flow=agg, lattice=lattice, out="device")
+
+        def step():
+            stats, glob = [], None
+            if ingest == "rows":
+                # Stage 0 on the local slice -> partial points; all-to-all(v) to the owners (RCCL over xGMI); the owners run the
+                # job(s) on the partials (re-aggregating sums of sums is bit-exact)
+                pts = eng.aggregate(key, tend, val, K * world, agg_flow=agg, lattice=lattice, out="device")
+                ptr = pts.device_pointers()
+                cols = [torch.as_tensor(td.DeviceColumn(ptr[f], pts.n_points), device=dev) for f in ("key_id", "flow_end_s", "value")]
+                if coll_dev is None and world > 1:
+                    cols = [c.cpu() for c in cols]                  # gloo test mode: host tensors
+                lk, lt, lv = td.exchange_points_torch(cols[0], cols[1], cols[2], world, rank)
+                pts.close()
+                lk, lt, lv = (c.to(dev) for c in (lk, lt, lv))
+            else:
+                lk, lt, lv = key, tend, val
+            for algo in algos:
+                res = one_job(algo, lk, lt, lv)
+                st = res.stats
+                # RCCL over xGMI: one 9-double all-gather (counters + moments) per job, started now and collected after the
+                # NEXT job has been issued, so its latency hides behind that job; the last one is collected inside the timed region
+                if world > 1:
+                    nxt = reducer.start(st)
+                    if pending[0] is not None:
+                        glob = pending[0].result()
+                    pending[0] = nxt
+                res.close()
+                stats.append(st)
+            return stats, glob
+
+        def drain():
+            g = pending[0].result() if pending[0] is not None else None
+            pending[0] = None
+            return g
+
         glob = None
+        for _ in range(warmup):
+            stats, glob = step()
         if world > 1:
-            nxt = reducer.start(st)
-            if pending[0] is not None:
-                glob = pending[0].result()
-            pending[0] = nxt
-        res.close()
-        return st, glob
+            glob = drain() or glob
+            dist.barrier()
+        torch.cuda.synchronize()
+        acc = [{"ms_meta": 0.0, "ms_stage0": 0.0, "ms_scatter": 0.0, "ms_detect": 0.0, "ms_total": 0.0} for _ in algos]
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stats, g2 = step()
+            glob = g2 or glob
+            for a, st in zip(acc, stats):
+                for f in a:
+                    a[f] += st[f]
+        if world > 1:
+            glob = drain() or glob          # the last job's reduction completes inside the timed region
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        else:
+            glob = td.JobReducer().reduce(stats[-1])
+        del key, tend, val
+        return dict(dt=dt, stats=stats, acc=acc, glob=glob, steps=steps, warmup=warmup, n=n, K=K, T=T, agg=agg, algos=algos)
 
-    pending = [None]
-
-    def drain():
-        g = pending[0].result() if pending[0] is not None else None
-        pending[0] = None
-        return g
-
-    for _ in range(args.warmup):
-        st, glob = step()
-    if world > 1:
-        glob = drain()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    acc = {"ms_meta": 0.0, "ms_stage0": 0.0, "ms_scatter": 0.0, "ms_detect": 0.0, "ms_total": 0.0}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st, glob = step()
-        for f in acc:
-            acc[f] += st[f]
-    if world > 1:
-        glob = drain()          # the last job's reduction completes inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    else:
-        glob = td.JobReducer().reduce(st)
-    g_counts = [glob["n_anomalies"], glob["n_keys"], glob["n_points"], glob["rows_used"]]
-
-    if rank == 0:
-        steps = args.steps
-        ms_step = dt * 1e3 / steps
-        A = st["n_anomalies"]
-        scatter_ms = acc["ms_scatter"] / steps
+    def describe(r, host_input=False, ingest="keys", hint=False):
+        """the JSON fields of one measured config (rank 0)"""
+        n, K, T, steps, algos = r["n"], r["K"], r["T"], r["steps"], r["algos"]
+        ms_step = r["dt"] * 1e3 / steps
+        st0, a0 = r["stats"][0], r["acc"][0]            # Stage 0 of the first job of the step (every job of a step re-runs it)
+        scatter_ms = a0["ms_scatter"] / steps
         achieved = BYTES_PER_ROW * n / (scatter_ms * 1e-3) / 1e9
+        dev_ms = sum(a["ms_total"] for a in r["acc"]) / steps
+        A = sum(st["n_anomalies"] for st in r["stats"])
         out = {
-            "metric": "flow-records/sec", "value": world * n * steps / dt, "unit": "flow-records/s",
-            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 (aggregates) + f64 (detectors)", "data": "synthetic",
-            "config": {"workload": "%s detector, %d rows / %d flow keys / %d time buckets per GPU, sum(throughput) (agg_flow=%s), "
+            "value": world * n * steps / r["dt"], "unit": "flow-records/s", "steps": steps, "warmup": r["warmup"], "ms_per_step": ms_step,
+            "config": {"workload": "%s detector%s, %d rows / %d flow keys / %d time buckets per GPU, %s(throughput) (agg_flow=%s), "
                                    "deterministic synthetic flow table (SURVEY.md 8d), %s"
-                                   % (args.algo, n, K, T, args.agg, "inputs in pinned HOST memory, results copied back (PCIe-inclusive)"
-                                      if args.host_input else "inputs and outputs resident in HBM"),
-                       "algo": args.algo, "rows_per_gpu": n, "keys_per_gpu": K, "buckets": T,
-                       "lattice": "hinted" if args.hint_lattice else "derived by the engine (extra pass over flow_end_s)",
+                                   % (" then ".join(algos), "s (one step = both jobs)" if len(algos) > 1 else "", n, K, T,
+                                      "sum" if r["agg"] else "max", r["agg"] or "None",
+                                      "inputs in pinned HOST memory, results copied back (PCIe-inclusive)" if host_input
+                                      else "inputs and outputs resident in HBM"),
+                       "algo": "+".join(algos), "rows_per_gpu": n, "keys_per_gpu": K, "buckets": T,
+                       "lattice": "hinted" if hint else "derived by the engine (extra pass over flow_end_s)",
                        "parallelism": ("key-sharded x%d, no data-path collective; one 9-double all-gather per job (counters + moments)" % world)
-                       if args.ingest == "keys" else
+                       if ingest == "keys" else
                        ("row-sharded x%d: tad_aggregate on the local slice, one all-to-all(v) of partial points, job on the owners; "
                         "one 9-double all-gather per job" % world)},
-            "roofline": {"bound": "hbm", "kernel": {2: "k_partition (Stage-0 v2, row partition pass, sort-by-tile)", 3: "k_partition_wc (Stage-0 v2, row partition pass, write-combining)"}.get(st["stage0_path"], "k_scatter (Stage-0 v1, direct atomics)"), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": STAGE0_KERNEL.get(st0["stage0_path"], "k_scatter (Stage-0 v1, direct atomics)"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": BYTES_PER_ROW * n, "avg_kernel_ms": scatter_ms},
-            "pipeline": {"ms_meta": acc["ms_meta"] / steps, "ms_stage0_clear_plus_scatter": acc["ms_stage0"] / steps,
-                         "ms_detect_and_emit": acc["ms_detect"] / steps, "ms_device_total": acc["ms_total"] / steps,
-                         "hbm_frac_whole_job": (BYTES_PER_ROW * n + BYTES_PER_ANOMALY * A) / (acc["ms_total"] / steps * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "result": {"anomalies": g_counts[0], "keys": g_counts[1], "points": g_counts[2], "rows_used": g_counts[3],
-                       "global_mean": glob["global_mean"], "global_sigma": glob["global_sigma"]},
+            "pipeline": {"ms_meta": a0["ms_meta"] / steps, "ms_stage0_clear_plus_scatter": a0["ms_stage0"] / steps,
+                         "ms_detect_and_emit": sum(a["ms_detect"] for a in r["acc"]) / steps, "ms_device_total": dev_ms,
+                         "hbm_frac_whole_job": (len(algos) * BYTES_PER_ROW * n + BYTES_PER_ANOMALY * A) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        if (n, K, T, args.algo) == (100_000_000, 100_000, 250, "EWMA"):   # the PMC passes were taken on this workload
-            out["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(st["stage0_path"], "k_scatter"))
-        if args.algo == "ARIMA":
-            sec = acc["ms_detect"] / steps * 1e-3
-            flops = FLOP_PER_KALMAN_STEP * st["kalman_steps"]
-            out["arima"] = {"fits_per_launch": st["arima_fits"], "kalman_steps_per_launch": st["kalman_steps"],
-                            "fits_per_s": st["arima_fits"] / sec, "bound": "fp64 vector ALU / dependency latency",
-                            "achieved_tflops": flops / sec / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                            "frac": flops / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "ms_detect": acc["ms_detect"] / steps}
+        g = r["glob"]
+        out["result"] = {"anomalies": g["n_anomalies"], "keys": g["n_keys"], "points": g["n_points"], "rows_used": g["rows_used"],
+                         "global_mean": g["global_mean"], "global_sigma": g["global_sigma"]}
+        for st, a, algo in zip(r["stats"], r["acc"], algos):
+            if algo == "ARIMA":
+                sec = a["ms_detect"] / steps * 1e-3
+                flops = FLOP_PER_KALMAN_STEP * st["kalman_steps"]
+                out["arima"] = {"fits_per_launch": st["arima_fits"], "kalman_steps_per_launch": st["kalman_steps"],
+                                "fits_per_s": st["arima_fits"] / sec, "bound": "fp64 vector ALU / dependency latency",
+                                "achieved_tflops": flops / sec / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                "frac": flops / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "ms_detect": a["ms_detect"] / steps,
+                                "flop_model": "60 flop per Kalman time-step x the engine's kalman_steps counter (SURVEY.md 8d)"}
+                if len(algos) == 1:     # the detector, not Stage 0, is this config's dominant kernel
+                    out["roofline"] = {"bound": "fp64-vector", "kernel": "k_arima_fit (per-lane L-BFGS-B over the 3-state Kalman likelihood)",
+                                       "achieved": flops / sec / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": flops / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                                       "algorithmic_flops_per_launch": flops, "avg_kernel_ms": a["ms_detect"] / steps,
+                                       "hbm_frac_of_24B_per_row": BYTES_PER_ROW * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        return out
+
+    head = run_config(cfg["algos"], cfg["rows"], cfg["keys"], cfg["buckets"], cfg["agg"], args.steps, args.warmup,
+                      ingest=args.ingest, host_input=args.host_input, hint=args.hint_lattice)
+    out = None
+    if rank == 0:
+        d = describe(head, args.host_input, args.ingest, args.hint_lattice)
+        out = {"metric": "flow-records/sec", "value": d["value"], "unit": d["unit"], "n_gpus": world, "steps": d["steps"], "warmup": d["warmup"],
+               "ms_per_step": d["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+               "dtype": "u64 (aggregates) + f64 (detectors)", "data": "synthetic", "config": d["config"], "roofline": d["roofline"],
+               "pipeline": d["pipeline"], "result": d["result"]}
+        out["config"]["baseline_config"] = args.config
+        if "arima" in d:
+            out["arima"] = d["arima"]
+        if headline_is_c2:   # the PMC passes were taken on this workload
+            out["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(head["stats"][0]["stage0_path"], "k_scatter"))
+    cores = os.cpu_count() or 1
+    if world == 1 and headline_is_c2 and not args.no_other_configs and not args.host_input and args.ingest == "keys":
+        # BASELINE.json configs[3] and configs[2], measured in the same run (their tables replace the C2 table in HBM)
+        others = {}
+        for name, steps, warmup in (("c4", 5, 2), ("c3", 1, 1)):
+            c = CONFIGS[name]
+            r = run_config(c["algos"], c["rows"], c["keys"], c["buckets"], c["agg"], steps, warmup)
+            d = describe(r)
+            d["baseline_config"] = name
+            if not args.no_cpu_baseline:
+                cr, ck, sr = cpu_sample(c["algos"][0], c["rows"], c["keys"], cores)
+                try:
+                    d["cpu_baseline"] = cpu_baseline(c["algos"][0], cr, ck, c["buckets"], c["agg"], sr)
+                    d["cpu_baseline"]["gpu_over_cpu"] = d["value"] / d["cpu_baseline"]["value"]
+                except Exception as exc:      # the headline line must still be printed
+                    d["cpu_baseline"] = {"error": repr(exc)[:200]}
+            others[name] = d
+        out["other_configs"] = others
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            crow = min(args.cpu_rows, n)
-            ckeys = max(1, int(K * crow / n))
-            out["cpu_baseline"] = cpu_baseline(args.algo, crow, ckeys, T, args.agg)
+            algo = cfg["algos"][-1] if len(cfg["algos"]) > 1 else cfg["algos"][0]
+            cr, ck, sr = cpu_sample(algo, cfg["rows"], cfg["keys"], cores)
+            if args.cpu_rows:
+                cr, ck = args.cpu_rows, max(1, int(cfg["keys"] * args.cpu_rows / cfg["rows"]))
+                sr = min(sr, cr)
+            out["cpu_baseline"] = cpu_baseline(algo, cr, ck, cfg["buckets"], cfg["agg"], sr)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     eng.close()
