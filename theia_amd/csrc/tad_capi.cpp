@@ -283,6 +283,7 @@ struct JobParams {
   double drop_nsigma;
   int drop_min_samples;
   bool all_points;
+  bool lazy_sigma = false;   // set by detect_and_count: the stddev column is computed by the emit kernel (DBSCAN jobs)
 };
 
 // reciprocals of the point counts 1..T for the exact-division FMA sequence (tad_internal.h:div_by_count);
@@ -318,7 +319,7 @@ int ensure_key_buffers(tad_engine *e, uint64_t K) {
 
 // Runs sigma + detector + scan on grid g.  On return *rows = number of rows emit will write.
 // stats_done: Stage 0 v2's tile pass already produced sigma / n_pts / (EWMA) n_anom / moments inputs / counters.
-int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ctr, uint64_t *rows, bool stats_done = false) {
+int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_t *rows, bool stats_done = false) {
   hipStream_t s = e->stream;
   int rc;
   if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
@@ -330,21 +331,25 @@ int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ct
 
   const bool ewma = jp.algo == TAD_ALGO_EWMA;
   const bool drop = jp.algo == TAD_ALGO_DROP;
+  // DBSCAN ignores sigma for its verdicts (anomaly_detection.py:325-349) — it is only an output column of the anomalous
+  // rows.  The tile kernel then delivers the per-key counts / moments itself and k_emit streams stddev_samp for the keys
+  // that have rows: no separate per-key walk over the whole grid (C4: -0.44 ms).  emit-all jobs keep the general path.
+  const bool db_fused = jp.algo == TAD_ALGO_DBSCAN && !jp.all_points && !stats_done && dbscan_uses_list(g);
+  jp.lazy_sigma = db_fused;
   if (drop) {   // mean / std / verdicts / counters in one kernel (pandas' pairwise arithmetic, not Spark's streaming update)
     if ((rc = ensure(e, e->calc, (g.K * g.T ? g.K * g.T : 1) * sizeof(double))) != TAD_OK) return rc;
     launch_drop(s, g, jp.drop_nsigma, jp.drop_min_samples, static_cast<double *>(e->calc.p), sigma, n_pts,
                 static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p), ctr);
-  } else if (!stats_done)
+  } else if (!stats_done && !db_fused)
     launch_key_sigma(s, g, jp.alpha, ewma && !jp.all_points, static_cast<const double *>(e->rcp_table.p), sigma, n_pts, n_anom, ctr, static_cast<double *>(e->key_mean.p),
                      static_cast<double *>(e->key_m2.p));
-  launch_moments(s, g.K, n_pts, static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
-                 static_cast<Moments *>(e->moments.p));
   if (jp.algo == TAD_ALGO_DBSCAN) {
-    const size_t scratch = dbscan_long_scratch_bytes(g);
-    if (scratch == 0) {
-      if (launch_dbscan(s, g, jp.eps, jp.min_samples) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN tile selection failed");
+    if ((rc = ensure(e, e->aux, dbscan_scratch_bytes(g))) != TAD_OK) return rc;
+    if (dbscan_uses_list(g)) {
+      DbscanStats dst{nullptr, nullptr, nullptr, nullptr};
+      if (db_fused) dst = DbscanStats{n_pts, n_anom, static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p)};
+      if (launch_dbscan(s, g, jp.eps, jp.min_samples, e->aux.p, dst) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
     } else {
-      if ((rc = ensure(e, e->aux, scratch)) != TAD_OK) return rc;
       launch_dbscan_long(s, g, jp.eps, jp.min_samples, e->aux.p);
     }
   } else if (jp.algo == TAD_ALGO_ARIMA) {
@@ -354,8 +359,11 @@ int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ct
     if (launch_arima(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, wsb) != 0)
       return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
   }
+  launch_moments(s, g.K, n_pts, static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
+                 static_cast<Moments *>(e->moments.p), db_fused ? ctr : nullptr);
   const uint32_t *cnt = n_anom;
   if (jp.all_points && jp.algo != TAD_ALGO_ARIMA && !drop) cnt = n_pts;
+  else if (db_fused) {}                                                             // the tile kernel counted the noise points
   else if (!ewma || jp.all_points) launch_count_flags(s, g, jp.all_points, n_anom);  // ARIMA / DROP all_points: skips no-result keys
   launch_scan(s, cnt, off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
   HIP_TRY(e, hipMemcpyAsync(e->total_host, off + g.K, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -368,7 +376,7 @@ int detect_and_count(tad_engine *e, Grid g, const JobParams &jp, DevCounters *ct
 }
 
 void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows out) {
-  const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : (jp.algo == TAD_ALGO_DROP ? 3 : 2));
+  const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : (jp.algo == TAD_ALGO_DROP ? 3 : (jp.lazy_sigma ? 4 : 2)));
   launch_emit(e->stream, g, L, kind, jp.all_points, jp.alpha, static_cast<const double *>(e->sigma.p),
               static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(kind == 3 ? e->key_mean.p : e->calc.p),
               static_cast<const unsigned long long *>(e->off.p), out);
@@ -1034,11 +1042,10 @@ int tad_series_dbscan_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, doub
   int rc = series_grid(e, x, n, &g);
   if (rc != TAD_OK || n == 0) return rc;
   JobParams jp = series_params(TAD_ALGO_DBSCAN, 0, eps, min_samples, 0);
-  const size_t scratch = dbscan_long_scratch_bytes(g);
-  if (scratch == 0) {
-    if (launch_dbscan(e->stream, g, jp.eps, jp.min_samples) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN tile selection failed");
+  if ((rc = ensure(e, e->aux, dbscan_scratch_bytes(g))) != TAD_OK) return rc;
+  if (dbscan_uses_list(g)) {
+    if (launch_dbscan(e->stream, g, jp.eps, jp.min_samples, e->aux.p) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
   } else {
-    if ((rc = ensure(e, e->aux, scratch)) != TAD_OK) return rc;
     launch_dbscan_long(e->stream, g, jp.eps, jp.min_samples, e->aux.p);
   }
   return series_emit_all(e, g, jp, false, 0.0, nullptr, verdict);

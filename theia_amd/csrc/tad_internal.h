@@ -91,20 +91,65 @@ __device__ __forceinline__ double div_by_count(double a, double b, double y) {
   return fma(r, y, q);
 }
 
+#if defined(__HIPCC__)
+// (the per-key walks are HBM-latency bound: one lane = one key, 64 consecutive keys = one coalesced 512-byte access)
+// Walk one key's column of the time-major grid in time order, calling step(t, flag, raw_value) for every bucket.
+// The walk is a dependency chain per lane fed by HBM: it is software-pipelined — the loads of chunk c+1 are
+// issued before chunk c is consumed, in fixed numbers (the last chunk re-loads itself) so that hipcc can wait with
+// vmcnt(N > 0) instead of draining the pipe.  kWalkChunk buckets = 2 loads each; two chunks stay in flight.
+static constexpr int kWalkChunk = 8;
+
+template <typename Step>
+__device__ __forceinline__ void walk_series(const Grid &g, uint64_t k, Step step) {
+  const uint64_t T = g.T;
+  const uint64_t nfull = T / kWalkChunk;
+  uint8_t fa[kWalkChunk], fb[kWalkChunk];
+  unsigned long long va[kWalkChunk], vb[kWalkChunk];
+  auto load = [&](uint64_t c, uint8_t *f, unsigned long long *v) {
+#pragma unroll
+    for (int u = 0; u < kWalkChunk; ++u) {
+      const uint64_t cell = (c * kWalkChunk + u) * g.K + k;
+      f[u] = g.flag[cell];
+      v[u] = g.val[cell];
+    }
+  };
+  if (nfull) {
+    load(0, fa, va);
+    uint64_t c = 0;
+    for (; c + 2 <= nfull; c += 2) {
+      load(c + 1, fb, vb);
+#pragma unroll
+      for (int u = 0; u < kWalkChunk; ++u) step(c * kWalkChunk + u, fa[u], va[u]);
+      load(c + 2 < nfull ? c + 2 : c + 1, fa, va);   // past the end: a redundant in-bounds reload keeps the count fixed
+#pragma unroll
+      for (int u = 0; u < kWalkChunk; ++u) step((c + 1) * kWalkChunk + u, fb[u], vb[u]);
+    }
+    if (c < nfull) {
+#pragma unroll
+      for (int u = 0; u < kWalkChunk; ++u) step(c * kWalkChunk + u, fa[u], va[u]);
+    }
+  }
+  for (uint64_t t = nfull * kWalkChunk; t < T; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
+}
+
+#endif
+
 // per-key n / sigma (+ EWMA anomaly count when ewma != 0).  rcp[n] = RN(1/n) for n = 0..T (rcp[0] unused).
 void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, const double *rcp, double *sigma,
                       uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2);
 // deterministic Chan merge of the per-key (n, mean, M2) into kMomentBlocks partials
 struct Moments { double n, mean, m2; };
 static constexpr int kMomentBlocks = 128;
+// ctr != NULL: also adds the job counters n_keys / n_points (for paths whose per-key kernel does not count them itself)
 void launch_moments(hipStream_t s, uint64_t K, const uint32_t *n_pts, const double *key_mean,
-                    const double *key_m2, Moments *partials);
+                    const double *key_m2, Moments *partials, DevCounters *ctr = nullptr);
 void launch_count_flags(hipStream_t s, Grid g, bool all_points, uint32_t *n_anom);
 // exclusive scan of cnt[K] into off[K], total in off[K]
 void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K,
                  unsigned long long *scratch);
 size_t scan_scratch_elems(uint64_t K);
-// kind: 0 EWMA (recompute), 1 flags + calc array, 2 flags with calc = 0, 3 flags with calc = per-key value calc[k]
+// kind: 0 EWMA (recompute), 1 flags + calc array, 2 flags with calc = 0, 3 flags with calc = per-key value calc[k],
+// 4 = 2 with the stddev column computed here (Spark's streaming update over the key's series) for the keys that have rows
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
                  const unsigned long long *off, OutRows out);
@@ -124,9 +169,17 @@ void launch_stream(hipStream_t s, Grid g, Lattice lat, double alpha, bool all_po
 // EWMA value for every present point into calc[T][K] (series entry points)
 void launch_ewma_values(hipStream_t s, Grid g, double alpha, double *calc);
 
-// DBSCAN: sets FLAG_ANOMALY on noise points.  Returns 0, or -1 if T is too large for the LDS tile.
-int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples);
-size_t dbscan_long_scratch_bytes(Grid g);  // 0 when the LDS tile kernel applies
+// DBSCAN: sets FLAG_ANOMALY on noise points.  scratch = dbscan_scratch_bytes(g) bytes of device memory.
+// dbscan_uses_list: the series fit an LDS row -> launch_dbscan (scan + work list); otherwise launch_dbscan_long.
+// st (all pointers NULL = not wanted): per-key point / anomaly counts and (mean, M2) moments
+struct DbscanStats {
+  uint32_t *n_pts, *n_anom;
+  double *key_mean, *key_m2;
+};
+size_t dbscan_scratch_bytes(Grid g);
+bool dbscan_uses_list(Grid g);
+int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch,
+                  DbscanStats st = DbscanStats{nullptr, nullptr, nullptr, nullptr});
 int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch);
 
 // drop detector (tad_drop.hip): sigma / n_pts / key_mean / key_m2 / counters + FLAG_ANOMALY; ws = K * T doubles

@@ -236,46 +236,7 @@ void launch_scatter(hipStream_t s, const uint64_t *key, const uint64_t *key2, co
 // (Spark >= 3.1 returns null; anomaly_detection.py:198-201 then yields False for every point).
 // EWMA_COUNT additionally runs the EWMA recurrence and counts the key's anomalous points.
 // ------------------------------------------------------------------------------------------------
-static constexpr int kUnroll = 16;  // independent loads in flight per lane: the per-key walks are HBM-latency bound
-
-// Walk one key's column of the time-major grid in time order, calling step(t, flag, raw_value) for every bucket.
-// The walk is a dependency chain per lane fed by HBM: it is software-pipelined — the loads of chunk c+1 are
-// issued before chunk c is consumed, in fixed numbers (the last chunk re-loads itself) so that hipcc can wait with
-// vmcnt(N > 0) instead of draining the pipe.  kWalkChunk buckets = 2 loads each; two chunks stay in flight.
-static constexpr int kWalkChunk = 8;
-
-template <typename Step>
-__device__ __forceinline__ void walk_series(const Grid &g, uint64_t k, Step step) {
-  const uint64_t T = g.T;
-  const uint64_t nfull = T / kWalkChunk;
-  uint8_t fa[kWalkChunk], fb[kWalkChunk];
-  unsigned long long va[kWalkChunk], vb[kWalkChunk];
-  auto load = [&](uint64_t c, uint8_t *f, unsigned long long *v) {
-#pragma unroll
-    for (int u = 0; u < kWalkChunk; ++u) {
-      const uint64_t cell = (c * kWalkChunk + u) * g.K + k;
-      f[u] = g.flag[cell];
-      v[u] = g.val[cell];
-    }
-  };
-  if (nfull) {
-    load(0, fa, va);
-    uint64_t c = 0;
-    for (; c + 2 <= nfull; c += 2) {
-      load(c + 1, fb, vb);
-#pragma unroll
-      for (int u = 0; u < kWalkChunk; ++u) step(c * kWalkChunk + u, fa[u], va[u]);
-      load(c + 2 < nfull ? c + 2 : c + 1, fa, va);   // past the end: a redundant in-bounds reload keeps the count fixed
-#pragma unroll
-      for (int u = 0; u < kWalkChunk; ++u) step((c + 1) * kWalkChunk + u, fb[u], vb[u]);
-    }
-    if (c < nfull) {
-#pragma unroll
-      for (int u = 0; u < kWalkChunk; ++u) step(c * kWalkChunk + u, fa[u], va[u]);
-    }
-  }
-  for (uint64_t t = nfull * kWalkChunk; t < T; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
-}
+static constexpr int kUnroll = 16;  // independent loads in flight per lane (k_emit_points)
 
 // RCP_LDS: the reciprocal table (T + 1 doubles) is copied to LDS first.  A table lookup from global memory inside the
 // step would be a vector-memory load YOUNGER than the prefetched chunk of the walk, and vmcnt retires in order: waiting
@@ -374,12 +335,20 @@ __device__ __forceinline__ Moments chan_merge(Moments a, Moments b) {
 __global__ __launch_bounds__(kBlock) void k_moments(uint64_t K, const uint32_t *__restrict__ n_pts,
                                                     const double *__restrict__ key_mean,
                                                     const double *__restrict__ key_m2,
-                                                    Moments *__restrict__ partials) {
+                                                    Moments *__restrict__ partials, DevCounters *ctr) {
   Moments acc{0.0, 0.0, 0.0};
+  unsigned long long pts = 0, keys = 0;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < K; k += stride) {
-    Moments m{(double)n_pts[k], key_mean[k], key_m2[k]};
+    const uint32_t n = n_pts[k];
+    Moments m{(double)n, key_mean[k], key_m2[k]};
     acc = chan_merge(acc, m);
+    pts += n;
+    keys += n > 0;
+  }
+  if (ctr != nullptr) {
+    for (int d = 32; d >= 1; d >>= 1) { pts += __shfl_down(pts, d); keys += __shfl_down(keys, d); }
+    if ((threadIdx.x & 63) == 0 && keys) { atomicAdd(&ctr->n_points, pts); atomicAdd(&ctr->n_keys, keys); }
   }
   for (int d = 1; d < 64; d <<= 1) {
     Moments o{__shfl_xor(acc.n, d), __shfl_xor(acc.mean, d), __shfl_xor(acc.m2, d)};
@@ -397,8 +366,8 @@ __global__ __launch_bounds__(kBlock) void k_moments(uint64_t K, const uint32_t *
 }
 
 void launch_moments(hipStream_t s, uint64_t K, const uint32_t *n_pts, const double *key_mean,
-                    const double *key_m2, Moments *partials) {
-  hipLaunchKernelGGL(k_moments, dim3(kMomentBlocks), dim3(kBlock), 0, s, K, n_pts, key_mean, key_m2, partials);
+                    const double *key_m2, Moments *partials, DevCounters *ctr) {
+  hipLaunchKernelGGL(k_moments, dim3(kMomentBlocks), dim3(kBlock), 0, s, K, n_pts, key_mean, key_m2, partials, ctr);
 }
 
 // per-key count of points flagged by a detector kernel (DBSCAN / ARIMA), or of all points
@@ -515,7 +484,10 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
   unsigned long long pos = off[k];
   const unsigned long long end = off[k + 1];
   if (pos == end) return;
-  const double sg = sigma[k];
+  constexpr bool LAZY = KIND == 4;   // stddev_samp is not in sigma[]: streamed here, written after the walk
+  const unsigned long long first = pos;
+  double sg = LAZY ? 0.0 : sigma[k];
+  double s_cnt = 0.0, s_avg = 0.0, s_m2 = 0.0;
   const bool has_sigma = n_pts[k] >= 2;
   const double one_minus = 1.0 - alpha;
   double e = 0.0;
@@ -530,12 +502,19 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
     out.flow_end_s[at] = ts;
     out.throughput[at] = x;
     out.algo_calc[at] = a;
-    out.stddev[at] = sg;
+    if (!LAZY) out.stddev[at] = sg;
     if (ALL) out.anomaly[at] = verdict ? 1 : 0;
   };
   auto step = [&](uint64_t t, uint8_t fl, unsigned long long raw) {
     if (!(fl & FLAG_PRESENT)) return;
     const double x = (double)raw;
+    if (LAZY) {   // Spark CentralMomentAgg, as k_key_sigma (an IEEE division = the bits of div_by_count)
+      s_cnt = s_cnt + 1.0;
+      const double d = x - s_avg;
+      const double dn = d / s_cnt;
+      s_avg = s_avg + dn;
+      s_m2 = s_m2 + d * (d - dn);
+    }
     double a;
     bool verdict;
     if (KIND == 0) {
@@ -565,9 +544,11 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
           reinterpret_cast<double2 *>(out.throughput + pos)[1] = make_double2(bx[2], bx[3]);
           reinterpret_cast<double2 *>(out.algo_calc + pos)[0] = make_double2(ba[0], ba[1]);
           reinterpret_cast<double2 *>(out.algo_calc + pos)[1] = make_double2(ba[2], ba[3]);
-          const double2 ss = make_double2(sg, sg);
-          reinterpret_cast<double2 *>(out.stddev + pos)[0] = ss;
-          reinterpret_cast<double2 *>(out.stddev + pos)[1] = ss;
+          if (!LAZY) {
+            const double2 ss = make_double2(sg, sg);
+            reinterpret_cast<double2 *>(out.stddev + pos)[0] = ss;
+            reinterpret_cast<double2 *>(out.stddev + pos)[1] = ss;
+          }
           if (ALL) *reinterpret_cast<uint32_t *>(out.anomaly + pos) = (uint32_t)bv[0] | ((uint32_t)bv[1] << 8) | ((uint32_t)bv[2] << 16) | ((uint32_t)bv[3] << 24);
           pos += 4;
           nb = 0;
@@ -579,6 +560,10 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
 #pragma unroll
   for (int i = 0; i < 3; ++i)   // tail of the segment: fewer than four buffered rows
     if (i < nb) write_row(pos + i, bt[i], bx[i], ba[i], ALL && bv[i] != 0);
+  if (LAZY) {
+    sg = has_sigma ? sqrt(s_m2 / (s_cnt - 1.0)) : 0.0;
+    for (unsigned long long at = first; at < end; ++at) out.stddev[at] = sg;
+  }
 }
 
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
@@ -591,7 +576,8 @@ void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, 
   if (all_points) {
     if (kind == 0) TAD_LAUNCH_EMIT(0, true); else if (kind == 1) TAD_LAUNCH_EMIT(1, true); else if (kind == 3) TAD_LAUNCH_EMIT(3, true); else TAD_LAUNCH_EMIT(2, true);
   } else {
-    if (kind == 0) TAD_LAUNCH_EMIT(0, false); else if (kind == 1) TAD_LAUNCH_EMIT(1, false); else if (kind == 3) TAD_LAUNCH_EMIT(3, false); else TAD_LAUNCH_EMIT(2, false);
+    if (kind == 0) TAD_LAUNCH_EMIT(0, false); else if (kind == 1) TAD_LAUNCH_EMIT(1, false); else if (kind == 3) TAD_LAUNCH_EMIT(3, false);
+    else if (kind == 4) TAD_LAUNCH_EMIT(4, false); else TAD_LAUNCH_EMIT(2, false);
   }
 #undef TAD_LAUNCH_EMIT
 }

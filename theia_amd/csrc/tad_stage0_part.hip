@@ -51,7 +51,7 @@ static constexpr int kPartThreads = 1024;
 // The cell field is cell_bits wide (15 .. kMaxCellBits, chosen by the plan from KP x T); the all-ones cell means
 // "no cell" (row off the lattice, or its value went to the overflow list).
 static constexpr int kMinCellBits = 15, kMaxCellBits = 24;
-static constexpr uint32_t kTileCells = 17000;   // cells of one LDS tile of pass C: 9 B per cell within kLdsBudget
+static constexpr uint32_t kTileCells = 17744;   // cells of one LDS tile of pass C: 9 B per cell within kLdsBudget (C4: 512 keys x 34 buckets, 3 rounds)
 static constexpr uint32_t kMaxParts = 2048;     // partitions of pass B: 12 B of LDS each, and >= ~5 records per run per tile
 static constexpr size_t kLdsBudget = 156 * 1024;  // dynamic LDS per workgroup; the rest of the CU's 160 KiB is for static __shared__
 static constexpr int kGcdSamples = 4;
@@ -990,6 +990,7 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   pl->tb = (uint32_t)(kTileCells >> sp);
   if (pl->tb > T) pl->tb = (uint32_t)T;
   pl->n_chunks = (uint32_t)((T + pl->tb - 1) / pl->tb);
+  pl->tb = (uint32_t)((T + pl->n_chunks - 1) / pl->n_chunks);   // same number of rounds, balanced (100 buckets: 34 + 33 + 33, not 34 + 34 + 32 ... + 1)
   pl->agg_lds = ((size_t)pl->tb * pl->KP * 9 + 15) & ~(size_t)15;
   // pass B: records per tile limited by LDS: 10 B per slot + 12 B per partition
   const size_t fixed = ((size_t)pl->nparts + 4) * 12 + 64;
