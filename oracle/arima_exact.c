@@ -418,8 +418,9 @@ static int dcsrch_next(struct mt *L, double *stp, double f, double g, double stp
  * --------------------------------------------------------------------------------------------------------------- */
 struct fitctx { const double *y; long n; };
 
-static void eval_fg(const struct fitctx *c, const double x[3], double *f, double g[3]) {   /* _approx_fprime, forward */
-  const double f0 = arima_nll(x, c->y, c->n, 0);
+/* f, the forward-difference gradient (_approx_fprime) and the one-step forecast of the model at x */
+static void eval_fg(const struct fitctx *c, const double x[3], double *f, double g[3], double *fc) {
+  const double f0 = arima_nll(x, c->y, c->n, fc);
   int i;
   for (i = 0; i < 3; ++i) {
     double xe[3] = {x[0], x[1], x[2]};
@@ -462,12 +463,14 @@ static double fit_forecast(const double *y, long n, int maxiter, int *nit_out) {
   struct fitctx c;
   struct hist h;
   struct mt L;
-  double x[3], g[3], f, d[3], xs[3], gs[3], fold, gd, gdold, stp, forecast;
+  double x[3], g[3], f, d[3], xs[3], gs[3], fold, gd, gdold, stp;
+  double fc, fcold;   /* forecast at x / at the start of the line search: the fitted model's forecast needs no extra filter run */
   int iter = 0, nit = 0, i;
   c.y = y; c.n = n;
   h.col = 0; h.head = 0; h.theta = 1.0;
   start_params(y, n, x);
-  eval_fg(&c, x, &f, g);
+  eval_fg(&c, x, &f, g, &fc);
+  fcold = fc;
   if (fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))) <= pgtol) goto done;
   for (;;) {
     int task, ifun, restart = 0;
@@ -479,6 +482,7 @@ static double fit_forecast(const double *y, long n, int maxiter, int *nit_out) {
       stp = iter == 0 ? fmin(1.0 / dnorm, 1e10) : 1.0;
       for (i = 0; i < 3; ++i) { xs[i] = x[i]; gs[i] = g[i]; }
       fold = f;
+      fcold = fc;
       gd = dot3(g, d);
       gdold = gd;
       task = T_ERROR;
@@ -490,7 +494,7 @@ static double fit_forecast(const double *y, long n, int maxiter, int *nit_out) {
     ifun = 1;
     for (i = 0; i < 3; ++i) x[i] = stp == 1.0 ? xs[i] + d[i] : stp * d[i] + xs[i];
     for (;;) {                                        /* line search */
-      eval_fg(&c, x, &f, g);
+      eval_fg(&c, x, &f, g, &fc);
       gd = dot3(g, d);
       task = dcsrch_next(&L, &stp, f, gd, 0.0, 1e10);
       if (task != T_FG) break;
@@ -498,6 +502,7 @@ static double fit_forecast(const double *y, long n, int maxiter, int *nit_out) {
       if (ifun - 1 >= 20) {                           /* maxls: back to the start of the search, memory refreshed */
         for (i = 0; i < 3; ++i) { x[i] = xs[i]; g[i] = gs[i]; }
         f = fold;
+        fc = fcold;
         if (h.col == 0) goto done;
         h.col = 0; h.head = 0; h.theta = 1.0;
         restart = 1;
@@ -525,9 +530,8 @@ static double fit_forecast(const double *y, long n, int maxiter, int *nit_out) {
     }
   }
 done:
-  arima_nll(x, y, n, &forecast);
   if (nit_out) *nit_out = nit;
-  return forecast;
+  return fc;
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -583,3 +587,26 @@ double arima_exact_log(double x) { return tad_det_log(x); }
 double arima_exact_exp(double x) { return tad_det_exp(x); }
 double arima_exact_expm1(double x) { return tad_det_expm1(x); }
 double arima_exact_log1p(double x) { return tad_det_log1p(x); }
+
+/* per-fit work profile of one series (load-balance studies): evals[i] = likelihood evaluations of the fit on y[:i], i >= 3 */
+int arima_exact_fit_profile(const double *x, long n, int maxiter, double *evals) {
+  double *lx, *y, lam = 0.0, sumlog = 0.0;
+  long i;
+  if (n <= 3) return 0;
+  for (i = 0; i < n; ++i) if (!(x[i] > 0.0)) return 0;
+  lx = (double *)malloc(sizeof(double) * (size_t)n * 2);
+  if (!lx) return -1;
+  y = lx + n;
+  for (i = 0; i < n; ++i) { lx[i] = tad_det_log(x[i]); sumlog += lx[i]; }
+  if (!boxcox_lambda(lx, n, sumlog, &lam)) { free(lx); return 0; }
+  for (i = 0; i < n; ++i) y[i] = lam == 0.0 ? lx[i] : tad_det_expm1(lam * lx[i]) / lam;
+  for (i = 0; i < 3; ++i) evals[i] = 0.0;
+  for (i = 3; i < n; ++i) {
+    const long long s0 = g_steps;
+    fit_forecast(y, i, maxiter, 0);
+    evals[i] = (double)(g_steps - s0) / (double)i;
+  }
+  free(lx);
+  return 1;
+}
+double arima_exact_frexp(double x, int *e) { return tad_det_frexp(x, e); }

@@ -40,3 +40,25 @@ def test_special_values():
     assert exp(-745.0) == 5e-324 and abs(exp(709.7) / np.exp(709.7) - 1.0) < 1e-15
     assert lib.arima_exact_expm1(0.0) == 0.0 and lib.arima_exact_expm1(-1e3) == -1.0 and lib.arima_exact_log1p(0.0) == 0.0
     assert lib.arima_exact_log1p(-1.0) == -np.inf and np.isnan(lib.arima_exact_log1p(-2.0))
+
+
+def test_frexp_semantics():
+    """tad_det_frexp = C frexp (sign kept, subnormals normalised) except that inf / NaN come back with e = 0 — the
+    semantics of the two gfx950 instructions the device code uses in its place."""
+    import ctypes
+    import math
+    lib = ao._load_exact()
+    lib.arima_exact_frexp.restype = ctypes.c_double
+    lib.arima_exact_frexp.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(9)
+    xs = list(np.exp(rng.uniform(-700, 700, 2000)) * rng.choice([-1.0, 1.0], 2000)) + [0.0, -0.0, 1.0, -1.0, 0.5, 5e-324, -3e-310, 2.0 ** -1022, 1.7976931348623157e308]
+    for x in xs:
+        e = ctypes.c_int()
+        m = lib.arima_exact_frexp(float(x), ctypes.byref(e))
+        assert (m, e.value) == math.frexp(float(x)), x
+        assert math.copysign(1.0, m) == math.copysign(1.0, x)
+    for x in (np.inf, -np.inf):
+        e = ctypes.c_int(7)
+        assert lib.arima_exact_frexp(x, ctypes.byref(e)) == x and e.value == 0
+    e = ctypes.c_int(7)
+    assert np.isnan(lib.arima_exact_frexp(np.nan, ctypes.byref(e))) and e.value == 0

@@ -23,6 +23,8 @@
 // so all lanes run Kalman loops of the same length; the optimiser is a per-lane state machine that asks
 // for exactly one likelihood evaluation per trip, so lanes in different optimiser phases (gradient
 // component, line-search trial, final forecast) still execute the expensive part in lockstep.
+#include <cstdlib>
+
 #include "tad_internal.h"
 #include "tad_detmath.h"
 
@@ -43,9 +45,12 @@ struct ArimaWs {
   double *xs;      // [T][K] compacted values (as double), position-major
   double *lx;      // [T][K] log(x)
   double *ys;      // [T][K] Box-Cox transformed
+  double *ysk;     // [K][Tpad] the same, KEY-major (Tpad = T rounded up to 8): the fit kernel's lanes hold arbitrary keys
+  double *u0[3];   // [T][K] start parameters of the fit on y[:p] (k_arima_start)
   uint32_t *tpos;  // [T][K] bucket of the p-th point
   double *lam;     // [K]
   uint8_t *state;  // [K] 0 = ok, 1 = no result
+  uint32_t Tpad;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const do
         const double l = lx[(size_t)i * st];
         const double y = lam == 0.0 ? l : tad_det_expm1(lam * l) / lam;  // scipy.special.boxcox
         ys[(size_t)i * st] = y;
+        ws.ysk[(size_t)k * ws.Tpad + i] = y;
         if (i < 3) {
           const uint64_t c = (uint64_t)tp[(size_t)i * st] * g.K + k;
           const double pred = inv_boxcox(y, lam);
@@ -244,68 +250,131 @@ struct KfOut {
   double forecast;  // Z a_{n+1|n}
 };
 
-TAD_HD KfOut arima_nll(const double u0, const double u1, const double u2, const double *__restrict__ y, size_t stride,
-                       uint32_t n) {
+struct KfState {
+  double phi, q11, q12, q22;     // model
+  double p00, p01, p11, a0, a1;  // predicted covariance (the entries that evolve) and state
+  double F, rF, pz0, pz1;        // frozen once converged
+  double prod, q;                // running product of the F_t (mantissa), sum of v^2 / F
+  int esum;                      // exponents of the product
+  uint32_t nconv;                // steps taken with the converged covariance
+  bool conv;
+};
+
+TAD_HD inline void kf_init(KfState &s, double u0, double u1, double u2) {
   const double phi = u0 / sqrt(1.0 + u0 * u0);
   const double theta = -(u1 / sqrt(1.0 + u1 * u1));
   const double s2 = u2 * u2;
-  const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
-  double p00 = kDiffuse, p01 = 0.0;
-  double p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
-  double a0 = 0.0, a1 = 0.0;
-  double F = 1.0, rF = 1.0, pz0 = 0.0, pz1 = 0.0;
-  double prod = 1.0, q = 0.0;
-  int esum = 0;
-  uint32_t nconv = 0, t = 0;
-  bool conv = false;
-  // phase 1: some lane of the wavefront still updates its covariance (on the host: this series does)
-  while (t < n && !TAD_WAVE_ALL(conv)) {
-    const double v = y[(size_t)t * stride] - (a0 + a1);
-    if (!conv) {
-      pz0 = p00 + p01; pz1 = p01 + p11;
-      F = pz0 + pz1;
-      rF = 1.0 / F;
-    }
-    const double w = rF * v;
-    if (t >= 1) {
-      q += v * w;
-      if (!conv) { int e; prod = tad_det_frexp(prod * F, &e); esum += e; }
-      else nconv++;
-    }
-    const double f0 = a0 + pz0 * w, f1 = a1 + pz1 * w, f2 = q12 * w;
-    a0 = f0 + f1;
-    a1 = phi * f1 + f2;
-    if (!conv) {
-      const double g0 = pz0 * rF, g1 = pz1 * rF, g2 = q12 * rF;
-      const double c00 = p00 - g0 * pz0, c01 = p01 - g0 * pz1, c02 = -(g0 * q12);
-      const double c11 = p11 - g1 * pz1, c12 = q12 - g1 * q12, c22 = q22 - g2 * q12;
-      const double n00 = c00 + 2.0 * c01 + c11;
-      const double n01 = phi * (c01 + c11) + (c02 + c12);
-      const double n11 = phi * (phi * c11 + c12) + (phi * c12 + c22) + q11;
-      const double d00 = p00 - n00, d01 = p01 - n01, d11 = p11 - n11;
-      const double dsq = d00 * d00 + 2.0 * (d01 * d01) + d11 * d11;
-      conv = dsq < kConvTol;
-      p00 = n00; p01 = n01; p11 = n11;
-    }
-    ++t;
+  s.phi = phi;
+  s.q11 = s2; s.q12 = s2 * theta; s.q22 = s2 * (theta * theta);
+  s.p00 = kDiffuse; s.p01 = 0.0;
+  s.p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
+  s.a0 = 0.0; s.a1 = 0.0;
+  s.F = 1.0; s.rF = 1.0; s.pz0 = 0.0; s.pz1 = 0.0;
+  s.prod = 1.0; s.q = 0.0;
+  s.esum = 0; s.nconv = 0; s.conv = false;
+}
+
+// prod * F renormalised to a mantissa in [0.5, 1): tad_det_frexp, on the device by the two instructions it restates
+TAD_HD inline double kf_frexp(double x, int *e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  *e = __builtin_amdgcn_frexp_exp(x);
+  return __builtin_amdgcn_frexp_mant(x);
+#else
+  return tad_det_frexp(x, e);
+#endif
+}
+
+// one time step while NO lane of the wavefront has converged (the common case by far: with an MA coefficient near -1 —
+// differenced level-plus-noise data — the covariance does not converge within a 250-point history): kf_step without
+// the per-lane predication, identical arithmetic
+TAD_HD inline void kf_step_nc(KfState &s, double yv, bool burn_done) {
+  const double v = yv - (s.a0 + s.a1);
+  s.pz0 = s.p00 + s.p01; s.pz1 = s.p01 + s.p11;
+  s.F = s.pz0 + s.pz1;
+  s.rF = 1.0 / s.F;
+  const double w = s.rF * v;
+  if (burn_done) {   // t >= 1: compile-time or wave-uniform
+    s.q += v * w;
+    int e;
+    s.prod = kf_frexp(s.prod * s.F, &e);
+    s.esum += e;
   }
-  // phase 2: steady state
-  nconv += n - t;
-  for (; t < n; ++t) {
-    const double v = y[(size_t)t * stride] - (a0 + a1);
-    const double w = rF * v;
-    q += v * w;
-    const double f0 = a0 + pz0 * w, f1 = a1 + pz1 * w, f2 = q12 * w;
-    a0 = f0 + f1;
-    a1 = phi * f1 + f2;
+  const double f0 = s.a0 + s.pz0 * w, f1 = s.a1 + s.pz1 * w, f2 = s.q12 * w;
+  s.a0 = f0 + f1;
+  s.a1 = s.phi * f1 + f2;
+  const double g0 = s.pz0 * s.rF, g1 = s.pz1 * s.rF, g2 = s.q12 * s.rF;
+  const double c00 = s.p00 - g0 * s.pz0, c01 = s.p01 - g0 * s.pz1, c02 = -(g0 * s.q12);
+  const double c11 = s.p11 - g1 * s.pz1, c12 = s.q12 - g1 * s.q12, c22 = s.q22 - g2 * s.q12;
+  const double n00 = c00 + 2.0 * c01 + c11;
+  const double n01 = s.phi * (c01 + c11) + (c02 + c12);
+  const double n11 = s.phi * (s.phi * c11 + c12) + (s.phi * c12 + c22) + s.q11;
+  const double d00 = s.p00 - n00, d01 = s.p01 - n01, d11 = s.p11 - n11;
+  const double dsq = d00 * d00 + 2.0 * (d01 * d01) + d11 * d11;
+  s.conv = dsq < kConvTol;
+  s.p00 = n00; s.p01 = n01; s.p11 = n11;
+}
+
+// one time step (observation yv at index t); updates the covariance unless it has converged
+TAD_HD inline void kf_step(KfState &s, double yv, uint32_t t) {
+  const double v = yv - (s.a0 + s.a1);
+  if (!s.conv) {
+    s.pz0 = s.p00 + s.p01; s.pz1 = s.p01 + s.p11;
+    s.F = s.pz0 + s.pz1;
+    s.rF = 1.0 / s.F;
   }
-  double sumlog = tad_det_log(prod) + (double)esum * TAD_DM_LN2;
-  if (nconv) sumlog += (double)nconv * tad_det_log(F);
-  const double llf = -0.5 * ((double)(n - 1) * kLog2Pi + sumlog) - 0.5 * q;
+  const double w = s.rF * v;
+  if (t >= 1) {
+    s.q += v * w;
+    if (!s.conv) { int e; s.prod = kf_frexp(s.prod * s.F, &e); s.esum += e; }
+    else s.nconv++;
+  }
+  const double f0 = s.a0 + s.pz0 * w, f1 = s.a1 + s.pz1 * w, f2 = s.q12 * w;
+  s.a0 = f0 + f1;
+  s.a1 = s.phi * f1 + f2;
+  if (!s.conv) {
+    const double g0 = s.pz0 * s.rF, g1 = s.pz1 * s.rF, g2 = s.q12 * s.rF;
+    const double c00 = s.p00 - g0 * s.pz0, c01 = s.p01 - g0 * s.pz1, c02 = -(g0 * s.q12);
+    const double c11 = s.p11 - g1 * s.pz1, c12 = s.q12 - g1 * s.q12, c22 = s.q22 - g2 * s.q12;
+    const double n00 = c00 + 2.0 * c01 + c11;
+    const double n01 = s.phi * (c01 + c11) + (c02 + c12);
+    const double n11 = s.phi * (s.phi * c11 + c12) + (s.phi * c12 + c22) + s.q11;
+    const double d00 = s.p00 - n00, d01 = s.p01 - n01, d11 = s.p11 - n11;
+    const double dsq = d00 * d00 + 2.0 * (d01 * d01) + d11 * d11;
+    s.conv = dsq < kConvTol;
+    s.p00 = n00; s.p01 = n01; s.p11 = n11;
+  }
+}
+
+// the same step when the covariance is known to have converged (t >= 1 then): the steady-state loop body
+TAD_HD inline void kf_step_conv(KfState &s, double yv) {
+  const double v = yv - (s.a0 + s.a1);
+  const double w = s.rF * v;
+  s.q += v * w;
+  s.nconv++;
+  const double f0 = s.a0 + s.pz0 * w, f1 = s.a1 + s.pz1 * w, f2 = s.q12 * w;
+  s.a0 = f0 + f1;
+  s.a1 = s.phi * f1 + f2;
+}
+
+TAD_HD inline KfOut kf_finish(const KfState &s, uint32_t n) {
+  double sumlog = tad_det_log(s.prod) + (double)s.esum * TAD_DM_LN2;
+  if (s.nconv) sumlog += (double)s.nconv * tad_det_log(s.F);
+  const double llf = -0.5 * ((double)(n - 1) * kLog2Pi + sumlog) - 0.5 * s.q;
   KfOut o;
   o.nll = -llf / (double)n;
-  o.forecast = a0 + a1;
+  o.forecast = s.a0 + s.a1;
   return o;
+}
+
+// scalar form over a strided series (the host instantiation in tools/arima_twin.cpp runs this one)
+TAD_HD KfOut arima_nll(const double u0, const double u1, const double u2, const double *__restrict__ y, size_t stride,
+                       uint32_t n) {
+  KfState s;
+  kf_init(s, u0, u1, u2);
+  uint32_t t = 0;
+  for (; t < n && !TAD_WAVE_ALL(s.conv); ++t) kf_step(s, y[(size_t)t * stride], t);
+  for (; t < n; ++t) kf_step_conv(s, y[(size_t)t * stride]);
+  return kf_finish(s, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -511,6 +580,7 @@ struct Lbfgs {
   double x[3], g[3], f;
   double d[3], t[3], r[3];  // search direction, iterate and gradient at the start of the line search
   double fold, gd, gdold, stp, dnorm, dtd, theta;
+  double fc, fcold;  // one-step forecast of the model at x / at the start of the line search (no extra filter run at the end)
   double S[kLbfgsM][3], Y[kLbfgsM][3];
   int col, head, iter, ifun, iback, nit;
   bool in_ls, done;
@@ -548,6 +618,7 @@ TAD_HD void lbfgs_begin_ls(Lbfgs &o) {
     o.stp = o.iter == 0 ? fmin(1.0 / o.dnorm, 1e10) : 1.0;
     for (int i = 0; i < 3; ++i) { o.t[i] = o.x[i]; o.r[i] = o.g[i]; }
     o.fold = o.f;
+    o.fcold = o.fc;
     o.ifun = 0;
     o.iback = 0;
     o.gd = o.g[0] * o.d[0] + o.g[1] * o.d[1] + o.g[2] * o.d[2];
@@ -582,6 +653,7 @@ TAD_HD void lbfgs_deliver(Lbfgs &o, int maxiter) {
     if (o.iback >= 20) {  // maxls: give up on this direction
       for (int i = 0; i < 3; ++i) { o.x[i] = o.t[i]; o.g[i] = o.r[i]; }
       o.f = o.fold;
+      o.fc = o.fcold;
       if (o.col == 0) { o.done = true; return; }
       o.col = 0; o.head = 0; o.theta = 1.0;
       o.in_ls = false;  // restart from the restored iterate
@@ -617,64 +689,138 @@ TAD_HD void lbfgs_deliver(Lbfgs &o, int maxiter) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_arima_fit — one lane = one (key, position) fit; a wavefront = 64 consecutive keys at one position
+// k_arima_start — start parameters of every fit (lane = (key, position), 64 consecutive keys per wavefront: coalesced)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_arima_fit(Grid g, ArimaWs ws, const double *__restrict__ sigma,
-                                                  const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,
-                                                  double *__restrict__ calc, DevCounters *ctr) {
+__global__ __launch_bounds__(64) void k_arima_start(Grid g, ArimaWs ws, const uint32_t *__restrict__ n_pts, uint32_t pmax) {
   const uint32_t kblocks = (uint32_t)((g.K + 63) / 64);
-  const uint32_t pb = blockIdx.x / kblocks;           // heaviest (longest history) positions first
-  const uint32_t p = pmax - 1 - pb;
+  const uint32_t p = pmax - 1 - blockIdx.x / kblocks;
   const uint64_t k = (uint64_t)(blockIdx.x % kblocks) * 64 + threadIdx.x;
-  const bool active = k < g.K && ws.state[k] == 0 && n_pts[k] > p;
+  if (k >= g.K || ws.state[k] != 0 || n_pts[k] <= p) return;
+  double u[3];
+  arima_start_params(ws.ys + k, g.K, p, u);
+  const size_t c = (size_t)p * g.K + k;
+  ws.u0[0][c] = u[0]; ws.u0[1][c] = u[1]; ws.u0[2][c] = u[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_arima_fit — one lane = one fit at a time; a wavefront = a chunk of keys at ONE series position p (so every lane's
+// Kalman loop has the same length) whose lanes pull the next key of the chunk as soon as their fit has converged.
+// Why: the optimiser needs 20 .. 370 likelihood evaluations per fit (mean 81, CV 0.5).  With a fixed lane <-> key map a
+// wavefront runs until its slowest lane is done — measured 2.4x the mean (oracle/arima_exact.c:arima_exact_fit_profile);
+// refilling lanes keeps all 64 busy until the chunk runs dry.
+// Lanes then hold arbitrary keys, so the series are read from the KEY-major copy: every 8 time steps the wavefront loads
+// the next 64 bytes of each lane's row cooperatively (4 lanes x 16 B per row: whole sectors, no over-fetch), stages them
+// in LDS (row stride 9 doubles: conflict-free) and every lane picks up its 8 values.
+// The optimiser runs in cycles of four evaluations (f at x, then the three forward-difference points) followed by one
+// state-machine step, the same for all lanes; finished lanes are refilled between cycles.
+// ------------------------------------------------------------------------------------------------
+static constexpr int kStage = 8;  // time steps staged per round: 64 B per row
+
+__device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double *__restrict__ sigma,
+                                               const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax, uint32_t chunk,
+                                               double *__restrict__ calc, DevCounters *ctr, double *buf) {
+  const uint32_t nchunks = (uint32_t)((g.K + chunk - 1) / chunk);
+  const uint32_t p = pmax - 1 - blockIdx.x / nchunks;           // heaviest (longest history) positions first
+  const uint64_t c0 = (uint64_t)(blockIdx.x % nchunks) * chunk;
+  const uint64_t c1 = c0 + chunk < g.K ? c0 + chunk : g.K;
+  const unsigned lane = threadIdx.x;
+  uint64_t next = c0;                                           // wave-uniform
+  uint64_t k = 0;
+  bool busy = false;
   unsigned long long steps = 0, fits = 0;
-  if (__any(active)) {
-    const size_t st = g.K;
-    const double *y = ws.ys + (active ? k : 0);
-    Lbfgs o;
-    o.col = 0; o.head = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = !active;
-    o.f = 0.0;
-    if (active) arima_start_params(y, st, p, o.x);
-    else { o.x[0] = 0.0; o.x[1] = 0.0; o.x[2] = 1.0; }
-    int phase = 0;  // 0: f at x; 1..3: f at x + h e_i; 4: final forecast
-    double f0 = 0.0, forecast = 0.0;
-    bool finished = !active;
-    while (__any(!finished)) {
+  Lbfgs o;
+  o.done = true;
+  size_t row[4] = {0, 0, 0, 0};                                 // element offset of the rows this lane loads for the wavefront
+
+  auto refill = [&]() {
+    for (;;) {
+      const unsigned long long m = __ballot(!busy);
+      if (m == 0 || next >= c1) break;
+      const uint64_t cand = next + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+      next += (uint64_t)__popcll(m);
+      if (!busy && cand < c1 && ws.state[cand] == 0 && n_pts[cand] > p) {
+        k = cand;
+        busy = true;
+        const size_t c = (size_t)p * g.K + k;
+        o.x[0] = ws.u0[0][c]; o.x[1] = ws.u0[1][c]; o.x[2] = ws.u0[2][c];
+        o.col = 0; o.head = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false;
+        o.f = 0.0; o.fc = 0.0; o.fcold = 0.0;
+      }
+    }
+    const unsigned long long mine = busy ? (unsigned long long)k : 0ull;   // idle lanes: row 0 (valid memory, values unused)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row[j] = (size_t)__shfl(mine, j * 16 + (int)(lane >> 2)) * ws.Tpad + (lane & 3u) * 2u;
+  };
+
+  auto evaluate = [&](double u0, double u1, double u2) -> KfOut {
+    KfState s;
+    kf_init(s, u0, u1, u2);
+    if (!busy) s.conv = true;   // an idle lane must not keep the wavefront in the covariance-updating loop
+    for (uint32_t t0 = 0; t0 < p; t0 += kStage) {
+      double2 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const double2 *>(ws.ysk + row[j] + t0);
+      __syncthreads();   // (one wavefront per workgroup) the previous round's reads are done
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double *d = buf + (size_t)(j * 16 + (int)(lane >> 2)) * (kStage + 1) + (lane & 3u) * 2u;
+        d[0] = v[j].x; d[1] = v[j].y;
+      }
+      __syncthreads();
+      double yv[kStage];
+#pragma unroll
+      for (int i = 0; i < kStage; ++i) yv[i] = buf[(size_t)lane * (kStage + 1) + i];
+      const uint32_t nb = p - t0 < (uint32_t)kStage ? p - t0 : (uint32_t)kStage;
+      // compile-time indices into yv (a runtime-indexed array would live in scratch memory); nb is wave-uniform
+      if (!__all(s.conv)) {
+#pragma unroll
+        for (int i = 0; i < kStage; ++i)
+          if ((uint32_t)i < nb) {
+            if (!__any(s.conv)) kf_step_nc(s, yv[i], t0 + (uint32_t)i >= 1u);
+            else kf_step(s, yv[i], t0 + (uint32_t)i);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < kStage; ++i)
+          if ((uint32_t)i < nb) kf_step_conv(s, yv[i]);
+      }
+    }
+    return kf_finish(s, p);
+  };
+
+  refill();
+  while (__any(busy)) {
+    double f0 = 0.0, fc0 = 0.0;
+    for (int phase = 0; phase < 4; ++phase) {
       double xe0 = o.x[0], xe1 = o.x[1], xe2 = o.x[2], dx = 1.0;
-      if (phase >= 1 && phase <= 3) {
+      if (phase >= 1) {
         double *xe = phase == 1 ? &xe0 : (phase == 2 ? &xe1 : &xe2);
         const double x0 = *xe;
         *xe = x0 + 1e-5;
         dx = *xe - x0;
       }
-      const KfOut r = arima_nll(xe0, xe1, xe2, y, st, p);  // uniform trip count across the wave
-      if (!finished) {
+      const KfOut r = evaluate(xe0, xe1, xe2);
+      if (busy) {
         steps += p;
-        if (phase == 4) {
-          forecast = r.forecast;
-          finished = true;
-        } else if (phase == 0) {
-          f0 = r.nll;
-          phase = 1;
-        } else {
-          o.g[phase - 1] = (r.nll - f0) / dx;
-          phase++;
-          if (phase == 4) {
-            o.f = f0;
-            lbfgs_deliver(o, maxiter);
-            phase = o.done ? 4 : 0;
-          }
-        }
+        if (phase == 0) { f0 = r.nll; fc0 = r.forecast; }
+        else o.g[phase - 1] = (r.nll - f0) / dx;
       }
     }
-    if (active) {
-      fits = 1;
-      const double lam = ws.lam[k];
-      const uint64_t c = (uint64_t)ws.tpos[(size_t)p * st + k] * g.K + k;
-      const double pred = inv_boxcox(forecast, lam);
-      calc[c] = pred;
-      if (fabs(ws.xs[(size_t)p * st + k] - pred) > sigma[k]) g.flag[c] = FLAG_PRESENT | FLAG_ANOMALY;
+    if (busy) {
+      o.f = f0;
+      o.fc = fc0;
+      lbfgs_deliver(o, maxiter);
+      if (o.done) {
+        const size_t st = g.K;
+        const uint64_t c = (uint64_t)ws.tpos[(size_t)p * st + k] * g.K + k;
+        const double pred = inv_boxcox(o.fc, ws.lam[k]);
+        calc[c] = pred;
+        if (fabs(ws.xs[(size_t)p * st + k] - pred) > sigma[k]) g.flag[c] = FLAG_PRESENT | FLAG_ANOMALY;
+        fits++;
+        busy = false;
+      }
     }
+    refill();
   }
   for (int d = 32; d >= 1; d >>= 1) { steps += __shfl_down(steps, d); fits += __shfl_down(fits, d); }
   if (threadIdx.x == 0 && fits) {
@@ -683,9 +829,28 @@ __global__ __launch_bounds__(64) void k_arima_fit(Grid g, ArimaWs ws, const doub
   }
 }
 
+// The register budget decides how many wavefronts share a SIMD (512 VGPRs: 128 -> 4, 96 -> 5, 80 -> 6, 64 -> 8); the
+// optimiser's state is only touched between evaluations, so a tighter budget spills exactly that to scratch and buys
+// latency hiding for the Kalman loop.  One kernel per budget; TAD_ARIMA_WAVES picks (default: measured best).
+#define TAD_ARIMA_FIT_KERNEL(W)                                                                                          \
+  __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_arima_fit_w##W(                    \
+      Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,  \
+      uint32_t chunk, double *__restrict__ calc, DevCounters *ctr) {                                                    \
+    __shared__ double buf[64 * (kStage + 1)];                                                                           \
+    arima_fit_body(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf);                                          \
+  }
+TAD_ARIMA_FIT_KERNEL(3)
+TAD_ARIMA_FIT_KERNEL(4)
+TAD_ARIMA_FIT_KERNEL(5)
+TAD_ARIMA_FIT_KERNEL(6)
+TAD_ARIMA_FIT_KERNEL(8)
+#undef TAD_ARIMA_FIT_KERNEL
+
+static uint32_t arima_tpad(uint64_t T) { return (uint32_t)((T + kStage - 1) / kStage * kStage); }
+
 size_t arima_workspace_bytes(Grid g) {
   const size_t cells = (size_t)g.K * g.T;
-  return cells * (8 + 8 + 8 + 4) + (size_t)g.K * 9 + 256;
+  return cells * (8 * 3 + 8 * 3 + 4) + (size_t)g.K * arima_tpad(g.T) * 8 + (size_t)g.K * 9 + 512;
 }
 
 int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc,
@@ -695,18 +860,36 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
   const size_t cells = (size_t)g.K * g.T;
   unsigned char *w = static_cast<unsigned char *>(workspace);
   ArimaWs ws;
+  ws.Tpad = arima_tpad(g.T);
   ws.xs = reinterpret_cast<double *>(w); w += cells * 8;
   ws.lx = reinterpret_cast<double *>(w); w += cells * 8;
   ws.ys = reinterpret_cast<double *>(w); w += cells * 8;
+  for (int i = 0; i < 3; ++i) { ws.u0[i] = reinterpret_cast<double *>(w); w += cells * 8; }
+  ws.ysk = reinterpret_cast<double *>(w); w += (size_t)g.K * ws.Tpad * 8;
   ws.lam = reinterpret_cast<double *>(w); w += (size_t)g.K * 8;
   ws.tpos = reinterpret_cast<uint32_t *>(w); w += cells * 4;
   ws.state = w;
   hipLaunchKernelGGL(k_arima_prep, dim3((unsigned)((g.K + 255) / 256)), dim3(256), 0, s, g, ws, sigma, calc, ctr);
   if (g.T > 3) {
     const uint64_t kblocks = (g.K + 63) / 64;
-    const uint64_t blocks = kblocks * (g.T - 3);
+    if (kblocks * (g.T - 3) > 0x7FFFFFFFull) return -1;
+    hipLaunchKernelGGL(k_arima_start, dim3((unsigned)(kblocks * (g.T - 3))), dim3(64), 0, s, g, ws, n_pts, (uint32_t)g.T);
+    uint32_t chunk = 4096;   // keys per wavefront and position: ~64 fits per lane (measured: 256 -> 1.48 s, 1024 -> 1.28 s, 4096 -> 1.22 s at C3)
+    if (const char *e = getenv("TAD_ARIMA_CHUNK")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 20)) chunk = (uint32_t)v; }
+    const uint64_t nchunks = (g.K + chunk - 1) / chunk;
+    const uint64_t blocks = nchunks * (g.T - 3);
     if (blocks > 0x7FFFFFFFull) return -1;
-    hipLaunchKernelGGL(k_arima_fit, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, calc, ctr);
+    int waves = 3;   // measured at C3: 3 -> 0.90 s, 4 -> 0.93 s, 5 -> 1.5 s, 6 -> 1.7 s, 8 -> 2.4 s (the loop is FP64-issue bound; spills cost more than occupancy buys)
+    if (const char *e = getenv("TAD_ARIMA_WAVES")) waves = atoi(e);
+#define TAD_ARIMA_LAUNCH(W) hipLaunchKernelGGL(k_arima_fit_w##W, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, chunk, calc, ctr)
+    switch (waves) {
+      case 4: TAD_ARIMA_LAUNCH(4); break;
+      case 5: TAD_ARIMA_LAUNCH(5); break;
+      case 6: TAD_ARIMA_LAUNCH(6); break;
+      case 8: TAD_ARIMA_LAUNCH(8); break;
+      default: TAD_ARIMA_LAUNCH(3); break;
+    }
+#undef TAD_ARIMA_LAUNCH
   }
   return 0;
 }

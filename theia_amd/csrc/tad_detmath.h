@@ -36,14 +36,20 @@ TAD_DM_FN double tad_dm_f64(uint64_t u) { tad_dm_bits b; b.u = u; return b.d; }
 #define TAD_DM_INV_LN2 1.44269504088896338700e+00
 #define TAD_DM_LN2 6.931471805599453094e-01
 
-/* x = m * 2^e with m in [0.5, 1) for positive NORMAL finite x; anything else (zero, subnormal, negative, inf,
- * NaN) is returned unchanged with e = 0, so that it propagates into whatever consumes the mantissa. */
+/* frexp with the semantics of the gfx950 instructions v_frexp_mant_f64 / v_frexp_exp_i32_f64 (= C frexp, except that
+ * infinities and NaNs come back unchanged with e = 0): x = m * 2^e, 0.5 <= |m| < 1, sign kept; +-0 -> (+-0, 0);
+ * subnormals are normalised first.  The device code may therefore use the two instructions instead of this function. */
 TAD_DM_FN double tad_det_frexp(double x, int *e) {
-  const uint64_t u = tad_dm_u64(x);
-  const int be = (int)(u >> 52);  /* sign + biased exponent */
-  if (be <= 0 || be >= 0x7ff) { *e = 0; return x; }
-  *e = be - 1022;
-  return tad_dm_f64((u & 0x000fffffffffffffULL) | 0x3fe0000000000000ULL);
+  uint64_t u = tad_dm_u64(x);
+  int be = (int)((u >> 52) & 0x7ff), adj = 0;
+  if (be == 0x7ff || (u << 1) == 0) { *e = 0; return x; }
+  if (be == 0) {                                    /* subnormal: scale by 2^54 (exact) */
+    tad_dm_bits b; b.u = u; b.d *= 18014398509481984.0; u = b.u;
+    be = (int)((u >> 52) & 0x7ff);
+    adj = -54;
+  }
+  *e = be - 1022 + adj;
+  return tad_dm_f64((u & 0x800fffffffffffffULL) | 0x3fe0000000000000ULL);
 }
 
 /* 2^k for -1022 <= k <= 1023 */

@@ -9,21 +9,22 @@ using namespace tad;
 
 static double twin_fit(const double *y, uint32_t p, int maxiter, unsigned long long *steps) {
   Lbfgs o;
-  o.col = 0; o.head = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false; o.f = 0.0;
+  o.col = 0; o.head = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false; o.f = 0.0; o.fc = 0.0; o.fcold = 0.0;
   arima_start_params(y, 1, p, o.x);
-  int phase = 0;
-  double f0 = 0.0;
-  for (;;) {
-    double xe[3] = {o.x[0], o.x[1], o.x[2]}, dx = 1.0;
-    if (phase >= 1 && phase <= 3) { const double x0 = xe[phase - 1]; xe[phase - 1] = x0 + 1e-5; dx = xe[phase - 1] - x0; }
-    const KfOut r = arima_nll(xe[0], xe[1], xe[2], y, 1, p);
-    *steps += p;
-    if (phase == 4) return r.forecast;
-    if (phase == 0) { f0 = r.nll; phase = 1; continue; }
-    o.g[phase - 1] = (r.nll - f0) / dx;
-    phase++;
-    if (phase == 4) { o.f = f0; lbfgs_deliver(o, maxiter); phase = o.done ? 4 : 0; }
+  while (!o.done) {
+    double f0 = 0.0, fc0 = 0.0;
+    for (int phase = 0; phase < 4; ++phase) {
+      double xe[3] = {o.x[0], o.x[1], o.x[2]}, dx = 1.0;
+      if (phase >= 1) { const double x0 = xe[phase - 1]; xe[phase - 1] = x0 + 1e-5; dx = xe[phase - 1] - x0; }
+      const KfOut r = arima_nll(xe[0], xe[1], xe[2], y, 1, p);
+      *steps += p;
+      if (phase == 0) { f0 = r.nll; fc0 = r.forecast; }
+      else o.g[phase - 1] = (r.nll - f0) / dx;
+    }
+    o.f = f0; o.fc = fc0;
+    lbfgs_deliver(o, maxiter);
   }
+  return o.fc;
 }
 
 extern "C" int twin_series(const double *x, long n, int maxiter, double *pred, double *info) {
