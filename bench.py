@@ -32,6 +32,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -127,6 +129,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU sample (0 = chosen from the host's core count)")
+    ap.add_argument("--dump-rows", default="", help="after the timed region run the step once more and save every rank's anomaly rows "
+                                                     "(GLOBAL key ids) to <path>.rank<r>.npz — used by the N-rank == 1-rank parity test")
     args = ap.parse_args()
 
     import torch
@@ -182,10 +186,12 @@ def main():
             hkey, htend, hval = (x.cpu().pin_memory() for x in (key, tend, val))
         pending = [None]
 
+        dump = {}
+
         def one_job(algo, k_, t_, v_):
             if host_input:
                 return eng.run(algo, hkey, htend, hval, K, agg_flow=agg, lattice=lattice, out="host")
-            return eng.run(algo, k_, t_, v_, K, agg_flow=agg, lattice=lattice, out="device")
+            return eng.run(algo, k_, t_, v_, K, agg_flow=agg, lattice=lattice, out="host" if dump.get("on") else "device")
 
         def step():
             stats, glob = [], None
@@ -195,11 +201,10 @@ def main():
                 pts = eng.aggregate(key, tend, val, K * world, agg_flow=agg, lattice=lattice, out="device")
                 ptr = pts.device_pointers()
                 cols = [torch.as_tensor(td.DeviceColumn(ptr[f], pts.n_points), device=dev) for f in ("key_id", "flow_end_s", "value")]
-                if coll_dev is None and world > 1:
-                    cols = [c.cpu() for c in cols]                  # gloo test mode: host tensors
-                lk, lt, lv = td.exchange_points_torch(cols[0], cols[1], cols[2], world, rank)
+                # bucketed by owner on the GPU (tad_shard_rows), shipped with one all-to-all(v) per column
+                lk, lt, lv = td.exchange_rows_device(eng, cols[0], cols[1], cols[2], world, rank,
+                                                     host_collective=(coll_dev is None and world > 1))
                 pts.close()
-                lk, lt, lv = (c.to(dev) for c in (lk, lt, lv))
             else:
                 lk, lt, lv = key, tend, val
             for algo in algos:
@@ -212,6 +217,10 @@ def main():
                     if pending[0] is not None:
                         glob = pending[0].result()
                     pending[0] = nxt
+                if dump.get("on"):
+                    h = res.to_host()
+                    dump[algo] = {f: (h[f] * np.uint64(world) + np.uint64(rank) if f == "key_id" else h[f]).copy()
+                                  for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev")}
                 res.close()
                 stats.append(st)
             return stats, glob
@@ -248,6 +257,12 @@ def main():
             dt = float(tt.item())
         else:
             glob = td.JobReducer().reduce(stats[-1])
+        if args.dump_rows:
+            dump["on"] = True
+            step()
+            if world > 1:
+                drain()
+            np.savez(args.dump_rows + ".rank%d.npz" % rank, **{"%s_%s" % (a, f): v for a in algos for f, v in dump[a].items()})
         del key, tend, val
         return dict(dt=dt, stats=stats, acc=acc, glob=glob, steps=steps, warmup=warmup, n=n, K=K, T=T, agg=agg, algos=algos)
 

@@ -239,6 +239,24 @@ func (e *Engine) Aggregate(job Job, cols Columns) ([]Point, error) {
 	return out, nil
 }
 
+// ShardRows buckets device-resident rows by the owner of their key (owner = key mod world, local id = key / world) for
+// the all-to-all(v) of row-sharded multi-GPU ingest (tad_shard_rows).  key, flowEnd, value and the three outputs are
+// DEVICE pointers to n 8-byte elements each (AllocDevice); the returned counts are the rows per destination rank.
+func (e *Engine) ShardRows(key, flowEnd, value unsafe.Pointer, n uint64, world uint32, outKey, outFlowEnd, outValue unsafe.Pointer) ([]uint64, error) {
+	var cc C.tad_columns
+	cc.n_rows = C.uint64_t(n)
+	cc.memory = C.TAD_MEM_DEVICE
+	cc.key_id = (*C.uint64_t)(key)
+	cc.flow_end_s = (*C.int64_t)(flowEnd)
+	cc.value = (*C.uint64_t)(value)
+	counts := make([]uint64, world)
+	if rc := C.tad_shard_rows(e.h, &cc, C.uint32_t(world), (*C.uint64_t)(outKey), (*C.int64_t)(outFlowEnd), (*C.uint64_t)(outValue),
+		(*C.uint64_t)(unsafe.Pointer(&counts[0]))); rc != C.TAD_OK {
+		return nil, fmt.Errorf("tad_shard_rows: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return counts, nil
+}
+
 // Progress feeds Status.CompletedStages / TotalStages (controller.go:426-453).
 func (e *Engine) Progress() (done, total int) {
 	var d, t C.int32_t

@@ -183,6 +183,17 @@ typedef struct {
 int tad_aggregate(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_points **out);
 void tad_points_free(tad_engine *e, tad_points *p);
 
+/* ---- row-sharded ingest: bucket rows by the owner of their key for ONE all-to-all(v) ----
+ * The reference has no such call: Spark's shuffle (anomaly_detection.py:664-684, groupby(key)) plays this role.  With G
+ * GPUs, key k is owned by rank k mod G under the local id k / G.  tad_shard_rows writes the rows of `cols` grouped by
+ * destination rank — destination 0's rows first — with LOCAL key ids, into three DEVICE arrays of cols->n_rows elements
+ * each, and the rows per destination into counts[world] (HOST): the send splits of the all-to-all(v).  Rows whose key is
+ * TAD_KEY_SKIP are dropped.  cols->memory must be TAD_MEM_DEVICE; key_id2 / flow_start_s must be NULL (pre-aggregate pod-mode
+ * tables with tad_aggregate first: its points have one key).  The order of rows inside a destination is unspecified
+ * (Stage 0 aggregates with commutative operators).  1 <= world <= 1024. */
+int tad_shard_rows(tad_engine *e, const tad_columns *cols, uint32_t world, uint64_t *out_key_id, int64_t *out_flow_end_s,
+                   uint64_t *out_value, uint64_t *counts);
+
 /* ---- streaming EWMA: per-key running state kept in HBM between batches ----
  * The batch job re-reads the whole window and judges every point against the stddev_samp of the WHOLE series
  * (anomaly_detection.py:664-684, 168-212).  A long-running detector appends: tad_state holds, per key, Spark's streaming

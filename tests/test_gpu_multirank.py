@@ -1,0 +1,88 @@
+"""GPU: the N>1 code path of bench.py on ONE GPU (ranks share the device, collectives over gloo on host tensors).
+
+BASELINE.json configs[4] (C5: EWMA then ARIMA on a table split over the ranks) at a reduced size: the row-sharded
+variant — every rank starts from an arbitrary slice of the rows, pre-aggregates it (tad_aggregate), buckets the partial
+points by owner on the GPU (tad_shard_rows) and ships them with the all-to-all(v) — must produce, over 2 ranks, exactly
+the anomaly rows of the 1-rank run on the whole table: every column of every row, bit for bit, for both detectors."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import tad_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_bench(world, rows, keys, dump, extra=()):
+    env = dict(os.environ, TAD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    common = ["--config", "c5", "--rows", str(rows // world), "--keys", str(keys // world), "--buckets", "60", "--steps", "1", "--warmup", "0",
+              "--no-cpu-baseline", "--dump-rows", dump] + list(extra)
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + common
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT).stdout
+    return json.loads(out.strip().splitlines()[-1])
+
+
+def merged_rows(dump, world, algo):
+    parts = [np.load(dump + ".rank%d.npz" % r) for r in range(world)]
+    cols = {f: np.concatenate([p["%s_%s" % (algo, f)] for p in parts]) for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev")}
+    order = np.lexsort((cols["flow_end_s"], cols["key_id"]))
+    return {f: v[order] for f, v in cols.items()}
+
+
+def test_c5_row_sharded_two_ranks_equal_one_rank(tmp_path):
+    rows, keys = 600_000, 600
+    one = run_bench(1, rows, keys, str(tmp_path / "w1"), ["--ingest", "rows"])
+    two = run_bench(2, rows, keys, str(tmp_path / "w2"), ["--ingest", "rows"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["algo"] == "EWMA+ARIMA" and "row-sharded x2" in two["config"]["parallelism"]
+    for f in ("anomalies", "keys", "points"):
+        assert one["result"][f] == two["result"][f], f
+    for algo in ("EWMA", "ARIMA"):
+        a, b = merged_rows(str(tmp_path / "w1"), 1, algo), merged_rows(str(tmp_path / "w2"), 2, algo)
+        assert a["key_id"].size == b["key_id"].size > 0
+        for f in a:
+            assert np.array_equal(a[f], b[f], equal_nan=True), (algo, f)
+    # and the 1-rank EWMA rows are the oracle's rows on the whole table
+    k, t, v = orc.synth_rows(0, rows, keys, 60)
+    want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+    a = merged_rows(str(tmp_path / "w1"), 1, "EWMA")
+    assert (a["key_id"] == want["key_id"]).all() and (a["flow_end_s"] == want["flow_end_s"]).all() and (a["algo_calc"] == want["algo_calc"]).all()
+
+
+def test_shard_rows_buckets_by_owner(engine):
+    import torch
+    k, t, v = orc.synth_rows(5, 300_000, 5000, 40)
+    k[::97] = orc.KEY_SKIP
+    dev = torch.device("cuda", engine.device)
+    tk, tt, tv = (torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x).to(dev) for x in (k, t, v))
+    for world in (1, 3, 8):
+        (dk, dt, dv), counts = engine.shard_rows(tk, tt, tv, world)
+        hk, ht, hv = dk.to_host(), dt.to_host(), dv.to_host()
+        live = k != orc.KEY_SKIP
+        assert sum(counts) == int(live.sum())
+        pos = 0
+        for d in range(world):
+            sel = live & (k % np.uint64(world) == d)
+            assert counts[d] == int(sel.sum())
+            got = np.stack([hk[pos:pos + counts[d]].astype(np.int64), ht[pos:pos + counts[d]], hv[pos:pos + counts[d]].astype(np.int64)], axis=1)
+            want = np.stack([(k[sel] // np.uint64(world)).astype(np.int64), t[sel], v[sel].astype(np.int64)], axis=1)
+            assert (got[np.lexsort(got.T[::-1])] == want[np.lexsort(want.T[::-1])]).all(), (world, d)     # same multiset of rows
+            pos += counts[d]
+        for a in (dk, dt, dv):
+            a.free()

@@ -68,6 +68,7 @@ SYMBOLS = {
     "tad_run_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Result))]),
     "tad_aggregate": (C.c_int, [C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Points))]),
     "tad_points_free": (None, [C.c_void_p, C.POINTER(Points)]),
+    "tad_shard_rows": (C.c_int, [C.c_void_p, C.POINTER(Columns), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tad_progress": (C.c_int, [C.c_void_p, C.POINTER(i32), C.POINTER(i32)]),
     "tad_series_ewma": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_void_p]),
     "tad_series_ewma_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, f64, C.c_void_p]),

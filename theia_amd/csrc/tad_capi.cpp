@@ -902,6 +902,36 @@ int tad_aggregate(tad_engine *e, const tad_job *job, const tad_columns *cols, ta
   return run_job(e, job, cols, out_memory, nullptr, out);
 }
 
+int tad_shard_rows(tad_engine *e, const tad_columns *cols, uint32_t world, uint64_t *out_key_id, int64_t *out_flow_end_s,
+                   uint64_t *out_value, uint64_t *counts) {
+  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: engine is NULL");
+  if (!cols || !counts || !shard_world_ok(world)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: bad arguments (1 <= world <= 1024)");
+  if (cols->memory != TAD_MEM_DEVICE || cols->key_id2 || cols->flow_start_s)
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: device columns with one key per row only");
+  const uint64_t n = cols->n_rows;
+  if (n && (!cols->key_id || !cols->flow_end_s || !cols->value || !out_key_id || !out_flow_end_s || !out_value))
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: key_id, flow_end_s, value and the three outputs are required");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  int rc;
+  if ((rc = ensure(e, e->scan_scratch, (size_t)world * 16)) != TAD_OK) return rc;
+  unsigned long long *d_counts = static_cast<unsigned long long *>(e->scan_scratch.p);
+  unsigned long long *d_cursor = d_counts + world;
+  HIP_TRY(e, hipMemsetAsync(d_counts, 0, (size_t)world * 8, s));
+  launch_shard_count(s, cols->key_id, n, world, d_counts);
+  std::vector<unsigned long long> h(world), off(world);
+  HIP_TRY(e, hipMemcpyAsync(h.data(), d_counts, (size_t)world * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  unsigned long long run = 0;
+  for (uint32_t d = 0; d < world; ++d) { off[d] = run; run += h[d]; counts[d] = h[d]; }
+  HIP_TRY(e, hipMemcpyAsync(d_cursor, off.data(), (size_t)world * 8, hipMemcpyHostToDevice, s));
+  launch_shard_scatter(s, cols->key_id, cols->flow_end_s, cols->value, n, world, d_cursor, out_key_id, out_flow_end_s, out_value);
+  HIP_TRY(e, hipStreamSynchronize(s));   // `off` goes out of scope; the caller may hand the buffers to a collective on another stream
+  HIP_TRY(e, hipGetLastError());
+  return TAD_OK;
+}
+
 void tad_points_free(tad_engine *e, tad_points *p) {
   if (!p) return;
   PointsPriv *pp = reinterpret_cast<PointsPriv *>(p);

@@ -232,6 +232,12 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
                            const unsigned long long *ovf_count, uint32_t ovf_cap);
 
+// ---- row-sharded ingest: bucket rows by owner = key mod world (tad_shard.hip) ----
+bool shard_world_ok(uint32_t world);
+void launch_shard_count(hipStream_t s, const uint64_t *key, uint64_t n, uint32_t world, unsigned long long *counts);
+void launch_shard_scatter(hipStream_t s, const uint64_t *key, const int64_t *t_end, const uint64_t *value, uint64_t n, uint32_t world,
+                          unsigned long long *cursor, uint64_t *out_key, int64_t *out_t, uint64_t *out_val);
+
 void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                   uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,
                   uint64_t *value);

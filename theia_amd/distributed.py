@@ -218,6 +218,44 @@ def exchange_points_torch(key, flow_end_s, value, world, rank, group=None):
     return recv[:, 0].contiguous(), recv[:, 1].contiguous(), recv[:, 2].contiguous()
 
 
+def exchange_rows_device(engine, key, flow_end_s, value, world, rank, group=None, host_collective=False):
+    """Row-sharded ingest with everything resident in HBM: the engine buckets this rank's rows (or partial points) by
+    owner on the GPU (tad_shard_rows: LDS histogram per workgroup, one reservation per destination, local key ids), the
+    per-destination counts travel first, then the three columns move with one all-to-all(v) each (RCCL over xGMI; the
+    send buffers are the engine's device arrays, viewed zero-copy).  Returns int64 CUDA tensors (local key, time, value
+    bit pattern) of the rows this rank owns.  host_collective=True routes the collectives through host tensors (gloo,
+    for running N ranks on fewer GPUs in tests)."""
+    import torch
+    import torch.distributed as dist
+    (dk, dt, dv), sc = engine.shard_rows(key, flow_end_s, value, world)
+    dev = key.device if hasattr(key, "device") else torch.device("cuda", engine.device)
+    cdev = "cpu" if host_collective else dev
+    send_counts = torch.tensor(sc, dtype=torch.int64, device=cdev)
+    recv_counts = torch.zeros_like(send_counts)
+    if world > 1:
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+    else:
+        recv_counts.copy_(send_counts)
+    rc = [int(c) for c in recv_counts.tolist()]
+    n_send, n_recv = sum(sc), sum(rc)
+    out = []
+    for arr in (dk, dt, dv):
+        send = torch.as_tensor(DeviceColumn(arr.ptr, max(arr.n, 1)), device=dev)[:n_send]
+        if host_collective:
+            send = send.cpu()
+        recv = torch.empty(n_recv, dtype=torch.int64, device=cdev)
+        if world > 1:
+            dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        else:
+            recv.copy_(send)
+        out.append(recv.to(dev))
+    if str(dev) != "cpu":
+        torch.cuda.synchronize(dev)      # the send buffers are freed below
+    for arr in (dk, dt, dv):
+        arr.free()
+    return tuple(out)
+
+
 class DeviceColumn:
     """Zero-copy torch view of an engine-owned device array (e.g. TadPoints.device_pointers()): torch.as_tensor accepts
     any object with __cuda_array_interface__ (ROCm builds of torch keep the CUDA name)."""

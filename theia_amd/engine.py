@@ -225,6 +225,7 @@ class TadEngine:
     def __init__(self, device=0, stream=None, workspace_limit=0):
         self._lib = capi.load_library()
         self._h = None
+        self.device = int(device)
         opts = capi.EngineOpts(device=int(device), stream=C.c_void_p(stream) if stream else None,
                                workspace_limit=int(workspace_limit))
         h = C.c_void_p()
@@ -316,6 +317,23 @@ class TadEngine:
         del keep1, keep2, keep3
         self._check(rc)
         return TadResult(self, res)
+
+    # ---- row-sharded ingest: bucket device rows by owner = key mod world (tad_shard_rows) ----
+    def shard_rows(self, key_id, flow_end_s, value, world):
+        """Device columns (torch CUDA tensors or DeviceArray) -> ((key_local, flow_end_s, value) DeviceArrays grouped by
+        destination rank, counts per destination): the payload and the send splits of the all-to-all(v)."""
+        pk, n, dev, keep1 = _as_column(key_id, np.uint64)
+        pt, nt, dev_t, keep2 = _as_column(flow_end_s, np.int64)
+        pv, nv, dev_v, keep3 = _as_column(value, np.uint64)
+        if nt != n or nv != n or not (dev and dev_t and dev_v):
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "shard_rows: three device columns of equal length")
+        outs = (DeviceArray(self, n, np.uint64), DeviceArray(self, n, np.int64), DeviceArray(self, n, np.uint64))
+        counts = np.zeros(int(world), dtype=np.uint64)
+        cols = capi.Columns(n_rows=n, key_id=pk, flow_end_s=pt, value=pv, num_keys=0, memory=capi.TAD_MEM_DEVICE)
+        rc = self._lib.tad_shard_rows(self._h, C.byref(cols), int(world), outs[0].ptr, outs[1].ptr, outs[2].ptr, counts.ctypes.data)
+        del keep1, keep2, keep3
+        self._check(rc)
+        return outs, [int(c) for c in counts]
 
     # ---- Stage 0 alone: the GROUP BY (anomaly_detection.py:507-614) ----
     def aggregate(self, key_id, flow_end_s, value, num_keys, agg_flow="", value_op="auto", key_id2=None, flow_start_s=None,
