@@ -46,6 +46,7 @@ struct tad_engine {
   DevBuf rcp_table;           // rcp_table[n] = RN(1/n), n = 0..rcp_n-1
   uint64_t rcp_n = 0;
   DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
+  DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
@@ -231,7 +232,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -601,21 +602,83 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     if (empty) { L = make_lattice(0, 1, 0); v2 = false; }
 
     // ---- Stage 0: GROUP BY (key, flowEndSeconds) into the time-major point grid ----
-    const uint64_t cells = empty ? 0 : K * L.nb;
-    if (!empty && L.nb != 0 && cells / L.nb != K) return fail(e, TAD_ERR_GRID_TOO_LARGE, "grid of %llu keys x %llu buckets overflows", (unsigned long long)K, (unsigned long long)L.nb);
-    const uint64_t need = cells * 9 + ((jp.algo == TAD_ALGO_ARIMA || jp.algo == TAD_ALGO_DROP) ? cells * 8 : 0);
-    if (need > e->ws_limit) {
+    uint64_t cells = empty ? 0 : K * L.nb;
+    const bool cells_overflow = !empty && L.nb != 0 && cells / L.nb != K;
+    uint64_t need = cells * 9 + ((jp.algo == TAD_ALGO_ARIMA || jp.algo == TAD_ALGO_DROP) ? cells * 8 : 0);
+    // Sparse tables (few points per key on a fine lattice: second-resolution timestamps, per-connection keys): the dense
+    // K x T grid would be mostly empty or not fit at all — sort the rows by (key, time) instead and lay each key's points
+    // out by rank (tad_sparse.hip).  Chosen when the rows could fill at most 1/8 of a large grid, or the grid does not fit.
+    const char *sp_env = getenv("TAD_SPARSE");
+    const uint64_t slots_all = n * (has2 ? 2 : 1);
+    bool sparse = !empty && !stream && K <= 0xFFFFFFFFull &&
+                  ((sp_env && atoi(sp_env) == 1) ||
+                   (!(sp_env && atoi(sp_env) == 0) && (cells_overflow || need > e->ws_limit || (cells >= (1ull << 24) && slots_all < cells / 8))));
+    Grid sparse_grid{};
+    if (sparse) {
+      v2 = false;
+      if ((rc = ensure(e, e->sp_comp_a, slots_all * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->sp_comp_b, slots_all * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->sp_val_a, slots_all * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->sp_val_b, slots_all * 8)) != TAD_OK) return rc;
+      const size_t tb = sparse_sort_temp_bytes(slots_all);
+      if ((rc = ensure(e, e->sp_temp, tb + 64)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->sp_first, K * 4 + 64)) != TAD_OK) return rc;
+      unsigned long long *d_runs = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->sp_temp.p) + tb);   // [0] runs, [1] tmax
+      HIP_TRY(e, hipMemsetAsync(d_runs, 0, 16, s));
+      HIP_TRY(e, hipEventRecord(e->ev[2], s));
+      unsigned long long *ucomp = static_cast<unsigned long long *>(e->sp_comp_a.p), *uval = static_cast<unsigned long long *>(e->sp_val_a.p);
+      if (launch_sparse_group(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
+                              rf, L.t0, op_max, ucomp, uval, static_cast<unsigned long long *>(e->sp_comp_b.p),
+                              static_cast<unsigned long long *>(e->sp_val_b.p), e->sp_temp.p, tb, d_runs, ctr) != 0)
+        return fail(e, TAD_ERR_HIP, "sparse Stage 0: sort / reduce failed");
+      unsigned long long runs = 0, last = 0;
+      HIP_TRY(e, hipMemcpyAsync(&runs, d_runs, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipStreamSynchronize(s));
+      if (runs) {
+        HIP_TRY(e, hipMemcpyAsync(&last, ucomp + (runs - 1), 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+      }
+      const uint64_t P = runs - ((runs && last == ~0ull) ? 1 : 0);    // the filtered-out slots form the last run
+      unsigned int tmax = 0;
+      if (P) {
+        launch_sparse_tmax(s, ucomp, P, static_cast<uint32_t *>(e->sp_first.p), reinterpret_cast<unsigned int *>(d_runs + 1));
+        HIP_TRY(e, hipMemcpyAsync(&tmax, d_runs + 1, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+      }
+      cells = K * (uint64_t)tmax;
+      need = cells * 17 + ((jp.algo == TAD_ALGO_ARIMA || jp.algo == TAD_ALGO_DROP) ? cells * 8 : 0);
+      if (need > e->ws_limit)
+        return fail(e, TAD_ERR_GRID_TOO_LARGE, "sparse point grid needs %llu bytes (%llu keys x longest series %u points) > workspace limit %llu",
+                    (unsigned long long)need, (unsigned long long)K, tmax, (unsigned long long)e->ws_limit);
+      if ((rc = ensure(e, e->grid_val, (cells ? cells : 1) * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->grid_flag, cells ? cells : 1)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->sp_times, (cells ? cells : 1) * 8)) != TAD_OK) return rc;
+      sparse_grid = Grid{static_cast<unsigned long long *>(e->grid_val.p), static_cast<uint8_t *>(e->grid_flag.p), tmax ? K : 0, tmax,
+                         static_cast<const long long *>(e->sp_times.p)};
+      if (cells) {
+        HIP_TRY(e, hipMemsetAsync(sparse_grid.flag, 0, cells, s));
+        launch_sparse_place(s, ucomp, uval, P, static_cast<const uint32_t *>(e->sp_first.p), L.t0, sparse_grid, static_cast<long long *>(e->sp_times.p));
+      }
+      HIP_TRY(e, hipEventRecord(e->ev[3], s));
+    }
+    if (!sparse && cells_overflow) return fail(e, TAD_ERR_GRID_TOO_LARGE, "grid of %llu keys x %llu buckets overflows", (unsigned long long)K, (unsigned long long)L.nb);
+    if (!sparse && need > e->ws_limit) {
       if (lat_mode == 1 && v2) { lat_mode = 2; continue; }  // a too-fine sampled step cannot happen (it is a multiple of the true one); be safe
       return fail(e, TAD_ERR_GRID_TOO_LARGE,
                   "dense point grid needs %llu bytes (%llu keys x %llu time buckets, step %lld s) > workspace limit %llu",
                   (unsigned long long)need, (unsigned long long)K, (unsigned long long)L.nb, (long long)L.step, (unsigned long long)e->ws_limit);
     }
-    if ((rc = ensure(e, e->grid_val, cells * 8)) != TAD_OK) return rc;
-    if ((rc = ensure(e, e->grid_flag, cells)) != TAD_OK) return rc;
-    Grid g{static_cast<unsigned long long *>(e->grid_val.p), static_cast<uint8_t *>(e->grid_flag.p), empty ? 0 : K, L.nb};
+    if (!sparse) {
+      if ((rc = ensure(e, e->grid_val, cells * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->grid_flag, cells)) != TAD_OK) return rc;
+    }
+    Grid g{static_cast<unsigned long long *>(e->grid_val.p), static_cast<uint8_t *>(e->grid_flag.p), empty ? 0 : K, L.nb, nullptr};
+    if (sparse) g = sparse_grid;
     if (v2 && !part_plan_tiles(K, L.nb, has2, &pl)) v2 = false;  // tile does not fit LDS: direct scatter
     bool stats_done = false;
-    if (v2) {
+    if (sparse) {
+      // the rank grid is already filled
+    } else if (v2) {
       part_plan_wc(n * (has2 ? 2 : 1), columns_aligned16(d_key, d_key2, d_te, d_val), has2, &pl);
       const uint64_t slots = n * (has2 ? 2 : 1) + pl.pad_slots;
       if ((rc = ensure(e, e->part_total, (size_t)pl.nparts * 4)) != TAD_OK) return rc;
@@ -756,7 +819,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
       hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
       hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
-      st.stage0_path = v2 ? (pl.wc_cap ? 3 : 2) : 1;
+      st.stage0_path = sparse ? 4 : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
       e->done.store(4);
       *points_out = &pp->pub;
       return TAD_OK;
@@ -828,7 +891,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     hipEventElapsedTime(&st.ms_stage0, e->ev[1], e->ev[5]);
     hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
     hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
-    st.stage0_path = v2 ? (pl.wc_cap ? 3 : 2) : 1;
+    st.stage0_path = sparse ? 4 : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)

@@ -25,6 +25,8 @@ struct Grid {
   uint8_t *flag;            // bit0: point present, bit1: anomaly verdict (DBSCAN / ARIMA detectors)
   uint64_t K;               // keys
   uint64_t T;               // buckets
+  const long long *times;   // NULL: cell (b, k) is at t0 + b * step (lattice); else the sparse path's RANK grid (tad_sparse.hip):
+                            // row b holds every key's b-th point in time order and times[b * K + k] its flowEndSeconds
 };
 
 enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u, DEV_ERR_LATE_ROW = 8u };
@@ -231,6 +233,16 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl);
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
                            const unsigned long long *ovf_count, uint32_t ovf_cap);
+
+// ---- Stage 0 for sparse tables: sort by (key, time), reduce, rank grid (tad_sparse.hip) ----
+size_t sparse_sort_temp_bytes(uint64_t slots);
+int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end, const int64_t *t_start,
+                        const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, int64_t t0, bool op_max, unsigned long long *comp_a,
+                        unsigned long long *val_a, unsigned long long *comp_b, unsigned long long *val_b, void *temp, size_t temp_bytes,
+                        unsigned long long *num_runs, DevCounters *ctr);
+void launch_sparse_tmax(hipStream_t s, const unsigned long long *ucomp, uint64_t P, uint32_t *first, unsigned int *tmax);
+void launch_sparse_place(hipStream_t s, const unsigned long long *ucomp, const unsigned long long *uval, uint64_t P, const uint32_t *first,
+                         int64_t t0, Grid g, long long *times);
 
 // ---- row-sharded ingest: bucket rows by owner = key mod world (tad_shard.hip) ----
 bool shard_world_ok(uint32_t world);

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
       verdict = (fl & FLAG_ANOMALY) != 0;
     }
     if ((ALL || verdict) && pos + nb < end) {
-      const long long ts = (long long)(L.t0 + (int64_t)t * L.step);
+      const long long ts = g.times != nullptr ? g.times[t * g.K + k] : (long long)(L.t0 + (int64_t)t * L.step);
       if (nb == 0 && (pos & 3ull) != 0) {  // head of the key's segment: single rows up to the next 4-row boundary
         write_row(pos, ts, x, a, verdict);
         pos++;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_points(Grid g, Lattice L, const
   auto step = [&](uint64_t t, uint8_t fl, unsigned long long raw) {
     if ((fl & FLAG_PRESENT) && pos < end) {
       out_key[pos] = k;
-      out_t[pos] = (long long)(L.t0 + (int64_t)t * L.step);
+      out_t[pos] = g.times != nullptr ? g.times[t * g.K + k] : (long long)(L.t0 + (int64_t)t * L.step);
       out_val[pos] = raw;
       pos++;
     }
