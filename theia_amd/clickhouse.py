@@ -48,35 +48,47 @@ class ClickHouseHTTP:
         self.password = password if password is not None else os.getenv("CH_PASSWORD")
         self.timeout = timeout
 
-    def _post(self, params, body):
+    def _request(self, params, body):
         req = urllib.request.Request(self.base + "/?" + urllib.parse.urlencode(params), data=body, method="POST")
         if self.user:
             token = base64.b64encode(("%s:%s" % (self.user, self.password or "")).encode()).decode()
             req.add_header("Authorization", "Basic " + token)
-        with urllib.request.urlopen(req, timeout=self.timeout) as resp:
+        return urllib.request.urlopen(req, timeout=self.timeout)
+
+    def _post(self, params, body):
+        with self._request(params, body) as resp:
             return resp.read()
 
     def query_columns(self, sql):
-        """Run a SELECT, return {column name: numpy array}.  DateTime -> int64 epoch seconds, String -> str."""
+        """Run a SELECT, return {column name: numpy array}.  DateTime -> int64 epoch seconds, String -> str.
+        The ArrowStream response is consumed record batch by record batch straight from the socket (the raw-rows read of
+        a large `flows` table is tens of GB: no whole-response buffer), strings are decoded through Arrow's dictionary
+        encoding (one Python object per DISTINCT value per batch, not per row)."""
         import pyarrow as pa
+        import pyarrow.compute as pc
         import pyarrow.ipc as ipc
-        raw = self._post({"output_format_arrow_string_as_string": 1}, (sql.rstrip() + " FORMAT ArrowStream").encode())
-        if not raw:
-            return {}
-        table = ipc.open_stream(io.BytesIO(raw)).read_all()
-        out = {}
-        for name in table.column_names:
-            col = table.column(name)
-            t = col.type
-            if pa.types.is_timestamp(t):
-                out[name] = col.cast(pa.timestamp("s")).cast(pa.int64()).to_numpy()
-            elif pa.types.is_binary(t) or pa.types.is_large_binary(t):
-                out[name] = np.asarray([b.decode() if b is not None else "" for b in col.to_pylist()], dtype=object).astype(str)
-            elif pa.types.is_string(t) or pa.types.is_large_string(t):
-                out[name] = np.asarray(col.to_pylist(), dtype=object).astype(str)
-            else:
-                out[name] = col.to_numpy(zero_copy_only=False)
-        return out
+        parts = {}
+        with self._request({"output_format_arrow_string_as_string": 1}, (sql.rstrip() + " FORMAT ArrowStream").encode()) as resp:
+            try:
+                reader = ipc.open_stream(resp)
+            except pa.ArrowInvalid:        # empty body: a result without rows carries no schema
+                return {}
+            for batch in reader:
+                for name, col in zip(batch.schema.names, batch.columns):
+                    t = col.type
+                    if pa.types.is_timestamp(t):
+                        arr = col.cast(pa.timestamp("s")).cast(pa.int64()).to_numpy(zero_copy_only=False)
+                    elif pa.types.is_binary(t) or pa.types.is_large_binary(t) or pa.types.is_string(t) or pa.types.is_large_string(t):
+                        if pa.types.is_binary(t) or pa.types.is_large_binary(t):
+                            col = col.cast(pa.string())
+                        d = pc.dictionary_encode(col.fill_null(""))
+                        values = np.asarray(d.dictionary.to_pylist(), dtype=object).astype(str)
+                        idx = d.indices.to_numpy(zero_copy_only=False)
+                        arr = values[idx] if values.size else np.zeros(0, dtype=str)
+                    else:
+                        arr = col.to_numpy(zero_copy_only=False)
+                    parts.setdefault(name, []).append(arr)
+        return {name: (np.concatenate(v) if len(v) > 1 else v[0]) for name, v in parts.items()}
 
     def insert_rows(self, rows, table=RESULT_TABLE):
         """Append dict rows (INSERT ... FORMAT JSONEachRow); columns a row lacks take the table defaults."""
@@ -98,12 +110,18 @@ class ClickHouseHTTP:
         arrays = {}
         for name, v in columns.items():
             v = np.asarray(v)
-            if name in ("flowEndSeconds", "flowStartSeconds") and v.dtype.kind in "iu":
+            kind = TADETECTOR_COLUMNS.get(name)          # explicit per-column types: nothing is narrowed by dtype guesswork
+            if kind is None:
+                raise ValueError("insert_columns: %r is not a column of %s (create_table.sh:363-384)" % (name, RESULT_TABLE))
+            if kind == "datetime":
                 arrays[name] = pa.array(v.astype(np.uint32), pa.uint32())
-            elif v.dtype.kind == "f":
+            elif kind == "f64":
                 arrays[name] = pa.array(v.astype(np.float64), pa.float64())
-            elif v.dtype.kind in "iu":
-                arrays[name] = pa.array(v.astype(np.uint16), pa.uint16())     # ports / protocolIdentifier (create_table.sh:364-368)
+            elif kind in ("u16", "u8"):
+                lim = 65535 if kind == "u16" else 255
+                if v.size and (v.astype(np.int64).min() < 0 or v.astype(np.int64).max() > lim):
+                    raise ValueError("insert_columns: %s out of range for %s" % (name, kind))
+                arrays[name] = pa.array(v.astype(np.uint16 if kind == "u16" else np.uint8), pa.uint16() if kind == "u16" else pa.uint8())
             else:
                 arrays[name] = pa.array([str(x) for x in v.tolist()], pa.string())
         table_ = pa.table(arrays)
@@ -114,6 +132,14 @@ class ClickHouseHTTP:
         self._post({"query": "INSERT INTO %s (%s) FORMAT ArrowStream" % (table, cols)}, sink.getvalue())
         return n
 
+
+# default.tadetector (create_table.sh:363-384): column -> wire type of the ArrowStream insert
+TADETECTOR_COLUMNS = {
+    "sourceIP": "str", "sourceTransportPort": "u16", "destinationIP": "str", "destinationTransportPort": "u16",
+    "protocolIdentifier": "u16", "flowStartSeconds": "datetime", "podNamespace": "str", "podLabels": "str", "podName": "str",
+    "destinationServicePortName": "str", "direction": "str", "flowEndSeconds": "datetime", "throughputStandardDeviation": "f64",
+    "aggType": "str", "algoType": "str", "algoCalc": "f64", "throughput": "f64", "anomaly": "str", "id": "str",
+}
 
 # raw columns each mode needs (create_table.sh:31-85)
 _RAW_COLUMNS = {

@@ -4,6 +4,7 @@ Reference: /root/reference/snowflake/udfs/udfs/drop_detection/drop_detection_udf
 partitioned by (endpoint, direction): `process` collects (date, drop_number) pairs (ref:25-40), `end_partition` yields one
 row per anomalous day (ref:42-56).  Same class and method names here; `end_partition` calls tad_series_drop through the C
 ABI, `drop_detection_table` runs every partition of an aggregated table in ONE tad_run (algo DROP).  No CPU fallback.
+Only the UDTF's call protocol is mirrored (a thin adaptor); the reference's Result helper class is not reproduced.
 """
 import datetime
 import uuid
@@ -13,47 +14,39 @@ import numpy as np
 from . import anomaly_detection as _ad
 
 
-class Result:   # ref:6-19
-    def __init__(self, job_type, detection_id, endpoint, direction, avg_drop, stdev_drop, anomaly_drop_date, anomaly_drop_number):
-        self.job_type = job_type
-        self.detection_id = detection_id if detection_id else str(uuid.uuid4())
-        self.time_created = datetime.datetime.now()
-        self.endpoint = endpoint
-        self.direction = direction
-        self.avg_drop = avg_drop
-        self.stdev_drop = stdev_drop
-        self.anomaly_drop_date = anomaly_drop_date
-        self.anomaly_drop_number = anomaly_drop_number
+RESULT_COLUMNS = ("job_type", "detection_id", "time_created", "endpoint", "direction", "avg_drop", "stdev_drop",
+                  "anomaly_drop_date", "anomaly_drop_number")      # the UDTF's output row (ref:6-19, 55-56)
 
 
 class DropDetection:
-    def __init__(self, engine=None):
-        self._date_dropnumber_pairs = []
-        self._engine = engine
+    """Thin adaptor with the UDTF's call protocol (ref:21-56: one instance per (endpoint, direction) partition,
+    `process` once per row, `end_partition` yields the anomalous days as RESULT_COLUMNS tuples).  The partition's
+    statistics and verdicts come from the engine (tad_series_drop); nothing is computed here."""
 
-    def process(self, job_type, detection_id, endpoint, direction, date, drop_number):   # ref:25-40
-        assert job_type == "initial"
-        self._job_type = job_type
-        self._detection_id = detection_id
-        self._endpoint = endpoint
-        self._direction = direction
-        self._date_dropnumber_pairs.append((date, drop_number))
+    def __init__(self, engine=None):
+        self._engine = engine
+        self._partition = None            # (job_type, detection_id, endpoint, direction), constant within a partition
+        self._dates, self._drops = [], []
+
+    def process(self, job_type, detection_id, endpoint, direction, date, drop_number):
+        if job_type != "initial":         # ref:33
+            raise AssertionError("drop detection supports job_type 'initial' only")
+        self._partition = (job_type, detection_id, endpoint, direction)
+        self._dates.append(date)
+        self._drops.append(int(drop_number))
         yield None
 
-    def end_partition(self):   # ref:42-56
-        pairs = self._date_dropnumber_pairs
-        if len(pairs) < 3:
+    def end_partition(self):
+        if len(self._drops) < 3:          # ref:44-45
             return
-        eng = self._engine or _ad.get_engine()
-        out = eng.series_drop([int(n) for _, n in pairs])
+        out = (self._engine or _ad.get_engine()).series_drop(self._drops)
         if out is None:
             return
         mean, std, verdict = out
-        for (date, drop_number), bad in zip(pairs, verdict.tolist()):
-            if bad:
-                row = Result(self._job_type, self._detection_id, self._endpoint, self._direction, mean, std, date, drop_number)
-                yield (row.job_type, row.detection_id, row.time_created, row.endpoint, row.direction, row.avg_drop,
-                       row.stdev_drop, row.anomaly_drop_date, row.anomaly_drop_number)
+        job_type, detection_id, endpoint, direction = self._partition
+        head = (job_type, detection_id or str(uuid.uuid4()))
+        for i in np.flatnonzero(verdict):
+            yield head + (datetime.datetime.now(), endpoint, direction, mean, std, self._dates[i], self._drops[i])
 
 
 def drop_detection_table(endpoint, direction, date, drop_number, detection_id=None, job_type="initial", engine=None):
