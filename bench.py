@@ -50,7 +50,8 @@ CONFIGS = {   # BASELINE.json configs[1..4]
     "c5": dict(algos=("EWMA", "ARIMA"), rows=1_000_000_000, keys=1_000_000, buckets=250, agg="svc"),   # totals, split over the ranks
 }
 STAGE0_KERNEL = {2: "k_partition (Stage-0 v2, row partition pass, sort-by-tile)",
-                 3: "k_partition_wc (Stage-0 v2, row partition pass, write-combining)"}
+                 3: "k_partition_wc (Stage-0 v2, row partition pass, write-combining)",
+                 5: "k_partition_wc (Stage-0 v2 two-level, level-1 row partition pass, write-combining)"}
 
 
 def cpu_baseline(algo, rows, keys, buckets, agg, single_rows=0):

@@ -134,7 +134,8 @@ typedef struct {
   float ms_detect;         /* per-key sigma + detector + compaction */
   float ms_total;          /* device time of the whole run, HIP events on the engine stream */
   int32_t stage0_path;     /* 1 = direct atomic scatter, 2 = partition (sort-by-tile pass B) + LDS tiles, 3 = partition (write-combining pass B) + LDS tiles,
-                              4 = sparse table: sort by (key, time) + rank grid (time proportional to the rows, not to keys x lattice) */
+                              4 = sparse table: sort by (key, time) + rank grid (time proportional to the rows, not to keys x lattice),
+                              5 = two-level partition (many keys: wide blocks through the write-combining pass, split again, single-round LDS tiles) */
 } tad_stats;
 
 /* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).

@@ -204,8 +204,35 @@ def test_job_wide_grids_take_several_rounds_per_partition(engine, stage0, n_rows
     # grids whose KP x T block does not fit one LDS tile (many buckets) or that would need more than 2048 partitions
     # (many keys): Stage-0 v2 widens the key block and walks the partition's records in several bucket rounds
     k, t, v = orc.synth_rows(0, n_rows, K, T)
-    res, want = check_job(engine, "EWMA", k, t, v, K, agg_flow="svc")
+    os.environ["TAD_SPARSE"] = "0"      # these thinly filled grids would otherwise take the sparse path (tests/test_gpu_sparse.py)
+    try:
+        res, want = check_job(engine, "EWMA", k, t, v, K, agg_flow="svc")
+    finally:
+        del os.environ["TAD_SPARSE"]
     assert res.stats["stage0_path"] in ((1,) if stage0 == "v1" else (2,) if stage0 == "v2" else (2, 3))   # wc needs >= 9 queue slots per partition in LDS
+
+
+@pytest.mark.parametrize("agg,hot", [("svc", False), ("", False), ("svc", True)])
+def test_job_two_level_partition_for_many_keys(engine, stage0, agg, hot):
+    # 250 000 keys x 100 buckets: a single-round LDS tile is 128 keys wide = 1954 partitions, too many for pass B's queues.
+    # The plan then partitions by 2048-key blocks (write-combining pass, whole lines), splits every block 16 ways by key
+    # sub-range (k_repartition) and aggregates single-round tiles.  With values beyond the packed-record range (overflow
+    # list -> empty slots in the level-2 regions) and, in one case, a key carrying a third of the rows (sliced partitions).
+    rng = np.random.default_rng(23)
+    k, t, v = orc.synth_rows(0, 4_400_000, 250_000, 100)
+    v = np.where(rng.random(v.size) < 0.002, rng.integers(2**50, 2**64 - 1, size=v.size, dtype=np.uint64), v)
+    if hot:
+        k = np.where(rng.random(k.size) < 0.33, np.uint64(123_457), k)
+    os.environ["TAD_TWO_LEVEL"] = "1"                      # opt-in plan (measured: no faster than the single-level plan at C4)
+    try:
+        res, want = check_job(engine, "EWMA", k, t, v, 250_000, agg_flow=agg)
+        path = {"v1": 1, "v2": 2, "v2wc": 5}[stage0]       # (the forced sort-by-tile pass B keeps the single-level plan)
+        assert res.stats["stage0_path"] == path
+        pts = engine.aggregate(k, t, v, 250_000, agg_flow=agg)
+        pk, pt, pv = want["points"]
+        assert pts.stats["stage0_path"] == path and (pts["key_id"] == pk).all() and (pts["flow_end_s"] == pt).all() and (pts["value"] == pv).all()
+    finally:
+        del os.environ["TAD_TWO_LEVEL"]
 
 
 @pytest.mark.parametrize("agg", ["svc", ""])

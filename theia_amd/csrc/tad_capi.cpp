@@ -47,6 +47,7 @@ struct tad_engine {
   uint64_t rcp_n = 0;
   DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
+  DevBuf part2_total, part2_start, part2_offs32, part2_cursor, recs2;             // Stage 0 v2, two-level partition
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
@@ -232,7 +233,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -675,9 +676,43 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     Grid g{static_cast<unsigned long long *>(e->grid_val.p), static_cast<uint8_t *>(e->grid_flag.p), empty ? 0 : K, L.nb, nullptr};
     if (sparse) g = sparse_grid;
     if (v2 && !part_plan_tiles(K, L.nb, has2, &pl)) v2 = false;  // tile does not fit LDS: direct scatter
-    bool stats_done = false;
+    bool stats_done = false, two_level = false;
+    PartPlan pl1{}, pl2{};
     if (sparse) {
       // the rank grid is already filled
+    } else if (v2 && part_plan_two_level(K, L.nb, has2, columns_aligned16(d_key, d_key2, d_te, d_val), n * (has2 ? 2 : 1), pl, &pl1, &pl2)) {
+      // many keys: wide level-1 blocks through the write-combining pass B, split again by key sub-range, single-round pass C
+      two_level = true;
+      const uint64_t slots = n * (has2 ? 2 : 1) + pl1.pad_slots;
+      if ((rc = ensure(e, e->part_total, (size_t)pl1.nparts * 4)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->part_start, ((size_t)pl1.nparts + 1) * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->part_offs32, (size_t)pl1.G * pl1.nparts * 4)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->part2_total, (size_t)pl2.nparts * 4)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->part2_start, ((size_t)pl2.nparts + 1) * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->part2_offs32, (size_t)pl2.G * pl2.nparts * 4)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->part2_cursor, (size_t)pl2.nparts * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->recs2, (size_t)slots * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->ovf, 16 + (size_t)kOverflowCap * sizeof(OverflowRec))) != TAD_OK) return rc;
+      unsigned long long *ovf_count = static_cast<unsigned long long *>(e->ovf.p);
+      OverflowRec *ovf = reinterpret_cast<OverflowRec *>(static_cast<unsigned char *>(e->ovf.p) + 16);
+      HIP_TRY(e, hipMemsetAsync(ovf_count, 0, 8, s));
+      if ((rc = ensure_key_buffers(e, K)) != TAD_OK) return rc;
+      if ((rc = ensure_rcp_table(e, L.nb)) != TAD_OK) return rc;
+      uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
+      unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
+      unsigned long long *part_start2 = static_cast<unsigned long long *>(e->part2_start.p);
+      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl1, offs32, static_cast<uint32_t *>(e->part_total.p), part_start);
+      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl2, static_cast<uint32_t *>(e->part2_offs32.p),
+                          static_cast<uint32_t *>(e->part2_total.p), part_start2);
+      HIP_TRY(e, hipEventRecord(e->ev[2], s));
+      launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
+                       (const uint64_t *)d_val, n, K, rf, L, pl1, offs32, part_start, e->recs.p, ovf, ovf_count, kOverflowCap, ctr);
+      HIP_TRY(e, hipEventRecord(e->ev[3], s));
+      if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl1) + slice_table_bytes(slots, pl2))) != TAD_OK) return rc;
+      launch_repartition(s, e->recs.p, part_start, pl1, pl2, slots, e->slices.p, part_start2, static_cast<unsigned long long *>(e->part2_cursor.p), e->recs2.p);
+      launch_tile_aggregate(s, e->recs2.p, part_start2, pl2, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap);
+      pl = pl2;
     } else if (v2) {
       part_plan_wc(n * (has2 ? 2 : 1), columns_aligned16(d_key, d_key2, d_te, d_val), has2, &pl);
       const uint64_t slots = n * (has2 ? 2 : 1) + pl.pad_slots;
@@ -819,7 +854,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
       hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
       hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
-      st.stage0_path = sparse ? 4 : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
+      st.stage0_path = sparse ? 4 : (two_level ? 5 : (v2 ? (pl.wc_cap ? 3 : 2) : 1));
       e->done.store(4);
       *points_out = &pp->pub;
       return TAD_OK;
@@ -891,7 +926,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     hipEventElapsedTime(&st.ms_stage0, e->ev[1], e->ev[5]);
     hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
     hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
-    st.stage0_path = sparse ? 4 : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
+    st.stage0_path = sparse ? 4 : (two_level ? 5 : (v2 ? (pl.wc_cap ? 3 : 2) : 1));
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)
@@ -1034,6 +1069,7 @@ int series_grid(tad_engine *e, const uint64_t *x, uint64_t n, Grid *g) {
   g->flag = static_cast<uint8_t *>(e->grid_flag.p);
   g->K = 1;
   g->T = n;
+  g->times = nullptr;
   return TAD_OK;
 }
 

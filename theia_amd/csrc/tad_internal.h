@@ -218,6 +218,9 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, PartPlan *pl);
 bool columns_aligned16(const void *key, const void *key2, const void *t_end, const void *value);
 bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl);
 bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
+bool part_plan_two_level(uint64_t K, uint64_t T, bool has2, bool aligned, uint64_t slots, const PartPlan &base, PartPlan *l1, PartPlan *l2);
+void launch_repartition(hipStream_t s, const void *recs1, const unsigned long long *part_start1, const PartPlan &l1, const PartPlan &l2,
+                        uint64_t slots, void *slice_mem, const unsigned long long *part_start2, unsigned long long *cursor2, void *recs2);
 void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, uint64_t n, uint64_t K, RowFilter f, const PartPlan &pl,
                       MetaPartial *partials, uint32_t *binhist, DevCounters *ctr);

@@ -898,7 +898,14 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
 #pragma unroll
       for (int u = 0; u < U; ++u) apply(r[u]);
     }
-    for (; i < hi; i += kPartThreads) apply(recs[i]);
+    if (i < hi) {   // the last, ragged batch: all its loads in flight at once too (`no cell` for the slots past the end) — a
+                    // load-apply-load chain here cost small partitions (two-level plan: ~12k records) more than the full batches
+      unsigned long long r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) r[u] = i + u * kPartThreads < hi ? recs[i + u * kPartThreads] : ~0ull;
+#pragma unroll
+      for (int u = 0; u < U; ++u) apply(r[u]);
+    }
     __syncthreads();
     for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
       const uint32_t b = b_lo + (c >> shift_part), kk = c & (KP - 1);
@@ -929,6 +936,114 @@ __global__ __launch_bounds__(256) void k_apply_overflow(const OverflowRec *__res
     else __hip_atomic_fetch_add(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     g.flag[r.gcell] = FLAG_PRESENT;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two-level partition (many keys: C4 = 1e6 keys x 100 buckets).  A KP x T tile that fits LDS in ONE round is 128 keys wide
+// there: 7813 partitions, far beyond what pass B's LDS queues can serve (<= ~820 for whole 128-byte lines) — round 1 fell
+// back to the sort-by-tile pass B (0.9-1.08 ms, runs of ~5 records) with 512-key blocks and 3-4 bucket rounds in pass C.
+// Instead: level 1 = the write-combining pass B over WIDE key blocks (2048 keys: 489 partitions, whole lines); level 2 =
+// k_repartition: the records of a wide block are split 16 ways by key sub-range through an LDS tile sort — few targets, so
+// every (tile, target) run is ~1 KB long and a global cursor per target (one atomic per run) replaces the offset tables;
+// pass C then aggregates single-round tiles.  The sub-partition sizes come from the fine histogram pass A already has.
+// LDS carve: rec[S] u64 | sub[S] u8 | cnt[NQ + 1] | base[NQ] (S = records per tile)
+// ------------------------------------------------------------------------------------------------
+struct RepartArgs {
+  const unsigned long long *recs1;
+  const unsigned long long *part_start1;   // [nparts1 + 1]
+  unsigned long long *recs2;
+  unsigned long long *cursor2;             // [nparts2] next free slot of every level-2 partition (starts at part_start2)
+  int cell_bits1, cell_bits2;
+  int shift1;        // log2(KP1)
+  int shift2;        // log2(KP2)
+  int sub_bits;      // shift1 - shift2
+  uint32_t nparts1;
+};
+
+static constexpr int kRepartRows = 4;   // records per thread per tile
+
+__global__ __launch_bounds__(kPartThreads) void k_repartition(RepartArgs A, SliceTable st) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint32_t S = kPartThreads * kRepartRows;
+  unsigned long long *rec = reinterpret_cast<unsigned long long *>(smem);
+  uint8_t *sub = smem + (size_t)S * 8;
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + (size_t)S * 9);
+  const uint32_t NQ = 1u << A.sub_bits;
+  unsigned long long *base = reinterpret_cast<unsigned long long *>(cnt + NQ + 2 + ((NQ & 1u) ? 1 : 0));
+  const uint32_t s_idx = blockIdx.x;
+  if (s_idx >= *st.n_slices) return;
+  const uint32_t p1 = st.slice_part[s_idx];
+  const uint32_t first = st.slice_first[p1];
+  const unsigned long long plo = A.part_start1[p1], phi = A.part_start1[p1 + 1];
+  const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * kSliceRecords;
+  const unsigned long long hi = lo + kSliceRecords < phi ? lo + kSliceRecords : phi;
+  const uint32_t none1 = (1u << A.cell_bits1) - 1u;
+  const uint32_t kp1_mask = (1u << A.shift1) - 1u, kp2_mask = (1u << A.shift2) - 1u;
+  for (unsigned long long t0 = lo; t0 < hi; t0 += S) {
+    for (uint32_t q = threadIdx.x; q <= NQ; q += kPartThreads) cnt[q] = 0;
+    __syncthreads();
+    unsigned long long r2[kRepartRows];
+    uint32_t sr[kRepartRows];    // sub << 16 | rank, or all ones
+#pragma unroll
+    for (int j = 0; j < kRepartRows; ++j) {
+      const unsigned long long i = t0 + (unsigned long long)j * kPartThreads + threadIdx.x;
+      sr[j] = 0xFFFFFFFFu;
+      r2[j] = 0;
+      if (i < hi) {
+        const unsigned long long r = A.recs1[i];
+        const uint32_t c1 = (uint32_t)r & none1;
+        if (c1 != none1) {
+          const uint32_t kin1 = c1 & kp1_mask, bucket = c1 >> A.shift1;
+          const uint32_t sb = kin1 >> A.shift2;
+          r2[j] = ((r >> A.cell_bits1) << A.cell_bits2) | ((bucket << A.shift2) | (kin1 & kp2_mask));
+          sr[j] = (sb << 16) | atomicAdd(&cnt[sb], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    // exclusive scan over the NQ (<= 32) targets by one wavefront; one global reservation per (tile, target)
+    if (threadIdx.x < 64) {
+      const uint32_t c = threadIdx.x < NQ ? cnt[threadIdx.x] : 0u;
+      uint32_t incl = c;
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += y; }
+      const uint32_t tile_total = __shfl(incl, 63);   // (all 64 lanes active here)
+      if (threadIdx.x < NQ) {
+        cnt[threadIdx.x] = incl - c;   // tile position of the target's run
+        base[threadIdx.x] = c ? atomicAdd(&A.cursor2[((unsigned long long)p1 << A.sub_bits) + threadIdx.x], (unsigned long long)c) : 0ull;
+      }
+      if (threadIdx.x == 63) cnt[NQ] = tile_total;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRepartRows; ++j) {
+      if (sr[j] != 0xFFFFFFFFu) {
+        const uint32_t sb = sr[j] >> 16, pos = cnt[sb] + (sr[j] & 0xFFFFu);
+        rec[pos] = r2[j];
+        sub[pos] = (uint8_t)sb;
+      }
+    }
+    __syncthreads();
+    const uint32_t total = cnt[NQ];
+    for (uint32_t idx = threadIdx.x; idx < total; idx += kPartThreads) {
+      const uint32_t sb = sub[idx];
+      A.recs2[base[sb] + (idx - cnt[sb])] = rec[idx];
+    }
+    __syncthreads();
+  }
+}
+
+// slots of a level-2 partition that stayed empty (rows that went to the overflow list, level-1 fillers): `no cell`
+__global__ __launch_bounds__(256) void k_fill_tails(const unsigned long long *__restrict__ cursor2, const unsigned long long *__restrict__ part_start2,
+                                                    uint32_t nparts2, unsigned long long *__restrict__ recs2) {
+  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= nparts2) return;
+  const unsigned long long end = part_start2[p + 1];
+  for (unsigned long long i = cursor2[p] + (threadIdx.x & 63); i < end; i += 64) recs2[i] = ~0ull;
+}
+
+__global__ __launch_bounds__(256) void k_copy_u64(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1128,6 +1243,70 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
     else { if (has2) TAD_PART(2, true, false, true); else TAD_PART(2, false, false, true); }
   }
 #undef TAD_PART
+}
+
+// Two-level plan: l2 = the partitions pass C aggregates in ONE round (the widest power-of-two key block whose KP x T tile
+// fits LDS), l1 = wide blocks of 2^sub_bits of them, few enough for pass B to write whole 128-byte lines.  Only when the
+// single-level plan cannot run the write-combining pass at all (more than ~1850 partitions).
+bool part_plan_two_level(uint64_t K, uint64_t T, bool has2, bool aligned, uint64_t slots, const PartPlan &base, PartPlan *l1, PartPlan *l2) {
+  // Opt-in (TAD_TWO_LEVEL=1).  Measured at C4 on one box, alternating runs: level 1 0.65 ms + level 2 0.31 ms + single-round pass C
+  // 0.55 ms = job 2.31 ms, against 0.90-1.09 ms (box-dependent) + 0.45 ms = 2.22-2.35 ms for the single-level plan: pass C on
+  // 128-key tiles is bound by the 0.9 GB grid it writes, one workgroup per CU, not by the record re-reads the extra level saves.
+  const char *env = getenv("TAD_TWO_LEVEL");
+  if (!(env && atoi(env) == 1)) return false;
+  if (!aligned || T == 0 || base.nparts <= kLdsBudget / (14 + 8 * 9)) return false;
+  int sp2 = -1;
+  for (int c = 13; c >= 0; --c)
+    if (((uint64_t)T << c) <= kTileCells) { sp2 = c; break; }
+  if (const char *e2 = getenv("TAD_L2_SHIFT")) { const int v = atoi(e2); if (v >= 1 && v < sp2) sp2 = v; }   // tuning knob: narrower level-2 blocks
+  if (sp2 < base.shift_bin || sp2 < 1) return false;
+  auto parts_of = [&](int c) { return (K + (1ull << c) - 1) >> c; };
+  const uint64_t line_parts = kLdsBudget / (8 * 22 + 14);
+  int sp1 = sp2 + 1;
+  while (sp1 - sp2 < 5 && parts_of(sp1) > line_parts) ++sp1;
+  if (parts_of(sp1) > line_parts) return false;
+  const uint64_t cells1 = ((uint64_t)T << sp1);
+  int cb1 = kMinCellBits;
+  while (cb1 < kMaxCellBits && (1ull << cb1) - 1 <= cells1) ++cb1;
+  if ((1ull << cb1) - 1 <= cells1) return false;
+  *l1 = base;
+  l1->shift_part = sp1; l1->KP = 1u << sp1; l1->nparts = (uint32_t)parts_of(sp1); l1->bins_per_part = 1u << (sp1 - base.shift_bin);
+  l1->cell_bits = cb1; l1->tb = 0; l1->n_chunks = 0; l1->rpt = 2;
+  part_plan_wc(slots, aligned, has2, l1);
+  if (l1->wc_cap == 0 || l1->wc_sec != 16) return false;
+  *l2 = base;
+  l2->shift_part = sp2; l2->KP = 1u << sp2; l2->nparts = l1->nparts << (sp1 - sp2);   // level-2 ids = (p1 << sub_bits) | sub: the last block may hold empty ones
+  l2->bins_per_part = 1u << (sp2 - base.shift_bin);
+  const uint64_t cells2 = ((uint64_t)T << sp2);
+  int cb2 = kMinCellBits;
+  while (cb2 < kMaxCellBits && (1ull << cb2) - 1 <= cells2) ++cb2;
+  l2->cell_bits = cb2 > cb1 ? cb1 : cb2;
+  if (l2->cell_bits > cb1) return false;
+  l2->tb = (uint32_t)T; l2->n_chunks = 1;
+  l2->agg_lds = ((size_t)l2->tb * l2->KP * 9 + 15) & ~(size_t)15;
+  l2->wc_cap = 0; l2->wc_sec = 0; l2->wc_rpt = 0; l2->pad_slots = l1->pad_slots;
+  return true;
+}
+
+// level 2: recs1 (grouped by the wide level-1 partitions) -> recs2 (grouped by the level-2 partitions)
+void launch_repartition(hipStream_t s, const void *recs1, const unsigned long long *part_start1, const PartPlan &l1, const PartPlan &l2,
+                        uint64_t slots, void *slice_mem, const unsigned long long *part_start2, unsigned long long *cursor2, void *recs2) {
+  const uint32_t max_slices = (uint32_t)((size_t)l1.nparts + (size_t)(slots / kSliceRecords) + 1);
+  SliceTable st;
+  st.slice_part = static_cast<uint32_t *>(slice_mem);
+  st.slice_first = st.slice_part + max_slices;
+  st.n_slices = st.slice_first + l1.nparts;
+  hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start1, l1.nparts, st);
+  hipLaunchKernelGGL(k_copy_u64, dim3((l2.nparts + 255) / 256), dim3(256), 0, s, part_start2, cursor2, l2.nparts);
+  RepartArgs A;
+  A.recs1 = static_cast<const unsigned long long *>(recs1); A.part_start1 = part_start1;
+  A.recs2 = static_cast<unsigned long long *>(recs2); A.cursor2 = cursor2;
+  A.cell_bits1 = l1.cell_bits; A.cell_bits2 = l2.cell_bits; A.shift1 = l1.shift_part; A.shift2 = l2.shift_part;
+  A.sub_bits = l1.shift_part - l2.shift_part; A.nparts1 = l1.nparts;
+  const uint32_t NQ = 1u << A.sub_bits;
+  const size_t lds = ((size_t)kPartThreads * kRepartRows * 9 + (size_t)(NQ + 4) * 4 + (size_t)NQ * 8 + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(k_repartition, dim3(max_slices), dim3(kPartThreads), lds, s, A, st);
+  hipLaunchKernelGGL(k_fill_tails, dim3((l2.nparts + 3) / 4), dim3(256), 0, s, cursor2, part_start2, l2.nparts, A.recs2);
 }
 
 size_t slice_table_bytes(uint64_t slots, const PartPlan &pl) {
