@@ -28,7 +28,8 @@
 #include "tad_internal.h"
 #include "tad_detmath.h"
 
-// helper functions are host+device so that tools/arima_trace.cpp can step through the same code on the CPU
+// helper functions are host+device so that tools/arima_twin.cpp can run the same source on a machine without a GPU
+// (tools/arima_twin_check.py: host instantiation == oracle/arima_exact.c bit for bit, before any GPU time is spent)
 #define TAD_HD __host__ __device__
 
 namespace tad {
