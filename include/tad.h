@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 4
+#define TAD_ABI_VERSION 5
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -136,6 +136,9 @@ typedef struct {
   int32_t stage0_path;     /* 1 = direct atomic scatter, 2 = partition (sort-by-tile pass B) + LDS tiles, 3 = partition (write-combining pass B) + LDS tiles,
                               4 = sparse table: sort by (key, time) + rank grid (time proportional to the rows, not to keys x lattice),
                               5 = two-level partition (many keys: wide blocks through the write-combining pass, split again, single-round LDS tiles) */
+  int32_t stage0_attempts; /* times Stage 0 ran before it settled: 1 normally; more after a wrong lattice hint, a sampled lattice or
+                              a sampled histogram that proved too optimistic (every fallback is exact), an overflow-list fallback */
+  int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/8 of pass A's reads) */
 } tad_stats;
 
 /* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).

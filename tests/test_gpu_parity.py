@@ -199,6 +199,34 @@ def test_job_sparse_live_rows_in_an_unsampled_stretch(engine, stage0):
     assert res.n_rows == want["n_anomalies"] and (res["key_id"] == want["key_id"]).all()
 
 
+def test_job_sampled_histogram_too_optimistic_falls_back_to_exact(engine, stage0):
+    # Stage-0 v2 sizes pass B's (workgroup, partition) regions from a SAMPLE of the key column (one 8192-row iteration in
+    # eight of every workgroup's chunk + the chunk ends).  Here 16 keys occur ONLY in stretches the sample skips: their
+    # regions are sized for nothing, pass B finds them full (DEV_ERR_REGION_FULL) and the job must be redone with the exact
+    # histogram — same rows as the oracle, bit for bit.
+    if stage0 == "v1":
+        pytest.skip("the direct scatter has no histogram")
+    n, K, T = 26_000_000, 2000, 60
+    k, t, v = orc.synth_rows_parallel(n, K, T)
+    chunk = (((n + 255) // 256) + 1) & ~1
+    it = (np.arange(n, dtype=np.int64) % chunk) // 8192
+    nit = (chunk + 8191) // 8192
+    hidden = (it % 8 >= 2) & (it % 8 <= 6) & (it < nit - 3)
+    k = np.where(hidden, k % np.uint64(16), np.uint64(16) + k % np.uint64(K - 16))
+    want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+    res = engine.run("EWMA", k, t, v, K, agg_flow="svc")
+    assert res.n_rows == want["n_anomalies"] and res.stats["n_points"] == want["n_points"] and res.stats["rows_used"] == n
+    for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+        assert (res[f] == want[f]).all(), f
+    if stage0 != "v1":
+        assert res.stats["stage0_attempts"] == 2 and res.stats["hist_sampled"] == 0      # sampled first, exact on the retry
+    # the unmodified table goes through on the sampled histogram
+    k2, t2, v2 = orc.synth_rows(0, 6_000_000, 3000, 50)
+    res2 = engine.run("EWMA", k2, t2, v2, 3000, agg_flow="svc")
+    if stage0 != "v1":
+        assert res2.stats["stage0_attempts"] == 1 and res2.stats["hist_sampled"] == 1
+
+
 @pytest.mark.parametrize("n_rows,K,T", [(1_500_000, 40_000, 2000), (300_000, 50, 20_000), (2_000_000, 300_000, 100)])
 def test_job_wide_grids_take_several_rounds_per_partition(engine, stage0, n_rows, K, T):
     # grids whose KP x T block does not fit one LDS tile (many buckets) or that would need more than 2048 partitions

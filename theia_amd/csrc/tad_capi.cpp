@@ -48,6 +48,7 @@ struct tad_engine {
   DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
   DevBuf part2_total, part2_start, part2_offs32, part2_cursor, recs2;             // Stage 0 v2, two-level partition
+  DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
@@ -233,7 +234,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->part_fin, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -545,20 +546,27 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   const bool force_v2 = s0env && !strcmp(s0env, "v2");
   const bool has2 = cols->key_id2 != nullptr;
   bool force_v1_retry = false;
+  // pass A may histogram a SAMPLE of the rows (1/8 of the key column instead of all of it): pass B's regions are then sized from
+  // the estimate with 6 sigma of slack; a region that still turns out too small (keys arriving in bursts the sample missed)
+  // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  TAD_HIST_SAMPLE=0 disables it.
+  const char *hs_env = getenv("TAD_HIST_SAMPLE"), *tl_env = getenv("TAD_TWO_LEVEL");
+  bool force_exact_hist = (hs_env && atoi(hs_env) == 0) || (tl_env && atoi(tl_env) == 1);
   // retries: wrong hint -> derive (0 -> 1); sampled lattice too coarse / saw no live row -> exact (1 -> 2); overflow list
   // full -> Stage 0 v1.  Each transition happens at most once, so 5 attempts cover every path.
-  for (int attempt = 0; attempt < 6; ++attempt) {
+  for (int attempt = 0; attempt < 7; ++attempt) {
     const bool hinted = lat_mode == 0;
     HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
     PartPlan pl{};
     bool v2 = !empty && !force_v1 && !force_v1_retry && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
     if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
     int meta_blocks = 0;
+    bool hist_sampled = false;
     if (v2) {
       // pass A: lattice partials + per-workgroup key-bin histogram in one read of the key/time columns
       if ((rc = ensure(e, e->binhist, (size_t)pl.G * pl.nbins * 4)) != TAD_OK) return rc;
-      launch_meta_hist(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, K, rf,
-                       pl, static_cast<MetaPartial *>(e->meta.p), static_cast<uint32_t *>(e->binhist.p), ctr);
+      hist_sampled = launch_meta_hist(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, K, rf,
+                                      pl, static_cast<MetaPartial *>(e->meta.p), static_cast<uint32_t *>(e->binhist.p), ctr,
+                                      !force_exact_hist && sampled_slots_bound(n * (has2 ? 2 : 1), pl) < (1ull << 32));
       meta_blocks = pl.G;
     }
     if (!hinted && !empty && (!v2 || lat_mode == 2)) {
@@ -714,8 +722,15 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       launch_tile_aggregate(s, e->recs2.p, part_start2, pl2, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap);
       pl = pl2;
     } else if (v2) {
-      part_plan_wc(n * (has2 ? 2 : 1), columns_aligned16(d_key, d_key2, d_te, d_val), has2, &pl);
-      const uint64_t slots = n * (has2 ? 2 : 1) + pl.pad_slots;
+      part_plan_wc(hist_sampled ? sampled_slots_bound(n * (has2 ? 2 : 1), pl) : n * (has2 ? 2 : 1), columns_aligned16(d_key, d_key2, d_te, d_val), has2, &pl);
+      // nparts is only known now: the bound is recomputed with the final plan (part_plan_bins' G, part_plan_tiles' nparts)
+      const uint64_t slots = hist_sampled ? sampled_slots_bound(n * (has2 ? 2 : 1), pl) : n * (has2 ? 2 : 1) + pl.pad_slots;
+      if (hist_sampled && slots >= (1ull << 32)) { force_exact_hist = true; continue; }
+      uint32_t *fin = nullptr;
+      if (hist_sampled) {
+        if ((rc = ensure(e, e->part_fin, (size_t)pl.G * pl.nparts * 8)) != TAD_OK) return rc;
+        fin = static_cast<uint32_t *>(e->part_fin.p);
+      }
       if ((rc = ensure(e, e->part_total, (size_t)pl.nparts * 4)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_start, ((size_t)pl.nparts + 1) * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_offs32, (size_t)pl.G * pl.nparts * 4)) != TAD_OK) return rc;
@@ -728,15 +743,17 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       if ((rc = ensure_rcp_table(e, L.nb)) != TAD_OK) return rc;
       uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
       unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
-      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start);
+      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start,
+                          hist_sampled, static_cast<const MetaPartial *>(e->meta.p), n);
       HIP_TRY(e, hipEventRecord(e->ev[2], s));
       launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
-                       (const uint64_t *)d_val, n, K, rf, L, pl, offs32, part_start, e->recs.p, ovf, ovf_count, kOverflowCap, ctr);
+                       (const uint64_t *)d_val, n, K, rf, L, pl, offs32, part_start, e->recs.p, ovf, ovf_count, kOverflowCap, ctr, fin);
       HIP_TRY(e, hipEventRecord(e->ev[3], s));
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
-      launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap);
+      launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap,
+                            hist_sampled ? offs32 : nullptr, fin);
     } else {
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));
@@ -789,6 +806,10 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
     if (c.err & DEV_ERR_LATE_ROW)
       return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: a row is not newer than the last flowEndSeconds of its key's state; state unchanged");
+    if (c.err & DEV_ERR_REGION_FULL) {   // a region sized from the sampled histogram was too small: exact histogram
+      if (!force_exact_hist) { force_exact_hist = true; continue; }
+      return fail(e, TAD_ERR_HIP, "internal error: a partition region overflowed with an exact histogram");
+    }
     if (c.err & DEV_ERR_OVERFLOW_LIST) {  // more than kOverflowCap values >= 2^49: the packed records do not pay off, use v1
       if (!force_v1_retry) { force_v1_retry = true; continue; }
       return fail(e, TAD_ERR_HIP, "internal error: overflow list full on the v1 path");
@@ -855,6 +876,8 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
       hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
       st.stage0_path = sparse ? 4 : (two_level ? 5 : (v2 ? (pl.wc_cap ? 3 : 2) : 1));
+      st.stage0_attempts = attempt + 1;
+      st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
       e->done.store(4);
       *points_out = &pp->pub;
       return TAD_OK;
@@ -927,6 +950,8 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
     hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
     st.stage0_path = sparse ? 4 : (two_level ? 5 : (v2 ? (pl.wc_cap ? 3 : 2) : 1));
+    st.stage0_attempts = attempt + 1;
+    st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)

@@ -29,7 +29,8 @@ struct Grid {
                             // row b holds every key's b-th point in time order and times[b * K + k] its flowEndSeconds
 };
 
-enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u, DEV_ERR_LATE_ROW = 8u };
+enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u, DEV_ERR_LATE_ROW = 8u,
+                  DEV_ERR_REGION_FULL = 16u };  // Stage 0 v2 with a SAMPLED histogram: a (workgroup, partition) region was sized too small
 enum : uint8_t { FLAG_PRESENT = 1, FLAG_ANOMALY = 2 };
 
 // Per-block partial of the lattice-derivation pass.
@@ -37,6 +38,7 @@ struct MetaPartial {
   int64_t tmin, tmax, tref;
   uint64_t g;     // gcd of |t - tref| over the rows this block kept
   uint64_t used;  // rows kept
+  uint64_t seen;  // rows examined (k_meta_hist with a sampled histogram: the histogram's sampling ratio is seen / chunk rows)
 };
 
 // Device-side counters of one run (one 64-byte block, zeroed per run).
@@ -221,21 +223,31 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
 bool part_plan_two_level(uint64_t K, uint64_t T, bool has2, bool aligned, uint64_t slots, const PartPlan &base, PartPlan *l1, PartPlan *l2);
 void launch_repartition(hipStream_t s, const void *recs1, const unsigned long long *part_start1, const PartPlan &l1, const PartPlan &l2,
                         uint64_t slots, void *slice_mem, const unsigned long long *part_start2, unsigned long long *cursor2, void *recs2);
-void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
+// sample_hist: histogram only the rows whose time is sampled too (one iteration in eight + the chunk ends): pass A then
+// reads 1/8 of the key column; the regions of pass B are SIZED from the estimate (launch_part_offsets) instead of counted.
+// Returns whether the histogram is sampled (only without a time-window filter and with 16-byte aligned columns).
+bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, uint64_t n, uint64_t K, RowFilter f, const PartPlan &pl,
-                      MetaPartial *partials, uint32_t *binhist, DevCounters *ctr);
+                      MetaPartial *partials, uint32_t *binhist, DevCounters *ctr, bool sample_hist);
 // offs32[G][nparts] (exclusive per-workgroup prefix inside each partition), total[nparts], part_start[nparts + 1]
+// sampled: the histogram is a sample -> region capacities (estimate + 6 sigma + margin); partials carry the sampling ratios
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
-                         unsigned long long *part_start);
+                         unsigned long long *part_start, bool sampled = false, const MetaPartial *partials = nullptr, uint64_t n = 0);
+// upper bound of the record slots pass B may be given when the regions are sized from a sampled histogram
+uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl);
+// fin != NULL (sampled regions): no fillers; fin[(g * nparts + p) * 2 + {0, 1}] = end of the records written upwards /
+// start of the spilled records written downwards in region (g, p)
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f,
                       Lattice L, const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start,
-                      void *recs, OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr);
+                      void *recs, OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr,
+                      uint32_t *fin = nullptr);
 // slots = record slots of the run (rows x keys per row); slice_mem = slice_table_bytes(slots, pl) bytes of device scratch
 size_t slice_table_bytes(uint64_t slots, const PartPlan &pl);
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
-                           const unsigned long long *ovf_count, uint32_t ovf_cap);
+                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32 = nullptr,
+                           const uint32_t *fin = nullptr);
 
 // ---- Stage 0 for sparse tables: sort by (key, time), reduce, rank grid (tad_sparse.hip) ----
 size_t sparse_sort_temp_bytes(uint64_t slots);

@@ -163,7 +163,7 @@ __device__ __forceinline__ void hist_row(MetaAcc &a, uint32_t *hist, uint64_t k1
   }
 }
 
-template <bool VEC, bool HAS2>
+template <bool VEC, bool HAS2, bool SAMPLE_H>
 __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__restrict__ key,
                                                             const uint64_t *__restrict__ key2,
                                                             const int64_t *__restrict__ t_end,
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
   const uint64_t lo = (uint64_t)blockIdx.x * chunk;
   const uint64_t hi = lo + chunk < n ? lo + chunk : n;
   MetaAcc acc{{0, 0, 0, 0, 0}, 0, 0};
+  uint32_t seen = 0;   // rows this thread examined (= histogrammed or rejected): the sampling ratio of the histogram
   const bool has_ts = t_start != nullptr && f.start_time != 0;
   if (VEC) {
     // two rows per lane per column: 1 KiB per wave-instruction
@@ -195,6 +196,8 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
     uint32_t it = 0;
     for (; i + (U - 1) * kPartThreads < npair; i += U * kPartThreads, ++it) {
       const bool with_t = !sample_t || (it & 7) == 0 || (i - threadIdx.x) + 2 * U * kPartThreads >= npair;  // workgroup-uniform
+      if (SAMPLE_H && !with_t) continue;   // sampled histogram: the unsampled iterations are not read at all
+      seen += 2 * U;
       ulonglong2 k[U], k2[U];
       longlong2 t[U];
 #pragma unroll
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
       }
     }
     for (; i < npair; i += kPartThreads) {
+      seen += 2;
       const ulonglong2 k = kv[i];
       const longlong2 t = tv[i];
       const ulonglong2 k2 = HAS2 ? k2v[i] : make_ulonglong2(TAD_KEY_SKIP, TAD_KEY_SKIP);
@@ -230,18 +234,22 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
       meta_row(acc, hist, k.y, k2.y, t.y, p_time_kept(t.y, ts1, has_ts, f), K, shift_bin);
     }
     if (((hi - lo) & 1) && threadIdx.x == 0 && hi > lo) {
+      seen += 1;
       const uint64_t r = hi - 1;
       const int64_t te = t_end[r];
       meta_row(acc, hist, key[r], HAS2 ? key2[r] : TAD_KEY_SKIP, te, p_time_kept(te, has_ts ? t_start[r] : 0, has_ts, f), K, shift_bin);
     }
   } else {
     for (uint64_t r = lo + threadIdx.x; r < hi; r += kPartThreads) {
+      seen += 1;
       const int64_t te = t_end[r];
       meta_row(acc, hist, key[r], HAS2 ? key2[r] : TAD_KEY_SKIP, te, p_time_kept(te, has_ts ? t_start[r] : 0, has_ts, f), K, shift_bin);
     }
   }
   PMeta m = acc.m;
   uint32_t err = acc.err;
+  unsigned long long seen_w = seen;
+  for (int d = 32; d >= 1; d >>= 1) seen_w += __shfl_down(seen_w, d);
   for (int d = 32; d >= 1; d >>= 1) {
     PMeta o;
     o.tmin = __shfl_down((long long)m.tmin, d);
@@ -254,15 +262,17 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
   }
   __shared__ PMeta s_acc[kPartThreads / 64];
   __shared__ uint32_t s_err[kPartThreads / 64];
+  __shared__ unsigned long long s_seen[kPartThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { s_acc[wave] = m; s_err[wave] = err; }
+  if (lane == 0) { s_acc[wave] = m; s_err[wave] = err; s_seen[wave] = seen_w; }
   __syncthreads();  // also: every histogram update of this workgroup is done
   if (threadIdx.x == 0) {
     PMeta a = s_acc[0];
     uint32_t e = s_err[0];
-    for (int w = 1; w < kPartThreads / 64; ++w) { a = pmeta_merge(a, s_acc[w]); e |= s_err[w]; }
+    unsigned long long sn = s_seen[0];
+    for (int w = 1; w < kPartThreads / 64; ++w) { a = pmeta_merge(a, s_acc[w]); e |= s_err[w]; sn += s_seen[w]; }
     MetaPartial p;
-    p.tmin = a.tmin; p.tmax = a.tmax; p.tref = a.tref; p.g = a.g; p.used = a.used;
+    p.tmin = a.tmin; p.tmax = a.tmax; p.tref = a.tref; p.g = a.g; p.used = a.used; p.seen = sn;
     partials[blockIdx.x] = p;
     if (e) atomicOr(&ctr->err, e);
   }
@@ -273,16 +283,34 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
 // ------------------------------------------------------------------------------------------------
 // offsets: cnt[g][p] (row reduce of the bins) -> column-wise exclusive prefix over g -> part_start[p]
 // ------------------------------------------------------------------------------------------------
+// Capacity of a (workgroup, partition) region from a SAMPLED count s at sampling ratio 1 / scale: the estimate s * scale
+// (std dev ~ sqrt(estimate * scale) for hashed keys) + 6 sigma + a floor for partitions the sample missed.  Too small
+// -> pass B raises DEV_ERR_REGION_FULL and the host reruns with the exact histogram; too large costs address space only
+// (nothing is written to or read from the slack).
+__device__ __forceinline__ uint32_t sampled_capacity(uint32_t s, double scale) {
+  const double est = (double)s * scale;
+  return (uint32_t)(est + 6.0 * sqrt(est * scale) + 8.0 * scale + 16.0);
+}
+
 __global__ __launch_bounds__(256) void k_part_rows(const uint32_t *__restrict__ binhist, uint32_t nbins,
                                                    uint32_t bins_per_part, uint32_t nparts, uint32_t *__restrict__ cnt,
-                                                   uint32_t round_mask) {
+                                                   uint32_t round_mask, const MetaPartial *__restrict__ partials, uint64_t n, uint64_t chunk) {
   const uint32_t *row = binhist + (size_t)blockIdx.x * nbins;
   uint32_t *out = cnt + (size_t)blockIdx.x * nparts;
+  double scale = 0.0;   // 0: exact histogram
+  if (partials != nullptr) {
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk;
+    const uint64_t rows = lo < n ? (lo + chunk < n ? chunk : n - lo) : 0;
+    const uint64_t seen = partials[blockIdx.x].seen;
+    scale = seen ? (double)rows / (double)seen : 1.0;
+    if (scale < 1.0) scale = 1.0;
+  }
   for (uint32_t p = threadIdx.x; p < nparts; p += 256) {
     const uint32_t b0 = p * bins_per_part;
     const uint32_t b1 = b0 + bins_per_part < nbins ? b0 + bins_per_part : nbins;
     uint32_t s = 0;
     for (uint32_t b = b0; b < b1; ++b) s += row[b];
+    if (scale != 0.0) s = sampled_capacity(s, scale);
     out[p] = (s + round_mask) & ~round_mask;  // write-combining pass B: every (workgroup, partition) region is whole sectors
   }
 }
@@ -356,6 +384,8 @@ struct PartArgs {
   unsigned long long *ovf_count;
   uint32_t ovf_cap;
   DevCounters *ctr;
+  uint32_t *fin;      // sampled regions (NULL = exact regions): [(g * nparts + p) * 2] = {end of the upward records, start of the spilled ones}
+  int G;
 };
 
 // in-place exclusive scan of a[0..n) held in LDS by the whole workgroup; a[n] = total
@@ -406,12 +436,24 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
   uint32_t *off = reinterpret_cast<uint32_t *>(smem + (size_t)S * 10);  // F + 1 entries
   uint32_t *gcur = off + (F + 1);  // next global record slot of (this workgroup, partition)
   uint32_t *delta = gcur + F;
+  uint32_t *gend = delta + F;      // end of the region (sampled regions: capacity, checked; exact regions: never reached)
   __shared__ uint32_t s_wave[kPartThreads / 64];
+  __shared__ uint32_t s_full;
 
   // no global load may sit inside the tile loop: vmcnt retires in order, so waiting for one fresh load would
   // also wait for every prefetched row behind it
   const uint32_t *my_offs = A.offs32 + (size_t)blockIdx.x * F;
-  for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) { gcur[p] = (uint32_t)A.part_start[p] + my_offs[p]; off[p] = 0; }
+  {
+    const uint32_t *nx = A.offs32 + (size_t)(blockIdx.x + 1) * F;
+    const bool last = (int)blockIdx.x + 1 == A.G;
+    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
+      const uint32_t ps = (uint32_t)A.part_start[p];
+      gcur[p] = ps + my_offs[p];
+      gend[p] = A.fin == nullptr ? 0xFFFFFFFFu : (last ? (uint32_t)A.part_start[p + 1] : ps + nx[p]);
+      off[p] = 0;
+    }
+    if (threadIdx.x == 0) s_full = 0;
+  }
 
   const uint64_t lo = (uint64_t)blockIdx.x * A.chunk;
   const uint64_t hi = lo + A.chunk < A.n ? lo + A.chunk : A.n;
@@ -550,18 +592,26 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
       const uint32_t o = off[p], c = off[p + 1] - o;
       const uint32_t gc = gcur[p];
-      delta[p] = gc - o;  // global slot of the partition's first record of this tile, minus its tile position
-      gcur[p] = gc + c;
+      const bool full = c > gend[p] - gc;   // only with regions sized from a sampled histogram
+      delta[p] = full ? 0xFFFFFFFFu : gc - o;  // global slot of the partition's first record of this tile, minus its tile position
+      if (!full) gcur[p] = gc + c;
+      else s_full = 1;
     }
     lds_barrier();
     // ---- phase 4: copy the runs out (consecutive lanes -> consecutive records of one partition) ----
     const uint32_t total = off[F];
     for (uint32_t idx = threadIdx.x; idx < total; idx += kPartThreads) {
-      A.recs[delta[part[idx]] + idx] = rec[idx];
+      const uint32_t dl = delta[part[idx]];
+      if (dl != 0xFFFFFFFFu) A.recs[dl + idx] = rec[idx];
     }
     lds_barrier();
     for (uint32_t p = threadIdx.x; p <= F; p += kPartThreads) off[p] = 0;
     lds_barrier();
+  }
+  if (A.fin != nullptr) {
+    uint32_t *fo = A.fin + (size_t)blockIdx.x * F * 2;
+    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) { fo[2 * p] = gcur[p]; fo[2 * p + 1] = gend[p]; }
+    if (s_full) err |= DEV_ERR_REGION_FULL;
   }
   unsigned long long u = used;
   for (int d = 32; d >= 1; d >>= 1) { u += __shfl_down(u, d); err |= __shfl_down(err, d); }
@@ -598,8 +648,9 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
   unsigned long long *q = reinterpret_cast<unsigned long long *>(smem);
   uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + (size_t)F * cap * 8);
   uint32_t *gcur = cnt + F;   // next sector of (this workgroup, partition), upward
-  uint32_t *gend = gcur + F;  // end of the region / first spilled record, downward
-  uint16_t *jobs = reinterpret_cast<uint16_t *>(gend + F);
+  uint32_t *gend = gcur + F;  // end of the region (constant)
+  uint32_t *nsp = gend + F;   // records spilled to the top of the region, downward from gend (a counter: it cannot wrap)
+  uint16_t *jobs = reinterpret_cast<uint16_t *>(nsp + F);
   __shared__ uint32_t s_njobs;
 
   {
@@ -609,6 +660,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
     for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
       const uint32_t ps = (uint32_t)A.part_start[p];
       cnt[p] = 0;
+      nsp[p] = 0;
       gcur[p] = ps + my[p];
       gend[p] = last ? (uint32_t)A.part_start[p + 1] : ps + nx[p];
     }
@@ -695,7 +747,11 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
           const unsigned long long rec = (r.v[j] << A.cell_bits) | cell;
           const uint32_t pos = atomicAdd(&cnt[p], 1u);
           if (pos < cap) q[p * cap + pos] = rec;
-          else A.recs[atomicSub(&gend[p], 1u) - 1u] = rec;  // queue full (a burst, or a hot key): top of the region
+          else {  // queue full (a burst, or a hot key): top of the region
+            const uint32_t k = atomicAdd(&nsp[p], 1u);
+            if (k < gend[p] - gcur[p]) A.recs[gend[p] - 1u - k] = rec;   // (gcur only moves in the emit phase)
+            else err |= DEV_ERR_REGION_FULL;                              // sampled regions only: the region is full
+          }
         }
       }
     }
@@ -725,7 +781,10 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       const uint32_t c = cnt[p], g = gcur[p];
       unsigned long long *qp = q + p * cap;
       const uint32_t whole = c & ~(uint32_t)(SEC - 1);
-      for (uint32_t o = 0; o < whole; o += SEC) A.recs[g + o + sl] = qp[o + sl];
+      const uint32_t room = gend[p] - g, sp = nsp[p];
+      const bool fits = sp <= room && whole <= room - sp;   // always with exact regions; a region sized from a sampled histogram may be full
+      if (fits) { for (uint32_t o = 0; o < whole; o += SEC) A.recs[g + o + sl] = qp[o + sl]; }
+      else err |= DEV_ERR_REGION_FULL;
       const bool mv = whole + sl < c;
       const unsigned long long tail = mv ? qp[whole + sl] : 0ull;
       if (mv) qp[sl] = tail;  // (one wavefront, LDS in order: every lane has read before any lane writes)
@@ -743,13 +802,22 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
     process(R0, tile);
     if (tile + 1 < ntiles) process(R1, tile + 1);
   }
-  // ---- close the regions: leftovers, then `no cell` fillers up to the spilled records ----
+  // ---- close the regions: leftovers, then (exact regions) `no cell` fillers up to the spilled records; sampled regions keep
+  // their slack untouched and record where the valid records end / the spilled ones start ----
   for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
     const uint32_t c = cnt[p] < cap ? cnt[p] : cap;
     uint32_t g = gcur[p];
-    const uint32_t e = gend[p];
-    for (uint32_t i = 0; i < c; ++i) A.recs[g + i] = q[p * cap + i];
-    for (g += c; g < e; ++g) A.recs[g] = ~0ull;
+    const uint32_t room = gend[p] - g;
+    const uint32_t e = gend[p] - (nsp[p] < room ? nsp[p] : room);   // first spilled record
+    if (A.fin != nullptr) {
+      if (c <= e - g && g <= e) { for (uint32_t i = 0; i < c; ++i) A.recs[g + i] = q[p * cap + i]; g += c; }
+      else err |= DEV_ERR_REGION_FULL;
+      uint32_t *fo = A.fin + ((size_t)blockIdx.x * F + p) * 2;
+      fo[0] = g; fo[1] = e;
+    } else {
+      for (uint32_t i = 0; i < c; ++i) A.recs[g + i] = q[p * cap + i];
+      for (g += c; g < e; ++g) A.recs[g] = ~0ull;
+    }
   }
   unsigned long long u = used;
   for (int d = 32; d >= 1; d >>= 1) { u += __shfl_down(u, d); err |= __shfl_down(err, d); }
@@ -779,13 +847,13 @@ struct SliceTable {
 
 // single workgroup: nsl[p] = max(1, ceil(cnt[p] / kSliceRecords)); exclusive scan -> slice_first; fill slice_part
 __global__ __launch_bounds__(kPartThreads) void k_build_slices(const unsigned long long *__restrict__ part_start, uint32_t nparts,
-                                                               SliceTable st) {
+                                                               SliceTable st, uint32_t slice_len) {
   __shared__ uint32_t s_wave[kPartThreads / 64];
   const uint32_t per = (nparts + kPartThreads - 1) / kPartThreads;
   const uint32_t b0 = threadIdx.x * per;
   auto nsl = [&](uint32_t p) -> uint32_t {
     const unsigned long long c = part_start[p + 1] - part_start[p];
-    const uint32_t k = (uint32_t)((c + kSliceRecords - 1) / kSliceRecords);
+    const uint32_t k = (uint32_t)((c + slice_len - 1) / slice_len);
     return k ? k : 1u;
   };
   uint32_t sum = 0;
@@ -829,12 +897,14 @@ struct TileGeom {
   uint32_t tb;        // buckets per round
   uint32_t n_chunks;  // ceil(T / tb)
   uint32_t par_rounds;  // 1: every round of a slice is its own workgroup (grid = slices x rounds), see k_tile_aggregate
+  uint32_t slice_len;   // record slots per slice (kSliceRecords; twice that when the regions carry the slack of a sampled histogram)
 };
 
 template <bool OPMAX>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
-                                                                 SliceTable st, TileGeom tg, Grid g, int phase) {
+                                                                 SliceTable st, TileGeom tg, Grid g, int phase,
+                                                                 const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G) {
   // Rounds as workgroups: a partition whose KP x T block needs R > 1 LDS tiles is read by R workgroups, one per bucket
   // round, instead of R times by one.  The R workgroups of a slice get block ids x + 8 * (R * j + r): the same XCD
   // (blocks are dealt round-robin over the 8 XCDs) and adjacent in dispatch order, so they stream the same records at
@@ -867,8 +937,8 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t cell_none = (1u << tg.cell_bits) - 1u;
   const unsigned long long plo = part_start[p], phi = part_start[p + 1];
-  const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * kSliceRecords;
-  const unsigned long long hi = lo + kSliceRecords < phi ? lo + kSliceRecords : phi;
+  const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * tg.slice_len;
+  const unsigned long long hi = lo + tg.slice_len < phi ? lo + tg.slice_len : phi;
   for (uint32_t chunk = r_lo; chunk < r_hi; ++chunk) {
     const uint32_t b_lo = chunk * tg.tb;
     const uint32_t nb = b_lo + tg.tb <= T ? tg.tb : T - b_lo;
@@ -890,7 +960,44 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
       flags[c] = FLAG_PRESENT;
     };
     constexpr int U = 8;
-    unsigned long long i = lo + threadIdx.x;
+    if (fin != nullptr) {
+      // Regions sized from a sampled histogram: the partition's record space [plo, phi) is tiled by one region per pass-B
+      // workgroup; a region holds valid records in [start, fin_lo) and [fin_hi, end) (spilled ones), untouched slack
+      // between.  Wavefront w takes the regions w, w + 16, ...; the bounds of its regions are fetched up front (one lane
+      // each) and broadcast, so that the record loads of consecutive regions are not serialised behind a bounds load.
+      const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+      const uint32_t F = tg.nparts;
+      for (uint32_t w0 = wave; w0 < (uint32_t)G; w0 += 64u * (kPartThreads / 64)) {
+        const uint32_t wm = w0 + lane * (kPartThreads / 64);       // the region lane `lane` fetches the bounds of
+        unsigned long long b_start = 0, b_lo = 0, b_hi = 0, b_end = 0;
+        if (wm < (uint32_t)G) {
+          b_start = plo + offs32[(size_t)wm * F + p];
+          b_end = wm + 1 < (uint32_t)G ? plo + offs32[(size_t)(wm + 1) * F + p] : phi;
+          b_lo = fin[((size_t)wm * F + p) * 2];
+          b_hi = fin[((size_t)wm * F + p) * 2 + 1];
+        }
+        for (uint32_t j = 0; j < 64u && w0 + j * (kPartThreads / 64) < (uint32_t)G; ++j) {
+          const unsigned long long r_start = __shfl(b_start, (int)j), r_lo = __shfl(b_lo, (int)j), r_hi = __shfl(b_hi, (int)j),
+                                   r_end = __shfl(b_end, (int)j);
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            unsigned long long a = half == 0 ? r_start : r_hi, b = half == 0 ? r_lo : r_end;
+            a = a < r_start ? r_start : a;   // (a job whose region overflowed is redone, but must not read out of bounds first)
+            b = b > r_end ? r_end : b;
+            a = a < lo ? lo : a;             // clip to this slice
+            b = b > hi ? hi : b;
+            for (unsigned long long i = a + lane; i < b; i += U * 64) {
+              unsigned long long r[U];
+#pragma unroll
+              for (int u = 0; u < U; ++u) r[u] = i + u * 64 < b ? recs[i + u * 64] : ~0ull;
+#pragma unroll
+              for (int u = 0; u < U; ++u) apply(r[u]);
+            }
+          }
+        }
+      }
+    }
+    unsigned long long i = fin != nullptr ? hi : lo + threadIdx.x;
     for (; i + (U - 1) * kPartThreads < hi; i += U * kPartThreads) {
       unsigned long long r[U];
 #pragma unroll
@@ -1085,7 +1192,7 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
     const char *wide_env = getenv("TAD_WIDE_KP");
     auto parts_of = [&](int c) { return (K + (1ull << c) - 1) >> c; };
     auto rounds_of = [&](int c) { const uint64_t tb = kTileCells >> c; return tb ? (T + tb - 1) / tb : (uint64_t)1 << 30; };
-    const uint64_t line_parts = kLdsBudget / (8 * 22 + 14);
+    const uint64_t line_parts = kLdsBudget / (8 * 22 + 18);
     if (!(wide_env && atoi(wide_env) == 0) && parts_of(sp) > line_parts) {
       int c = sp;
       while (c < 13 && parts_of(c) > line_parts) ++c;
@@ -1107,8 +1214,8 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   pl->n_chunks = (uint32_t)((T + pl->tb - 1) / pl->tb);
   pl->tb = (uint32_t)((T + pl->n_chunks - 1) / pl->n_chunks);   // same number of rounds, balanced (100 buckets: 34 + 33 + 33, not 34 + 34 + 32 ... + 1)
   pl->agg_lds = ((size_t)pl->tb * pl->KP * 9 + 15) & ~(size_t)15;
-  // pass B: records per tile limited by LDS: 10 B per slot + 12 B per partition
-  const size_t fixed = ((size_t)pl->nparts + 4) * 12 + 64;
+  // pass B: records per tile limited by LDS: 10 B per slot + 16 B per partition
+  const size_t fixed = ((size_t)pl->nparts + 4) * 16 + 64;
   pl->rpt = 0;
   const int mult = has2 ? 2 : 1;
   const char *rpt_env = getenv("TAD_RPT");  // tuning knob: cap the rows per thread of pass B
@@ -1140,8 +1247,8 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, PartPlan *pl) {
   if (env && !strcmp(env, "sort")) return;
   if (!aligned || pl->nparts == 0) return;
   const size_t per = kLdsBudget / pl->nparts;
-  if (per < 14 + 8 * 9) return;
-  uint32_t cap = (uint32_t)((per - 14) / 8);
+  if (per < 18 + 8 * 9) return;
+  uint32_t cap = (uint32_t)((per - 18) / 8);
   if (cap > 64) cap = 64;
   uint32_t sec = cap >= 22 ? 16 : 8;   // 15 leftovers + room for a tile's arrivals
   if (const char *e = getenv("TAD_WC_SEC")) { const int v = atoi(e); if (v == 8 || (v == 16 && cap >= 20)) sec = (uint32_t)v; }
@@ -1164,26 +1271,38 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, PartPlan *pl) {
   pl->pad_slots = pad;
 }
 
-void launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
+bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, uint64_t n, uint64_t K, RowFilter f, const PartPlan &pl,
-                      MetaPartial *partials, uint32_t *binhist, DevCounters *ctr) {
+                      MetaPartial *partials, uint32_t *binhist, DevCounters *ctr, bool sample_hist) {
   const bool vec = aligned16(key) && aligned16(key2) && aligned16(t_end);
   const bool has2 = key2 != nullptr;
-#define TAD_MH(V, H2)                                                                                                  \
+  // the histogram can only be sampled where the time column is (no time-window filter, 16-byte loads)
+  const bool sh = sample_hist && vec && f.end_time == 0 && !(t_start != nullptr && f.start_time != 0);
+#define TAD_MH(V, H2, SH)                                                                                              \
   do {                                                                                                                 \
-    allow_big_lds(reinterpret_cast<const void *>(k_meta_hist<V, H2>), kLdsBudget);                                     \
-    hipLaunchKernelGGL((k_meta_hist<V, H2>), dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n, \
+    allow_big_lds(reinterpret_cast<const void *>(k_meta_hist<V, H2, SH>), kLdsBudget);                                 \
+    hipLaunchKernelGGL((k_meta_hist<V, H2, SH>), dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n, \
                        pl.chunk, K, f, pl.shift_bin, pl.nbins, partials, binhist, ctr);                                \
   } while (0)
-  if (vec) { if (has2) TAD_MH(true, true); else TAD_MH(true, false); }
-  else { if (has2) TAD_MH(false, true); else TAD_MH(false, false); }
+  if (vec) {
+    if (sh) { if (has2) TAD_MH(true, true, true); else TAD_MH(true, false, true); }
+    else { if (has2) TAD_MH(true, true, false); else TAD_MH(true, false, false); }
+  } else { if (has2) TAD_MH(false, true, false); else TAD_MH(false, false, false); }
 #undef TAD_MH
+  return sh;
+}
+
+// 6 sigma of every region summed by Cauchy-Schwarz over R = G * nparts regions whose estimates total <= slots
+uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl) {
+  const double R = (double)pl.G * (double)pl.nparts, scale = 9.0;   // sampling ratio 1/8 plus the chunk ends
+  return slots + (uint64_t)(6.0 * sqrt(scale * R * (double)slots) + R * (8.0 * scale + 16.0 + 16.0)) + 1024;
 }
 
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
-                         unsigned long long *part_start) {
+                         unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n) {
+  // sampled regions are rounded to 16 records (128-byte lines) whatever pass B runs, so that they start line-aligned
   hipLaunchKernelGGL(k_part_rows, dim3(pl.G), dim3(256), 0, s, binhist, pl.nbins, pl.bins_per_part, pl.nparts, offs32,
-                     pl.wc_cap ? pl.wc_sec - 1u : 0u);
+                     sampled ? 15u : (pl.wc_cap ? pl.wc_sec - 1u : 0u), sampled ? partials : nullptr, n, pl.chunk);
   hipLaunchKernelGGL(k_part_colscan, dim3((pl.nparts + 255) / 256), dim3(256), 0, s, offs32, pl.G, pl.nparts, total);
   hipLaunchKernelGGL(k_part_scan1, dim3(1), dim3(kPartThreads), 0, s, total, pl.nparts, part_start);
 }
@@ -1191,8 +1310,9 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, Lattice L,
                       const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start, void *recs,
-                      OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr) {
+                      OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr, uint32_t *fin) {
   PartArgs A;
+  A.fin = fin; A.G = pl.G;
   A.key = key; A.key2 = key2; A.t_end = t_end; A.t_start = t_start; A.value = value;
   A.n = n; A.chunk = pl.chunk; A.K = K; A.f = f; A.L = L;
   A.shift_part = pl.shift_part; A.kp_mask = pl.KP - 1; A.nparts = pl.nparts; A.cell_bits = pl.cell_bits;
@@ -1204,7 +1324,7 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   // fast path: 16-byte loads, no time-window filter, bucket by one multiply-high
   const bool generic = !vec || L.mode == 2 || f.end_time != 0 || (f.start_time != 0 && t_start != nullptr);
   if (pl.wc_cap) {  // write-combining variant (the plan checked the alignment)
-    const size_t wlds = ((size_t)pl.nparts * (8 * (size_t)pl.wc_cap + 14) + 15) & ~(size_t)15;
+    const size_t wlds = ((size_t)pl.nparts * (8 * (size_t)pl.wc_cap + 18) + 15) & ~(size_t)15;
 #define TAD_WC(RPT, SEC, H2, GEN)                                                                                       \
   do {                                                                                                                \
     allow_big_lds(reinterpret_cast<const void *>(k_partition_wc<RPT, SEC, H2, GEN>), kLdsBudget);                      \
@@ -1220,7 +1340,7 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   }
   int rpt = pl.rpt;
   if (generic && rpt > 4) rpt = 4;
-  const size_t fixed = ((size_t)pl.nparts + 4) * 12 + 64;
+  const size_t fixed = ((size_t)pl.nparts + 4) * 16 + 64;
   const size_t lds = ((size_t)rpt * kPartThreads * (has2 ? 2 : 1) * 10 + fixed + 15) & ~(size_t)15;
 #define TAD_PART(RPT, H2, V, GEN)                                                                                       \
   do {                                                                                                                \
@@ -1254,14 +1374,14 @@ bool part_plan_two_level(uint64_t K, uint64_t T, bool has2, bool aligned, uint64
   // 128-key tiles is bound by the 0.9 GB grid it writes, one workgroup per CU, not by the record re-reads the extra level saves.
   const char *env = getenv("TAD_TWO_LEVEL");
   if (!(env && atoi(env) == 1)) return false;
-  if (!aligned || T == 0 || base.nparts <= kLdsBudget / (14 + 8 * 9)) return false;
+  if (!aligned || T == 0 || base.nparts <= kLdsBudget / (18 + 8 * 9)) return false;
   int sp2 = -1;
   for (int c = 13; c >= 0; --c)
     if (((uint64_t)T << c) <= kTileCells) { sp2 = c; break; }
   if (const char *e2 = getenv("TAD_L2_SHIFT")) { const int v = atoi(e2); if (v >= 1 && v < sp2) sp2 = v; }   // tuning knob: narrower level-2 blocks
   if (sp2 < base.shift_bin || sp2 < 1) return false;
   auto parts_of = [&](int c) { return (K + (1ull << c) - 1) >> c; };
-  const uint64_t line_parts = kLdsBudget / (8 * 22 + 14);
+  const uint64_t line_parts = kLdsBudget / (8 * 22 + 18);
   int sp1 = sp2 + 1;
   while (sp1 - sp2 < 5 && parts_of(sp1) > line_parts) ++sp1;
   if (parts_of(sp1) > line_parts) return false;
@@ -1296,7 +1416,7 @@ void launch_repartition(hipStream_t s, const void *recs1, const unsigned long lo
   st.slice_part = static_cast<uint32_t *>(slice_mem);
   st.slice_first = st.slice_part + max_slices;
   st.n_slices = st.slice_first + l1.nparts;
-  hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start1, l1.nparts, st);
+  hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start1, l1.nparts, st, kSliceRecords);
   hipLaunchKernelGGL(k_copy_u64, dim3((l2.nparts + 255) / 256), dim3(256), 0, s, part_start2, cursor2, l2.nparts);
   RepartArgs A;
   A.recs1 = static_cast<const unsigned long long *>(recs1); A.part_start1 = part_start1;
@@ -1316,7 +1436,7 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl) {
 
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
-                           const unsigned long long *ovf_count, uint32_t ovf_cap) {
+                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin) {
   const unsigned long long *rr = static_cast<const unsigned long long *>(recs);
   const uint32_t max_slices = (uint32_t)((size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1);
   SliceTable st;
@@ -1324,19 +1444,22 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   st.slice_first = st.slice_part + max_slices;
   st.n_slices = st.slice_first + pl.nparts;
   allow_big_lds(reinterpret_cast<const void *>(op_max ? k_tile_aggregate<true> : k_tile_aggregate<false>), kLdsBudget);
-  hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st);
-  const bool may_split = slots > kSliceRecords;  // some partition could exceed one slice
+  // regions sized from a sampled histogram hold ~2x the slots of their records: slices twice as long keep one slice per
+  // partition for uniform tables (a split partition merges into the grid with atomics instead of plain stores)
+  const uint32_t slice_len = fin != nullptr ? 2 * kSliceRecords : kSliceRecords;
+  hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st, slice_len);
+  const bool may_split = slots > slice_len;  // some partition could exceed one slice
   const char *pr_env = getenv("TAD_PAR_ROUNDS");
   const uint32_t par = pl.n_chunks > 1 && !(pr_env && atoi(pr_env) == 0) ? 1u : 0u;
-  TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par};
+  TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len};
   const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
   if (op_max) {
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0);
-    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1);
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G);
+    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G);
     hipLaunchKernelGGL((k_apply_overflow<true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
   } else {
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0);
-    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1);
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G);
+    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G);
     hipLaunchKernelGGL((k_apply_overflow<false>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
   }
 }
