@@ -566,7 +566,11 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       if ((rc = ensure(e, e->binhist, (size_t)pl.G * pl.nbins * 4)) != TAD_OK) return rc;
       hist_sampled = launch_meta_hist(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, K, rf,
                                       pl, static_cast<MetaPartial *>(e->meta.p), static_cast<uint32_t *>(e->binhist.p), ctr,
-                                      !force_exact_hist && sampled_slots_bound(n * (has2 ? 2 : 1), pl) < (1ull << 32));
+                                      // small regions (many keys: C4 has ~50 records per workgroup and 128-key block) make pass C's walk
+                                      // over the regions cost more than the sampled pass A saves: sample only when a region of a
+                                      // 128-key block is expected to hold a few hundred records
+                                      !force_exact_hist && sampled_slots_bound(n * (has2 ? 2 : 1), pl) < (1ull << 32) &&
+                                          n * (has2 ? 2 : 1) / ((uint64_t)pl.G * ((K >> 7) ? (K >> 7) : 1)) >= 384);
       meta_blocks = pl.G;
     }
     if (!hinted && !empty && (!v2 || lat_mode == 2)) {

@@ -986,12 +986,13 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
             b = b > r_end ? r_end : b;
             a = a < lo ? lo : a;             // clip to this slice
             b = b > hi ? hi : b;
-            for (unsigned long long i = a + lane; i < b; i += U * 64) {
-              unsigned long long r[U];
+            constexpr int UR = 12;   // a region of the uniform C2 table holds ~500 +- 22 records: one batch of 768 covers it
+            for (unsigned long long i = a + lane; i < b; i += UR * 64) {
+              unsigned long long r[UR];
 #pragma unroll
-              for (int u = 0; u < U; ++u) r[u] = i + u * 64 < b ? recs[i + u * 64] : ~0ull;
+              for (int u = 0; u < UR; ++u) r[u] = i + u * 64 < b ? recs[i + u * 64] : ~0ull;
 #pragma unroll
-              for (int u = 0; u < U; ++u) apply(r[u]);
+              for (int u = 0; u < UR; ++u) apply(r[u]);
             }
           }
         }
