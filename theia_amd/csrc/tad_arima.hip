@@ -717,6 +717,7 @@ __global__ __launch_bounds__(64) void k_arima_start(Grid g, ArimaWs ws, const ui
 // ------------------------------------------------------------------------------------------------
 static constexpr int kStage = 8;  // time steps staged per round: 64 B per row
 
+template <int CHAINS>
 __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double *__restrict__ sigma,
                                                const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax, uint32_t chunk,
                                                double *__restrict__ calc, DevCounters *ctr, double *buf) {
@@ -789,8 +790,87 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     return kf_finish(s, p);
   };
 
+  // CHAINS == 4: f at x and at the three forward-difference points in ONE pass over the series — four independent Kalman
+  // recursions per lane.  Same arithmetic per recursion (bit-identical results); the series is staged once instead of four
+  // times and, above all, the four dependency chains interleave: the loop is bound by FP64 dependency latency (one division
+  // and ~25 dependent operations per step), not by issue, at the 2-3 wavefronts per SIMD its register footprint allows.
+  auto evaluate4 = [&](const double (&xe)[4][3], double (&nll)[4], double &fc) {
+    KfState s4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      kf_init(s4[c], xe[c][0], xe[c][1], xe[c][2]);
+      if (!busy) s4[c].conv = true;
+    }
+    for (uint32_t t0 = 0; t0 < p; t0 += kStage) {
+      double2 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const double2 *>(ws.ysk + row[j] + t0);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double *d = buf + (size_t)(j * 16 + (int)(lane >> 2)) * (kStage + 1) + (lane & 3u) * 2u;
+        d[0] = v[j].x; d[1] = v[j].y;
+      }
+      __syncthreads();
+      double yv[kStage];
+#pragma unroll
+      for (int i = 0; i < kStage; ++i) yv[i] = buf[(size_t)lane * (kStage + 1) + i];
+      const uint32_t nb = p - t0 < (uint32_t)kStage ? p - t0 : (uint32_t)kStage;
+#pragma unroll
+      for (int i = 0; i < kStage; ++i)
+        if ((uint32_t)i < nb) {
+          const bool any_conv = __any(s4[0].conv || s4[1].conv || s4[2].conv || s4[3].conv);
+          if (!any_conv) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kf_step_nc(s4[c], yv[i], t0 + (uint32_t)i >= 1u);
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kf_step(s4[c], yv[i], t0 + (uint32_t)i);
+          }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const KfOut r = kf_finish(s4[c], p);
+      nll[c] = r.nll;
+      if (c == 0) fc = r.forecast;
+    }
+  };
+
   refill();
-  while (__any(busy)) {
+  while (CHAINS == 4 && __any(busy)) {
+    double xe[4][3], dx[3], nll[4], fc0 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      xe[c][0] = o.x[0]; xe[c][1] = o.x[1]; xe[c][2] = o.x[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double x0 = xe[i + 1][i];
+      xe[i + 1][i] = x0 + 1e-5;
+      dx[i] = xe[i + 1][i] - x0;
+    }
+    evaluate4(xe, nll, fc0);
+    if (busy) {
+      steps += 4ull * p;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o.g[i] = (nll[i + 1] - nll[0]) / dx[i];
+      o.f = nll[0];
+      o.fc = fc0;
+      lbfgs_deliver(o, maxiter);
+      if (o.done) {
+        const size_t st = g.K;
+        const uint64_t c = (uint64_t)ws.tpos[(size_t)p * st + k] * g.K + k;
+        const double pred = inv_boxcox(o.fc, ws.lam[k]);
+        calc[c] = pred;
+        if (fabs(ws.xs[(size_t)p * st + k] - pred) > sigma[k]) g.flag[c] = FLAG_PRESENT | FLAG_ANOMALY;
+        fits++;
+        busy = false;
+      }
+    }
+    refill();
+  }
+  while (CHAINS == 1 && __any(busy)) {
     double f0 = 0.0, fc0 = 0.0;
     for (int phase = 0; phase < 4; ++phase) {
       double xe0 = o.x[0], xe1 = o.x[1], xe2 = o.x[2], dx = 1.0;
@@ -833,18 +913,18 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
 // The register budget decides how many wavefronts share a SIMD (512 VGPRs: 128 -> 4, 96 -> 5, 80 -> 6, 64 -> 8); the
 // optimiser's state is only touched between evaluations, so a tighter budget spills exactly that to scratch and buys
 // latency hiding for the Kalman loop.  One kernel per budget; TAD_ARIMA_WAVES picks (default: measured best).
-#define TAD_ARIMA_FIT_KERNEL(W)                                                                                          \
-  __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void k_arima_fit_w##W(                    \
+#define TAD_ARIMA_FIT_KERNEL(NAME, W, CH)                                                                                \
+  __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void NAME(                                \
       Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,  \
       uint32_t chunk, double *__restrict__ calc, DevCounters *ctr) {                                                    \
     __shared__ double buf[64 * (kStage + 1)];                                                                           \
-    arima_fit_body(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf);                                          \
+    arima_fit_body<CH>(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf);                                      \
   }
-TAD_ARIMA_FIT_KERNEL(3)
-TAD_ARIMA_FIT_KERNEL(4)
-TAD_ARIMA_FIT_KERNEL(5)
-TAD_ARIMA_FIT_KERNEL(6)
-TAD_ARIMA_FIT_KERNEL(8)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_w3, 3, 1)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_w4, 4, 1)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w1, 1, 4)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w2, 2, 4)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w3, 3, 4)
 #undef TAD_ARIMA_FIT_KERNEL
 
 static uint32_t arima_tpad(uint64_t T) { return (uint32_t)((T + kStage - 1) / kStage * kStage); }
@@ -880,15 +960,19 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
     const uint64_t nchunks = (g.K + chunk - 1) / chunk;
     const uint64_t blocks = nchunks * (g.T - 3);
     if (blocks > 0x7FFFFFFFull) return -1;
-    int waves = 3;   // measured at C3: 3 -> 0.90 s, 4 -> 0.93 s, 5 -> 1.5 s, 6 -> 1.7 s, 8 -> 2.4 s (the loop is FP64-issue bound; spills cost more than occupancy buys)
+    // measured at C3 — one chain per lane: 3 wavefronts per SIMD 0.89 s, 4 -> 0.93 s, 5 -> 1.5 s, 8 -> 2.4 s (spills);
+    // four chains per lane: 2 wavefronts per SIMD 0.77 s, 1 -> 1.06 s, 3 -> 1.9 s (spills)
+    int waves = 2, chains = 4;
     if (const char *e = getenv("TAD_ARIMA_WAVES")) waves = atoi(e);
-#define TAD_ARIMA_LAUNCH(W) hipLaunchKernelGGL(k_arima_fit_w##W, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, chunk, calc, ctr)
-    switch (waves) {
-      case 4: TAD_ARIMA_LAUNCH(4); break;
-      case 5: TAD_ARIMA_LAUNCH(5); break;
-      case 6: TAD_ARIMA_LAUNCH(6); break;
-      case 8: TAD_ARIMA_LAUNCH(8); break;
-      default: TAD_ARIMA_LAUNCH(3); break;
+    if (const char *e = getenv("TAD_ARIMA_CHAINS")) chains = atoi(e);
+#define TAD_ARIMA_LAUNCH(NAME) hipLaunchKernelGGL(NAME, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, chunk, calc, ctr)
+    if (chains == 4) {
+      if (waves == 1) TAD_ARIMA_LAUNCH(k_arima_fit_c4w1);
+      else if (waves == 3) TAD_ARIMA_LAUNCH(k_arima_fit_c4w3);
+      else TAD_ARIMA_LAUNCH(k_arima_fit_c4w2);
+    } else {
+      if (waves == 4) TAD_ARIMA_LAUNCH(k_arima_fit_w4);
+      else TAD_ARIMA_LAUNCH(k_arima_fit_w3);   // TAD_ARIMA_CHAINS=1
     }
 #undef TAD_ARIMA_LAUNCH
   }
