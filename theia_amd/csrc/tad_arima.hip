@@ -17,12 +17,11 @@
 // xtol 0.1) — the unconstrained path of L-BFGS-B 3.0, where the subspace step equals the two-loop
 // L-BFGS direction with H0 = (s'y / y'y) I.
 //
-// GPU mapping: there is no dense contraction here (3 parameters, 3 states): the work is ~200 sequential
-// likelihood evaluations per fit, each a sequential Kalman recursion over the history.  Parallelism is
-// across the P - 3K independent fits.  A wavefront takes 64 consecutive keys at the SAME series position,
-// so all lanes run Kalman loops of the same length; the optimiser is a per-lane state machine that asks
-// for exactly one likelihood evaluation per trip, so lanes in different optimiser phases (gradient
-// component, line-search trial, final forecast) still execute the expensive part in lockstep.
+// GPU mapping: there is no dense contraction here (3 parameters, 3 states): the work is ~80 cycles of four likelihood
+// evaluations per fit, each a sequential Kalman recursion over the history.  Parallelism is across the P - 3K independent
+// fits.  A wavefront takes a chunk of keys at ONE series position (every lane's Kalman loop has the same length) and its
+// lanes pull the next key as soon as their fit has converged; the four evaluations of an optimiser cycle run as four
+// interleaved recursions per lane; the optimiser itself is a per-lane state machine stepped once per cycle (k_arima_fit).
 #include <cstdlib>
 
 #include "tad_internal.h"
