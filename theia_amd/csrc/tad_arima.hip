@@ -17,7 +17,7 @@
 // xtol 0.1) — the unconstrained path of L-BFGS-B 3.0, where the subspace step equals the two-loop
 // L-BFGS direction with H0 = (s'y / y'y) I.
 //
-// GPU mapping: there is no dense contraction here (3 parameters, 3 states): the work is ~80 cycles of four likelihood
+// GPU mapping: there is no dense contraction here (3 parameters, 3 states): the work is ~20 optimiser cycles of four likelihood
 // evaluations per fit, each a sequential Kalman recursion over the history.  Parallelism is across the P - 3K independent
 // fits.  A wavefront takes a chunk of keys at ONE series position (every lane's Kalman loop has the same length) and its
 // lanes pull the next key as soon as their fit has converged; the four evaluations of an optimiser cycle run as four
