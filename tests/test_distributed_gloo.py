@@ -69,7 +69,7 @@ def free_port():
 
 
 @pytest.mark.parametrize("world,mode,algo,pod", [(2, "key", "EWMA", False), (2, "rows", "EWMA", True), (3, "key", "DBSCAN", True),
-                                                 (2, "rows", "DBSCAN", False)])
+                                                 (2, "rows", "DBSCAN", False), (2, "rows", "ARIMA", False), (2, "key", "ARIMA", False)])
 def test_sharded_job_equals_single_process(world, mode, algo, pod):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -86,7 +86,7 @@ def test_sharded_job_equals_single_process(world, mode, algo, pod):
     cat = {f: np.concatenate([g[1][f] for g in sorted(got, key=lambda g: g[0])]) for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev")}
     order = np.lexsort((cat["flow_end_s"], cat["key_id"]))
     for f in cat:
-        assert (cat[f][order] == want[f]).all(), f                 # the union of the shards' rows IS the single-GPU result
+        assert np.array_equal(cat[f][order], want[f], equal_nan=True), f   # the union of the shards' rows IS the single-GPU result
     x = orc.u64_to_f64(want["points"][2])
     for _, _, glob in got:
         assert glob["n_anomalies"] == want["n_anomalies"] and glob["n_keys"] == want["n_keys"] and glob["n_points"] == want["n_points"]
