@@ -66,11 +66,12 @@ def test_c5_row_sharded_two_ranks_equal_one_rank(tmp_path):
 
 
 def test_shard_rows_buckets_by_owner(engine):
-    import torch
+    from theia_amd.engine import DeviceArray
     k, t, v = orc.synth_rows(5, 300_000, 5000, 40)
     k[::97] = orc.KEY_SKIP
-    dev = torch.device("cuda", engine.device)
-    tk, tt, tv = (torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x).to(dev) for x in (k, t, v))
+    # engine-owned device arrays (no torch in this process: the torch wheel carries its own HIP runtime, and which of two
+    # runtimes in one process gets the device is not something a test should depend on; bench.py initialises torch first)
+    tk, tt, tv = (DeviceArray.from_host(engine, x) for x in (k, t, v))
     for world in (1, 3, 8):
         (dk, dt, dv), counts = engine.shard_rows(tk, tt, tv, world)
         hk, ht, hv = dk.to_host(), dt.to_host(), dv.to_host()
@@ -86,3 +87,18 @@ def test_shard_rows_buckets_by_owner(engine):
             pos += counts[d]
         for a in (dk, dt, dv):
             a.free()
+
+
+def test_default_config_key_sharded_two_ranks(tmp_path):
+    # the weak-scaling path the driver launches (`bench.py --gpus N`, key-sharded, one all-gather per job), reduced in size,
+    # two ranks on one GPU: the line must describe the whole job (both ranks' rows), and the reduced counters must add up
+    env = dict(os.environ, TAD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "3000000", "--keys", "3000",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT).stdout
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["metric"] == "flow-records/sec"
+    assert d["result"]["rows_used"] == 2 * 3_000_000 and d["result"]["keys"] == 2 * 3000
+    assert abs(d["value"] - 2 * 3_000_000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9       # whole-job rate over both ranks
+    assert "other_configs" not in d and "cpu_baseline" not in d and d["roofline"]["frac"] > 0

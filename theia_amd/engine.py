@@ -31,6 +31,15 @@ class DeviceArray:
         engine._check(engine._lib.tad_device_alloc(engine._h, self.n * self.dtype.itemsize, C.byref(ptr)))
         self.ptr = ptr.value
 
+    @classmethod
+    def from_host(cls, engine, array):
+        """device copy of an 8-byte numpy array (tad_device_alloc + tad_copy_to_device)"""
+        a = np.ascontiguousarray(array)
+        d = cls(engine, a.size, a.dtype)
+        if a.size:
+            engine._check(engine._lib.tad_copy_to_device(engine._h, d.ptr, a.ctypes.data, a.nbytes))
+        return d
+
     def to_host(self):
         out = np.empty(self.n, dtype=self.dtype)
         if self.n:
