@@ -101,7 +101,7 @@ size_t sparse_sort_temp_bytes(uint64_t slots) {
   hipcub::DeviceReduce::ReduceByKey(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
                                     (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, SumOp(),
                                     slots);
-  return (a > b ? a : b) + 256;
+  return (((a > b ? a : b) + 255) & ~(size_t)255) + 256;   // 256-byte multiple: the caller places two counters right behind it
 }
 
 // rows -> sorted unique (key, time) points with aggregated values: ucomp / uval (device), *num_runs (device)
