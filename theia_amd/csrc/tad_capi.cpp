@@ -569,7 +569,8 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
                                       // small regions (many keys: C4 has ~50 records per workgroup and 128-key block) make pass C's walk
                                       // over the regions cost more than the sampled pass A saves: sample only when a region of a
                                       // 128-key block is expected to hold a few hundred records
-                                      !force_exact_hist && sampled_slots_bound(n * (has2 ? 2 : 1), pl) < (1ull << 32) &&
+                                      // (lat_mode 2 re-derives the lattice with k_meta, which reuses the partials buffer the sampling ratios live in)
+                                      !force_exact_hist && lat_mode != 2 && sampled_slots_bound(n * (has2 ? 2 : 1), pl) < (1ull << 32) &&
                                           n * (has2 ? 2 : 1) / ((uint64_t)pl.G * ((K >> 7) ? (K >> 7) : 1)) >= 384);
       meta_blocks = pl.G;
     }
