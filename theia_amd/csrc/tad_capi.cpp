@@ -618,7 +618,8 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     // ---- Stage 0: GROUP BY (key, flowEndSeconds) into the time-major point grid ----
     uint64_t cells = empty ? 0 : K * L.nb;
     const bool cells_overflow = !empty && L.nb != 0 && cells / L.nb != K;
-    uint64_t need = cells * 9 + ((jp.algo == TAD_ALGO_ARIMA || jp.algo == TAD_ALGO_DROP) ? cells * 8 : 0);
+    // (ARIMA: predictions + 60 B per cell of workspace, arima_workspace_bytes; DROP: one double per cell)
+    uint64_t need = cells * 9 + (jp.algo == TAD_ALGO_ARIMA ? cells * 68 : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
     // Sparse tables (few points per key on a fine lattice: second-resolution timestamps, per-connection keys): the dense
     // K x T grid would be mostly empty or not fit at all — sort the rows by (key, time) instead and lay each key's points
     // out by rank (tad_sparse.hip).  Chosen when the rows could fill at most 1/8 of a large grid, or the grid does not fit.
@@ -660,7 +661,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
         HIP_TRY(e, hipStreamSynchronize(s));
       }
       cells = K * (uint64_t)tmax;
-      need = cells * 17 + ((jp.algo == TAD_ALGO_ARIMA || jp.algo == TAD_ALGO_DROP) ? cells * 8 : 0);
+      need = cells * 17 + (jp.algo == TAD_ALGO_ARIMA ? cells * 68 : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
       if (need > e->ws_limit)
         return fail(e, TAD_ERR_GRID_TOO_LARGE, "sparse point grid needs %llu bytes (%llu keys x longest series %u points) > workspace limit %llu",
                     (unsigned long long)need, (unsigned long long)K, tmax, (unsigned long long)e->ws_limit);
