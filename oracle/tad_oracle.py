@@ -359,6 +359,8 @@ def synth_rows_parallel(n_rows, num_keys, n_buckets, procs=None, chunk=5_000_000
     if procs <= 1:
         parts = [synth_rows(*j) for j in jobs]
     else:
-        with cf.ProcessPoolExecutor(procs) as ex:
+        import multiprocessing as mp
+        # spawn, not fork: the GPU tests call this from a process that has the HIP runtime loaded
+        with cf.ProcessPoolExecutor(procs, mp_context=mp.get_context("spawn")) as ex:
             parts = list(ex.map(_synth_chunk, jobs))
     return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
