@@ -96,10 +96,10 @@ def cpu_sample(algo, rows, keys, cores):
     return cr, max(1, cr // rpk), min(cr, 20_000_000)
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, name="pmc_latest.json"):
     """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
         k = d["kernels"][kernel]
         return {"bytes": k["fetch_bytes"] + k["write_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
@@ -340,6 +340,9 @@ def main():
             r = run_config(c["algos"], c["rows"], c["keys"], c["buckets"], c["agg"], steps, warmup)
             d = describe(r)
             d["baseline_config"] = name
+            if name == "c4":     # PMC passes of `bench.py --config c4` (profiles/README.md)
+                d["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(r["stats"][0]["stage0_path"], "k_scatter"),
+                                                       "r2_v3_pmc_c4.json")
             if not args.no_cpu_baseline:
                 cr, ck, sr = cpu_sample(c["algos"][0], c["rows"], c["keys"], cores)
                 try:
