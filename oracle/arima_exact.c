@@ -160,6 +160,7 @@ static double inv_boxcox(double y, double lam) {       /* scipy.special.inv_boxc
  * over the series with the covariance update skipped once converged.
  * --------------------------------------------------------------------------------------------------------------- */
 static long long g_steps;   /* filter time-steps executed (reported next to the GPU's kalman_steps counter) */
+static double *g_trace; static long g_trace_cap, g_trace_n;   /* debugging: every evaluation (x[3], f) of a traced fit */
 
 static double arima_nll(const double u[3], const double *y, long n, double *forecast) {
   const double phi = u[0] / sqrt(1.0 + u[0] * u[0]);
@@ -206,6 +207,7 @@ static double arima_nll(const double u[3], const double *y, long n, double *fore
   if (nconv) sumlog += (double)nconv * tad_det_log(F);
   llf = -0.5 * ((double)(n - 1) * LOG_2PI + sumlog) - 0.5 * q;
   if (forecast) *forecast = a0 + a1;
+  if (g_trace && g_trace_n < g_trace_cap) { double *r = g_trace + 4 * g_trace_n++; r[0] = u[0]; r[1] = u[1]; r[2] = u[2]; r[3] = -llf / (double)n; }
   return -llf / (double)n;
 }
 
@@ -428,6 +430,11 @@ static void eval_fg(const struct fitctx *c, const double x[3], double *f, double
     double dx;
     xe[i] = x0 + 1e-5;
     dx = xe[i] - x0;
+    if (dx == 0.0) {   /* scipy _numdiff.approx_derivative: an absolute step that does not change x falls back to the relative step */
+      const double h = 1.4901161193847656e-08 * (x0 >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(x0));
+      xe[i] = x0 + h;
+      dx = xe[i] - x0;
+    }
     g[i] = (arima_nll(xe, c->y, c->n, 0) - f0) / dx;
   }
   *f = f0;
@@ -610,3 +617,11 @@ int arima_exact_fit_profile(const double *x, long n, int maxiter, double *evals)
   return 1;
 }
 double arima_exact_frexp(double x, int *e) { return tad_det_frexp(x, e); }
+
+/* debugging: the evaluations of one fit, rows of (x0, x1, x2, f) */
+long arima_exact_trace_fit(const double *y, long n, int maxiter, double *buf, long cap, double *forecast) {
+  g_trace = buf; g_trace_cap = cap; g_trace_n = 0;
+  *forecast = fit_forecast(y, n, maxiter, 0);
+  g_trace = 0;
+  return g_trace_n;
+}

@@ -609,6 +609,20 @@ TAD_HD void lbfgs_direction(Lbfgs &o) {
   for (int c = 0; c < 3; ++c) o.d[c] = -q[c];
 }
 
+// forward-difference point of scipy's approx_derivative(method='2-point', abs_step=1e-5): x + 1e-5, unless that does not
+// change x (|x| > ~1e11: the huge sigma parameters of void Box-Cox regimes) — then the relative step sqrt(eps) * sign(x) *
+// max(1, |x|) (scipy/optimize/_numdiff.py: "cannot have a zero step ... fall back to relative step").  Returns x + h.
+TAD_HD inline double fd_point(double x0, double *dx) {
+  double xe = x0 + 1e-5;
+  *dx = xe - x0;
+  if (*dx == 0.0) {
+    const double h = 1.4901161193847656e-08 * (x0 >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(x0));
+    xe = x0 + h;
+    *dx = xe - x0;
+  }
+  return xe;
+}
+
 // begin a line search from the current (x, f, g); sets the first trial point in x
 TAD_HD void lbfgs_begin_ls(Lbfgs &o) {
   for (;;) {
@@ -844,11 +858,7 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
       xe[c][0] = o.x[0]; xe[c][1] = o.x[1]; xe[c][2] = o.x[2];
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const double x0 = xe[i + 1][i];
-      xe[i + 1][i] = x0 + 1e-5;
-      dx[i] = xe[i + 1][i] - x0;
-    }
+    for (int i = 0; i < 3; ++i) xe[i + 1][i] = fd_point(xe[i + 1][i], &dx[i]);
     evaluate4(xe, nll, fc0);
     if (busy) {
       steps += 4ull * p;
@@ -875,9 +885,7 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
       double xe0 = o.x[0], xe1 = o.x[1], xe2 = o.x[2], dx = 1.0;
       if (phase >= 1) {
         double *xe = phase == 1 ? &xe0 : (phase == 2 ? &xe1 : &xe2);
-        const double x0 = *xe;
-        *xe = x0 + 1e-5;
-        dx = *xe - x0;
+        *xe = fd_point(*xe, &dx);
       }
       const KfOut r = evaluate(xe0, xe1, xe2);
       if (busy) {

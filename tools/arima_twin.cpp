@@ -15,7 +15,7 @@ static double twin_fit(const double *y, uint32_t p, int maxiter, unsigned long l
     double f0 = 0.0, fc0 = 0.0;
     for (int phase = 0; phase < 4; ++phase) {
       double xe[3] = {o.x[0], o.x[1], o.x[2]}, dx = 1.0;
-      if (phase >= 1) { const double x0 = xe[phase - 1]; xe[phase - 1] = x0 + 1e-5; dx = xe[phase - 1] - x0; }
+      if (phase >= 1) xe[phase - 1] = fd_point(xe[phase - 1], &dx);
       const KfOut r = arima_nll(xe[0], xe[1], xe[2], y, 1, p);
       *steps += p;
       if (phase == 0) { f0 = r.nll; fc0 = r.forecast; }
