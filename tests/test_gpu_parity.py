@@ -109,6 +109,24 @@ def test_job_synthetic_tables_match_oracle(engine, stage0, algo, n_rows, K, T):
     assert res.stats["stage0_path"] == {"v1": 1, "v2": 2, "v2wc": 3}[stage0]
 
 
+@pytest.mark.parametrize("emit_env", [{}, {"TAD_EMIT_CAP": "64"}, {"TAD_EMIT_STAGED": "0"}])
+def test_job_ewma_emit_staged_rows_overflow_and_direct_variants(engine, stage0, emit_env):
+    """The EWMA emit parks a wavefront's rows in LDS and stores them coalesced (k_emit_staged); rows beyond the LDS
+    capacity are stored directly.  Default capacity, a capacity of one row per key (most rows overflow) and the
+    lane-per-key kernel k_emit must all give the oracle's rows; K is not a multiple of 64."""
+    if stage0 != "v2wc":
+        pytest.skip("emit does not depend on the Stage-0 strategy")
+    K, T = 1000 + 37, 250
+    k, t, v = orc.synth_rows(0, 400_000, K, T)
+    os.environ.update(emit_env)
+    try:
+        res, want = check_job(engine, "EWMA", k, t, v, K, agg_flow="svc")
+    finally:
+        for name in emit_env:
+            os.environ.pop(name, None)
+    assert want["n_anomalies"] > 64 * 16
+
+
 @pytest.mark.parametrize("algo", ["EWMA", "DBSCAN"])
 def test_job_max_mode_per_connection(engine, algo):
     k, t, v = orc.synth_rows(0, 200000, 5000, 100)      # mode None: max(throughput), ~0.4 rows/point

@@ -378,11 +378,11 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
   return TAD_OK;
 }
 
-void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows out) {
+void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows out, uint64_t rows = 0) {
   const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : (jp.algo == TAD_ALGO_DROP ? 3 : (jp.lazy_sigma ? 4 : 2)));
   launch_emit(e->stream, g, L, kind, jp.all_points, jp.alpha, static_cast<const double *>(e->sigma.p),
               static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(kind == 3 ? e->key_mean.p : e->calc.p),
-              static_cast<const unsigned long long *>(e->off.p), out);
+              static_cast<const unsigned long long *>(e->off.p), out, rows);
 }
 
 int make_result(tad_engine *e, uint64_t rows, bool with_anomaly, tad_mem out_memory, ResultPriv **out, OutRows *dev_rows,
@@ -898,7 +898,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       launch_stream(s, g, L, jp.alpha, jp.all_points, true, state_view(stream, stream->cur), state_view(stream, stream->cur ^ 1),
                     nullptr, static_cast<const unsigned long long *>(e->off.p), dev_rows, ctr);
     else if (rows)
-      emit_rows(e, g, L, jp, dev_rows);
+      emit_rows(e, g, L, jp, dev_rows, rows);
     {
       const hipError_t er = hipEventRecord(e->ev[4], s);
       if (er != hipSuccess) {

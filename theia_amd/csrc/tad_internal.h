@@ -156,7 +156,7 @@ size_t scan_scratch_elems(uint64_t K);
 // 4 = 2 with the stddev column computed here (Spark's streaming update over the key's series) for the keys that have rows
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
-                 const unsigned long long *off, OutRows out);
+                 const unsigned long long *off, OutRows out, uint64_t rows_hint = 0);   // rows_hint: off[K] if the caller knows it
 void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long long *off, unsigned long long *out_key,
                         long long *out_t, unsigned long long *out_val);
 // streaming EWMA: per-key running state (tad_state); k_stream continues the recurrences over the new grid

@@ -8,6 +8,8 @@
 //   EWMA     :146-165  e_t = (1-a) e_{t-1} + a float(x_t), e_-1 = 0
 //   verdict  :168-212  |float(x_t) - e_t| > stddev  (strict; stddev null -> False)
 //   filter   :352-421  keep anomaly == True
+#include <cstdlib>
+
 #include "tad_internal.h"
 
 namespace tad {
@@ -566,10 +568,103 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
   }
 }
 
+// k_emit_staged — the EWMA job's emit (KIND 0, anomalous rows only) with COALESCED row stores.
+// k_emit's lanes each store their own key's rows: ~5 lanes of a wavefront per time step, every one a separate partial-line
+// write (and, on gfx9, stores share vmcnt with the walk's prefetched loads).  Four lanes per key did not help (§3 table):
+// the kernel is bound by those write transactions.  Here one wavefront = 64 consecutive keys, whose rows are ONE contiguous
+// range [off[k0], off[k0 + 64]) of every output column: during the walk a lane parks (e_t, lane, t) of each anomalous point
+// in LDS at its row's position inside that range (12 B per row), and afterwards the wavefront writes the range row by row —
+// five fully coalesced stores per 64 rows; throughput is re-read from the grid cell the marker names (an L2 / MALL hit: the
+// wavefront has just walked it) and sigma comes from a 64-entry LDS table.  Rows past the LDS capacity (a wavefront with
+// far more anomalies than usual) are stored directly, as k_emit does, so any capacity >= 0 is correct.
+static constexpr int kStageMarkTBits = 26;   // marker = lane << 26 | t
+__global__ __launch_bounds__(64) void k_emit_staged(Grid g, Lattice L, double alpha, const double *__restrict__ sigma,
+                                                    const uint32_t *__restrict__ n_pts,
+                                                    const unsigned long long *__restrict__ off, OutRows out, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_stage[];
+  double *s_e = reinterpret_cast<double *>(smem_stage);                       // [cap]
+  double *s_sg = s_e + cap;                                                   // [64]
+  uint32_t *s_m = reinterpret_cast<uint32_t *>(s_sg + 64);                    // [cap]
+  const uint32_t lane = threadIdx.x;
+  const uint64_t k0 = (uint64_t)blockIdx.x * 64;
+  const uint64_t k = k0 + lane;
+  const uint64_t kend = k0 + 64 < g.K ? k0 + 64 : g.K;
+  const unsigned long long base = off[k0];
+  const unsigned long long total = off[kend] - base;
+  if (total == 0) return;   // uniform over the wavefront
+  const bool live = k < g.K;
+  unsigned long long pos = live ? off[k] - base : 0;
+  const unsigned long long end = live ? off[k + 1] - base : 0;
+  const double sg = live ? sigma[k] : 0.0;
+  s_sg[lane] = sg;
+  if (pos != end) {   // n_anom > 0 implies a defined sigma (k_key_sigma counts nothing otherwise)
+    const double one_minus = 1.0 - alpha;
+    double e = 0.0;
+    walk_series(g, k, [&](uint64_t t, uint8_t fl, unsigned long long raw) {
+      if (!(fl & FLAG_PRESENT)) return;
+      const double x = (double)raw;
+      e = one_minus * e + alpha * x;
+      if (fabs(x - e) > sg && pos < end) {
+        if (pos < cap) {
+          s_e[pos] = e;
+          s_m[pos] = (lane << kStageMarkTBits) | (uint32_t)t;
+        } else {
+          const unsigned long long at = base + pos;
+          out.key_id[at] = k;
+          out.flow_end_s[at] = g.times != nullptr ? g.times[t * g.K + k] : (long long)(L.t0 + (int64_t)t * L.step);
+          out.throughput[at] = x;
+          out.algo_calc[at] = e;
+          out.stddev[at] = sg;
+        }
+        pos++;
+      }
+    });
+  }
+  __syncthreads();
+  const unsigned long long staged = total < cap ? total : cap;
+  for (unsigned long long r = lane; r < staged; r += 64) {
+    const uint32_t m = s_m[r];
+    const uint32_t ln = m >> kStageMarkTBits;
+    const uint64_t t = m & ((1u << kStageMarkTBits) - 1u);
+    const uint64_t cell = t * g.K + (k0 + ln);
+    const unsigned long long at = base + r;
+    out.key_id[at] = k0 + ln;
+    out.flow_end_s[at] = g.times != nullptr ? g.times[cell] : (long long)(L.t0 + (int64_t)t * L.step);
+    out.throughput[at] = (double)g.val[cell];
+    out.algo_calc[at] = s_e[r];
+    out.stddev[at] = s_sg[ln];
+  }
+}
+
+// LDS rows per wavefront.  The mean row count of a 64-key range plus 1/8 plus 128 rows (C2: 1290 -> 1600 rows, 19.3 KB:
+// eight wavefronts per CU, so that its 1563 wavefronts are resident together; 2048 rows = six per CU put 27 of them into a
+// second round: 254 vs 223 us for detect + emit).  TAD_EMIT_STAGED=0 -> k_emit; TAD_EMIT_CAP=<rows> pins the capacity (tests).
+static uint32_t emit_stage_rows(uint64_t K, uint64_t rows_hint) {
+  const char *on = getenv("TAD_EMIT_STAGED");
+  if (on != nullptr && on[0] == '0') return 0;
+  uint64_t cap = 1536;
+  if (rows_hint != 0) {
+    const uint64_t mean = (rows_hint * 64 + K - 1) / K;
+    cap = mean + mean / 8 + 128;
+  }
+  if (const char *c = getenv("TAD_EMIT_CAP")) cap = (uint64_t)atol(c);
+  cap = (cap + 63) & ~63ull;
+  if (cap < 64) cap = 64;
+  if (cap > 4096) cap = 4096;
+  return (uint32_t)cap;
+}
+
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
-                 const unsigned long long *off, OutRows out) {
+                 const unsigned long long *off, OutRows out, uint64_t rows_hint) {
   if (g.K == 0) return;
+  if (kind == 0 && !all_points && g.T < (1ull << kStageMarkTBits)) {
+    if (const uint32_t cap = emit_stage_rows(g.K, rows_hint)) {
+      const unsigned blocks64 = (unsigned)((g.K + 63) / 64);
+      hipLaunchKernelGGL(k_emit_staged, dim3(blocks64), dim3(64), (size_t)cap * 12 + 64 * 8, s, g, lat, alpha, sigma, n_pts, off, out, cap);
+      return;
+    }
+  }
   const int blocks = (int)((g.K + kBlock - 1) / kBlock);
 #define TAD_LAUNCH_EMIT(KIND, ALL) \
   hipLaunchKernelGGL((k_emit<KIND, ALL>), dim3(blocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out)
