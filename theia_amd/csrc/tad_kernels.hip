@@ -341,12 +341,27 @@ __global__ __launch_bounds__(kBlock) void k_moments(uint64_t K, const uint32_t *
   Moments acc{0.0, 0.0, 0.0};
   unsigned long long pts = 0, keys = 0;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < K; k += stride) {
-    const uint32_t n = n_pts[k];
-    Moments m{(double)n, key_mean[k], key_m2[k]};
-    acc = chan_merge(acc, m);
-    pts += n;
-    keys += n > 0;
+  // The merge order is fixed (strided per thread); the loads are not part of that chain: eight keys' triples are fetched
+  // together, then merged in order — at 1e6 keys a thread has ~30 keys and the loop was 30 dependent memory round trips
+  // (C4: detect + emit 0.50 -> 0.48 ms).
+  constexpr int kMU = 8;
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < K; k += stride * kMU) {
+    uint32_t n[kMU];
+    double mean[kMU], m2[kMU];
+#pragma unroll
+    for (int u = 0; u < kMU; ++u) {
+      const uint64_t ku = k + (uint64_t)u * stride;
+      const bool in = ku < K;
+      n[u] = in ? n_pts[ku] : 0u;
+      mean[u] = in ? key_mean[ku] : 0.0;
+      m2[u] = in ? key_m2[ku] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kMU; ++u) {
+      acc = chan_merge(acc, Moments{(double)n[u], mean[u], m2[u]});   // n == 0 (also: past the end) leaves acc unchanged
+      pts += n[u];
+      keys += n[u] > 0;
+    }
   }
   if (ctr != nullptr) {
     for (int d = 32; d >= 1; d >>= 1) { pts += __shfl_down(pts, d); keys += __shfl_down(keys, d); }
