@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
                                                             uint64_t n, uint64_t chunk, uint64_t K, RowFilter f,
                                                             int shift_bin, uint32_t nbins,
                                                             MetaPartial *__restrict__ partials,
-                                                            uint32_t *__restrict__ binhist, DevCounters *ctr) {
+                                                            uint32_t *__restrict__ binhist, DevCounters *ctr, int prefetch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
   for (uint32_t i = threadIdx.x; i < nbins; i += kPartThreads) hist[i] = 0;
@@ -194,6 +194,45 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
     const bool sample_t = f.end_time == 0 && !has_ts;
     uint64_t i = threadIdx.x;
     uint32_t it = 0;
+    if (SAMPLE_H && prefetch) {
+      // Sampled histogram, software-pipelined (TAD_META_PREFETCH=1; queued for measurement): a workgroup reads one iteration in
+      // eight, so the loop below is a chain of dependent load -> histogram round trips (~8 per workgroup at C2).  Here the
+      // loads of the NEXT sampled iteration are issued before the current one is histogrammed.  Same rows, same counts.
+      constexpr uint64_t step = (uint64_t)U * kPartThreads;
+      auto full = [&](uint64_t ii) { return ii + (U - 1) * kPartThreads < npair; };
+      auto sampled = [&](uint64_t ii, uint32_t iit) { return (iit & 7) == 0 || (ii - threadIdx.x) + 2 * U * kPartThreads >= npair; };
+      struct Regs { ulonglong2 k[U], k2[U]; longlong2 t[U]; };
+      auto load = [&](Regs &r, uint64_t ii) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          r.k[u] = kv[ii + u * kPartThreads];
+          r.k2[u] = HAS2 ? k2v[ii + u * kPartThreads] : make_ulonglong2(TAD_KEY_SKIP, TAD_KEY_SKIP);
+          r.t[u] = tv[ii + u * kPartThreads];
+        }
+      };
+      while (full(i) && !sampled(i, it)) { i += step; ++it; }
+      if (full(i)) {
+        Regs cur, nxt;
+        load(cur, i);
+        for (;;) {
+          uint64_t j = i + step;
+          uint32_t jt = it + 1;
+          while (full(j) && !sampled(j, jt)) { j += step; ++jt; }
+          const bool more = full(j);
+          if (more) load(nxt, j);
+          seen += 2 * U;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {   // (no time-window filter in this mode: every row is kept)
+            meta_row(acc, hist, cur.k[u].x, cur.k2[u].x, cur.t[u].x, true, K, shift_bin);
+            meta_row(acc, hist, cur.k[u].y, cur.k2[u].y, cur.t[u].y, true, K, shift_bin);
+          }
+          i = j;
+          it = jt;
+          if (!more) break;
+          cur = nxt;
+        }
+      }
+    }
     for (; i + (U - 1) * kPartThreads < npair; i += U * kPartThreads, ++it) {
       const bool with_t = !sample_t || (it & 7) == 0 || (i - threadIdx.x) + 2 * U * kPartThreads >= npair;  // workgroup-uniform
       if (SAMPLE_H && !with_t) continue;   // sampled histogram: the unsampled iterations are not read at all
@@ -1279,11 +1318,13 @@ bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   const bool has2 = key2 != nullptr;
   // the histogram can only be sampled where the time column is (no time-window filter, 16-byte loads)
   const bool sh = sample_hist && vec && f.end_time == 0 && !(t_start != nullptr && f.start_time != 0);
+  const char *pf_env = getenv("TAD_META_PREFETCH");
+  const int prefetch = pf_env != nullptr && pf_env[0] == '1';
 #define TAD_MH(V, H2, SH)                                                                                              \
   do {                                                                                                                 \
     allow_big_lds(reinterpret_cast<const void *>(k_meta_hist<V, H2, SH>), kLdsBudget);                                 \
     hipLaunchKernelGGL((k_meta_hist<V, H2, SH>), dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n, \
-                       pl.chunk, K, f, pl.shift_bin, pl.nbins, partials, binhist, ctr);                                \
+                       pl.chunk, K, f, pl.shift_bin, pl.nbins, partials, binhist, ctr, prefetch);                      \
   } while (0)
   if (vec) {
     if (sh) { if (has2) TAD_MH(true, true, true); else TAD_MH(true, false, true); }
