@@ -75,6 +75,23 @@ def test_product_code_never_touches_the_oracle():
     assert not bad, bad
 
 
+def test_host_emulator_is_a_development_aid_only():
+    """tools/hipemu executes the kernels' logic on the host to debug them before GPU time is spent.  It must never become a
+    code path: nothing in the product, the tests, bench.py or __graft_entry__ refers to it, and its build never reaches the GPU box."""
+    bad = []
+    for base in ("theia_amd", "include", "tests", "oracle"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".cpp", ".h", ".c")) and fn != os.path.basename(__file__):
+                    if "hipemu" in open(os.path.join(dp, fn), errors="ignore").read():
+                        bad.append(os.path.join(dp, fn))
+    for fn in ("bench.py", "__graft_entry__.py"):
+        if "hipemu" in open(os.path.join(ROOT, fn)).read():
+            bad.append(fn)
+    assert not bad, bad
+    assert "tools/hipemu/_build/" in open(os.path.join(ROOT, ".gpurunignore")).read().split()
+
+
 def _build_c_driver(tmp_path):
     from theia_amd import build
     build.build_library()

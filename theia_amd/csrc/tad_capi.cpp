@@ -41,7 +41,7 @@ struct tad_engine {
   std::string err;
   std::atomic<int32_t> done{0}, total{0};
   // grow-only device scratch
-  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2, moments;
+  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2, moments, tile_stats;
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
   DevBuf rcp_table;           // rcp_table[n] = RN(1/n), n = 0..rcp_n-1
   uint64_t rcp_n = 0;
@@ -234,7 +234,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->part_fin, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->part_fin, &e->tile_stats, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -287,6 +287,7 @@ struct JobParams {
   int drop_min_samples;
   bool all_points;
   bool lazy_sigma = false;   // set by detect_and_count: the stddev column is computed by the emit kernel (DBSCAN jobs)
+  TileStats tile_stats{nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // set by Stage 0 when pass C left per-round key statistics
 };
 
 // reciprocals of the point counts 1..T for the exact-division FMA sequence (tad_internal.h:div_by_count);
@@ -351,7 +352,8 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
     if (dbscan_uses_list(g)) {
       DbscanStats dst{nullptr, nullptr, nullptr, nullptr};
       if (db_fused) dst = DbscanStats{n_pts, n_anom, static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p)};
-      if (launch_dbscan(s, g, jp.eps, jp.min_samples, e->aux.p, dst) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
+      if (launch_dbscan(s, g, jp.eps, jp.min_samples, e->aux.p, dst, db_fused ? jp.tile_stats : TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) != 0)
+        return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
     } else {
       launch_dbscan_long(s, g, jp.eps, jp.min_samples, e->aux.p);
     }
@@ -555,6 +557,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   // full -> Stage 0 v1.  Each transition happens at most once, so 5 attempts cover every path.
   for (int attempt = 0; attempt < 7; ++attempt) {
     const bool hinted = lat_mode == 0;
+    jp.tile_stats = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
     PartPlan pl{};
     bool v2 = !empty && !force_v1 && !force_v1_retry && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
@@ -758,8 +761,16 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
+      // DBSCAN (opt-in, TAD_DBSCAN_TILESTATS=1; queued for measurement): pass C leaves per-round key statistics, the detector
+      // settles most keys from them instead of reading the grid back (tad_dbscan.hip:k_dbscan_scan)
+      jp.tile_stats = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+      const char *ts_env = getenv("TAD_DBSCAN_TILESTATS");
+      if (ts_env != nullptr && ts_env[0] == '1' && jp.algo == TAD_ALGO_DBSCAN && !jp.all_points && dbscan_uses_list(g)) {
+        if ((rc = ensure(e, e->tile_stats, tile_stats_bytes(K, pl.n_chunks))) != TAD_OK) return rc;
+        jp.tile_stats = tile_stats_carve(e->tile_stats.p, K, pl.n_chunks);
+      }
       launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap,
-                            hist_sampled ? offs32 : nullptr, fin);
+                            hist_sampled ? offs32 : nullptr, fin, jp.tile_stats);
     } else {
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));

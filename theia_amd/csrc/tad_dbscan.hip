@@ -31,32 +31,59 @@ __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63; }
 // (M2 from sums shifted by the key's first value; only the exact stddev_samp column of emitted rows follows Spark's
 // streaming order, k_emit<4>).
 // ------------------------------------------------------------------------------------------------
+// ts (optional, TAD_DBSCAN_TILESTATS=1): pass C left count / min / max / (mean, M2) per (bucket round, key); a key whose
+// partials are all usable is settled from them — 36 B per round instead of its column of the grid — with the rounds'
+// moments merged in round order (Chan et al.); the others are walked as before.
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, int min_samples, DbscanStats st,
-                                                         uint32_t *__restrict__ list, unsigned int *__restrict__ count) {
+                                                         uint32_t *__restrict__ list, unsigned int *__restrict__ count, TileStats ts) {
   const uint64_t k = (uint64_t)blockIdx.x * kDbBlock + threadIdx.x;
   bool slow = false;
   if (k < g.K) {
     uint32_t n = 0;
-    double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
-    walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
-      if (fl & FLAG_PRESENT) {
-        const double x = (double)raw;
-        if (n == 0) { mn = x; mx = x; x0 = x; }
-        mn = fmin(mn, x);
-        mx = fmax(mx, x);
-        const double d = x - x0;
-        s1 += d;
-        s2 += d * d;
-        n++;
+    double mn = 0.0, mx = 0.0, mean = 0.0, m2 = 0.0;
+    bool walk = ts.rounds == 0;
+    if (!walk) {
+      Moments acc{0.0, 0.0, 0.0};
+      for (uint32_t r = 0; r < ts.rounds; ++r) {
+        const size_t o = (size_t)r * g.K + k;
+        const uint32_t nr = ts.n[o];
+        if (nr == kTileStatsRedo) { walk = true; break; }
+        if (nr == 0) continue;
+        const double a = ts.mn[o], b = ts.mx[o];
+        if (n == 0) { mn = a; mx = b; }
+        mn = fmin(mn, a);
+        mx = fmax(mx, b);
+        acc = chan_merge(acc, Moments{(double)nr, ts.mean[o], ts.m2[o]});
+        n += nr;
       }
-    });
+      mean = acc.mean;
+      m2 = acc.m2;
+    }
+    if (walk) {
+      n = 0;
+      double x0 = 0.0, s1 = 0.0, s2 = 0.0;
+      walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
+        if (fl & FLAG_PRESENT) {
+          const double x = (double)raw;
+          if (n == 0) { mn = x; mx = x; x0 = x; }
+          mn = fmin(mn, x);
+          mx = fmax(mx, x);
+          const double d = x - x0;
+          s1 += d;
+          s2 += d * d;
+          n++;
+        }
+      });
+      const double dn = (double)(n ? n : 1);
+      mean = n ? x0 + s1 / dn : 0.0;
+      m2 = n ? fmax(s2 - s1 * (s1 / dn), 0.0) : 0.0;
+    }
     slow = n > 0 && (!(mx - mn <= eps) || n < (uint32_t)min_samples);
     if (st.n_pts != nullptr) {
       st.n_pts[k] = n;
       st.n_anom[k] = 0;
-      const double dn = (double)(n ? n : 1);
-      st.key_mean[k] = n ? x0 + s1 / dn : 0.0;
-      st.key_m2[k] = n ? fmax(s2 - s1 * (s1 / dn), 0.0) : 0.0;
+      st.key_mean[k] = n ? mean : 0.0;
+      st.key_m2[k] = n ? m2 : 0.0;
     }
   }
   const unsigned long long m = __ballot(slow);
@@ -135,6 +162,65 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list(Grid g, double eps, in
   }
 }
 
+// k_dbscan_list_wave (opt-in, TAD_DBSCAN_WAVELIST=1; queued for measurement) — the same predicate with ONE WAVEFRONT per
+// listed key and no LDS, no workgroup barrier: lane l holds the key's buckets l, l + 64, ... (PPL of them: T <= 64 * PPL);
+// x_j reaches all lanes by a readlane with a wavefront-uniform index, absent buckets are skipped through the ballot masks.
+// k_dbscan_list spends a workgroup and ~8 barriers on a key of ~100 points (C4: ~7 listed keys per workgroup, 97 us);
+// here four keys are in flight per workgroup and nothing waits for anything.
+template <int PPL>
+__global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double eps, int min_samples, const uint32_t *__restrict__ list,
+                                                              const unsigned int *__restrict__ count, uint32_t *__restrict__ n_anom) {
+  const unsigned lane = lane_id();
+  const unsigned wave = threadIdx.x >> 6;
+  const unsigned total = *count;
+  for (unsigned e = blockIdx.x * kDbWaves + wave; e < total; e += gridDim.x * kDbWaves) {   // wavefront-uniform
+    const uint64_t k = list[e];
+    double x[PPL];
+    bool p[PPL];
+    unsigned long long pm[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const uint64_t t = lane + 64u * (unsigned)j;
+      p[j] = t < g.T && (g.flag[t * g.K + k] & FLAG_PRESENT);
+      x[j] = p[j] ? (double)g.val[t * g.K + k] : 0.0;
+      pm[j] = __ballot(p[j]);
+    }
+    int cnt[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) cnt[i] = 0;
+#pragma unroll
+    for (int jj = 0; jj < PPL; ++jj)
+      for (unsigned long long m = pm[jj]; m; m &= m - 1) {
+        const double xj = __shfl(x[jj], __ffsll((long long)m) - 1);
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) cnt[i] += fabs(x[i] - xj) <= eps ? 1 : 0;
+      }
+    bool core[PPL], reach[PPL];
+    unsigned long long cm[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+      core[i] = p[i] && cnt[i] >= min_samples;
+      reach[i] = false;
+      cm[i] = __ballot(core[i]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < PPL; ++jj)
+      for (unsigned long long m = cm[jj]; m; m &= m - 1) {
+        const double xj = __shfl(x[jj], __ffsll((long long)m) - 1);
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) reach[i] = reach[i] || fabs(x[i] - xj) <= eps;
+      }
+    uint32_t noise = 0;
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+      const bool nz = p[i] && !core[i] && !reach[i];
+      if (nz) g.flag[(uint64_t)(lane + 64u * (unsigned)i) * g.K + k] = FLAG_PRESENT | FLAG_ANOMALY;
+      noise += (uint32_t)__popcll(__ballot(nz));
+    }
+    if (lane == 0 && n_anom != nullptr) n_anom[k] = noise;
+  }
+}
+
 // Fallback for series too long for an LDS row: one workgroup per key, points compacted into a global
 // scratch row, x_j streamed from L1/L2 (every lane reads the same address -> one fetch per wave).
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_long(Grid g, double eps, int min_samples,
@@ -202,16 +288,23 @@ size_t dbscan_scratch_bytes(Grid g) {
 
 bool dbscan_uses_list(Grid g) { return list_fits_lds(g.T); }
 
-int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch, DbscanStats st) {
+int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch, DbscanStats st, TileStats ts) {
   if (g.K == 0 || g.T == 0) return 0;
   if (!list_fits_lds(g.T)) return -1;
   unsigned int *count = static_cast<unsigned int *>(scratch);
   uint32_t *list = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + 64);
   hipMemsetAsync(count, 0, sizeof(unsigned int), s);
-  hipLaunchKernelGGL(k_dbscan_scan, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+  hipLaunchKernelGGL(k_dbscan_scan, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, ts);
+  uint64_t blocks = g.K < 2048 ? g.K : 2048;   // grid-stride over the (device-side) list length
+  const char *wl_env = getenv("TAD_DBSCAN_WAVELIST");
+  if (wl_env != nullptr && wl_env[0] == '1' && g.T <= 256) {
+#define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom)
+    if (g.T <= 64) TAD_DBW(1); else if (g.T <= 128) TAD_DBW(2); else if (g.T <= 192) TAD_DBW(3); else TAD_DBW(4);
+#undef TAD_DBW
+    return 0;
+  }
   const size_t lds = (size_t)((g.T * 13 + 15) & ~(uint64_t)15);
   allow_big_lds(reinterpret_cast<const void *>(k_dbscan_list), 152 * 1024);
-  uint64_t blocks = g.K < 2048 ? g.K : 2048;   // grid-stride over the (device-side) list length
   hipLaunchKernelGGL(k_dbscan_list, dim3((unsigned)blocks), dim3(kDbBlock), lds, s, g, eps, min_samples, list, count, st.n_anom);
   return 0;
 }

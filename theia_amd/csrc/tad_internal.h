@@ -95,6 +95,8 @@ __device__ __forceinline__ double div_by_count(double a, double b, double y) {
   return fma(r, y, q);
 }
 
+struct Moments { double n, mean, m2; };   // per-key / per-block (n, mean, M2) of the points
+
 #if defined(__HIPCC__)
 // (the per-key walks are HBM-latency bound: one lane = one key, 64 consecutive keys = one coalesced 512-byte access)
 // Walk one key's column of the time-major grid in time order, calling step(t, flag, raw_value) for every bucket.
@@ -136,13 +138,24 @@ __device__ __forceinline__ void walk_series(const Grid &g, uint64_t k, Step step
   for (uint64_t t = nfull * kWalkChunk; t < T; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
 }
 
+// Chan et al. pairwise merge of (n, mean, M2)
+__device__ __forceinline__ Moments chan_merge(Moments a, Moments b) {
+  if (b.n == 0.0) return a;
+  if (a.n == 0.0) return b;
+  Moments r;
+  r.n = a.n + b.n;
+  const double d = b.mean - a.mean;
+  r.mean = a.mean + d * (b.n / r.n);
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+  return r;
+}
+
 #endif
 
 // per-key n / sigma (+ EWMA anomaly count when ewma != 0).  rcp[n] = RN(1/n) for n = 0..T (rcp[0] unused).
 void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, const double *rcp, double *sigma,
                       uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2);
 // deterministic Chan merge of the per-key (n, mean, M2) into kMomentBlocks partials
-struct Moments { double n, mean, m2; };
 static constexpr int kMomentBlocks = 128;
 // ctr != NULL: also adds the job counters n_keys / n_points (for paths whose per-key kernel does not count them itself)
 void launch_moments(hipStream_t s, uint64_t K, const uint32_t *n_pts, const double *key_mean,
@@ -176,6 +189,22 @@ void launch_ewma_values(hipStream_t s, Grid g, double alpha, double *calc);
 // DBSCAN: sets FLAG_ANOMALY on noise points.  scratch = dbscan_scratch_bytes(g) bytes of device memory.
 // dbscan_uses_list: the series fit an LDS row -> launch_dbscan (scan + work list); otherwise launch_dbscan_long.
 // st (all pointers NULL = not wanted): per-key point / anomaly counts and (mean, M2) moments
+// Per-(bucket round, key) partial statistics pass C can leave for the DBSCAN detector (TAD_DBSCAN_TILESTATS=1): arrays of
+// [rounds][K]; n == kTileStatsRedo: the partials of this key are not usable (split partition, overflow record) -> the
+// detector walks the grid for it.  rounds == 0: not in use.
+struct TileStats {
+  uint32_t *n;
+  double *mn, *mx, *mean, *m2;
+  uint32_t rounds;
+};
+static constexpr uint32_t kTileStatsRedo = 0xFFFFFFFFu;
+inline size_t tile_stats_bytes(uint64_t K, uint32_t rounds) { return (size_t)K * rounds * 36 + 64; }
+inline TileStats tile_stats_carve(void *mem, uint64_t K, uint32_t rounds) {
+  double *d = static_cast<double *>(mem);
+  const size_t c = (size_t)K * rounds;
+  return TileStats{reinterpret_cast<uint32_t *>(d + 4 * c), d, d + c, d + 2 * c, d + 3 * c, rounds};
+}
+
 struct DbscanStats {
   uint32_t *n_pts, *n_anom;
   double *key_mean, *key_m2;
@@ -183,7 +212,8 @@ struct DbscanStats {
 size_t dbscan_scratch_bytes(Grid g);
 bool dbscan_uses_list(Grid g);
 int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch,
-                  DbscanStats st = DbscanStats{nullptr, nullptr, nullptr, nullptr});
+                  DbscanStats st = DbscanStats{nullptr, nullptr, nullptr, nullptr},
+                  TileStats ts = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
 int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch);
 
 // drop detector (tad_drop.hip): sigma / n_pts / key_mean / key_m2 / counters + FLAG_ANOMALY; ws = K * T doubles
@@ -247,7 +277,7 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl);
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
                            const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32 = nullptr,
-                           const uint32_t *fin = nullptr);
+                           const uint32_t *fin = nullptr, TileStats ts = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
 
 // ---- Stage 0 for sparse tables: sort by (key, time), reduce, rank grid (tad_sparse.hip) ----
 size_t sparse_sort_temp_bytes(uint64_t slots);

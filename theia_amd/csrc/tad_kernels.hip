@@ -323,16 +323,6 @@ void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, cons
 // (strided per thread, then a fixed shuffle tree), so a shard's moments do not depend on scheduling.
 // The host merges the kMomentBlocks partials, and the multi-GPU host merges shards the same way.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ Moments chan_merge(Moments a, Moments b) {
-  if (b.n == 0.0) return a;
-  if (a.n == 0.0) return b;
-  Moments r;
-  r.n = a.n + b.n;
-  const double d = b.mean - a.mean;
-  r.mean = a.mean + d * (b.n / r.n);
-  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
-  return r;
-}
 
 __global__ __launch_bounds__(kBlock) void k_moments(uint64_t K, const uint32_t *__restrict__ n_pts,
                                                     const double *__restrict__ key_mean,

@@ -943,7 +943,8 @@ template <bool OPMAX>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
                                                                  SliceTable st, TileGeom tg, Grid g, int phase,
-                                                                 const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G) {
+                                                                 const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G,
+                                                                 TileStats ts) {
   // Rounds as workgroups: a partition whose KP x T block needs R > 1 LDS tiles is read by R workgroups, one per bucket
   // round, instead of R times by one.  The R workgroups of a slice get block ids x + 8 * (R * j + r): the same XCD
   // (blocks are dealt round-robin over the 8 XCDs) and adjacent in dispatch order, so they stream the same records at
@@ -1054,6 +1055,40 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
       for (int u = 0; u < U; ++u) apply(r[u]);
     }
     __syncthreads();
+    if (ts.rounds != 0) {
+      // DBSCAN (opt-in): the tile holds this round's buckets of every key of the partition — leave count / min / max / (mean, M2)
+      // of each key's values, so that the detector need not read the grid back for the keys it can settle from them.
+      // A split partition's tile is partial: its keys are marked for a grid walk.
+      for (uint32_t kk = threadIdx.x; kk < KP; kk += kPartThreads) {
+        const uint64_t k = k0 + kk;
+        if (k >= g.K) continue;
+        const size_t o = (size_t)chunk * g.K + k;
+        if (split) { ts.n[o] = kTileStatsRedo; continue; }
+        uint32_t n = 0;
+        double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (uint32_t b = 0; b < nb; ++b) {
+          const uint32_t c = (b << shift_part) + kk;
+          if (flags[c]) {
+            const double x = (double)vals[c];
+            if (n == 0) { mn = x; mx = x; x0 = x; }
+            mn = fmin(mn, x);
+            mx = fmax(mx, x);
+            const double d = x - x0;
+            s1 += d;
+            s2 += d * d;
+            n++;
+          }
+        }
+        ts.n[o] = n;
+        if (n) {
+          const double dn = (double)n;
+          ts.mn[o] = mn;
+          ts.mx[o] = mx;
+          ts.mean[o] = x0 + s1 / dn;
+          ts.m2[o] = fmax(s2 - s1 * (s1 / dn), 0.0);
+        }
+      }
+    }
     for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
       const uint32_t b = b_lo + (c >> shift_part), kk = c & (KP - 1);
       const uint64_t k = k0 + kk;
@@ -1074,11 +1109,13 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
 // records whose value did not fit the packed form: fold them into the finished grid (agent-scope integer atomics)
 template <bool OPMAX>
 __global__ __launch_bounds__(256) void k_apply_overflow(const OverflowRec *__restrict__ ovf,
-                                                        const unsigned long long *__restrict__ ovf_count, uint32_t cap, Grid g) {
+                                                        const unsigned long long *__restrict__ ovf_count, uint32_t cap, Grid g,
+                                                        TileStats ts) {
   unsigned long long n = *ovf_count;
   if (n > cap) n = cap;
   for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
     const OverflowRec r = ovf[i];
+    if (ts.rounds != 0) ts.n[r.gcell % g.K] = kTileStatsRedo;   // the tile pass did not see this record: round 0 of the key says "walk the grid"
     if (OPMAX) __hip_atomic_fetch_max(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_fetch_add(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     g.flag[r.gcell] = FLAG_PRESENT;
@@ -1478,8 +1515,9 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl) {
 
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
-                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin) {
+                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, TileStats ts) {
   const unsigned long long *rr = static_cast<const unsigned long long *>(recs);
+  const TileStats none{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   const uint32_t max_slices = (uint32_t)((size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1);
   SliceTable st;
   st.slice_part = static_cast<uint32_t *>(slice_mem);
@@ -1496,13 +1534,13 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len};
   const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
   if (op_max) {
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G);
-    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G);
-    hipLaunchKernelGGL((k_apply_overflow<true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none);
+    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G, ts);
+    hipLaunchKernelGGL((k_apply_overflow<true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);
   } else {
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G);
-    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G);
-    hipLaunchKernelGGL((k_apply_overflow<false>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none);
+    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G, ts);
+    hipLaunchKernelGGL((k_apply_overflow<false>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);
   }
 }
 

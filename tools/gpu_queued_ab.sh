@@ -1,0 +1,15 @@
+#!/bin/bash
+# First GPU call for the experiments that were written without GPU time (env switches, default off; parity checked on the
+# host emulator, tools/hipemu): the parity tests with each switch on, then same-box A/B of the bench lines.
+#   TAD_META_PREFETCH=1      C2: software-pipelined sampled histogram in pass A
+#   TAD_DBSCAN_TILESTATS=1   C4: DBSCAN scan from pass C's per-round key statistics
+#   TAD_DBSCAN_WAVELIST=1    C4: exact pair tests with one wavefront per listed key
+cd /root/repo
+for e in TAD_META_PREFETCH=1 TAD_DBSCAN_TILESTATS=1 TAD_DBSCAN_WAVELIST=1; do
+  echo "== parity with $e"
+  env $e timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random.py tests/test_gpu_fullsize.py -m gpu -x -q -k "not arima and not c3" 2>&1 | tail -2
+done
+c2() { env $1 timeout 60 python bench.py --config c2 --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); p=d['pipeline']; print('C2 [$1]', round(d['ms_per_step'],3), 'ms; meta', round(p['ms_meta'],3), 'stage0', round(p['ms_stage0_clear_plus_scatter'],3), 'detect', round(p['ms_detect_and_emit'],3))"; }
+c4() { env $1 timeout 60 python bench.py --config c4 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); p=d['pipeline']; print('C4 [$1]', round(d['ms_per_step'],3), 'ms; stage0', round(p['ms_stage0_clear_plus_scatter'],3), 'detect', round(p['ms_detect_and_emit'],3), d['result']['anomalies'])"; }
+for r in 1 2; do c2 TAD_META_PREFETCH=0; c2 TAD_META_PREFETCH=1; done
+for r in 1 2; do c4 TAD_DBSCAN_TILESTATS=0; c4 TAD_DBSCAN_TILESTATS=1; c4 TAD_DBSCAN_WAVELIST=1; c4 "TAD_DBSCAN_TILESTATS=1 TAD_DBSCAN_WAVELIST=1"; done

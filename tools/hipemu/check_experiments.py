@@ -1,0 +1,91 @@
+"""Parity of the opt-in experiments (env switches, default off, queued for measurement on the GPU) on the host emulator:
+   TAD_META_PREFETCH=1      software-pipelined sampled histogram in pass A
+   TAD_DBSCAN_TILESTATS=1   pass C leaves per-round key statistics, the DBSCAN scan settles keys from them
+   TAD_DBSCAN_WAVELIST=1    exact DBSCAN pair tests with one wavefront per listed key (readlane broadcast, no LDS / barriers)
+Run:  python tools/hipemu/build.py && python tools/hipemu/check_experiments.py
+Every case runs the whole job through the C ABI of the emulated library and compares all rows with the oracle."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+os.environ["TAD_LIBRARY_PATH"] = os.path.join(HERE, "_build", "libtad_hipemu.so")
+
+import numpy as np  # noqa: E402
+
+from oracle import tad_oracle as orc  # noqa: E402
+from theia_amd import TadEngine  # noqa: E402
+
+FIELDS = ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev")
+
+
+def run(eng, algo, k, t, v, K, agg, env):
+    old = {name: os.environ.get(name) for name in env}
+    os.environ.update(env)
+    try:
+        return eng.run(algo, k, t, v, K, agg_flow=agg)
+    finally:
+        for name, val in old.items():
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
+
+
+def check(eng, label, algo, k, t, v, K, agg, env):
+    want = orc.run_job(algo, k, t, v, agg_flow=agg)
+    base = run(eng, algo, k, t, v, K, agg, {kk: vv for kk, vv in env.items() if not kk.startswith(("TAD_META_PREFETCH", "TAD_DBSCAN_TILESTATS", "TAD_DBSCAN_WAVELIST"))})
+    res = run(eng, algo, k, t, v, K, agg, env)
+    assert res.n_rows == want["n_anomalies"] == base.n_rows, (label, res.n_rows, want["n_anomalies"])
+    for f in FIELDS:
+        assert (res[f] == want[f]).all(), (label, f)
+    for f in ("n_points", "n_keys", "rows_used"):
+        assert res.stats[f] == base.stats[f], (label, f)
+    assert abs(res.stats["pts_mean"] - base.stats["pts_mean"]) <= 1e-12 * abs(base.stats["pts_mean"]), label
+    assert abs(res.stats["pts_m2"] - base.stats["pts_m2"]) <= 1e-12 * abs(base.stats["pts_m2"]), label
+    print("ok  %-58s rows %6d  path %d  sampled %d" % (label, res.n_rows, res.stats["stage0_path"], res.stats["hist_sampled"]))
+
+
+def main():
+    eng = TadEngine(device=0)
+    rng = np.random.default_rng(17)
+    v2 = {"TAD_STAGE0": "v2"}
+    for partb in ("wc", "sort"):
+        e = dict(v2, TAD_PARTB=partb)
+        k, t, v = orc.synth_rows(0, 100003, 100, 250)
+        check(eng, "prefetch  %s 1e5 rows / 100 keys (sampled histogram)" % partb, "EWMA", k, t, v, 100, "svc", dict(e, TAD_META_PREFETCH="1"))
+        check(eng, "tilestats %s one round" % partb, "DBSCAN", k, t, v, 100, "svc", dict(e, TAD_DBSCAN_TILESTATS="1"))
+        k, t, v = orc.synth_rows(0, 120000, 300, 250)
+        check(eng, "tilestats %s two rounds (128-key blocks x 250 buckets)" % partb, "DBSCAN", k, t, v, 300, "svc",
+              dict(e, TAD_DBSCAN_TILESTATS="1", TAD_KP_SHIFT_MIN="7"))
+        check(eng, "tilestats %s max mode, three rounds" % partb, "DBSCAN", k, t, v, 300, "", dict(e, TAD_DBSCAN_TILESTATS="1", TAD_KP_SHIFT_MIN="8"))
+        v2_ = v.copy()
+        v2_[::997] = rng.integers(2**50, 2**63, size=v2_[::997].size, dtype=np.uint64)    # overflow-list records
+        check(eng, "tilestats %s values beyond the packed record range" % partb, "DBSCAN", k, t, v2_, 300, "svc",
+              dict(e, TAD_DBSCAN_TILESTATS="1", TAD_KP_SHIFT_MIN="7"))
+    # a hot key: its partition is split over several workgroups (partial tiles -> the detector walks the grid for its keys)
+    k, t, v = orc.synth_rows(0, 400000, 300, 64)
+    k = np.where(rng.random(k.size) < 0.5, np.uint64(7), k)
+    check(eng, "tilestats hot key (split partition)", "DBSCAN", k, t, v, 300, "svc", dict(v2, TAD_DBSCAN_TILESTATS="1", TAD_HIST_SAMPLE="0"))
+    check(eng, "prefetch  hot key", "EWMA", k, t, v, 300, "svc", dict(v2, TAD_META_PREFETCH="1"))
+    # wavefront-per-key pair tests: 1..4 buckets per lane, keys with fewer than min_samples points, spikes and dips
+    for n, K, T in ((3000, 40, 13), (60000, 300, 100), (100003, 100, 250), (40000, 200, 190)):
+        k, t, v = orc.synth_rows(0, n, K, T)
+        check(eng, "wavelist  %d rows / %d keys / %d buckets" % (n, K, T), "DBSCAN", k, t, v, K, "svc", dict(v2, TAD_DBSCAN_WAVELIST="1"))
+        check(eng, "wavelist + tilestats, max mode, same table", "DBSCAN", k, t, v, K, "", dict(v2, TAD_DBSCAN_WAVELIST="1", TAD_DBSCAN_TILESTATS="1"))
+    gold = __import__("json").load(open(os.path.join(ROOT, "tests", "golden", "reference_golden.json")))
+    os.environ["TAD_DBSCAN_WAVELIST"] = "1"
+    assert eng.series_dbscan_anomaly(gold["throughput_list"]).tolist() == gold["expected_dbscan_anomaly_list"]
+    x = [1000000000, 1250000000, 1500000000, 1750000001, 5000000000, 5000000001, 5000000002, 5250000002]   # exact-eps chains
+    os.environ["TAD_DBSCAN_WAVELIST"] = "0"
+    ref = eng.series_dbscan_anomaly(x).tolist()
+    os.environ["TAD_DBSCAN_WAVELIST"] = "1"
+    assert eng.series_dbscan_anomaly(x).tolist() == ref == orc.dbscan_noise_1d(orc.u64_to_f64(np.array(x, dtype=np.uint64))).tolist()
+    os.environ.pop("TAD_DBSCAN_WAVELIST")
+    print("ok  wavelist  reference golden series + exact-eps chain")
+    print("all experiments agree with the oracle on the emulator")
+
+
+if __name__ == "__main__":
+    main()
