@@ -18,6 +18,9 @@
  * IEEE-754 double +, -, *, /, sqrt only, no FMA contraction (-ffp-contract=off), sums strictly left to right, and the
  * transcendental functions from the one shared source theia_amd/csrc/tad_detmath.h.  Control flow here is an ordinary
  * sequential program (the GPU runs the optimiser as a per-lane state machine); the expressions are the contract.
+ * The likelihood recursion exists in two such contracts: the general three-state filter (default, arima_nll_general) and
+ * the collapsed form (arima_nll_collapsed; the engine's opt-in TAD_ARIMA_FILTER=collapsed) — arima_exact_set_filter()
+ * switches, oracle/arima_oracle.py does it from the same environment variable the engine reads.
  *
  * PARITY STATUS vs the reference: "unpinned at 1e-6" (the reference's tests pin the verdict list and five leading
  * characters only, anomaly_detection_test.py:261-283, 320-345) — tests/test_oracle_arima.py records the distances.
@@ -161,15 +164,24 @@ static double inv_boxcox(double y, double lam) {       /* scipy.special.inv_boxc
  * --------------------------------------------------------------------------------------------------------------- */
 static long long g_steps;   /* filter time-steps executed (reported next to the GPU's kalman_steps counter) */
 static double *g_trace; static long g_trace_cap, g_trace_n;   /* debugging: every evaluation (x[3], f) of a traced fit */
+static int g_filter;        /* 0: general three-state form (the default contract); 1: collapsed form (arima_nll_collapsed) */
 
-static double arima_nll(const double u[3], const double *y, long n, double *forecast) {
+static double nll_finish(const double u[3], double prod, int esum, long nconv, double F, double q, long n) {
+  double sumlog = tad_det_log(prod) + (double)esum * TAD_DM_LN2, llf;
+  if (nconv) sumlog += (double)nconv * tad_det_log(F);
+  llf = -0.5 * ((double)(n - 1) * LOG_2PI + sumlog) - 0.5 * q;
+  if (g_trace && g_trace_n < g_trace_cap) { double *r = g_trace + 4 * g_trace_n++; r[0] = u[0]; r[1] = u[1]; r[2] = u[2]; r[3] = -llf / (double)n; }
+  return -llf / (double)n;
+}
+
+static double arima_nll_general(const double u[3], const double *y, long n, double *forecast) {
   const double phi = u[0] / sqrt(1.0 + u[0] * u[0]);
   const double theta = -(u[1] / sqrt(1.0 + u[1] * u[1]));
   const double s2 = u[2] * u[2];
   const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
   double p00 = DIFFUSE, p01 = 0.0;
   double p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
-  double a0 = 0.0, a1 = 0.0, F = 1.0, rF = 1.0, pz0 = 0.0, pz1 = 0.0, prod = 1.0, q = 0.0, sumlog, llf;
+  double a0 = 0.0, a1 = 0.0, F = 1.0, rF = 1.0, pz0 = 0.0, pz1 = 0.0, prod = 1.0, q = 0.0;
   int esum = 0, conv = 0;
   long nconv = 0, t;
   for (t = 0; t < n; ++t) {
@@ -203,12 +215,60 @@ static double arima_nll(const double u[3], const double *y, long n, double *fore
     }
   }
   g_steps += n;
-  sumlog = tad_det_log(prod) + (double)esum * TAD_DM_LN2;
-  if (nconv) sumlog += (double)nconv * tad_det_log(F);
-  llf = -0.5 * ((double)(n - 1) * LOG_2PI + sumlog) - 0.5 * q;
   if (forecast) *forecast = a0 + a1;
-  if (g_trace && g_trace_n < g_trace_cap) { double *r = g_trace + 4 * g_trace_n++; r[0] = u[0]; r[1] = u[1]; r[2] = u[2]; r[3] = -llf / (double)n; }
-  return -llf / (double)n;
+  return nll_finish(u, prod, esum, nconv, F, q, n);
+}
+
+/* The same likelihood with the structure of the model used up (contract "collapsed", tad_arima.hip:kfc_*).  The
+ * observation equation has no noise (H = 0), so the filtered covariance C_t = P_t - P_t Z' F^-1 Z P_t has Z' in its null
+ * space: C Z' = P Z' - P Z' (Z P Z') / F = 0.  Row 0 of T is Z, hence after EVERY update (T C T')_00 = (T C T')_01 = 0: from
+ * t = 1 on the predicted covariance is zero except p11 (and the constant q12, q22), the level state is known exactly
+ * (a0_t = y_t-1) and the three-state filter is the innovations recursion of the ARMA(1,1) on the differences:
+ *     v = (y_t - y_t-1) - a1;  F = p;  g = q12 / F;  a1' = phi (a1 + v) + g v;  p' = (q11 + q22) - q12 g
+ * In the general form the same zeros are computed as differences of numbers of size 1e6 (the diffuse prior) and carry
+ * rounding residue of ~1e-10 into F; the likelihood is the same function of the parameters in exact arithmetic.  The
+ * t = 0 step (approximate diffuse prior, a = 0) is the general update written out with p00 = 1e6, p01 = 0. */
+static double arima_nll_collapsed(const double u[3], const double *y, long n, double *forecast) {
+  const double phi = u[0] / sqrt(1.0 + u[0] * u[0]);
+  const double theta = -(u[1] / sqrt(1.0 + u[1] * u[1]));
+  const double s2 = u[2] * u[2];
+  const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
+  const double qs = q11 + q22;
+  const double p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
+  const double F0 = DIFFUSE + p11, r0 = 1.0 / F0;
+  const double m = DIFFUSE * (p11 * r0), c12 = DIFFUSE * (q12 * r0), c22 = q22 - (q12 * r0) * q12;
+  double p = phi * (phi * m + c12) + (phi * c12 + c22) + q11;     /* predicted p11 for t = 1 */
+  double a1 = 0.0, F = p11, r = r0, g = 0.0, prod = 1.0, q = 0.0, yprev = 0.0;
+  int esum = 0, conv = 0;
+  long nconv = 0, t;
+  if (n >= 1) {                                                   /* t = 0: burned (loglikelihood_burn = 1) */
+    const double w0 = r * y[0];
+    a1 = phi * (F * w0) + q12 * w0;
+    yprev = y[0];
+  }
+  for (t = 1; t < n; ++t) {
+    const double v = (y[t] - yprev) - a1;
+    double w;
+    if (!conv) { F = p; r = 1.0 / F; g = q12 * r; }
+    w = r * v;
+    q += v * w;
+    if (!conv) { int e; prod = tad_det_frexp(prod * F, &e); esum += e; }
+    else nconv++;
+    a1 = phi * (a1 + v) + g * v;
+    if (!conv) {
+      const double pn = qs - q12 * g, d = p - pn;
+      conv = d * d < CONV_TOL;
+      p = pn;
+    }
+    yprev = y[t];
+  }
+  g_steps += n;
+  if (forecast) *forecast = yprev + a1;
+  return nll_finish(u, prod, esum, nconv, F, q, n);
+}
+
+static double arima_nll(const double u[3], const double *y, long n, double *forecast) {
+  return g_filter ? arima_nll_collapsed(u, y, n, forecast) : arima_nll_general(u, y, n, forecast);
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -572,6 +632,10 @@ int arima_exact_series(const double *x, long n, int maxiter, double *pred, doubl
   free(lx);
   return 1;
 }
+
+/* which likelihood recursion the fits use: 0 = general three-state form (default), 1 = collapsed form */
+void arima_exact_set_filter(int collapsed) { g_filter = collapsed != 0; }
+int arima_exact_get_filter(void) { return g_filter; }
 
 /* pieces, for the unit tests */
 double arima_exact_nll(const double *y, long n, double u0, double u1, double u2, double *forecast) {

@@ -23,6 +23,7 @@
 // lanes pull the next key as soon as their fit has converged; the four evaluations of an optimiser cycle run as four
 // interleaved recursions per lane; the optimiser itself is a per-lane state machine stepped once per cycle (k_arima_fit).
 #include <cstdlib>
+#include <cstring>
 
 #include "tad_internal.h"
 #include "tad_detmath.h"
@@ -378,6 +379,111 @@ TAD_HD KfOut arima_nll(const double u0, const double u1, const double u2, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same likelihood with the model's structure used up — contract "collapsed" (opt-in: TAD_ARIMA_FILTER=collapsed;
+// oracle/arima_exact.c:arima_nll_collapsed is its host statement, expression for expression).
+// H = 0 (no observation noise) puts Z' in the null space of the filtered covariance: C Z' = P Z' - P Z' (Z P Z') / F = 0.
+// Row 0 of T is Z, so after EVERY update (T C T')_00 = (T C T')_01 = 0: from t = 1 on only p11 is non-zero (q12, q22
+// are constants), the level is known exactly (a0_t = y_t-1) and the filter is the innovations recursion of the ARMA(1,1)
+// on the differences:
+//   v = (y_t - y_t-1) - a1;  F = p;  r = 1 / F;  g = q12 r;  w = r v;  a1' = phi (a1 + v) + g v;  p' = (q11 + q22) - q12 g
+// (the general form computes those zeros as differences of numbers of size 1e6 — the diffuse prior — and feeds ~1e-10 of
+// rounding residue into F).  The t = 0 step is the general update written out for p00 = 1e6, p01 = 0, a = 0; it does not
+// depend on y except through a1.  ~30 instead of ~70 operations per step, 10 instead of 15 doubles of state.
+// ------------------------------------------------------------------------------------------------
+struct KfStateC {
+  double phi, q12, qs;       // model: qs = q11 + q22
+  double p, a1;              // predicted p11 and AR state
+  double F, r, g;            // frozen once converged (before the t = 0 step: p11_0, 1 / (1e6 + p11_0), unused)
+  double prod, q;
+  int esum;
+  uint32_t nconv;
+  bool conv;
+};
+
+TAD_HD inline void kfc_init(KfStateC &s, double u0, double u1, double u2) {
+  const double phi = u0 / sqrt(1.0 + u0 * u0);
+  const double theta = -(u1 / sqrt(1.0 + u1 * u1));
+  const double s2 = u2 * u2;
+  const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
+  const double p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
+  const double F0 = kDiffuse + p11, r0 = 1.0 / F0;
+  const double m = kDiffuse * (p11 * r0), c12 = kDiffuse * (q12 * r0), c22 = q22 - (q12 * r0) * q12;
+  s.phi = phi; s.q12 = q12; s.qs = q11 + q22;
+  s.p = phi * (phi * m + c12) + (phi * c12 + c22) + q11;
+  s.a1 = 0.0;
+  s.F = p11; s.r = r0; s.g = 0.0;
+  s.prod = 1.0; s.q = 0.0;
+  s.esum = 0; s.nconv = 0; s.conv = false;
+}
+
+// t = 0 (burned: no likelihood term)
+TAD_HD inline void kfc_first(KfStateC &s, double y0) {
+  const double w0 = s.r * y0;
+  s.a1 = s.phi * (s.F * w0) + s.q12 * w0;
+}
+
+// t >= 1, d = y_t - y_t-1; no lane of the wavefront has converged
+TAD_HD inline void kfc_step_nc(KfStateC &s, double d) {
+  const double v = d - s.a1;
+  s.F = s.p; s.r = 1.0 / s.F; s.g = s.q12 * s.r;
+  const double w = s.r * v;
+  s.q += v * w;
+  int e;
+  s.prod = kf_frexp(s.prod * s.F, &e);
+  s.esum += e;
+  s.a1 = s.phi * (s.a1 + v) + s.g * v;
+  const double pn = s.qs - s.q12 * s.g, dp = s.p - pn;
+  s.conv = dp * dp < kConvTol;
+  s.p = pn;
+}
+
+TAD_HD inline void kfc_step(KfStateC &s, double d) {
+  const double v = d - s.a1;
+  if (!s.conv) { s.F = s.p; s.r = 1.0 / s.F; s.g = s.q12 * s.r; }
+  const double w = s.r * v;
+  s.q += v * w;
+  if (!s.conv) { int e; s.prod = kf_frexp(s.prod * s.F, &e); s.esum += e; }
+  else s.nconv++;
+  s.a1 = s.phi * (s.a1 + v) + s.g * v;
+  if (!s.conv) {
+    const double pn = s.qs - s.q12 * s.g, dp = s.p - pn;
+    s.conv = dp * dp < kConvTol;
+    s.p = pn;
+  }
+}
+
+TAD_HD inline void kfc_step_conv(KfStateC &s, double d) {
+  const double v = d - s.a1;
+  const double w = s.r * v;
+  s.q += v * w;
+  s.nconv++;
+  s.a1 = s.phi * (s.a1 + v) + s.g * v;
+}
+
+TAD_HD inline KfOut kfc_finish(const KfStateC &s, uint32_t n, double ylast) {
+  double sumlog = tad_det_log(s.prod) + (double)s.esum * TAD_DM_LN2;
+  if (s.nconv) sumlog += (double)s.nconv * tad_det_log(s.F);
+  const double llf = -0.5 * ((double)(n - 1) * kLog2Pi + sumlog) - 0.5 * s.q;
+  KfOut o;
+  o.nll = -llf / (double)n;
+  o.forecast = ylast + s.a1;
+  return o;
+}
+
+// scalar form over a strided series (tools/arima_twin.cpp)
+TAD_HD KfOut arima_nll_collapsed(const double u0, const double u1, const double u2, const double *__restrict__ y, size_t stride,
+                                 uint32_t n) {
+  KfStateC s;
+  kfc_init(s, u0, u1, u2);
+  double yprev = 0.0;
+  if (n >= 1) { yprev = y[0]; kfc_first(s, yprev); }
+  uint32_t t = 1;
+  for (; t < n && !TAD_WAVE_ALL(s.conv); ++t) { const double yt = y[(size_t)t * stride]; kfc_step(s, yt - yprev); yprev = yt; }
+  for (; t < n; ++t) { const double yt = y[(size_t)t * stride]; kfc_step_conv(s, yt - yprev); yprev = yt; }
+  return kfc_finish(s, n, yprev);
+}
+
+// ------------------------------------------------------------------------------------------------
 // start parameters (SARIMAX.start_params -> _conditional_sum_squares, k_ar = k_ma = 1), streaming
 // ------------------------------------------------------------------------------------------------
 struct Ls2 { double a, b; };
@@ -730,7 +836,7 @@ __global__ __launch_bounds__(64) void k_arima_start(Grid g, ArimaWs ws, const ui
 // ------------------------------------------------------------------------------------------------
 static constexpr int kStage = 8;  // time steps staged per round: 64 B per row
 
-template <int CHAINS>
+template <int CHAINS, int FILTER>
 __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double *__restrict__ sigma,
                                                const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax, uint32_t chunk,
                                                double *__restrict__ calc, DevCounters *ctr, double *buf) {
@@ -850,6 +956,58 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     }
   };
 
+  // the same pass with the collapsed filter (FILTER == 1): the difference y_t - y_t-1 is shared by the four recursions
+  auto evaluate4c = [&](const double (&xe)[4][3], double (&nll)[4], double &fc) {
+    KfStateC s4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      kfc_init(s4[c], xe[c][0], xe[c][1], xe[c][2]);
+      if (!busy) s4[c].conv = true;
+    }
+    double yprev = 0.0;
+    for (uint32_t t0 = 0; t0 < p; t0 += kStage) {
+      double2 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const double2 *>(ws.ysk + row[j] + t0);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double *d = buf + (size_t)(j * 16 + (int)(lane >> 2)) * (kStage + 1) + (lane & 3u) * 2u;
+        d[0] = v[j].x; d[1] = v[j].y;
+      }
+      __syncthreads();
+      double yv[kStage];
+#pragma unroll
+      for (int i = 0; i < kStage; ++i) yv[i] = buf[(size_t)lane * (kStage + 1) + i];
+      const uint32_t nb = p - t0 < (uint32_t)kStage ? p - t0 : (uint32_t)kStage;
+#pragma unroll
+      for (int i = 0; i < kStage; ++i)
+        if ((uint32_t)i < nb) {
+          const double d = yv[i] - yprev;
+          yprev = yv[i];
+          if (i == 0 && t0 == 0) {   // wave-uniform
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kfc_first(s4[c], yv[0]);
+          } else {
+            const bool any_conv = __any(s4[0].conv || s4[1].conv || s4[2].conv || s4[3].conv);
+            if (!any_conv) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) kfc_step_nc(s4[c], d);
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) kfc_step(s4[c], d);
+            }
+          }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const KfOut r = kfc_finish(s4[c], p, yprev);
+      nll[c] = r.nll;
+      if (c == 0) fc = r.forecast;
+    }
+  };
+
   refill();
   while (CHAINS == 4 && __any(busy)) {
     double xe[4][3], dx[3], nll[4], fc0 = 0.0;
@@ -859,7 +1017,8 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) xe[i + 1][i] = fd_point(xe[i + 1][i], &dx[i]);
-    evaluate4(xe, nll, fc0);
+    if (FILTER == 1) evaluate4c(xe, nll, fc0);
+    else evaluate4(xe, nll, fc0);
     if (busy) {
       steps += 4ull * p;
 #pragma unroll
@@ -920,18 +1079,22 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
 // The register budget decides how many wavefronts share a SIMD (512 VGPRs: 128 -> 4, 96 -> 5, 80 -> 6, 64 -> 8); the
 // optimiser's state is only touched between evaluations, so a tighter budget spills exactly that to scratch and buys
 // latency hiding for the Kalman loop.  One kernel per budget; TAD_ARIMA_WAVES picks (default: measured best).
-#define TAD_ARIMA_FIT_KERNEL(NAME, W, CH)                                                                                \
+#define TAD_ARIMA_FIT_KERNEL(NAME, W, CH, FL)                                                                            \
   __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void NAME(                                \
       Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,  \
       uint32_t chunk, double *__restrict__ calc, DevCounters *ctr) {                                                    \
     __shared__ double buf[64 * (kStage + 1)];                                                                           \
-    arima_fit_body<CH>(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf);                                      \
+    arima_fit_body<CH, FL>(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf);                                  \
   }
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_w3, 3, 1)
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_w4, 4, 1)
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w1, 1, 4)
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w2, 2, 4)
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w3, 3, 4)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_w3, 3, 1, 0)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_w4, 4, 1, 0)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w1, 1, 4, 0)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w2, 2, 4, 0)
+TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w3, 3, 4, 0)
+// collapsed filter (TAD_ARIMA_FILTER=collapsed; queued for measurement): four chains per lane at 2 / 3 / 4 wavefronts per SIMD
+TAD_ARIMA_FIT_KERNEL(k_arima_fitc_c4w2, 2, 4, 1)
+TAD_ARIMA_FIT_KERNEL(k_arima_fitc_c4w3, 3, 4, 1)
+TAD_ARIMA_FIT_KERNEL(k_arima_fitc_c4w4, 4, 4, 1)
 #undef TAD_ARIMA_FIT_KERNEL
 
 static uint32_t arima_tpad(uint64_t T) { return (uint32_t)((T + kStage - 1) / kStage * kStage); }
@@ -973,7 +1136,15 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
     if (const char *e = getenv("TAD_ARIMA_WAVES")) waves = atoi(e);
     if (const char *e = getenv("TAD_ARIMA_CHAINS")) chains = atoi(e);
 #define TAD_ARIMA_LAUNCH(NAME) hipLaunchKernelGGL(NAME, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, chunk, calc, ctr)
-    if (chains == 4) {
+    const char *fl = getenv("TAD_ARIMA_FILTER");
+    if (fl != nullptr && !strcmp(fl, "collapsed")) {   // opt-in arithmetic contract (kfc_*); four chains per lane only
+      // 10 doubles of state per chain: at 3 wavefronts per SIMD (168 VGPRs) the step loop is still free of scratch traffic
+      // (ISA checked), at 4 it is not; not yet measured — TAD_ARIMA_WAVES=2|3|4 for the A/B
+      if (getenv("TAD_ARIMA_WAVES") == nullptr) waves = 3;
+      if (waves == 4) TAD_ARIMA_LAUNCH(k_arima_fitc_c4w4);
+      else if (waves == 2) TAD_ARIMA_LAUNCH(k_arima_fitc_c4w2);
+      else TAD_ARIMA_LAUNCH(k_arima_fitc_c4w3);
+    } else if (chains == 4) {
       if (waves == 1) TAD_ARIMA_LAUNCH(k_arima_fit_c4w1);
       else if (waves == 3) TAD_ARIMA_LAUNCH(k_arima_fit_c4w3);
       else TAD_ARIMA_LAUNCH(k_arima_fit_c4w2);

@@ -34,11 +34,37 @@ __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63; }
 // ts (optional, TAD_DBSCAN_TILESTATS=1): pass C left count / min / max / (mean, M2) per (bucket round, key); a key whose
 // partials are all usable is settled from them — 36 B per round instead of its column of the grid — with the rounds'
 // moments merged in round order (Chan et al.); the others are walked as before.
+template <bool TS>
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, int min_samples, DbscanStats st,
                                                          uint32_t *__restrict__ list, unsigned int *__restrict__ count, TileStats ts) {
   const uint64_t k = (uint64_t)blockIdx.x * kDbBlock + threadIdx.x;
   bool slow = false;
-  if (k < g.K) {
+  if constexpr (!TS) {   // the default path, kept as measured (tools/isa_diff.py)
+    if (k < g.K) {
+      uint32_t n = 0;
+      double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
+      walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
+        if (fl & FLAG_PRESENT) {
+          const double x = (double)raw;
+          if (n == 0) { mn = x; mx = x; x0 = x; }
+          mn = fmin(mn, x);
+          mx = fmax(mx, x);
+          const double d = x - x0;
+          s1 += d;
+          s2 += d * d;
+          n++;
+        }
+      });
+      slow = n > 0 && (!(mx - mn <= eps) || n < (uint32_t)min_samples);
+      if (st.n_pts != nullptr) {
+        st.n_pts[k] = n;
+        st.n_anom[k] = 0;
+        const double dn = (double)(n ? n : 1);
+        st.key_mean[k] = n ? x0 + s1 / dn : 0.0;
+        st.key_m2[k] = n ? fmax(s2 - s1 * (s1 / dn), 0.0) : 0.0;
+      }
+    }
+  } else if (k < g.K) {
     uint32_t n = 0;
     double mn = 0.0, mx = 0.0, mean = 0.0, m2 = 0.0;
     bool walk = ts.rounds == 0;
@@ -294,7 +320,8 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   unsigned int *count = static_cast<unsigned int *>(scratch);
   uint32_t *list = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + 64);
   hipMemsetAsync(count, 0, sizeof(unsigned int), s);
-  hipLaunchKernelGGL(k_dbscan_scan, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, ts);
+  if (ts.rounds != 0) hipLaunchKernelGGL(k_dbscan_scan<true>, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, ts);
+  else hipLaunchKernelGGL(k_dbscan_scan<false>, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, ts);
   uint64_t blocks = g.K < 2048 ? g.K : 2048;   // grid-stride over the (device-side) list length
   const char *wl_env = getenv("TAD_DBSCAN_WAVELIST");
   if (wl_env != nullptr && wl_env[0] == '1' && g.T <= 256) {

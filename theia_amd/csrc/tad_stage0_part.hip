@@ -163,7 +163,9 @@ __device__ __forceinline__ void hist_row(MetaAcc &a, uint32_t *hist, uint64_t k1
   }
 }
 
-template <bool VEC, bool HAS2, bool SAMPLE_H>
+// (PF, TS, ... : the queued experiments are template parameters, not runtime branches, so that the instantiations the
+// default path launches stay instruction-for-instruction what was measured — tools/isa_diff.py checks that)
+template <bool VEC, bool HAS2, bool SAMPLE_H, bool PF = false>
 __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__restrict__ key,
                                                             const uint64_t *__restrict__ key2,
                                                             const int64_t *__restrict__ t_end,
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
                                                             uint64_t n, uint64_t chunk, uint64_t K, RowFilter f,
                                                             int shift_bin, uint32_t nbins,
                                                             MetaPartial *__restrict__ partials,
-                                                            uint32_t *__restrict__ binhist, DevCounters *ctr, int prefetch) {
+                                                            uint32_t *__restrict__ binhist, DevCounters *ctr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
   for (uint32_t i = threadIdx.x; i < nbins; i += kPartThreads) hist[i] = 0;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
     const bool sample_t = f.end_time == 0 && !has_ts;
     uint64_t i = threadIdx.x;
     uint32_t it = 0;
-    if (SAMPLE_H && prefetch) {
+    if (SAMPLE_H && PF) {
       // Sampled histogram, software-pipelined (TAD_META_PREFETCH=1; queued for measurement): a workgroup reads one iteration in
       // eight, so the loop below is a chain of dependent load -> histogram round trips (~8 per workgroup at C2).  Here the
       // loads of the NEXT sampled iteration are issued before the current one is histogrammed.  Same rows, same counts.
@@ -939,7 +941,7 @@ struct TileGeom {
   uint32_t slice_len;   // record slots per slice (kSliceRecords; twice that when the regions carry the slack of a sampled histogram)
 };
 
-template <bool OPMAX>
+template <bool OPMAX, bool TS = false>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
                                                                  SliceTable st, TileGeom tg, Grid g, int phase,
@@ -1055,7 +1057,7 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
       for (int u = 0; u < U; ++u) apply(r[u]);
     }
     __syncthreads();
-    if (ts.rounds != 0) {
+    if (TS && ts.rounds != 0) {
       // DBSCAN (opt-in): the tile holds this round's buckets of every key of the partition — leave count / min / max / (mean, M2)
       // of each key's values, so that the detector need not read the grid back for the keys it can settle from them.
       // A split partition's tile is partial: its keys are marked for a grid walk.
@@ -1107,7 +1109,7 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
 }
 
 // records whose value did not fit the packed form: fold them into the finished grid (agent-scope integer atomics)
-template <bool OPMAX>
+template <bool OPMAX, bool TS = false>
 __global__ __launch_bounds__(256) void k_apply_overflow(const OverflowRec *__restrict__ ovf,
                                                         const unsigned long long *__restrict__ ovf_count, uint32_t cap, Grid g,
                                                         TileStats ts) {
@@ -1115,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_apply_overflow(const OverflowRec *__res
   if (n > cap) n = cap;
   for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
     const OverflowRec r = ovf[i];
-    if (ts.rounds != 0) ts.n[r.gcell % g.K] = kTileStatsRedo;   // the tile pass did not see this record: round 0 of the key says "walk the grid"
+    if (TS && ts.rounds != 0) ts.n[r.gcell % g.K] = kTileStatsRedo;   // the tile pass did not see this record: round 0 of the key says "walk the grid"
     if (OPMAX) __hip_atomic_fetch_max(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_fetch_add(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     g.flag[r.gcell] = FLAG_PRESENT;
@@ -1357,16 +1359,17 @@ bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   const bool sh = sample_hist && vec && f.end_time == 0 && !(t_start != nullptr && f.start_time != 0);
   const char *pf_env = getenv("TAD_META_PREFETCH");
   const int prefetch = pf_env != nullptr && pf_env[0] == '1';
-#define TAD_MH(V, H2, SH)                                                                                              \
+#define TAD_MH(V, H2, SH, PF)                                                                                          \
   do {                                                                                                                 \
-    allow_big_lds(reinterpret_cast<const void *>(k_meta_hist<V, H2, SH>), kLdsBudget);                                 \
-    hipLaunchKernelGGL((k_meta_hist<V, H2, SH>), dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n, \
-                       pl.chunk, K, f, pl.shift_bin, pl.nbins, partials, binhist, ctr, prefetch);                      \
+    allow_big_lds(reinterpret_cast<const void *>(k_meta_hist<V, H2, SH, PF>), kLdsBudget);                             \
+    hipLaunchKernelGGL((k_meta_hist<V, H2, SH, PF>), dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n, \
+                       pl.chunk, K, f, pl.shift_bin, pl.nbins, partials, binhist, ctr);                                \
   } while (0)
   if (vec) {
-    if (sh) { if (has2) TAD_MH(true, true, true); else TAD_MH(true, false, true); }
-    else { if (has2) TAD_MH(true, true, false); else TAD_MH(true, false, false); }
-  } else { if (has2) TAD_MH(false, true, false); else TAD_MH(false, false, false); }
+    if (sh && prefetch) { if (has2) TAD_MH(true, true, true, true); else TAD_MH(true, false, true, true); }
+    else if (sh) { if (has2) TAD_MH(true, true, true, false); else TAD_MH(true, false, true, false); }
+    else { if (has2) TAD_MH(true, true, false, false); else TAD_MH(true, false, false, false); }
+  } else { if (has2) TAD_MH(false, true, false, false); else TAD_MH(false, false, false, false); }
 #undef TAD_MH
   return sh;
 }
@@ -1533,15 +1536,16 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   const uint32_t par = pl.n_chunks > 1 && !(pr_env && atoi(pr_env) == 0) ? 1u : 0u;
   TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len};
   const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
-  if (op_max) {
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none);
-    hipLaunchKernelGGL((k_tile_aggregate<true>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G, ts);
-    hipLaunchKernelGGL((k_apply_overflow<true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);
-  } else {
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none);
-    hipLaunchKernelGGL((k_tile_aggregate<false>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G, ts);
-    hipLaunchKernelGGL((k_apply_overflow<false>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);
-  }
+#define TAD_TA(OPMAX, TS)                                                                                                                                                              \
+  do {                                                                                                                                                                                 \
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX, false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none);           \
+    if (TS) allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, TS>), kLdsBudget);                                                                                    \
+    hipLaunchKernelGGL((k_tile_aggregate<OPMAX, TS>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G, ts);                          \
+    hipLaunchKernelGGL((k_apply_overflow<OPMAX, TS>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);                                                                      \
+  } while (0)
+  if (ts.rounds != 0) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }
+  else { if (op_max) TAD_TA(true, false); else TAD_TA(false, false); }
+#undef TAD_TA
 }
 
 }  // namespace tad

@@ -7,6 +7,9 @@
 #include "../theia_amd/csrc/tad_arima.hip"
 using namespace tad;
 
+static int g_collapsed = 0;   // which arithmetic contract: arima_nll (general three-state form) or arima_nll_collapsed
+extern "C" void twin_set_filter(int collapsed) { g_collapsed = collapsed != 0; }
+
 static double twin_fit(const double *y, uint32_t p, int maxiter, unsigned long long *steps) {
   Lbfgs o;
   o.col = 0; o.head = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false; o.f = 0.0; o.fc = 0.0; o.fcold = 0.0;
@@ -16,7 +19,7 @@ static double twin_fit(const double *y, uint32_t p, int maxiter, unsigned long l
     for (int phase = 0; phase < 4; ++phase) {
       double xe[3] = {o.x[0], o.x[1], o.x[2]}, dx = 1.0;
       if (phase >= 1) xe[phase - 1] = fd_point(xe[phase - 1], &dx);
-      const KfOut r = arima_nll(xe[0], xe[1], xe[2], y, 1, p);
+      const KfOut r = g_collapsed ? arima_nll_collapsed(xe[0], xe[1], xe[2], y, 1, p) : arima_nll(xe[0], xe[1], xe[2], y, 1, p);
       *steps += p;
       if (phase == 0) { f0 = r.nll; fc0 = r.forecast; }
       else o.g[phase - 1] = (r.nll - f0) / dx;

@@ -4,6 +4,8 @@
 #   TAD_META_PREFETCH=1      C2: software-pipelined sampled histogram in pass A
 #   TAD_DBSCAN_TILESTATS=1   C4: DBSCAN scan from pass C's per-round key statistics
 #   TAD_DBSCAN_WAVELIST=1    C4: exact pair tests with one wavefront per listed key
+#   TAD_ARIMA_FILTER=collapsed   C3: ARIMA likelihood by the collapsed recursion (2.3x fewer instructions per Kalman step);
+#                                TAD_ARIMA_WAVES=2|3|4 wavefronts per SIMD (the tests switch the oracle with the same variable)
 cd /root/repo
 for e in TAD_META_PREFETCH=1 TAD_DBSCAN_TILESTATS=1 TAD_DBSCAN_WAVELIST=1; do
   echo "== parity with $e"
@@ -13,3 +15,8 @@ c2() { env $1 timeout 60 python bench.py --config c2 --steps 20 --warmup 3 --no-
 c4() { env $1 timeout 60 python bench.py --config c4 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); p=d['pipeline']; print('C4 [$1]', round(d['ms_per_step'],3), 'ms; stage0', round(p['ms_stage0_clear_plus_scatter'],3), 'detect', round(p['ms_detect_and_emit'],3), d['result']['anomalies'])"; }
 for r in 1 2; do c2 TAD_META_PREFETCH=0; c2 TAD_META_PREFETCH=1; done
 for r in 1 2; do c4 TAD_DBSCAN_TILESTATS=0; c4 TAD_DBSCAN_TILESTATS=1; c4 TAD_DBSCAN_WAVELIST=1; c4 "TAD_DBSCAN_TILESTATS=1 TAD_DBSCAN_WAVELIST=1"; done
+echo "== ARIMA parity with the collapsed filter"
+env TAD_ARIMA_FILTER=collapsed timeout 900 python -m pytest tests/test_gpu_arima.py tests/test_gpu_fullsize.py tests/test_gpu_job.py -m gpu -x -q -k "arima or c3 or e2e" 2>&1 | tail -2
+c3() { env $1 timeout 120 python bench.py --config c3 --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C3 [$1]', round(d['ms_per_step'],1), 'ms  kalman steps', d['result'].get('kalman_steps'))"; }
+c3 TAD_ARIMA_FILTER=general
+for w in 2 3 4; do c3 "TAD_ARIMA_FILTER=collapsed TAD_ARIMA_WAVES=$w"; done

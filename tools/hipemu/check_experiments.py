@@ -2,6 +2,7 @@
    TAD_META_PREFETCH=1      software-pipelined sampled histogram in pass A
    TAD_DBSCAN_TILESTATS=1   pass C leaves per-round key statistics, the DBSCAN scan settles keys from them
    TAD_DBSCAN_WAVELIST=1    exact DBSCAN pair tests with one wavefront per listed key (readlane broadcast, no LDS / barriers)
+   TAD_ARIMA_FILTER=collapsed   ARIMA likelihood by the collapsed recursion (oracle switched with the same variable)
 Run:  python tools/hipemu/build.py && python tools/hipemu/check_experiments.py
 Every case runs the whole job through the C ABI of the emulated library and compares all rows with the oracle."""
 import os
@@ -84,6 +85,28 @@ def main():
     assert eng.series_dbscan_anomaly(x).tolist() == ref == orc.dbscan_noise_1d(orc.u64_to_f64(np.array(x, dtype=np.uint64))).tolist()
     os.environ.pop("TAD_DBSCAN_WAVELIST")
     print("ok  wavelist  reference golden series + exact-eps chain")
+    # collapsed ARIMA filter: the four-chain fit kernel at 2 / 3 / 4 wavefronts per SIMD against oracle/arima_exact.c in the
+    # same mode (bit for bit: predictions, verdicts, Kalman-step counter), and the default contract untouched next to it
+    from oracle import arima_oracle as ao
+    k, t, v = orc.synth_rows(0, 3000, 20, 40)
+    for flt in ("general", "collapsed"):
+        os.environ["TAD_ARIMA_FILTER"] = flt
+        want = orc.run_job("ARIMA", k, t, v, agg_flow="svc")
+        for waves in ((None,) if flt == "general" else ("2", "3", "4")):
+            if waves: os.environ["TAD_ARIMA_WAVES"] = waves
+            res = eng.run("ARIMA", k, t, v, 20, agg_flow="svc")
+            os.environ.pop("TAD_ARIMA_WAVES", None)
+            assert res.n_rows == want["n_anomalies"], (flt, waves)
+            for f in FIELDS:
+                a, b = res[f], want[f]
+                assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype == np.float64 else (a == b).all(), (flt, waves, f)
+            assert res.stats["kalman_steps"] == want["kalman_steps"], (flt, waves)
+            print("ok  arima     %-9s filter, waves %-4s rows %5d  kalman steps %d" % (flt, waves, res.n_rows, want["kalman_steps"]))
+        got = eng.series_arima(gold["throughput_list"])
+        assert (np.asarray(got).view(np.uint64) == np.asarray(ao.calculate_arima_exact(gold["throughput_list"])).view(np.uint64)).all(), flt
+        assert eng.series_arima_anomaly(gold["throughput_list"], gold["stddev"]).tolist() == gold["expected_anomaly_list_arima"], flt
+    os.environ.pop("TAD_ARIMA_FILTER")
+    print("ok  arima     reference golden series, both filters")
     print("all experiments agree with the oracle on the emulator")
 
 
