@@ -135,7 +135,9 @@ typedef struct {
   float ms_total;          /* device time of the whole run, HIP events on the engine stream */
   int32_t stage0_path;     /* 1 = direct atomic scatter, 2 = partition (sort-by-tile pass B) + LDS tiles, 3 = partition (write-combining pass B) + LDS tiles,
                               4 = sparse table: sort by (key, time) + rank grid (time proportional to the rows, not to keys x lattice),
-                              5 = two-level partition (many keys: wide blocks through the write-combining pass, split again, single-round LDS tiles) */
+                              5 = two-level partition (many keys: wide blocks through the write-combining pass, split again, single-round LDS tiles),
+                              6 = sparse table with skewed series lengths: as 4, then one job per length class of keys (<= 16, <= 64, ... points),
+                                  rows merged back in key order (the K x longest-series rank grid would not fit the workspace) */
   int32_t stage0_attempts; /* times Stage 0 ran before it settled: 1 normally; more after a wrong lattice hint, a sampled lattice or
                               a sampled histogram that proved too optimistic (every fallback is exact), an overflow-list fallback */
   int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/8 of pass A's reads) */

@@ -117,3 +117,86 @@ def test_sparse_with_second_key_time_window_and_aggregate(engine):
             engine.run("EWMA", np.array([500], dtype=np.uint64), t[:1], v[:1], 400, agg_flow="svc")        # key id out of range
     finally:
         del os.environ["TAD_SPARSE"]
+
+
+def skewed_table(K, long_keys, long_len, seed, span=86400):
+    """a few keys with a point at (almost) every second of a day, the rest with 1..12 points: the rank grid of the sparse path
+    would be K x long_len cells for ~K * 6 points"""
+    rng = np.random.default_rng(seed)
+    n_k = rng.integers(1, 13, size=K)
+    n_k[rng.choice(K, size=long_keys, replace=False)] = long_len
+    n_k[rng.choice(K, size=K // 50, replace=False)] = 0          # keys without rows
+    pk = np.repeat(np.arange(K, dtype=np.uint64), n_k)
+    pt = np.concatenate([np.sort(rng.choice(span, size=n, replace=False)) for n in n_k]).astype(np.int64) + 1660202814
+    base = 1_000_000_000 + (orc.mix64(pk + np.uint64(3)) % np.uint64(3_000_000_000)).astype(np.int64)
+    v = (base + rng.integers(-1_000_000, 1_000_000, size=pk.size)).astype(np.uint64)
+    v = np.where(rng.random(pk.size) < 3e-3, v * np.uint64(9), v)
+    dup = rng.random(pk.size) < 0.2                                # some points have two rows
+    k = np.concatenate([pk, pk[dup]]); t = np.concatenate([pt, pt[dup]]); v = np.concatenate([v, v[dup] // np.uint64(3)])
+    order = rng.permutation(k.size)
+    return k[order], t[order], v[order]
+
+
+def check_classes(engine, algo, k, t, v, K, agg_flow):
+    want = orc.run_job(algo, k, t, v, agg_flow=agg_flow)
+    allp = engine.run(algo, k, t, v, K, agg_flow=agg_flow, emit_all=True)
+    assert allp.stats["stage0_path"] == 6
+    pk, pt, pv = want["points"]
+    keep = np.ones(pk.size, dtype=bool)
+    if algo == "ARIMA":
+        keep = np.repeat(np.array([r is not None for r in want["arima_results"]]), np.diff(want["ptr"]))
+    assert allp.n_rows == int(keep.sum())
+    assert (allp["key_id"] == pk[keep]).all() and (allp["flow_end_s"] == pt[keep]).all()          # merged back in (key, time) order
+    assert (allp["throughput"] == orc.u64_to_f64(pv)[keep]).all()
+    assert (allp["stddev"] == np.repeat(want["sigma"], np.diff(want["ptr"]))[keep]).all()
+    assert np.array_equal(allp["algo_calc"], want["calc_all"][keep], equal_nan=True)
+    assert (allp["anomaly"].astype(bool) == want["anomaly_all"][keep]).all()
+    assert allp.stats["n_anomalies"] == int(want["anomaly_all"][keep].sum())
+    res = engine.run(algo, k, t, v, K, agg_flow=agg_flow)
+    assert res.stats["stage0_path"] == 6 and res.n_rows == want["n_anomalies"] == res.stats["n_anomalies"]
+    for f in ("key_id", "flow_end_s", "throughput", "stddev"):
+        assert (res[f] == want[f]).all(), f
+    assert np.array_equal(res["algo_calc"], want["algo_calc"], equal_nan=True)
+    assert res.stats["n_keys"] == want["n_keys"] and res.stats["n_points"] == want["n_points"] and res.stats["rows_used"] == k.size
+    gm = orc.u64_to_f64(pv).mean()
+    assert abs(res.stats["pts_mean"] - gm) <= 1e-12 * gm
+    return res, want
+
+
+@pytest.mark.parametrize("algo,agg", [("EWMA", "svc"), ("DBSCAN", "")])
+def test_skewed_series_lengths_run_as_length_classes(algo, agg):
+    """one key with a day of seconds next to thousands of short-lived ones: the K x longest-series rank grid does not fit
+    the workspace -> the keys run as length classes (stage0_path 6), rows identical to the oracle's"""
+    from theia_amd import TadEngine
+    K = 3000
+    k, t, v = skewed_table(K, long_keys=2, long_len=20000, seed=11)
+    eng = TadEngine(device=0, workspace_limit=256 << 20)          # rank grid: 3000 x 20000 cells x 17 B = 1 GB
+    try:
+        res, want = check_classes(eng, algo, k, t, v, K, agg)
+        print("%s: %d rows, %d points in length classes, %.2f ms" % (algo, k.size, want["n_points"], res.stats["ms_total"]))
+        with pytest.raises(TadError):                              # Stage 0 alone has no class form: the limit stays an error there
+            eng.aggregate(k, t, v, K, agg_flow=agg)
+    finally:
+        eng.close()
+
+
+def test_length_classes_forced_small_tables(engine):
+    # every class boundary (16 / 64 / 256 points), keys without points, ARIMA's no-result keys, a single class
+    os.environ["TAD_SPARSE"] = "1"
+    os.environ["TAD_SPARSE_CLASSES"] = "1"
+    try:
+        rng = np.random.default_rng(3)
+        n_k = np.array([0, 1, 2, 3, 4, 15, 16, 17, 63, 64, 65, 255, 256, 257, 300, 0, 5, 40], dtype=np.int64)
+        K = n_k.size
+        pk = np.repeat(np.arange(K, dtype=np.uint64), n_k)
+        pt = np.concatenate([np.sort(rng.choice(5000, size=n, replace=False)) for n in n_k]).astype(np.int64) + 1660202814
+        v = (2_000_000_000 + rng.integers(-3_000_000, 3_000_000, size=pk.size)).astype(np.uint64)
+        v = np.where(rng.random(pk.size) < 0.02, v * np.uint64(5), v)
+        order = rng.permutation(pk.size)
+        k, t, v = pk[order], pt[order], v[order]
+        for algo, agg in (("EWMA", "svc"), ("DBSCAN", ""), ("ARIMA", "svc")):
+            check_classes(engine, algo, k, t, v, K, agg)
+        k1, t1, v1 = day_table(40, 10, 2, seed=9, span=3000)      # all keys in one class
+        check_classes(engine, "EWMA", k1, t1, v1, 40, "svc")
+    finally:
+        del os.environ["TAD_SPARSE"], os.environ["TAD_SPARSE_CLASSES"]

@@ -47,6 +47,7 @@ struct tad_engine {
   uint64_t rcp_n = 0;
   DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
+  DevBuf sp_cls;                                                                  // Stage 0 sparse, length classes: per-key class arrays
   DevBuf part2_total, part2_start, part2_offs32, part2_cursor, recs2;             // Stage 0 v2, two-level partition
   DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
   hipEvent_t ev[8] = {};
@@ -234,7 +235,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->part_fin, &e->tile_stats, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->part_fin, &e->tile_stats, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -253,6 +254,23 @@ int tad_progress(tad_engine *e, int32_t *done, int32_t *total) {
   if (done) *done = e->done.load();
   if (total) *total = e->total.load();
   return TAD_OK;
+}
+
+// the caller holds e->mu (or e is NULL)
+static void result_free_locked(tad_engine *e, tad_result *r) {
+  if (!r) return;
+  ResultPriv *rp = reinterpret_cast<ResultPriv *>(r);
+  if (rp->block) {
+    if (r->memory == TAD_MEM_DEVICE && e) {
+      if (e->free_blocks.size() < 8) e->free_blocks.push_back({rp->block, rp->block_cap});
+      else { hipSetDevice(e->device); hipFree(rp->block); }
+    } else if (r->memory == TAD_MEM_DEVICE) {
+      hipFree(rp->block);
+    } else {
+      free(rp->block);
+    }
+  }
+  delete rp;
 }
 
 void tad_result_free(tad_engine *e, tad_result *r) {
@@ -445,14 +463,6 @@ int stage_column(tad_engine *e, DevBuf &buf, const void *src, uint64_t n, tad_me
   return TAD_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-}  // extern "C"
-
-namespace {
-
 struct PointsPriv {  // tad_points + its storage
   tad_points pub;
   void *block;
@@ -472,6 +482,11 @@ StreamState state_view(const tad_state *st, int which) {
   v.seen = reinterpret_cast<unsigned char *>(v.n + st->K);
   return v;
 }
+
+int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
+                   tad_state *stream, int depth);
+int run_sparse_classes(tad_engine *e, const tad_job *job, const JobParams &jp, bool op_max, uint64_t n_rows_in, uint64_t rows_used, uint64_t K, Lattice L,
+                       uint64_t P, uint32_t tmax, tad_mem out_memory, tad_result **out);
 
 // The job (points_out == nullptr), Stage 0 alone (points_out != nullptr), or one streaming batch (stream != nullptr).
 int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
@@ -505,10 +520,19 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: detector parameter out of range");
 
   std::lock_guard<std::mutex> lk(e->mu);
+  return run_job_locked(e, job, cols, out_memory, out, points_out, stream, 0);
+}
+
+// the validated job with e->mu held; depth > 0: a length class of a skewed sparse table run as a job of its own
+int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
+                   tad_state *stream, int depth) {
+  const bool points_mode = points_out != nullptr;
   HIP_TRY(e, hipSetDevice(e->device));
   hipStream_t s = e->stream;
-  e->done.store(0);
-  e->total.store(4);
+  if (depth == 0) {
+    e->done.store(0);
+    e->total.store(4);
+  }
 
   JobParams jp;
   jp.algo = job->algo;
@@ -536,6 +560,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
   DevCounters *ctr = static_cast<DevCounters *>(e->counters.p);
 
   HIP_TRY(e, hipEventRecord(e->ev[0], s));
+  if (depth == 0) HIP_TRY(e, hipEventRecord(e->ev[6], s));   // (class jobs of a skewed sparse table re-record ev[0..5])
   // ---- time lattice ----
   // lat_mode 0: the caller's hint; 1: derived — v2 samples the gcd (pass A) and pass B verifies every row, v1 derives it
   // exactly; 2: exact derivation (k_meta).  A row off the lattice (wrong hint / sample missed a residue) moves to the next mode.
@@ -615,7 +640,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       }
     }
     HIP_TRY(e, hipEventRecord(e->ev[1], s));
-    e->done.store(1);
+    if (depth == 0) e->done.store(1);
     if (empty) { L = make_lattice(0, 1, 0); v2 = false; }
 
     // ---- Stage 0: GROUP BY (key, flowEndSeconds) into the time-major point grid ----
@@ -665,6 +690,21 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       }
       cells = K * (uint64_t)tmax;
       need = cells * 17 + (jp.algo == TAD_ALGO_ARIMA ? cells * 68 : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
+      // Skewed series lengths (one key with a day of seconds next to many short-lived ones): K x Tmax does not fit although the
+      // points do.  The keys are split into length classes that run as jobs of their own (run_sparse_classes).
+      const char *cl_env = getenv("TAD_SPARSE_CLASSES");
+      if (P && !points_mode && depth == 0 && (need > e->ws_limit || (cl_env && atoi(cl_env) == 1))) {
+        HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        const DevCounters c0 = *e->ctr_host;
+        if (c0.err & DEV_ERR_KEY_RANGE)
+          return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
+        if (c0.err & DEV_ERR_OFF_LATTICE) {
+          if (lat_mode < 2) { lat_mode = (lat_mode == 0) ? 1 : 2; continue; }
+          return fail(e, TAD_ERR_HIP, "internal error: a row fell off the derived time lattice");
+        }
+        return run_sparse_classes(e, job, jp, op_max, n, c0.rows_used, K, L, P, tmax, out_memory, out);
+      }
       if (need > e->ws_limit)
         return fail(e, TAD_ERR_GRID_TOO_LARGE, "sparse point grid needs %llu bytes (%llu keys x longest series %u points) > workspace limit %llu",
                     (unsigned long long)need, (unsigned long long)K, tmax, (unsigned long long)e->ws_limit);
@@ -783,7 +823,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       HIP_TRY(e, hipEventRecord(e->ev[3], s));
     }
     HIP_TRY(e, hipEventRecord(e->ev[5], s));
-    e->done.store(2);
+    if (depth == 0) e->done.store(2);
 
     // ---- Stage 1+2: sigma, detector, count, scan ----
     uint64_t rows = 0;
@@ -835,7 +875,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       if (lat_mode < 2) { lat_mode = (lat_mode == 0) ? 1 : 2; continue; }  // wrong hint -> derive; sampled gcd too coarse -> exact
       return fail(e, TAD_ERR_HIP, "internal error: a row fell off the derived time lattice");
     }
-    e->done.store(3);
+    if (depth == 0) e->done.store(3);
 
     if (points_mode) {
       PointsPriv *pp = new (std::nothrow) PointsPriv();
@@ -849,7 +889,10 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       if (rows)
         launch_emit_points(s, g, L, static_cast<const unsigned long long *>(e->off.p), reinterpret_cast<unsigned long long *>(d),
                            reinterpret_cast<long long *>(d + r * 8), reinterpret_cast<unsigned long long *>(d + r * 16));
-      HIP_TRY(e, hipEventRecord(e->ev[4], s));
+      {
+        const hipError_t er = hipEventRecord(e->ev[4], s);
+        if (er != hipSuccess) { e->free_blocks.push_back({blk.base, blk.cap}); delete pp; return fail(e, TAD_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er)); }
+      }
       unsigned char *base = d;
       if (out_memory == TAD_MEM_HOST) {
         void *h = malloc(bytes);
@@ -861,10 +904,18 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
         base = static_cast<unsigned char *>(h);
         pp->block = h; pp->block_cap = bytes;
       } else {
-        HIP_TRY(e, hipStreamSynchronize(s));
+        const hipError_t hr = hipStreamSynchronize(s);
+        if (hr != hipSuccess) { e->free_blocks.push_back({blk.base, blk.cap}); delete pp; return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(hr)); }
         pp->block = blk.base; pp->block_cap = blk.cap;
       }
-      HIP_TRY(e, hipGetLastError());
+      {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+          if (out_memory == TAD_MEM_HOST) free(pp->block); else e->free_blocks.push_back({pp->block, pp->block_cap});
+          delete pp;
+          return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le));
+        }
+      }
       pp->pub.n_points = rows;
       pp->pub.key_id = reinterpret_cast<uint64_t *>(base);
       pp->pub.flow_end_s = reinterpret_cast<int64_t *>(base + r * 8);
@@ -921,7 +972,7 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
     hipError_t le = hipStreamSynchronize(s);
     if (le == hipSuccess) le = hipGetLastError();
-    if (le != hipSuccess) { tad_result_free(nullptr, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
+    if (le != hipSuccess) { result_free_locked(e, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
 
     tad_stats &st = rp->pub.stats;
     st.rows_in = n;
@@ -956,7 +1007,8 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
         const uint8_t *a = rp->pub.anomaly;
         if (out_memory == TAD_MEM_DEVICE) {
           tmp.resize(rows);
-          HIP_TRY(e, hipMemcpy(tmp.data(), rp->pub.anomaly, rows, hipMemcpyDeviceToHost));
+          const hipError_t cr = hipMemcpy(tmp.data(), rp->pub.anomaly, rows, hipMemcpyDeviceToHost);
+          if (cr != hipSuccess) { result_free_locked(e, &rp->pub); return fail(e, TAD_ERR_HIP, "verdict copy failed: %s", hipGetErrorString(cr)); }
           a = tmp.data();
         }
         for (uint64_t i = 0; i < rows; ++i) st.n_anomalies += a[i];
@@ -972,11 +1024,157 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)
-    e->done.store(4);
+    if (depth == 0) e->done.store(4);
     *out = &rp->pub;
     return TAD_OK;
   }
   return fail(e, TAD_ERR_HIP, "internal error: Stage 0 did not settle on a lattice / strategy after 6 attempts");
+}
+
+// A sparse table whose K x Tmax rank grid does not fit (skewed series lengths): the keys are split into classes by series
+// length (tad_sparse.hip), every class is handed to run_job_locked as a points table of its own — renumbered dense key ids,
+// (key, time) order kept, one row per point, so its Stage 0 only re-sorts what is sorted — and the row sets are merged back in
+// ORIGINAL key order.  Detectors are per key, so the rows are the rows of the single-grid run, bit for bit; the job-wide
+// moments are Chan-merged in class order (telemetry).  On entry the sorted unique points are in e->sp_comp_a / e->sp_val_a
+// (P of them), e->sp_first[k] = first point of key k; the class jobs reuse every engine buffer, so the parent's state moves
+// to a block of its own first.
+int run_sparse_classes(tad_engine *e, const tad_job *job, const JobParams &jp, bool op_max, uint64_t n_rows_in, uint64_t rows_used, uint64_t K, Lattice L,
+                       uint64_t P, uint32_t tmax, tad_mem out_memory, tad_result **out) {
+  hipStream_t s = e->stream;
+  int rc;
+  const uint32_t nclass = sparse_class_count(tmax);
+  // per-key arrays: len u32 | member u32 | pts u32 | key_off u64[K + 1] | pt_off u64[K + 1]
+  const size_t kpad = (size_t)((K + 3) & ~3ull);
+  if ((rc = ensure(e, e->sp_cls, kpad * 12 + (kpad + 4) * 16 + 64)) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->scan_scratch, scan_scratch_elems(K ? K : 1) * sizeof(unsigned long long))) != TAD_OK) return rc;
+  uint32_t *len = static_cast<uint32_t *>(e->sp_cls.p), *member = len + kpad, *pts = member + kpad;
+  unsigned long long *key_off = reinterpret_cast<unsigned long long *>(pts + kpad), *pt_off = key_off + kpad + 4;
+  unsigned long long *scratch = static_cast<unsigned long long *>(e->scan_scratch.p);
+  const unsigned long long *ucomp = static_cast<const unsigned long long *>(e->sp_comp_a.p), *uval = static_cast<const unsigned long long *>(e->sp_val_a.p);
+  const uint32_t *first = static_cast<const uint32_t *>(e->sp_first.p);
+  HIP_TRY(e, hipMemsetAsync(len, 0, (size_t)K * 4, s));
+  launch_sparse_len(s, ucomp, P, first, len);
+
+  // the class tables: three 8-byte columns per point, class after class, then the key maps (class key -> original key)
+  const uint64_t kmax = K < P ? K : P;   // keys with points
+  ResultBlock blk;
+  if ((rc = alloc_device_block(e, (size_t)P * 24 + (size_t)kmax * 4 + 256, &blk)) != TAD_OK) return rc;
+  unsigned long long *c_key = static_cast<unsigned long long *>(blk.base);
+  long long *c_t = reinterpret_cast<long long *>(c_key + P);
+  unsigned long long *c_val = reinterpret_cast<unsigned long long *>(c_t + P);
+  uint32_t *c_map = reinterpret_cast<uint32_t *>(c_val + P);
+  struct Cls { uint64_t keys, points, key0, pt0; tad_result *res; };
+  std::vector<Cls> cls;
+  auto release = [&]() {
+    for (Cls &c : cls) if (c.res) { result_free_locked(e, c.res); c.res = nullptr; }
+    e->free_blocks.push_back({blk.base, blk.cap});
+  };
+  uint64_t key0 = 0, pt0 = 0;
+  for (uint32_t c = 0; c < nclass; ++c) {
+    launch_sparse_class_counts(s, len, K, c, member, pts);
+    launch_scan(s, member, key_off, K, scratch);
+    launch_scan(s, pts, pt_off, K, scratch);
+    unsigned long long kc = 0, pc = 0;
+    hipError_t hr = hipMemcpyAsync(&kc, key_off + K, 8, hipMemcpyDeviceToHost, s);
+    if (hr == hipSuccess) hr = hipMemcpyAsync(&pc, pt_off + K, 8, hipMemcpyDeviceToHost, s);
+    if (hr == hipSuccess) hr = hipStreamSynchronize(s);
+    if (hr != hipSuccess) { release(); return fail(e, TAD_ERR_HIP, "length classes: %s", hipGetErrorString(hr)); }
+    if (kc == 0) continue;
+    launch_sparse_class_columns(s, ucomp, uval, P, first, len, c, key_off, pt_off, L.t0, c_key + pt0, c_t + pt0, c_val + pt0, c_map + key0);
+    cls.push_back(Cls{kc, pc, key0, pt0, nullptr});
+    key0 += kc;
+    pt0 += pc;
+  }
+  if (pt0 != P || key0 > kmax) { release(); return fail(e, TAD_ERR_HIP, "internal error: length classes cover %llu of %llu points", (unsigned long long)pt0, (unsigned long long)P); }
+  {
+    const hipError_t hr = hipStreamSynchronize(s);   // the class jobs below overwrite the sort buffers the kernels above read
+    if (hr != hipSuccess) { release(); return fail(e, TAD_ERR_HIP, "length classes: %s", hipGetErrorString(hr)); }
+  }
+
+  // one job per class (filters are applied, every (key, time) is unique: the operator no longer matters)
+  tad_job sub = *job;
+  sub.start_time = 0;
+  sub.end_time = 0;
+  sub.value_op = op_max ? TAD_OP_MAX : TAD_OP_SUM;
+  uint64_t rows = 0;
+  for (Cls &c : cls) {
+    tad_columns cc;
+    memset(&cc, 0, sizeof cc);
+    cc.n_rows = c.points;
+    cc.num_keys = c.keys;
+    cc.key_id = reinterpret_cast<const uint64_t *>(c_key + c.pt0);
+    cc.flow_end_s = reinterpret_cast<const int64_t *>(c_t + c.pt0);
+    cc.value = reinterpret_cast<const uint64_t *>(c_val + c.pt0);
+    cc.memory = TAD_MEM_DEVICE;
+    if ((rc = run_job_locked(e, &sub, &cc, TAD_MEM_DEVICE, &c.res, nullptr, nullptr, 1)) != TAD_OK) { release(); return rc; }
+    rows += c.res->n_rows;
+  }
+  e->done.store(3);
+
+  // merge: rows of original key k start at off[k] = rows of all smaller original keys (whatever their class)
+  if ((rc = ensure_key_buffers(e, K)) != TAD_OK) { release(); return rc; }
+  if ((rc = ensure(e, e->aux, (size_t)(K ? K : 1) * 8)) != TAD_OK) { release(); return rc; }
+  uint32_t *cnt = static_cast<uint32_t *>(e->n_anom.p);
+  unsigned long long *off = static_cast<unsigned long long *>(e->off.p), *first_row = static_cast<unsigned long long *>(e->aux.p);
+  ResultPriv *rp = nullptr;
+  OutRows dev_rows;
+  ResultBlock dev_block;
+  if ((rc = make_result(e, rows, jp.all_points, out_memory, &rp, &dev_rows, &dev_block)) != TAD_OK) { release(); return rc; }
+  hipError_t hr = hipMemsetAsync(cnt, 0, (size_t)K * 4, s);
+  for (Cls &c : cls)
+    launch_class_count_rows(s, reinterpret_cast<const unsigned long long *>(c.res->key_id), c.res->n_rows, c_map + c.key0, cnt, first_row);
+  launch_scan(s, cnt, off, K, static_cast<unsigned long long *>(e->scan_scratch.p));
+  for (Cls &c : cls) {
+    OutRows src{reinterpret_cast<unsigned long long *>(c.res->key_id), reinterpret_cast<long long *>(c.res->flow_end_s), c.res->throughput,
+                c.res->algo_calc, c.res->stddev, c.res->anomaly};
+    launch_class_gather(s, src, c.res->n_rows, c_map + c.key0, off, first_row, dev_rows);
+  }
+  if (hr == hipSuccess) hr = hipEventRecord(e->ev[7], s);
+  if (hr == hipSuccess) hr = hipStreamSynchronize(s);
+  if (hr == hipSuccess) hr = hipGetLastError();
+  if (hr != hipSuccess) {
+    e->free_blocks.push_back({dev_block.base, dev_block.cap});
+    delete rp;
+    release();
+    return fail(e, TAD_ERR_HIP, "length classes, merge: %s", hipGetErrorString(hr));
+  }
+  if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; release(); return rc; }
+
+  tad_stats &st = rp->pub.stats;
+  st.rows_in = n_rows_in;
+  st.rows_used = rows_used;
+  st.t0 = L.t0; st.step = L.step; st.n_buckets = L.nb;
+  double mn = 0.0, mean = 0.0, m2 = 0.0;   // Chan merge of the classes' (n_points, mean, M2), class order
+  float ms_classes = 0.0f;
+  for (const Cls &c : cls) {
+    const tad_stats &cs = c.res->stats;
+    st.n_keys += cs.n_keys;
+    st.n_points += cs.n_points;
+    st.n_anomalies += cs.n_anomalies;
+    st.keys_no_result += cs.keys_no_result;
+    st.kalman_steps += cs.kalman_steps;
+    st.arima_fits += cs.arima_fits;
+    ms_classes += cs.ms_total;
+    const double pn = (double)cs.n_points;
+    if (pn == 0.0) continue;
+    if (mn == 0.0) { mn = pn; mean = cs.pts_mean; m2 = cs.pts_m2; continue; }
+    const double nn = mn + pn, d = cs.pts_mean - mean;
+    mean = mean + d * (pn / nn);
+    m2 = m2 + cs.pts_m2 + d * d * (mn * pn / nn);
+    mn = nn;
+  }
+  st.pts_mean = mean;
+  st.pts_m2 = m2;
+  hipEventElapsedTime(&st.ms_total, e->ev[6], e->ev[7]);
+  st.ms_detect = ms_classes;                       // the class jobs, each with its own (small) Stage 0
+  st.ms_stage0 = st.ms_total - ms_classes;         // sort + reduce + class tables + merge
+  st.stage0_path = 6;
+  st.stage0_attempts = 1;
+  strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
+  release();
+  e->done.store(4);
+  *out = &rp->pub;
+  return TAD_OK;
 }
 
 }  // namespace

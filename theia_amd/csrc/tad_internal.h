@@ -288,6 +288,18 @@ int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2
 void launch_sparse_tmax(hipStream_t s, const unsigned long long *ucomp, uint64_t P, uint32_t *first, unsigned int *tmax);
 void launch_sparse_place(hipStream_t s, const unsigned long long *ucomp, const unsigned long long *uval, uint64_t P, const uint32_t *first,
                          int64_t t0, Grid g, long long *times);
+// length classes for skewed sparse tables (tad_sparse.hip; orchestration: tad_capi.cpp:run_sparse_classes)
+uint32_t sparse_class_count(uint32_t tmax);   // classes 0 .. count-1: series of <= 16, <= 64, <= 256, ... points
+void launch_sparse_len(hipStream_t s, const unsigned long long *ucomp, uint64_t P, const uint32_t *first, uint32_t *len);
+void launch_sparse_class_counts(hipStream_t s, const uint32_t *len, uint64_t K, uint32_t c, uint32_t *member, uint32_t *pts);
+void launch_sparse_class_columns(hipStream_t s, const unsigned long long *ucomp, const unsigned long long *uval, uint64_t P, const uint32_t *first,
+                                 const uint32_t *len, uint32_t c, const unsigned long long *key_off, const unsigned long long *pt_off, int64_t t0,
+                                 unsigned long long *out_key, long long *out_t, unsigned long long *out_val, uint32_t *keymap);
+void launch_class_count_rows(hipStream_t s, const unsigned long long *row_key, uint64_t R, const uint32_t *keymap, uint32_t *cnt,
+                             unsigned long long *first_row);
+void launch_class_gather(hipStream_t s, OutRows src, uint64_t R, const uint32_t *keymap, const unsigned long long *off,
+                         const unsigned long long *first_row, OutRows dst);
+
 
 // ---- row-sharded ingest: bucket rows by owner = key mod world (tad_shard.hip) ----
 bool shard_world_ok(uint32_t world);

@@ -94,6 +94,89 @@ __global__ __launch_bounds__(kSpBlock) void k_sparse_place(const unsigned long l
   times[cell] = (long long)(t0 + (int64_t)(c & 0xffffffffull));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Length classes (skewed sparse tables).  The rank grid is K x Tmax cells: one key with a day of second-resolution points
+// next to a million short-lived keys would need 86 400 cells for every key.  When that does not fit the workspace the keys
+// are split into classes by series length (<= 16, <= 64, <= 256, ... points), every class becomes a points table of its own
+// (key ids renumbered densely, order kept) and runs as a job of its own — its rank grid holds at most 4x its points (16
+// cells per key in the first class) — and the row sets are merged back in key order (tad_capi.cpp:run_sparse_classes).
+// Plain kernels: one thread per key / point / row, no shared state beyond integer atomics.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t sparse_class_of(uint32_t len) {   // 1..16 -> 0, 17..64 -> 1, 65..256 -> 2, ...
+  uint32_t c = 0;
+  for (uint64_t bound = 16; len > bound; bound <<= 2) ++c;
+  return c;
+}
+
+// len[k] = points of key k (len zeroed by the caller: keys without points are not visited)
+__global__ __launch_bounds__(kSpBlock) void k_sparse_len(const unsigned long long *__restrict__ ucomp, uint64_t P, const uint32_t *__restrict__ first,
+                                                        uint32_t *__restrict__ len) {
+  const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t k = (uint32_t)(ucomp[i] >> 32);
+  if (i + 1 == P || (uint32_t)(ucomp[i + 1] >> 32) != k) len[k] = (uint32_t)(i - first[k] + 1);
+}
+
+// member[k] = 1 and pts[k] = len[k] for the keys of class c, 0 otherwise (inputs of the two exclusive scans)
+__global__ __launch_bounds__(kSpBlock) void k_sparse_class_counts(const uint32_t *__restrict__ len, uint64_t K, uint32_t c,
+                                                                 uint32_t *__restrict__ member, uint32_t *__restrict__ pts) {
+  const uint64_t k = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
+  if (k >= K) return;
+  const uint32_t n = len[k];
+  const bool in = n != 0 && sparse_class_of(n) == c;
+  member[k] = in ? 1u : 0u;
+  pts[k] = in ? n : 0u;
+}
+
+// the points of class c as a table of their own: (renumbered key, flowEndSeconds, aggregated value), (key, time) order kept
+__global__ __launch_bounds__(kSpBlock) void k_sparse_class_columns(const unsigned long long *__restrict__ ucomp, const unsigned long long *__restrict__ uval,
+                                                                  uint64_t P, const uint32_t *__restrict__ first, const uint32_t *__restrict__ len,
+                                                                  uint32_t c, const unsigned long long *__restrict__ key_off,
+                                                                  const unsigned long long *__restrict__ pt_off, int64_t t0,
+                                                                  unsigned long long *__restrict__ out_key, long long *__restrict__ out_t,
+                                                                  unsigned long long *__restrict__ out_val, uint32_t *__restrict__ keymap) {
+  const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
+  if (i >= P) return;
+  const unsigned long long comp = ucomp[i];
+  const uint32_t k = (uint32_t)(comp >> 32);
+  if (sparse_class_of(len[k]) != c) return;
+  const uint64_t rank = i - first[k];
+  const unsigned long long nk = key_off[k];
+  const unsigned long long at = pt_off[k] + rank;
+  out_key[at] = nk;
+  out_t[at] = (long long)(t0 + (int64_t)(comp & 0xffffffffull));
+  out_val[at] = uval[i];
+  if (rank == 0) keymap[nk] = k;
+}
+
+// rows of one class result (ordered by its renumbered keys): per ORIGINAL key the row count and the first row
+__global__ __launch_bounds__(kSpBlock) void k_class_count_rows(const unsigned long long *__restrict__ row_key, uint64_t R, const uint32_t *__restrict__ keymap,
+                                                              uint32_t *__restrict__ cnt, unsigned long long *__restrict__ first_row) {
+  const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
+  if (i >= R) return;
+  const unsigned long long nk = row_key[i];
+  const uint32_t k = keymap[nk];
+  atomicAdd(&cnt[k], 1u);
+  if (i == 0 || row_key[i - 1] != nk) first_row[k] = i;
+}
+
+// ... and the rows moved to their place in the merged result (ordered by original key, then time)
+__global__ __launch_bounds__(kSpBlock) void k_class_gather(OutRows src, uint64_t R, const uint32_t *__restrict__ keymap,
+                                                          const unsigned long long *__restrict__ off, const unsigned long long *__restrict__ first_row,
+                                                          OutRows dst) {
+  const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
+  if (i >= R) return;
+  const uint32_t k = keymap[src.key_id[i]];
+  const unsigned long long at = off[k] + (i - first_row[k]);
+  dst.key_id[at] = k;
+  dst.flow_end_s[at] = src.flow_end_s[i];
+  dst.throughput[at] = src.throughput[i];
+  dst.algo_calc[at] = src.algo_calc[i];
+  dst.stddev[at] = src.stddev[i];
+  if (src.anomaly != nullptr) dst.anomaly[at] = src.anomaly[i];
+}
+
 size_t sparse_sort_temp_bytes(uint64_t slots) {
   size_t a = 0, b = 0;
   hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
@@ -132,6 +215,38 @@ void launch_sparse_place(hipStream_t s, const unsigned long long *ucomp, const u
                          int64_t t0, Grid g, long long *times) {
   if (P == 0) return;
   hipLaunchKernelGGL(k_sparse_place, dim3((unsigned)((P + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, ucomp, uval, P, first, t0, g, times);
+}
+
+uint32_t sparse_class_count(uint32_t tmax) { return tmax ? sparse_class_of(tmax) + 1 : 0; }
+
+void launch_sparse_len(hipStream_t s, const unsigned long long *ucomp, uint64_t P, const uint32_t *first, uint32_t *len) {
+  if (P == 0) return;
+  hipLaunchKernelGGL(k_sparse_len, dim3((unsigned)((P + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, ucomp, P, first, len);
+}
+
+void launch_sparse_class_counts(hipStream_t s, const uint32_t *len, uint64_t K, uint32_t c, uint32_t *member, uint32_t *pts) {
+  if (K == 0) return;
+  hipLaunchKernelGGL(k_sparse_class_counts, dim3((unsigned)((K + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, len, K, c, member, pts);
+}
+
+void launch_sparse_class_columns(hipStream_t s, const unsigned long long *ucomp, const unsigned long long *uval, uint64_t P, const uint32_t *first,
+                                 const uint32_t *len, uint32_t c, const unsigned long long *key_off, const unsigned long long *pt_off, int64_t t0,
+                                 unsigned long long *out_key, long long *out_t, unsigned long long *out_val, uint32_t *keymap) {
+  if (P == 0) return;
+  hipLaunchKernelGGL(k_sparse_class_columns, dim3((unsigned)((P + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, ucomp, uval, P, first, len, c, key_off,
+                     pt_off, t0, out_key, out_t, out_val, keymap);
+}
+
+void launch_class_count_rows(hipStream_t s, const unsigned long long *row_key, uint64_t R, const uint32_t *keymap, uint32_t *cnt,
+                             unsigned long long *first_row) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(k_class_count_rows, dim3((unsigned)((R + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, row_key, R, keymap, cnt, first_row);
+}
+
+void launch_class_gather(hipStream_t s, OutRows src, uint64_t R, const uint32_t *keymap, const unsigned long long *off,
+                         const unsigned long long *first_row, OutRows dst) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(k_class_gather, dim3((unsigned)((R + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, src, R, keymap, off, first_row, dst);
 }
 
 }  // namespace tad
