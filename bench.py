@@ -40,9 +40,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
 FLOP_PER_KALMAN_STEP = 60
-# opt-in contract TAD_ARIMA_FILTER=collapsed (tad_arima.hip:kfc_step_nc): 1 division + 15 add/mul per step are what is
-# executed; the fraction is then priced on THOSE flops (the 60-flop figure of the three-state form is reported next to it)
-FLOP_PER_KALMAN_STEP_COLLAPSED = 16
+# opt-in contract TAD_ARIMA_FILTER=collapsed (tad_arima.hip:kfc_step4_nc): 15 add/mul per chain and step plus a quarter of
+# the batched inversion (9 multiplications + 1 division per four chains) are what is executed; the fraction is then priced
+# on THOSE flops (the 60-flop figure of the three-state form is reported next to it)
+FLOP_PER_KALMAN_STEP_COLLAPSED = 18
 BYTES_PER_ROW = 24      # key_id u64 + flow_end_s i64 + value u64, read once
 BYTES_PER_ANOMALY = 40  # key_id, flow_end_s, throughput, algo_calc, stddev
 
@@ -312,7 +313,7 @@ def main():
                                 "fits_per_s": st["arima_fits"] / sec, "bound": "fp64 vector ALU / dependency latency",
                                 "achieved_tflops": flops / sec / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                                 "frac": flops / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "ms_detect": a["ms_detect"] / steps,
-                                "flop_model": ("16 flop per time-step of the collapsed recursion (executed) x the engine's kalman_steps counter; "
+                                "flop_model": ("18 flop per time-step of the collapsed recursion (executed) x the engine's kalman_steps counter; "
                                                "three-state form equivalent: %.2f TFLOP/s" % (FLOP_PER_KALMAN_STEP * st["kalman_steps"] / sec / 1e12))
                                               if collapsed else "60 flop per Kalman time-step x the engine's kalman_steps counter (SURVEY.md 8d)"}
                 if len(algos) == 1:     # the detector, not Stage 0, is this config's dominant kernel

@@ -227,48 +227,76 @@ static double arima_nll_general(const double u[3], const double *y, long n, doub
  *     v = (y_t - y_t-1) - a1;  F = p;  g = q12 / F;  a1' = phi (a1 + v) + g v;  p' = (q11 + q22) - q12 g
  * In the general form the same zeros are computed as differences of numbers of size 1e6 (the diffuse prior) and carry
  * rounding residue of ~1e-10 into F; the likelihood is the same function of the parameters in exact arithmetic.  The
- * t = 0 step (approximate diffuse prior, a = 0) is the general update written out with p00 = 1e6, p01 = 0. */
-static double arima_nll_collapsed(const double u[3], const double *y, long n, double *forecast) {
-  const double phi = u[0] / sqrt(1.0 + u[0] * u[0]);
-  const double theta = -(u[1] / sqrt(1.0 + u[1] * u[1]));
-  const double s2 = u[2] * u[2];
-  const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
-  const double qs = q11 + q22;
-  const double p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
-  const double F0 = DIFFUSE + p11, r0 = 1.0 / F0;
-  const double m = DIFFUSE * (p11 * r0), c12 = DIFFUSE * (q12 * r0), c22 = q22 - (q12 * r0) * q12;
-  double p = phi * (phi * m + c12) + (phi * c12 + c22) + q11;     /* predicted p11 for t = 1 */
-  double a1 = 0.0, F = p11, r = r0, g = 0.0, prod = 1.0, q = 0.0, yprev = 0.0;
-  int esum = 0, conv = 0;
-  long nconv = 0, t;
-  if (n >= 1) {                                                   /* t = 0: burned (loglikelihood_burn = 1) */
-    const double w0 = r * y[0];
-    a1 = phi * (F * w0) + q12 * w0;
-    yprev = y[0];
+ * t = 0 step (approximate diffuse prior, a = 0) is the general update written out with p00 = 1e6, p01 = 0.
+ * The optimiser always needs the objective at x and at the three forward-difference points together, so the contract
+ * evaluates the FOUR recursions jointly and takes the four reciprocals 1 / F from ONE division (batched inversion:
+ * inv = 1 / (F0 F1 F2 F3), r0 = inv (F2 F3) F1, ...): IEEE operations in a fixed order like everything else, a quarter
+ * of the divisions. */
+static void arima_nll4_collapsed(const double u4[4][3], const double *y, long n, double nll[4], double *forecast) {
+  double phi[4], q12[4], qs[4], p[4], a1[4], F[4], r[4], g[4], prod[4], q[4], yprev = 0.0;
+  int esum[4], conv[4], c;
+  long nconv[4], t;
+  for (c = 0; c < 4; ++c) {
+    const double ph = u4[c][0] / sqrt(1.0 + u4[c][0] * u4[c][0]);
+    const double theta = -(u4[c][1] / sqrt(1.0 + u4[c][1] * u4[c][1]));
+    const double s2 = u4[c][2] * u4[c][2];
+    const double q11 = s2, q12c = s2 * theta, q22 = s2 * (theta * theta);
+    const double p11 = s2 * (1.0 + theta * theta + 2.0 * ph * theta) / (1.0 - ph * ph);
+    const double F0 = DIFFUSE + p11, r0 = 1.0 / F0;
+    const double m = DIFFUSE * (p11 * r0), c12 = DIFFUSE * (q12c * r0), c22 = q22 - (q12c * r0) * q12c;
+    phi[c] = ph; q12[c] = q12c; qs[c] = q11 + q22;
+    p[c] = ph * (ph * m + c12) + (ph * c12 + c22) + q11;          /* predicted p11 for t = 1 */
+    a1[c] = 0.0; F[c] = p11; r[c] = r0; g[c] = 0.0; prod[c] = 1.0; q[c] = 0.0;
+    esum[c] = 0; conv[c] = 0; nconv[c] = 0;
+    if (n >= 1) {                                                 /* t = 0: burned (loglikelihood_burn = 1) */
+      const double w0 = r[c] * y[0];
+      a1[c] = ph * (F[c] * w0) + q12c * w0;
+    }
   }
+  if (n >= 1) yprev = y[0];
   for (t = 1; t < n; ++t) {
-    const double v = (y[t] - yprev) - a1;
-    double w;
-    if (!conv) { F = p; r = 1.0 / F; g = q12 * r; }
-    w = r * v;
-    q += v * w;
-    if (!conv) { int e; prod = tad_det_frexp(prod * F, &e); esum += e; }
-    else nconv++;
-    a1 = phi * (a1 + v) + g * v;
-    if (!conv) {
-      const double pn = qs - q12 * g, d = p - pn;
-      conv = d * d < CONV_TOL;
-      p = pn;
+    const double d = y[t] - yprev;
+    double Fn[4], rn[4];
+    for (c = 0; c < 4; ++c) Fn[c] = conv[c] ? F[c] : p[c];
+    {
+      const double t12 = Fn[0] * Fn[1], t34 = Fn[2] * Fn[3];
+      const double inv = 1.0 / (t12 * t34);
+      const double i12 = inv * t34, i34 = inv * t12;
+      rn[0] = i12 * Fn[1]; rn[1] = i12 * Fn[0]; rn[2] = i34 * Fn[3]; rn[3] = i34 * Fn[2];
+    }
+    for (c = 0; c < 4; ++c) {
+      const double v = d - a1[c];
+      double w;
+      if (!conv[c]) { F[c] = Fn[c]; r[c] = rn[c]; g[c] = q12[c] * r[c]; }
+      w = r[c] * v;
+      q[c] += v * w;
+      if (!conv[c]) { int e; prod[c] = tad_det_frexp(prod[c] * F[c], &e); esum[c] += e; }
+      else nconv[c]++;
+      a1[c] = phi[c] * (a1[c] + v) + g[c] * v;
+      if (!conv[c]) {
+        const double pn = qs[c] - q12[c] * g[c], dp = p[c] - pn;
+        conv[c] = dp * dp < CONV_TOL;
+        p[c] = pn;
+      }
     }
     yprev = y[t];
   }
-  g_steps += n;
-  if (forecast) *forecast = yprev + a1;
-  return nll_finish(u, prod, esum, nconv, F, q, n);
+  g_steps += 4 * n;
+  for (c = 0; c < 4; ++c) nll[c] = nll_finish(u4[c], prod[c], esum[c], nconv[c], F[c], q[c], n);
+  if (forecast) *forecast = yprev + a1[0];
 }
 
+/* one evaluation (unit tests of the pieces): the joint recursion with four times the same parameters */
 static double arima_nll(const double u[3], const double *y, long n, double *forecast) {
-  return g_filter ? arima_nll_collapsed(u, y, n, forecast) : arima_nll_general(u, y, n, forecast);
+  if (g_filter) {
+    double u4[4][3], nll[4];
+    int c;
+    for (c = 0; c < 4; ++c) { u4[c][0] = u[0]; u4[c][1] = u[1]; u4[c][2] = u[2]; }
+    arima_nll4_collapsed(u4, y, n, nll, forecast);
+    g_steps -= 3 * n;
+    return nll[0];
+  }
+  return arima_nll_general(u, y, n, forecast);
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -482,22 +510,26 @@ struct fitctx { const double *y; long n; };
 
 /* f, the forward-difference gradient (_approx_fprime) and the one-step forecast of the model at x */
 static void eval_fg(const struct fitctx *c, const double x[3], double *f, double g[3], double *fc) {
-  const double f0 = arima_nll(x, c->y, c->n, fc);
-  int i;
+  double u4[4][3], dx[3], nll[4];
+  int i, j;
+  for (i = 0; i < 4; ++i) for (j = 0; j < 3; ++j) u4[i][j] = x[j];
   for (i = 0; i < 3; ++i) {
-    double xe[3] = {x[0], x[1], x[2]};
-    const double x0 = xe[i];
-    double dx;
-    xe[i] = x0 + 1e-5;
-    dx = xe[i] - x0;
-    if (dx == 0.0) {   /* scipy _numdiff.approx_derivative: an absolute step that does not change x falls back to the relative step */
+    const double x0 = x[i];
+    u4[i + 1][i] = x0 + 1e-5;
+    dx[i] = u4[i + 1][i] - x0;
+    if (dx[i] == 0.0) {   /* scipy _numdiff.approx_derivative: an absolute step that does not change x falls back to the relative step */
       const double h = 1.4901161193847656e-08 * (x0 >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(x0));
-      xe[i] = x0 + h;
-      dx = xe[i] - x0;
+      u4[i + 1][i] = x0 + h;
+      dx[i] = u4[i + 1][i] - x0;
     }
-    g[i] = (arima_nll(xe, c->y, c->n, 0) - f0) / dx;
   }
-  *f = f0;
+  if (g_filter) arima_nll4_collapsed(u4, c->y, c->n, nll, fc);   /* the four recursions jointly (batched inversion) */
+  else {
+    nll[0] = arima_nll_general(u4[0], c->y, c->n, fc);
+    for (i = 1; i < 4; ++i) nll[i] = arima_nll_general(u4[i], c->y, c->n, 0);
+  }
+  for (i = 0; i < 3; ++i) g[i] = (nll[i + 1] - nll[0]) / dx[i];
+  *f = nll[0];
 }
 
 static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }

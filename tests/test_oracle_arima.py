@@ -183,7 +183,7 @@ def test_collapsed_filter_against_the_reference_goldens(golden, golden_exact, go
     assert np.median(rel) < 1e-8 and (rel <= 1e-6).sum() >= 60 and rel.max() < 5e-3
     rel = np.abs(np.array(pred) - np.array(golden_exact)) / np.abs(np.array(golden_exact))
     assert np.median(rel) < 1e-8 and (rel <= 1e-6).sum() >= 60 and rel.max() < 5e-3        # measured 1.1e-10, 69 / 90, 1.3e-4
-    assert c["kalman_steps"] < 737856             # the cleaner likelihood also stops the optimiser earlier here (488832)
+    assert c["kalman_steps"] < 737856             # the cleaner likelihood also stops the optimiser earlier here (488148)
 
 
 def test_collapsed_none_cases(collapsed):

@@ -422,33 +422,58 @@ TAD_HD inline void kfc_first(KfStateC &s, double y0) {
   s.a1 = s.phi * (s.F * w0) + s.q12 * w0;
 }
 
-// t >= 1, d = y_t - y_t-1; no lane of the wavefront has converged
-TAD_HD inline void kfc_step_nc(KfStateC &s, double d) {
-  const double v = d - s.a1;
-  s.F = s.p; s.r = 1.0 / s.F; s.g = s.q12 * s.r;
-  const double w = s.r * v;
-  s.q += v * w;
-  int e;
-  s.prod = kf_frexp(s.prod * s.F, &e);
-  s.esum += e;
-  s.a1 = s.phi * (s.a1 + v) + s.g * v;
-  const double pn = s.qs - s.q12 * s.g, dp = s.p - pn;
-  s.conv = dp * dp < kConvTol;
-  s.p = pn;
+// The optimiser always needs the objective at x and at the three forward-difference points together, so the contract runs
+// the FOUR recursions jointly and takes their reciprocals 1 / F from ONE division (batched inversion): IEEE operations in a
+// fixed order like everything else, a quarter of the divisions (a division is ~11 of the ~28 instructions of a step).
+TAD_HD inline void kfc_recip4(const double (&F)[4], double (&r)[4]) {
+  const double t12 = F[0] * F[1], t34 = F[2] * F[3];
+  const double inv = 1.0 / (t12 * t34);
+  const double i12 = inv * t34, i34 = inv * t12;
+  r[0] = i12 * F[1]; r[1] = i12 * F[0]; r[2] = i34 * F[3]; r[3] = i34 * F[2];
 }
 
-TAD_HD inline void kfc_step(KfStateC &s, double d) {
-  const double v = d - s.a1;
-  if (!s.conv) { s.F = s.p; s.r = 1.0 / s.F; s.g = s.q12 * s.r; }
-  const double w = s.r * v;
-  s.q += v * w;
-  if (!s.conv) { int e; s.prod = kf_frexp(s.prod * s.F, &e); s.esum += e; }
-  else s.nconv++;
-  s.a1 = s.phi * (s.a1 + v) + s.g * v;
-  if (!s.conv) {
-    const double pn = s.qs - s.q12 * s.g, dp = s.p - pn;
-    s.conv = dp * dp < kConvTol;
-    s.p = pn;
+// t >= 1, d = y_t - y_t-1; no chain of any lane of the wavefront has converged
+TAD_HD inline void kfc_step4_nc(KfStateC (&s)[4], double d) {
+  double F[4], r[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) F[c] = s[c].p;
+  kfc_recip4(F, r);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double v = d - s[c].a1;
+    s[c].F = F[c]; s[c].r = r[c]; s[c].g = s[c].q12 * s[c].r;
+    const double w = s[c].r * v;
+    s[c].q += v * w;
+    int e;
+    s[c].prod = kf_frexp(s[c].prod * s[c].F, &e);
+    s[c].esum += e;
+    s[c].a1 = s[c].phi * (s[c].a1 + v) + s[c].g * v;
+    const double pn = s[c].qs - s[c].q12 * s[c].g, dp = s[c].p - pn;
+    s[c].conv = dp * dp < kConvTol;
+    s[c].p = pn;
+  }
+}
+
+// the same step with per-chain predication (a converged chain keeps F, r, g; its frozen F still enters the product)
+TAD_HD inline void kfc_step4(KfStateC (&s)[4], double d) {
+  double F[4], r[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) F[c] = s[c].conv ? s[c].F : s[c].p;
+  kfc_recip4(F, r);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double v = d - s[c].a1;
+    if (!s[c].conv) { s[c].F = F[c]; s[c].r = r[c]; s[c].g = s[c].q12 * s[c].r; }
+    const double w = s[c].r * v;
+    s[c].q += v * w;
+    if (!s[c].conv) { int e; s[c].prod = kf_frexp(s[c].prod * s[c].F, &e); s[c].esum += e; }
+    else s[c].nconv++;
+    s[c].a1 = s[c].phi * (s[c].a1 + v) + s[c].g * v;
+    if (!s[c].conv) {
+      const double pn = s[c].qs - s[c].q12 * s[c].g, dp = s[c].p - pn;
+      s[c].conv = dp * dp < kConvTol;
+      s[c].p = pn;
+    }
   }
 }
 
@@ -470,17 +495,26 @@ TAD_HD inline KfOut kfc_finish(const KfStateC &s, uint32_t n, double ylast) {
   return o;
 }
 
-// scalar form over a strided series (tools/arima_twin.cpp)
-TAD_HD KfOut arima_nll_collapsed(const double u0, const double u1, const double u2, const double *__restrict__ y, size_t stride,
-                                 uint32_t n) {
-  KfStateC s;
-  kfc_init(s, u0, u1, u2);
+// the four recursions over a strided series (tools/arima_twin.cpp): nll[0..3], forecast of the first
+TAD_HD void arima_nll4_collapsed(const double (&xe)[4][3], const double *__restrict__ y, size_t stride, uint32_t n, double (&nll)[4],
+                                 double &forecast) {
+  KfStateC s4[4];
+  for (int c = 0; c < 4; ++c) kfc_init(s4[c], xe[c][0], xe[c][1], xe[c][2]);
   double yprev = 0.0;
-  if (n >= 1) { yprev = y[0]; kfc_first(s, yprev); }
-  uint32_t t = 1;
-  for (; t < n && !TAD_WAVE_ALL(s.conv); ++t) { const double yt = y[(size_t)t * stride]; kfc_step(s, yt - yprev); yprev = yt; }
-  for (; t < n; ++t) { const double yt = y[(size_t)t * stride]; kfc_step_conv(s, yt - yprev); yprev = yt; }
-  return kfc_finish(s, n, yprev);
+  if (n >= 1) {
+    yprev = y[0];
+    for (int c = 0; c < 4; ++c) kfc_first(s4[c], yprev);
+  }
+  for (uint32_t t = 1; t < n; ++t) {
+    const double yt = y[(size_t)t * stride];
+    kfc_step4(s4, yt - yprev);
+    yprev = yt;
+  }
+  for (int c = 0; c < 4; ++c) {
+    const KfOut r = kfc_finish(s4[c], n, yprev);
+    nll[c] = r.nll;
+    if (c == 0) forecast = r.forecast;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -990,13 +1024,8 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
             for (int c = 0; c < 4; ++c) kfc_first(s4[c], yv[0]);
           } else {
             const bool any_conv = __any(s4[0].conv || s4[1].conv || s4[2].conv || s4[3].conv);
-            if (!any_conv) {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) kfc_step_nc(s4[c], d);
-            } else {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) kfc_step(s4[c], d);
-            }
+            if (!any_conv) kfc_step4_nc(s4, d);
+            else kfc_step4(s4, d);
           }
         }
     }
