@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 5
+#define TAD_ABI_VERSION 6
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -141,6 +141,8 @@ typedef struct {
   int32_t stage0_attempts; /* times Stage 0 ran before it settled: 1 normally; more after a wrong lattice hint, a sampled lattice or
                               a sampled histogram that proved too optimistic (every fallback is exact), an overflow-list fallback */
   int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/8 of pass A's reads) */
+  int32_t detect_path;     /* how Stage 1-3 ran: 0 = per-key statistics / detector / scan / emit as separate kernels,
+                              1 = the EWMA job's single fused kernel (opt-in TAD_EWMA_FUSED=1: no count pass, no host round trip) */
 } tad_stats;
 
 /* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).

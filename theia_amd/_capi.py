@@ -6,7 +6,7 @@ from . import build as _build
 
 u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
 
-TAD_ABI_VERSION = 5
+TAD_ABI_VERSION = 6
 TAD_KEY_SKIP = (1 << 64) - 1
 TAD_OK = 0
 TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
@@ -40,7 +40,7 @@ class Stats(C.Structure):
                 ("n_anomalies", u64), ("keys_no_result", u64), ("kalman_steps", u64),
                 ("arima_fits", u64), ("pts_mean", f64), ("pts_m2", f64), ("t0", i64), ("step", i64), ("n_buckets", u64),
                 ("ms_meta", f32), ("ms_stage0", f32), ("ms_scatter", f32), ("ms_detect", f32),
-                ("ms_total", f32), ("stage0_path", i32), ("stage0_attempts", i32), ("hist_sampled", i32)]
+                ("ms_total", f32), ("stage0_path", i32), ("stage0_attempts", i32), ("hist_sampled", i32), ("detect_path", i32)]
 
 
 class Result(C.Structure):

@@ -48,6 +48,8 @@ struct tad_engine {
   DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
   DevBuf sp_cls;                                                                  // Stage 0 sparse, length classes: per-key class arrays
+  DevBuf fused_ctl;                                                               // k_ewma_fused: ticket, row total, look-back status words
+  uint64_t ewma_rows_hint = 0;   // rows of the last EWMA job + slack: the result capacity the fused kernel is given (no count pass)
   DevBuf part2_total, part2_start, part2_offs32, part2_cursor, recs2;             // Stage 0 v2, two-level partition
   DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
   hipEvent_t ev[8] = {};
@@ -235,7 +237,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->part_fin, &e->tile_stats, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->fused_ctl, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->part_fin, &e->tile_stats, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -450,6 +452,72 @@ int finish_result(tad_engine *e, ResultPriv *rp, uint64_t rows, bool with_anomal
   rp->pub.algo_calc = ho.algo_calc;
   rp->pub.stddev = ho.stddev;
   rp->pub.anomaly = ho.anomaly;
+  return TAD_OK;
+}
+
+// the same for a device block carved for cap_rows >= rows (k_ewma_fused: the capacity was chosen before the rows were known)
+int finish_result_cap(tad_engine *e, ResultPriv *rp, uint64_t rows, ResultBlock dev_block, OutRows dev_rows) {
+  rp->pub.n_rows = rows;
+  if (rp->pub.memory == TAD_MEM_DEVICE) return finish_result(e, rp, rows, false, dev_block, dev_rows);
+  const size_t bytes = result_bytes(rows, false);
+  void *h = malloc(bytes);
+  if (!h) { e->free_blocks.push_back({dev_block.base, dev_block.cap}); return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu result bytes", bytes); }
+  OutRows ho;
+  carve(h, rows, false, &ho);
+  const void *src[5] = {dev_rows.key_id, dev_rows.flow_end_s, dev_rows.throughput, dev_rows.algo_calc, dev_rows.stddev};
+  void *dst[5] = {ho.key_id, ho.flow_end_s, ho.throughput, ho.algo_calc, ho.stddev};
+  hipError_t r = hipSuccess;
+  for (int c = 0; c < 5 && r == hipSuccess && rows; ++c) r = hipMemcpyAsync(dst[c], src[c], (size_t)rows * 8, hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+  e->free_blocks.push_back({dev_block.base, dev_block.cap});
+  if (r != hipSuccess) { free(h); return fail(e, TAD_ERR_HIP, "result copy failed: %s", hipGetErrorString(r)); }
+  rp->block = h;
+  rp->block_cap = bytes;
+  rp->pub.key_id = reinterpret_cast<uint64_t *>(ho.key_id);
+  rp->pub.flow_end_s = reinterpret_cast<int64_t *>(ho.flow_end_s);
+  rp->pub.throughput = ho.throughput;
+  rp->pub.algo_calc = ho.algo_calc;
+  rp->pub.stddev = ho.stddev;
+  rp->pub.anomaly = nullptr;
+  return TAD_OK;
+}
+
+// EWMA job with TAD_EWMA_FUSED=1: sigma + detector + compaction + emit in one kernel (tad_kernels.hip:k_ewma_fused).  The result
+// block is sized from the engine's last EWMA job (+ 1/8): there is no count pass and no host round trip before the rows are
+// written.  *fused = false on return: the capacity was too small (or there was no hint yet) — the per-key counts are in place,
+// *rows is exact and the caller emits the classic way; true: the rows are in *dev_rows.
+int ewma_fused_run(tad_engine *e, Grid g, Lattice L, const JobParams &jp, DevCounters *ctr, tad_mem out_memory, uint32_t cap, uint64_t out_cap,
+                   ResultPriv **rp_out, OutRows *dev_rows, ResultBlock *dev_block, uint64_t *rows, bool *fused) {
+  hipStream_t s = e->stream;
+  int rc;
+  *fused = false;
+  if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
+  if ((rc = ensure_rcp_table(e, g.T)) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->fused_ctl, ewma_fused_ctl_bytes(g.K))) != TAD_OK) return rc;
+  ResultPriv *rp = nullptr;
+  if ((rc = make_result(e, out_cap, false, out_memory, &rp, dev_rows, dev_block)) != TAD_OK) return rc;
+  auto drop = [&]() { e->free_blocks.push_back({dev_block->base, dev_block->cap}); delete rp; };
+  launch_ewma_fused(s, g, L, jp.alpha, static_cast<const double *>(e->rcp_table.p), static_cast<double *>(e->sigma.p), static_cast<uint32_t *>(e->n_pts.p),
+                    static_cast<uint32_t *>(e->n_anom.p), ctr, static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p), e->fused_ctl.p,
+                    *dev_rows, out_cap, cap);
+  launch_moments(s, g.K, static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
+                 static_cast<Moments *>(e->moments.p), nullptr);
+  hipError_t hr = hipMemcpyAsync(e->total_host, static_cast<unsigned long long *>(e->fused_ctl.p) + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+  if (hr == hipSuccess) hr = hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s);
+  if (hr == hipSuccess) hr = hipMemcpyAsync(e->moments_host, e->moments.p, kMomentBlocks * sizeof(Moments), hipMemcpyDeviceToHost, s);
+  if (hr == hipSuccess) hr = hipEventRecord(e->ev[4], s);
+  if (hr == hipSuccess) hr = hipStreamSynchronize(s);
+  if (hr == hipSuccess) hr = hipGetLastError();
+  if (hr != hipSuccess) { drop(); return fail(e, TAD_ERR_HIP, "fused EWMA kernel: %s", hipGetErrorString(hr)); }
+  *rows = *e->total_host;
+  if (*rows > out_cap) {   // counted, not written: classic emit with the exact size (the counts per key are in n_anom)
+    drop();
+    unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
+    launch_scan(s, static_cast<const uint32_t *>(e->n_anom.p), off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
+    return TAD_OK;
+  }
+  *rp_out = rp;
+  *fused = true;
   return TAD_OK;
 }
 
@@ -827,6 +895,10 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
 
     // ---- Stage 1+2: sigma, detector, count, scan ----
     uint64_t rows = 0;
+    ResultPriv *rp = nullptr;
+    OutRows dev_rows{};
+    ResultBlock dev_block;
+    bool fused_done = false;   // k_ewma_fused has already written the rows into dev_rows
     if (points_mode) {   // every present point: counts = n_pts
       if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
       if ((rc = ensure_rcp_table(e, g.T)) != TAD_OK) return rc;
@@ -855,10 +927,27 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       HIP_TRY(e, hipGetLastError());
       rows = *e->total_host;
       for (int b = 0; b < kMomentBlocks; ++b) e->moments_host[b] = Moments{0.0, 0.0, 0.0};
-    } else if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) {
-      return rc;
+    } else {
+      // EWMA, opt-in: everything after Stage 0 in one kernel, the result block sized from this engine's last EWMA job
+      const char *fu_env = getenv("TAD_EWMA_FUSED");
+      uint32_t fcap = 0;
+      uint64_t fout = 0;
+      if (fu_env != nullptr && fu_env[0] == '1' && jp.algo == TAD_ALGO_EWMA && !jp.all_points && !stats_done && g.K != 0) {
+        fout = e->ewma_rows_hint;
+        if (const char *fr = getenv("TAD_EWMA_FUSED_ROWS")) fout = (uint64_t)atoll(fr);   // tests: pin the capacity of the result block
+        if (fout != 0) fcap = ewma_fused_cap(g, fout);
+      }
+      if (fcap != 0) {
+        if ((rc = ewma_fused_run(e, g, L, jp, ctr, out_memory, fcap, fout, &rp, &dev_rows, &dev_block, &rows, &fused_done)) != TAD_OK) return rc;
+      } else if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) {
+        return rc;
+      }
     }
+    auto drop_fused = [&]() {
+      if (fused_done) { e->free_blocks.push_back({dev_block.base, dev_block.cap}); delete rp; rp = nullptr; fused_done = false; }
+    };
     const DevCounters c = *e->ctr_host;
+    if (c.err != 0) drop_fused();
     if (c.err & DEV_ERR_KEY_RANGE)
       return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
     if (c.err & DEV_ERR_LATE_ROW)
@@ -952,9 +1041,10 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     }
 
     // ---- Stage 3: emit ----
-    ResultPriv *rp = nullptr;
-    OutRows dev_rows;
-    ResultBlock dev_block;
+    const bool fused_ran = fused_done;
+    if (fused_done) {
+      if ((rc = finish_result_cap(e, rp, rows, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
+    } else {
     if ((rc = make_result(e, rows, jp.all_points, out_memory, &rp, &dev_rows, &dev_block)) != TAD_OK) return rc;
     if (rows && stream)
       launch_stream(s, g, L, jp.alpha, jp.all_points, true, state_view(stream, stream->cur), state_view(stream, stream->cur ^ 1),
@@ -970,6 +1060,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       }
     }
     if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
+    }
+    if (jp.algo == TAD_ALGO_EWMA && !jp.all_points && !stream) e->ewma_rows_hint = rows + rows / 8 + 4096;
     hipError_t le = hipStreamSynchronize(s);
     if (le == hipSuccess) le = hipGetLastError();
     if (le != hipSuccess) { result_free_locked(e, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
@@ -1021,6 +1113,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     st.stage0_path = sparse ? 4 : (two_level ? 5 : (v2 ? (pl.wc_cap ? 3 : 2) : 1));
     st.stage0_attempts = attempt + 1;
     st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
+    st.detect_path = fused_ran ? 1 : 0;
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)

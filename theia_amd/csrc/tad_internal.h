@@ -170,6 +170,12 @@ size_t scan_scratch_elems(uint64_t K);
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
                  const unsigned long long *off, OutRows out, uint64_t rows_hint = 0);   // rows_hint: off[K] if the caller knows it
+// EWMA job, Stage 1 + 2 + 3 in one kernel (k_ewma_fused, opt-in).  cap = ewma_fused_cap(g, rows_hint) (0: shape not supported);
+// ctl = ewma_fused_ctl_bytes(K) bytes; afterwards the 8-byte word ctl[1] holds the row total; rows >= out_cap are not written.
+size_t ewma_fused_ctl_bytes(uint64_t K);
+uint32_t ewma_fused_cap(Grid g, uint64_t rows_hint);
+void launch_ewma_fused(hipStream_t s, Grid g, Lattice lat, double alpha, const double *rcp, double *sigma, uint32_t *n_pts, uint32_t *n_anom,
+                       DevCounters *ctr, double *key_mean, double *key_m2, void *ctl, OutRows out, uint64_t out_cap, uint32_t cap);
 void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long long *off, unsigned long long *out_key,
                         long long *out_t, unsigned long long *out_val);
 // streaming EWMA: per-key running state (tad_state); k_stream continues the recurrences over the new grid

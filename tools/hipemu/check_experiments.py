@@ -3,6 +3,7 @@
    TAD_DBSCAN_TILESTATS=1   pass C leaves per-round key statistics, the DBSCAN scan settles keys from them
    TAD_DBSCAN_WAVELIST=1    exact DBSCAN pair tests with one wavefront per listed key (readlane broadcast, no LDS / barriers)
    TAD_ARIMA_FILTER=collapsed   ARIMA likelihood by the collapsed recursion (oracle switched with the same variable)
+   TAD_EWMA_FUSED=1         EWMA job: sigma + detector + compaction + emit in one kernel with a decoupled look-back (k_ewma_fused)
 Run:  python tools/hipemu/build.py && python tools/hipemu/check_experiments.py
 Every case runs the whole job through the C ABI of the emulated library and compares all rows with the oracle."""
 import os
@@ -46,6 +47,57 @@ def check(eng, label, algo, k, t, v, K, agg, env):
     assert abs(res.stats["pts_mean"] - base.stats["pts_mean"]) <= 1e-12 * abs(base.stats["pts_mean"]), label
     assert abs(res.stats["pts_m2"] - base.stats["pts_m2"]) <= 1e-12 * abs(base.stats["pts_m2"]), label
     print("ok  %-58s rows %6d  path %d  sampled %d" % (label, res.n_rows, res.stats["stage0_path"], res.stats["hist_sampled"]))
+
+
+def check_fused(eng):
+    """k_ewma_fused: capacity from the previous job, pinned capacities (exact / too small -> classic emit), a tiny LDS capacity
+    (overflow walk), device and host results, ragged keys (none / one point), the sparse rank grid.  (Workgroups run in
+    order on the emulator, so the look-back never has to wait here; what is checked is everything else.)"""
+    F = {"TAD_EWMA_FUSED": "1"}
+
+    def one(label, k, t, v, K, env, want_path, out="host"):
+        want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+        old = {name: os.environ.get(name) for name in env}
+        os.environ.update(env)
+        try:
+            res = eng.run("EWMA", k, t, v, K, agg_flow="svc", out=out)
+        finally:
+            for name, val in old.items():
+                if val is None:
+                    os.environ.pop(name, None)
+                else:
+                    os.environ[name] = val
+        h = res.to_host() if out == "device" else res
+        assert res.n_rows == want["n_anomalies"], (label, res.n_rows, want["n_anomalies"])
+        for f in FIELDS:
+            assert (h[f] == want[f]).all(), (label, f)
+        assert res.stats["n_keys"] == want["n_keys"] and res.stats["n_points"] == want["n_points"], label
+        assert want_path is None or res.stats["detect_path"] == want_path, (label, res.stats["detect_path"])
+        print("ok  fused     %-58s rows %6d  detect_path %d" % (label, res.n_rows, res.stats["detect_path"]))
+        return res
+
+    for n, K, T in ((3000, 40, 13), (100003, 100, 250), (60000, 300, 100), (5000, 65, 7)):
+        k, t, v = orc.synth_rows(0, n, K, T)
+        rows = one("%d rows / %d keys / %d buckets, first job" % (n, K, T), k, t, v, K, F, None).n_rows
+        one("capacity from the previous job", k, t, v, K, F, 1)
+        one("device result", k, t, v, K, F, 1, out="device")
+        one("result block exactly the rows", k, t, v, K, dict(F, TAD_EWMA_FUSED_ROWS=str(max(rows, 1))), 1)
+        one("result block too small -> classic emit", k, t, v, K, dict(F, TAD_EWMA_FUSED_ROWS=str(max(rows // 2, 1))), 0)
+        one("tiny LDS capacity (overflow walk)", k, t, v, K, dict(F, TAD_EMIT_CAP=str(T + 1)), 1)
+        one("Stage 0 v2", k, t, v, K, dict(F, TAD_STAGE0="v2"), 1)
+    rng = np.random.default_rng(5)
+    K = 150
+    n_k = rng.integers(0, 40, size=K)
+    n_k[::7] = 0
+    n_k[3::11] = 1
+    pk = np.repeat(np.arange(K, dtype=np.uint64), n_k)
+    pt = np.concatenate([np.sort(rng.choice(60, size=n, replace=False)) for n in n_k]).astype(np.int64) * 60 + 1660202814
+    v = (1_000_000_000 * np.exp(rng.normal(0, 0.8, size=pk.size))).astype(np.uint64)
+    o = rng.permutation(pk.size)
+    k, t, v = pk[o], pt[o], v[o]
+    one("ragged noisy table", k, t, v, K, F, 1)
+    one("ragged noisy table, tiny LDS capacity", k, t, v, K, dict(F, TAD_EMIT_CAP="64"), 1)
+    one("sparse rank grid (timestamps from the grid)", k, t, v, K, dict(F, TAD_SPARSE="1"), 1)
 
 
 def main():
@@ -107,6 +159,7 @@ def main():
         assert eng.series_arima_anomaly(gold["throughput_list"], gold["stddev"]).tolist() == gold["expected_anomaly_list_arima"], flt
     os.environ.pop("TAD_ARIMA_FILTER")
     print("ok  arima     reference golden series, both filters")
+    check_fused(eng)
     print("all experiments agree with the oracle on the emulator")
 
 

@@ -142,6 +142,8 @@ template <typename T, typename U> inline T atomicCAS(T *p, U cmp, U v) {
 template <typename T, typename U> inline T __hip_atomic_fetch_add(T *p, U v, int, int) { return atomicAdd(p, v); }
 template <typename T, typename U> inline T __hip_atomic_fetch_max(T *p, U v, int, int) { return atomicMax(p, v); }
 template <typename T, typename U> inline T __hip_atomic_fetch_min(T *p, U v, int, int) { return atomicMin(p, v); }
+template <typename T> inline T __hip_atomic_load(const T *p, int, int) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+template <typename T, typename U> inline void __hip_atomic_store(T *p, U v, int, int) { __atomic_store_n(p, (T)v, __ATOMIC_RELAXED); }
 
 using std::max;
 using std::min;
