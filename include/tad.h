@@ -137,7 +137,8 @@ typedef struct {
                               4 = sparse table: sort by (key, time) + rank grid (time proportional to the rows, not to keys x lattice),
                               5 = two-level partition (many keys: wide blocks through the write-combining pass, split again, single-round LDS tiles),
                               6 = sparse table with skewed series lengths: as 4, then one job per length class of keys (<= 16, <= 64, ... points),
-                                  rows merged back in key order (the K x longest-series rank grid would not fit the workspace) */
+                                  rows merged back in key order (the K x longest-series rank grid would not fit the workspace),
+                              7 = tad_aggregate on such a table: the sorted unique points are the result, no grid at all */
   int32_t stage0_attempts; /* times Stage 0 ran before it settled: 1 normally; more after a wrong lattice hint, a sampled lattice or
                               a sampled histogram that proved too optimistic (every fallback is exact), an overflow-list fallback */
   int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/8 of pass A's reads) */

@@ -174,8 +174,14 @@ def test_skewed_series_lengths_run_as_length_classes(algo, agg):
     try:
         res, want = check_classes(eng, algo, k, t, v, K, agg)
         print("%s: %d rows, %d points in length classes, %.2f ms" % (algo, k.size, want["n_points"], res.stats["ms_total"]))
-        with pytest.raises(TadError):                              # Stage 0 alone has no class form: the limit stays an error there
-            eng.aggregate(k, t, v, K, agg_flow=agg)
+        # Stage 0 alone needs no grid at all: the sorted unique points are the result (stage0_path 7)
+        pts = eng.aggregate(k, t, v, K, agg_flow=agg)
+        pk, pt, pv = orc.stage0(k, t, v, "max" if agg == "" else "sum")
+        assert pts.stats["stage0_path"] == 7 and pts.n_points == pk.size == pts.stats["n_points"]
+        assert (pts["key_id"] == pk).all() and (pts["flow_end_s"] == pt).all() and (pts["value"] == pv).all()
+        assert pts.stats["n_keys"] == np.unique(pk).size and pts.stats["rows_used"] == k.size
+        gm = orc.u64_to_f64(pv).mean()
+        assert abs(pts.stats["pts_mean"] - gm) <= 1e-12 * gm
     finally:
         eng.close()
 

@@ -555,6 +555,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
                    tad_state *stream, int depth);
 int run_sparse_classes(tad_engine *e, const tad_job *job, const JobParams &jp, bool op_max, uint64_t n_rows_in, uint64_t rows_used, uint64_t K, Lattice L,
                        uint64_t P, uint32_t tmax, tad_mem out_memory, tad_result **out);
+int sparse_points_direct(tad_engine *e, uint64_t n_rows_in, uint64_t rows_used, Lattice L, uint64_t P, DevCounters *ctr, tad_mem out_memory,
+                         tad_points **points_out);
 
 // The job (points_out == nullptr), Stage 0 alone (points_out != nullptr), or one streaming batch (stream != nullptr).
 int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
@@ -761,7 +763,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       // Skewed series lengths (one key with a day of seconds next to many short-lived ones): K x Tmax does not fit although the
       // points do.  The keys are split into length classes that run as jobs of their own (run_sparse_classes).
       const char *cl_env = getenv("TAD_SPARSE_CLASSES");
-      if (P && !points_mode && depth == 0 && (need > e->ws_limit || (cl_env && atoi(cl_env) == 1))) {
+      if (P && depth == 0 && (need > e->ws_limit || (cl_env && atoi(cl_env) == 1))) {
         HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
         const DevCounters c0 = *e->ctr_host;
@@ -771,6 +773,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
           if (lat_mode < 2) { lat_mode = (lat_mode == 0) ? 1 : 2; continue; }
           return fail(e, TAD_ERR_HIP, "internal error: a row fell off the derived time lattice");
         }
+        if (points_mode) return sparse_points_direct(e, n, c0.rows_used, L, P, ctr, out_memory, points_out);   // Stage 0 alone needs no grid
         return run_sparse_classes(e, job, jp, op_max, n, c0.rows_used, K, L, P, tmax, out_memory, out);
       }
       if (need > e->ws_limit)
@@ -1122,6 +1125,77 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     return TAD_OK;
   }
   return fail(e, TAD_ERR_HIP, "internal error: Stage 0 did not settle on a lattice / strategy after 6 attempts");
+}
+
+// Stage 0 alone on a sparse table whose rank grid does not fit: the sorted unique points (e->sp_comp_a / e->sp_val_a) are
+// the answer — three columns out, counters and moments from the same pass (tad_sparse.hip:k_sparse_points_out).
+int sparse_points_direct(tad_engine *e, uint64_t n_rows_in, uint64_t rows_used, Lattice L, uint64_t P, DevCounters *ctr, tad_mem out_memory,
+                         tad_points **points_out) {
+  hipStream_t s = e->stream;
+  int rc;
+  if ((rc = ensure(e, e->moments, kMomentBlocks * sizeof(Moments))) != TAD_OK) return rc;
+  PointsPriv *pp = new (std::nothrow) PointsPriv();
+  if (!pp) return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
+  memset(pp, 0, sizeof *pp);
+  const size_t bytes = (size_t)P * 24;
+  ResultBlock blk;
+  if ((rc = alloc_device_block(e, bytes, &blk)) != TAD_OK) { delete pp; return rc; }
+  unsigned char *d = static_cast<unsigned char *>(blk.base);
+  launch_sparse_points_out(s, static_cast<const unsigned long long *>(e->sp_comp_a.p), static_cast<const unsigned long long *>(e->sp_val_a.p), P, L.t0,
+                           reinterpret_cast<unsigned long long *>(d), reinterpret_cast<long long *>(d + P * 8),
+                           reinterpret_cast<unsigned long long *>(d + P * 16), static_cast<Moments *>(e->moments.p), ctr);
+  hipError_t hr = hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s);
+  if (hr == hipSuccess) hr = hipMemcpyAsync(e->moments_host, e->moments.p, kMomentBlocks * sizeof(Moments), hipMemcpyDeviceToHost, s);
+  if (hr == hipSuccess) hr = hipEventRecord(e->ev[7], s);
+  void *h = nullptr;
+  if (hr == hipSuccess && out_memory == TAD_MEM_HOST) {
+    h = malloc(bytes);
+    if (!h) { e->free_blocks.push_back({blk.base, blk.cap}); delete pp; return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu bytes of points", bytes); }
+    hr = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
+  }
+  if (hr == hipSuccess) hr = hipStreamSynchronize(s);
+  if (hr == hipSuccess) hr = hipGetLastError();
+  if (hr != hipSuccess) {
+    e->free_blocks.push_back({blk.base, blk.cap});
+    free(h);
+    delete pp;
+    return fail(e, TAD_ERR_HIP, "sparse Stage 0, points: %s", hipGetErrorString(hr));
+  }
+  unsigned char *base = d;
+  if (out_memory == TAD_MEM_HOST) {
+    e->free_blocks.push_back({blk.base, blk.cap});
+    base = static_cast<unsigned char *>(h);
+    pp->block = h; pp->block_cap = bytes;
+  } else {
+    pp->block = blk.base; pp->block_cap = blk.cap;
+  }
+  pp->pub.n_points = P;
+  pp->pub.key_id = reinterpret_cast<uint64_t *>(base);
+  pp->pub.flow_end_s = reinterpret_cast<int64_t *>(base + P * 8);
+  pp->pub.value = reinterpret_cast<uint64_t *>(base + P * 16);
+  pp->pub.memory = out_memory;
+  tad_stats &st = pp->pub.stats;
+  const DevCounters c = *e->ctr_host;
+  st.rows_in = n_rows_in; st.rows_used = rows_used; st.n_keys = c.n_keys; st.n_points = c.n_points;
+  st.t0 = L.t0; st.step = L.step; st.n_buckets = L.nb;
+  double mn = 0.0, mean = 0.0, m2 = 0.0;
+  for (int b = 0; b < kMomentBlocks; ++b) {
+    const Moments &p = e->moments_host[b];
+    if (p.n == 0.0) continue;
+    if (mn == 0.0) { mn = p.n; mean = p.mean; m2 = p.m2; continue; }
+    const double nn = mn + p.n, dd = p.mean - mean;
+    mean = mean + dd * (p.n / nn);
+    m2 = m2 + p.m2 + dd * dd * (mn * p.n / nn);
+    mn = nn;
+  }
+  st.pts_mean = mean; st.pts_m2 = m2;
+  hipEventElapsedTime(&st.ms_total, e->ev[6], e->ev[7]);
+  st.ms_stage0 = st.ms_total;
+  st.stage0_path = 7;
+  st.stage0_attempts = 1;
+  e->done.store(4);
+  *points_out = &pp->pub;
+  return TAD_OK;
 }
 
 // A sparse table whose K x Tmax rank grid does not fit (skewed series lengths): the keys are split into classes by series

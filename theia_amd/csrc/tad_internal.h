@@ -301,6 +301,9 @@ void launch_sparse_class_counts(hipStream_t s, const uint32_t *len, uint64_t K, 
 void launch_sparse_class_columns(hipStream_t s, const unsigned long long *ucomp, const unsigned long long *uval, uint64_t P, const uint32_t *first,
                                  const uint32_t *len, uint32_t c, const unsigned long long *key_off, const unsigned long long *pt_off, int64_t t0,
                                  unsigned long long *out_key, long long *out_t, unsigned long long *out_val, uint32_t *keymap);
+// Stage 0 alone on a sparse table: the sorted unique points as columns + counters + kMomentBlocks partials of (n, mean, M2)
+void launch_sparse_points_out(hipStream_t s, const unsigned long long *ucomp, const unsigned long long *uval, uint64_t P, int64_t t0,
+                              unsigned long long *out_key, long long *out_t, unsigned long long *out_val, Moments *partials, DevCounters *ctr);
 void launch_class_count_rows(hipStream_t s, const unsigned long long *row_key, uint64_t R, const uint32_t *keymap, uint32_t *cnt,
                              unsigned long long *first_row);
 void launch_class_gather(hipStream_t s, OutRows src, uint64_t R, const uint32_t *keymap, const unsigned long long *off,

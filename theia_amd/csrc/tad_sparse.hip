@@ -217,6 +217,45 @@ void launch_sparse_place(hipStream_t s, const unsigned long long *ucomp, const u
   hipLaunchKernelGGL(k_sparse_place, dim3((unsigned)((P + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, ucomp, uval, P, first, t0, g, times);
 }
 
+// Stage 0 alone (tad_aggregate) needs no grid at all: the sorted unique list IS the result.  Columns out, plus the job
+// counters (keys = key changes in the sorted list) and the points' (n, mean, M2) partials in k_moments' fixed order
+// (strided per thread, shuffle tree, per-block partials; every point enters as (1, value, 0)).
+__global__ __launch_bounds__(kSpBlock) void k_sparse_points_out(const unsigned long long *__restrict__ ucomp, const unsigned long long *__restrict__ uval,
+                                                               uint64_t P, int64_t t0, unsigned long long *__restrict__ out_key,
+                                                               long long *__restrict__ out_t, unsigned long long *__restrict__ out_val,
+                                                               Moments *__restrict__ partials, DevCounters *ctr) {
+  Moments acc{0.0, 0.0, 0.0};
+  unsigned long long keys = 0, pts = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x; i < P; i += (uint64_t)gridDim.x * kSpBlock) {
+    const unsigned long long c = ucomp[i], v = uval[i];
+    out_key[i] = c >> 32;
+    out_t[i] = (long long)(t0 + (int64_t)(c & 0xffffffffull));
+    out_val[i] = v;
+    acc = chan_merge(acc, Moments{1.0, (double)v, 0.0});
+    pts++;
+    keys += (i == 0 || (ucomp[i - 1] >> 32) != (c >> 32)) ? 1u : 0u;
+  }
+  for (int d = 32; d >= 1; d >>= 1) { pts += __shfl_down(pts, d); keys += __shfl_down(keys, d); }
+  if ((threadIdx.x & 63) == 0 && pts) { atomicAdd(&ctr->n_points, pts); atomicAdd(&ctr->n_keys, keys); }
+  for (int d = 1; d < 64; d <<= 1) {
+    Moments o{__shfl_xor(acc.n, d), __shfl_xor(acc.mean, d), __shfl_xor(acc.m2, d)};
+    acc = (threadIdx.x & d) ? chan_merge(o, acc) : chan_merge(acc, o);
+  }
+  __shared__ Moments s_m[kSpBlock / 64];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Moments a = s_m[0];
+    for (int w = 1; w < kSpBlock / 64; ++w) a = chan_merge(a, s_m[w]);
+    partials[blockIdx.x] = a;
+  }
+}
+
+void launch_sparse_points_out(hipStream_t s, const unsigned long long *ucomp, const unsigned long long *uval, uint64_t P, int64_t t0,
+                              unsigned long long *out_key, long long *out_t, unsigned long long *out_val, Moments *partials, DevCounters *ctr) {
+  hipLaunchKernelGGL(k_sparse_points_out, dim3(kMomentBlocks), dim3(kSpBlock), 0, s, ucomp, uval, P, t0, out_key, out_t, out_val, partials, ctr);
+}
+
 uint32_t sparse_class_count(uint32_t tmax) { return tmax ? sparse_class_of(tmax) + 1 : 0; }
 
 void launch_sparse_len(hipStream_t s, const unsigned long long *ucomp, uint64_t P, const uint32_t *first, uint32_t *len) {
