@@ -806,6 +806,19 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     if (v2 && !part_plan_tiles(K, L.nb, has2, &pl)) v2 = false;  // tile does not fit LDS: direct scatter
     bool stats_done = false, two_level = false;
     PartPlan pl1{}, pl2{};
+    // DBSCAN (opt-in, TAD_DBSCAN_TILESTATS=1|2; queued for measurement): pass C leaves per-round key statistics, the detector
+    // settles most keys from them instead of reading the grid back (tad_dbscan.hip:k_dbscan_scan); 2: with one bucket round
+    // per partition (two-level plan) pass C does not even write the columns of the keys it can see are settled
+    auto want_tile_stats = [&](const PartPlan &p) -> int {
+      jp.tile_stats = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+      const char *ts_env = getenv("TAD_DBSCAN_TILESTATS");
+      if (ts_env == nullptr || (ts_env[0] != '1' && ts_env[0] != '2') || jp.algo != TAD_ALGO_DBSCAN || jp.all_points || !dbscan_uses_list(g)) return TAD_OK;
+      const int erc = ensure(e, e->tile_stats, tile_stats_bytes(K, p.n_chunks));
+      if (erc != TAD_OK) return erc;
+      jp.tile_stats = tile_stats_carve(e->tile_stats.p, K, p.n_chunks);
+      if (ts_env[0] == '2') { jp.tile_stats.skip_settled = 1; jp.tile_stats.min_samples = jp.min_samples; jp.tile_stats.eps = jp.eps; }
+      return TAD_OK;
+    };
     if (sparse) {
       // the rank grid is already filled
     } else if (v2 && part_plan_two_level(K, L.nb, has2, columns_aligned16(d_key, d_key2, d_te, d_val), n * (has2 ? 2 : 1), pl, &pl1, &pl2)) {
@@ -839,7 +852,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       HIP_TRY(e, hipEventRecord(e->ev[3], s));
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl1) + slice_table_bytes(slots, pl2))) != TAD_OK) return rc;
       launch_repartition(s, e->recs.p, part_start, pl1, pl2, slots, e->slices.p, part_start2, static_cast<unsigned long long *>(e->part2_cursor.p), e->recs2.p);
-      launch_tile_aggregate(s, e->recs2.p, part_start2, pl2, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap);
+      if ((rc = want_tile_stats(pl2)) != TAD_OK) return rc;
+      launch_tile_aggregate(s, e->recs2.p, part_start2, pl2, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap, nullptr, nullptr, jp.tile_stats);
       pl = pl2;
     } else if (v2) {
       part_plan_wc(hist_sampled ? sampled_slots_bound(n * (has2 ? 2 : 1), pl) : n * (has2 ? 2 : 1), columns_aligned16(d_key, d_key2, d_te, d_val), has2, &pl);
@@ -874,12 +888,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
       // DBSCAN (opt-in, TAD_DBSCAN_TILESTATS=1; queued for measurement): pass C leaves per-round key statistics, the detector
       // settles most keys from them instead of reading the grid back (tad_dbscan.hip:k_dbscan_scan)
-      jp.tile_stats = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-      const char *ts_env = getenv("TAD_DBSCAN_TILESTATS");
-      if (ts_env != nullptr && ts_env[0] == '1' && jp.algo == TAD_ALGO_DBSCAN && !jp.all_points && dbscan_uses_list(g)) {
-        if ((rc = ensure(e, e->tile_stats, tile_stats_bytes(K, pl.n_chunks))) != TAD_OK) return rc;
-        jp.tile_stats = tile_stats_carve(e->tile_stats.p, K, pl.n_chunks);
-      }
+      if ((rc = want_tile_stats(pl)) != TAD_OK) return rc;
       launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap,
                             hist_sampled ? offs32 : nullptr, fin, jp.tile_stats);
     } else {

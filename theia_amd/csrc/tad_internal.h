@@ -202,6 +202,12 @@ struct TileStats {
   uint32_t *n;
   double *mn, *mx, *mean, *m2;
   uint32_t rounds;
+  // TAD_DBSCAN_TILESTATS=2: with ONE bucket round per partition the tile holds every key's whole series, so pass C can see that
+  // a key is settled (no points, or >= min_samples points within eps of each other: no noise) and then does not write its
+  // column of the grid at all — nothing reads it (the detector takes the statistics, emit only visits keys with rows)
+  uint32_t skip_settled;
+  int32_t min_samples;
+  double eps;
 };
 static constexpr uint32_t kTileStatsRedo = 0xFFFFFFFFu;
 inline size_t tile_stats_bytes(uint64_t K, uint32_t rounds) { return (size_t)K * rounds * 36 + 64; }

@@ -946,7 +946,7 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
                                                                  const unsigned long long *__restrict__ part_start,
                                                                  SliceTable st, TileGeom tg, Grid g, int phase,
                                                                  const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G,
-                                                                 TileStats ts) {
+                                                                 TileStats ts, const unsigned long long *__restrict__ ovf_count_in) {
   // Rounds as workgroups: a partition whose KP x T block needs R > 1 LDS tiles is read by R workgroups, one per bucket
   // round, instead of R times by one.  The R workgroups of a slice get block ids x + 8 * (R * j + r): the same XCD
   // (blocks are dealt round-robin over the 8 XCDs) and adjacent in dispatch order, so they stream the same records at
@@ -1057,18 +1057,24 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
       for (int u = 0; u < U; ++u) apply(r[u]);
     }
     __syncthreads();
+    // TS: settled[kk] != 0 -> the key's column of the grid is not written (see TileStats::skip_settled)
+    uint8_t *settled = flags + (((size_t)(tg.tb << shift_part) + 3) & ~(size_t)3);
+    bool skip_cols = false;
     if (TS && ts.rounds != 0) {
       // DBSCAN (opt-in): the tile holds this round's buckets of every key of the partition — leave count / min / max / (mean, M2)
       // of each key's values, so that the detector need not read the grid back for the keys it can settle from them.
-      // A split partition's tile is partial: its keys are marked for a grid walk.
-      for (uint32_t kk = threadIdx.x; kk < KP; kk += kPartThreads) {
+      // A split partition's tile is partial: its keys are marked for a grid walk.  1024 / KP threads share a key (at most a
+      // wavefront's 64): each takes every TPK-th bucket, the partials meet in a shuffle tree (moments: Chan et al., the
+      // lower part first — both partners compute the same value).
+      skip_cols = ts.skip_settled != 0 && tg.n_chunks == 1 && !split && *ovf_count_in == 0ull;
+      const uint32_t tpk_shift = shift_part >= 10 ? 0u : (10u - (uint32_t)shift_part > 6u ? 6u : 10u - (uint32_t)shift_part);
+      const uint32_t TPK = 1u << tpk_shift;
+      for (uint32_t w = threadIdx.x; w < (KP << tpk_shift); w += kPartThreads) {
+        const uint32_t kk = w >> tpk_shift, part = w & (TPK - 1u);
         const uint64_t k = k0 + kk;
-        if (k >= g.K) continue;
-        const size_t o = (size_t)chunk * g.K + k;
-        if (split) { ts.n[o] = kTileStatsRedo; continue; }
         uint32_t n = 0;
         double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
-        for (uint32_t b = 0; b < nb; ++b) {
+        for (uint32_t b = part; b < nb; b += TPK) {
           const uint32_t c = (b << shift_part) + kk;
           if (flags[c]) {
             const double x = (double)vals[c];
@@ -1081,15 +1087,32 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
             n++;
           }
         }
+        Moments m{(double)n, 0.0, 0.0};
+        if (n) { const double dn = (double)n; m.mean = x0 + s1 / dn; m.m2 = fmax(s2 - s1 * (s1 / dn), 0.0); }
+        for (uint32_t d = 1; d < TPK; d <<= 1) {
+          const uint32_t on = __shfl_xor(n, (int)d);
+          const double omn = __shfl_xor(mn, (int)d), omx = __shfl_xor(mx, (int)d);
+          const Moments o{__shfl_xor(m.n, (int)d), __shfl_xor(m.mean, (int)d), __shfl_xor(m.m2, (int)d)};
+          if (on) {
+            mn = n ? fmin(mn, omn) : omn;
+            mx = n ? fmax(mx, omx) : omx;
+          }
+          n += on;
+          m = (part & d) ? chan_merge(o, m) : chan_merge(m, o);
+        }
+        if (part != 0 || k >= g.K) continue;
+        const size_t o = (size_t)chunk * g.K + k;
+        if (split) { ts.n[o] = kTileStatsRedo; continue; }
         ts.n[o] = n;
         if (n) {
-          const double dn = (double)n;
           ts.mn[o] = mn;
           ts.mx[o] = mx;
-          ts.mean[o] = x0 + s1 / dn;
-          ts.m2[o] = fmax(s2 - s1 * (s1 / dn), 0.0);
+          ts.mean[o] = m.mean;
+          ts.m2[o] = m.m2;
         }
+        if (skip_cols) settled[kk] = (n == 0 || (n >= (uint32_t)ts.min_samples && mx - mn <= ts.eps)) ? 1 : 0;   // (LDS for it only then)
       }
+      if (skip_cols) __syncthreads();
     }
     for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
       const uint32_t b = b_lo + (c >> shift_part), kk = c & (KP - 1);
@@ -1097,6 +1120,7 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
       if (k >= g.K) continue;
       const uint64_t gc = (uint64_t)b * g.K + k;
       if (!split) {
+        if (TS && skip_cols && settled[kk]) continue;
         g.val[gc] = vals[c];
         g.flag[gc] = flags[c];
       } else if (flags[c]) {
@@ -1536,11 +1560,15 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   const uint32_t par = pl.n_chunks > 1 && !(pr_env && atoi(pr_env) == 0) ? 1u : 0u;
   TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len};
   const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
+  // settled-key bytes behind the tile: only with one bucket round per partition and if they still fit
+  const size_t settled_lds = ((size_t)pl.KP + 15) & ~(size_t)15;
+  if (ts.skip_settled && (pl.n_chunks != 1 || pl.agg_lds + settled_lds > kLdsBudget)) ts.skip_settled = 0;
 #define TAD_TA(OPMAX, TS)                                                                                                                                                              \
   do {                                                                                                                                                                                 \
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX, false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none);           \
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX, false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none, ovf_count); \
     if (TS) allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, TS>), kLdsBudget);                                                                                    \
-    hipLaunchKernelGGL((k_tile_aggregate<OPMAX, TS>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G, ts);                          \
+    hipLaunchKernelGGL((k_tile_aggregate<OPMAX, TS>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds + (ts.skip_settled ? settled_lds : 0), s, rr, part_start, st, tg, g, 1,            \
+                       offs32, fin, pl.G, ts, ovf_count);                                                                                                                              \
     hipLaunchKernelGGL((k_apply_overflow<OPMAX, TS>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);                                                                      \
   } while (0)
   if (ts.rounds != 0) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }

@@ -37,7 +37,7 @@ def run(eng, algo, k, t, v, K, agg, env):
 
 def check(eng, label, algo, k, t, v, K, agg, env):
     want = orc.run_job(algo, k, t, v, agg_flow=agg)
-    base = run(eng, algo, k, t, v, K, agg, {kk: vv for kk, vv in env.items() if not kk.startswith(("TAD_META_PREFETCH", "TAD_DBSCAN_TILESTATS", "TAD_DBSCAN_WAVELIST"))})
+    base = run(eng, algo, k, t, v, K, agg, {kk_: vv for kk_, vv in env.items() if not kk_.startswith(("TAD_META_PREFETCH", "TAD_DBSCAN_TILESTATS", "TAD_DBSCAN_WAVELIST"))})
     res = run(eng, algo, k, t, v, K, agg, env)
     assert res.n_rows == want["n_anomalies"] == base.n_rows, (label, res.n_rows, want["n_anomalies"])
     for f in FIELDS:
@@ -117,6 +117,30 @@ def main():
         v2_[::997] = rng.integers(2**50, 2**63, size=v2_[::997].size, dtype=np.uint64)    # overflow-list records
         check(eng, "tilestats %s values beyond the packed record range" % partb, "DBSCAN", k, t, v2_, 300, "svc",
               dict(e, TAD_DBSCAN_TILESTATS="1", TAD_KP_SHIFT_MIN="7"))
+    # TILESTATS=2: with one bucket round per partition pass C does not write the columns of the keys it sees are settled (fresh
+    # "device" memory is 0xA5 here: a reader of such a column would show)
+    for partb in ("wc", "sort"):
+        e = dict(v2, TAD_PARTB=partb, TAD_DBSCAN_TILESTATS="2")
+        k, t, v = orc.synth_rows(0, 100003, 100, 250)
+        check(eng, "tilestats=2 %s one round: settled columns not written" % partb, "DBSCAN", k, t, v, 100, "svc", e)
+        check(eng, "tilestats=2 %s + wavelist, max mode" % partb, "DBSCAN", k, t, v, 100, "", dict(e, TAD_DBSCAN_WAVELIST="1"))
+        k, t, v = orc.synth_rows(0, 120000, 300, 250)
+        check(eng, "tilestats=2 %s two rounds (columns written as before)" % partb, "DBSCAN", k, t, v, 300, "svc", dict(e, TAD_KP_SHIFT_MIN="7"))
+        k, t, v = orc.synth_rows(0, 60000, 300, 100)
+        v3 = v.copy()
+        v3[::997] = rng.integers(2**50, 2**63, size=v3[::997].size, dtype=np.uint64)
+        check(eng, "tilestats=2 %s overflow-list records (skipping off for the job)" % partb, "DBSCAN", k, t, v3, 300, "svc", e)
+        kk = np.where(k % np.uint64(5) == 0, k, np.where(rng.random(k.size) < 0.97, orc.KEY_SKIP, k))   # most keys with 0..3 points
+        check(eng, "tilestats=2 %s keys with fewer than min_samples points" % partb, "DBSCAN", kk, t, v, 300, "svc", e)
+    k, t, v = orc.synth_rows(0, 300000, 250000, 100)        # many keys -> two-level plan, single-round 128-key tiles
+    v2 = dict(v2, TAD_SPARSE="0")                           # (so few rows per key would otherwise take the sparse path)
+    res_tl = run(eng, "DBSCAN", k, t, v, 250000, "", dict(v2, TAD_TWO_LEVEL="1"))
+    if res_tl.stats["stage0_path"] == 5:
+        check(eng, "tilestats=2 two-level plan, 250000 keys", "DBSCAN", k, t, v, 250000, "", dict(v2, TAD_TWO_LEVEL="1", TAD_DBSCAN_TILESTATS="2"))
+        check(eng, "tilestats=1 two-level plan, 250000 keys", "DBSCAN", k, t, v, 250000, "", dict(v2, TAD_TWO_LEVEL="1", TAD_DBSCAN_TILESTATS="1"))
+    else:
+        print("--  two-level plan not taken at this size (path %d)" % res_tl.stats["stage0_path"])
+    v2 = {"TAD_STAGE0": "v2"}
     # a hot key: its partition is split over several workgroups (partial tiles -> the detector walks the grid for its keys)
     k, t, v = orc.synth_rows(0, 400000, 300, 64)
     k = np.where(rng.random(k.size) < 0.5, np.uint64(7), k)
