@@ -809,13 +809,16 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     // DBSCAN (opt-in, TAD_DBSCAN_TILESTATS=1|2; queued for measurement): pass C leaves per-round key statistics, the detector
     // settles most keys from them instead of reading the grid back (tad_dbscan.hip:k_dbscan_scan); 2: with one bucket round
     // per partition (two-level plan) pass C does not even write the columns of the keys it can see are settled
-    auto want_tile_stats = [&](const PartPlan &p) -> int {
+    auto want_tile_stats = [&](PartPlan &p) -> int {
       jp.tile_stats = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
       const char *ts_env = getenv("TAD_DBSCAN_TILESTATS");
       if (ts_env == nullptr || (ts_env[0] != '1' && ts_env[0] != '2') || jp.algo != TAD_ALGO_DBSCAN || jp.all_points || !dbscan_uses_list(g)) return TAD_OK;
-      const int erc = ensure(e, e->tile_stats, tile_stats_bytes(K, p.n_chunks));
+      // 2: a multi-round partition is split by key sub-range instead of bucket range, so that its tiles hold whole series too
+      if (ts_env[0] == '2') { const bool kr = part_plan_key_rounds(L.nb, &p); if (getenv("TAD_DEBUG_PLAN")) fprintf(stderr, "key rounds %d: ks_shift %u rounds %u tb %u\n", (int)kr, p.ks_shift, p.n_chunks, p.tb); }
+      const uint32_t rounds = p.ks_shift != 0 ? 1u : p.n_chunks;
+      const int erc = ensure(e, e->tile_stats, tile_stats_bytes(K, rounds));
       if (erc != TAD_OK) return erc;
-      jp.tile_stats = tile_stats_carve(e->tile_stats.p, K, p.n_chunks);
+      jp.tile_stats = tile_stats_carve(e->tile_stats.p, K, rounds);
       if (ts_env[0] == '2') { jp.tile_stats.skip_settled = 1; jp.tile_stats.min_samples = jp.min_samples; jp.tile_stats.eps = jp.eps; }
       return TAD_OK;
     };

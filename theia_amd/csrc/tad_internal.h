@@ -208,6 +208,9 @@ struct TileStats {
   uint32_t skip_settled;
   int32_t min_samples;
   double eps;
+  // ... and for partitions that need several LDS tiles the rounds then split the partition by KEY sub-range (2^ks_shift keys
+  // x all buckets per tile) instead of by bucket range, so that every tile still holds whole series (0: bucket rounds)
+  uint32_t ks_shift;
 };
 static constexpr uint32_t kTileStatsRedo = 0xFFFFFFFFu;
 inline size_t tile_stats_bytes(uint64_t K, uint32_t rounds) { return (size_t)K * rounds * 36 + 64; }
@@ -253,6 +256,7 @@ struct PartPlan {
   int rpt;             // rows per thread per tile in pass B
   int cell_bits;       // record = value << cell_bits | partition-local cell
   uint32_t tb, n_chunks;  // pass C: buckets per LDS round, rounds per partition
+  uint32_t ks_shift;      // pass C, key rounds (TileStats::ks_shift): 2^ks_shift keys x all buckets per round; 0 = bucket rounds
   uint32_t wc_cap;        // write-combining pass B: queue slots per partition (0 = use the sort-by-tile pass B)
   uint32_t wc_sec, wc_rpt;  // wc: records per emitted piece (8 or 16), rows per thread per tile (2 or 4)
   uint64_t pad_slots;     // wc: upper bound of the filler slots (regions rounded up to whole 64-byte sectors)
@@ -262,6 +266,8 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, PartPlan *pl);
 bool columns_aligned16(const void *key, const void *key2, const void *t_end, const void *value);
 bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl);
 bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
+// rounds by key sub-range instead of bucket range, if the tiles allow it (no-op for single-round plans); true = changed
+bool part_plan_key_rounds(uint64_t T, PartPlan *pl);
 bool part_plan_two_level(uint64_t K, uint64_t T, bool has2, bool aligned, uint64_t slots, const PartPlan &base, PartPlan *l1, PartPlan *l2);
 void launch_repartition(hipStream_t s, const void *recs1, const unsigned long long *part_start1, const PartPlan &l1, const PartPlan &l2,
                         uint64_t slots, void *slice_mem, const unsigned long long *part_start2, unsigned long long *cursor2, void *recs2);

@@ -941,7 +941,7 @@ struct TileGeom {
   uint32_t slice_len;   // record slots per slice (kSliceRecords; twice that when the regions carry the slack of a sampled histogram)
 };
 
-template <bool OPMAX, bool TS = false>
+template <bool OPMAX, bool TS = false, bool KR = false>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
                                                                  SliceTable st, TileGeom tg, Grid g, int phase,
@@ -982,20 +982,29 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
   const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * tg.slice_len;
   const unsigned long long hi = lo + tg.slice_len < phi ? lo + tg.slice_len : phi;
   for (uint32_t chunk = r_lo; chunk < r_hi; ++chunk) {
-    const uint32_t b_lo = chunk * tg.tb;
-    const uint32_t nb = b_lo + tg.tb <= T ? tg.tb : T - b_lo;
-    const uint32_t cells = nb << shift_part;
+    // KR (key rounds, with TS only): round `chunk` holds the keys [chunk << ks, (chunk + 1) << ks) of the partition with ALL their
+    // buckets — tile cell = bucket << ks | key within the sub-range — instead of all keys with the buckets [b_lo, b_lo + nb)
+    const int tile_shift = KR ? (int)ts.ks_shift : shift_part;   // log2 of the keys per tile row
+    const uint32_t KT = 1u << tile_shift;
+    const uint32_t kt0 = KR ? chunk << tile_shift : 0u;           // first key of the tile within the partition
+    const uint32_t b_lo = KR ? 0u : chunk * tg.tb;
+    const uint32_t nb = KR ? T : (b_lo + tg.tb <= T ? tg.tb : T - b_lo);
+    const uint32_t cells = nb << tile_shift;
     const uint32_t c_lo = b_lo << shift_part;  // first partition-local cell of this round
     unsigned long long *vals = reinterpret_cast<unsigned long long *>(smem);
-    uint8_t *flags = smem + (size_t)(tg.tb << shift_part) * 8;
+    uint8_t *flags = smem + (size_t)(tg.tb << tile_shift) * 8;
     if (chunk != r_lo) __syncthreads();  // the previous round's tile has been written out
     for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
     for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
     __syncthreads();
     auto apply = [&](unsigned long long r) {
       const uint32_t cg = (uint32_t)r & cell_none;
-      const uint32_t c = cg - c_lo;  // wraps for cells before this round: the unsigned compare rejects them
-      if (cg == cell_none || c >= cells) return;
+      uint32_t c = cg - c_lo;  // wraps for cells before this round: the unsigned compare rejects them
+      if (KR) {
+        const uint32_t kk = cg & (KP - 1u);
+        if (cg == cell_none || (kk >> tile_shift) != chunk) return;
+        c = ((cg >> shift_part) << tile_shift) | (kk & (KT - 1u));
+      } else if (cg == cell_none || c >= cells) return;
       const unsigned long long v = r >> tg.cell_bits;
       if (OPMAX) atomicMax(&vals[c], v);
       else atomicAdd(&vals[c], v);
@@ -1058,7 +1067,7 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
     }
     __syncthreads();
     // TS: settled[kk] != 0 -> the key's column of the grid is not written (see TileStats::skip_settled)
-    uint8_t *settled = flags + (((size_t)(tg.tb << shift_part) + 3) & ~(size_t)3);
+    uint8_t *settled = flags + (((size_t)(tg.tb << tile_shift) + 3) & ~(size_t)3);
     bool skip_cols = false;
     if (TS && ts.rounds != 0) {
       // DBSCAN (opt-in): the tile holds this round's buckets of every key of the partition — leave count / min / max / (mean, M2)
@@ -1066,16 +1075,16 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
       // A split partition's tile is partial: its keys are marked for a grid walk.  1024 / KP threads share a key (at most a
       // wavefront's 64): each takes every TPK-th bucket, the partials meet in a shuffle tree (moments: Chan et al., the
       // lower part first — both partners compute the same value).
-      skip_cols = ts.skip_settled != 0 && tg.n_chunks == 1 && !split && *ovf_count_in == 0ull;
-      const uint32_t tpk_shift = shift_part >= 10 ? 0u : (10u - (uint32_t)shift_part > 6u ? 6u : 10u - (uint32_t)shift_part);
+      skip_cols = ts.skip_settled != 0 && (KR || tg.n_chunks == 1) && !split && *ovf_count_in == 0ull;
+      const uint32_t tpk_shift = tile_shift >= 10 ? 0u : (10u - (uint32_t)tile_shift > 6u ? 6u : 10u - (uint32_t)tile_shift);
       const uint32_t TPK = 1u << tpk_shift;
-      for (uint32_t w = threadIdx.x; w < (KP << tpk_shift); w += kPartThreads) {
+      for (uint32_t w = threadIdx.x; w < (KT << tpk_shift); w += kPartThreads) {
         const uint32_t kk = w >> tpk_shift, part = w & (TPK - 1u);
-        const uint64_t k = k0 + kk;
+        const uint64_t k = k0 + kt0 + kk;
         uint32_t n = 0;
         double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
         for (uint32_t b = part; b < nb; b += TPK) {
-          const uint32_t c = (b << shift_part) + kk;
+          const uint32_t c = (b << tile_shift) + kk;
           if (flags[c]) {
             const double x = (double)vals[c];
             if (n == 0) { mn = x; mx = x; x0 = x; }
@@ -1101,7 +1110,7 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
           m = (part & d) ? chan_merge(o, m) : chan_merge(m, o);
         }
         if (part != 0 || k >= g.K) continue;
-        const size_t o = (size_t)chunk * g.K + k;
+        const size_t o = KR ? (size_t)k : (size_t)chunk * g.K + k;   // key rounds: one set of statistics per key
         if (split) { ts.n[o] = kTileStatsRedo; continue; }
         ts.n[o] = n;
         if (n) {
@@ -1115,8 +1124,8 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
       if (skip_cols) __syncthreads();
     }
     for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
-      const uint32_t b = b_lo + (c >> shift_part), kk = c & (KP - 1);
-      const uint64_t k = k0 + kk;
+      const uint32_t b = b_lo + (c >> tile_shift), kk = c & (KT - 1);
+      const uint64_t k = k0 + kt0 + kk;
       if (k >= g.K) continue;
       const uint64_t gc = (uint64_t)b * g.K + k;
       if (!split) {
@@ -1329,6 +1338,24 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
     if (slots * 10 + fixed <= kLdsBudget) { pl->rpt = r; pl->part_lds = (slots * 10 + fixed + 15) & ~(size_t)15; break; }
   }
   return pl->rpt != 0;
+}
+
+// Key rounds (pass C with per-tile key statistics, TileStats::ks_shift): a partition that needs R > 1 LDS tiles is split by
+// key sub-range — KP / R' keys x ALL buckets per tile, R' = R rounded up to a power of two — instead of by bucket range, so
+// that every tile holds whole series (C4: 512 keys x 34 buckets, 3 rounds -> 128 keys x 100 buckets, 4 rounds).
+bool part_plan_key_rounds(uint64_t T, PartPlan *pl) {
+  pl->ks_shift = 0;
+  if (pl->n_chunks <= 1) return false;
+  int rs = 0;
+  while ((1u << rs) < pl->n_chunks) ++rs;
+  if (rs >= pl->shift_part) return false;
+  const int ks = pl->shift_part - rs;
+  if (ks < 1 || (T << ks) > kTileCells) return false;
+  pl->ks_shift = (uint32_t)ks;
+  pl->n_chunks = 1u << rs;
+  pl->tb = (uint32_t)T;
+  pl->agg_lds = ((size_t)(T << ks) * 9 + 15) & ~(size_t)15;
+  return true;
 }
 
 static bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1561,8 +1588,16 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len};
   const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
   // settled-key bytes behind the tile: only with one bucket round per partition and if they still fit
-  const size_t settled_lds = ((size_t)pl.KP + 15) & ~(size_t)15;
-  if (ts.skip_settled && (pl.n_chunks != 1 || pl.agg_lds + settled_lds > kLdsBudget)) ts.skip_settled = 0;
+  const size_t settled_lds = ((size_t)(pl.ks_shift ? 1u << pl.ks_shift : pl.KP) + 15) & ~(size_t)15;
+  if (ts.skip_settled && ((pl.n_chunks != 1 && pl.ks_shift == 0) || pl.agg_lds + settled_lds > kLdsBudget)) ts.skip_settled = 0;
+#define TAD_TA_KR(OPMAX)                                                                                                                                                               \
+  do {                                                                                                                                                                                 \
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX, false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none, ovf_count); \
+    allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, true, true>), kLdsBudget);                                                                                    \
+    hipLaunchKernelGGL((k_tile_aggregate<OPMAX, true, true>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds + (ts.skip_settled ? settled_lds : 0), s, rr, part_start, st, tg, g, 1,    \
+                       offs32, fin, pl.G, ts, ovf_count);                                                                                                                              \
+    hipLaunchKernelGGL((k_apply_overflow<OPMAX, true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);                                                                    \
+  } while (0)
 #define TAD_TA(OPMAX, TS)                                                                                                                                                              \
   do {                                                                                                                                                                                 \
     if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX, false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none, ovf_count); \
@@ -1571,9 +1606,11 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
                        offs32, fin, pl.G, ts, ovf_count);                                                                                                                              \
     hipLaunchKernelGGL((k_apply_overflow<OPMAX, TS>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);                                                                      \
   } while (0)
-  if (ts.rounds != 0) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }
+  if (ts.rounds != 0 && pl.ks_shift != 0) { ts.ks_shift = pl.ks_shift; if (op_max) TAD_TA_KR(true); else TAD_TA_KR(false); }
+  else if (ts.rounds != 0) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }
   else { if (op_max) TAD_TA(true, false); else TAD_TA(false, false); }
 #undef TAD_TA
+#undef TAD_TA_KR
 }
 
 }  // namespace tad

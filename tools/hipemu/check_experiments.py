@@ -132,6 +132,22 @@ def main():
         check(eng, "tilestats=2 %s overflow-list records (skipping off for the job)" % partb, "DBSCAN", k, t, v3, 300, "svc", e)
         kk = np.where(k % np.uint64(5) == 0, k, np.where(rng.random(k.size) < 0.97, orc.KEY_SKIP, k))   # most keys with 0..3 points
         check(eng, "tilestats=2 %s keys with fewer than min_samples points" % partb, "DBSCAN", kk, t, v, 300, "svc", e)
+    # ... and a partition that needs several LDS tiles is then split by KEY sub-range (whole series per tile) instead of by buckets
+    for partb in ("wc", "sort"):
+        e = dict(v2, TAD_PARTB=partb, TAD_DBSCAN_TILESTATS="2")
+        k, t, v = orc.synth_rows(0, 120000, 300, 250)
+        check(eng, "key rounds %s: 128-key blocks x 250 buckets -> 2 x 64 keys" % partb, "DBSCAN", k, t, v, 300, "svc", dict(e, TAD_KP_SHIFT_MIN="7"))
+        check(eng, "key rounds %s: 256-key blocks, max mode -> 4 x 64 keys" % partb, "DBSCAN", k, t, v, 300, "", dict(e, TAD_KP_SHIFT_MIN="8"))
+        check(eng, "key rounds %s + wavelist" % partb, "DBSCAN", k, t, v, 300, "svc", dict(e, TAD_KP_SHIFT_MIN="8", TAD_DBSCAN_WAVELIST="1"))
+        check(eng, "key rounds %s, rounds one after the other" % partb, "DBSCAN", k, t, v, 300, "svc", dict(e, TAD_KP_SHIFT_MIN="8", TAD_PAR_ROUNDS="0"))
+        v3 = v.copy()
+        v3[::997] = rng.integers(2**50, 2**63, size=v3[::997].size, dtype=np.uint64)
+        check(eng, "key rounds %s overflow-list records" % partb, "DBSCAN", k, t, v3, 300, "svc", dict(e, TAD_KP_SHIFT_MIN="8"))
+        kk = np.where(k % np.uint64(5) == 0, k, np.where(rng.random(k.size) < 0.97, orc.KEY_SKIP, k))
+        check(eng, "key rounds %s keys with fewer than min_samples points" % partb, "DBSCAN", kk, t, v, 300, "svc", dict(e, TAD_KP_SHIFT_MIN="8"))
+    k, t, v = orc.synth_rows(0, 400000, 300, 64)
+    k = np.where(rng.random(k.size) < 0.5, np.uint64(7), k)
+    check(eng, "key rounds hot key (split partition)", "DBSCAN", k, t, v, 300, "svc", dict(v2, TAD_DBSCAN_TILESTATS="2", TAD_HIST_SAMPLE="0", TAD_KP_SHIFT_MIN="9"))
     k, t, v = orc.synth_rows(0, 300000, 250000, 100)        # many keys -> two-level plan, single-round 128-key tiles
     v2 = dict(v2, TAD_SPARSE="0")                           # (so few rows per key would otherwise take the sparse path)
     res_tl = run(eng, "DBSCAN", k, t, v, 250000, "", dict(v2, TAD_TWO_LEVEL="1"))
