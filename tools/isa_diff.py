@@ -70,8 +70,13 @@ def main():
             kb = by_short(*kernels(*b[f]))
             ka = by_short(*kernels(*a[f])) if f in a and a[f][0] else {}
             for short in list(ka):   # a template parameter added with the default 'false' for the existing instantiations
-                if short not in kb and short.endswith(">") and short[:-1] + ", false>" in kb:
-                    ka[short[:-1] + ", false>"] = ka.pop(short)
+                cand = short
+                for _ in range(3):   # up to three added parameters
+                    if cand in kb or not cand.endswith(">"):
+                        break
+                    cand = cand[:-1] + ", false>"
+                if short not in kb and cand in kb:
+                    ka[cand] = ka.pop(short)
                 elif short not in kb and short + "<false>" in kb:
                     ka[short + "<false>"] = ka.pop(short)
             for short in sorted(set(ka) | set(kb)):
