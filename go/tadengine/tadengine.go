@@ -106,6 +106,7 @@ type Row struct {
 type Stats struct {
 	RowsIn, RowsUsed, Keys, Points, Anomalies, KeysNoResult uint64
 	MsTotal                                                  float32
+	Stage0Path, DetectPath                                   int32 // how the engine ran (tad.h: tad_stats.stage0_path / detect_path), for the controller's logs
 }
 
 // cColumn copies a Go slice into C memory: cgo forbids handing Go pointers nested in a C struct, and the
@@ -184,7 +185,8 @@ func (e *Engine) Run(job Job, cols Columns) ([]Row, Stats, error) {
 		}
 	}
 	st = Stats{uint64(res.stats.rows_in), uint64(res.stats.rows_used), uint64(res.stats.n_keys), uint64(res.stats.n_points),
-		uint64(res.stats.n_anomalies), uint64(res.stats.keys_no_result), float32(res.stats.ms_total)}
+		uint64(res.stats.n_anomalies), uint64(res.stats.keys_no_result), float32(res.stats.ms_total),
+		int32(res.stats.stage0_path), int32(res.stats.detect_path)}
 	return rows, st, nil
 }
 
