@@ -402,6 +402,10 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
 
 void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows out, uint64_t rows = 0) {
   const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : (jp.algo == TAD_ALGO_DROP ? 3 : (jp.lazy_sigma ? 4 : 2)));
+  // DBSCAN job: only keys of the detector's work list (still in e->aux) can have rows
+  if (kind == 4 && !jp.all_points &&
+      launch_emit_dbscan_list(e->stream, g, L, e->aux.p, static_cast<const uint32_t *>(e->n_anom.p), static_cast<const unsigned long long *>(e->off.p), out))
+    return;
   launch_emit(e->stream, g, L, kind, jp.all_points, jp.alpha, static_cast<const double *>(e->sigma.p),
               static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(kind == 3 ? e->key_mean.p : e->calc.p),
               static_cast<const unsigned long long *>(e->off.p), out, rows);

@@ -247,6 +247,63 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
   }
 }
 
+// k_emit_dbscan_wave (opt-in with TAD_DBSCAN_WAVELIST=1; queued for measurement) — the DBSCAN job's emit from the detector's
+// WORK LIST instead of a walk over all keys: only listed keys can have noise points, and there are few of them (C4: 1.8 % of
+// the keys, 14 488 rows).  One wavefront per listed key, lane l holds the buckets l, l + 64, ...: one load round instead of a
+// T-step walk with one or two useful lanes per wavefront (k_emit<4>, 0.11 ms at C4); stddev_samp in Spark's streaming order
+// by a readlane loop over the present points (every lane computes the same recurrence); the rows of the key go to
+// off[k] + rank in time order.
+template <int PPL>
+__global__ __launch_bounds__(kDbBlock) void k_emit_dbscan_wave(Grid g, Lattice L, const uint32_t *__restrict__ list,
+                                                              const unsigned int *__restrict__ count, const uint32_t *__restrict__ n_anom,
+                                                              const unsigned long long *__restrict__ off, OutRows out) {
+  const unsigned lane = lane_id();
+  const unsigned wave = threadIdx.x >> 6;
+  const unsigned total = *count;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (unsigned e = blockIdx.x * kDbWaves + wave; e < total; e += gridDim.x * kDbWaves) {   // wavefront-uniform
+    const uint64_t k = list[e];
+    if (n_anom[k] == 0) continue;
+    double x[PPL];
+    unsigned long long pm[PPL], am[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const uint64_t t = lane + 64u * (unsigned)j;
+      const uint8_t fl = t < g.T ? g.flag[t * g.K + k] : (uint8_t)0;
+      x[j] = (fl & FLAG_PRESENT) ? (double)g.val[t * g.K + k] : 0.0;
+      pm[j] = __ballot((fl & FLAG_PRESENT) != 0);
+      am[j] = __ballot((fl & FLAG_ANOMALY) != 0);
+    }
+    // stddev_samp, Spark CentralMomentAgg in time order (k_emit<4>: an IEEE division = the bits of div_by_count)
+    double cnt = 0.0, avg = 0.0, m2 = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < PPL; ++jj)
+      for (unsigned long long m = pm[jj]; m; m &= m - 1) {
+        const double xv = __shfl(x[jj], __ffsll((long long)m) - 1);
+        cnt = cnt + 1.0;
+        const double d = xv - avg;
+        const double dn = d / cnt;
+        avg = avg + dn;
+        m2 = m2 + d * (d - dn);
+      }
+    const double sg = cnt >= 2.0 ? sqrt(m2 / (cnt - 1.0)) : 0.0;
+    unsigned long long at = off[k];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      if ((am[j] >> lane) & 1ull) {
+        const uint64_t t = lane + 64u * (unsigned)j;
+        const unsigned long long r = at + (unsigned long long)__popcll(am[j] & lt_mask);
+        out.key_id[r] = k;
+        out.flow_end_s[r] = g.times != nullptr ? g.times[t * g.K + k] : (long long)(L.t0 + (int64_t)t * L.step);
+        out.throughput[r] = x[j];
+        out.algo_calc[r] = 0.0;
+        out.stddev[r] = sg;
+      }
+      at += (unsigned long long)__popcll(am[j]);
+    }
+  }
+}
+
 // Fallback for series too long for an LDS row: one workgroup per key, points compacted into a global
 // scratch row, x_j streamed from L1/L2 (every lane reads the same address -> one fetch per wave).
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_long(Grid g, double eps, int min_samples,
@@ -334,6 +391,20 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   allow_big_lds(reinterpret_cast<const void *>(k_dbscan_list), 152 * 1024);
   hipLaunchKernelGGL(k_dbscan_list, dim3((unsigned)blocks), dim3(kDbBlock), lds, s, g, eps, min_samples, list, count, st.n_anom);
   return 0;
+}
+
+// the DBSCAN job's emit from the work list launch_dbscan left in `scratch` (false: shape not supported, use launch_emit kind 4)
+bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scratch, const uint32_t *n_anom, const unsigned long long *off,
+                             OutRows out) {
+  const char *wl_env = getenv("TAD_DBSCAN_WAVELIST");
+  if (!(wl_env != nullptr && wl_env[0] == '1') || g.K == 0 || g.T == 0 || g.T > 256 || !list_fits_lds(g.T)) return false;
+  const unsigned int *count = static_cast<const unsigned int *>(scratch);
+  const uint32_t *list = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(scratch) + 64);
+  const uint64_t blocks = g.K < 2048 ? g.K : 2048;
+#define TAD_DBE(PPL) hipLaunchKernelGGL((k_emit_dbscan_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, lat, list, count, n_anom, off, out)
+  if (g.T <= 64) TAD_DBE(1); else if (g.T <= 128) TAD_DBE(2); else if (g.T <= 192) TAD_DBE(3); else TAD_DBE(4);
+#undef TAD_DBE
+  return true;
 }
 
 int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch) {

@@ -230,6 +230,10 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
                   DbscanStats st = DbscanStats{nullptr, nullptr, nullptr, nullptr},
                   TileStats ts = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
 int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch);
+// DBSCAN job (statistics from the scan, sigma computed at emit): the rows from the work list launch_dbscan left in `scratch`,
+// one wavefront per listed key (opt-in with TAD_DBSCAN_WAVELIST=1).  false: not applicable -> launch_emit(kind 4)
+bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scratch, const uint32_t *n_anom, const unsigned long long *off,
+                             OutRows out);
 
 // drop detector (tad_drop.hip): sigma / n_pts / key_mean / key_m2 / counters + FLAG_ANOMALY; ws = K * T doubles
 void launch_drop(hipStream_t s, Grid g, double n_sigma, int min_samples, double *ws, double *sigma, uint32_t *n_pts,

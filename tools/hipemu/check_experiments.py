@@ -1,7 +1,8 @@
 """Parity of the opt-in experiments (env switches, default off, queued for measurement on the GPU) on the host emulator:
    TAD_META_PREFETCH=1      software-pipelined sampled histogram in pass A
    TAD_DBSCAN_TILESTATS=1   pass C leaves per-round key statistics, the DBSCAN scan settles keys from them
-   TAD_DBSCAN_WAVELIST=1    exact DBSCAN pair tests with one wavefront per listed key (readlane broadcast, no LDS / barriers)
+   TAD_DBSCAN_WAVELIST=1    exact DBSCAN pair tests with one wavefront per listed key (readlane broadcast, no LDS / barriers) and
+                            the emit from the same work list (k_emit_dbscan_wave)
    TAD_ARIMA_FILTER=collapsed   ARIMA likelihood by the collapsed recursion (oracle switched with the same variable)
    TAD_EWMA_FUSED=1         EWMA job: sigma + detector + compaction + emit in one kernel with a decoupled look-back (k_ewma_fused)
 Run:  python tools/hipemu/build.py && python tools/hipemu/check_experiments.py
@@ -163,7 +164,7 @@ def main():
     check(eng, "tilestats hot key (split partition)", "DBSCAN", k, t, v, 300, "svc", dict(v2, TAD_DBSCAN_TILESTATS="1", TAD_HIST_SAMPLE="0"))
     check(eng, "prefetch  hot key", "EWMA", k, t, v, 300, "svc", dict(v2, TAD_META_PREFETCH="1"))
     # wavefront-per-key pair tests: 1..4 buckets per lane, keys with fewer than min_samples points, spikes and dips
-    for n, K, T in ((3000, 40, 13), (60000, 300, 100), (100003, 100, 250), (40000, 200, 190)):
+    for n, K, T in ((3000, 40, 13), (60000, 300, 100), (100003, 100, 250), (40000, 200, 190), (20000, 70, 64), (30000, 90, 129)):
         k, t, v = orc.synth_rows(0, n, K, T)
         check(eng, "wavelist  %d rows / %d keys / %d buckets" % (n, K, T), "DBSCAN", k, t, v, K, "svc", dict(v2, TAD_DBSCAN_WAVELIST="1"))
         check(eng, "wavelist + tilestats, max mode, same table", "DBSCAN", k, t, v, K, "", dict(v2, TAD_DBSCAN_WAVELIST="1", TAD_DBSCAN_TILESTATS="1"))
