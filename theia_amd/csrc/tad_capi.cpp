@@ -50,6 +50,7 @@ struct tad_engine {
   DevBuf sp_cls;                                                                  // Stage 0 sparse, length classes: per-key class arrays
   DevBuf fused_ctl;                                                               // k_ewma_fused: ticket, row total, look-back status words
   uint64_t ewma_rows_hint = 0;   // rows of the last EWMA job + slack: the result capacity the fused kernel is given (no count pass)
+  uint64_t ewma_rows_last = 0;   // ... and the rows themselves: sizes the kernel's LDS staging (mean rows per wavefront)
   DevBuf part2_total, part2_start, part2_offs32, part2_cursor, recs2;             // Stage 0 v2, two-level partition
   DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
   hipEvent_t ev[8] = {};
@@ -954,7 +955,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       if (fu_env != nullptr && fu_env[0] == '1' && jp.algo == TAD_ALGO_EWMA && !jp.all_points && !stats_done && g.K != 0) {
         fout = e->ewma_rows_hint;
         if (const char *fr = getenv("TAD_EWMA_FUSED_ROWS")) fout = (uint64_t)atoll(fr);   // tests: pin the capacity of the result block
-        if (fout != 0) fcap = ewma_fused_cap(g, fout);
+        if (fout != 0) fcap = ewma_fused_cap(g, e->ewma_rows_last != 0 ? e->ewma_rows_last : fout);
       }
       if (fcap != 0) {
         if ((rc = ewma_fused_run(e, g, L, jp, ctr, out_memory, fcap, fout, &rp, &dev_rows, &dev_block, &rows, &fused_done)) != TAD_OK) return rc;
@@ -1080,7 +1081,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     }
     if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
     }
-    if (jp.algo == TAD_ALGO_EWMA && !jp.all_points && !stream) e->ewma_rows_hint = rows + rows / 8 + 4096;
+    if (jp.algo == TAD_ALGO_EWMA && !jp.all_points && !stream) { e->ewma_rows_last = rows; e->ewma_rows_hint = rows + rows / 8 + 4096; }
     hipError_t le = hipStreamSynchronize(s);
     if (le == hipSuccess) le = hipGetLastError();
     if (le != hipSuccess) { result_free_locked(e, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
