@@ -206,3 +206,22 @@ def test_length_classes_forced_small_tables(engine):
         check_classes(engine, "EWMA", k1, t1, v1, 40, "svc")
     finally:
         del os.environ["TAD_SPARSE"], os.environ["TAD_SPARSE_CLASSES"]
+
+
+def test_grids_that_do_not_fit_while_the_points_do():
+    """1000 rows over 100 000 keys x 250 buckets under a 1 MB workspace: neither the dense grid (225 MB) nor the rank grid fits,
+    the points do -> length classes; 200 000 rows over 1000 keys: the one class the keys form does not fit either -> refused"""
+    from theia_amd import TadEngine
+    small = TadEngine(device=0, workspace_limit=1 << 20)
+    try:
+        k, t, v = orc.synth_rows(0, 1000, 100000, 250)
+        res = small.run("EWMA", k, t, v, 100000, agg_flow="svc")
+        want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+        assert res.stats["stage0_path"] == 6 and res.n_rows == want["n_anomalies"] and res.stats["n_points"] == want["n_points"]
+        for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+            assert (res[f] == want[f]).all(), f
+        with pytest.raises(TadError) as ei:
+            small.run("EWMA", *orc.synth_rows(0, 200000, 1000, 250), 1000)
+        assert ei.value.code == -6
+    finally:
+        small.close()
