@@ -37,6 +37,34 @@ for name in ("empty", "as_tensor", "tensor", "zeros"):
     orig = getattr(torch, name)
     setattr(torch, name, (lambda f: lambda *a, **k: f(*a, **_host(k)))(orig))
 
+# engine-owned "device" arrays are host memory here: expose them through the array interface numpy / torch read on the host
+sys.path.insert(0, ROOT)
+from theia_amd import distributed as _td  # noqa: E402
+
+
+class HostColumn:
+    def __init__(self, ptr, n, typestr="<i8"):
+        self.__array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 3}
+
+
+_td.DeviceColumn = HostColumn
+_as_tensor = torch.as_tensor
+torch.as_tensor = lambda x, *a, **k: _as_tensor(__import__("numpy").asarray(x) if isinstance(x, HostColumn) else x, *a, **k)
+
+# ... and a host tensor IS a device column here (the engine would otherwise stage it through its host-input path)
+from theia_amd import engine as _eng  # noqa: E402
+
+_as_column = _eng._as_column
+
+
+def _as_column_host_is_device(x, dtype, n_expected=None):
+    if hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and not x.is_cuda and x.is_contiguous() and x.element_size() == 8:
+        return x.data_ptr(), x.numel(), True, x
+    return _as_column(x, dtype, n_expected)
+
+
+_eng._as_column = _as_column_host_is_device
+
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
 os.chdir(ROOT)
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
