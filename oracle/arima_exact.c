@@ -175,8 +175,8 @@ static double nll_finish(const double u[3], double prod, int esum, long nconv, d
 }
 
 static double arima_nll_general(const double u[3], const double *y, long n, double *forecast) {
-  const double phi = u[0] / sqrt(1.0 + u[0] * u[0]);
-  const double theta = -(u[1] / sqrt(1.0 + u[1] * u[1]));
+  const double phi = -(u[0] / sqrt(1.0 + u[0] * u[0]));     /* statsmodels: constrain_stationary_univariate returns -r, */
+  const double theta = u[1] / sqrt(1.0 + u[1] * u[1]);       /* SARIMAX.transform_params negates it again for the MA block */
   const double s2 = u[2] * u[2];
   const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
   double p00 = DIFFUSE, p01 = 0.0;
@@ -237,8 +237,8 @@ static void arima_nll4_collapsed(const double u4[4][3], const double *y, long n,
   int esum[4], conv[4], c;
   long nconv[4], t;
   for (c = 0; c < 4; ++c) {
-    const double ph = u4[c][0] / sqrt(1.0 + u4[c][0] * u4[c][0]);
-    const double theta = -(u4[c][1] / sqrt(1.0 + u4[c][1] * u4[c][1]));
+    const double ph = -(u4[c][0] / sqrt(1.0 + u4[c][0] * u4[c][0]));
+    const double theta = u4[c][1] / sqrt(1.0 + u4[c][1] * u4[c][1]);
     const double s2 = u4[c][2] * u4[c][2];
     const double q11 = s2, q12c = s2 * theta, q22 = s2 * (theta * theta);
     const double p11 = s2 * (1.0 + theta * theta + 2.0 * ph * theta) / (1.0 - ph * ph);
@@ -377,8 +377,8 @@ static void start_params(const double *y, long n, double u[3]) {
   if (!(fabs(phi0) < 1.0)) phi0 = 0.0;
   if (!(fabs(theta0) < 1.0)) theta0 = 0.0;
   var0 = fmax(var0, 1e-10);
-  u[0] = phi0 / sqrt(1.0 - phi0 * phi0);
-  u[1] = -theta0 / sqrt(1.0 - theta0 * theta0);
+  u[0] = -phi0 / sqrt(1.0 - phi0 * phi0);             /* SARIMAX.untransform_params: unconstrain_stationary_univariate(phi), */
+  u[1] = theta0 / sqrt(1.0 - theta0 * theta0);        /* unconstrain_stationary_univariate(-theta) */
   u[2] = sqrt(var0);
 }
 

@@ -66,13 +66,13 @@ def boxcox_transform(x, lam):
 def transform_params(u):
     """unconstrained -> (phi, theta, sigma2): SARIMAX.transform_params with enforce_stationarity /
     enforce_invertibility (constrain_stationary_univariate for one lag) and variance = u**2."""
-    phi = u[0] / math.sqrt(1.0 + u[0] * u[0])
-    theta = -(u[1] / math.sqrt(1.0 + u[1] * u[1]))
+    phi = -(u[0] / math.sqrt(1.0 + u[0] * u[0]))
+    theta = u[1] / math.sqrt(1.0 + u[1] * u[1])
     return phi, theta, u[2] * u[2]
 
 
 def untransform_params(phi, theta, sigma2):
-    return np.array([phi / math.sqrt(1.0 - phi * phi), -theta / math.sqrt(1.0 - theta * theta), math.sqrt(sigma2)])
+    return np.array([-phi / math.sqrt(1.0 - phi * phi), theta / math.sqrt(1.0 - theta * theta), math.sqrt(sigma2)])
 
 
 def kalman_arima111(y, phi, theta, sigma2, counters=None):

@@ -29,10 +29,10 @@ def test_arima_values_against_both_reference_lists(golden, golden_pred):
     # the asserted and the unasserted reference lists agree with each other at only 78 of 90 indices
     self_hits = sum(int(str(v)[:5]) == b for v, b in zip(golden["expanded_arima_row_list"], golden["expected_arima_row_list"]))
     assert self_hits == 78
-    assert hits >= 75, hits                      # measured: 77 / 90
+    assert hits >= 80, hits                      # measured: 81 / 90 (77 before round 3's switch to statsmodels' parameter signs)
     full = np.array(golden["expanded_arima_row_list"])
     rel = np.abs(np.array(golden_pred) - full) / full
-    assert np.median(rel) < 1e-7 and np.percentile(rel, 90) < 1e-4 and rel.max() < 5e-3   # measured 1e-9 / 1.6e-5 / 1.9e-3
+    assert np.median(rel) < 1e-7 and np.percentile(rel, 90) < 5e-5 and rel.max() < 5e-4   # measured 1e-9 / 1.2e-5 / 2.5e-4
     # the first three predictions are inv_boxcox(boxcox(x)) (:241,255-256)
     assert np.allclose(golden_pred[:3], golden["throughput_list"][:3], rtol=1e-12)
 
@@ -89,10 +89,11 @@ def test_exact_verdicts_equal_reference_golden(golden, golden_exact):
 def test_exact_values_against_both_reference_lists(golden, golden_exact):
     five = [int(str(v)[:5]) for v in golden_exact]
     hits = sum(a == b for a, b in zip(five, golden["expected_arima_row_list"]))   # :261-283, first five characters
-    assert hits >= 76, hits                       # measured 78 / 90 — as many as the reference's own two lists share
+    assert hits >= 80, hits                       # measured 82 / 90 (the reference's own two lists share 78); every miss but index 4
+    #                                               is an index where those two lists disagree with each other
     full = np.array(golden["expanded_arima_row_list"])                            # :288-318, never asserted by the reference
     rel = np.abs(np.array(golden_exact) - full) / full
-    assert np.median(rel) < 1e-7 and np.percentile(rel, 90) < 1e-4 and rel.max() < 5e-3   # measured 3.4e-10 / 2.5e-5 / 1.9e-3
+    assert np.median(rel) < 1e-7 and np.percentile(rel, 90) < 5e-5 and rel.max() < 5e-4   # measured 3.2e-10 / 7.0e-6 / 2.7e-4
     assert np.allclose(golden_exact[:3], golden["throughput_list"][:3], rtol=1e-12)
 
 
@@ -174,10 +175,10 @@ def test_collapsed_filter_against_the_reference_goldens(golden, golden_exact, go
     assert verdict == golden["expected_anomaly_list_arima"]                       # anomaly_detection_test.py:320-345
     five = [int(str(v)[:5]) for v in pred]
     hits = sum(a == b for a, b in zip(five, golden["expected_arima_row_list"]))
-    assert hits >= 76, hits                       # measured 76 / 90 (general form 78; the reference's own two lists share 78)
+    assert hits >= 80, hits                       # measured 81 / 90 (general form 82; the reference's own two lists share 78)
     full = np.array(golden["expanded_arima_row_list"])
     rel = np.abs(np.array(pred) - full) / full
-    assert np.median(rel) < 1e-7 and np.percentile(rel, 90) < 1e-4 and rel.max() < 5e-3   # measured 9.3e-10 / 1.5e-5 / 1.9e-3
+    assert np.median(rel) < 1e-7 and np.percentile(rel, 90) < 5e-5 and rel.max() < 5e-4   # measured 9.3e-10 / 4.9e-6 / 2.5e-4
     # as close to the scipy-driven restatement as the general form is (73 vs 72 of 90 within 1e-6), and to the general form itself
     rel = np.abs(np.array(pred) - np.array(golden_pred)) / np.abs(np.array(golden_pred))
     assert np.median(rel) < 1e-8 and (rel <= 1e-6).sum() >= 60 and rel.max() < 5e-3

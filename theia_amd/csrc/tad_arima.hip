@@ -262,8 +262,8 @@ struct KfState {
 };
 
 TAD_HD inline void kf_init(KfState &s, double u0, double u1, double u2) {
-  const double phi = u0 / sqrt(1.0 + u0 * u0);
-  const double theta = -(u1 / sqrt(1.0 + u1 * u1));
+  const double phi = -(u0 / sqrt(1.0 + u0 * u0));   // statsmodels' convention: constrain_stationary_univariate returns -r,
+  const double theta = u1 / sqrt(1.0 + u1 * u1);     // SARIMAX.transform_params negates it once more for the MA block
   const double s2 = u2 * u2;
   s.phi = phi;
   s.q11 = s2; s.q12 = s2 * theta; s.q22 = s2 * (theta * theta);
@@ -401,8 +401,8 @@ struct KfStateC {
 };
 
 TAD_HD inline void kfc_init(KfStateC &s, double u0, double u1, double u2) {
-  const double phi = u0 / sqrt(1.0 + u0 * u0);
-  const double theta = -(u1 / sqrt(1.0 + u1 * u1));
+  const double phi = -(u0 / sqrt(1.0 + u0 * u0));   // statsmodels' convention: constrain_stationary_univariate returns -r,
+  const double theta = u1 / sqrt(1.0 + u1 * u1);     // SARIMAX.transform_params negates it once more for the MA block
   const double s2 = u2 * u2;
   const double q11 = s2, q12 = s2 * theta, q22 = s2 * (theta * theta);
   const double p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
@@ -590,8 +590,8 @@ TAD_HD void arima_start_params(const double *__restrict__ y, size_t stride, uint
   if (!(fabs(phi0) < 1.0)) phi0 = 0.0;      // non-stationary start -> zeros
   if (!(fabs(theta0) < 1.0)) theta0 = 0.0;  // non-invertible start -> zeros
   var0 = fmax(var0, 1e-10);
-  u[0] = phi0 / sqrt(1.0 - phi0 * phi0);
-  u[1] = -theta0 / sqrt(1.0 - theta0 * theta0);
+  u[0] = -phi0 / sqrt(1.0 - phi0 * phi0);   // SARIMAX.untransform_params (the inverse of the signs in kf_init)
+  u[1] = theta0 / sqrt(1.0 - theta0 * theta0);
   u[2] = sqrt(var0);
 }
 
