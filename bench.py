@@ -39,11 +39,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
-FLOP_PER_KALMAN_STEP = 60
-# opt-in contract TAD_ARIMA_FILTER=collapsed (tad_arima.hip:kfc_step4_nc): 15 add/mul per chain and step plus a quarter of
-# the batched inversion (9 multiplications + 1 division per four chains) are what is executed; the fraction is then priced
-# on THOSE flops (the 60-flop figure of the three-state form is reported next to it)
-FLOP_PER_KALMAN_STEP_COLLAPSED = 18
+FLOP_PER_KALMAN_STEP_3STATE = 60   # SURVEY.md 8d's model (one predict + update of the textbook three-state filter): rounds 1-2 priced on it
+# the contract since round 3 (tad_arima.hip:kfc_step4_nc, the collapsed recursion): 15 add/mul per chain and step plus a quarter
+# of the batched inversion (9 multiplications + 1 division per four chains) are what is EXECUTED; `frac` is priced on those
+# flops, the 60-flop-equivalent fraction is reported next to it so that the rounds stay comparable
+FLOP_PER_KALMAN_STEP = 18
 BYTES_PER_ROW = 24      # key_id u64 + flow_end_s i64 + value u64, read once
 BYTES_PER_ANOMALY = 40  # key_id, flow_end_s, throughput, algo_calc, stddev
 
@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--host-input", action="store_true",
                     help="hand the columns over as pinned HOST buffers (tad_columns.memory = TAD_MEM_HOST): the PCIe-inclusive "
                          "rate DESIGN.md quotes; never the headline value")
+    ap.add_argument("--plan", default="", help="tad_plan overrides for A/B runs, e.g. histogram=exact,partition_pass=sort (default: the engine decides)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU sample (0 = chosen from the host's core count)")
@@ -171,7 +172,11 @@ def main():
             cfg[f] = getattr(args, f)
     headline_is_c2 = (args.config == "c2" and not args.algo and all(getattr(args, f) is None for f in ("rows", "keys", "buckets", "agg")))
 
-    eng = TadEngine(device=dev.index)
+    plan = {}
+    for item in filter(None, args.plan.split(",")):
+        name, _, val = item.partition("=")
+        plan[name.strip()] = int(val) if val.strip().lstrip("-").isdigit() else val.strip()
+    eng = TadEngine(device=dev.index, plan=plan)
     reducer = td.JobReducer(device=coll_dev)
 
     def make_table(n, K, T, ingest):
@@ -307,20 +312,22 @@ def main():
         for st, a, algo in zip(r["stats"], r["acc"], algos):
             if algo == "ARIMA":
                 sec = a["ms_detect"] / steps * 1e-3
-                collapsed = os.environ.get("TAD_ARIMA_FILTER", "") == "collapsed"
-                flops = (FLOP_PER_KALMAN_STEP_COLLAPSED if collapsed else FLOP_PER_KALMAN_STEP) * st["kalman_steps"]
+                flops = FLOP_PER_KALMAN_STEP * st["kalman_steps"]
+                eq60 = FLOP_PER_KALMAN_STEP_3STATE * st["kalman_steps"] / sec / 1e12
                 out["arima"] = {"fits_per_launch": st["arima_fits"], "kalman_steps_per_launch": st["kalman_steps"],
-                                "fits_per_s": st["arima_fits"] / sec, "bound": "fp64 vector ALU / dependency latency",
+                                "fits_per_s": st["arima_fits"] / sec, "nan_fits": st.get("arima_nan_fits", 0),
+                                "bound": "fp64 vector ALU: instruction issue + dependency latency",
                                 "achieved_tflops": flops / sec / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                                 "frac": flops / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "ms_detect": a["ms_detect"] / steps,
-                                "flop_model": ("18 flop per time-step of the collapsed recursion (executed) x the engine's kalman_steps counter; "
-                                               "three-state form equivalent: %.2f TFLOP/s" % (FLOP_PER_KALMAN_STEP * st["kalman_steps"] / sec / 1e12))
-                                              if collapsed else "60 flop per Kalman time-step x the engine's kalman_steps counter (SURVEY.md 8d)"}
+                                "tflops_60flop_equivalent": eq60, "frac_60flop_equivalent": eq60 / FP64_VECTOR_PEAK_TFLOPS,
+                                "flop_model": "18 flop per time-step of the collapsed recursion (executed) x the engine's kalman_steps counter; "
+                                              "60-flop-equivalent = SURVEY.md 8d's three-state model on the same counter (rounds 1-2 reported that)"}
                 if len(algos) == 1:     # the detector, not Stage 0, is this config's dominant kernel
-                    out["roofline"] = {"bound": "fp64-vector", "kernel": "k_arima_fit (per-lane L-BFGS-B over the 3-state Kalman likelihood)",
+                    out["roofline"] = {"bound": "fp64-vector", "kernel": "k_arima_fit (per-lane L-BFGS-B over the ARIMA(1,1,1) likelihood, four recursions per lane)",
                                        "achieved": flops / sec / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": flops / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
                                        "algorithmic_flops_per_launch": flops, "avg_kernel_ms": a["ms_detect"] / steps,
+                                       "frac_60flop_equivalent": eq60 / FP64_VECTOR_PEAK_TFLOPS,
                                        "hbm_frac_of_24B_per_row": BYTES_PER_ROW * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
         return out
 

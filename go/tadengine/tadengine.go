@@ -68,6 +68,15 @@ func NewEngine(device int) (*Engine, error) {
 	return e, nil
 }
 
+// SetPlan replaces the engine's plan overrides (tad.h: tad_plan, ABI 7; the zero value = the engine decides, which is what
+// the controller uses).  Tests and A/B measurements force a strategy with it; the library reads no environment variable.
+func (e *Engine) SetPlan(p C.tad_plan) error {
+	if rc := C.tad_engine_set_plan(e.h, &p); rc != C.TAD_OK {
+		return fmt.Errorf("tad_engine_set_plan: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return nil
+}
+
 func (e *Engine) Close() {
 	if e.h != nil {
 		C.tad_engine_destroy(e.h)
@@ -105,8 +114,9 @@ type Row struct {
 
 type Stats struct {
 	RowsIn, RowsUsed, Keys, Points, Anomalies, KeysNoResult uint64
+	ArimaNanFits                                             uint64 // ARIMA fits voided by a non-finite likelihood (tad.h: tad_stats.arima_nan_fits)
 	MsTotal                                                  float32
-	Stage0Path, DetectPath                                   int32 // how the engine ran (tad.h: tad_stats.stage0_path / detect_path), for the controller's logs
+	Stage0Path                                               int32 // how Stage 0 ran (tad.h: tad_stats.stage0_path), for the controller's logs
 }
 
 // cColumn copies a Go slice into C memory: cgo forbids handing Go pointers nested in a C struct, and the
@@ -185,8 +195,8 @@ func (e *Engine) Run(job Job, cols Columns) ([]Row, Stats, error) {
 		}
 	}
 	st = Stats{uint64(res.stats.rows_in), uint64(res.stats.rows_used), uint64(res.stats.n_keys), uint64(res.stats.n_points),
-		uint64(res.stats.n_anomalies), uint64(res.stats.keys_no_result), float32(res.stats.ms_total),
-		int32(res.stats.stage0_path), int32(res.stats.detect_path)}
+		uint64(res.stats.n_anomalies), uint64(res.stats.keys_no_result), uint64(res.stats.arima_nan_fits), float32(res.stats.ms_total),
+		int32(res.stats.stage0_path)}
 	return rows, st, nil
 }
 
@@ -251,6 +261,9 @@ func (e *Engine) ShardRows(key, flowEnd, value unsafe.Pointer, n uint64, world u
 	cc.key_id = (*C.uint64_t)(key)
 	cc.flow_end_s = (*C.int64_t)(flowEnd)
 	cc.value = (*C.uint64_t)(value)
+	if world == 0 {
+		return nil, fmt.Errorf("tad_shard_rows: world must be >= 1")
+	}
 	counts := make([]uint64, world)
 	if rc := C.tad_shard_rows(e.h, &cc, C.uint32_t(world), (*C.uint64_t)(outKey), (*C.int64_t)(outFlowEnd), (*C.uint64_t)(outValue),
 		(*C.uint64_t)(unsafe.Pointer(&counts[0]))); rc != C.TAD_OK {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 6
+#define TAD_ABI_VERSION 7
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -69,10 +69,27 @@ typedef enum { TAD_MEM_HOST = 0, TAD_MEM_DEVICE = 1 } tad_mem;
 
 typedef struct tad_engine tad_engine; /* opaque; one per GPU */
 
+/* Plan overrides (ABI 7).  Every field 0 = the engine decides from the shape of the batch, which is what a production host
+ * passes.  A non-zero field forces one of the strategies the engine would otherwise choose between: the parity tests run
+ * every strategy on the same table, A/B measurements time them on the same box.  ABI <= 6 read TAD_* environment variables
+ * per job for this — process-global state that a host with several workers (controller.go:199-201) cannot scope to a job
+ * or an engine; since ABI 7 the library reads no environment variable at all. */
+typedef struct {
+  int32_t stage0;            /* 1 = direct atomic scatter into the grid, 2 = partition + LDS tiles whatever the batch size */
+  int32_t partition_pass;    /* 1 = sort-by-tile pass B, 2 = write-combining pass B whenever its queues fit LDS */
+  int32_t histogram;         /* 1 = exact per-workgroup histogram in pass A (regions of pass B never sized from a sample) */
+  int32_t sparse;            /* 1 = never, 2 = always the sort-based Stage 0 for sparse tables */
+  int32_t sparse_classes;    /* 1 = always run a sparse table as length classes of keys */
+  int32_t ewma_emit;         /* 1 = lane-per-key emit for the EWMA job instead of the LDS-staged one */
+  uint32_t ewma_emit_rows;   /* LDS rows per wavefront of the staged EWMA emit (<= 4096); 0 = sized from the row count */
+  int32_t reserved;          /* 0 */
+} tad_plan;
+
 typedef struct {
   int32_t device;            /* HIP device ordinal */
   void *stream;              /* hipStream_t to run on, or NULL: the engine creates its own */
   uint64_t workspace_limit;  /* bytes of HBM the engine may use for its grid; 0 = 3/4 of free */
+  tad_plan plan;             /* all zero in production */
 } tad_engine_opts;
 
 /* Mirrors the job's argument vector (anomaly_detection.py:781-870). */
@@ -122,6 +139,10 @@ typedef struct {
   uint64_t keys_no_result; /* ARIMA keys that yield no rows (n<=3, x<=0, constant; :232-234,260-264) */
   uint64_t kalman_steps;   /* ARIMA: filter time-steps over all likelihood evaluations */
   uint64_t arima_fits;     /* ARIMA: number of (key,t) fits */
+  uint64_t arima_nan_fits; /* ARIMA: fits whose prediction is not finite (the optimiser walked into a non-finite likelihood: Box-Cox
+                              with a strongly negative lambda next to the 1e6 diffuse prior).  Python's abs(x - nan) > sigma is False,
+                              so such a point is never an anomaly (anomaly_detection.py:306-307) — counted so that an operator can
+                              tell voided fits from clean ones */
   double pts_mean;         /* mean and sum of squared deviations (M2) of the aggregated point values of */
   double pts_m2;           /* this shard: (n_points, mean, M2) triples Chan-merge across GPUs into the global
                               mean / sigma the multi-GPU host reports (telemetry; the reference has none) */
@@ -135,15 +156,14 @@ typedef struct {
   float ms_total;          /* device time of the whole run, HIP events on the engine stream */
   int32_t stage0_path;     /* 1 = direct atomic scatter, 2 = partition (sort-by-tile pass B) + LDS tiles, 3 = partition (write-combining pass B) + LDS tiles,
                               4 = sparse table: sort by (key, time) + rank grid (time proportional to the rows, not to keys x lattice),
-                              5 = two-level partition (many keys: wide blocks through the write-combining pass, split again, single-round LDS tiles),
+                              (5 was the two-level partition of ABI 6: measured no faster than the single-level plan, removed)
                               6 = sparse table with skewed series lengths: as 4, then one job per length class of keys (<= 16, <= 64, ... points),
                                   rows merged back in key order (the K x longest-series rank grid would not fit the workspace),
                               7 = tad_aggregate on such a table: the sorted unique points are the result, no grid at all */
   int32_t stage0_attempts; /* times Stage 0 ran before it settled: 1 normally; more after a wrong lattice hint, a sampled lattice or
                               a sampled histogram that proved too optimistic (every fallback is exact), an overflow-list fallback */
   int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/8 of pass A's reads) */
-  int32_t detect_path;     /* how Stage 1-3 ran: 0 = per-key statistics / detector / scan / emit as separate kernels,
-                              1 = the EWMA job's single fused kernel (opt-in TAD_EWMA_FUSED=1: no count pass, no host round trip) */
+  int32_t reserved;        /* 0 (ABI 6: detect_path of the fused EWMA kernel — measured no faster than the separate kernels, removed) */
 } tad_stats;
 
 /* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).
@@ -168,6 +188,8 @@ typedef struct {
 int tad_abi_version(void);
 int tad_engine_create(const tad_engine_opts *opts, tad_engine **out);
 void tad_engine_destroy(tad_engine *e);
+/* Replace the engine's plan overrides (NULL = all zero); serialised with the jobs, takes effect with the next one. */
+int tad_engine_set_plan(tad_engine *e, const tad_plan *plan);
 /* Thread-safe; the returned string is owned by the engine (or static when e == NULL). */
 const char *tad_last_error(tad_engine *e);
 

@@ -18,9 +18,9 @@
  * IEEE-754 double +, -, *, /, sqrt only, no FMA contraction (-ffp-contract=off), sums strictly left to right, and the
  * transcendental functions from the one shared source theia_amd/csrc/tad_detmath.h.  Control flow here is an ordinary
  * sequential program (the GPU runs the optimiser as a per-lane state machine); the expressions are the contract.
- * The likelihood recursion exists in two such contracts: the general three-state filter (default, arima_nll_general) and
- * the collapsed form (arima_nll_collapsed; the engine's opt-in TAD_ARIMA_FILTER=collapsed) — arima_exact_set_filter()
- * switches, oracle/arima_oracle.py does it from the same environment variable the engine reads.
+ * The likelihood recursion of the contract is the collapsed form (arima_nll4_collapsed = tad_arima.hip:kfc_*: the model's
+ * structure used up, four recursions jointly with one division); the textbook three-state filter (arima_nll_general, round
+ * 2's contract) stays here as a cross-check of the likelihood only — arima_exact_set_filter(0) selects it.
  *
  * PARITY STATUS vs the reference: "unpinned at 1e-6" (the reference's tests pin the verdict list and five leading
  * characters only, anomaly_detection_test.py:261-283, 320-345) — tests/test_oracle_arima.py records the distances.
@@ -159,12 +159,13 @@ static double inv_boxcox(double y, double lam) {       /* scipy.special.inv_boxc
 
 /* ---------------------------------------------------------------------------------------------------------------
  * -loglike / nobs of ARIMA(1,1,1) in statsmodels' state-space form and the one-step forecast.  The arithmetic
- * contract (operation order) is documented at tad_arima.hip:arima_nll; this is the same recursion written as ONE loop
- * over the series with the covariance update skipped once converged.
+ * textbook three-state recursion (round 2's contract; cross-check only) written as ONE loop over the series with the
+ * covariance update skipped once converged.
  * --------------------------------------------------------------------------------------------------------------- */
 static long long g_steps;   /* filter time-steps executed (reported next to the GPU's kalman_steps counter) */
 static double *g_trace; static long g_trace_cap, g_trace_n;   /* debugging: every evaluation (x[3], f) of a traced fit */
-static int g_filter;        /* 0: general three-state form (the default contract); 1: collapsed form (arima_nll_collapsed) */
+static int g_filter = 1;    /* 1: the contract the engine runs (arima_nll4_collapsed); 0: the textbook three-state form, kept to check that
+                              * both are the same likelihood (tests/test_oracle_arima.py) */
 
 static double nll_finish(const double u[3], double prod, int esum, long nconv, double F, double q, long n) {
   double sumlog = tad_det_log(prod) + (double)esum * TAD_DM_LN2, llf;
@@ -665,7 +666,7 @@ int arima_exact_series(const double *x, long n, int maxiter, double *pred, doubl
   return 1;
 }
 
-/* which likelihood recursion the fits use: 0 = general three-state form (default), 1 = collapsed form */
+/* which likelihood recursion the fits use: 1 = the contract (collapsed form, default), 0 = textbook three-state form */
 void arima_exact_set_filter(int collapsed) { g_filter = collapsed != 0; }
 int arima_exact_get_filter(void) { return g_filter; }
 

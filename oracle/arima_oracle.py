@@ -285,14 +285,7 @@ def _load_exact():
         lib.arima_exact_set_filter.restype = None
         lib.arima_exact_set_filter.argtypes = [ctypes.c_int]
         _xlib = lib
-    # one switch for both sides: the engine reads TAD_ARIMA_FILTER per job (tad_arima.hip:launch_arima), the checker here
-    _xlib.arima_exact_set_filter(1 if exact_filter() == "collapsed" else 0)
     return _xlib
-
-
-def exact_filter():
-    """Which likelihood recursion oracle/arima_exact.c (and the engine) use: "general" (default) or "collapsed"."""
-    return "collapsed" if os.environ.get("TAD_ARIMA_FILTER", "") == "collapsed" else "general"
 
 
 def calculate_arima_exact(throughputs, maxiter=50, counters=None):

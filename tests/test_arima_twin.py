@@ -3,9 +3,7 @@
 theia_amd/csrc/tad_arima.hip marks its arithmetic `__host__ __device__`; tools/arima_twin.cpp instantiates exactly those
 functions for the host (hipcc compiles both halves) and drives them like k_arima_prep / k_arima_fit do.  If the twin and
 oracle/arima_exact.c agree on every bit, the device SOURCE and the checker follow one arithmetic contract — what the
-`-m gpu` tests then establish on the hardware is only that gfx950 executes that source the way the host does.  Both
-contracts (general three-state filter, collapsed recursion with batched inversion) on the reference's golden series and
-seeded random series.  Not a fallback: nothing in the product loads this library."""
+`-m gpu` tests then establish on the hardware is only that gfx950 executes that source the way the host does.  The reference's golden series and seeded random series.  Not a fallback: nothing in the product loads this library."""
 import ctypes
 import os
 import shutil
@@ -31,7 +29,6 @@ def twin(tmp_path_factory):
     lib = ctypes.CDLL(str(out))
     lib.twin_series.restype = ctypes.c_int
     lib.twin_series.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    lib.twin_set_filter.argtypes = [ctypes.c_int]
     return lib
 
 
@@ -49,27 +46,19 @@ def series_set(golden):
     return out
 
 
-@pytest.mark.parametrize("flt", ["general", "collapsed"])
-def test_device_source_on_the_host_equals_the_oracle(twin, golden, monkeypatch, flt):
-    monkeypatch.setenv("TAD_ARIMA_FILTER", flt)
-    twin.twin_set_filter(1 if flt == "collapsed" else 0)
-    try:
-        for name, x in series_set(golden).items():
-            x = np.ascontiguousarray(x, dtype=np.float64)
-            c = {}
-            want = ao.calculate_arima_exact(x, counters=c)
-            pred = np.empty(max(x.size, 1))
-            info = np.zeros(4)
-            rc = twin.twin_series(x.ctypes.data, x.size, 50, pred.ctypes.data, info.ctypes.data)
-            if want is None:
-                assert rc == 0, name
-                continue
-            assert rc == 1, name
-            got = pred[:x.size]
-            want = np.array(want)
-            assert (got.view(np.uint64) == want.view(np.uint64)).all(), (flt, name, float(np.nanmax(np.abs(got - want) / np.abs(want))))
-            assert int(info[1]) == c["kalman_steps"], (flt, name)      # the flop figure's counter too
-    finally:
-        twin.twin_set_filter(0)
-        monkeypatch.delenv("TAD_ARIMA_FILTER")
-        ao._load_exact()
+def test_device_source_on_the_host_equals_the_oracle(twin, golden):
+    for name, x in series_set(golden).items():
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        c = {}
+        want = ao.calculate_arima_exact(x, counters=c)
+        pred = np.empty(max(x.size, 1))
+        info = np.zeros(4)
+        rc = twin.twin_series(x.ctypes.data, x.size, 50, pred.ctypes.data, info.ctypes.data)
+        if want is None:
+            assert rc == 0, name
+            continue
+        assert rc == 1, name
+        got = pred[:x.size]
+        want = np.array(want)
+        assert (got.view(np.uint64) == want.view(np.uint64)).all(), (name, float(np.nanmax(np.abs(got - want) / np.abs(want))))
+        assert int(info[1]) == c["kalman_steps"], name      # the flop figure's counter too

@@ -39,13 +39,26 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 def test_ctypes_struct_layout_matches_the_c_compiler(tmp_path):
     from theia_amd import _capi
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include "tad.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
-                    'sizeof(tad_engine_opts),sizeof(tad_job),sizeof(tad_columns),sizeof(tad_stats),sizeof(tad_result),sizeof(tad_points));return 0;}\n')
+    prog.write_text('#include <stdio.h>\n#include "tad.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+                    'sizeof(tad_plan),sizeof(tad_engine_opts),sizeof(tad_job),sizeof(tad_columns),sizeof(tad_stats),sizeof(tad_result),sizeof(tad_points));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    mine = [ctypes.sizeof(c) for c in (_capi.EngineOpts, _capi.Job, _capi.Columns, _capi.Stats, _capi.Result, _capi.Points)]
+    mine = [ctypes.sizeof(c) for c in (_capi.Plan, _capi.EngineOpts, _capi.Job, _capi.Columns, _capi.Stats, _capi.Result, _capi.Points)]
     assert sizes == mine
+
+
+def test_library_reads_no_environment_variable():
+    """ABI 7: plan overrides are fields of tad_engine_opts / tad_engine_set_plan; a host with several workers
+    (controller.go:199-201) cannot scope process-global switches, so the library has none."""
+    for dp, _, files in os.walk(os.path.join(ROOT, "theia_amd", "csrc")):
+        for fn in files:
+            assert "getenv" not in open(os.path.join(dp, fn), errors="ignore").read(), fn
+    from theia_amd import _capi
+    with pytest.raises(ValueError):
+        _capi.make_plan(no_such_field=1)
+    p = _capi.make_plan(stage0="v2", partition_pass="sort", ewma_emit_rows=64)
+    assert (p.stage0, p.partition_pass, p.ewma_emit_rows, p.sparse) == (2, 1, 64, 0)
 
 
 def test_engine_create_fails_loudly_without_a_gpu():

@@ -9,7 +9,6 @@ import pytest
 
 from oracle import tad_oracle as orc
 
-import os
 
 pytestmark = pytest.mark.gpu
 
@@ -17,15 +16,13 @@ SKIP = np.uint64(orc.MASK64)
 
 
 @pytest.fixture(autouse=True, params=["v1", "v2", "v2wc"])
-def stage0(request):
+def stage0(request, engine):
     """Every test runs with every Stage-0 strategy: v1 = direct atomic scatter, v2 = partition + LDS tiles (forced
     even on tiny inputs) with the sort-by-tile partition pass, v2wc = v2 with the write-combining partition pass.
-    All must give the reference's integers bit for bit."""
-    os.environ["TAD_STAGE0"] = request.param[:2]
-    os.environ["TAD_PARTB"] = "wc" if request.param == "v2wc" else "sort"
+    All must give the reference's integers bit for bit.  (tad_plan overrides of the engine, include/tad.h.)"""
+    engine.set_plan(stage0=request.param[:2], partition_pass="wc" if request.param == "v2wc" else "sort")
     yield request.param
-    os.environ.pop("TAD_STAGE0", None)
-    os.environ.pop("TAD_PARTB", None)
+    engine.set_plan()
 
 
 # ------------------------------------------------------------------ (a) reference golden vectors
@@ -109,8 +106,8 @@ def test_job_synthetic_tables_match_oracle(engine, stage0, algo, n_rows, K, T):
     assert res.stats["stage0_path"] == {"v1": 1, "v2": 2, "v2wc": 3}[stage0]
 
 
-@pytest.mark.parametrize("emit_env", [{}, {"TAD_EMIT_CAP": "64"}, {"TAD_EMIT_STAGED": "0"}])
-def test_job_ewma_emit_staged_rows_overflow_and_direct_variants(engine, stage0, emit_env):
+@pytest.mark.parametrize("emit_plan", [{}, {"ewma_emit_rows": 64}, {"ewma_emit": "lane"}])
+def test_job_ewma_emit_staged_rows_overflow_and_direct_variants(engine, stage0, emit_plan):
     """The EWMA emit parks a wavefront's rows in LDS and stores them coalesced (k_emit_staged); rows beyond the LDS
     capacity are stored directly.  Default capacity, a capacity of one row per key (most rows overflow) and the
     lane-per-key kernel k_emit must all give the oracle's rows; K is not a multiple of 64."""
@@ -118,12 +115,8 @@ def test_job_ewma_emit_staged_rows_overflow_and_direct_variants(engine, stage0, 
         pytest.skip("emit does not depend on the Stage-0 strategy")
     K, T = 1000 + 37, 250
     k, t, v = orc.synth_rows(0, 400_000, K, T)
-    os.environ.update(emit_env)
-    try:
+    with engine.plan(**emit_plan):
         res, want = check_job(engine, "EWMA", k, t, v, K, agg_flow="svc")
-    finally:
-        for name in emit_env:
-            os.environ.pop(name, None)
     assert want["n_anomalies"] > 64 * 16
 
 
@@ -250,35 +243,9 @@ def test_job_wide_grids_take_several_rounds_per_partition(engine, stage0, n_rows
     # grids whose KP x T block does not fit one LDS tile (many buckets) or that would need more than 2048 partitions
     # (many keys): Stage-0 v2 widens the key block and walks the partition's records in several bucket rounds
     k, t, v = orc.synth_rows(0, n_rows, K, T)
-    os.environ["TAD_SPARSE"] = "0"      # these thinly filled grids would otherwise take the sparse path (tests/test_gpu_sparse.py)
-    try:
+    with engine.plan(sparse="never"):   # these thinly filled grids would otherwise take the sparse path (tests/test_gpu_sparse.py)
         res, want = check_job(engine, "EWMA", k, t, v, K, agg_flow="svc")
-    finally:
-        del os.environ["TAD_SPARSE"]
     assert res.stats["stage0_path"] in ((1,) if stage0 == "v1" else (2,) if stage0 == "v2" else (2, 3))   # wc needs >= 9 queue slots per partition in LDS
-
-
-@pytest.mark.parametrize("agg,hot", [("svc", False), ("", False), ("svc", True)])
-def test_job_two_level_partition_for_many_keys(engine, stage0, agg, hot):
-    # 250 000 keys x 100 buckets: a single-round LDS tile is 128 keys wide = 1954 partitions, too many for pass B's queues.
-    # The plan then partitions by 2048-key blocks (write-combining pass, whole lines), splits every block 16 ways by key
-    # sub-range (k_repartition) and aggregates single-round tiles.  With values beyond the packed-record range (overflow
-    # list -> empty slots in the level-2 regions) and, in one case, a key carrying a third of the rows (sliced partitions).
-    rng = np.random.default_rng(23)
-    k, t, v = orc.synth_rows(0, 4_400_000, 250_000, 100)
-    v = np.where(rng.random(v.size) < 0.002, rng.integers(2**50, 2**64 - 1, size=v.size, dtype=np.uint64), v)
-    if hot:
-        k = np.where(rng.random(k.size) < 0.33, np.uint64(123_457), k)
-    os.environ["TAD_TWO_LEVEL"] = "1"                      # opt-in plan (measured: no faster than the single-level plan at C4)
-    try:
-        res, want = check_job(engine, "EWMA", k, t, v, 250_000, agg_flow=agg)
-        path = {"v1": 1, "v2": 2, "v2wc": 5}[stage0]       # (the forced sort-by-tile pass B keeps the single-level plan)
-        assert res.stats["stage0_path"] == path
-        pts = engine.aggregate(k, t, v, 250_000, agg_flow=agg)
-        pk, pt, pv = want["points"]
-        assert pts.stats["stage0_path"] == path and (pts["key_id"] == pk).all() and (pts["flow_end_s"] == pt).all() and (pts["value"] == pv).all()
-    finally:
-        del os.environ["TAD_TWO_LEVEL"]
 
 
 @pytest.mark.parametrize("agg", ["svc", ""])
@@ -377,14 +344,13 @@ def test_job_rejects_bad_arguments(engine):
     assert ei.value.code == -1 and "EndInterval should be after StartInterval" in ei.value.message
     with pytest.raises(TadError):
         engine.run("KMEANS", k, t, v, 10)
-    small = type(engine)(device=0, workspace_limit=1 << 20)
-    os.environ["TAD_SPARSE"] = "0"          # the dense grid's limit (the sparse path has its own tests, tests/test_gpu_sparse.py)
+    # the dense grid's limit (the sparse path has its own tests, tests/test_gpu_sparse.py)
+    small = type(engine)(device=0, workspace_limit=1 << 20, plan={"sparse": "never"})
     try:
         with pytest.raises(TadError) as ei:
             small.run("EWMA", *orc.synth_rows(0, 1000, 100000, 250), 100000)
         assert ei.value.code == -6
     finally:
-        del os.environ["TAD_SPARSE"]
         small.close()
 
 

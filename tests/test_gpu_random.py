@@ -2,7 +2,6 @@
 1 .. 400 buckets), lattice (step 1 / 7 / 60 / 3600 s, arbitrary origin), aggregation operator, second key column,
 rejected rows, time-window filter, values beyond 2^49 / wrap-around sums and Stage-0 strategy; every one must equal the
 oracle bit for bit (integers, sigma, EWMA, verdicts)."""
-import os
 
 import numpy as np
 import pytest
@@ -42,10 +41,5 @@ def test_random_job(engine, seed):
         kw["flow_start_s"] = t - rng.integers(0, 5 * step + 1, size=n)
         kw["start_time"] = int(t0 + step * (T // 4))
         kw["end_time"] = int(t0 + step * max(1, (3 * T) // 4) + 1)
-    os.environ["TAD_STAGE0"] = str(rng.choice(["v1", "v2"]))
-    os.environ["TAD_PARTB"] = str(rng.choice(["sort", "wc"]))
-    try:
+    with engine.plan(stage0=str(rng.choice(["v1", "v2"])), partition_pass=str(rng.choice(["sort", "wc"]))):
         check_job(engine, algo, key, t, v, K, agg_flow=agg, **kw)
-    finally:
-        os.environ.pop("TAD_STAGE0", None)
-        os.environ.pop("TAD_PARTB", None)

@@ -2,7 +2,6 @@
 would not fit: second-resolution timestamps with gcd 1 over a day, and a million short-lived per-connection keys (mode
 None: the key contains flowStartSeconds, anomaly_detection.py:52-61, 109-116).  Results must equal the oracle bit for
 bit like the dense path's, and the run time must follow the rows, not keys x lattice."""
-import os
 
 import numpy as np
 import pytest
@@ -67,11 +66,8 @@ def test_gcd1_arima(engine):
     K = 300
     k, t, v = day_table(K, 40, 2, seed=2)
     k, t, v = k[:], t[:], v[:]
-    os.environ["TAD_SPARSE"] = "1"        # (24 000 rows would also fit the dense path's threshold)
-    try:
+    with engine.plan(sparse="always"):
         check(engine, "ARIMA", k, t, v, K, "svc")
-    finally:
-        del os.environ["TAD_SPARSE"]
 
 
 def test_a_million_short_lived_connections(engine):
@@ -103,8 +99,7 @@ def test_sparse_with_second_key_time_window_and_aggregate(engine):
     k2 = np.where(k2 % np.uint64(5) == 0, orc.KEY_SKIP, k2)
     k = np.where(k % np.uint64(7) == 0, orc.KEY_SKIP, k)
     ts = t - rng.integers(0, 600, size=t.size)
-    os.environ["TAD_SPARSE"] = "1"
-    try:
+    with engine.plan(sparse="always"):
         check(engine, "EWMA", k, t, v, 400, "pod", key_id2=k2, flow_start_s=ts, start_time=int(t.min()) + 100, end_time=int(t.max()) - 300)
         pts = engine.aggregate(k, t, v, 400, agg_flow="pod", key_id2=k2)
         pk, pt, pv = orc.stage0(k, t, v, "sum", k2)
@@ -115,8 +110,6 @@ def test_sparse_with_second_key_time_window_and_aggregate(engine):
         check(engine, "EWMA", k, t, big, 400, "svc")
         with pytest.raises(TadError):
             engine.run("EWMA", np.array([500], dtype=np.uint64), t[:1], v[:1], 400, agg_flow="svc")        # key id out of range
-    finally:
-        del os.environ["TAD_SPARSE"]
 
 
 def skewed_table(K, long_keys, long_len, seed, span=86400):
@@ -188,9 +181,7 @@ def test_skewed_series_lengths_run_as_length_classes(algo, agg):
 
 def test_length_classes_forced_small_tables(engine):
     # every class boundary (16 / 64 / 256 points), keys without points, ARIMA's no-result keys, a single class
-    os.environ["TAD_SPARSE"] = "1"
-    os.environ["TAD_SPARSE_CLASSES"] = "1"
-    try:
+    with engine.plan(sparse="always", sparse_classes="always"):
         rng = np.random.default_rng(3)
         n_k = np.array([0, 1, 2, 3, 4, 15, 16, 17, 63, 64, 65, 255, 256, 257, 300, 0, 5, 40], dtype=np.int64)
         K = n_k.size
@@ -204,8 +195,6 @@ def test_length_classes_forced_small_tables(engine):
             check_classes(engine, algo, k, t, v, K, agg)
         k1, t1, v1 = day_table(40, 10, 2, seed=9, span=3000)      # all keys in one class
         check_classes(engine, "EWMA", k1, t1, v1, 40, "svc")
-    finally:
-        del os.environ["TAD_SPARSE"], os.environ["TAD_SPARSE_CLASSES"]
 
 
 def test_grids_that_do_not_fit_while_the_points_do():

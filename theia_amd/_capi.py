@@ -6,7 +6,7 @@ from . import build as _build
 
 u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
 
-TAD_ABI_VERSION = 6
+TAD_ABI_VERSION = 7
 TAD_KEY_SKIP = (1 << 64) - 1
 TAD_OK = 0
 TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
@@ -18,8 +18,31 @@ TAD_MEM_HOST, TAD_MEM_DEVICE = 0, 1
 TAD_FLAG_EMIT_ALL_POINTS = 1
 
 
+class Plan(C.Structure):
+    """tad_plan: plan overrides, every field 0 = the engine decides (tests and A/B measurements set them)."""
+    _fields_ = [("stage0", i32), ("partition_pass", i32), ("histogram", i32), ("sparse", i32), ("sparse_classes", i32),
+                ("ewma_emit", i32), ("ewma_emit_rows", u32), ("reserved", i32)]
+
+
+PLAN_VALUES = {   # symbolic values accepted by TadEngine(plan=...) / TadEngine.plan(...)
+    "stage0": {"auto": 0, "v1": 1, "v2": 2}, "partition_pass": {"auto": 0, "sort": 1, "wc": 2}, "histogram": {"auto": 0, "exact": 1},
+    "sparse": {"auto": 0, "never": 1, "always": 2}, "sparse_classes": {"auto": 0, "always": 1}, "ewma_emit": {"auto": 0, "staged": 0, "lane": 1},
+}
+
+
+def make_plan(**kw):
+    p = Plan()
+    for name, v in kw.items():
+        if name not in dict((f[0], 1) for f in Plan._fields_) or name == "reserved":
+            raise ValueError("unknown tad_plan field %r" % name)
+        if isinstance(v, str):
+            v = PLAN_VALUES[name][v]
+        setattr(p, name, int(v))
+    return p
+
+
 class EngineOpts(C.Structure):
-    _fields_ = [("device", i32), ("stream", C.c_void_p), ("workspace_limit", u64)]
+    _fields_ = [("device", i32), ("stream", C.c_void_p), ("workspace_limit", u64), ("plan", Plan)]
 
 
 class Job(C.Structure):
@@ -38,9 +61,9 @@ class Columns(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rows_in", u64), ("rows_used", u64), ("n_keys", u64), ("n_points", u64),
                 ("n_anomalies", u64), ("keys_no_result", u64), ("kalman_steps", u64),
-                ("arima_fits", u64), ("pts_mean", f64), ("pts_m2", f64), ("t0", i64), ("step", i64), ("n_buckets", u64),
+                ("arima_fits", u64), ("arima_nan_fits", u64), ("pts_mean", f64), ("pts_m2", f64), ("t0", i64), ("step", i64), ("n_buckets", u64),
                 ("ms_meta", f32), ("ms_stage0", f32), ("ms_scatter", f32), ("ms_detect", f32),
-                ("ms_total", f32), ("stage0_path", i32), ("stage0_attempts", i32), ("hist_sampled", i32), ("detect_path", i32)]
+                ("ms_total", f32), ("stage0_path", i32), ("stage0_attempts", i32), ("hist_sampled", i32), ("reserved", i32)]
 
 
 class Result(C.Structure):
@@ -59,6 +82,7 @@ SYMBOLS = {
     "tad_abi_version": (C.c_int, []),
     "tad_engine_create": (C.c_int, [C.POINTER(EngineOpts), C.POINTER(C.c_void_p)]),
     "tad_engine_destroy": (None, [C.c_void_p]),
+    "tad_engine_set_plan": (C.c_int, [C.c_void_p, C.POINTER(Plan)]),
     "tad_last_error": (C.c_char_p, [C.c_void_p]),
     "tad_run": (C.c_int, [C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Result))]),
     "tad_result_free": (None, [C.c_void_p, C.POINTER(Result)]),

@@ -10,8 +10,8 @@
 // The fit restates statsmodels 0.14 SARIMAX/ARIMA (not in /root/reference; pinned in
 // plugins/anomaly-detection/requirements.txt:3):  state space Z=[1 1 0], T=[[1 1 0],[0 phi 1],[0 0 0]],
 // R=[0 1 theta]', approximate-diffuse (1e6) + stationary initial covariance, loglikelihood_burn = 1,
-// covariance frozen once ||P_t - P_{t+1}||_F^2 < 1e-19 (arithmetic contract: see arima_nll); start parameters by conditional sum of squares on
-// diff(y) with numpy-pinv semantics; phi = u/sqrt(1+u^2), theta = -u/sqrt(1+u^2), sigma2 = u^2;
+// covariance frozen once ||P_t - P_{t+1}||_F^2 < 1e-19 (arithmetic contract: see kfc_*); start parameters by conditional sum of squares on
+// diff(y) with numpy-pinv semantics; phi = -u/sqrt(1+u^2), theta = u/sqrt(1+u^2) (statsmodels' signs), sigma2 = u^2;
 // objective -loglike/nobs minimised by L-BFGS-B (m = 10, factr = 1e7, pgtol = 1e-5, maxiter = 50, maxls = 20)
 // with forward-difference gradients (h = 1e-5) and the More'-Thuente line search (ftol 1e-3, gtol 0.9,
 // xtol 0.1) — the unconstrained path of L-BFGS-B 3.0, where the subspace step equals the two-loop
@@ -22,6 +22,7 @@
 // fits.  A wavefront takes a chunk of keys at ONE series position (every lane's Kalman loop has the same length) and its
 // lanes pull the next key as soon as their fit has converged; the four evaluations of an optimiser cycle run as four
 // interleaved recursions per lane; the optimiser itself is a per-lane state machine stepped once per cycle (k_arima_fit).
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -227,53 +228,25 @@ __global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const do
 }
 
 // ------------------------------------------------------------------------------------------------
-// ARIMA(1,1,1) likelihood: conventional Kalman filter written out for the 3-state model
+// ARIMA(1,1,1) likelihood.  statsmodels' state space is Z = [1 1 0], T = [[1 1 0],[0 phi 1],[0 0 0]], R = [0 1 theta]',
+// Q = sigma2, H = 0, approximate-diffuse (1e6) level + stationary ARMA block, loglikelihood_burn = 1, covariance frozen once
+// ||P_t - P_t+1||_F^2 < 1e-19.  ARITHMETIC CONTRACT (the one the oracle, oracle/arima_exact.c:arima_nll4_collapsed, states
+// expression for expression — IEEE double + - * / sqrt, fixed order, no FMA contraction, tad_detmath.h for log):
+// H = 0 (no observation noise) puts Z' in the null space of the filtered covariance: C Z' = P Z' - P Z' (Z P Z') / F = 0.
+// Row 0 of T is Z, so after EVERY update (T C T')_00 = (T C T')_01 = 0: from t = 1 on only p11 is non-zero (q12, q22
+// are constants), the level is known exactly (a0_t = y_t-1) and the filter is the innovations recursion of the ARMA(1,1)
+// on the differences:
+//   v = (y_t - y_t-1) - a1;  F = p;  r = 1 / F;  g = q12 r;  w = r v;  a1' = phi (a1 + v) + g v;  p' = (q11 + q22) - q12 g
+// (the textbook three-state form computes those zeros as differences of numbers of size 1e6 — the diffuse prior — and
+// feeds ~1e-10 of rounding residue into F; round 2 ran it, round 3 measured this form 1.44x faster at C3 and made it THE
+// contract).  The t = 0 step is the general update written out for p00 = 1e6, p01 = 0, a = 0; it does not depend on y
+// except through a1.  sum_t log F_t is one log of the running product of the F_t (mantissa renormalised every step, the
+// exponents summed as integers) plus, once p has converged, (number of converged steps) x log F.
 // ------------------------------------------------------------------------------------------------
-// Arithmetic contract of the likelihood (fixed operation order, no FMA contraction, tad_detmath.h for the one
-// transcendental) — oracle/arima_exact.c evaluates the same expressions in the same order on the host, which is what
-// makes the optimiser trajectories, and so every prediction, coincide bit for bit.  Restated after statsmodels'
-// conventional filter (_kalman_filter / _conventional: forecast error v, tmp2 = F^-1 v, a_t|t = a + P Z' tmp2,
-// P_t|t = P - P Z' (F^-1 Z) P, loglike_obs = -0.5 (log 2 pi + log F + v tmp2)), i.e. with the RECIPROCAL of F:
-//   v = y_t - (a0 + a1);  pz = P Z' = (p00 + p01, p01 + p11, q12);  F = pz0 + pz1;  r = 1 / F;  w = r v
-//   a_t|t = a + pz w;  a' = T a_t|t;  g = pz r;  C = P - g pz';  P' = T C T' + R Q R'
-// Structure used: P[0][2] = 0, P[1][2] = q12 = s2 theta and P[2][2] = q22 = s2 theta^2 hold from t = 0 on, so only p00,
-// p01, p11 evolve.  sum_t log F_t is one log of the running product of the F_t (mantissa renormalised every step, the
-// exponents summed as integers) plus, once the covariance has converged (||P_t - P_t+1||_F^2 < 1e-19: F, r, pz frozen),
-// (number of converged steps) x log F — one `log` per evaluation instead of one per step.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TAD_WAVE_ALL(c) __all(c)
-#else
-#define TAD_WAVE_ALL(c) (c)
-#endif
-
 struct KfOut {
   double nll;       // -loglike / nobs
   double forecast;  // Z a_{n+1|n}
 };
-
-struct KfState {
-  double phi, q11, q12, q22;     // model
-  double p00, p01, p11, a0, a1;  // predicted covariance (the entries that evolve) and state
-  double F, rF, pz0, pz1;        // frozen once converged
-  double prod, q;                // running product of the F_t (mantissa), sum of v^2 / F
-  int esum;                      // exponents of the product
-  uint32_t nconv;                // steps taken with the converged covariance
-  bool conv;
-};
-
-TAD_HD inline void kf_init(KfState &s, double u0, double u1, double u2) {
-  const double phi = -(u0 / sqrt(1.0 + u0 * u0));   // statsmodels' convention: constrain_stationary_univariate returns -r,
-  const double theta = u1 / sqrt(1.0 + u1 * u1);     // SARIMAX.transform_params negates it once more for the MA block
-  const double s2 = u2 * u2;
-  s.phi = phi;
-  s.q11 = s2; s.q12 = s2 * theta; s.q22 = s2 * (theta * theta);
-  s.p00 = kDiffuse; s.p01 = 0.0;
-  s.p11 = s2 * (1.0 + theta * theta + 2.0 * phi * theta) / (1.0 - phi * phi);
-  s.a0 = 0.0; s.a1 = 0.0;
-  s.F = 1.0; s.rF = 1.0; s.pz0 = 0.0; s.pz1 = 0.0;
-  s.prod = 1.0; s.q = 0.0;
-  s.esum = 0; s.nconv = 0; s.conv = false;
-}
 
 // prod * F renormalised to a mantissa in [0.5, 1): tad_det_frexp, on the device by the two instructions it restates
 TAD_HD inline double kf_frexp(double x, int *e) {
@@ -285,111 +258,6 @@ TAD_HD inline double kf_frexp(double x, int *e) {
 #endif
 }
 
-// one time step while NO lane of the wavefront has converged (the common case by far: with an MA coefficient near -1 —
-// differenced level-plus-noise data — the covariance does not converge within a 250-point history): kf_step without
-// the per-lane predication, identical arithmetic
-TAD_HD inline void kf_step_nc(KfState &s, double yv, bool burn_done) {
-  const double v = yv - (s.a0 + s.a1);
-  s.pz0 = s.p00 + s.p01; s.pz1 = s.p01 + s.p11;
-  s.F = s.pz0 + s.pz1;
-  s.rF = 1.0 / s.F;
-  const double w = s.rF * v;
-  if (burn_done) {   // t >= 1: compile-time or wave-uniform
-    s.q += v * w;
-    int e;
-    s.prod = kf_frexp(s.prod * s.F, &e);
-    s.esum += e;
-  }
-  const double f0 = s.a0 + s.pz0 * w, f1 = s.a1 + s.pz1 * w, f2 = s.q12 * w;
-  s.a0 = f0 + f1;
-  s.a1 = s.phi * f1 + f2;
-  const double g0 = s.pz0 * s.rF, g1 = s.pz1 * s.rF, g2 = s.q12 * s.rF;
-  const double c00 = s.p00 - g0 * s.pz0, c01 = s.p01 - g0 * s.pz1, c02 = -(g0 * s.q12);
-  const double c11 = s.p11 - g1 * s.pz1, c12 = s.q12 - g1 * s.q12, c22 = s.q22 - g2 * s.q12;
-  const double n00 = c00 + 2.0 * c01 + c11;
-  const double n01 = s.phi * (c01 + c11) + (c02 + c12);
-  const double n11 = s.phi * (s.phi * c11 + c12) + (s.phi * c12 + c22) + s.q11;
-  const double d00 = s.p00 - n00, d01 = s.p01 - n01, d11 = s.p11 - n11;
-  const double dsq = d00 * d00 + 2.0 * (d01 * d01) + d11 * d11;
-  s.conv = dsq < kConvTol;
-  s.p00 = n00; s.p01 = n01; s.p11 = n11;
-}
-
-// one time step (observation yv at index t); updates the covariance unless it has converged
-TAD_HD inline void kf_step(KfState &s, double yv, uint32_t t) {
-  const double v = yv - (s.a0 + s.a1);
-  if (!s.conv) {
-    s.pz0 = s.p00 + s.p01; s.pz1 = s.p01 + s.p11;
-    s.F = s.pz0 + s.pz1;
-    s.rF = 1.0 / s.F;
-  }
-  const double w = s.rF * v;
-  if (t >= 1) {
-    s.q += v * w;
-    if (!s.conv) { int e; s.prod = kf_frexp(s.prod * s.F, &e); s.esum += e; }
-    else s.nconv++;
-  }
-  const double f0 = s.a0 + s.pz0 * w, f1 = s.a1 + s.pz1 * w, f2 = s.q12 * w;
-  s.a0 = f0 + f1;
-  s.a1 = s.phi * f1 + f2;
-  if (!s.conv) {
-    const double g0 = s.pz0 * s.rF, g1 = s.pz1 * s.rF, g2 = s.q12 * s.rF;
-    const double c00 = s.p00 - g0 * s.pz0, c01 = s.p01 - g0 * s.pz1, c02 = -(g0 * s.q12);
-    const double c11 = s.p11 - g1 * s.pz1, c12 = s.q12 - g1 * s.q12, c22 = s.q22 - g2 * s.q12;
-    const double n00 = c00 + 2.0 * c01 + c11;
-    const double n01 = s.phi * (c01 + c11) + (c02 + c12);
-    const double n11 = s.phi * (s.phi * c11 + c12) + (s.phi * c12 + c22) + s.q11;
-    const double d00 = s.p00 - n00, d01 = s.p01 - n01, d11 = s.p11 - n11;
-    const double dsq = d00 * d00 + 2.0 * (d01 * d01) + d11 * d11;
-    s.conv = dsq < kConvTol;
-    s.p00 = n00; s.p01 = n01; s.p11 = n11;
-  }
-}
-
-// the same step when the covariance is known to have converged (t >= 1 then): the steady-state loop body
-TAD_HD inline void kf_step_conv(KfState &s, double yv) {
-  const double v = yv - (s.a0 + s.a1);
-  const double w = s.rF * v;
-  s.q += v * w;
-  s.nconv++;
-  const double f0 = s.a0 + s.pz0 * w, f1 = s.a1 + s.pz1 * w, f2 = s.q12 * w;
-  s.a0 = f0 + f1;
-  s.a1 = s.phi * f1 + f2;
-}
-
-TAD_HD inline KfOut kf_finish(const KfState &s, uint32_t n) {
-  double sumlog = tad_det_log(s.prod) + (double)s.esum * TAD_DM_LN2;
-  if (s.nconv) sumlog += (double)s.nconv * tad_det_log(s.F);
-  const double llf = -0.5 * ((double)(n - 1) * kLog2Pi + sumlog) - 0.5 * s.q;
-  KfOut o;
-  o.nll = -llf / (double)n;
-  o.forecast = s.a0 + s.a1;
-  return o;
-}
-
-// scalar form over a strided series (the host instantiation in tools/arima_twin.cpp runs this one)
-TAD_HD KfOut arima_nll(const double u0, const double u1, const double u2, const double *__restrict__ y, size_t stride,
-                       uint32_t n) {
-  KfState s;
-  kf_init(s, u0, u1, u2);
-  uint32_t t = 0;
-  for (; t < n && !TAD_WAVE_ALL(s.conv); ++t) kf_step(s, y[(size_t)t * stride], t);
-  for (; t < n; ++t) kf_step_conv(s, y[(size_t)t * stride]);
-  return kf_finish(s, n);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same likelihood with the model's structure used up — contract "collapsed" (opt-in: TAD_ARIMA_FILTER=collapsed;
-// oracle/arima_exact.c:arima_nll_collapsed is its host statement, expression for expression).
-// H = 0 (no observation noise) puts Z' in the null space of the filtered covariance: C Z' = P Z' - P Z' (Z P Z') / F = 0.
-// Row 0 of T is Z, so after EVERY update (T C T')_00 = (T C T')_01 = 0: from t = 1 on only p11 is non-zero (q12, q22
-// are constants), the level is known exactly (a0_t = y_t-1) and the filter is the innovations recursion of the ARMA(1,1)
-// on the differences:
-//   v = (y_t - y_t-1) - a1;  F = p;  r = 1 / F;  g = q12 r;  w = r v;  a1' = phi (a1 + v) + g v;  p' = (q11 + q22) - q12 g
-// (the general form computes those zeros as differences of numbers of size 1e6 — the diffuse prior — and feeds ~1e-10 of
-// rounding residue into F).  The t = 0 step is the general update written out for p00 = 1e6, p01 = 0, a = 0; it does not
-// depend on y except through a1.  ~30 instead of ~70 operations per step, 10 instead of 15 doubles of state.
-// ------------------------------------------------------------------------------------------------
 struct KfStateC {
   double phi, q12, qs;       // model: qs = q11 + q22
   double p, a1;              // predicted p11 and AR state
@@ -716,20 +584,64 @@ TAD_HD int mt_iterate(LineSearch &L, double &stp, double f, double g, double stp
 // ------------------------------------------------------------------------------------------------
 // L-BFGS-B 3.0, unconstrained path, as a per-lane state machine driven by (f, g) deliveries
 // ------------------------------------------------------------------------------------------------
+#if defined(TAD_LBFGS_DYNAMIC)
+#define TAD_LBFGS_RESET_HEAD(o) (o).head = 0
+#else
+#define TAD_LBFGS_RESET_HEAD(o) (void)0
+#endif
 struct Lbfgs {
   double x[3], g[3], f;
   double d[3], t[3], r[3];  // search direction, iterate and gradient at the start of the line search
   double fold, gd, gdold, stp, dnorm, dtd, theta;
   double fc, fcold;  // one-step forecast of the model at x / at the start of the line search (no extra filter run at the end)
   double S[kLbfgsM][3], Y[kLbfgsM][3];
-  int col, head, iter, ifun, iback, nit;
+  int col, iter, ifun, iback, nit;
+#if defined(TAD_LBFGS_DYNAMIC)
+  int head = 0;
+#endif
   bool in_ls, done;
   LineSearch ls;
 };
 
+// The history is kept in LOGICAL order (pair 0 = oldest) and shifted down when full, and every loop below has compile-time
+// bounds with a `j < col` predicate: all indices into S / Y / alpha are static, so the 60 doubles live in registers (or
+// in statically addressed spill slots the compiler reloads in bulk) instead of a dynamically indexed scratch array whose
+// dependent loads serialised the two-loop recursion.  Same operations in the same order as before.
+#if !defined(TAD_LBFGS_DYNAMIC)
 TAD_HD void lbfgs_direction(Lbfgs &o) {
   if (o.col == 0) {
     for (int i = 0; i < 3; ++i) o.d[i] = -o.g[i];  // Cauchy point with B = theta I, theta = 1
+    return;
+  }
+  double q[3] = {o.g[0], o.g[1], o.g[2]}, alpha[kLbfgsM];
+#pragma unroll
+  for (int j = kLbfgsM - 1; j >= 0; --j) {
+    alpha[j] = 0.0;
+    if (j < o.col) {
+      const double sy = o.S[j][0] * o.Y[j][0] + o.S[j][1] * o.Y[j][1] + o.S[j][2] * o.Y[j][2];
+      alpha[j] = (o.S[j][0] * q[0] + o.S[j][1] * q[1] + o.S[j][2] * q[2]) / sy;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) q[c] -= alpha[j] * o.Y[j][c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) q[c] /= o.theta;
+#pragma unroll
+  for (int j = 0; j < kLbfgsM; ++j) {
+    if (j < o.col) {
+      const double sy = o.S[j][0] * o.Y[j][0] + o.S[j][1] * o.Y[j][1] + o.S[j][2] * o.Y[j][2];
+      const double beta = (o.Y[j][0] * q[0] + o.Y[j][1] * q[1] + o.Y[j][2] * q[2]) / sy;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) q[c] += o.S[j][c] * (alpha[j] - beta);
+    }
+  }
+  for (int c = 0; c < 3; ++c) o.d[c] = -q[c];
+}
+
+#else   // A/B only (tools/gpu_arima_prof.sh): round 2's circular buffer with run-time indices
+TAD_HD void lbfgs_direction(Lbfgs &o) {
+  if (o.col == 0) {
+    for (int i = 0; i < 3; ++i) o.d[i] = -o.g[i];
     return;
   }
   double q[3] = {o.g[0], o.g[1], o.g[2]}, alpha[kLbfgsM];
@@ -749,6 +661,7 @@ TAD_HD void lbfgs_direction(Lbfgs &o) {
   for (int c = 0; c < 3; ++c) o.d[c] = -q[c];
 }
 
+#endif
 // forward-difference point of scipy's approx_derivative(method='2-point', abs_step=1e-5): x + 1e-5, unless that does not
 // change x (|x| > ~1e11: the huge sigma parameters of void Box-Cox regimes) — then the relative step sqrt(eps) * sign(x) *
 // max(1, |x|) (scipy/optimize/_numdiff.py: "cannot have a zero step ... fall back to relative step").  Returns x + h.
@@ -782,7 +695,7 @@ TAD_HD void lbfgs_begin_ls(Lbfgs &o) {
     if (task == LS_FG) break;
     // ascent direction / bad step: info != 0
     if (o.col == 0) { o.done = true; return; }  // ABNORMAL_TERMINATION_IN_LNSRCH (x, f already the old iterate)
-    o.col = 0; o.head = 0; o.theta = 1.0;          // refresh the memory and restart with steepest descent
+    o.col = 0; o.theta = 1.0; TAD_LBFGS_RESET_HEAD(o);          // refresh the memory and restart with steepest descent
   }
   o.ifun = 1;
   o.iback = 0;
@@ -809,7 +722,7 @@ TAD_HD void lbfgs_deliver(Lbfgs &o, int maxiter) {
       o.f = o.fold;
       o.fc = o.fcold;
       if (o.col == 0) { o.done = true; return; }
-      o.col = 0; o.head = 0; o.theta = 1.0;
+      o.col = 0; o.theta = 1.0; TAD_LBFGS_RESET_HEAD(o);
       o.in_ls = false;  // restart from the restored iterate
       lbfgs_begin_ls(o);
       return;
@@ -832,10 +745,26 @@ TAD_HD void lbfgs_deliver(Lbfgs &o, int maxiter) {
   if (o.stp == 1.0) { dr = o.gd - o.gdold; ddum = -o.gdold; }
   else { dr = (o.gd - o.gdold) * o.stp; for (int i = 0; i < 3; ++i) o.d[i] *= o.stp; ddum = -o.gdold * o.stp; }
   if (!(dr <= kEpsMch * ddum)) {
+#if !defined(TAD_LBFGS_DYNAMIC)
+    if (o.col == kLbfgsM) {   // full: drop the oldest pair
+#pragma unroll
+      for (int j = 0; j + 1 < kLbfgsM; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { o.S[j][i] = o.S[j + 1][i]; o.Y[j][i] = o.Y[j + 1][i]; }
+      o.col = kLbfgsM - 1;
+    }
+#pragma unroll
+    for (int j = 0; j < kLbfgsM; ++j)
+      if (j == o.col)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { o.S[j][i] = o.d[i]; o.Y[j][i] = o.r[i]; }
+    o.col++;
+#else
     int slot;
     if (o.col < kLbfgsM) { slot = (o.head + o.col) % kLbfgsM; o.col++; }
     else { slot = o.head; o.head = (o.head + 1) % kLbfgsM; }
     for (int i = 0; i < 3; ++i) { o.S[slot][i] = o.d[i]; o.Y[slot][i] = o.r[i]; }
+#endif
     o.theta = rr / dr;
   }
   o.in_ls = false;
@@ -865,12 +794,23 @@ __global__ __launch_bounds__(64) void k_arima_start(Grid g, ArimaWs ws, const ui
 // Lanes then hold arbitrary keys, so the series are read from the KEY-major copy: every 8 time steps the wavefront loads
 // the next 64 bytes of each lane's row cooperatively (4 lanes x 16 B per row: whole sectors, no over-fetch), stages them
 // in LDS (row stride 9 doubles: conflict-free) and every lane picks up its 8 values.
-// The optimiser runs in cycles of four evaluations (f at x, then the three forward-difference points) followed by one
+// The optimiser runs in cycles: f at x and at the three forward-difference points as FOUR interleaved recursions per lane in
+// one pass over the series (the joint recursion of the contract: one division per step for the four reciprocals), then one
 // state-machine step, the same for all lanes; finished lanes are refilled between cycles.
 // ------------------------------------------------------------------------------------------------
 static constexpr int kStage = 8;  // time steps staged per round: 64 B per row
 
-template <int CHAINS, int FILTER>
+#if defined(TAD_ARIMA_PROF)
+// profiling build (tools/gpu_arima_prof.sh; never the shipped library): shader-clock cycles per wavefront spent in the
+// likelihood pass / the optimiser step / refill, summed over all wavefronts
+__device__ unsigned long long g_arima_prof[8];
+#define TAD_PROF_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define TAD_PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
+#else
+#define TAD_PROF_T(v)
+#define TAD_PROF_ADD(slot, t0, t1)
+#endif
+
 __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double *__restrict__ sigma,
                                                const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax, uint32_t chunk,
                                                double *__restrict__ calc, DevCounters *ctr, double *buf) {
@@ -882,9 +822,13 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
   uint64_t next = c0;                                           // wave-uniform
   uint64_t k = 0;
   bool busy = false;
-  unsigned long long steps = 0, fits = 0;
+  unsigned long long steps = 0, fits = 0, nanfits = 0;
+#if defined(TAD_ARIMA_PROF)
+  unsigned long long prof[4] = {0, 0, 0, 0};
+#endif
   Lbfgs o;
   o.done = true;
+  o.col = 0;
   size_t row[4] = {0, 0, 0, 0};                                 // element offset of the rows this lane loads for the wavefront
 
   auto refill = [&]() {
@@ -898,7 +842,7 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
         busy = true;
         const size_t c = (size_t)p * g.K + k;
         o.x[0] = ws.u0[0][c]; o.x[1] = ws.u0[1][c]; o.x[2] = ws.u0[2][c];
-        o.col = 0; o.head = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false;
+        o.col = 0; TAD_LBFGS_RESET_HEAD(o); o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false;
         o.f = 0.0; o.fc = 0.0; o.fcold = 0.0;
       }
     }
@@ -907,10 +851,15 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     for (int j = 0; j < 4; ++j) row[j] = (size_t)__shfl(mine, j * 16 + (int)(lane >> 2)) * ws.Tpad + (lane & 3u) * 2u;
   };
 
-  auto evaluate = [&](double u0, double u1, double u2) -> KfOut {
-    KfState s;
-    kf_init(s, u0, u1, u2);
-    if (!busy) s.conv = true;   // an idle lane must not keep the wavefront in the covariance-updating loop
+  // one pass over the series: the four recursions of the contract (the difference y_t - y_t-1 is shared by them)
+  auto evaluate4 = [&](const double (&xe)[4][3], double (&nll)[4], double &fc) {
+    KfStateC s4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      kfc_init(s4[c], xe[c][0], xe[c][1], xe[c][2]);
+      if (!busy) s4[c].conv = true;   // an idle lane must not keep the wavefront in the covariance-updating loop
+    }
+    double yprev = 0.0;
     for (uint32_t t0 = 0; t0 < p; t0 += kStage) {
       double2 v[4];
 #pragma unroll
@@ -927,93 +876,6 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
       for (int i = 0; i < kStage; ++i) yv[i] = buf[(size_t)lane * (kStage + 1) + i];
       const uint32_t nb = p - t0 < (uint32_t)kStage ? p - t0 : (uint32_t)kStage;
       // compile-time indices into yv (a runtime-indexed array would live in scratch memory); nb is wave-uniform
-      if (!__all(s.conv)) {
-#pragma unroll
-        for (int i = 0; i < kStage; ++i)
-          if ((uint32_t)i < nb) {
-            if (!__any(s.conv)) kf_step_nc(s, yv[i], t0 + (uint32_t)i >= 1u);
-            else kf_step(s, yv[i], t0 + (uint32_t)i);
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < kStage; ++i)
-          if ((uint32_t)i < nb) kf_step_conv(s, yv[i]);
-      }
-    }
-    return kf_finish(s, p);
-  };
-
-  // CHAINS == 4: f at x and at the three forward-difference points in ONE pass over the series — four independent Kalman
-  // recursions per lane.  Same arithmetic per recursion (bit-identical results); the series is staged once instead of four
-  // times and, above all, the four dependency chains interleave: the loop is bound by FP64 dependency latency (one division
-  // and ~25 dependent operations per step), not by issue, at the 2-3 wavefronts per SIMD its register footprint allows.
-  auto evaluate4 = [&](const double (&xe)[4][3], double (&nll)[4], double &fc) {
-    KfState s4[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      kf_init(s4[c], xe[c][0], xe[c][1], xe[c][2]);
-      if (!busy) s4[c].conv = true;
-    }
-    for (uint32_t t0 = 0; t0 < p; t0 += kStage) {
-      double2 v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const double2 *>(ws.ysk + row[j] + t0);
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double *d = buf + (size_t)(j * 16 + (int)(lane >> 2)) * (kStage + 1) + (lane & 3u) * 2u;
-        d[0] = v[j].x; d[1] = v[j].y;
-      }
-      __syncthreads();
-      double yv[kStage];
-#pragma unroll
-      for (int i = 0; i < kStage; ++i) yv[i] = buf[(size_t)lane * (kStage + 1) + i];
-      const uint32_t nb = p - t0 < (uint32_t)kStage ? p - t0 : (uint32_t)kStage;
-#pragma unroll
-      for (int i = 0; i < kStage; ++i)
-        if ((uint32_t)i < nb) {
-          const bool any_conv = __any(s4[0].conv || s4[1].conv || s4[2].conv || s4[3].conv);
-          if (!any_conv) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) kf_step_nc(s4[c], yv[i], t0 + (uint32_t)i >= 1u);
-          } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) kf_step(s4[c], yv[i], t0 + (uint32_t)i);
-          }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const KfOut r = kf_finish(s4[c], p);
-      nll[c] = r.nll;
-      if (c == 0) fc = r.forecast;
-    }
-  };
-
-  // the same pass with the collapsed filter (FILTER == 1): the difference y_t - y_t-1 is shared by the four recursions
-  auto evaluate4c = [&](const double (&xe)[4][3], double (&nll)[4], double &fc) {
-    KfStateC s4[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      kfc_init(s4[c], xe[c][0], xe[c][1], xe[c][2]);
-      if (!busy) s4[c].conv = true;
-    }
-    double yprev = 0.0;
-    for (uint32_t t0 = 0; t0 < p; t0 += kStage) {
-      double2 v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const double2 *>(ws.ysk + row[j] + t0);
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double *d = buf + (size_t)(j * 16 + (int)(lane >> 2)) * (kStage + 1) + (lane & 3u) * 2u;
-        d[0] = v[j].x; d[1] = v[j].y;
-      }
-      __syncthreads();
-      double yv[kStage];
-#pragma unroll
-      for (int i = 0; i < kStage; ++i) yv[i] = buf[(size_t)lane * (kStage + 1) + i];
-      const uint32_t nb = p - t0 < (uint32_t)kStage ? p - t0 : (uint32_t)kStage;
 #pragma unroll
       for (int i = 0; i < kStage; ++i)
         if ((uint32_t)i < nb) {
@@ -1038,7 +900,8 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
   };
 
   refill();
-  while (CHAINS == 4 && __any(busy)) {
+  while (__any(busy)) {
+    TAD_PROF_T(t_a);
     double xe[4][3], dx[3], nll[4], fc0 = 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1046,8 +909,8 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) xe[i + 1][i] = fd_point(xe[i + 1][i], &dx[i]);
-    if (FILTER == 1) evaluate4c(xe, nll, fc0);
-    else evaluate4(xe, nll, fc0);
+    evaluate4(xe, nll, fc0);
+    TAD_PROF_T(t_b);
     if (busy) {
       steps += 4ull * p;
 #pragma unroll
@@ -1061,70 +924,35 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
         const double pred = inv_boxcox(o.fc, ws.lam[k]);
         calc[c] = pred;
         if (fabs(ws.xs[(size_t)p * st + k] - pred) > sigma[k]) g.flag[c] = FLAG_PRESENT | FLAG_ANOMALY;
+        if (!tad_finite(pred)) nanfits++;   // the optimiser walked into a non-finite likelihood: the point can never be an anomaly
         fits++;
         busy = false;
       }
     }
+    TAD_PROF_T(t_c);
     refill();
+    TAD_PROF_T(t_d);
+    TAD_PROF_ADD(0, t_a, t_b); TAD_PROF_ADD(1, t_b, t_c); TAD_PROF_ADD(2, t_c, t_d); TAD_PROF_ADD(3, 0ull, 1ull);
   }
-  while (CHAINS == 1 && __any(busy)) {
-    double f0 = 0.0, fc0 = 0.0;
-    for (int phase = 0; phase < 4; ++phase) {
-      double xe0 = o.x[0], xe1 = o.x[1], xe2 = o.x[2], dx = 1.0;
-      if (phase >= 1) {
-        double *xe = phase == 1 ? &xe0 : (phase == 2 ? &xe1 : &xe2);
-        *xe = fd_point(*xe, &dx);
-      }
-      const KfOut r = evaluate(xe0, xe1, xe2);
-      if (busy) {
-        steps += p;
-        if (phase == 0) { f0 = r.nll; fc0 = r.forecast; }
-        else o.g[phase - 1] = (r.nll - f0) / dx;
-      }
-    }
-    if (busy) {
-      o.f = f0;
-      o.fc = fc0;
-      lbfgs_deliver(o, maxiter);
-      if (o.done) {
-        const size_t st = g.K;
-        const uint64_t c = (uint64_t)ws.tpos[(size_t)p * st + k] * g.K + k;
-        const double pred = inv_boxcox(o.fc, ws.lam[k]);
-        calc[c] = pred;
-        if (fabs(ws.xs[(size_t)p * st + k] - pred) > sigma[k]) g.flag[c] = FLAG_PRESENT | FLAG_ANOMALY;
-        fits++;
-        busy = false;
-      }
-    }
-    refill();
-  }
-  for (int d = 32; d >= 1; d >>= 1) { steps += __shfl_down(steps, d); fits += __shfl_down(fits, d); }
+  for (int d = 32; d >= 1; d >>= 1) { steps += __shfl_down(steps, d); fits += __shfl_down(fits, d); nanfits += __shfl_down(nanfits, d); }
   if (threadIdx.x == 0 && fits) {
     atomicAdd(&ctr->kalman_steps, steps);
     atomicAdd(&ctr->arima_fits, fits);
+    if (nanfits) atomicAdd(&ctr->arima_nan_fits, nanfits);
   }
+#if defined(TAD_ARIMA_PROF)
+  if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) atomicAdd(&g_arima_prof[i], prof[i]);
+#endif
 }
 
-// The register budget decides how many wavefronts share a SIMD (512 VGPRs: 128 -> 4, 96 -> 5, 80 -> 6, 64 -> 8); the
-// optimiser's state is only touched between evaluations, so a tighter budget spills exactly that to scratch and buys
-// latency hiding for the Kalman loop.  One kernel per budget; TAD_ARIMA_WAVES picks (default: measured best).
-#define TAD_ARIMA_FIT_KERNEL(NAME, W, CH, FL)                                                                            \
-  __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void NAME(                                \
-      Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,  \
-      uint32_t chunk, double *__restrict__ calc, DevCounters *ctr) {                                                    \
-    __shared__ double buf[64 * (kStage + 1)];                                                                           \
-    arima_fit_body<CH, FL>(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf);                                  \
-  }
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_w3, 3, 1, 0)
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_w4, 4, 1, 0)
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w1, 1, 4, 0)
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w2, 2, 4, 0)
-TAD_ARIMA_FIT_KERNEL(k_arima_fit_c4w3, 3, 4, 0)
-// collapsed filter (TAD_ARIMA_FILTER=collapsed; queued for measurement): four chains per lane at 2 / 3 / 4 wavefronts per SIMD
-TAD_ARIMA_FIT_KERNEL(k_arima_fitc_c4w2, 2, 4, 1)
-TAD_ARIMA_FIT_KERNEL(k_arima_fitc_c4w3, 3, 4, 1)
-TAD_ARIMA_FIT_KERNEL(k_arima_fitc_c4w4, 4, 4, 1)
-#undef TAD_ARIMA_FIT_KERNEL
+// Two wavefronts per SIMD (256 VGPRs each): measured at C3 on MI355X 0.53 s against 0.63 s at three (168 VGPRs) and 1.43 s at
+// four (128 VGPRs: the step loop spills) — profiles/r3_v0_queued_ab_c3.log.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_arima_fit(
+    Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,
+    uint32_t chunk, double *__restrict__ calc, DevCounters *ctr) {
+  __shared__ double buf[64 * (kStage + 1)];
+  arima_fit_body(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf);
+}
 
 static uint32_t arima_tpad(uint64_t T) { return (uint32_t)((T + kStage - 1) / kStage * kStage); }
 
@@ -1154,34 +982,22 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
     const uint64_t kblocks = (g.K + 63) / 64;
     if (kblocks * (g.T - 3) > 0x7FFFFFFFull) return -1;
     hipLaunchKernelGGL(k_arima_start, dim3((unsigned)(kblocks * (g.T - 3))), dim3(64), 0, s, g, ws, n_pts, (uint32_t)g.T);
-    uint32_t chunk = 4096;   // keys per wavefront and position: ~64 fits per lane (measured: 256 -> 1.48 s, 1024 -> 1.28 s, 4096 -> 1.22 s at C3)
-    if (const char *e = getenv("TAD_ARIMA_CHUNK")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 20)) chunk = (uint32_t)v; }
+    const uint32_t chunk = 4096;   // keys per wavefront and position: ~64 fits per lane (measured: 256 -> 1.48 s, 1024 -> 1.28 s, 4096 -> 1.22 s at C3)
     const uint64_t nchunks = (g.K + chunk - 1) / chunk;
     const uint64_t blocks = nchunks * (g.T - 3);
     if (blocks > 0x7FFFFFFFull) return -1;
-    // measured at C3 — one chain per lane: 3 wavefronts per SIMD 0.89 s, 4 -> 0.93 s, 5 -> 1.5 s, 8 -> 2.4 s (spills);
-    // four chains per lane: 2 wavefronts per SIMD 0.77 s, 1 -> 1.06 s, 3 -> 1.9 s (spills)
-    int waves = 2, chains = 4;
-    if (const char *e = getenv("TAD_ARIMA_WAVES")) waves = atoi(e);
-    if (const char *e = getenv("TAD_ARIMA_CHAINS")) chains = atoi(e);
-#define TAD_ARIMA_LAUNCH(NAME) hipLaunchKernelGGL(NAME, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, chunk, calc, ctr)
-    const char *fl = getenv("TAD_ARIMA_FILTER");
-    if (fl != nullptr && !strcmp(fl, "collapsed")) {   // opt-in arithmetic contract (kfc_*); four chains per lane only
-      // 10 doubles of state per chain: at 3 wavefronts per SIMD (168 VGPRs) the step loop is still free of scratch traffic
-      // (ISA checked), at 4 it is not; not yet measured — TAD_ARIMA_WAVES=2|3|4 for the A/B
-      if (getenv("TAD_ARIMA_WAVES") == nullptr) waves = 3;
-      if (waves == 4) TAD_ARIMA_LAUNCH(k_arima_fitc_c4w4);
-      else if (waves == 2) TAD_ARIMA_LAUNCH(k_arima_fitc_c4w2);
-      else TAD_ARIMA_LAUNCH(k_arima_fitc_c4w3);
-    } else if (chains == 4) {
-      if (waves == 1) TAD_ARIMA_LAUNCH(k_arima_fit_c4w1);
-      else if (waves == 3) TAD_ARIMA_LAUNCH(k_arima_fit_c4w3);
-      else TAD_ARIMA_LAUNCH(k_arima_fit_c4w2);
-    } else {
-      if (waves == 4) TAD_ARIMA_LAUNCH(k_arima_fit_w4);
-      else TAD_ARIMA_LAUNCH(k_arima_fit_w3);   // TAD_ARIMA_CHAINS=1
+    hipLaunchKernelGGL(k_arima_fit, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, chunk, calc, ctr);
+#if defined(TAD_ARIMA_PROF)
+    {
+      unsigned long long h[8] = {0};
+      hipStreamSynchronize(s);
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(g_arima_prof), sizeof h);
+      fprintf(stderr, "arima prof: wavefront cycles in likelihood pass %llu | optimiser step %llu | refill %llu | optimiser cycles %llu | wavefronts %llu\n",
+              h[0], h[1], h[2], h[3], (unsigned long long)blocks);
+      unsigned long long z[8] = {0};
+      hipMemcpyToSymbol(HIP_SYMBOL(g_arima_prof), z, sizeof z);
     }
-#undef TAD_ARIMA_LAUNCH
+#endif
   }
   return 0;
 }

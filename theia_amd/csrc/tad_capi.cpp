@@ -36,22 +36,19 @@ struct tad_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   uint64_t ws_limit = 0;
+  tad_plan plan{};    // plan overrides (tests / A-B measurements); all zero = the engine decides.  Read under mu.
   std::mutex mu;      // serialises runs on this engine (controller.go:199-201 has 4 workers)
   std::mutex err_mu;  // protects err
   std::string err;
   std::atomic<int32_t> done{0}, total{0};
   // grow-only device scratch
-  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2, moments, tile_stats;
+  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2, moments;
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
   DevBuf rcp_table;           // rcp_table[n] = RN(1/n), n = 0..rcp_n-1
   uint64_t rcp_n = 0;
   DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
   DevBuf sp_cls;                                                                  // Stage 0 sparse, length classes: per-key class arrays
-  DevBuf fused_ctl;                                                               // k_ewma_fused: ticket, row total, look-back status words
-  uint64_t ewma_rows_hint = 0;   // rows of the last EWMA job + slack: the result capacity the fused kernel is given (no count pass)
-  uint64_t ewma_rows_last = 0;   // ... and the rows themselves: sizes the kernel's LDS staging (mean rows per wavefront)
-  DevBuf part2_total, part2_start, part2_offs32, part2_cursor, recs2;             // Stage 0 v2, two-level partition
   DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
@@ -72,6 +69,11 @@ struct tad_state {
 namespace {
 
 constexpr int kMetaBlocks = 2048;
+
+bool plan_ok(const tad_plan &p) {
+  return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 2 && p.histogram >= 0 && p.histogram <= 1 && p.sparse >= 0 &&
+         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096;
+}
 constexpr uint32_t kOverflowCap = 1u << 20;  // Stage 0 v2: rows with a value >= 2^49 per run before falling back to v1
 
 int fail(tad_engine *e, int code, const char *fmt, ...) {
@@ -210,6 +212,7 @@ int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
     return fail(nullptr, TAD_ERR_NO_DEVICE, "no HIP device available (%s)", r != hipSuccess ? hipGetErrorString(r) : "count = 0");
   const int dev = opts ? opts->device : 0;
   if (dev < 0 || dev >= ndev) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "device %d out of range (have %d)", dev, ndev);
+  if (opts && !plan_ok(opts->plan)) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_engine_create: a tad_plan field is out of range");
   tad_engine *e = new (std::nothrow) tad_engine();
   if (!e) return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
   e->device = dev;
@@ -223,6 +226,7 @@ int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
   e->ws_limit = (opts && opts->workspace_limit) ? opts->workspace_limit : (uint64_t)(free_b / 4 * 3);
+  if (opts) e->plan = opts->plan;
   for (auto &ev : e->ev) hipEventCreate(&ev);
   hipHostMalloc(reinterpret_cast<void **>(&e->meta_host), sizeof(MetaPartial) * kMetaBlocks, hipHostMallocDefault);
   hipHostMalloc(reinterpret_cast<void **>(&e->ctr_host), sizeof(DevCounters), hipHostMallocDefault);
@@ -238,7 +242,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->fused_ctl, &e->part2_total, &e->part2_start, &e->part2_offs32, &e->part2_cursor, &e->recs2, &e->part_fin, &e->tile_stats, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part_fin, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -250,6 +254,16 @@ void tad_engine_destroy(tad_engine *e) {
   if (e->moments_host) hipHostFree(e->moments_host);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
+}
+
+int tad_engine_set_plan(tad_engine *e, const tad_plan *plan) {
+  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_engine_set_plan: engine is NULL");
+  tad_plan p{};
+  if (plan) p = *plan;
+  if (!plan_ok(p)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_engine_set_plan: a tad_plan field is out of range");
+  std::lock_guard<std::mutex> lk(e->mu);   // takes effect with the next job
+  e->plan = p;
+  return TAD_OK;
 }
 
 int tad_progress(tad_engine *e, int32_t *done, int32_t *total) {
@@ -308,7 +322,6 @@ struct JobParams {
   int drop_min_samples;
   bool all_points;
   bool lazy_sigma = false;   // set by detect_and_count: the stddev column is computed by the emit kernel (DBSCAN jobs)
-  TileStats tile_stats{nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // set by Stage 0 when pass C left per-round key statistics
 };
 
 // reciprocals of the point counts 1..T for the exact-division FMA sequence (tad_internal.h:div_by_count);
@@ -373,7 +386,7 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
     if (dbscan_uses_list(g)) {
       DbscanStats dst{nullptr, nullptr, nullptr, nullptr};
       if (db_fused) dst = DbscanStats{n_pts, n_anom, static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p)};
-      if (launch_dbscan(s, g, jp.eps, jp.min_samples, e->aux.p, dst, db_fused ? jp.tile_stats : TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0}) != 0)
+      if (launch_dbscan(s, g, jp.eps, jp.min_samples, e->aux.p, dst) != 0)
         return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
     } else {
       launch_dbscan_long(s, g, jp.eps, jp.min_samples, e->aux.p);
@@ -409,7 +422,7 @@ void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows ou
     return;
   launch_emit(e->stream, g, L, kind, jp.all_points, jp.alpha, static_cast<const double *>(e->sigma.p),
               static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(kind == 3 ? e->key_mean.p : e->calc.p),
-              static_cast<const unsigned long long *>(e->off.p), out, rows);
+              static_cast<const unsigned long long *>(e->off.p), out, rows, e->plan.ewma_emit, e->plan.ewma_emit_rows);
 }
 
 int make_result(tad_engine *e, uint64_t rows, bool with_anomaly, tad_mem out_memory, ResultPriv **out, OutRows *dev_rows,
@@ -457,72 +470,6 @@ int finish_result(tad_engine *e, ResultPriv *rp, uint64_t rows, bool with_anomal
   rp->pub.algo_calc = ho.algo_calc;
   rp->pub.stddev = ho.stddev;
   rp->pub.anomaly = ho.anomaly;
-  return TAD_OK;
-}
-
-// the same for a device block carved for cap_rows >= rows (k_ewma_fused: the capacity was chosen before the rows were known)
-int finish_result_cap(tad_engine *e, ResultPriv *rp, uint64_t rows, ResultBlock dev_block, OutRows dev_rows) {
-  rp->pub.n_rows = rows;
-  if (rp->pub.memory == TAD_MEM_DEVICE) return finish_result(e, rp, rows, false, dev_block, dev_rows);
-  const size_t bytes = result_bytes(rows, false);
-  void *h = malloc(bytes);
-  if (!h) { e->free_blocks.push_back({dev_block.base, dev_block.cap}); return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu result bytes", bytes); }
-  OutRows ho;
-  carve(h, rows, false, &ho);
-  const void *src[5] = {dev_rows.key_id, dev_rows.flow_end_s, dev_rows.throughput, dev_rows.algo_calc, dev_rows.stddev};
-  void *dst[5] = {ho.key_id, ho.flow_end_s, ho.throughput, ho.algo_calc, ho.stddev};
-  hipError_t r = hipSuccess;
-  for (int c = 0; c < 5 && r == hipSuccess && rows; ++c) r = hipMemcpyAsync(dst[c], src[c], (size_t)rows * 8, hipMemcpyDeviceToHost, e->stream);
-  if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
-  e->free_blocks.push_back({dev_block.base, dev_block.cap});
-  if (r != hipSuccess) { free(h); return fail(e, TAD_ERR_HIP, "result copy failed: %s", hipGetErrorString(r)); }
-  rp->block = h;
-  rp->block_cap = bytes;
-  rp->pub.key_id = reinterpret_cast<uint64_t *>(ho.key_id);
-  rp->pub.flow_end_s = reinterpret_cast<int64_t *>(ho.flow_end_s);
-  rp->pub.throughput = ho.throughput;
-  rp->pub.algo_calc = ho.algo_calc;
-  rp->pub.stddev = ho.stddev;
-  rp->pub.anomaly = nullptr;
-  return TAD_OK;
-}
-
-// EWMA job with TAD_EWMA_FUSED=1: sigma + detector + compaction + emit in one kernel (tad_kernels.hip:k_ewma_fused).  The result
-// block is sized from the engine's last EWMA job (+ 1/8): there is no count pass and no host round trip before the rows are
-// written.  *fused = false on return: the capacity was too small (or there was no hint yet) — the per-key counts are in place,
-// *rows is exact and the caller emits the classic way; true: the rows are in *dev_rows.
-int ewma_fused_run(tad_engine *e, Grid g, Lattice L, const JobParams &jp, DevCounters *ctr, tad_mem out_memory, uint32_t cap, uint64_t out_cap,
-                   ResultPriv **rp_out, OutRows *dev_rows, ResultBlock *dev_block, uint64_t *rows, bool *fused) {
-  hipStream_t s = e->stream;
-  int rc;
-  *fused = false;
-  if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
-  if ((rc = ensure_rcp_table(e, g.T)) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->fused_ctl, ewma_fused_ctl_bytes(g.K))) != TAD_OK) return rc;
-  ResultPriv *rp = nullptr;
-  if ((rc = make_result(e, out_cap, false, out_memory, &rp, dev_rows, dev_block)) != TAD_OK) return rc;
-  auto drop = [&]() { e->free_blocks.push_back({dev_block->base, dev_block->cap}); delete rp; };
-  launch_ewma_fused(s, g, L, jp.alpha, static_cast<const double *>(e->rcp_table.p), static_cast<double *>(e->sigma.p), static_cast<uint32_t *>(e->n_pts.p),
-                    static_cast<uint32_t *>(e->n_anom.p), ctr, static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p), e->fused_ctl.p,
-                    *dev_rows, out_cap, cap);
-  launch_moments(s, g.K, static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
-                 static_cast<Moments *>(e->moments.p), nullptr);
-  hipError_t hr = hipMemcpyAsync(e->total_host, static_cast<unsigned long long *>(e->fused_ctl.p) + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
-  if (hr == hipSuccess) hr = hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s);
-  if (hr == hipSuccess) hr = hipMemcpyAsync(e->moments_host, e->moments.p, kMomentBlocks * sizeof(Moments), hipMemcpyDeviceToHost, s);
-  if (hr == hipSuccess) hr = hipEventRecord(e->ev[4], s);
-  if (hr == hipSuccess) hr = hipStreamSynchronize(s);
-  if (hr == hipSuccess) hr = hipGetLastError();
-  if (hr != hipSuccess) { drop(); return fail(e, TAD_ERR_HIP, "fused EWMA kernel: %s", hipGetErrorString(hr)); }
-  *rows = *e->total_host;
-  if (*rows > out_cap) {   // counted, not written: classic emit with the exact size (the counts per key are in n_anom)
-    drop();
-    unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
-    launch_scan(s, static_cast<const uint32_t *>(e->n_anom.p), off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
-    return TAD_OK;
-  }
-  *rp_out = rp;
-  *fused = true;
   return TAD_OK;
 }
 
@@ -643,21 +590,19 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   Lattice L = make_lattice(cols->t0, lat_mode == 0 ? cols->step : 1, cols->n_buckets);
   bool empty = (n == 0 || K == 0);
   // Stage 0 strategy: v2 (partition + LDS tiles) for big batches, v1 (direct atomics) otherwise / as fallback.
-  const char *s0env = getenv("TAD_STAGE0");
-  const bool force_v1 = s0env && !strcmp(s0env, "v1");
-  const bool force_v2 = s0env && !strcmp(s0env, "v2");
+  const tad_plan plan = e->plan;   // (e->mu is held)
+  const bool force_v1 = plan.stage0 == 1;
+  const bool force_v2 = plan.stage0 == 2;
   const bool has2 = cols->key_id2 != nullptr;
   bool force_v1_retry = false;
   // pass A may histogram a SAMPLE of the rows (1/8 of the key column instead of all of it): pass B's regions are then sized from
   // the estimate with 6 sigma of slack; a region that still turns out too small (keys arriving in bursts the sample missed)
-  // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  TAD_HIST_SAMPLE=0 disables it.
-  const char *hs_env = getenv("TAD_HIST_SAMPLE"), *tl_env = getenv("TAD_TWO_LEVEL");
-  bool force_exact_hist = (hs_env && atoi(hs_env) == 0) || (tl_env && atoi(tl_env) == 1);
+  // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  tad_plan.histogram = 1 disables it.
+  bool force_exact_hist = plan.histogram == 1;
   // retries: wrong hint -> derive (0 -> 1); sampled lattice too coarse / saw no live row -> exact (1 -> 2); overflow list
   // full -> Stage 0 v1.  Each transition happens at most once, so 5 attempts cover every path.
   for (int attempt = 0; attempt < 7; ++attempt) {
     const bool hinted = lat_mode == 0;
-    jp.tile_stats = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
     PartPlan pl{};
     bool v2 = !empty && !force_v1 && !force_v1_retry && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
@@ -726,11 +671,11 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     // Sparse tables (few points per key on a fine lattice: second-resolution timestamps, per-connection keys): the dense
     // K x T grid would be mostly empty or not fit at all — sort the rows by (key, time) instead and lay each key's points
     // out by rank (tad_sparse.hip).  Chosen when the rows could fill at most 1/8 of a large grid, or the grid does not fit.
-    const char *sp_env = getenv("TAD_SPARSE");
     const uint64_t slots_all = n * (has2 ? 2 : 1);
-    bool sparse = !empty && !stream && K <= 0xFFFFFFFFull &&
-                  ((sp_env && atoi(sp_env) == 1) ||
-                   (!(sp_env && atoi(sp_env) == 0) && (cells_overflow || need > e->ws_limit || (cells >= (1ull << 24) && slots_all < cells / 8))));
+    // (first[], len[] and the class offsets are 32-bit indices into the sorted point list: 2^32 slots and beyond stay dense or fail cleanly)
+    bool sparse = !empty && !stream && K <= 0xFFFFFFFFull && slots_all < (1ull << 32) &&
+                  (plan.sparse == 2 ||
+                   (plan.sparse != 1 && (cells_overflow || need > e->ws_limit || (cells >= (1ull << 24) && slots_all < cells / 8))));
     Grid sparse_grid{};
     if (sparse) {
       v2 = false;
@@ -767,8 +712,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       need = cells * 17 + (jp.algo == TAD_ALGO_ARIMA ? cells * 68 : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
       // Skewed series lengths (one key with a day of seconds next to many short-lived ones): K x Tmax does not fit although the
       // points do.  The keys are split into length classes that run as jobs of their own (run_sparse_classes).
-      const char *cl_env = getenv("TAD_SPARSE_CLASSES");
-      if (P && depth == 0 && (need > e->ws_limit || (cl_env && atoi(cl_env) == 1))) {
+      if (P && depth == 0 && (need > e->ws_limit || plan.sparse_classes == 1)) {
         HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
         const DevCounters c0 = *e->ctr_host;
@@ -809,62 +753,11 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     Grid g{static_cast<unsigned long long *>(e->grid_val.p), static_cast<uint8_t *>(e->grid_flag.p), empty ? 0 : K, L.nb, nullptr};
     if (sparse) g = sparse_grid;
     if (v2 && !part_plan_tiles(K, L.nb, has2, &pl)) v2 = false;  // tile does not fit LDS: direct scatter
-    bool stats_done = false, two_level = false;
-    PartPlan pl1{}, pl2{};
-    // DBSCAN (opt-in, TAD_DBSCAN_TILESTATS=1|2; queued for measurement): pass C leaves per-round key statistics, the detector
-    // settles most keys from them instead of reading the grid back (tad_dbscan.hip:k_dbscan_scan); 2: with one bucket round
-    // per partition (two-level plan) pass C does not even write the columns of the keys it can see are settled
-    auto want_tile_stats = [&](PartPlan &p) -> int {
-      jp.tile_stats = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-      const char *ts_env = getenv("TAD_DBSCAN_TILESTATS");
-      if (ts_env == nullptr || (ts_env[0] != '1' && ts_env[0] != '2') || jp.algo != TAD_ALGO_DBSCAN || jp.all_points || !dbscan_uses_list(g)) return TAD_OK;
-      // 2: a multi-round partition is split by key sub-range instead of bucket range, so that its tiles hold whole series too
-      if (ts_env[0] == '2') { const bool kr = part_plan_key_rounds(L.nb, &p); if (getenv("TAD_DEBUG_PLAN")) fprintf(stderr, "key rounds %d: ks_shift %u rounds %u tb %u\n", (int)kr, p.ks_shift, p.n_chunks, p.tb); }
-      const uint32_t rounds = p.ks_shift != 0 ? 1u : p.n_chunks;
-      const int erc = ensure(e, e->tile_stats, tile_stats_bytes(K, rounds));
-      if (erc != TAD_OK) return erc;
-      jp.tile_stats = tile_stats_carve(e->tile_stats.p, K, rounds);
-      if (ts_env[0] == '2') { jp.tile_stats.skip_settled = 1; jp.tile_stats.min_samples = jp.min_samples; jp.tile_stats.eps = jp.eps; }
-      return TAD_OK;
-    };
+    const bool stats_done = false;
     if (sparse) {
       // the rank grid is already filled
-    } else if (v2 && part_plan_two_level(K, L.nb, has2, columns_aligned16(d_key, d_key2, d_te, d_val), n * (has2 ? 2 : 1), pl, &pl1, &pl2)) {
-      // many keys: wide level-1 blocks through the write-combining pass B, split again by key sub-range, single-round pass C
-      two_level = true;
-      const uint64_t slots = n * (has2 ? 2 : 1) + pl1.pad_slots;
-      if ((rc = ensure(e, e->part_total, (size_t)pl1.nparts * 4)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->part_start, ((size_t)pl1.nparts + 1) * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->part_offs32, (size_t)pl1.G * pl1.nparts * 4)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->part2_total, (size_t)pl2.nparts * 4)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->part2_start, ((size_t)pl2.nparts + 1) * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->part2_offs32, (size_t)pl2.G * pl2.nparts * 4)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->part2_cursor, (size_t)pl2.nparts * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->recs2, (size_t)slots * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->ovf, 16 + (size_t)kOverflowCap * sizeof(OverflowRec))) != TAD_OK) return rc;
-      unsigned long long *ovf_count = static_cast<unsigned long long *>(e->ovf.p);
-      OverflowRec *ovf = reinterpret_cast<OverflowRec *>(static_cast<unsigned char *>(e->ovf.p) + 16);
-      HIP_TRY(e, hipMemsetAsync(ovf_count, 0, 8, s));
-      if ((rc = ensure_key_buffers(e, K)) != TAD_OK) return rc;
-      if ((rc = ensure_rcp_table(e, L.nb)) != TAD_OK) return rc;
-      uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
-      unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
-      unsigned long long *part_start2 = static_cast<unsigned long long *>(e->part2_start.p);
-      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl1, offs32, static_cast<uint32_t *>(e->part_total.p), part_start);
-      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl2, static_cast<uint32_t *>(e->part2_offs32.p),
-                          static_cast<uint32_t *>(e->part2_total.p), part_start2);
-      HIP_TRY(e, hipEventRecord(e->ev[2], s));
-      launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
-                       (const uint64_t *)d_val, n, K, rf, L, pl1, offs32, part_start, e->recs.p, ovf, ovf_count, kOverflowCap, ctr);
-      HIP_TRY(e, hipEventRecord(e->ev[3], s));
-      if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl1) + slice_table_bytes(slots, pl2))) != TAD_OK) return rc;
-      launch_repartition(s, e->recs.p, part_start, pl1, pl2, slots, e->slices.p, part_start2, static_cast<unsigned long long *>(e->part2_cursor.p), e->recs2.p);
-      if ((rc = want_tile_stats(pl2)) != TAD_OK) return rc;
-      launch_tile_aggregate(s, e->recs2.p, part_start2, pl2, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap, nullptr, nullptr, jp.tile_stats);
-      pl = pl2;
     } else if (v2) {
-      part_plan_wc(hist_sampled ? sampled_slots_bound(n * (has2 ? 2 : 1), pl) : n * (has2 ? 2 : 1), columns_aligned16(d_key, d_key2, d_te, d_val), has2, &pl);
+      part_plan_wc(hist_sampled ? sampled_slots_bound(n * (has2 ? 2 : 1), pl) : n * (has2 ? 2 : 1), columns_aligned16(d_key, d_key2, d_te, d_val), has2, plan.partition_pass, &pl);
       // nparts is only known now: the bound is recomputed with the final plan (part_plan_bins' G, part_plan_tiles' nparts)
       const uint64_t slots = hist_sampled ? sampled_slots_bound(n * (has2 ? 2 : 1), pl) : n * (has2 ? 2 : 1) + pl.pad_slots;
       if (hist_sampled && slots >= (1ull << 32)) { force_exact_hist = true; continue; }
@@ -894,11 +787,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
-      // DBSCAN (opt-in, TAD_DBSCAN_TILESTATS=1; queued for measurement): pass C leaves per-round key statistics, the detector
-      // settles most keys from them instead of reading the grid back (tad_dbscan.hip:k_dbscan_scan)
-      if ((rc = want_tile_stats(pl)) != TAD_OK) return rc;
       launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap,
-                            hist_sampled ? offs32 : nullptr, fin, jp.tile_stats);
+                            hist_sampled ? offs32 : nullptr, fin);
     } else {
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));
@@ -918,7 +808,6 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     ResultPriv *rp = nullptr;
     OutRows dev_rows{};
     ResultBlock dev_block;
-    bool fused_done = false;   // k_ewma_fused has already written the rows into dev_rows
     if (points_mode) {   // every present point: counts = n_pts
       if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
       if ((rc = ensure_rcp_table(e, g.T)) != TAD_OK) return rc;
@@ -948,26 +837,9 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       rows = *e->total_host;
       for (int b = 0; b < kMomentBlocks; ++b) e->moments_host[b] = Moments{0.0, 0.0, 0.0};
     } else {
-      // EWMA, opt-in: everything after Stage 0 in one kernel, the result block sized from this engine's last EWMA job
-      const char *fu_env = getenv("TAD_EWMA_FUSED");
-      uint32_t fcap = 0;
-      uint64_t fout = 0;
-      if (fu_env != nullptr && fu_env[0] == '1' && jp.algo == TAD_ALGO_EWMA && !jp.all_points && !stats_done && g.K != 0) {
-        fout = e->ewma_rows_hint;
-        if (const char *fr = getenv("TAD_EWMA_FUSED_ROWS")) fout = (uint64_t)atoll(fr);   // tests: pin the capacity of the result block
-        if (fout != 0) fcap = ewma_fused_cap(g, e->ewma_rows_last != 0 ? e->ewma_rows_last : fout);
-      }
-      if (fcap != 0) {
-        if ((rc = ewma_fused_run(e, g, L, jp, ctr, out_memory, fcap, fout, &rp, &dev_rows, &dev_block, &rows, &fused_done)) != TAD_OK) return rc;
-      } else if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) {
-        return rc;
-      }
+      if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) return rc;
     }
-    auto drop_fused = [&]() {
-      if (fused_done) { e->free_blocks.push_back({dev_block.base, dev_block.cap}); delete rp; rp = nullptr; fused_done = false; }
-    };
     const DevCounters c = *e->ctr_host;
-    if (c.err != 0) drop_fused();
     if (c.err & DEV_ERR_KEY_RANGE)
       return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
     if (c.err & DEV_ERR_LATE_ROW)
@@ -1052,7 +924,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
       hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
       hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
-      st.stage0_path = sparse ? 4 : (two_level ? 5 : (v2 ? (pl.wc_cap ? 3 : 2) : 1));
+      st.stage0_path = sparse ? 4 : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
       st.stage0_attempts = attempt + 1;
       st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
       e->done.store(4);
@@ -1061,10 +933,6 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     }
 
     // ---- Stage 3: emit ----
-    const bool fused_ran = fused_done;
-    if (fused_done) {
-      if ((rc = finish_result_cap(e, rp, rows, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
-    } else {
     if ((rc = make_result(e, rows, jp.all_points, out_memory, &rp, &dev_rows, &dev_block)) != TAD_OK) return rc;
     if (rows && stream)
       launch_stream(s, g, L, jp.alpha, jp.all_points, true, state_view(stream, stream->cur), state_view(stream, stream->cur ^ 1),
@@ -1080,8 +948,6 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       }
     }
     if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
-    }
-    if (jp.algo == TAD_ALGO_EWMA && !jp.all_points && !stream) { e->ewma_rows_last = rows; e->ewma_rows_hint = rows + rows / 8 + 4096; }
     hipError_t le = hipStreamSynchronize(s);
     if (le == hipSuccess) le = hipGetLastError();
     if (le != hipSuccess) { result_free_locked(e, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
@@ -1094,6 +960,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     st.keys_no_result = c.keys_no_result;
     st.kalman_steps = c.kalman_steps;
     st.arima_fits = c.arima_fits;
+    st.arima_nan_fits = c.arima_nan_fits;
     st.t0 = L.t0; st.step = L.step; st.n_buckets = L.nb;
     {
       double mn = 0.0, mean = 0.0, m2 = 0.0;  // Chan merge of the block partials, fixed order
@@ -1130,10 +997,9 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     hipEventElapsedTime(&st.ms_stage0, e->ev[1], e->ev[5]);
     hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
     hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
-    st.stage0_path = sparse ? 4 : (two_level ? 5 : (v2 ? (pl.wc_cap ? 3 : 2) : 1));
+    st.stage0_path = sparse ? 4 : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
     st.stage0_attempts = attempt + 1;
     st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
-    st.detect_path = fused_ran ? 1 : 0;
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)

@@ -8,8 +8,9 @@
 // are exact.
 //
 // Two kernels: k_dbscan_scan (one lane per key, one coalesced walk over the time-major grid) settles every key whose
-// values all lie within eps of each other and lists the rest; k_dbscan_list runs the exact pair tests for the listed
-// keys (a workgroup per key, points compacted into LDS, lanes = points i, LDS-broadcast x_j stream).
+// values all lie within eps of each other and lists the rest; the exact pair tests for the listed keys run with one
+// wavefront per key (k_dbscan_list_wave, series of up to 256 buckets held in registers) or one workgroup per key
+// (k_dbscan_list: points compacted into LDS, lanes = points i, LDS-broadcast x_j stream) for longer series.
 #include <cstdlib>
 
 #include "tad_internal.h"
@@ -31,85 +32,32 @@ __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63; }
 // (M2 from sums shifted by the key's first value; only the exact stddev_samp column of emitted rows follows Spark's
 // streaming order, k_emit<4>).
 // ------------------------------------------------------------------------------------------------
-// ts (optional, TAD_DBSCAN_TILESTATS=1): pass C left count / min / max / (mean, M2) per (bucket round, key); a key whose
-// partials are all usable is settled from them — 36 B per round instead of its column of the grid — with the rounds'
-// moments merged in round order (Chan et al.); the others are walked as before.
-template <bool TS>
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, int min_samples, DbscanStats st,
-                                                         uint32_t *__restrict__ list, unsigned int *__restrict__ count, TileStats ts) {
+                                                         uint32_t *__restrict__ list, unsigned int *__restrict__ count) {
   const uint64_t k = (uint64_t)blockIdx.x * kDbBlock + threadIdx.x;
   bool slow = false;
-  if constexpr (!TS) {   // the default path, kept as measured (tools/isa_diff.py)
-    if (k < g.K) {
-      uint32_t n = 0;
-      double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
-      walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
-        if (fl & FLAG_PRESENT) {
-          const double x = (double)raw;
-          if (n == 0) { mn = x; mx = x; x0 = x; }
-          mn = fmin(mn, x);
-          mx = fmax(mx, x);
-          const double d = x - x0;
-          s1 += d;
-          s2 += d * d;
-          n++;
-        }
-      });
-      slow = n > 0 && (!(mx - mn <= eps) || n < (uint32_t)min_samples);
-      if (st.n_pts != nullptr) {
-        st.n_pts[k] = n;
-        st.n_anom[k] = 0;
-        const double dn = (double)(n ? n : 1);
-        st.key_mean[k] = n ? x0 + s1 / dn : 0.0;
-        st.key_m2[k] = n ? fmax(s2 - s1 * (s1 / dn), 0.0) : 0.0;
-      }
-    }
-  } else if (k < g.K) {
+  if (k < g.K) {
     uint32_t n = 0;
-    double mn = 0.0, mx = 0.0, mean = 0.0, m2 = 0.0;
-    bool walk = ts.rounds == 0;
-    if (!walk) {
-      Moments acc{0.0, 0.0, 0.0};
-      for (uint32_t r = 0; r < ts.rounds; ++r) {
-        const size_t o = (size_t)r * g.K + k;
-        const uint32_t nr = ts.n[o];
-        if (nr == kTileStatsRedo) { walk = true; break; }
-        if (nr == 0) continue;
-        const double a = ts.mn[o], b = ts.mx[o];
-        if (n == 0) { mn = a; mx = b; }
-        mn = fmin(mn, a);
-        mx = fmax(mx, b);
-        acc = chan_merge(acc, Moments{(double)nr, ts.mean[o], ts.m2[o]});
-        n += nr;
+    double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
+    walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
+      if (fl & FLAG_PRESENT) {
+        const double x = (double)raw;
+        if (n == 0) { mn = x; mx = x; x0 = x; }
+        mn = fmin(mn, x);
+        mx = fmax(mx, x);
+        const double d = x - x0;
+        s1 += d;
+        s2 += d * d;
+        n++;
       }
-      mean = acc.mean;
-      m2 = acc.m2;
-    }
-    if (walk) {
-      n = 0;
-      double x0 = 0.0, s1 = 0.0, s2 = 0.0;
-      walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
-        if (fl & FLAG_PRESENT) {
-          const double x = (double)raw;
-          if (n == 0) { mn = x; mx = x; x0 = x; }
-          mn = fmin(mn, x);
-          mx = fmax(mx, x);
-          const double d = x - x0;
-          s1 += d;
-          s2 += d * d;
-          n++;
-        }
-      });
-      const double dn = (double)(n ? n : 1);
-      mean = n ? x0 + s1 / dn : 0.0;
-      m2 = n ? fmax(s2 - s1 * (s1 / dn), 0.0) : 0.0;
-    }
+    });
     slow = n > 0 && (!(mx - mn <= eps) || n < (uint32_t)min_samples);
     if (st.n_pts != nullptr) {
       st.n_pts[k] = n;
       st.n_anom[k] = 0;
-      st.key_mean[k] = n ? mean : 0.0;
-      st.key_m2[k] = n ? m2 : 0.0;
+      const double dn = (double)(n ? n : 1);
+      st.key_mean[k] = n ? x0 + s1 / dn : 0.0;
+      st.key_m2[k] = n ? fmax(s2 - s1 * (s1 / dn), 0.0) : 0.0;
     }
   }
   const unsigned long long m = __ballot(slow);
@@ -188,8 +136,8 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list(Grid g, double eps, in
   }
 }
 
-// k_dbscan_list_wave (opt-in, TAD_DBSCAN_WAVELIST=1; queued for measurement) — the same predicate with ONE WAVEFRONT per
-// listed key and no LDS, no workgroup barrier: lane l holds the key's buckets l, l + 64, ... (PPL of them: T <= 64 * PPL);
+// k_dbscan_list_wave (series of up to 256 buckets; round 3: C4 detect + emit 0.48 -> 0.41 ms against k_dbscan_list) — the same
+// predicate with ONE WAVEFRONT per listed key and no LDS, no workgroup barrier: lane l holds the key's buckets l, l + 64, ... (PPL of them: T <= 64 * PPL);
 // x_j reaches all lanes by a readlane with a wavefront-uniform index, absent buckets are skipped through the ballot masks.
 // k_dbscan_list spends a workgroup and ~8 barriers on a key of ~100 points (C4: ~7 listed keys per workgroup, 97 us);
 // here four keys are in flight per workgroup and nothing waits for anything.
@@ -247,7 +195,7 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
   }
 }
 
-// k_emit_dbscan_wave (opt-in with TAD_DBSCAN_WAVELIST=1; queued for measurement) — the DBSCAN job's emit from the detector's
+// k_emit_dbscan_wave — the DBSCAN job's emit from the detector's
 // WORK LIST instead of a walk over all keys: only listed keys can have noise points, and there are few of them (C4: 1.8 % of
 // the keys, 14 488 rows).  One wavefront per listed key, lane l holds the buckets l, l + 64, ...: one load round instead of a
 // T-step walk with one or two useful lanes per wavefront (k_emit<4>, 0.11 ms at C4); stddev_samp in Spark's streaming order
@@ -371,17 +319,15 @@ size_t dbscan_scratch_bytes(Grid g) {
 
 bool dbscan_uses_list(Grid g) { return list_fits_lds(g.T); }
 
-int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch, DbscanStats st, TileStats ts) {
+int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch, DbscanStats st) {
   if (g.K == 0 || g.T == 0) return 0;
   if (!list_fits_lds(g.T)) return -1;
   unsigned int *count = static_cast<unsigned int *>(scratch);
   uint32_t *list = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + 64);
   hipMemsetAsync(count, 0, sizeof(unsigned int), s);
-  if (ts.rounds != 0) hipLaunchKernelGGL(k_dbscan_scan<true>, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, ts);
-  else hipLaunchKernelGGL(k_dbscan_scan<false>, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, ts);
+  hipLaunchKernelGGL(k_dbscan_scan, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
   uint64_t blocks = g.K < 2048 ? g.K : 2048;   // grid-stride over the (device-side) list length
-  const char *wl_env = getenv("TAD_DBSCAN_WAVELIST");
-  if (wl_env != nullptr && wl_env[0] == '1' && g.T <= 256) {
+  if (g.T <= 256) {   // a wavefront's registers hold the whole series
 #define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom)
     if (g.T <= 64) TAD_DBW(1); else if (g.T <= 128) TAD_DBW(2); else if (g.T <= 192) TAD_DBW(3); else TAD_DBW(4);
 #undef TAD_DBW
@@ -396,8 +342,7 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
 // the DBSCAN job's emit from the work list launch_dbscan left in `scratch` (false: shape not supported, use launch_emit kind 4)
 bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scratch, const uint32_t *n_anom, const unsigned long long *off,
                              OutRows out) {
-  const char *wl_env = getenv("TAD_DBSCAN_WAVELIST");
-  if (!(wl_env != nullptr && wl_env[0] == '1') || g.K == 0 || g.T == 0 || g.T > 256 || !list_fits_lds(g.T)) return false;
+  if (g.K == 0 || g.T == 0 || g.T > 256 || !list_fits_lds(g.T)) return false;
   const unsigned int *count = static_cast<const unsigned int *>(scratch);
   const uint32_t *list = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(scratch) + 64);
   const uint64_t blocks = g.K < 2048 ? g.K : 2048;

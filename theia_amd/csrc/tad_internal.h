@@ -49,6 +49,7 @@ struct DevCounters {
   unsigned long long keys_no_result;
   unsigned long long kalman_steps;
   unsigned long long arima_fits;
+  unsigned long long arima_nan_fits;   // fits whose prediction is not finite (the optimiser walked into a non-finite likelihood)
   uint32_t err;
   uint32_t pad;
 };
@@ -169,13 +170,8 @@ size_t scan_scratch_elems(uint64_t K);
 // 4 = 2 with the stddev column computed here (Spark's streaming update over the key's series) for the keys that have rows
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
-                 const unsigned long long *off, OutRows out, uint64_t rows_hint = 0);   // rows_hint: off[K] if the caller knows it
-// EWMA job, Stage 1 + 2 + 3 in one kernel (k_ewma_fused, opt-in).  cap = ewma_fused_cap(g, rows_hint) (0: shape not supported);
-// ctl = ewma_fused_ctl_bytes(K) bytes; afterwards the 8-byte word ctl[1] holds the row total; rows >= out_cap are not written.
-size_t ewma_fused_ctl_bytes(uint64_t K);
-uint32_t ewma_fused_cap(Grid g, uint64_t rows_hint);
-void launch_ewma_fused(hipStream_t s, Grid g, Lattice lat, double alpha, const double *rcp, double *sigma, uint32_t *n_pts, uint32_t *n_anom,
-                       DevCounters *ctr, double *key_mean, double *key_m2, void *ctl, OutRows out, uint64_t out_cap, uint32_t cap);
+                 const unsigned long long *off, OutRows out, uint64_t rows_hint = 0,   // rows_hint: off[K] if the caller knows it
+                 int ewma_emit = 0, uint32_t ewma_emit_rows = 0);   // tad_plan: 1 = lane-per-key k_emit for the EWMA job; LDS rows per wavefront of the staged emit
 void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long long *off, unsigned long long *out_key,
                         long long *out_t, unsigned long long *out_val);
 // streaming EWMA: per-key running state (tad_state); k_stream continues the recurrences over the new grid
@@ -195,31 +191,6 @@ void launch_ewma_values(hipStream_t s, Grid g, double alpha, double *calc);
 // DBSCAN: sets FLAG_ANOMALY on noise points.  scratch = dbscan_scratch_bytes(g) bytes of device memory.
 // dbscan_uses_list: the series fit an LDS row -> launch_dbscan (scan + work list); otherwise launch_dbscan_long.
 // st (all pointers NULL = not wanted): per-key point / anomaly counts and (mean, M2) moments
-// Per-(bucket round, key) partial statistics pass C can leave for the DBSCAN detector (TAD_DBSCAN_TILESTATS=1): arrays of
-// [rounds][K]; n == kTileStatsRedo: the partials of this key are not usable (split partition, overflow record) -> the
-// detector walks the grid for it.  rounds == 0: not in use.
-struct TileStats {
-  uint32_t *n;
-  double *mn, *mx, *mean, *m2;
-  uint32_t rounds;
-  // TAD_DBSCAN_TILESTATS=2: with ONE bucket round per partition the tile holds every key's whole series, so pass C can see that
-  // a key is settled (no points, or >= min_samples points within eps of each other: no noise) and then does not write its
-  // column of the grid at all — nothing reads it (the detector takes the statistics, emit only visits keys with rows)
-  uint32_t skip_settled;
-  int32_t min_samples;
-  double eps;
-  // ... and for partitions that need several LDS tiles the rounds then split the partition by KEY sub-range (2^ks_shift keys
-  // x all buckets per tile) instead of by bucket range, so that every tile still holds whole series (0: bucket rounds)
-  uint32_t ks_shift;
-};
-static constexpr uint32_t kTileStatsRedo = 0xFFFFFFFFu;
-inline size_t tile_stats_bytes(uint64_t K, uint32_t rounds) { return (size_t)K * rounds * 36 + 64; }
-inline TileStats tile_stats_carve(void *mem, uint64_t K, uint32_t rounds) {
-  double *d = static_cast<double *>(mem);
-  const size_t c = (size_t)K * rounds;
-  return TileStats{reinterpret_cast<uint32_t *>(d + 4 * c), d, d + c, d + 2 * c, d + 3 * c, rounds};
-}
-
 struct DbscanStats {
   uint32_t *n_pts, *n_anom;
   double *key_mean, *key_m2;
@@ -227,11 +198,10 @@ struct DbscanStats {
 size_t dbscan_scratch_bytes(Grid g);
 bool dbscan_uses_list(Grid g);
 int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch,
-                  DbscanStats st = DbscanStats{nullptr, nullptr, nullptr, nullptr},
-                  TileStats ts = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
+                  DbscanStats st = DbscanStats{nullptr, nullptr, nullptr, nullptr});
 int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch);
 // DBSCAN job (statistics from the scan, sigma computed at emit): the rows from the work list launch_dbscan left in `scratch`,
-// one wavefront per listed key (opt-in with TAD_DBSCAN_WAVELIST=1).  false: not applicable -> launch_emit(kind 4)
+// one wavefront per listed key.  false: not applicable (series longer than a wavefront's registers hold) -> launch_emit(kind 4)
 bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scratch, const uint32_t *n_anom, const unsigned long long *off,
                              OutRows out);
 
@@ -260,21 +230,16 @@ struct PartPlan {
   int rpt;             // rows per thread per tile in pass B
   int cell_bits;       // record = value << cell_bits | partition-local cell
   uint32_t tb, n_chunks;  // pass C: buckets per LDS round, rounds per partition
-  uint32_t ks_shift;      // pass C, key rounds (TileStats::ks_shift): 2^ks_shift keys x all buckets per round; 0 = bucket rounds
   uint32_t wc_cap;        // write-combining pass B: queue slots per partition (0 = use the sort-by-tile pass B)
   uint32_t wc_sec, wc_rpt;  // wc: records per emitted piece (8 or 16), rows per thread per tile (2 or 4)
   uint64_t pad_slots;     // wc: upper bound of the filler slots (regions rounded up to whole 64-byte sectors)
 };
 // decide whether pass B runs as the write-combining variant (sets wc_cap / pad_slots; needs 16-byte aligned columns)
-void part_plan_wc(uint64_t slots, bool aligned, bool has2, PartPlan *pl);
+// partition_pass: tad_plan.partition_pass (0 = decide from the shape, 1 = sort-by-tile, 2 = write-combining whenever it fits)
+void part_plan_wc(uint64_t slots, bool aligned, bool has2, int partition_pass, PartPlan *pl);
 bool columns_aligned16(const void *key, const void *key2, const void *t_end, const void *value);
 bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl);
 bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
-// rounds by key sub-range instead of bucket range, if the tiles allow it (no-op for single-round plans); true = changed
-bool part_plan_key_rounds(uint64_t T, PartPlan *pl);
-bool part_plan_two_level(uint64_t K, uint64_t T, bool has2, bool aligned, uint64_t slots, const PartPlan &base, PartPlan *l1, PartPlan *l2);
-void launch_repartition(hipStream_t s, const void *recs1, const unsigned long long *part_start1, const PartPlan &l1, const PartPlan &l2,
-                        uint64_t slots, void *slice_mem, const unsigned long long *part_start2, unsigned long long *cursor2, void *recs2);
 // sample_hist: histogram only the rows whose time is sampled too (one iteration in eight + the chunk ends): pass A then
 // reads 1/8 of the key column; the regions of pass B are SIZED from the estimate (launch_part_offsets) instead of counted.
 // Returns whether the histogram is sampled (only without a time-window filter and with 16-byte aligned columns).
@@ -299,7 +264,7 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl);
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
                            const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32 = nullptr,
-                           const uint32_t *fin = nullptr, TileStats ts = TileStats{nullptr, nullptr, nullptr, nullptr, nullptr, 0});
+                           const uint32_t *fin = nullptr);
 
 // ---- Stage 0 for sparse tables: sort by (key, time), reduce, rank grid (tad_sparse.hip) ----
 size_t sparse_sort_temp_bytes(uint64_t slots);

@@ -641,236 +641,17 @@ __global__ __launch_bounds__(64) void k_emit_staged(Grid g, Lattice L, double al
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_ewma_fused — the EWMA job's Stage 1 + 2 + 3 in ONE kernel (opt-in, TAD_EWMA_FUSED=1; written without GPU time, queued for
-// measurement): stddev_samp walk, EWMA walk, compaction and the coalesced row stores of k_emit_staged, with no count pass, no
-// scan kernels, no host round trip for the row total and two walks over the grid instead of three.
-//   * one wavefront = 64 consecutive keys (a ticket taken at the start orders the wavefronts by the time they begin, so a
-//     wavefront only ever waits for wavefronts that are already running);
-//   * sigma walk: exactly k_key_sigma's arithmetic (reciprocal table in LDS — the same bytes later hold staged rows);
-//   * EWMA walk: an anomalous point is parked in LDS in ARRIVAL order (slot = running count of the wavefront + rank among the
-//     lanes that fire at this time step: one ballot, no atomics) as (e_t, lane, t, rank within its key);
-//   * the per-key counts are scanned across the lanes, a 2-byte permutation row -> slot is built in LDS, and the base of
-//     the wavefront's row range comes from a decoupled look-back over the status words of the preceding wavefronts
-//     (flag << 62 | rows: 1 = this wavefront's rows, 2 = rows of all wavefronts up to and including it);
-//   * the rows are written as in k_emit_staged: five coalesced stores per 64 rows, throughput re-read from the grid.
-// Rows that do not fit the LDS capacity (slot or position >= cap) are written by a repeat of the EWMA walk with direct stores;
-// rows past the capacity of the result block are counted but not written (the host then redoes the emit the classic way).
-// ------------------------------------------------------------------------------------------------
-static constexpr unsigned long long kFusedFlagShift = 62, kFusedValMask = (1ull << 62) - 1;
-
-__device__ __forceinline__ unsigned long long fused_load(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(64) void k_ewma_fused(Grid g, Lattice L, double alpha, const double *__restrict__ rcp_g, double *__restrict__ sigma,
-                                                   uint32_t *__restrict__ n_pts, uint32_t *__restrict__ n_anom, DevCounters *ctr,
-                                                   double *__restrict__ key_mean, double *__restrict__ key_m2, unsigned int *ticket,
-                                                   unsigned long long *status, unsigned long long *total_out, OutRows out,
-                                                   unsigned long long out_cap, uint32_t cap) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_fused[];
-  double *s_e = reinterpret_cast<double *>(smem_fused);                       // [cap]; the first T + 1 doubles are the reciprocal table first
-  double *s_sg = s_e + cap;                                                   // [64]
-  uint32_t *s_m = reinterpret_cast<uint32_t *>(s_sg + 64);                    // [cap]  lane << 26 | t
-  uint32_t *s_pre = s_m + cap;                                                // [64]   rows of the lower lanes
-  uint16_t *s_r = reinterpret_cast<uint16_t *>(s_pre + 64);                   // [cap]  rank of the row within its key
-  uint16_t *s_perm = s_r + cap;                                               // [cap]  row position -> slot
-  const uint32_t lane = threadIdx.x;
-  unsigned int wid = 0;
-  if (lane == 0) wid = atomicAdd(ticket, 1u);
-  wid = __shfl(wid, 0);
-  const uint64_t k0 = (uint64_t)wid * 64;
-  const bool live = k0 + lane < g.K;
-  const uint64_t k = live ? k0 + lane : g.K - 1;   // dead lanes walk the last key (valid memory), their results are dropped
-  for (uint64_t i = lane; i <= g.T; i += 64) s_e[i] = rcp_g[i];
-  __syncthreads();
-  // ---- Stage 1: stddev_samp, Spark's streaming update (k_key_sigma) ----
-  double cnt = 0.0, avg = 0.0, m2 = 0.0;
-  uint32_t n = 0;
-  walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
-    if (fl & FLAG_PRESENT) {
-      const double x = (double)raw;
-      cnt = cnt + 1.0;
-      n++;
-      const double d = x - avg;
-      const double dn = div_by_count(d, cnt, s_e[n]);
-      avg = avg + dn;
-      m2 = m2 + d * (d - dn);
-    }
-  });
-  const bool has_sigma = live && n >= 2;
-  const double sg = has_sigma ? sqrt(m2 / (cnt - 1.0)) : 0.0;
-  if (live) {
-    sigma[k] = sg;
-    n_pts[k] = n;
-    if (key_mean != nullptr) { key_mean[k] = avg; key_m2[k] = m2; }
-  }
-  {
-    unsigned long long my_pts = live ? n : 0;
-    unsigned my_key = live && n > 0;
-    for (int d = 32; d >= 1; d >>= 1) { my_pts += __shfl_down(my_pts, d); my_key += __shfl_down(my_key, d); }
-    if (lane == 0 && my_key) {
-      atomicAdd(&ctr->n_points, my_pts);
-      atomicAdd(&ctr->n_keys, (unsigned long long)my_key);
-    }
-  }
-  __syncthreads();   // the reciprocal table is dead: its bytes become staging space
-  s_sg[lane] = sg;
-  // ---- Stage 2: EWMA, anomalous points parked in arrival order ----
-  const double one_minus = 1.0 - alpha;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  uint32_t a = 0, wave_rows = 0;
-  {
-    double e = 0.0;
-    walk_series(g, k, [&](uint64_t t, uint8_t fl, unsigned long long raw) {
-      bool anom = false;
-      if (fl & FLAG_PRESENT) {
-        const double x = (double)raw;
-        e = one_minus * e + alpha * x;
-        anom = has_sigma && fabs(x - e) > sg;
-      }
-      const unsigned long long fire = __ballot(anom);
-      if (fire != 0) {   // wavefront-uniform
-        if (anom) {
-          const uint32_t slot = wave_rows + (uint32_t)__popcll(fire & lt_mask);
-          if (slot < cap) {
-            s_e[slot] = e;
-            s_m[slot] = (lane << kStageMarkTBits) | (uint32_t)t;
-            s_r[slot] = (uint16_t)a;
-          }
-          a++;
-        }
-        wave_rows += (uint32_t)__popcll(fire);
-      }
-    });
-  }
-  if (live) n_anom[k] = a;
-  // rows of the lower lanes, rows of the wavefront
-  uint32_t incl = a;
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(incl, d);
-    if ((int)lane >= d) incl += o;
-  }
-  const uint32_t pre = incl - a;
-  const uint32_t total = __shfl(incl, 63);
-  s_pre[lane] = pre;
-  const uint32_t lim = total < cap ? total : cap;   // row positions and slots below lim go through LDS
-  for (uint32_t r = lane; r < lim; r += 64) s_perm[r] = 0xFFFFu;
-  __syncthreads();
-  for (uint32_t j = lane; j < lim; j += 64) {
-    const uint32_t pos = s_pre[s_m[j] >> kStageMarkTBits] + s_r[j];
-    if (pos < cap) s_perm[pos] = (uint16_t)j;
-  }
-  // ---- base of this wavefront's row range: decoupled look-back ----
-  unsigned long long base = 0;
-  if (lane == 0) __hip_atomic_store(&status[wid], ((wid == 0 ? 2ull : 1ull) << kFusedFlagShift) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (wid != 0) {
-    long long look = (long long)wid - 1;   // wavefront-uniform
-    for (;;) {
-      const long long idx = look - (long long)lane;
-      unsigned long long w = idx >= 0 ? fused_load(&status[idx]) : (2ull << kFusedFlagShift);   // before the first wavefront: inclusive 0
-      while (__any((w >> kFusedFlagShift) == 0)) {
-        if ((w >> kFusedFlagShift) == 0) w = fused_load(&status[idx]);
-      }
-      const unsigned long long incl_mask = __ballot((w >> kFusedFlagShift) == 2);
-      const int stop = incl_mask != 0 ? __ffsll((long long)incl_mask) - 1 : 63;   // nearest wavefront that knows its inclusive total
-      unsigned long long v = (int)lane <= stop ? (w & kFusedValMask) : 0ull;
-      for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
-      base += __shfl(v, 0);
-      if (incl_mask != 0) break;
-      look -= 64;
-    }
-    if (lane == 0) __hip_atomic_store(&status[wid], (2ull << kFusedFlagShift) | (base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (lane == 0 && k0 + 64 >= g.K) *total_out = base + total;   // the last wavefront: rows of the job
-  __syncthreads();
-  // ---- Stage 3: coalesced row stores ----
-  for (uint32_t r = lane; r < lim; r += 64) {
-    const uint32_t j = s_perm[r];
-    const unsigned long long at = base + r;
-    if (j == 0xFFFFu || at >= out_cap) continue;
-    const uint32_t m = s_m[j];
-    const uint32_t ln = m >> kStageMarkTBits;
-    const uint64_t t = m & ((1u << kStageMarkTBits) - 1u);
-    const uint64_t cell = t * g.K + (k0 + ln);
-    out.key_id[at] = k0 + ln;
-    out.flow_end_s[at] = g.times != nullptr ? g.times[cell] : (long long)(L.t0 + (int64_t)t * L.step);
-    out.throughput[at] = (double)g.val[cell];
-    out.algo_calc[at] = s_e[j];
-    out.stddev[at] = s_sg[ln];
-  }
-  if (total > cap) {   // wavefront-uniform: the rows LDS had no room for, by a repeat of the walk
-    double e = 0.0;
-    uint32_t a2 = 0, rows2 = 0;
-    walk_series(g, k, [&](uint64_t t, uint8_t fl, unsigned long long raw) {
-      bool anom = false;
-      double x = 0.0;
-      if (fl & FLAG_PRESENT) {
-        x = (double)raw;
-        e = one_minus * e + alpha * x;
-        anom = has_sigma && fabs(x - e) > sg;
-      }
-      const unsigned long long fire = __ballot(anom);
-      if (fire != 0) {
-        if (anom) {
-          const uint32_t slot = rows2 + (uint32_t)__popcll(fire & lt_mask), pos = pre + a2;
-          const unsigned long long at = base + pos;
-          if ((slot >= cap || pos >= cap) && at < out_cap) {
-            out.key_id[at] = k;
-            out.flow_end_s[at] = g.times != nullptr ? g.times[t * g.K + k] : (long long)(L.t0 + (int64_t)t * L.step);
-            out.throughput[at] = x;
-            out.algo_calc[at] = e;
-            out.stddev[at] = sg;
-          }
-          a2++;
-        }
-        rows2 += (uint32_t)__popcll(fire);
-      }
-    });
-  }
-}
-
-size_t ewma_fused_ctl_bytes(uint64_t K) { return 64 + (size_t)((K + 63) / 64) * 8; }
-
-// cap rows of LDS staging per wavefront; 0: the shape does not fit the fused kernel (use the separate kernels)
-uint32_t ewma_fused_cap(Grid g, uint64_t rows_hint) {
-  if (g.K == 0 || g.T >= 65535 || (g.T + 1) * 8 > 32768) return 0;
-  uint64_t cap = 1376;   // 16 B per row + 768 B: 22.8 KB, seven wavefronts per CU (C2: mean 1292 rows per wavefront)
-  if (rows_hint != 0) {
-    const uint64_t mean = (rows_hint * 64 + g.K - 1) / g.K;
-    cap = mean + mean / 16 + 8;
-  }
-  if (const char *c = getenv("TAD_EMIT_CAP")) cap = (uint64_t)atol(c);
-  if (cap < g.T + 1) cap = g.T + 1;   // the reciprocal table lives in the same bytes
-  cap = (cap + 7) & ~7ull;
-  if (cap > 8192) cap = 8192;
-  if (cap < g.T + 1) return 0;
-  return (uint32_t)cap;
-}
-
-// ctl: ewma_fused_ctl_bytes(K) bytes of device memory (zeroed here); on return ctl[1] (8-byte words) will hold the row total
-void launch_ewma_fused(hipStream_t s, Grid g, Lattice lat, double alpha, const double *rcp, double *sigma, uint32_t *n_pts, uint32_t *n_anom,
-                       DevCounters *ctr, double *key_mean, double *key_m2, void *ctl, OutRows out, uint64_t out_cap, uint32_t cap) {
-  hipMemsetAsync(ctl, 0, ewma_fused_ctl_bytes(g.K), s);
-  unsigned long long *w = static_cast<unsigned long long *>(ctl);
-  const size_t lds = (size_t)cap * 16 + 64 * 8 + 64 * 4;
-  allow_big_lds(reinterpret_cast<const void *>(k_ewma_fused), lds);
-  hipLaunchKernelGGL(k_ewma_fused, dim3((unsigned)((g.K + 63) / 64)), dim3(64), lds, s, g, lat, alpha, rcp, sigma, n_pts, n_anom, ctr, key_mean,
-                     key_m2, reinterpret_cast<unsigned int *>(w), w + 8, w + 1, out, (unsigned long long)out_cap, cap);
-}
-
 // LDS rows per wavefront.  The mean row count of a 64-key range plus 1/8 plus 128 rows (C2: 1290 -> 1600 rows, 19.3 KB:
 // eight wavefronts per CU, so that its 1563 wavefronts are resident together; 2048 rows = six per CU put 27 of them into a
-// second round: 254 vs 223 us for detect + emit).  TAD_EMIT_STAGED=0 -> k_emit; TAD_EMIT_CAP=<rows> pins the capacity (tests).
-static uint32_t emit_stage_rows(uint64_t K, uint64_t rows_hint) {
-  const char *on = getenv("TAD_EMIT_STAGED");
-  if (on != nullptr && on[0] == '0') return 0;
+// second round: 254 vs 223 us for detect + emit).  tad_plan: ewma_emit = 1 -> k_emit; ewma_emit_rows pins the capacity (tests).
+static uint32_t emit_stage_rows(uint64_t K, uint64_t rows_hint, int ewma_emit, uint32_t ewma_emit_rows) {
+  if (ewma_emit == 1) return 0;
   uint64_t cap = 1536;
   if (rows_hint != 0) {
     const uint64_t mean = (rows_hint * 64 + K - 1) / K;
     cap = mean + mean / 8 + 128;
   }
-  if (const char *c = getenv("TAD_EMIT_CAP")) cap = (uint64_t)atol(c);
+  if (ewma_emit_rows != 0) cap = ewma_emit_rows;
   cap = (cap + 63) & ~63ull;
   if (cap < 64) cap = 64;
   if (cap > 4096) cap = 4096;
@@ -879,10 +660,10 @@ static uint32_t emit_stage_rows(uint64_t K, uint64_t rows_hint) {
 
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
-                 const unsigned long long *off, OutRows out, uint64_t rows_hint) {
+                 const unsigned long long *off, OutRows out, uint64_t rows_hint, int ewma_emit, uint32_t ewma_emit_rows) {
   if (g.K == 0) return;
   if (kind == 0 && !all_points && g.T < (1ull << kStageMarkTBits)) {
-    if (const uint32_t cap = emit_stage_rows(g.K, rows_hint)) {
+    if (const uint32_t cap = emit_stage_rows(g.K, rows_hint, ewma_emit, ewma_emit_rows)) {
       const unsigned blocks64 = (unsigned)((g.K + 63) / 64);
       hipLaunchKernelGGL(k_emit_staged, dim3(blocks64), dim3(64), (size_t)cap * 12 + 64 * 8, s, g, lat, alpha, sigma, n_pts, off, out, cap);
       return;

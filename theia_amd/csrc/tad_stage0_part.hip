@@ -163,9 +163,7 @@ __device__ __forceinline__ void hist_row(MetaAcc &a, uint32_t *hist, uint64_t k1
   }
 }
 
-// (PF, TS, ... : the queued experiments are template parameters, not runtime branches, so that the instantiations the
-// default path launches stay instruction-for-instruction what was measured — tools/isa_diff.py checks that)
-template <bool VEC, bool HAS2, bool SAMPLE_H, bool PF = false>
+template <bool VEC, bool HAS2, bool SAMPLE_H>
 __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__restrict__ key,
                                                             const uint64_t *__restrict__ key2,
                                                             const int64_t *__restrict__ t_end,
@@ -196,45 +194,6 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
     const bool sample_t = f.end_time == 0 && !has_ts;
     uint64_t i = threadIdx.x;
     uint32_t it = 0;
-    if (SAMPLE_H && PF) {
-      // Sampled histogram, software-pipelined (TAD_META_PREFETCH=1; queued for measurement): a workgroup reads one iteration in
-      // eight, so the loop below is a chain of dependent load -> histogram round trips (~8 per workgroup at C2).  Here the
-      // loads of the NEXT sampled iteration are issued before the current one is histogrammed.  Same rows, same counts.
-      constexpr uint64_t step = (uint64_t)U * kPartThreads;
-      auto full = [&](uint64_t ii) { return ii + (U - 1) * kPartThreads < npair; };
-      auto sampled = [&](uint64_t ii, uint32_t iit) { return (iit & 7) == 0 || (ii - threadIdx.x) + 2 * U * kPartThreads >= npair; };
-      struct Regs { ulonglong2 k[U], k2[U]; longlong2 t[U]; };
-      auto load = [&](Regs &r, uint64_t ii) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          r.k[u] = kv[ii + u * kPartThreads];
-          r.k2[u] = HAS2 ? k2v[ii + u * kPartThreads] : make_ulonglong2(TAD_KEY_SKIP, TAD_KEY_SKIP);
-          r.t[u] = tv[ii + u * kPartThreads];
-        }
-      };
-      while (full(i) && !sampled(i, it)) { i += step; ++it; }
-      if (full(i)) {
-        Regs cur, nxt;
-        load(cur, i);
-        for (;;) {
-          uint64_t j = i + step;
-          uint32_t jt = it + 1;
-          while (full(j) && !sampled(j, jt)) { j += step; ++jt; }
-          const bool more = full(j);
-          if (more) load(nxt, j);
-          seen += 2 * U;
-#pragma unroll
-          for (int u = 0; u < U; ++u) {   // (no time-window filter in this mode: every row is kept)
-            meta_row(acc, hist, cur.k[u].x, cur.k2[u].x, cur.t[u].x, true, K, shift_bin);
-            meta_row(acc, hist, cur.k[u].y, cur.k2[u].y, cur.t[u].y, true, K, shift_bin);
-          }
-          i = j;
-          it = jt;
-          if (!more) break;
-          cur = nxt;
-        }
-      }
-    }
     for (; i + (U - 1) * kPartThreads < npair; i += U * kPartThreads, ++it) {
       const bool with_t = !sample_t || (it & 7) == 0 || (i - threadIdx.x) + 2 * U * kPartThreads >= npair;  // workgroup-uniform
       if (SAMPLE_H && !with_t) continue;   // sampled histogram: the unsampled iterations are not read at all
@@ -675,7 +634,6 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
 // LDS: q[F * cap] u64 | cnt[F] | gcur[F] | gend[F] u32 | jobs[F] u16.  Tiles are small (RPT rows per thread, 2 * RPT
 // with a second key), two register sets alternate so that every load has more than a tile to land.
 // ------------------------------------------------------------------------------------------------
-static constexpr bool kWcDefault = true;   // measured: k_partition 0.99 -> 0.71 ms at C2, same box (TAD_PARTB=sort selects the old pass)
 
 // SEC = records per emitted piece: 8 (one 64-byte sector) when LDS leaves only 9..12 queue slots per partition, 16 (one
 // whole 128-byte line — streaming speed in the micro-benchmark) when there are few enough partitions for >= 22 slots.
@@ -941,12 +899,11 @@ struct TileGeom {
   uint32_t slice_len;   // record slots per slice (kSliceRecords; twice that when the regions carry the slack of a sampled histogram)
 };
 
-template <bool OPMAX, bool TS = false, bool KR = false>
+template <bool OPMAX>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
                                                                  SliceTable st, TileGeom tg, Grid g, int phase,
-                                                                 const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G,
-                                                                 TileStats ts, const unsigned long long *__restrict__ ovf_count_in) {
+                                                                 const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G) {
   // Rounds as workgroups: a partition whose KP x T block needs R > 1 LDS tiles is read by R workgroups, one per bucket
   // round, instead of R times by one.  The R workgroups of a slice get block ids x + 8 * (R * j + r): the same XCD
   // (blocks are dealt round-robin over the 8 XCDs) and adjacent in dispatch order, so they stream the same records at
@@ -982,29 +939,20 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
   const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * tg.slice_len;
   const unsigned long long hi = lo + tg.slice_len < phi ? lo + tg.slice_len : phi;
   for (uint32_t chunk = r_lo; chunk < r_hi; ++chunk) {
-    // KR (key rounds, with TS only): round `chunk` holds the keys [chunk << ks, (chunk + 1) << ks) of the partition with ALL their
-    // buckets — tile cell = bucket << ks | key within the sub-range — instead of all keys with the buckets [b_lo, b_lo + nb)
-    const int tile_shift = KR ? (int)ts.ks_shift : shift_part;   // log2 of the keys per tile row
-    const uint32_t KT = 1u << tile_shift;
-    const uint32_t kt0 = KR ? chunk << tile_shift : 0u;           // first key of the tile within the partition
-    const uint32_t b_lo = KR ? 0u : chunk * tg.tb;
-    const uint32_t nb = KR ? T : (b_lo + tg.tb <= T ? tg.tb : T - b_lo);
-    const uint32_t cells = nb << tile_shift;
+    const uint32_t b_lo = chunk * tg.tb;
+    const uint32_t nb = b_lo + tg.tb <= T ? tg.tb : T - b_lo;
+    const uint32_t cells = nb << shift_part;
     const uint32_t c_lo = b_lo << shift_part;  // first partition-local cell of this round
     unsigned long long *vals = reinterpret_cast<unsigned long long *>(smem);
-    uint8_t *flags = smem + (size_t)(tg.tb << tile_shift) * 8;
+    uint8_t *flags = smem + (size_t)(tg.tb << shift_part) * 8;
     if (chunk != r_lo) __syncthreads();  // the previous round's tile has been written out
     for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
     for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
     __syncthreads();
     auto apply = [&](unsigned long long r) {
       const uint32_t cg = (uint32_t)r & cell_none;
-      uint32_t c = cg - c_lo;  // wraps for cells before this round: the unsigned compare rejects them
-      if (KR) {
-        const uint32_t kk = cg & (KP - 1u);
-        if (cg == cell_none || (kk >> tile_shift) != chunk) return;
-        c = ((cg >> shift_part) << tile_shift) | (kk & (KT - 1u));
-      } else if (cg == cell_none || c >= cells) return;
+      const uint32_t c = cg - c_lo;  // wraps for cells before this round: the unsigned compare rejects them
+      if (cg == cell_none || c >= cells) return;
       const unsigned long long v = r >> tg.cell_bits;
       if (OPMAX) atomicMax(&vals[c], v);
       else atomicAdd(&vals[c], v);
@@ -1066,70 +1014,12 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
       for (int u = 0; u < U; ++u) apply(r[u]);
     }
     __syncthreads();
-    // TS: settled[kk] != 0 -> the key's column of the grid is not written (see TileStats::skip_settled)
-    uint8_t *settled = flags + (((size_t)(tg.tb << tile_shift) + 3) & ~(size_t)3);
-    bool skip_cols = false;
-    if (TS && ts.rounds != 0) {
-      // DBSCAN (opt-in): the tile holds this round's buckets of every key of the partition — leave count / min / max / (mean, M2)
-      // of each key's values, so that the detector need not read the grid back for the keys it can settle from them.
-      // A split partition's tile is partial: its keys are marked for a grid walk.  1024 / KP threads share a key (at most a
-      // wavefront's 64): each takes every TPK-th bucket, the partials meet in a shuffle tree (moments: Chan et al., the
-      // lower part first — both partners compute the same value).
-      skip_cols = ts.skip_settled != 0 && (KR || tg.n_chunks == 1) && !split && *ovf_count_in == 0ull;
-      const uint32_t tpk_shift = tile_shift >= 10 ? 0u : (10u - (uint32_t)tile_shift > 6u ? 6u : 10u - (uint32_t)tile_shift);
-      const uint32_t TPK = 1u << tpk_shift;
-      for (uint32_t w = threadIdx.x; w < (KT << tpk_shift); w += kPartThreads) {
-        const uint32_t kk = w >> tpk_shift, part = w & (TPK - 1u);
-        const uint64_t k = k0 + kt0 + kk;
-        uint32_t n = 0;
-        double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
-        for (uint32_t b = part; b < nb; b += TPK) {
-          const uint32_t c = (b << tile_shift) + kk;
-          if (flags[c]) {
-            const double x = (double)vals[c];
-            if (n == 0) { mn = x; mx = x; x0 = x; }
-            mn = fmin(mn, x);
-            mx = fmax(mx, x);
-            const double d = x - x0;
-            s1 += d;
-            s2 += d * d;
-            n++;
-          }
-        }
-        Moments m{(double)n, 0.0, 0.0};
-        if (n) { const double dn = (double)n; m.mean = x0 + s1 / dn; m.m2 = fmax(s2 - s1 * (s1 / dn), 0.0); }
-        for (uint32_t d = 1; d < TPK; d <<= 1) {
-          const uint32_t on = __shfl_xor(n, (int)d);
-          const double omn = __shfl_xor(mn, (int)d), omx = __shfl_xor(mx, (int)d);
-          const Moments o{__shfl_xor(m.n, (int)d), __shfl_xor(m.mean, (int)d), __shfl_xor(m.m2, (int)d)};
-          if (on) {
-            mn = n ? fmin(mn, omn) : omn;
-            mx = n ? fmax(mx, omx) : omx;
-          }
-          n += on;
-          m = (part & d) ? chan_merge(o, m) : chan_merge(m, o);
-        }
-        if (part != 0 || k >= g.K) continue;
-        const size_t o = KR ? (size_t)k : (size_t)chunk * g.K + k;   // key rounds: one set of statistics per key
-        if (split) { ts.n[o] = kTileStatsRedo; continue; }
-        ts.n[o] = n;
-        if (n) {
-          ts.mn[o] = mn;
-          ts.mx[o] = mx;
-          ts.mean[o] = m.mean;
-          ts.m2[o] = m.m2;
-        }
-        if (skip_cols) settled[kk] = (n == 0 || (n >= (uint32_t)ts.min_samples && mx - mn <= ts.eps)) ? 1 : 0;   // (LDS for it only then)
-      }
-      if (skip_cols) __syncthreads();
-    }
     for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
-      const uint32_t b = b_lo + (c >> tile_shift), kk = c & (KT - 1);
-      const uint64_t k = k0 + kt0 + kk;
+      const uint32_t b = b_lo + (c >> shift_part), kk = c & (KP - 1);
+      const uint64_t k = k0 + kk;
       if (k >= g.K) continue;
       const uint64_t gc = (uint64_t)b * g.K + k;
       if (!split) {
-        if (TS && skip_cols && settled[kk]) continue;
         g.val[gc] = vals[c];
         g.flag[gc] = flags[c];
       } else if (flags[c]) {
@@ -1142,127 +1032,17 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
 }
 
 // records whose value did not fit the packed form: fold them into the finished grid (agent-scope integer atomics)
-template <bool OPMAX, bool TS = false>
+template <bool OPMAX>
 __global__ __launch_bounds__(256) void k_apply_overflow(const OverflowRec *__restrict__ ovf,
-                                                        const unsigned long long *__restrict__ ovf_count, uint32_t cap, Grid g,
-                                                        TileStats ts) {
+                                                        const unsigned long long *__restrict__ ovf_count, uint32_t cap, Grid g) {
   unsigned long long n = *ovf_count;
   if (n > cap) n = cap;
   for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
     const OverflowRec r = ovf[i];
-    if (TS && ts.rounds != 0) ts.n[r.gcell % g.K] = kTileStatsRedo;   // the tile pass did not see this record: round 0 of the key says "walk the grid"
     if (OPMAX) __hip_atomic_fetch_max(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_fetch_add(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     g.flag[r.gcell] = FLAG_PRESENT;
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Two-level partition (many keys: C4 = 1e6 keys x 100 buckets).  A KP x T tile that fits LDS in ONE round is 128 keys wide
-// there: 7813 partitions, far beyond what pass B's LDS queues can serve (<= ~820 for whole 128-byte lines) — round 1 fell
-// back to the sort-by-tile pass B (0.9-1.08 ms, runs of ~5 records) with 512-key blocks and 3-4 bucket rounds in pass C.
-// Instead: level 1 = the write-combining pass B over WIDE key blocks (2048 keys: 489 partitions, whole lines); level 2 =
-// k_repartition: the records of a wide block are split 16 ways by key sub-range through an LDS tile sort — few targets, so
-// every (tile, target) run is ~1 KB long and a global cursor per target (one atomic per run) replaces the offset tables;
-// pass C then aggregates single-round tiles.  The sub-partition sizes come from the fine histogram pass A already has.
-// LDS carve: rec[S] u64 | sub[S] u8 | cnt[NQ + 1] | base[NQ] (S = records per tile)
-// ------------------------------------------------------------------------------------------------
-struct RepartArgs {
-  const unsigned long long *recs1;
-  const unsigned long long *part_start1;   // [nparts1 + 1]
-  unsigned long long *recs2;
-  unsigned long long *cursor2;             // [nparts2] next free slot of every level-2 partition (starts at part_start2)
-  int cell_bits1, cell_bits2;
-  int shift1;        // log2(KP1)
-  int shift2;        // log2(KP2)
-  int sub_bits;      // shift1 - shift2
-  uint32_t nparts1;
-};
-
-static constexpr int kRepartRows = 4;   // records per thread per tile
-
-__global__ __launch_bounds__(kPartThreads) void k_repartition(RepartArgs A, SliceTable st) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr uint32_t S = kPartThreads * kRepartRows;
-  unsigned long long *rec = reinterpret_cast<unsigned long long *>(smem);
-  uint8_t *sub = smem + (size_t)S * 8;
-  uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + (size_t)S * 9);
-  const uint32_t NQ = 1u << A.sub_bits;
-  unsigned long long *base = reinterpret_cast<unsigned long long *>(cnt + NQ + 2 + ((NQ & 1u) ? 1 : 0));
-  const uint32_t s_idx = blockIdx.x;
-  if (s_idx >= *st.n_slices) return;
-  const uint32_t p1 = st.slice_part[s_idx];
-  const uint32_t first = st.slice_first[p1];
-  const unsigned long long plo = A.part_start1[p1], phi = A.part_start1[p1 + 1];
-  const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * kSliceRecords;
-  const unsigned long long hi = lo + kSliceRecords < phi ? lo + kSliceRecords : phi;
-  const uint32_t none1 = (1u << A.cell_bits1) - 1u;
-  const uint32_t kp1_mask = (1u << A.shift1) - 1u, kp2_mask = (1u << A.shift2) - 1u;
-  for (unsigned long long t0 = lo; t0 < hi; t0 += S) {
-    for (uint32_t q = threadIdx.x; q <= NQ; q += kPartThreads) cnt[q] = 0;
-    __syncthreads();
-    unsigned long long r2[kRepartRows];
-    uint32_t sr[kRepartRows];    // sub << 16 | rank, or all ones
-#pragma unroll
-    for (int j = 0; j < kRepartRows; ++j) {
-      const unsigned long long i = t0 + (unsigned long long)j * kPartThreads + threadIdx.x;
-      sr[j] = 0xFFFFFFFFu;
-      r2[j] = 0;
-      if (i < hi) {
-        const unsigned long long r = A.recs1[i];
-        const uint32_t c1 = (uint32_t)r & none1;
-        if (c1 != none1) {
-          const uint32_t kin1 = c1 & kp1_mask, bucket = c1 >> A.shift1;
-          const uint32_t sb = kin1 >> A.shift2;
-          r2[j] = ((r >> A.cell_bits1) << A.cell_bits2) | ((bucket << A.shift2) | (kin1 & kp2_mask));
-          sr[j] = (sb << 16) | atomicAdd(&cnt[sb], 1u);
-        }
-      }
-    }
-    __syncthreads();
-    // exclusive scan over the NQ (<= 32) targets by one wavefront; one global reservation per (tile, target)
-    if (threadIdx.x < 64) {
-      const uint32_t c = threadIdx.x < NQ ? cnt[threadIdx.x] : 0u;
-      uint32_t incl = c;
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += y; }
-      const uint32_t tile_total = __shfl(incl, 63);   // (all 64 lanes active here)
-      if (threadIdx.x < NQ) {
-        cnt[threadIdx.x] = incl - c;   // tile position of the target's run
-        base[threadIdx.x] = c ? atomicAdd(&A.cursor2[((unsigned long long)p1 << A.sub_bits) + threadIdx.x], (unsigned long long)c) : 0ull;
-      }
-      if (threadIdx.x == 63) cnt[NQ] = tile_total;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kRepartRows; ++j) {
-      if (sr[j] != 0xFFFFFFFFu) {
-        const uint32_t sb = sr[j] >> 16, pos = cnt[sb] + (sr[j] & 0xFFFFu);
-        rec[pos] = r2[j];
-        sub[pos] = (uint8_t)sb;
-      }
-    }
-    __syncthreads();
-    const uint32_t total = cnt[NQ];
-    for (uint32_t idx = threadIdx.x; idx < total; idx += kPartThreads) {
-      const uint32_t sb = sub[idx];
-      A.recs2[base[sb] + (idx - cnt[sb])] = rec[idx];
-    }
-    __syncthreads();
-  }
-}
-
-// slots of a level-2 partition that stayed empty (rows that went to the overflow list, level-1 fillers): `no cell`
-__global__ __launch_bounds__(256) void k_fill_tails(const unsigned long long *__restrict__ cursor2, const unsigned long long *__restrict__ part_start2,
-                                                    uint32_t nparts2, unsigned long long *__restrict__ recs2) {
-  const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= nparts2) return;
-  const unsigned long long end = part_start2[p + 1];
-  for (unsigned long long i = cursor2[p] + (threadIdx.x & 63); i < end; i += 64) recs2[i] = ~0ull;
-}
-
-__global__ __launch_bounds__(256) void k_copy_u64(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst, uint32_t n) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1292,7 +1072,6 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   for (int c = 13; c >= 0; --c)
     if (((uint64_t)T << c) <= kTileCells) { sp_fit = c; break; }
   int sp = sp_fit >= pl->shift_bin ? sp_fit : pl->shift_bin;
-  if (const char *e = getenv("TAD_KP_SHIFT_MIN")) { const int v = atoi(e); if (v > sp && v <= 13) sp = v; }  // tuning knob: wider key blocks
   while (((K + (1ull << sp) - 1) >> sp) > kMaxParts && sp < 13) ++sp;
   if (((K + (1ull << sp) - 1) >> sp) > kMaxParts) return false;
   while (sp > pl->shift_bin && (1ull << (sp - 1)) >= K) --sp;  // no wider than the key space
@@ -1301,11 +1080,10 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   // (they run as parallel workgroups sharing an XCD's L2, k_tile_aggregate) and no more than 4.  C2: 1563 partitions of
   // 64 keys -> 782 of 128 keys, 2 rounds: partition pass 0.715 -> 0.59 ms, pass C 0.26 -> 0.29 ms.
   {
-    const char *wide_env = getenv("TAD_WIDE_KP");
     auto parts_of = [&](int c) { return (K + (1ull << c) - 1) >> c; };
     auto rounds_of = [&](int c) { const uint64_t tb = kTileCells >> c; return tb ? (T + tb - 1) / tb : (uint64_t)1 << 30; };
     const uint64_t line_parts = kLdsBudget / (8 * 22 + 18);
-    if (!(wide_env && atoi(wide_env) == 0) && parts_of(sp) > line_parts) {
+    if (parts_of(sp) > line_parts) {
       int c = sp;
       while (c < 13 && parts_of(c) > line_parts) ++c;
       if (parts_of(c) <= line_parts && (1ull << c) <= kTileCells && rounds_of(c) <= 2 * rounds_of(sp) && rounds_of(c) <= 4) sp = c;
@@ -1330,32 +1108,11 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   const size_t fixed = ((size_t)pl->nparts + 4) * 16 + 64;
   pl->rpt = 0;
   const int mult = has2 ? 2 : 1;
-  const char *rpt_env = getenv("TAD_RPT");  // tuning knob: cap the rows per thread of pass B
-  const int rpt_cap = rpt_env ? atoi(rpt_env) : 10;  // 12 spills registers at 1024 threads (measured slower)
-  for (int r : {12, 10, 8, 4, 2}) {
-    if (r > rpt_cap && r > 2) continue;
+  for (int r : {10, 8, 4, 2}) {   // (12 rows per thread spill registers at 1024 threads: measured slower)
     const size_t slots = (size_t)r * kPartThreads * mult;
     if (slots * 10 + fixed <= kLdsBudget) { pl->rpt = r; pl->part_lds = (slots * 10 + fixed + 15) & ~(size_t)15; break; }
   }
   return pl->rpt != 0;
-}
-
-// Key rounds (pass C with per-tile key statistics, TileStats::ks_shift): a partition that needs R > 1 LDS tiles is split by
-// key sub-range — KP / R' keys x ALL buckets per tile, R' = R rounded up to a power of two — instead of by bucket range, so
-// that every tile holds whole series (C4: 512 keys x 34 buckets, 3 rounds -> 128 keys x 100 buckets, 4 rounds).
-bool part_plan_key_rounds(uint64_t T, PartPlan *pl) {
-  pl->ks_shift = 0;
-  if (pl->n_chunks <= 1) return false;
-  int rs = 0;
-  while ((1u << rs) < pl->n_chunks) ++rs;
-  if (rs >= pl->shift_part) return false;
-  const int ks = pl->shift_part - rs;
-  if (ks < 1 || (T << ks) > kTileCells) return false;
-  pl->ks_shift = (uint32_t)ks;
-  pl->n_chunks = 1u << rs;
-  pl->tb = (uint32_t)T;
-  pl->agg_lds = ((size_t)(T << ks) * 9 + 15) & ~(size_t)15;
-  return true;
 }
 
 static bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1367,32 +1124,28 @@ bool columns_aligned16(const void *key, const void *key2, const void *t_end, con
 // write-combining pass B: F * (8 * cap + 14) bytes of LDS.  With >= 28 slots per partition the queues emit whole
 // 128-byte lines (16 records), with 9..21 slots 64-byte sectors; below 9 slots (more than ~1800 partitions) and for
 // tables with so few partitions that the sort-by-tile pass already writes long runs, the old pass runs.
-// TAD_PARTB=sort / =wc overrides the choice, TAD_WC_SEC / TAD_WC_RPT the emit size and rows per thread.
-void part_plan_wc(uint64_t slots, bool aligned, bool has2, PartPlan *pl) {
+// partition_pass (tad_plan): 1 = always the sort-by-tile pass, 2 = the write-combining pass whenever its queues fit LDS.
+void part_plan_wc(uint64_t slots, bool aligned, bool has2, int partition_pass, PartPlan *pl) {
   pl->wc_cap = 0;
   pl->wc_sec = 0;
   pl->wc_rpt = 0;
   pl->pad_slots = 0;
-  const char *env = getenv("TAD_PARTB");
-  if (env && !strcmp(env, "sort")) return;
+  if (partition_pass == 1) return;
   if (!aligned || pl->nparts == 0) return;
   const size_t per = kLdsBudget / pl->nparts;
   if (per < 18 + 8 * 9) return;
   uint32_t cap = (uint32_t)((per - 18) / 8);
   if (cap > 64) cap = 64;
   uint32_t sec = cap >= 22 ? 16 : 8;   // 15 leftovers + room for a tile's arrivals
-  if (const char *e = getenv("TAD_WC_SEC")) { const int v = atoi(e); if (v == 8 || (v == 16 && cap >= 20)) sec = (uint32_t)v; }
   if (sec == 8 && cap > 16) cap = 16;
   // the sort-by-tile pass writes runs of (tile slots / partitions) records: long runs beat 64-byte sectors
-  const bool forced = env && !strcmp(env, "wc");
-  if (!forced && !kWcDefault) return;
+  const bool forced = partition_pass == 2;
   if (!forced && sec == 8 && (uint64_t)pl->rpt * kPartThreads * (has2 ? 2 : 1) / pl->nparts >= 24) return;
   // few, large partitions: a tile brings more records per partition than a queue can take (and the sort pass writes long runs)
   if (!forced && 2.0 * kPartThreads * (has2 ? 2 : 1) / (double)pl->nparts > 0.5 * (double)(cap - (sec - 1))) return;
   // rows per thread: 4 when a queue holding SEC - 1 leftovers still has room for twice the expected arrivals of a tile
   const double lam4 = 4.0 * kPartThreads * (has2 ? 2 : 1) / (double)pl->nparts;
-  uint32_t rpt = !has2 && (double)(cap - (sec - 1)) >= 2.0 * lam4 + 4.0 ? 4 : 2;
-  if (const char *e = getenv("TAD_WC_RPT")) { const int v = atoi(e); if (v == 2 || (v == 4 && !has2)) rpt = (uint32_t)v; }
+  const uint32_t rpt = !has2 && (double)(cap - (sec - 1)) >= 2.0 * lam4 + 4.0 ? 4 : 2;
   const uint64_t pad = (uint64_t)(sec - 1) * pl->G * pl->nparts;
   if (slots + pad >= (1ull << 32)) return;
   pl->wc_cap = cap;
@@ -1408,19 +1161,16 @@ bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   const bool has2 = key2 != nullptr;
   // the histogram can only be sampled where the time column is (no time-window filter, 16-byte loads)
   const bool sh = sample_hist && vec && f.end_time == 0 && !(t_start != nullptr && f.start_time != 0);
-  const char *pf_env = getenv("TAD_META_PREFETCH");
-  const int prefetch = pf_env != nullptr && pf_env[0] == '1';
-#define TAD_MH(V, H2, SH, PF)                                                                                          \
+#define TAD_MH(V, H2, SH)                                                                                              \
   do {                                                                                                                 \
-    allow_big_lds(reinterpret_cast<const void *>(k_meta_hist<V, H2, SH, PF>), kLdsBudget);                             \
-    hipLaunchKernelGGL((k_meta_hist<V, H2, SH, PF>), dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n, \
+    allow_big_lds(reinterpret_cast<const void *>(k_meta_hist<V, H2, SH>), kLdsBudget);                                 \
+    hipLaunchKernelGGL((k_meta_hist<V, H2, SH>), dim3(pl.G), dim3(kPartThreads), (size_t)pl.nbins * 4, s, key, key2, t_end, t_start, n, \
                        pl.chunk, K, f, pl.shift_bin, pl.nbins, partials, binhist, ctr);                                \
   } while (0)
   if (vec) {
-    if (sh && prefetch) { if (has2) TAD_MH(true, true, true, true); else TAD_MH(true, false, true, true); }
-    else if (sh) { if (has2) TAD_MH(true, true, true, false); else TAD_MH(true, false, true, false); }
-    else { if (has2) TAD_MH(true, true, false, false); else TAD_MH(true, false, false, false); }
-  } else { if (has2) TAD_MH(false, true, false, false); else TAD_MH(false, false, false, false); }
+    if (sh) { if (has2) TAD_MH(true, true, true); else TAD_MH(true, false, true); }
+    else { if (has2) TAD_MH(true, true, false); else TAD_MH(true, false, false); }
+  } else { if (has2) TAD_MH(false, true, false); else TAD_MH(false, false, false); }
 #undef TAD_MH
   return sh;
 }
@@ -1482,7 +1232,6 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   } while (0)
   if (!generic) {
     switch (rpt) {
-      case 12: if (has2) TAD_PART(8, true, true, false); else TAD_PART(12, false, true, false); break;
       case 10: if (has2) TAD_PART(8, true, true, false); else TAD_PART(10, false, true, false); break;
       case 8: if (has2) TAD_PART(8, true, true, false); else TAD_PART(8, false, true, false); break;
       case 6: case 4: if (has2) TAD_PART(4, true, true, false); else TAD_PART(4, false, true, false); break;
@@ -1498,70 +1247,6 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 #undef TAD_PART
 }
 
-// Two-level plan: l2 = the partitions pass C aggregates in ONE round (the widest power-of-two key block whose KP x T tile
-// fits LDS), l1 = wide blocks of 2^sub_bits of them, few enough for pass B to write whole 128-byte lines.  Only when the
-// single-level plan cannot run the write-combining pass at all (more than ~1850 partitions).
-bool part_plan_two_level(uint64_t K, uint64_t T, bool has2, bool aligned, uint64_t slots, const PartPlan &base, PartPlan *l1, PartPlan *l2) {
-  // Opt-in (TAD_TWO_LEVEL=1).  Measured at C4 on one box, alternating runs: level 1 0.65 ms + level 2 0.31 ms + single-round pass C
-  // 0.55 ms = job 2.31 ms, against 0.90-1.09 ms (box-dependent) + 0.45 ms = 2.22-2.35 ms for the single-level plan: pass C on
-  // 128-key tiles is bound by the 0.9 GB grid it writes, one workgroup per CU, not by the record re-reads the extra level saves.
-  const char *env = getenv("TAD_TWO_LEVEL");
-  if (!(env && atoi(env) == 1)) return false;
-  if (!aligned || T == 0 || base.nparts <= kLdsBudget / (18 + 8 * 9)) return false;
-  int sp2 = -1;
-  for (int c = 13; c >= 0; --c)
-    if (((uint64_t)T << c) <= kTileCells) { sp2 = c; break; }
-  if (const char *e2 = getenv("TAD_L2_SHIFT")) { const int v = atoi(e2); if (v >= 1 && v < sp2) sp2 = v; }   // tuning knob: narrower level-2 blocks
-  if (sp2 < base.shift_bin || sp2 < 1) return false;
-  auto parts_of = [&](int c) { return (K + (1ull << c) - 1) >> c; };
-  const uint64_t line_parts = kLdsBudget / (8 * 22 + 18);
-  int sp1 = sp2 + 1;
-  while (sp1 - sp2 < 5 && parts_of(sp1) > line_parts) ++sp1;
-  if (parts_of(sp1) > line_parts) return false;
-  const uint64_t cells1 = ((uint64_t)T << sp1);
-  int cb1 = kMinCellBits;
-  while (cb1 < kMaxCellBits && (1ull << cb1) - 1 <= cells1) ++cb1;
-  if ((1ull << cb1) - 1 <= cells1) return false;
-  *l1 = base;
-  l1->shift_part = sp1; l1->KP = 1u << sp1; l1->nparts = (uint32_t)parts_of(sp1); l1->bins_per_part = 1u << (sp1 - base.shift_bin);
-  l1->cell_bits = cb1; l1->tb = 0; l1->n_chunks = 0; l1->rpt = 2;
-  part_plan_wc(slots, aligned, has2, l1);
-  if (l1->wc_cap == 0 || l1->wc_sec != 16) return false;
-  *l2 = base;
-  l2->shift_part = sp2; l2->KP = 1u << sp2; l2->nparts = l1->nparts << (sp1 - sp2);   // level-2 ids = (p1 << sub_bits) | sub: the last block may hold empty ones
-  l2->bins_per_part = 1u << (sp2 - base.shift_bin);
-  const uint64_t cells2 = ((uint64_t)T << sp2);
-  int cb2 = kMinCellBits;
-  while (cb2 < kMaxCellBits && (1ull << cb2) - 1 <= cells2) ++cb2;
-  l2->cell_bits = cb2 > cb1 ? cb1 : cb2;
-  if (l2->cell_bits > cb1) return false;
-  l2->tb = (uint32_t)T; l2->n_chunks = 1;
-  l2->agg_lds = ((size_t)l2->tb * l2->KP * 9 + 15) & ~(size_t)15;
-  l2->wc_cap = 0; l2->wc_sec = 0; l2->wc_rpt = 0; l2->pad_slots = l1->pad_slots;
-  return true;
-}
-
-// level 2: recs1 (grouped by the wide level-1 partitions) -> recs2 (grouped by the level-2 partitions)
-void launch_repartition(hipStream_t s, const void *recs1, const unsigned long long *part_start1, const PartPlan &l1, const PartPlan &l2,
-                        uint64_t slots, void *slice_mem, const unsigned long long *part_start2, unsigned long long *cursor2, void *recs2) {
-  const uint32_t max_slices = (uint32_t)((size_t)l1.nparts + (size_t)(slots / kSliceRecords) + 1);
-  SliceTable st;
-  st.slice_part = static_cast<uint32_t *>(slice_mem);
-  st.slice_first = st.slice_part + max_slices;
-  st.n_slices = st.slice_first + l1.nparts;
-  hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start1, l1.nparts, st, kSliceRecords);
-  hipLaunchKernelGGL(k_copy_u64, dim3((l2.nparts + 255) / 256), dim3(256), 0, s, part_start2, cursor2, l2.nparts);
-  RepartArgs A;
-  A.recs1 = static_cast<const unsigned long long *>(recs1); A.part_start1 = part_start1;
-  A.recs2 = static_cast<unsigned long long *>(recs2); A.cursor2 = cursor2;
-  A.cell_bits1 = l1.cell_bits; A.cell_bits2 = l2.cell_bits; A.shift1 = l1.shift_part; A.shift2 = l2.shift_part;
-  A.sub_bits = l1.shift_part - l2.shift_part; A.nparts1 = l1.nparts;
-  const uint32_t NQ = 1u << A.sub_bits;
-  const size_t lds = ((size_t)kPartThreads * kRepartRows * 9 + (size_t)(NQ + 4) * 4 + (size_t)NQ * 8 + 15) & ~(size_t)15;
-  hipLaunchKernelGGL(k_repartition, dim3(max_slices), dim3(kPartThreads), lds, s, A, st);
-  hipLaunchKernelGGL(k_fill_tails, dim3((l2.nparts + 3) / 4), dim3(256), 0, s, cursor2, part_start2, l2.nparts, A.recs2);
-}
-
 size_t slice_table_bytes(uint64_t slots, const PartPlan &pl) {
   const size_t max_slices = (size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1;
   return (max_slices + pl.nparts + 4) * sizeof(uint32_t);
@@ -1569,9 +1254,8 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl) {
 
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
-                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, TileStats ts) {
+                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin) {
   const unsigned long long *rr = static_cast<const unsigned long long *>(recs);
-  const TileStats none{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   const uint32_t max_slices = (uint32_t)((size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1);
   SliceTable st;
   st.slice_part = static_cast<uint32_t *>(slice_mem);
@@ -1583,34 +1267,18 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   const uint32_t slice_len = fin != nullptr ? 2 * kSliceRecords : kSliceRecords;
   hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st, slice_len);
   const bool may_split = slots > slice_len;  // some partition could exceed one slice
-  const char *pr_env = getenv("TAD_PAR_ROUNDS");
-  const uint32_t par = pl.n_chunks > 1 && !(pr_env && atoi(pr_env) == 0) ? 1u : 0u;
+  // the bucket rounds of a partition run as parallel workgroups on one XCD (measured: C2 pass C 0.39 -> 0.29 ms against sequential rounds)
+  const uint32_t par = pl.n_chunks > 1 ? 1u : 0u;
   TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len};
   const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
-  // settled-key bytes behind the tile: only with one bucket round per partition and if they still fit
-  const size_t settled_lds = ((size_t)(pl.ks_shift ? 1u << pl.ks_shift : pl.KP) + 15) & ~(size_t)15;
-  if (ts.skip_settled && ((pl.n_chunks != 1 && pl.ks_shift == 0) || pl.agg_lds + settled_lds > kLdsBudget)) ts.skip_settled = 0;
-#define TAD_TA_KR(OPMAX)                                                                                                                                                               \
-  do {                                                                                                                                                                                 \
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX, false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none, ovf_count); \
-    allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, true, true>), kLdsBudget);                                                                                    \
-    hipLaunchKernelGGL((k_tile_aggregate<OPMAX, true, true>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds + (ts.skip_settled ? settled_lds : 0), s, rr, part_start, st, tg, g, 1,    \
-                       offs32, fin, pl.G, ts, ovf_count);                                                                                                                              \
-    hipLaunchKernelGGL((k_apply_overflow<OPMAX, true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);                                                                    \
+#define TAD_TA(OPMAX)                                                                                                                                                     \
+  do {                                                                                                                                                                    \
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G);            \
+    hipLaunchKernelGGL((k_tile_aggregate<OPMAX>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G);                    \
+    hipLaunchKernelGGL((k_apply_overflow<OPMAX>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);                                                                 \
   } while (0)
-#define TAD_TA(OPMAX, TS)                                                                                                                                                              \
-  do {                                                                                                                                                                                 \
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX, false>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none, ovf_count); \
-    if (TS) allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, TS>), kLdsBudget);                                                                                    \
-    hipLaunchKernelGGL((k_tile_aggregate<OPMAX, TS>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds + (ts.skip_settled ? settled_lds : 0), s, rr, part_start, st, tg, g, 1,            \
-                       offs32, fin, pl.G, ts, ovf_count);                                                                                                                              \
-    hipLaunchKernelGGL((k_apply_overflow<OPMAX, TS>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g, ts);                                                                      \
-  } while (0)
-  if (ts.rounds != 0 && pl.ks_shift != 0) { ts.ks_shift = pl.ks_shift; if (op_max) TAD_TA_KR(true); else TAD_TA_KR(false); }
-  else if (ts.rounds != 0) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }
-  else { if (op_max) TAD_TA(true, false); else TAD_TA(false, false); }
+  if (op_max) TAD_TA(true); else TAD_TA(false);
 #undef TAD_TA
-#undef TAD_TA_KR
 }
 
 }  // namespace tad

@@ -231,12 +231,15 @@ class TadState:
 class TadEngine:
     """One engine per GPU.  Thread-safe (runs serialise inside the library)."""
 
-    def __init__(self, device=0, stream=None, workspace_limit=0):
+    def __init__(self, device=0, stream=None, workspace_limit=0, plan=None):
+        """plan: dict of tad_plan overrides (include/tad.h), e.g. {"stage0": "v2", "partition_pass": "sort"}; None = the
+        engine decides everything (production)."""
         self._lib = capi.load_library()
         self._h = None
         self.device = int(device)
+        self._plan = dict(plan or {})
         opts = capi.EngineOpts(device=int(device), stream=C.c_void_p(stream) if stream else None,
-                               workspace_limit=int(workspace_limit))
+                               workspace_limit=int(workspace_limit), plan=capi.make_plan(**self._plan))
         h = C.c_void_p()
         rc = self._lib.tad_engine_create(C.byref(opts), C.byref(h))
         if rc != capi.TAD_OK:
@@ -247,6 +250,29 @@ class TadEngine:
     def _check(self, rc):
         if rc != capi.TAD_OK:
             raise TadError(rc, (self._lib.tad_last_error(self._h) or b"").decode())
+
+    def set_plan(self, **overrides):
+        """Replace the engine's plan overrides (tad_engine_set_plan); no arguments = back to automatic."""
+        p = capi.make_plan(**overrides)
+        self._check(self._lib.tad_engine_set_plan(self._h, C.byref(p)))
+        self._plan = dict(overrides)
+
+    def plan(self, **overrides):
+        """Context manager: the jobs inside run with these overrides ON TOP of the current ones, which are restored after."""
+        engine = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                self_inner.saved = dict(engine._plan)
+                merged = dict(engine._plan)
+                merged.update(overrides)
+                engine.set_plan(**merged)
+                return engine
+
+            def __exit__(self_inner, *exc):
+                engine.set_plan(**self_inner.saved)
+                return False
+        return _Scope()
 
     def close(self):
         if self._h is not None:

@@ -7,26 +7,15 @@
 #include "../theia_amd/csrc/tad_arima.hip"
 using namespace tad;
 
-static int g_collapsed = 0;   // which arithmetic contract: arima_nll (general three-state form) or arima_nll_collapsed
-extern "C" void twin_set_filter(int collapsed) { g_collapsed = collapsed != 0; }
-
 static double twin_fit(const double *y, uint32_t p, int maxiter, unsigned long long *steps) {
   Lbfgs o;
-  o.col = 0; o.head = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false; o.f = 0.0; o.fc = 0.0; o.fcold = 0.0;
+  o.col = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false; o.f = 0.0; o.fc = 0.0; o.fcold = 0.0;
   arima_start_params(y, 1, p, o.x);
   while (!o.done) {
     double xe[4][3], dx[3], nll[4], fc0 = 0.0;
     for (int c = 0; c < 4; ++c) { xe[c][0] = o.x[0]; xe[c][1] = o.x[1]; xe[c][2] = o.x[2]; }
     for (int i = 0; i < 3; ++i) xe[i + 1][i] = fd_point(xe[i + 1][i], &dx[i]);
-    if (g_collapsed) {
-      arima_nll4_collapsed(xe, y, 1, p, nll, fc0);          // the four recursions jointly (batched inversion)
-    } else {
-      for (int c = 0; c < 4; ++c) {
-        const KfOut r = arima_nll(xe[c][0], xe[c][1], xe[c][2], y, 1, p);
-        nll[c] = r.nll;
-        if (c == 0) fc0 = r.forecast;
-      }
-    }
+    arima_nll4_collapsed(xe, y, 1, p, nll, fc0);            // the four recursions jointly (batched inversion)
     *steps += 4ull * p;
     for (int i = 0; i < 3; ++i) o.g[i] = (nll[i + 1] - nll[0]) / dx[i];
     o.f = nll[0]; o.fc = fc0;

@@ -28,10 +28,6 @@ for i in range(20):
     if rng.random() < 0.5:
         x[rng.integers(0, n)] *= rng.uniform(2, 12)
     series["rand%d" % i] = np.floor(x) + 1.0
-if len(sys.argv) > 1 and sys.argv[1] == "collapsed":      # the opt-in contract (TAD_ARIMA_FILTER=collapsed) on both sides
-    os.environ["TAD_ARIMA_FILTER"] = "collapsed"
-tw.twin_set_filter(1 if ao.exact_filter() == "collapsed" else 0)
-print("filter:", ao.exact_filter())
 bad = 0
 for name, x in series.items():
     t0 = time.time(); c = {}

@@ -33,17 +33,15 @@ def check_c2():
     verdict = np.repeat(has, np.diff(ptr)) & (np.abs(pvf - calc) > np.repeat(sigma, np.diff(ptr)))
     sg_rows = np.repeat(sigma, np.diff(ptr))[verdict]
     print("oracle ready, %d anomalies, %.0f s" % (verdict.sum(), time.time()-t0))
-    for label, env in (("classic", {}), ("fused (capacity from the previous job)", {"TAD_EWMA_FUSED":"1"}), ("fused + prefetch", {"TAD_EWMA_FUSED":"1","TAD_META_PREFETCH":"1"}),
-                       ("fused, LDS capacity 1000 rows (overflow walk in most wavefronts)", {"TAD_EWMA_FUSED":"1","TAD_EMIT_CAP":"1000"})):
-        os.environ.update(env)
-        res = eng.run("EWMA", dk, dt, dv, K, agg_flow="svc", out="device")
-        for n_ in env: os.environ.pop(n_)
-        assert res.stats["stage0_path"] == 3 and res.n_rows == int(verdict.sum()), (label, res.n_rows)
-        assert res.stats["detect_path"] == (0 if label == "classic" else 1), label
+    for label, plan in (("default plan", {}), ("exact histogram", {"histogram": "exact"}), ("staged emit, 64 LDS rows per wavefront", {"ewma_emit_rows": 64}),
+                        ("sort-by-tile pass B, lane-per-key emit", {"partition_pass": "sort", "ewma_emit": "lane"})):
+        with eng.plan(**plan):
+            res = eng.run("EWMA", dk, dt, dv, K, agg_flow="svc", out="device")
+        assert res.stats["stage0_path"] == (2 if plan.get("partition_pass") == "sort" else 3) and res.n_rows == int(verdict.sum()), (label, res.n_rows)
         h = res.to_host()
         for f, want in (("key_id", pk[verdict]), ("flow_end_s", pt[verdict]), ("throughput", pvf[verdict]), ("algo_calc", calc[verdict]), ("stddev", sg_rows)):
             assert (h[f] == want).all(), (label, f)
-        print("ok full-size C2 %-70s rows %d sampled %d detect_path %d  %.0f s" % (label, res.n_rows, res.stats["hist_sampled"], res.stats["detect_path"], time.time()-t0))
+        print("ok full-size C2 %-70s rows %d sampled %d  %.0f s" % (label, res.n_rows, res.stats["hist_sampled"], time.time()-t0))
 
 
 
@@ -61,12 +59,9 @@ def check_c4():
     noise = orc.dbscan_noise_all(pvf, ptr)
     sg_rows = np.repeat(sigma, np.diff(ptr))[noise]
     print("oracle ready, %d noise points, %.0f s" % (noise.sum(), time.time()-t0))
-    for label, env in (("default", {}), ("tilestats=1", {"TAD_DBSCAN_TILESTATS":"1"}), ("wavelist (+ emit from the list)", {"TAD_DBSCAN_WAVELIST":"1"}),
-                       ("tilestats=2 (key rounds, settled columns not written)", {"TAD_DBSCAN_TILESTATS":"2"}),
-                       ("tilestats=2 + wavelist", {"TAD_DBSCAN_TILESTATS":"2","TAD_DBSCAN_WAVELIST":"1"})):
-        os.environ.update(env)
-        res = eng.run("DBSCAN", dk, dt, dv, K, agg_flow="", out="device")
-        for n_ in env: os.environ.pop(n_)
+    for label, plan in (("default plan", {}), ("write-combining pass B forced", {"partition_pass": "wc"})):
+        with eng.plan(**plan):
+            res = eng.run("DBSCAN", dk, dt, dv, K, agg_flow="", out="device")
         assert res.n_rows == int(noise.sum()), (label, res.n_rows, int(noise.sum()))
         assert res.stats["n_points"] == pk.size and res.stats["n_keys"] == K
         h = res.to_host()
@@ -82,5 +77,4 @@ if __name__ == "__main__":
     if what in ("c2", "all"):
         check_c2()
     if what in ("c4", "all"):
-        os.environ["TAD_DEBUG_PLAN"] = "1"
         check_c4()
