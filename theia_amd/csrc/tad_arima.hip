@@ -52,6 +52,7 @@ struct ArimaWs {
   uint32_t *tpos;  // [T][K] bucket of the p-th point
   double *lam;     // [K]
   uint8_t *state;  // [K] 0 = ok, 1 = no result
+  double *hist;    // [wavefronts of k_arima_fit][kHistDoubles][64] every lane's L-BFGS (s, y) history (struct Lbfgs)
   uint32_t Tpad;
 };
 
@@ -584,31 +585,42 @@ TAD_HD int mt_iterate(LineSearch &L, double &stp, double f, double g, double stp
 // ------------------------------------------------------------------------------------------------
 // L-BFGS-B 3.0, unconstrained path, as a per-lane state machine driven by (f, g) deliveries
 // ------------------------------------------------------------------------------------------------
-#if defined(TAD_LBFGS_DYNAMIC)
-#define TAD_LBFGS_RESET_HEAD(o) (o).head = 0
-#else
-#define TAD_LBFGS_RESET_HEAD(o) (void)0
-#endif
 struct Lbfgs {
   double x[3], g[3], f;
   double d[3], t[3], r[3];  // search direction, iterate and gradient at the start of the line search
-  double fold, gd, gdold, stp, dnorm, dtd, theta;
+  double fold, gd, gdold, stp, theta;
   double fc, fcold;  // one-step forecast of the model at x / at the start of the line search (no extra filter run at the end)
-  double S[kLbfgsM][3], Y[kLbfgsM][3];
-  int col, iter, ifun, iback, nit;
-#if defined(TAD_LBFGS_DYNAMIC)
-  int head = 0;
-#endif
+  // The (s, y) history (kLbfgsM pairs of 3-vectors = 60 doubles) lives in MEMORY the caller provides, a circular buffer:
+  // element c of s / y of physical slot i at hist[((i * 2 + {0, 1}) * 3 + c) * hstride].  On the device that is a per-wavefront
+  // block of global memory with the lanes interleaved (hstride = 64: every access a coalesced 512-byte line) — as registers the
+  // history pushed ~100 VGPRs of spills into the optimiser step (measured: a third of k_arima_fit's time went into that step);
+  // lbfgs_load_hist fetches all of it in ONE batch of independent loads right before the direction is computed.
+  double *hist;
+  uint32_t hstride;
+  double *park;       // where lbfgs_park / lbfgs_unpark keep the rest of this struct between steps (kParkDoubles values, element stride pstride)
+  uint32_t pstride;
+  int col, head, iter, ifun, iback, nit;
   bool in_ls, done;
   LineSearch ls;
 };
 
-// The history is kept in LOGICAL order (pair 0 = oldest) and shifted down when full, and every loop below has compile-time
-// bounds with a `j < col` predicate: all indices into S / Y / alpha are static, so the 60 doubles live in registers (or
-// in statically addressed spill slots the compiler reloads in bulk) instead of a dynamically indexed scratch array whose
-// dependent loads serialised the two-loop recursion.  Same operations in the same order as before.
-#if !defined(TAD_LBFGS_DYNAMIC)
-TAD_HD void lbfgs_direction(Lbfgs &o) {
+TAD_HD inline double &lbfgs_hist(const Lbfgs &o, int slot, int which, int c) { return o.hist[(size_t)((slot * 2 + which) * 3 + c) * o.hstride]; }
+
+struct LbfgsHist { double S[kLbfgsM][3], Y[kLbfgsM][3]; };   // the pairs in LOGICAL order (0 = oldest), registers
+
+// all m slots, independent loads, no branches (slots beyond col hold stale values that the `j < col` predicates never use)
+TAD_HD inline void lbfgs_load_hist(const Lbfgs &o, LbfgsHist &h) {
+#pragma unroll
+  for (int j = 0; j < kLbfgsM; ++j) {
+    int slot = o.head + j;
+    if (slot >= kLbfgsM) slot -= kLbfgsM;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { h.S[j][c] = lbfgs_hist(o, slot, 0, c); h.Y[j][c] = lbfgs_hist(o, slot, 1, c); }
+  }
+}
+
+// -H g by the two-loop recursion, H0 = I / theta
+TAD_HD void lbfgs_direction(Lbfgs &o, const LbfgsHist &h) {
   if (o.col == 0) {
     for (int i = 0; i < 3; ++i) o.d[i] = -o.g[i];  // Cauchy point with B = theta I, theta = 1
     return;
@@ -618,10 +630,10 @@ TAD_HD void lbfgs_direction(Lbfgs &o) {
   for (int j = kLbfgsM - 1; j >= 0; --j) {
     alpha[j] = 0.0;
     if (j < o.col) {
-      const double sy = o.S[j][0] * o.Y[j][0] + o.S[j][1] * o.Y[j][1] + o.S[j][2] * o.Y[j][2];
-      alpha[j] = (o.S[j][0] * q[0] + o.S[j][1] * q[1] + o.S[j][2] * q[2]) / sy;
+      const double sy = h.S[j][0] * h.Y[j][0] + h.S[j][1] * h.Y[j][1] + h.S[j][2] * h.Y[j][2];
+      alpha[j] = (h.S[j][0] * q[0] + h.S[j][1] * q[1] + h.S[j][2] * q[2]) / sy;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) q[c] -= alpha[j] * o.Y[j][c];
+      for (int c = 0; c < 3; ++c) q[c] -= alpha[j] * h.Y[j][c];
     }
   }
 #pragma unroll
@@ -629,39 +641,50 @@ TAD_HD void lbfgs_direction(Lbfgs &o) {
 #pragma unroll
   for (int j = 0; j < kLbfgsM; ++j) {
     if (j < o.col) {
-      const double sy = o.S[j][0] * o.Y[j][0] + o.S[j][1] * o.Y[j][1] + o.S[j][2] * o.Y[j][2];
-      const double beta = (o.Y[j][0] * q[0] + o.Y[j][1] * q[1] + o.Y[j][2] * q[2]) / sy;
+      const double sy = h.S[j][0] * h.Y[j][0] + h.S[j][1] * h.Y[j][1] + h.S[j][2] * h.Y[j][2];
+      const double beta = (h.Y[j][0] * q[0] + h.Y[j][1] * q[1] + h.Y[j][2] * q[2]) / sy;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) q[c] += o.S[j][c] * (alpha[j] - beta);
+      for (int c = 0; c < 3; ++c) q[c] += h.S[j][c] * (alpha[j] - beta);
     }
   }
   for (int c = 0; c < 3; ++c) o.d[c] = -q[c];
 }
 
-#else   // A/B only (tools/gpu_arima_prof.sh): round 2's circular buffer with run-time indices
-TAD_HD void lbfgs_direction(Lbfgs &o) {
-  if (o.col == 0) {
-    for (int i = 0; i < 3; ++i) o.d[i] = -o.g[i];
-    return;
-  }
-  double q[3] = {o.g[0], o.g[1], o.g[2]}, alpha[kLbfgsM];
-  for (int j = o.col - 1; j >= 0; --j) {
-    const int i = (o.head + j) % kLbfgsM;
-    const double sy = o.S[i][0] * o.Y[i][0] + o.S[i][1] * o.Y[i][1] + o.S[i][2] * o.Y[i][2];
-    alpha[j] = (o.S[i][0] * q[0] + o.S[i][1] * q[1] + o.S[i][2] * q[2]) / sy;
-    for (int c = 0; c < 3; ++c) q[c] -= alpha[j] * o.Y[i][c];
-  }
-  for (int c = 0; c < 3; ++c) q[c] /= o.theta;
-  for (int j = 0; j < o.col; ++j) {
-    const int i = (o.head + j) % kLbfgsM;
-    const double sy = o.S[i][0] * o.Y[i][0] + o.S[i][1] * o.Y[i][1] + o.S[i][2] * o.Y[i][2];
-    const double beta = (o.Y[i][0] * q[0] + o.Y[i][1] * q[1] + o.Y[i][2] * q[2]) / sy;
-    for (int c = 0; c < 3; ++c) q[c] += o.S[i][c] * (alpha[j] - beta);
-  }
-  for (int c = 0; c < 3; ++c) o.d[c] = -q[c];
+// Everything of the optimiser's state that the likelihood pass does not need (all but x, col, head and the flags) is PARKED
+// while the pass runs — on the device in LDS (kParkDoubles x 64 lanes x 8 B = 14.5 KB per wavefront: with the 4.5 KB staging
+// buffer eight wavefronts per CU still fit), on the host twin in an array — and fetched back at the start of lbfgs_deliver: the
+// pass has the registers to itself and nothing of the step's state is spilled to scratch memory (a reload from there costs a
+// memory round trip; as members of one long-lived struct the fields also stayed live around the loop on the idle-lane path).
+static constexpr int kParkDoubles = 29;
+TAD_HD inline void lbfgs_park(const Lbfgs &o) {
+  double *m = o.park;
+  const size_t st = o.pstride;
+  const uint64_t ints = (uint64_t)(uint16_t)o.iter | (uint64_t)(uint16_t)o.ifun << 16 | (uint64_t)(uint16_t)o.iback << 32 | (uint64_t)(uint16_t)o.nit << 48;
+  const uint64_t flags = (o.in_ls ? 1u : 0u) | (o.ls.brackt ? 2u : 0u) | (uint64_t)(uint32_t)o.ls.stage << 8;
+  const double v[kParkDoubles] = {o.d[0], o.d[1], o.d[2], o.t[0], o.t[1], o.t[2], o.r[0], o.r[1], o.r[2],
+                                  o.fold, o.gdold, o.stp, o.theta, o.fcold,
+                                  o.ls.stx, o.ls.fx, o.ls.gx, o.ls.sty, o.ls.fy, o.ls.gy, o.ls.stmin, o.ls.stmax, o.ls.width, o.ls.width1,
+                                  o.ls.finit, o.ls.ginit, o.ls.gtest, tad_dm_f64(ints), tad_dm_f64(flags)};
+#pragma unroll
+  for (int i = 0; i < kParkDoubles; ++i) m[(size_t)i * st] = v[i];
 }
+TAD_HD inline void lbfgs_unpark(Lbfgs &o) {
+  const double *m = o.park;
+  const size_t st = o.pstride;
+  double v[kParkDoubles];
+#pragma unroll
+  for (int i = 0; i < kParkDoubles; ++i) v[i] = m[(size_t)i * st];
+  o.d[0] = v[0]; o.d[1] = v[1]; o.d[2] = v[2]; o.t[0] = v[3]; o.t[1] = v[4]; o.t[2] = v[5]; o.r[0] = v[6]; o.r[1] = v[7]; o.r[2] = v[8];
+  o.fold = v[9]; o.gdold = v[10]; o.stp = v[11]; o.theta = v[12]; o.fcold = v[13];
+  o.ls.stx = v[14]; o.ls.fx = v[15]; o.ls.gx = v[16]; o.ls.sty = v[17]; o.ls.fy = v[18]; o.ls.gy = v[19]; o.ls.stmin = v[20]; o.ls.stmax = v[21];
+  o.ls.width = v[22]; o.ls.width1 = v[23]; o.ls.finit = v[24]; o.ls.ginit = v[25]; o.ls.gtest = v[26];
+  const uint64_t ints = tad_dm_u64(v[27]), flags = tad_dm_u64(v[28]);
+  o.iter = (int)(ints & 0xffff); o.ifun = (int)(ints >> 16 & 0xffff); o.iback = (int)(ints >> 32 & 0xffff); o.nit = (int)(ints >> 48);
+  o.in_ls = (flags & 1) != 0; o.ls.brackt = (flags & 2) != 0; o.ls.stage = (int)(flags >> 8);
+}
+static constexpr int kHistDoubles = kLbfgsM * 6;   // doubles of (s, y) history per lane in global memory
 
-#endif
+
 // forward-difference point of scipy's approx_derivative(method='2-point', abs_step=1e-5): x + 1e-5, unless that does not
 // change x (|x| > ~1e11: the huge sigma parameters of void Box-Cox regimes) — then the relative step sqrt(eps) * sign(x) *
 // max(1, |x|) (scipy/optimize/_numdiff.py: "cannot have a zero step ... fall back to relative step").  Returns x + h.
@@ -677,12 +700,12 @@ TAD_HD inline double fd_point(double x0, double *dx) {
 }
 
 // begin a line search from the current (x, f, g); sets the first trial point in x
-TAD_HD void lbfgs_begin_ls(Lbfgs &o) {
+TAD_HD void lbfgs_begin_ls(Lbfgs &o, const LbfgsHist &h) {
   for (;;) {
-    lbfgs_direction(o);
-    o.dtd = o.d[0] * o.d[0] + o.d[1] * o.d[1] + o.d[2] * o.d[2];
-    o.dnorm = sqrt(o.dtd);
-    o.stp = o.iter == 0 ? fmin(1.0 / o.dnorm, 1e10) : 1.0;
+    lbfgs_direction(o, h);
+    const double dtd = o.d[0] * o.d[0] + o.d[1] * o.d[1] + o.d[2] * o.d[2];
+    const double dnorm = sqrt(dtd);
+    o.stp = o.iter == 0 ? fmin(1.0 / dnorm, 1e10) : 1.0;
     for (int i = 0; i < 3; ++i) { o.t[i] = o.x[i]; o.r[i] = o.g[i]; }
     o.fold = o.f;
     o.fcold = o.fc;
@@ -695,7 +718,7 @@ TAD_HD void lbfgs_begin_ls(Lbfgs &o) {
     if (task == LS_FG) break;
     // ascent direction / bad step: info != 0
     if (o.col == 0) { o.done = true; return; }  // ABNORMAL_TERMINATION_IN_LNSRCH (x, f already the old iterate)
-    o.col = 0; o.theta = 1.0; TAD_LBFGS_RESET_HEAD(o);          // refresh the memory and restart with steepest descent
+    o.col = 0; o.head = 0; o.theta = 1.0;          // refresh the memory and restart with steepest descent
   }
   o.ifun = 1;
   o.iback = 0;
@@ -703,13 +726,13 @@ TAD_HD void lbfgs_begin_ls(Lbfgs &o) {
   o.in_ls = true;
 }
 
-// (f, g) at o.x have just been delivered
-TAD_HD void lbfgs_deliver(Lbfgs &o, int maxiter) {
+// (the inner function; lbfgs_deliver below wraps it in the unpark / park of the state)
+TAD_HD void lbfgs_deliver_core(Lbfgs &o, LbfgsHist &h, int maxiter) {
   const double pgtol = 1e-5, factr = 1e7;
   if (!o.in_ls) {  // first evaluation
     const double sbg = fmax(fabs(o.g[0]), fmax(fabs(o.g[1]), fabs(o.g[2])));
     if (sbg <= pgtol) { o.done = true; return; }
-    lbfgs_begin_ls(o);
+    lbfgs_begin_ls(o, h);
     return;
   }
   o.gd = o.g[0] * o.d[0] + o.g[1] * o.d[1] + o.g[2] * o.d[2];
@@ -722,9 +745,9 @@ TAD_HD void lbfgs_deliver(Lbfgs &o, int maxiter) {
       o.f = o.fold;
       o.fc = o.fcold;
       if (o.col == 0) { o.done = true; return; }
-      o.col = 0; o.theta = 1.0; TAD_LBFGS_RESET_HEAD(o);
+      o.col = 0; o.head = 0; o.theta = 1.0;
       o.in_ls = false;  // restart from the restored iterate
-      lbfgs_begin_ls(o);
+      lbfgs_begin_ls(o, h);
       return;
     }
     for (int i = 0; i < 3; ++i) o.x[i] = o.stp == 1.0 ? o.t[i] + o.d[i] : o.stp * o.d[i] + o.t[i];
@@ -738,6 +761,7 @@ TAD_HD void lbfgs_deliver(Lbfgs &o, int maxiter) {
   if (sbg <= pgtol) { o.done = true; return; }
   const double ddum0 = fmax(fabs(o.fold), fmax(fabs(o.f), 1.0));
   if ((o.fold - o.f) <= kEpsMch * factr * ddum0) { o.done = true; return; }
+  lbfgs_load_hist(o, h);   // (here, not at the start of the step: the 60 values are not live during the line-search arithmetic above)
   // BFGS update
   double rr = 0.0;
   for (int i = 0; i < 3; ++i) { o.r[i] = o.g[i] - o.r[i]; rr += o.r[i] * o.r[i]; }
@@ -745,30 +769,68 @@ TAD_HD void lbfgs_deliver(Lbfgs &o, int maxiter) {
   if (o.stp == 1.0) { dr = o.gd - o.gdold; ddum = -o.gdold; }
   else { dr = (o.gd - o.gdold) * o.stp; for (int i = 0; i < 3; ++i) o.d[i] *= o.stp; ddum = -o.gdold * o.stp; }
   if (!(dr <= kEpsMch * ddum)) {
-#if !defined(TAD_LBFGS_DYNAMIC)
-    if (o.col == kLbfgsM) {   // full: drop the oldest pair
+    int slot;
+    if (o.col < kLbfgsM) { slot = o.head + o.col; if (slot >= kLbfgsM) slot -= kLbfgsM; }
+    else {   // full: the oldest pair is overwritten; the logical order moves up by one
+      slot = o.head;
+      o.head = o.head + 1 == kLbfgsM ? 0 : o.head + 1;
 #pragma unroll
       for (int j = 0; j + 1 < kLbfgsM; ++j)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { o.S[j][i] = o.S[j + 1][i]; o.Y[j][i] = o.Y[j + 1][i]; }
+        for (int i = 0; i < 3; ++i) { h.S[j][i] = h.S[j + 1][i]; h.Y[j][i] = h.Y[j + 1][i]; }
       o.col = kLbfgsM - 1;
     }
+    for (int i = 0; i < 3; ++i) { lbfgs_hist(o, slot, 0, i) = o.d[i]; lbfgs_hist(o, slot, 1, i) = o.r[i]; }
 #pragma unroll
     for (int j = 0; j < kLbfgsM; ++j)
       if (j == o.col)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { o.S[j][i] = o.d[i]; o.Y[j][i] = o.r[i]; }
+        for (int i = 0; i < 3; ++i) { h.S[j][i] = o.d[i]; h.Y[j][i] = o.r[i]; }
     o.col++;
-#else
-    int slot;
-    if (o.col < kLbfgsM) { slot = (o.head + o.col) % kLbfgsM; o.col++; }
-    else { slot = o.head; o.head = (o.head + 1) % kLbfgsM; }
-    for (int i = 0; i < 3; ++i) { o.S[slot][i] = o.d[i]; o.Y[slot][i] = o.r[i]; }
-#endif
     o.theta = rr / dr;
   }
   o.in_ls = false;
-  lbfgs_begin_ls(o);
+  lbfgs_begin_ls(o, h);
+}
+
+// What a lane keeps in REGISTERS between optimiser steps (across the likelihood pass): the point to evaluate, the history's
+// shape and where its state block is.  Everything else is local to lbfgs_deliver — declared there, so that it is provably dead
+// during the pass (as members of one long-lived struct the fields stayed live on the idle-lane path around the loop and the
+// compiler spilled them, one memory round trip per reload).
+struct LbfgsLive {
+  double x[3];
+  double fc;       // forecast of the accepted iterate (valid once done)
+  double *hist;    // this lane's (s, y) history: kHistDoubles doubles, element stride hstride
+  uint32_t hstride;
+  double *park;    // this lane's parked state: kParkDoubles doubles, element stride pstride
+  uint32_t pstride;
+  int col, head;
+  bool done;
+};
+
+// a fresh fit: start parameters in x; the parked state says "first evaluation"
+TAD_HD inline void lbfgs_reset(LbfgsLive &L, double u0, double u1, double u2) {
+  L.x[0] = u0; L.x[1] = u1; L.x[2] = u2;
+  L.fc = 0.0; L.col = 0; L.head = 0; L.done = false;
+  Lbfgs o{};
+  o.park = L.park; o.pstride = L.pstride;
+  o.theta = 1.0; o.in_ls = false;
+  lbfgs_park(o);
+}
+
+// (f, g, forecast) at L.x have just been delivered: one optimiser step.  The parked state and the whole history come in as one
+// batch of independent loads; the step's state goes back (the new (s, y) pair is written by the update itself).
+TAD_HD void lbfgs_deliver(LbfgsLive &L, double f, const double (&g)[3], double fc, int maxiter) {
+  Lbfgs o;
+  LbfgsHist h;
+  o.hist = L.hist; o.hstride = L.hstride; o.park = L.park; o.pstride = L.pstride; o.col = L.col; o.head = L.head; o.done = false;
+  lbfgs_unpark(o);
+  for (int i = 0; i < 3; ++i) { o.x[i] = L.x[i]; o.g[i] = g[i]; }
+  o.f = f; o.fc = fc;
+  lbfgs_deliver_core(o, h, maxiter);
+  lbfgs_park(o);
+  for (int i = 0; i < 3; ++i) L.x[i] = o.x[i];
+  L.fc = o.fc; L.col = o.col; L.head = o.head; L.done = o.done;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -800,6 +862,8 @@ __global__ __launch_bounds__(64) void k_arima_start(Grid g, ArimaWs ws, const ui
 // ------------------------------------------------------------------------------------------------
 static constexpr int kStage = 8;  // time steps staged per round: 64 B per row
 
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #if defined(TAD_ARIMA_PROF)
 // profiling build (tools/gpu_arima_prof.sh; never the shipped library): shader-clock cycles per wavefront spent in the
 // likelihood pass / the optimiser step / refill, summed over all wavefronts
@@ -813,7 +877,7 @@ __device__ unsigned long long g_arima_prof[8];
 
 __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double *__restrict__ sigma,
                                                const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax, uint32_t chunk,
-                                               double *__restrict__ calc, DevCounters *ctr, double *buf) {
+                                               double *__restrict__ calc, DevCounters *ctr, double *buf, double *park) {
   const uint32_t nchunks = (uint32_t)((g.K + chunk - 1) / chunk);
   const uint32_t p = pmax - 1 - blockIdx.x / nchunks;           // heaviest (longest history) positions first
   const uint64_t c0 = (uint64_t)(blockIdx.x % nchunks) * chunk;
@@ -826,9 +890,13 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
 #if defined(TAD_ARIMA_PROF)
   unsigned long long prof[4] = {0, 0, 0, 0};
 #endif
-  Lbfgs o;
-  o.done = true;
-  o.col = 0;
+  LbfgsLive o;
+  o.x[0] = 0.0; o.x[1] = 0.0; o.x[2] = 1.0;
+  o.fc = 0.0; o.col = 0; o.head = 0; o.done = true;
+  o.hist = ws.hist + (size_t)blockIdx.x * (kHistDoubles * 64) + lane;   // this wavefront's block of global memory, lanes interleaved
+  o.hstride = 64;
+  o.park = park + lane;                                                  // LDS, lanes interleaved: conflict-free
+  o.pstride = 64;
   size_t row[4] = {0, 0, 0, 0};                                 // element offset of the rows this lane loads for the wavefront
 
   auto refill = [&]() {
@@ -841,9 +909,7 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
         k = cand;
         busy = true;
         const size_t c = (size_t)p * g.K + k;
-        o.x[0] = ws.u0[0][c]; o.x[1] = ws.u0[1][c]; o.x[2] = ws.u0[2][c];
-        o.col = 0; TAD_LBFGS_RESET_HEAD(o); o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false;
-        o.f = 0.0; o.fc = 0.0; o.fcold = 0.0;
+        lbfgs_reset(o, ws.u0[0][c], ws.u0[1][c], ws.u0[2][c]);
       }
     }
     const unsigned long long mine = busy ? (unsigned long long)k : 0ull;   // idle lanes: row 0 (valid memory, values unused)
@@ -860,17 +926,27 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
       if (!busy) s4[c].conv = true;   // an idle lane must not keep the wavefront in the covariance-updating loop
     }
     double yprev = 0.0;
+    // The rows of the NEXT stage are requested before this stage's steps run (two register sets of 4 x 16 B): the recursion
+    // used to wait out a full memory round trip every eight steps.  The barriers order LDS only (one wavefront per workgroup;
+    // __syncthreads() would also wait for the loads just issued).
+    double2 vn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vn[j] = *reinterpret_cast<const double2 *>(ws.ysk + row[j]);
     for (uint32_t t0 = 0; t0 < p; t0 += kStage) {
       double2 v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const double2 *>(ws.ysk + row[j] + t0);
-      __syncthreads();   // (one wavefront per workgroup) the previous round's reads are done
+      for (int j = 0; j < 4; ++j) v[j] = vn[j];
+      if (t0 + kStage < p) {   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vn[j] = *reinterpret_cast<const double2 *>(ws.ysk + row[j] + t0 + kStage);
+      }
+      lds_only_barrier();   // the previous round's reads are done
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         double *d = buf + (size_t)(j * 16 + (int)(lane >> 2)) * (kStage + 1) + (lane & 3u) * 2u;
         d[0] = v[j].x; d[1] = v[j].y;
       }
-      __syncthreads();
+      lds_only_barrier();
       double yv[kStage];
 #pragma unroll
       for (int i = 0; i < kStage; ++i) yv[i] = buf[(size_t)lane * (kStage + 1) + i];
@@ -913,11 +989,10 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     TAD_PROF_T(t_b);
     if (busy) {
       steps += 4ull * p;
+      double gr[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) o.g[i] = (nll[i + 1] - nll[0]) / dx[i];
-      o.f = nll[0];
-      o.fc = fc0;
-      lbfgs_deliver(o, maxiter);
+      for (int i = 0; i < 3; ++i) gr[i] = (nll[i + 1] - nll[0]) / dx[i];
+      lbfgs_deliver(o, nll[0], gr, fc0, maxiter);
       if (o.done) {
         const size_t st = g.K;
         const uint64_t c = (uint64_t)ws.tpos[(size_t)p * st + k] * g.K + k;
@@ -947,18 +1022,26 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
 
 // Two wavefronts per SIMD (256 VGPRs each): measured at C3 on MI355X 0.53 s against 0.63 s at three (168 VGPRs) and 1.43 s at
 // four (128 VGPRs: the step loop spills) — profiles/r3_v0_queued_ab_c3.log.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_arima_fit(
+#if !defined(TAD_ARIMA_WAVES)
+#define TAD_ARIMA_WAVES 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAD_ARIMA_WAVES, TAD_ARIMA_WAVES))) void k_arima_fit(
     Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,
     uint32_t chunk, double *__restrict__ calc, DevCounters *ctr) {
   __shared__ double buf[64 * (kStage + 1)];
-  arima_fit_body(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf);
+  __shared__ double park[64 * kParkDoubles];
+  arima_fit_body(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf, park);
 }
 
 static uint32_t arima_tpad(uint64_t T) { return (uint32_t)((T + kStage - 1) / kStage * kStage); }
 
+static constexpr uint32_t kArimaChunk = 4096;   // keys per wavefront and position: ~64 fits per lane (measured: 256 -> 1.48 s, 1024 -> 1.28 s, 4096 -> 1.22 s at C3)
+static uint64_t arima_fit_blocks(Grid g) { return g.T > 3 ? ((g.K + kArimaChunk - 1) / kArimaChunk) * (g.T - 3) : 0; }
+
 size_t arima_workspace_bytes(Grid g) {
   const size_t cells = (size_t)g.K * g.T;
-  return cells * (8 * 3 + 8 * 3 + 4) + (size_t)g.K * arima_tpad(g.T) * 8 + (size_t)g.K * 9 + 512;
+  return cells * (8 * 3 + 8 * 3 + 4) + (size_t)g.K * arima_tpad(g.T) * 8 + (size_t)g.K * 9 + 512 +
+         (size_t)arima_fit_blocks(g) * (kHistDoubles * 64 * 8) + 512;   // + the L-BFGS history block of every wavefront of k_arima_fit (30 KB each)
 }
 
 int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc,
@@ -976,15 +1059,15 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
   ws.ysk = reinterpret_cast<double *>(w); w += (size_t)g.K * ws.Tpad * 8;
   ws.lam = reinterpret_cast<double *>(w); w += (size_t)g.K * 8;
   ws.tpos = reinterpret_cast<uint32_t *>(w); w += cells * 4;
-  ws.state = w;
+  ws.state = w; w += ((size_t)g.K + 511) & ~(size_t)511;
+  ws.hist = reinterpret_cast<double *>(w);
   hipLaunchKernelGGL(k_arima_prep, dim3((unsigned)((g.K + 255) / 256)), dim3(256), 0, s, g, ws, sigma, calc, ctr);
   if (g.T > 3) {
     const uint64_t kblocks = (g.K + 63) / 64;
     if (kblocks * (g.T - 3) > 0x7FFFFFFFull) return -1;
     hipLaunchKernelGGL(k_arima_start, dim3((unsigned)(kblocks * (g.T - 3))), dim3(64), 0, s, g, ws, n_pts, (uint32_t)g.T);
-    const uint32_t chunk = 4096;   // keys per wavefront and position: ~64 fits per lane (measured: 256 -> 1.48 s, 1024 -> 1.28 s, 4096 -> 1.22 s at C3)
-    const uint64_t nchunks = (g.K + chunk - 1) / chunk;
-    const uint64_t blocks = nchunks * (g.T - 3);
+    const uint32_t chunk = kArimaChunk;
+    const uint64_t blocks = arima_fit_blocks(g);
     if (blocks > 0x7FFFFFFFull) return -1;
     hipLaunchKernelGGL(k_arima_fit, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, chunk, calc, ctr);
 #if defined(TAD_ARIMA_PROF)

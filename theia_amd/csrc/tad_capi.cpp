@@ -69,6 +69,7 @@ struct tad_state {
 namespace {
 
 constexpr int kMetaBlocks = 2048;
+constexpr int kSampleBlockShift = 7;   // (C4 with 1024-key blocks and a sampled histogram: pass A 0.21 -> 0.10 ms but pass C 0.68 -> 0.86 ms, profiles/r3_v2_c4_keyblock_ab.log)
 
 bool plan_ok(const tad_plan &p) {
   return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 2 && p.histogram >= 0 && p.histogram <= 1 && p.sparse >= 0 &&
@@ -619,7 +620,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
                                       // 128-key block is expected to hold a few hundred records
                                       // (lat_mode 2 re-derives the lattice with k_meta, which reuses the partials buffer the sampling ratios live in)
                                       !force_exact_hist && lat_mode != 2 && sampled_slots_bound(n * (has2 ? 2 : 1), pl) < (1ull << 32) &&
-                                          n * (has2 ? 2 : 1) / ((uint64_t)pl.G * ((K >> 7) ? (K >> 7) : 1)) >= 384);
+                                          n * (has2 ? 2 : 1) / ((uint64_t)pl.G * ((K >> kSampleBlockShift) ? (K >> kSampleBlockShift) : 1)) >= 384);
       meta_blocks = pl.G;
     }
     if (!hinted && !empty && (!v2 || lat_mode == 2)) {
@@ -667,7 +668,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     uint64_t cells = empty ? 0 : K * L.nb;
     const bool cells_overflow = !empty && L.nb != 0 && cells / L.nb != K;
     // (ARIMA: predictions + 60 B per cell of workspace, arima_workspace_bytes; DROP: one double per cell)
-    uint64_t need = cells * 9 + (jp.algo == TAD_ALGO_ARIMA ? cells * 68 : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
+    uint64_t need = cells * 9 + (jp.algo == TAD_ALGO_ARIMA ? cells * 76 + (1ull << 22) : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
     // Sparse tables (few points per key on a fine lattice: second-resolution timestamps, per-connection keys): the dense
     // K x T grid would be mostly empty or not fit at all — sort the rows by (key, time) instead and lay each key's points
     // out by rank (tad_sparse.hip).  Chosen when the rows could fill at most 1/8 of a large grid, or the grid does not fit.
@@ -709,7 +710,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         HIP_TRY(e, hipStreamSynchronize(s));
       }
       cells = K * (uint64_t)tmax;
-      need = cells * 17 + (jp.algo == TAD_ALGO_ARIMA ? cells * 68 : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
+      need = cells * 17 + (jp.algo == TAD_ALGO_ARIMA ? cells * 76 + (1ull << 22) : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
       // Skewed series lengths (one key with a day of seconds next to many short-lived ones): K x Tmax does not fit although the
       // points do.  The keys are split into length classes that run as jobs of their own (run_sparse_classes).
       if (P && depth == 0 && (need > e->ws_limit || plan.sparse_classes == 1)) {

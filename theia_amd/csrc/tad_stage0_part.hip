@@ -1089,6 +1089,17 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
       if (parts_of(c) <= line_parts && (1ull << c) <= kTileCells && rounds_of(c) <= 2 * rounds_of(sp) && rounds_of(c) <= 4) sp = c;
     }
   }
+  // Too many partitions even for 64-byte sectors (the queues need >= 9 slots each: ~1770 partitions): one more doubling of the
+  // key block puts pass B on the write-combining kernel if pass C then needs at most 8 bucket rounds.  C4 (1e6 keys x 100
+  // buckets): 1954 partitions of 512 keys, sort-by-tile pass B 1.00-1.09 ms + pass C (3 rounds) 0.50 ms -> 977 of 1024 keys,
+  // write-combining pass B 0.78-0.81 ms + pass C (6 rounds) 0.69 ms: 2.14-2.29 -> 2.09-2.18 ms per job, same boxes
+  // (profiles/r3_v2_c4_keyblock_ab.log; 2048-key blocks: pass B 0.65 ms but 13 rounds, pass C 1.8 ms).
+  {
+    auto parts_of = [&](int c) { return (K + (1ull << c) - 1) >> c; };
+    auto rounds_of = [&](int c) { const uint64_t tb = kTileCells >> c; return tb ? (T + tb - 1) / tb : (uint64_t)1 << 30; };
+    const uint64_t sector_parts = kLdsBudget / (8 * 9 + 18);
+    if (parts_of(sp) > sector_parts && sp < 13 && parts_of(sp + 1) <= sector_parts && (1ull << (sp + 1)) <= kTileCells && rounds_of(sp + 1) <= 8) ++sp;
+  }
   if ((1ull << sp) > kTileCells) return false;                 // one bucket of the block must fit a tile
   pl->shift_part = sp;
   pl->KP = 1u << sp;

@@ -8,18 +8,20 @@
 using namespace tad;
 
 static double twin_fit(const double *y, uint32_t p, int maxiter, unsigned long long *steps) {
-  Lbfgs o;
-  o.col = 0; o.iter = 0; o.nit = 0; o.theta = 1.0; o.in_ls = false; o.done = false; o.f = 0.0; o.fc = 0.0; o.fcold = 0.0;
-  arima_start_params(y, 1, p, o.x);
+  LbfgsLive o;
+  double hist[kHistDoubles], park[kParkDoubles];
+  double u[3];
+  o.hist = hist; o.hstride = 1; o.park = park; o.pstride = 1;
+  arima_start_params(y, 1, p, u);
+  lbfgs_reset(o, u[0], u[1], u[2]);
   while (!o.done) {
-    double xe[4][3], dx[3], nll[4], fc0 = 0.0;
+    double xe[4][3], dx[3], nll[4], fc0 = 0.0, g[3];
     for (int c = 0; c < 4; ++c) { xe[c][0] = o.x[0]; xe[c][1] = o.x[1]; xe[c][2] = o.x[2]; }
     for (int i = 0; i < 3; ++i) xe[i + 1][i] = fd_point(xe[i + 1][i], &dx[i]);
     arima_nll4_collapsed(xe, y, 1, p, nll, fc0);            // the four recursions jointly (batched inversion)
     *steps += 4ull * p;
-    for (int i = 0; i < 3; ++i) o.g[i] = (nll[i + 1] - nll[0]) / dx[i];
-    o.f = nll[0]; o.fc = fc0;
-    lbfgs_deliver(o, maxiter);
+    for (int i = 0; i < 3; ++i) g[i] = (nll[i + 1] - nll[0]) / dx[i];
+    lbfgs_deliver(o, nll[0], g, fc0, maxiter);
   }
   return o.fc;
 }
