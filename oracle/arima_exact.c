@@ -33,7 +33,8 @@
 #include "tad_detmath.h"
 
 #define DIFFUSE 1e6          /* statsmodels: initial_variance of the approximate diffuse prior */
-#define CONV_TOL 1e-19       /* statsmodels: KalmanFilter.tolerance */
+#define CONV_TOL 1e-19       /* statsmodels: KalmanFilter.tolerance on ||P_t - P_t+1||_F^2 */
+#define CONV_TOL_ABS 3.1622776601683794e-10   /* its square root: the contract's test on |p_t - p_t+1| (only p11 evolves) */
 #define LOG_2PI 1.8378770664093453
 #define EPSMCH 2.220446049250313e-16
 #define LBFGS_M 10
@@ -232,7 +233,9 @@ static double arima_nll_general(const double u[3], const double *y, long n, doub
  * The optimiser always needs the objective at x and at the three forward-difference points together, so the contract
  * evaluates the FOUR recursions jointly and takes the four reciprocals 1 / F from ONE division (batched inversion:
  * inv = 1 / (F0 F1 F2 F3), r0 = inv (F2 F3) F1, ...): IEEE operations in a fixed order like everything else, a quarter
- * of the divisions. */
+ * of the divisions.  Round 3: the three multiply-adds of a chain are IEEE fma (q, a1, p'), the running product of the F_t is
+ * renormalised after every fourth step (t & 3 == 0), the convergence test is |p_t - p_t+1| < sqrt(1e-19) — expression for
+ * expression what tad_arima.hip:kfc_step4 executes. */
 static void arima_nll4_collapsed(const double u4[4][3], const double *y, long n, double nll[4], double *forecast) {
   double phi[4], q12[4], qs[4], p[4], a1[4], F[4], r[4], g[4], prod[4], q[4], yprev = 0.0;
   int esum[4], conv[4], c;
@@ -257,6 +260,7 @@ static void arima_nll4_collapsed(const double u4[4][3], const double *y, long n,
   if (n >= 1) yprev = y[0];
   for (t = 1; t < n; ++t) {
     const double d = y[t] - yprev;
+    const int renorm = (t & 3) == 0;      /* the product is renormalised after every fourth step (exact scaling by 2^-e) */
     double Fn[4], rn[4];
     for (c = 0; c < 4; ++c) Fn[c] = conv[c] ? F[c] : p[c];
     {
@@ -270,13 +274,14 @@ static void arima_nll4_collapsed(const double u4[4][3], const double *y, long n,
       double w;
       if (!conv[c]) { F[c] = Fn[c]; r[c] = rn[c]; g[c] = q12[c] * r[c]; }
       w = r[c] * v;
-      q[c] += v * w;
-      if (!conv[c]) { int e; prod[c] = tad_det_frexp(prod[c] * F[c], &e); esum[c] += e; }
+      q[c] = fma(v, w, q[c]);
+      if (!conv[c]) prod[c] = prod[c] * F[c];
       else nconv[c]++;
-      a1[c] = phi[c] * (a1[c] + v) + g[c] * v;
+      if (renorm) { int e; prod[c] = tad_det_frexp(prod[c], &e); esum[c] += e; }
+      a1[c] = fma(g[c], v, phi[c] * (a1[c] + v));
       if (!conv[c]) {
-        const double pn = qs[c] - q12[c] * g[c], dp = p[c] - pn;
-        conv[c] = dp * dp < CONV_TOL;
+        const double pn = fma(-q12[c], g[c], qs[c]), dp = p[c] - pn;
+        conv[c] = fabs(dp) < CONV_TOL_ABS;
         p[c] = pn;
       }
     }

@@ -36,7 +36,8 @@
 namespace tad {
 
 static constexpr double kDiffuse = 1e6;
-static constexpr double kConvTol = 1e-19;
+static constexpr double kConvTol = 1e-19;                   // statsmodels: KalmanFilter.tolerance on ||P_t - P_t+1||_F^2
+static constexpr double kConvTolAbs = 3.1622776601683794e-10;  // its square root: the test on |p_t - p_t+1| (only p11 evolves)
 static constexpr double kLog2Pi = 1.8378770664093453;  // log(2*pi)
 static constexpr double kEpsMch = 2.220446049250313e-16;
 static constexpr int kLbfgsM = 10;
@@ -301,8 +302,13 @@ TAD_HD inline void kfc_recip4(const double (&F)[4], double (&r)[4]) {
   r[0] = i12 * F[1]; r[1] = i12 * F[0]; r[2] = i34 * F[3]; r[3] = i34 * F[2];
 }
 
-// t >= 1, d = y_t - y_t-1; no chain of any lane of the wavefront has converged
-TAD_HD inline void kfc_step4_nc(KfStateC (&s)[4], double d) {
+// One time step t >= 1 of the four recursions, d = y_t - y_t-1.  Contract details (round 3; oracle/arima_exact.c:arima_nll4_collapsed
+// states the same expressions): the three multiply-adds of a chain are FUSED (IEEE fma: q, a1, p'), the running product of
+// the F_t is renormalised after every fourth step only (t & 3 == 0: an exact scaling by a power of two, so the product's bits
+// are those of renormalising every step as long as four factors stay in range) and the convergence test
+// ||P_t - P_t+1||_F^2 < 1e-19 is taken as |p_t - p_t+1| < sqrt(1e-19) (only p11 evolves).  115 -> 78 instructions per step.
+// RENORM = (t & 3) == 0: a constant in every unrolled step of the device loop (the 8-step stages start at multiples of 8).
+TAD_HD inline void kfc_step4_nc(KfStateC (&s)[4], double d, const bool RENORM) {   // no chain of any lane of the wavefront has converged
   double F[4], r[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) F[c] = s[c].p;
@@ -312,19 +318,18 @@ TAD_HD inline void kfc_step4_nc(KfStateC (&s)[4], double d) {
     const double v = d - s[c].a1;
     s[c].F = F[c]; s[c].r = r[c]; s[c].g = s[c].q12 * s[c].r;
     const double w = s[c].r * v;
-    s[c].q += v * w;
-    int e;
-    s[c].prod = kf_frexp(s[c].prod * s[c].F, &e);
-    s[c].esum += e;
-    s[c].a1 = s[c].phi * (s[c].a1 + v) + s[c].g * v;
-    const double pn = s[c].qs - s[c].q12 * s[c].g, dp = s[c].p - pn;
-    s[c].conv = dp * dp < kConvTol;
+    s[c].q = fma(v, w, s[c].q);
+    s[c].prod = s[c].prod * s[c].F;
+    if (RENORM) { int e; s[c].prod = kf_frexp(s[c].prod, &e); s[c].esum += e; }
+    s[c].a1 = fma(s[c].g, v, s[c].phi * (s[c].a1 + v));
+    const double pn = fma(-s[c].q12, s[c].g, s[c].qs), dp = s[c].p - pn;
+    s[c].conv = fabs(dp) < kConvTolAbs;
     s[c].p = pn;
   }
 }
 
-// the same step with per-chain predication (a converged chain keeps F, r, g; its frozen F still enters the product)
-TAD_HD inline void kfc_step4(KfStateC (&s)[4], double d) {
+// the same step with per-chain predication (a converged chain keeps F, r, g; its frozen F still enters the joint inversion)
+TAD_HD inline void kfc_step4(KfStateC (&s)[4], double d, const bool RENORM) {
   double F[4], r[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) F[c] = s[c].conv ? s[c].F : s[c].p;
@@ -334,24 +339,17 @@ TAD_HD inline void kfc_step4(KfStateC (&s)[4], double d) {
     const double v = d - s[c].a1;
     if (!s[c].conv) { s[c].F = F[c]; s[c].r = r[c]; s[c].g = s[c].q12 * s[c].r; }
     const double w = s[c].r * v;
-    s[c].q += v * w;
-    if (!s[c].conv) { int e; s[c].prod = kf_frexp(s[c].prod * s[c].F, &e); s[c].esum += e; }
+    s[c].q = fma(v, w, s[c].q);
+    if (!s[c].conv) s[c].prod = s[c].prod * s[c].F;
     else s[c].nconv++;
-    s[c].a1 = s[c].phi * (s[c].a1 + v) + s[c].g * v;
+    if (RENORM) { int e; s[c].prod = kf_frexp(s[c].prod, &e); s[c].esum += e; }   // (a converged chain's product is already a mantissa: e = 0)
+    s[c].a1 = fma(s[c].g, v, s[c].phi * (s[c].a1 + v));
     if (!s[c].conv) {
-      const double pn = s[c].qs - s[c].q12 * s[c].g, dp = s[c].p - pn;
-      s[c].conv = dp * dp < kConvTol;
+      const double pn = fma(-s[c].q12, s[c].g, s[c].qs), dp = s[c].p - pn;
+      s[c].conv = fabs(dp) < kConvTolAbs;
       s[c].p = pn;
     }
   }
-}
-
-TAD_HD inline void kfc_step_conv(KfStateC &s, double d) {
-  const double v = d - s.a1;
-  const double w = s.r * v;
-  s.q += v * w;
-  s.nconv++;
-  s.a1 = s.phi * (s.a1 + v) + s.g * v;
 }
 
 TAD_HD inline KfOut kfc_finish(const KfStateC &s, uint32_t n, double ylast) {
@@ -376,7 +374,7 @@ TAD_HD void arima_nll4_collapsed(const double (&xe)[4][3], const double *__restr
   }
   for (uint32_t t = 1; t < n; ++t) {
     const double yt = y[(size_t)t * stride];
-    kfc_step4(s4, yt - yprev);
+    kfc_step4(s4, yt - yprev, (t & 3u) == 0);
     yprev = yt;
   }
   for (int c = 0; c < 4; ++c) {
@@ -962,8 +960,8 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
             for (int c = 0; c < 4; ++c) kfc_first(s4[c], yv[0]);
           } else {
             const bool any_conv = __any(s4[0].conv || s4[1].conv || s4[2].conv || s4[3].conv);
-            if (!any_conv) kfc_step4_nc(s4, d);
-            else kfc_step4(s4, d);
+            if (!any_conv) kfc_step4_nc(s4, d, (i & 3) == 0);   // t = t0 + i with t0 a multiple of 8: t & 3 == i & 3
+            else kfc_step4(s4, d, (i & 3) == 0);
           }
         }
     }
