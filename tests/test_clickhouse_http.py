@@ -27,7 +27,7 @@ class FakeClickHouse:
 
     def __init__(self):
         self.responses = {}
-        self.queries, self.inserted, self.auth = [], [], []
+        self.queries, self.inserted, self.auth, self.commands = [], [], [], []
         owner = self
 
         class Handler(BaseHTTPRequestHandler):
@@ -46,6 +46,9 @@ class FakeClickHouse:
                     owner.inserted.append((params["query"][0], rows))
                     self.send_response(200); self.end_headers(); return
                 sql = body.decode()
+                if sql.startswith("ALTER TABLE"):                      # a statement without a result set
+                    owner.commands.append(sql)
+                    self.send_response(200); self.end_headers(); return
                 owner.queries.append(sql)
                 assert sql.endswith(" FORMAT ArrowStream")
                 key = sql[: -len(" FORMAT ArrowStream")]

@@ -1,0 +1,198 @@
+"""theia_amd/controller.py — the in-process job runner against the reference controller's own tests:
+the invalid-spec table of pkg/controller/anomalydetector/controller_test.go:318-441 (exact messages), the argument vector
+of controller.go:525-623, the NEW -> SCHEDULED -> RUNNING -> COMPLETED / FAILED walk (controller.go:370-381), progress,
+finishJob's EndTime and cleanupTADetector's DELETE statement (controller.go:385-398).  CPU tests inject the job body; the
+`-m gpu` test runs the real engine between an in-process ClickHouse and the state machine."""
+import threading
+import uuid
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+
+from theia_amd import controller as ctl
+
+NS = "flow-visibility"
+
+
+def tad(name=None, **spec):
+    return ctl.ThroughputAnomalyDetector(name=name or "tad-" + str(uuid.uuid4()), namespace=NS, spec=ctl.ThroughputAnomalyDetectorSpec(**spec))
+
+
+# controller_test.go:318-441, one row per test case: (name, spec fields, expected message)
+NOW = datetime(2022, 8, 11, 7, 26, 54)
+INVALID = [
+    ("tad-invalid-job-type", dict(jobType="nonexistent-job-type"),
+     "invalid request: Throughput Anomaly Detector algorithm type should be 'EWMA' or 'ARIMA' or 'DBSCAN'"),
+    ("tad-invalid-end-interval", dict(jobType="ARIMA", startInterval=NOW + timedelta(seconds=10), endInterval=NOW),
+     "invalid request: EndInterval should be after StartInterval"),
+    ("tad-invalid-executor-instances", dict(jobType="ARIMA", executorInstances=-1),
+     "invalid request: ExecutorInstances should be an integer >= 0"),
+    ("tad-invalid-driver-core-request", dict(jobType="ARIMA", executorInstances=1, driverCoreRequest="m200"),
+     "invalid request: DriverCoreRequest should conform to the Kubernetes resource quantity convention"),
+    ("tad-invalid-driver-memory", dict(jobType="ARIMA", executorInstances=1, driverCoreRequest="200m", driverMemory="m512"),
+     "invalid request: DriverMemory should conform to the Kubernetes resource quantity convention"),
+    ("tad-invalid-executor-core-request", dict(jobType="ARIMA", executorInstances=1, driverCoreRequest="200m", driverMemory="512M",
+                                               executorCoreRequest="m200"),
+     "invalid request: ExecutorCoreRequest should conform to the Kubernetes resource quantity convention"),
+    ("tad-invalid-executor-memory", dict(jobType="ARIMA", executorInstances=1, driverCoreRequest="200m", driverMemory="512M",
+                                         executorCoreRequest="200m", executorMemory="m512"),
+     "invalid request: ExecutorMemory should conform to the Kubernetes resource quantity convention"),
+    ("tad-invalid-agg-flow-pod-podNamespace-combo", dict(jobType="ARIMA", aggFlow="pod", podNameSpace="podNameSpace", podName="", podLabel=""),
+     "invalid request: 'pod-namespace' argument can not be used alone"),
+    ("tad-invalid-agg-flow", dict(jobType="ARIMA", aggFlow="nonexistent-agg-flow"),
+     "invalid request: Throughput Anomaly Detector aggregated flow type should be 'pod' or 'external' or 'svc'"),
+]
+
+
+@pytest.fixture()
+def controller():
+    ran = []
+    c = ctl.AnomalyDetectorController(run_job=lambda args, t: ran.append(args), progress=lambda: (3, 5))
+    c.ran = ran
+    yield c
+    c.shutdown()
+
+
+@pytest.mark.parametrize("name,spec,msg", INVALID, ids=[c[0] for c in INVALID])
+def test_invalid_specs_fail_with_the_reference_messages(controller, name, spec, msg):
+    controller.create(tad(name, **spec))
+    got = controller.wait(NS, name, states=(ctl.STATE_FAILED,), timeout=10)
+    assert got.status.state == ctl.STATE_FAILED
+    assert msg in got.status.errorMsg and got.status.errorMsg.startswith("error in creating AnomalyDetector: ")   # controller.go:510
+    assert controller.ran == [] and got.status.sparkApplication == ""
+
+
+def test_name_must_be_tad_uuid(controller):
+    controller.create(tad("tad-not-a-uuid", jobType="EWMA"))
+    got = controller.wait(NS, "tad-not-a-uuid", states=(ctl.STATE_FAILED,), timeout=10)
+    assert "invalid request: Throughput Anomaly Detector Querier job name is invalid" in got.status.errorMsg
+
+
+def test_argument_vector_is_the_spark_applications():
+    jid = str(uuid.uuid4())
+    t = tad("tad-" + jid, jobType="DBSCAN", startInterval=datetime(2022, 8, 11, 7, 0, 0), endInterval=datetime(2022, 8, 11, 9, 30, 5),
+            nsIgnoreList=["kube-system", "flow-visibility"], aggFlow="pod", podLabel="app:web", podNameSpace="default")
+    assert ctl.job_arguments(t) == ["--algo", "DBSCAN", "--start_time", "2022-08-11 07:00:00", "--end_time", "2022-08-11 09:30:05",
+                                    "--ns-ignore-list", '["kube-system","flow-visibility"]', "--agg-flow", "pod", "--pod-label", "app:web",
+                                    "--pod-namespace", "default", "--id", jid]
+    assert ctl.job_arguments(tad("tad-" + jid, jobType="EWMA", aggFlow="svc", servicePortName="p")) == \
+        ["--algo", "EWMA", "--agg-flow", "svc", "--svc-port-name", "p", "--id", jid]
+    assert ctl.job_arguments(tad("tad-" + jid, jobType="ARIMA", aggFlow="external", externalIp="10.0.0.1")) == \
+        ["--algo", "ARIMA", "--agg-flow", "external", "--external-ip", "10.0.0.1", "--id", jid]
+    # an EndInterval alone is fine: a zero StartInterval is before everything (controller.go:537-541)
+    assert "--end_time" in ctl.job_arguments(tad("tad-" + jid, jobType="EWMA", endInterval=NOW))
+    # the argument vector is what the job's own command line accepts (anomaly_detection.py:781-870)
+    from theia_amd import anomaly_detection as ad
+    assert ad.RESULT_TABLE_NAME.endswith(ctl.RESULT_TABLE)
+    assert ctl.cleanup_query(jid) == "ALTER TABLE tadetector ON CLUSTER '{cluster}' DELETE WHERE id = (" + jid + ");"   # controller.go:396
+
+
+def test_states_progress_end_time_and_cleanup():
+    gate, seen_states, commands = threading.Event(), [], []
+
+    class FakeCH:
+        def command(self, sql):
+            commands.append(sql)
+
+    def job(args, t):
+        gate.wait(10)
+
+    c = ctl.AnomalyDetectorController(clickhouse=FakeCH(), run_job=job, progress=lambda: (3, 5))
+    try:
+        t = tad(jobType="EWMA", aggFlow="svc")
+        created = c.create(t)
+        assert created.status.state in ("", ctl.STATE_NEW, ctl.STATE_SCHEDULED, ctl.STATE_RUNNING)
+        running = c.wait(NS, t.name, states=(ctl.STATE_RUNNING,), timeout=10)
+        assert running.status.state == ctl.STATE_RUNNING and running.status.sparkApplication == t.name[4:]
+        assert running.status.startTime is not None and running.status.endTime is None
+        # RUNNING resources get CompletedStages / TotalStages from the progress source (controller.go:426-453)
+        for _ in range(200):
+            running = c.get(NS, t.name)
+            if running.status.totalStages:
+                break
+            threading.Event().wait(0.01)
+        assert (running.status.completedStages, running.status.totalStages) == (3, 5)
+        gate.set()
+        done = c.wait(NS, t.name, timeout=10)
+        assert done.status.state == ctl.STATE_COMPLETED and done.status.errorMsg == ""
+        assert done.status.startTime < done.status.endTime                      # controller_test.go:306
+        assert [x.name for x in c.list(NS)] == [t.name]                         # controller_test.go:308-311
+        c.delete(NS, t.name)                                                    # -> cleanupTADetector
+        assert commands == [ctl.cleanup_query(t.name[4:])]
+        assert c.list(NS) == []
+    finally:
+        gate.set()
+        c.shutdown()
+
+
+def test_a_failing_job_ends_failed_with_the_reference_wording():
+    def job(args, t):
+        raise RuntimeError("tad error -6: dense point grid needs 9 bytes")
+
+    c = ctl.AnomalyDetectorController(run_job=job, progress=lambda: (0, 4))
+    try:
+        t = tad(jobType="EWMA")
+        c.create(t)
+        got = c.wait(NS, t.name, states=(ctl.STATE_FAILED,), timeout=10)
+        assert got.status.state == ctl.STATE_FAILED
+        assert got.status.errorMsg == "Throughput Anomaly Detector job failed, state: FAILED, error message: tad error -6: dense point grid needs 9 bytes"
+    finally:
+        c.shutdown()
+
+
+def test_four_workers_run_jobs_concurrently():
+    """controller.go:199-201: 4 workers; four jobs are in flight at once (the engine serialises tad_run internally)."""
+    barrier = threading.Barrier(4, timeout=10)
+    c = ctl.AnomalyDetectorController(run_job=lambda a, t: barrier.wait(), progress=lambda: (0, 4))
+    try:
+        names = []
+        for _ in range(4):
+            t = tad(jobType="DBSCAN")
+            names.append(t.name)
+            c.create(t)
+        for n in names:
+            assert c.wait(NS, n, timeout=15).status.state == ctl.STATE_COMPLETED
+    finally:
+        c.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo,agg", [("EWMA", "svc"), ("DBSCAN", ""), ("ARIMA", "pod")])
+def test_job_walks_the_states_on_the_gpu_engine(engine, algo, agg):
+    """ClickHouse (in-process) -> controller -> tad_run on the MI355X -> rows in tadetector -> COMPLETED; the rows are the
+    oracle's (oracle/job_oracle.py), then delete -> the DELETE statement of the reference."""
+    from oracle import job_oracle as jo
+    from theia_amd import anomaly_detection as ad
+    from theia_amd import clickhouse as ch
+    from test_clickhouse_http import FakeClickHouse, arrow_table
+    server = FakeClickHouse()
+    c = None
+    try:
+        flows = jo.synth_flows(6000)
+        kw = dict(start_time="", end_time="", ns_ignore_list=[], agg_flow=agg, pod_label="app1" if agg == "pod" else "", external_ip="",
+                  svc_port_name="", pod_name="", pod_namespace="")
+        sql = ch.rows_query(kw["start_time"], kw["end_time"], kw["ns_ignore_list"], kw["agg_flow"], kw["pod_label"], kw["external_ip"],
+                            kw["svc_port_name"], kw["pod_name"], kw["pod_namespace"])
+        cols = sql[len("SELECT "):sql.index(" FROM ")].split(", ")
+        server.responses[sql] = arrow_table({name: flows[name] for name in cols})
+        client = ch.ClickHouseHTTP(server.url, user="", password="")
+        c = ctl.AnomalyDetectorController(clickhouse=client, engine=engine)
+        t = tad(jobType=algo, aggFlow=agg, podLabel=kw["pod_label"])
+        c.create(t)
+        done = c.wait(NS, t.name, timeout=120)
+        assert done.status.state == ctl.STATE_COMPLETED, done.status.errorMsg
+        assert done.status.totalStages == 4 and done.status.completedStages == 4 and done.status.startTime < done.status.endTime
+        want = jo.run(flows, algo, tad_id=t.name[4:], **kw)
+        got = [r for _, rows in server.inserted for r in rows]
+        assert len(got) == len(want) and len(got) > 0
+        assert sorted(float(r["throughput"]) for r in got) == sorted(float(r["throughput"]) for r in want)
+        assert sorted(float(r["algoCalc"]) for r in got) == sorted(float(r["algoCalc"]) for r in want)
+        assert all(r["id"] == t.name[4:] and r["algoType"] == algo for r in got)
+        assert all(r["anomaly"] == w["anomaly"] for r, w in zip(got[:1], want[:1]))
+        c.delete(NS, t.name)
+        assert server.commands == [ctl.cleanup_query(t.name[4:])]
+    finally:
+        if c is not None:
+            c.shutdown()
+        server.close()

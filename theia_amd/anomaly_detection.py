@@ -440,6 +440,16 @@ def write_anomaly_detection_result(result_rows_, destination, result_table_name=
     return tad_id
 
 
+def store_result_columns(client, cols, table=RESULT_TABLE_NAME):
+    """ref:713-726: append the result columns to default.tadetector — columnar (Arrow) insert, no per-row work on the host.
+    Returns the number of rows written (1 for the 'NO ANOMALY DETECTED' sentinel row, ref:395-420)."""
+    if len(cols["anomaly"]) == 1 and cols["anomaly"][0] != "true":   # the sentinel row: its DateTime fields are text
+        client.insert_rows([_db_row({k: (v[0].item() if hasattr(v[0], "item") else v[0]) for k, v in cols.items()})], table)
+        return 1
+    client.insert_columns(cols, table)
+    return len(cols["anomaly"])
+
+
 def _db_row(row):
     """A result row as ClickHouse's JSONEachRow wants it: DateTime columns as 'YYYY-MM-DD hh:mm:ss' (UTC)."""
     out = {k: row[k] for k in RESULT_COLUMNS if k in row}
@@ -575,11 +585,8 @@ def main(argv=None):
     t1 = time.time()
     if a["out"] or client is None:
         write_anomaly_detection_result(rows, sys.stdout if a["out"] in ("", "-") else a["out"], RESULT_TABLE_NAME, tad_id)
-    else:   # ref:713-726: append to default.tadetector — columnar (Arrow) insert, no per-row work on the host
-        if len(rows["anomaly"]) == 1 and rows["anomaly"][0] != "true":   # the sentinel row: its DateTime fields are text
-            client.insert_rows([_db_row({k: (v[0].item() if hasattr(v[0], "item") else v[0]) for k, v in rows.items()})], RESULT_TABLE_NAME)
-        else:
-            client.insert_columns(rows, RESULT_TABLE_NAME)
+    else:
+        store_result_columns(client, rows)
     logger.info("Anomaly Detection completed, id: %s, in %s seconds ", tad_id, t1 - t0)
     return tad_id
 

@@ -69,10 +69,14 @@ class ClickHouseHTTP:
         import pyarrow.ipc as ipc
         parts = {}
         with self._request({"output_format_arrow_string_as_string": 1}, (sql.rstrip() + " FORMAT ArrowStream").encode()) as resp:
-            try:
-                reader = ipc.open_stream(resp)
-            except pa.ArrowInvalid:        # empty body: a result without rows carries no schema
+            if not resp.peek(1):           # a truly empty body: a result without rows carries no schema
                 return {}
+            # anything else must be an Arrow stream: a proxy's error page or exception text after the headers raises
+            # pa.ArrowInvalid here instead of turning into a job on zero rows that reports "no anomalies"
+            reader = ipc.open_stream(resp)
+            for name, t in zip(reader.schema.names, reader.schema.types):   # a schema without batches: empty typed columns
+                parts[name] = [np.zeros(0, dtype=np.int64 if pa.types.is_timestamp(t) or pa.types.is_integer(t) else
+                                        (np.float64 if pa.types.is_floating(t) else str))]
             for batch in reader:
                 for name, col in zip(batch.schema.names, batch.columns):
                     t = col.type
@@ -88,7 +92,11 @@ class ClickHouseHTTP:
                     else:
                         arr = col.to_numpy(zero_copy_only=False)
                     parts.setdefault(name, []).append(arr)
-        return {name: (np.concatenate(v) if len(v) > 1 else v[0]) for name, v in parts.items()}
+        return {name: (np.concatenate(v[1:]) if len(v) > 2 else (v[1] if len(v) == 2 else v[0])) for name, v in parts.items()}
+
+    def command(self, sql):
+        """Run a statement without a result set (e.g. cleanupTADetector's ALTER TABLE ... DELETE, controller.go:396)."""
+        self._post({}, sql.encode())
 
     def insert_rows(self, rows, table=RESULT_TABLE):
         """Append dict rows (INSERT ... FORMAT JSONEachRow); columns a row lacks take the table defaults."""
