@@ -87,7 +87,28 @@ def cpu_baseline(algo, rows, keys, buckets, agg, single_rows=0):
         out["single_core_value"] = single
     if multi is not None:
         out["all_cores_value"] = multi
+    ref = reference_functions(algo)
+    if ref is not None:
+        out["reference_functions"] = ref
     return out
+
+
+def reference_functions(algo):
+    """The reference's OWN per-series functions (calculate_ewma[_anomaly], calculate_dbscan[_anomaly]) timed by oracle/ref_baseline.py
+    in the BUILD CONTAINER — /root/reference does not exist on the GPU box, so the committed figures are copied into the line,
+    labelled with where they come from (they are not measured by this run)."""
+    path = os.path.join(ROOT, "profiles", "r3_reference_functions_cpu.json")
+    shape = {"EWMA": "c2_shape", "DBSCAN": "c4_shape"}.get(algo)
+    if shape is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    m = d[shape]
+    return {"measured": "NOT by this run: committed figures of oracle/ref_baseline.py, %s, %d cores (%s)" % (d["where"], d["cores"], d["cpu"]),
+            "what": "reference functions imported from /root/reference, unmodified, on %d rows / %d keys / %d buckets of the synthetic table; "
+                    "pandas Stage 0 + series assembly included" % (m["rows"], m["keys"], m["buckets"]),
+            "rows_per_s_one_core": m["rows_per_s_one_core_with_pandas_stage0"], "rows_per_s_all_cores": m["rows_per_s_all_cores_with_pandas_stage0"],
+            "rows_per_s_one_core_udf_only": m["rows_per_s_one_core_udf_only"], "cores": d["cores"]}
 
 
 def cpu_sample(algo, rows, keys, cores):
@@ -131,6 +152,9 @@ def main():
     ap.add_argument("--host-input", action="store_true",
                     help="hand the columns over as pinned HOST buffers (tad_columns.memory = TAD_MEM_HOST): the PCIe-inclusive "
                          "rate DESIGN.md quotes; never the headline value")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="with ONE rank: create the process group anyway and run the job's all-gather / all-to-all(v) through it "
+                         "(backend nccl = RCCL on device tensors) — the single-GPU check of the N>1 RCCL path")
     ap.add_argument("--plan", default="", help="tad_plan overrides for A/B runs, e.g. histogram=exact,partition_pass=sort (default: the engine decides)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -153,13 +177,18 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    grouped = world > 1 or args.force_collectives
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    coll_dev = dev if (world > 1 and backend == "nccl") else None
+    coll_dev = dev if (grouped and backend == "nccl") else None
 
     cfg = dict(CONFIGS[args.config])
     strong = args.config == "c5"
@@ -213,7 +242,7 @@ def main():
                 cols = [torch.as_tensor(td.DeviceColumn(ptr[f], pts.n_points), device=dev) for f in ("key_id", "flow_end_s", "value")]
                 # bucketed by owner on the GPU (tad_shard_rows), shipped with one all-to-all(v) per column
                 lk, lt, lv = td.exchange_rows_device(eng, cols[0], cols[1], cols[2], world, rank,
-                                                     host_collective=(coll_dev is None and world > 1))
+                                                     host_collective=(coll_dev is None and grouped))
                 pts.close()
             else:
                 lk, lt, lv = key, tend, val
@@ -222,7 +251,7 @@ def main():
                 st = res.stats
                 # RCCL over xGMI: one 9-double all-gather (counters + moments) per job, started now and collected after the
                 # NEXT job has been issued, so its latency hides behind that job; the last one is collected inside the timed region
-                if world > 1:
+                if grouped:
                     nxt = reducer.start(st)
                     if pending[0] is not None:
                         glob = pending[0].result()
@@ -243,7 +272,7 @@ def main():
         glob = None
         for _ in range(warmup):
             stats, glob = step()
-        if world > 1:
+        if grouped:
             glob = drain() or glob
             dist.barrier()
         torch.cuda.synchronize()
@@ -255,13 +284,13 @@ def main():
             for a, st in zip(acc, stats):
                 for f in a:
                     a[f] += st[f]
-        if world > 1:
+        if grouped:
             glob = drain() or glob          # the last job's reduction completes inside the timed region
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if grouped:
             tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -270,7 +299,7 @@ def main():
         if args.dump_rows:
             dump["on"] = True
             step()
-            if world > 1:
+            if grouped:
                 drain()
             np.savez(args.dump_rows + ".rank%d.npz" % rank, **{"%s_%s" % (a, f): v for a in algos for f, v in dump[a].items()})
         del key, tend, val

@@ -102,3 +102,28 @@ def test_default_config_key_sharded_two_ranks(tmp_path):
     assert d["result"]["rows_used"] == 2 * 3_000_000 and d["result"]["keys"] == 2 * 3000
     assert abs(d["value"] - 2 * 3_000_000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9       # whole-job rate over both ranks
     assert "other_configs" not in d and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+
+
+def test_rccl_one_rank_group_runs_the_collectives_on_device_tensors(tmp_path):
+    """The only way a single-GPU box can execute this repository's RCCL calls before the driver's 8-GPU run does:
+    `bench.py --force-collectives` creates a ONE-rank process group with backend "nccl" (= RCCL) and pushes the job's
+    9-double all-gather, the all-to-all of the send counts and the three all-to-all(v) of the partial points through it, on
+    device tensors (no TAD_BENCH_BACKEND=gloo here).  API / dtype / stream mistakes in theia_amd/distributed.py surface
+    here; the rows must be those of the plain one-rank run, bit for bit."""
+    rows, keys = 400_000, 400
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("TAD_BENCH_BACKEND", None)
+    common = ["--config", "c5", "--rows", str(rows), "--keys", str(keys), "--buckets", "60", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out = {}
+    for name, extra in (("plain", ["--ingest", "rows"]), ("rccl", ["--ingest", "rows", "--force-collectives"]), ("rccl_keys", ["--force-collectives"])):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common + extra + ["--dump-rows", str(tmp_path / name)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["rccl"]["result"] == out["plain"]["result"] and out["rccl_keys"]["result"]["anomalies"] == out["plain"]["result"]["anomalies"]
+    assert out["rccl"]["result"]["global_sigma"] is not None
+    for algo in ("EWMA", "ARIMA"):
+        a, b, c = (merged_rows(str(tmp_path / n), 1, algo) for n in ("plain", "rccl", "rccl_keys"))
+        assert a["key_id"].size > 0
+        for f in a:
+            assert np.array_equal(a[f], b[f], equal_nan=True) and np.array_equal(a[f], c[f], equal_nan=True), (algo, f)

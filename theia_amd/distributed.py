@@ -27,6 +27,19 @@ SKIP = np.uint64(0xFFFFFFFFFFFFFFFF)  # TAD_KEY_SKIP
 STAT_FIELDS = ("n_anomalies", "n_keys", "n_points", "rows_used", "keys_no_result", "rows_in")
 
 
+def collectives_on(world):
+    """Whether the collectives run: always with more than one rank, and with ONE rank when a process group exists — a
+    one-rank RCCL group executes the same all-gather / all-to-all(v) calls on device tensors, which is how a single-GPU box
+    exercises this module's RCCL path (tests/test_gpu_multirank.py::test_rccl_one_rank_group...)."""
+    if world > 1:
+        return True
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except ImportError:
+        return False
+
+
 def owner_of(key_id, world):
     """Rank that owns a key.  Key ids are dense dictionary codes (first-appearance order on the host), so
     `id mod world` is already a uniform hash partition and keeps the local ids dense: local = id // world."""
@@ -113,7 +126,7 @@ class JobReducer:
             o = self.owner
             if self.work is not None:
                 self.work.wait()
-            if o.world > 1:
+            if o.collective:
                 rows = o.gathered[self.slot].view(o.world, o.WIDTH).tolist()
             else:
                 rows = [o.payload[self.slot].tolist()]
@@ -131,6 +144,7 @@ class JobReducer:
         self.torch, self.dist, self.group = torch, dist, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collective = collectives_on(self.world)
         on_gpu = device is not None and str(device) != "cpu"
         self.payload = [torch.zeros(self.WIDTH, dtype=torch.float64, device=device) for _ in range(2)]
         self.gathered = [torch.zeros(self.world * self.WIDTH, dtype=torch.float64, device=device) for _ in range(2)]
@@ -149,7 +163,7 @@ class JobReducer:
         else:
             self.payload[slot].copy_(torch.tensor(vals, dtype=torch.float64))
         work = None
-        if self.world > 1:
+        if self.collective:
             work = dist.all_gather_into_tensor(self.gathered[slot], self.payload[slot], group=self.group, async_op=True)
         return JobReducer.Pending(self, slot, work)
 
@@ -175,13 +189,13 @@ def exchange_rows(cols, world, rank, group=None, device=None):
     send = torch.from_numpy(np.concatenate(send_parts, axis=0)).to(device or "cpu")
     counts = torch.tensor(send_counts, dtype=torch.int64, device=device or "cpu")
     recv_counts = torch.zeros(world, dtype=torch.int64, device=device or "cpu")
-    if world > 1:
+    if collectives_on(world):
         dist.all_to_all_single(recv_counts, counts, group=group)
     else:
         recv_counts.copy_(counts)
     rc = [int(c) for c in recv_counts.tolist()]
     recv = torch.zeros((sum(rc), len(names)), dtype=torch.int64, device=device or "cpu")
-    if world > 1:
+    if collectives_on(world):
         dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=send_counts, group=group)
     else:
         recv.copy_(send)
@@ -205,13 +219,13 @@ def exchange_points_torch(key, flow_end_s, value, world, rank, group=None):
     payload = torch.stack([torch.div(key, world, rounding_mode="floor"), flow_end_s, value], dim=1)[order].contiguous()
     send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
     recv_counts = torch.zeros_like(send_counts)
-    if world > 1:
+    if collectives_on(world):
         dist.all_to_all_single(recv_counts, send_counts, group=group)
     else:
         recv_counts.copy_(send_counts)
     sc, rc = [int(c) for c in send_counts.tolist()], [int(c) for c in recv_counts.tolist()]
     recv = torch.empty((sum(rc), 3), dtype=torch.int64, device=payload.device)
-    if world > 1:
+    if collectives_on(world):
         dist.all_to_all_single(recv, payload, output_split_sizes=rc, input_split_sizes=sc, group=group)
     else:
         recv.copy_(payload)
@@ -232,7 +246,7 @@ def exchange_rows_device(engine, key, flow_end_s, value, world, rank, group=None
     cdev = "cpu" if host_collective else dev
     send_counts = torch.tensor(sc, dtype=torch.int64, device=cdev)
     recv_counts = torch.zeros_like(send_counts)
-    if world > 1:
+    if collectives_on(world):
         dist.all_to_all_single(recv_counts, send_counts, group=group)
     else:
         recv_counts.copy_(send_counts)
@@ -244,7 +258,7 @@ def exchange_rows_device(engine, key, flow_end_s, value, world, rank, group=None
         if host_collective:
             send = send.cpu()
         recv = torch.empty(n_recv, dtype=torch.int64, device=cdev)
-        if world > 1:
+        if collectives_on(world):
             dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
         else:
             recv.copy_(send)

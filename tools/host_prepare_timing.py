@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Host-side cost of the job OUTSIDE tad_run: prepare_columns (string predicates + dictionary encoding of the key columns,
+theia_amd/anomaly_detection.py) on a svc-mode table with C2's shape.  The numbers go into DESIGN.md section 5 next to the
+kernel times: with a real ClickHouse ingest this, not the 1.4 ms of GPU time, is what an operator waits for.
+usage: python tools/host_prepare_timing.py [rows] [keys]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from theia_amd import anomaly_detection as ad  # noqa: E402
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+keys = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
+rng = np.random.default_rng(1)
+names = np.array(["svc-%06d:http" % i for i in range(keys)])      # 15-character service port names
+t0 = time.perf_counter()
+flows = {"destinationServicePortName": names[rng.integers(0, keys, size=rows)],
+         "flowEndSeconds": 1660202814 + 60 * rng.integers(0, 250, size=rows),
+         "flowStartSeconds": np.full(rows, 1660202000, dtype=np.int64),
+         "throughput": rng.integers(1_000_000_000, 4_000_000_000, size=rows).astype(np.uint64),
+         "sourcePodNamespace": np.full(rows, "default"), "destinationPodNamespace": np.full(rows, "default")}
+t_gen = time.perf_counter() - t0
+for label, kw in (("svc, no filters", dict(agg_flow="svc")), ("svc, ns-ignore-list + time window", dict(agg_flow="svc", ns_ignore_list=["kube-system"],
+                                                                                                       start_time="2022-08-11 00:00:00", end_time="2022-08-12 00:00:00"))):
+    t0 = time.perf_counter()
+    prep = ad.prepare_columns(flows, **kw)
+    dt = time.perf_counter() - t0
+    print("prepare_columns [%s]: %d rows / %d keys in %.2f s = %.2e rows/s on one host core (%d distinct keys found); table generation %.1f s"
+          % (label, rows, keys, dt, rows / dt, prep.num_keys, t_gen))
