@@ -404,10 +404,12 @@ def main():
                 sr = min(sr, cr)
             out["cpu_baseline"] = cpu_baseline(algo, cr, ck, cfg["buckets"], cfg["agg"], sr)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
+    if rank == 0:      # the ONE JSON line, last on stdout (after the process group is gone: RCCL may print on teardown)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

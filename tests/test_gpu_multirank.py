@@ -119,7 +119,9 @@ def test_rccl_one_rank_group_runs_the_collectives_on_device_tensors(tmp_path):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common + extra + ["--dump-rows", str(tmp_path / name)]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
-        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        assert lines, (r.stdout[-2000:], r.stderr[-2000:])
+        out[name] = json.loads(lines[-1])
     assert out["rccl"]["result"] == out["plain"]["result"] and out["rccl_keys"]["result"]["anomalies"] == out["plain"]["result"]["anomalies"]
     assert out["rccl"]["result"]["global_sigma"] is not None
     for algo in ("EWMA", "ARIMA"):
