@@ -146,7 +146,9 @@ typedef struct {
   double pts_mean;         /* mean and sum of squared deviations (M2) of the aggregated point values of */
   double pts_m2;           /* this shard: (n_points, mean, M2) triples Chan-merge across GPUs into the global
                               mean / sigma the multi-GPU host reports (telemetry; the reference has none) */
-  int64_t t0, step;        /* the time lattice used */
+  int64_t t0, step;        /* the time lattice used.  stage0_path >= 4 (sparse tables) does not place rows on a lattice: there t0 is the
+                              smallest flowEndSeconds, and step / n_buckets are the caller's hint or pass A's (min, max, gcd) estimate,
+                              reported for information — rows are never rejected for being off it (the dense path does reject) */
   uint64_t n_buckets;
   float ms_meta;           /* lattice derivation pass */
   float ms_stage0;         /* Stage 0 after the lattice pass: v1 grid clear + k_scatter; v2 offsets +

@@ -132,3 +132,22 @@ def test_write_result_json_lines():
     assert ad.write_anomaly_detection_result(rows, buf, tad_id_input="abc") == "abc"
     assert json.loads(buf.getvalue())["destinationServicePortName"] == "s"
     assert len(ad.write_anomaly_detection_result(rows, io.StringIO())) == 36     # generated uuid (ref:715-718)
+
+
+def test_job_arima_exact_vs_scipy_driven():
+    """The GPU path is held bit for bit to oracle/arima_exact.c, which shares tad_detmath.h and the arithmetic contract with the
+    kernel by design: a shared mistake in start parameters, Box-Cox or the optimiser would pass those tests.  This one
+    holds the exact oracle's JOB against the scipy-driven restatement (real scipy Brent + L-BFGS-B, numpy filter, glibc) on a
+    synthetic table: same keys emitted, verdict sets equal up to the flips two optimisers show on flat likelihoods, algoCalc close."""
+    from oracle import arima_oracle as ao
+    flows = jo.synth_flows(2500, n_buckets=30)
+    a = jo.run(flows, "ARIMA", agg_flow="svc", tad_id="x")                                   # calculate_arima_exact (the contract)
+    b = jo.run(flows, "ARIMA", agg_flow="svc", tad_id="x", arima_fn=ao.calculate_arima)      # scipy-driven
+    ka = {(r["destinationServicePortName"], r["flowEndSeconds"]): r for r in a if r["anomaly"] == "true"}
+    kb = {(r["destinationServicePortName"], r["flowEndSeconds"]): r for r in b if r["anomaly"] == "true"}
+    assert len(ka) > 20
+    both = set(ka) & set(kb)
+    assert len(both) >= 0.9 * max(len(ka), len(kb)), (len(ka), len(kb), len(both))           # verdict flips stay a small minority
+    rel = np.array([abs(ka[k]["algoCalc"] - kb[k]["algoCalc"]) / abs(kb[k]["algoCalc"]) for k in both])
+    assert (rel < 1e-3).mean() >= 0.9 and np.median(rel) < 1e-5, (np.median(rel), (rel < 1e-3).mean())
+    assert all(ka[k]["throughput"] == kb[k]["throughput"] and ka[k]["throughputStandardDeviation"] == kb[k]["throughputStandardDeviation"] for k in both)

@@ -685,6 +685,9 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       if ((rc = ensure(e, e->sp_val_a, slots_all * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->sp_val_b, slots_all * 8)) != TAD_OK) return rc;
       const size_t tb = sparse_sort_temp_bytes(slots_all);
+      if ((uint64_t)slots_all * 32 + tb > e->ws_limit)   // the four sort buffers count against the workspace too: fail cleanly, not in hipMalloc
+        return fail(e, TAD_ERR_GRID_TOO_LARGE, "sparse Stage 0 needs %llu bytes of sort buffers for %llu row slots > workspace limit %llu",
+                    (unsigned long long)(slots_all * 32 + tb), (unsigned long long)slots_all, (unsigned long long)e->ws_limit);
       if ((rc = ensure(e, e->sp_temp, tb + 64)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->sp_first, K * 4 + 64)) != TAD_OK) return rc;
       unsigned long long *d_runs = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->sp_temp.p) + tb);   // [0] runs, [1] tmax
