@@ -457,3 +457,32 @@ def test_full_size_properties(engine, algo, N, K, T, agg):
     else:
         for a, b in zip(ptr[:-1], ptr[1:]):
             assert (orc.dbscan_noise_1d(pvf[a:b]) == sel[first][a:b]).all()
+
+
+@pytest.mark.parametrize("agg", ["svc", ""])
+def test_job_present_cells_that_aggregate_to_zero(engine, stage0, agg):
+    """A cell's presence is not visible in its aggregate: records that carry the value 0, and a sum that wraps to exactly 2^64,
+    leave a PRESENT cell at 0 (round 3 measured a pass C that derives presence from value != 0 with an exact fallback for these
+    cases: no faster than the flag byte per record, DESIGN.md rejected table — this test is what such a variant must pass).  Built here:
+    a key whose every row is 0, zeros mixed into ordinary cells, values in [2^46, 2^49) (packed records, the 'could wrap' range),
+    and one cell with 65536 rows of 2^48 each: sum = 2^64 = 0 (mod 2^64), present, value 0 (ClickHouse UInt64 wraps)."""
+    rng = np.random.default_rng(5)
+    k, t, v = orc.synth_rows(0, 500_000, 64, 40)
+    v = v.copy()
+    v[rng.random(v.size) < 0.01] = 0                                  # zeros inside ordinary cells
+    big = rng.random(v.size) < 0.002
+    v[big] = rng.integers(2**46, 2**49 - 1, size=int(big.sum()), dtype=np.uint64)
+    v[k == 3] = 0                                                     # a key of zeros only: present points with value 0
+    hot_k = np.full(65536, 9, dtype=np.uint64)
+    hot_t = np.full(65536, t.min() + 60 * 7, dtype=np.int64)
+    hot_v = np.full(65536, 2**48, dtype=np.uint64)
+    sel = ~((k == 9) & (t == hot_t[0]))                               # that cell holds the 65536 rows only
+    k, t, v = np.concatenate([k[sel], hot_k]), np.concatenate([t[sel], hot_t]), np.concatenate([v[sel], hot_v])
+    order = rng.permutation(k.size)
+    k, t, v = k[order], t[order], v[order]
+    res, want = check_job(engine, "EWMA", k, t, v, 64, agg_flow=agg)
+    pk, pt, pv = want["points"]
+    if agg == "svc":                                                  # sum: the hot cell exists and holds exactly 0
+        hit = (pk == 9) & (pt == hot_t[0])
+        assert hit.sum() == 1 and pv[hit][0] == 0
+    assert (pv[pk == 3] == 0).all() and (pk == 3).sum() == 40
