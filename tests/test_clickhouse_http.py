@@ -215,3 +215,45 @@ def test_cli_against_clickhouse_http(engine, server, pushdown):
             assert r["anomaly"] == "true" and r["id"] == "c-1" and r["aggType"] == "svc"
     finally:
         ad.set_engine(None)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join("%s=%s" % kv for kv in c.items()))
+def test_dictionary_encoded_columns_prepare_like_plain_strings(case):
+    """DictColumn (codes + distinct values, what query_columns(dict_strings=True) returns) through prepare_columns gives the
+    same key ids, key table and kept rows as the plain string arrays: the predicates run on the distinct values only."""
+    flows = jo.synth_flows(4000)
+    kw = dict(KW); kw.update(case)
+    enc = {}
+    for name, col in flows.items():
+        a = np.asarray(col)
+        if a.dtype.kind in "US":
+            values, codes = np.unique(a.astype(str), return_inverse=True)
+            perm = np.random.default_rng(3).permutation(values.size)          # an arbitrary dictionary order
+            inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
+            enc[name] = ad.DictColumn(inv[codes], values[perm])
+        else:
+            enc[name] = a
+    a, b = ad.prepare_columns(flows, **kw), ad.prepare_columns(enc, **kw)
+    assert a.mode == b.mode and a.num_keys == b.num_keys and (a.start_time, a.end_time) == (b.start_time, b.end_time)
+    assert (a.key_id == b.key_id).all() and (a.flow_end_s == b.flow_end_s).all() and (a.value == b.value).all()
+    assert (a.key_id2 is None) == (b.key_id2 is None) and (a.key_id2 is None or (a.key_id2 == b.key_id2).all())
+    for name in a.key_table:
+        assert (np.asarray(a.key_table[name]).astype(str) == np.asarray(b.key_table[name]).astype(str)).all(), name
+
+
+def test_query_columns_unifies_the_dictionaries_of_the_record_batches(server):
+    t1 = pa.table({"s": pa.array(["b", "a", "b", ""]), "n": pa.array([1, 2, 3, 4], pa.uint16())})
+    t2 = pa.table({"s": pa.array(["c", "a", "c"]), "n": pa.array([5, 6, 7], pa.uint16())})
+
+    class TwoBatches:
+        schema = t1.schema
+    sink = io.BytesIO()
+    with ipc.new_stream(sink, t1.schema) as w:
+        w.write_table(t1); w.write_table(t2)
+    server.responses["SELECT s, n FROM x"] = pa.concat_tables([t1, t2])   # (the fake re-serialises; batches are per input table)
+    client = ch.ClickHouseHTTP(server.url, user="", password="")
+    plain = client.query_columns("SELECT s, n FROM x")
+    enc = client.query_columns("SELECT s, n FROM x", dict_strings=True)
+    assert isinstance(enc["s"], ad.DictColumn) and sorted(enc["s"].values.tolist()) == ["", "a", "b", "c"]
+    assert enc["s"].materialise().tolist() == plain["s"].tolist() == ["b", "a", "b", "", "c", "a", "c"]
+    assert enc["n"].tolist() == [1, 2, 3, 4, 5, 6, 7]

@@ -201,12 +201,65 @@ def _like_regex(pattern):
     return re.compile("^" + "".join(out) + "$", re.IGNORECASE | re.DOTALL)
 
 
+class DictColumn:
+    """A string column as (codes[N], values[D]): row i holds values[codes[i]].  This is what Arrow dictionary arrays and
+    ClickHouse's LowCardinality columns are, and what theia_amd.clickhouse.query_columns(dict_strings=True) delivers: the host
+    then evaluates the SQL's string predicates on the D distinct values and touches the N rows with integer operations only
+    (prepare_columns on plain string arrays runs at 1-3e6 rows/s — DESIGN.md section 5)."""
+
+    def __init__(self, codes, values):
+        self.codes = np.asarray(codes)
+        self.values = np.asarray(values).astype(str)
+
+    def __len__(self):
+        return self.codes.size
+
+    def materialise(self):
+        return self.values[self.codes] if self.values.size else np.zeros(self.codes.size, dtype=str)
+
+    def take(self, sel):
+        return DictColumn(self.codes[sel], self.values)
+
+    def per_row(self, value_mask):
+        """bool[D] over the distinct values -> bool[N] over the rows"""
+        return np.asarray(value_mask, dtype=bool)[self.codes] if self.values.size else np.zeros(self.codes.size, dtype=bool)
+
+    @staticmethod
+    def concatenate(cols):
+        """rows of several DictColumns over ONE unified dictionary (distinct strings merged)"""
+        values, inv = np.unique(np.concatenate([c.values for c in cols]), return_inverse=True)
+        out, at = [], 0
+        for c in cols:
+            out.append(inv[at:at + c.values.size][c.codes] if c.values.size else np.zeros(0, dtype=np.int64))
+            at += c.values.size
+        return DictColumn(np.concatenate(out), values)
+
+
 def _str_col(flows, name):
-    return np.asarray(flows[name]).astype(str)
+    c = flows[name]
+    return c if isinstance(c, DictColumn) else np.asarray(c).astype(str)
+
+
+def _eq(col, s):
+    return col.per_row(col.values == s) if isinstance(col, DictColumn) else col == s
+
+
+def _isin(col, lst):
+    return col.per_row(np.isin(col.values, lst)) if isinstance(col, DictColumn) else np.isin(col, lst)
+
+
+def _take(col, sel):
+    return col.take(sel) if isinstance(col, DictColumn) else col[sel]
+
+
+def _concat(cols):
+    return DictColumn.concatenate(cols) if any(isinstance(c, DictColumn) for c in cols) else np.concatenate(cols)
 
 
 def _ilike_contains(col, needle):
     rx = _like_regex("%" + needle + "%")
+    if isinstance(col, DictColumn):
+        return col.per_row(np.fromiter((rx.match(u) is not None for u in col.values), dtype=bool, count=col.values.size))
     uniq, inv = np.unique(col, return_inverse=True)
     hit = np.fromiter((rx.match(u) is not None for u in uniq), dtype=bool, count=uniq.size)
     return hit[inv]
@@ -232,16 +285,20 @@ class PreparedColumns:
 
 
 def _factorize(columns):
-    """Rows of `columns` (list of equally long arrays) -> (codes int64[N], list of unique-value arrays)."""
+    """Rows of `columns` (list of equally long arrays or DictColumns) -> (codes int64[N], list of unique-value arrays), ids in
+    order of first appearance.  DictColumns take part with their integer codes; their strings are only looked up for the
+    distinct keys at the end."""
     import pandas as pd
     n = len(columns[0])
     if n == 0:
-        return np.zeros(0, dtype=np.int64), [np.asarray(c)[:0] for c in columns]
-    codes, uniques = pd.MultiIndex.from_arrays(columns).factorize() if len(columns) > 1 else pd.factorize(np.asarray(columns[0]))
-    if len(columns) > 1:
-        uniq_cols = [np.asarray(uniques.get_level_values(i)) for i in range(len(columns))]
+        return np.zeros(0, dtype=np.int64), [(c.values[:0] if isinstance(c, DictColumn) else np.asarray(c)[:0]) for c in columns]
+    raw = [c.codes if isinstance(c, DictColumn) else np.asarray(c) for c in columns]
+    codes, uniques = pd.MultiIndex.from_arrays(raw).factorize() if len(raw) > 1 else pd.factorize(raw[0])
+    if len(raw) > 1:
+        uniq_cols = [np.asarray(uniques.get_level_values(i)) for i in range(len(raw))]
     else:
         uniq_cols = [np.asarray(uniques)]
+    uniq_cols = [(c.values[u] if isinstance(c, DictColumn) else u) for c, u in zip(columns, uniq_cols)]
     return np.asarray(codes, dtype=np.int64), uniq_cols
 
 
@@ -255,7 +312,7 @@ def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_fl
     keep = np.ones(n, dtype=bool)
     if ns_ignore_list:  # ref:549-553, 576-580
         ign = np.asarray(list(ns_ignore_list), dtype=str)
-        keep &= ~np.isin(_str_col(flows, "sourcePodNamespace"), ign) & ~np.isin(_str_col(flows, "destinationPodNamespace"), ign)
+        keep &= ~_isin(_str_col(flows, "sourcePodNamespace"), ign) & ~_isin(_str_col(flows, "destinationPodNamespace"), ign)
 
     if agg_flow == "pod":
         by_name = bool(pod_name) and not pod_label
@@ -267,17 +324,17 @@ def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_fl
             if pod_label:                                      # ref:516-527
                 ok = _ilike_contains(col, pod_label)
                 if pod_namespace:
-                    ok &= ns == pod_namespace
+                    ok &= _eq(ns, pod_namespace)
             elif pod_name:                                     # ref:528-543
-                ok = col == pod_name
+                ok = _eq(col, pod_name)
                 if pod_namespace:
-                    ok &= ns == pod_namespace
+                    ok &= _eq(ns, pod_namespace)
             else:                                              # ref:544-548
-                ok = col != ""
+                ok = ~_eq(col, "")
             sides.append((ok & keep, ns, col, direction))
         sel = [np.flatnonzero(s[0]) for s in sides]
-        codes, uniq = _factorize([np.concatenate([sides[i][1][sel[i]] for i in range(2)]),
-                                  np.concatenate([sides[i][2][sel[i]] for i in range(2)]),
+        codes, uniq = _factorize([_concat([_take(sides[i][1], sel[i]) for i in range(2)]),
+                                  _concat([_take(sides[i][2], sel[i]) for i in range(2)]),
                                   np.concatenate([np.full(sel[i].size, sides[i][3]) for i in range(2)])])
         key_id = np.full(n, skip, dtype=np.uint64)
         key_id2 = np.full(n, skip, dtype=np.uint64)
@@ -291,11 +348,11 @@ def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_fl
     if agg_flow == "external":
         keep &= np.asarray(flows["flowType"]).astype(np.int64) == 3      # ref:590
         if external_ip:
-            keep &= _str_col(flows, "destinationIP") == external_ip      # ref:591-593
+            keep &= _eq(_str_col(flows, "destinationIP"), external_ip)   # ref:591-593
         cols = [_str_col(flows, "destinationIP")]
     elif agg_flow == "svc":
         svc = _str_col(flows, "destinationServicePortName")
-        keep &= (svc == svc_port_name) if svc_port_name else (svc != "")  # ref:594-601
+        keep &= _eq(svc, svc_port_name) if svc_port_name else ~_eq(svc, "")  # ref:594-601
         cols = [svc]
     elif not agg_flow:
         cols = [_str_col(flows, "sourceIP"), np.asarray(flows["sourceTransportPort"]).astype(np.int64),
@@ -304,7 +361,7 @@ def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_fl
     else:
         raise ValueError("aggregated flow type should be 'pod' or 'external' or 'svc'")
     sel = np.flatnonzero(keep)
-    codes, uniq = _factorize([c[sel] for c in cols])
+    codes, uniq = _factorize([_take(c, sel) for c in cols])
     key_id = np.full(n, skip, dtype=np.uint64)
     key_id[sel] = codes.astype(np.uint64)
     mode = agg_flow or ""

@@ -59,8 +59,11 @@ class ClickHouseHTTP:
         with self._request(params, body) as resp:
             return resp.read()
 
-    def query_columns(self, sql):
-        """Run a SELECT, return {column name: numpy array}.  DateTime -> int64 epoch seconds, String -> str.
+    def query_columns(self, sql, dict_strings=False):
+        """Run a SELECT, return {column name: numpy array}.  DateTime -> int64 epoch seconds, String -> str — or, with
+        dict_strings=True, String -> theia_amd.anomaly_detection.DictColumn (integer codes per row + the distinct values, one
+        dictionary per column unified over the record batches): no Python object per row is ever created, which is what makes
+        the host side of a 1e8-row job tractable (prepare_columns evaluates the string predicates on the distinct values).
         The ArrowStream response is consumed record batch by record batch straight from the socket (the raw-rows read of
         a large `flows` table is tens of GB: no whole-response buffer), strings are decoded through Arrow's dictionary
         encoding (one Python object per DISTINCT value per batch, not per row)."""
@@ -68,6 +71,7 @@ class ClickHouseHTTP:
         import pyarrow.compute as pc
         import pyarrow.ipc as ipc
         parts = {}
+        vocab = {}     # dict_strings: column -> {string: code}
         with self._request({"output_format_arrow_string_as_string": 1}, (sql.rstrip() + " FORMAT ArrowStream").encode()) as resp:
             if not resp.peek(1):           # a truly empty body: a result without rows carries no schema
                 return {}
@@ -75,8 +79,11 @@ class ClickHouseHTTP:
             # pa.ArrowInvalid here instead of turning into a job on zero rows that reports "no anomalies"
             reader = ipc.open_stream(resp)
             for name, t in zip(reader.schema.names, reader.schema.types):   # a schema without batches: empty typed columns
-                parts[name] = [np.zeros(0, dtype=np.int64 if pa.types.is_timestamp(t) or pa.types.is_integer(t) else
-                                        (np.float64 if pa.types.is_floating(t) else str))]
+                is_str = not (pa.types.is_timestamp(t) or pa.types.is_integer(t) or pa.types.is_floating(t))
+                if is_str and dict_strings:
+                    vocab.setdefault(name, {})
+                parts[name] = [np.zeros(0, dtype=np.int64 if (not is_str or dict_strings) else str) if not pa.types.is_floating(t)
+                               else np.zeros(0, dtype=np.float64)]
             for batch in reader:
                 for name, col in zip(batch.schema.names, batch.columns):
                     t = col.type
@@ -85,14 +92,28 @@ class ClickHouseHTTP:
                     elif pa.types.is_binary(t) or pa.types.is_large_binary(t) or pa.types.is_string(t) or pa.types.is_large_string(t):
                         if pa.types.is_binary(t) or pa.types.is_large_binary(t):
                             col = col.cast(pa.string())
-                        d = pc.dictionary_encode(col.fill_null(""))
-                        values = np.asarray(d.dictionary.to_pylist(), dtype=object).astype(str)
+                        d = col if pa.types.is_dictionary(col.type) else pc.dictionary_encode(col.fill_null(""))
                         idx = d.indices.to_numpy(zero_copy_only=False)
-                        arr = values[idx] if values.size else np.zeros(0, dtype=str)
+                        if dict_strings:      # remap this batch's dictionary into the column's unified one: per-row work is one integer gather
+                            voc = vocab.setdefault(name, {})
+                            remap = np.fromiter((voc.setdefault(v, len(voc)) for v in d.dictionary.to_pylist()), dtype=np.int64,
+                                                count=len(d.dictionary))
+                            arr = remap[idx] if remap.size else np.zeros(0, dtype=np.int64)
+                        else:
+                            values = np.asarray(d.dictionary.to_pylist(), dtype=object).astype(str)
+                            arr = values[idx] if values.size else np.zeros(0, dtype=str)
                     else:
                         arr = col.to_numpy(zero_copy_only=False)
                     parts.setdefault(name, []).append(arr)
-        return {name: (np.concatenate(v[1:]) if len(v) > 2 else (v[1] if len(v) == 2 else v[0])) for name, v in parts.items()}
+        out = {name: (np.concatenate(v[1:]) if len(v) > 2 else (v[1] if len(v) == 2 else v[0])) for name, v in parts.items()}
+        if dict_strings:
+            from .anomaly_detection import DictColumn
+            for name, voc in vocab.items():
+                values = np.empty(len(voc), dtype=object)
+                for v, c in voc.items():
+                    values[c] = v
+                out[name] = DictColumn(np.asarray(out[name], dtype=np.int64), values.astype(str) if len(voc) else np.zeros(0, dtype=str))
+        return out
 
     def command(self, sql):
         """Run a statement without a result set (e.g. cleanupTADetector's ALTER TABLE ... DELETE, controller.go:396)."""
@@ -207,7 +228,7 @@ def fetch_flows(client, start_time="", end_time="", ns_ignore_list=(), agg_flow=
                 svc_port_name="", pod_name="", pod_namespace=""):
     """Raw-rows read: the column dict theia_amd.anomaly_detection.prepare_columns expects."""
     flows = client.query_columns(rows_query(start_time, end_time, list(ns_ignore_list), agg_flow, pod_label, external_ip,
-                                            svc_port_name, pod_name, pod_namespace))
+                                            svc_port_name, pod_name, pod_namespace), dict_strings=True)
     if not flows:   # empty result: ArrowStream carries no batch
         mode = agg_flow if agg_flow in ("pod", "external", "svc") else ""
         flows = {c: np.zeros(0, dtype=np.int64 if c.endswith("Seconds") or c in ("flowType", "throughput") else str)
