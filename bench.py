@@ -24,7 +24,8 @@ engine's stream (tad_stats.ms_scatter); `traffic` = that kernel's HBM bytes per 
 rocprofv3 PMC passes (profiles/pmc_latest.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE;
 separate --pmc runs of this same command).  `cpu_baseline` = the oracle (numpy port of the reference
 job) timed on this box's host cores on a bounded sample.  ARIMA lines add `arima`: fits/s and the
-FP64 flop rate from the engine's Kalman-step counter (60 flop per 3-state predict+update).
+FP64 flop rate from the engine's Kalman-step counter (18 flop per step of the recursion the kernel executes; the
+60-flop-equivalent of SURVEY.md 8d's three-state model beside it).
 """
 import argparse
 import json
