@@ -486,3 +486,32 @@ def test_job_present_cells_that_aggregate_to_zero(engine, stage0, agg):
         hit = (pk == 9) & (pt == hot_t[0])
         assert hit.sum() == 1 and pv[hit][0] == 0
     assert (pv[pk == 3] == 0).all() and (pk == 3).sum() == 40
+
+
+@pytest.mark.parametrize("variant", ["plain", "hot_key", "overflow_values", "short_and_empty_keys"])
+def test_job_dbscan_settled_in_the_tile_pass(engine, stage0, variant):
+    """DBSCAN jobs on the partition path run pass C in settle mode (tad_stage0_part.hip:k_tile_aggregate<.., true>): the tile pass
+    decides per key whether it can have noise points and writes the grid columns of undecided keys only.  The cases it cannot see
+    whole must fall back to the detector's walk (k_dbscan_scan, redo keys): a partition split over several slices (hot key),
+    values on the overflow list (folded into the grid after the tile pass); plus keys with fewer than min_samples points (all
+    noise), keys without rows, and exact-eps spreads.  Rows and job counters must be the oracle's in every case."""
+    rng = np.random.default_rng(11)
+    K, T = 3000, 100
+    k, t, v = orc.synth_rows(0, 600_000, K, T)
+    v = v.copy()
+    if variant == "hot_key":
+        k = np.where(rng.random(k.size) < 0.45, np.uint64(77), k)                       # > 2^17 records in one partition: slices
+    elif variant == "overflow_values":
+        sel = rng.random(v.size) < 0.003
+        v[sel] = rng.integers(2**50, 2**63, size=int(sel.sum()), dtype=np.uint64)       # overflow list -> whole job takes the redo walk
+    elif variant == "short_and_empty_keys":
+        keep = (k % np.uint64(50) != 3) | (rng.random(k.size) < 0.01)                    # keys with 0..3 points: every point is noise
+        k, t, v = k[keep], t[keep], v[keep]
+        keep = k % np.uint64(50) != 4                                                    # keys without any row
+        k, t, v = k[keep], t[keep], v[keep]
+        spread = k % np.uint64(50) == 5                                                  # max - min == eps exactly: still settled
+        v[spread] = np.where(rng.random(int(spread.sum())) < 0.5, np.uint64(1_000_000_000), np.uint64(1_250_000_000))
+    res, want = check_job(engine, "DBSCAN", k, t, v, K, agg_flow="")
+    assert res.stats["n_keys"] == want["n_keys"] and res.stats["n_points"] == want["n_points"]
+    if stage0 != "v1":
+        assert res.stats["stage0_path"] in (2, 3)

@@ -323,6 +323,7 @@ struct JobParams {
   int drop_min_samples;
   bool all_points;
   bool lazy_sigma = false;   // set by detect_and_count: the stddev column is computed by the emit kernel (DBSCAN jobs)
+  bool settled = false;      // set by Stage 0: pass C ran in settle mode (SettleArgs) — the DBSCAN scan only walks the keys it marked
 };
 
 // reciprocals of the point counts 1..T for the exact-division FMA sequence (tad_internal.h:div_by_count);
@@ -387,7 +388,7 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
     if (dbscan_uses_list(g)) {
       DbscanStats dst{nullptr, nullptr, nullptr, nullptr};
       if (db_fused) dst = DbscanStats{n_pts, n_anom, static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p)};
-      if (launch_dbscan(s, g, jp.eps, jp.min_samples, e->aux.p, dst) != 0)
+      if (launch_dbscan(s, g, jp.eps, jp.min_samples, e->aux.p, dst, jp.settled && db_fused) != 0)
         return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
     } else {
       launch_dbscan_long(s, g, jp.eps, jp.min_samples, e->aux.p);
@@ -605,6 +606,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   for (int attempt = 0; attempt < 7; ++attempt) {
     const bool hinted = lat_mode == 0;
     HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
+    jp.settled = false;
     PartPlan pl{};
     bool v2 = !empty && !force_v1 && !force_v1_retry && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
     if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
@@ -791,8 +793,24 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
+      // DBSCAN job: pass C in settle mode — key rounds, the detector's per-key pass on the LDS tile, grid columns of unsettled keys only
+      SettleArgs settle{{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, 0.0, 0, 0};
+      jp.settled = false;
+      if (jp.algo == TAD_ALGO_DBSCAN && !jp.all_points && !points_mode && !stream && dbscan_uses_list(g) && part_plan_settle(L.nb, &pl)) {
+        if ((rc = ensure(e, e->aux, dbscan_scratch_bytes(g))) != TAD_OK) return rc;
+        unsigned int *cnt = static_cast<unsigned int *>(e->aux.p);
+        HIP_TRY(e, hipMemsetAsync(cnt, 0, sizeof(unsigned int), s));
+        settle.st = DbscanStats{static_cast<uint32_t *>(e->n_pts.p), static_cast<uint32_t *>(e->n_anom.p), static_cast<double *>(e->key_mean.p),
+                                static_cast<double *>(e->key_m2.p)};
+        settle.list = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(e->aux.p) + 64);
+        settle.count = cnt;
+        settle.eps = jp.eps;
+        settle.min_samples = jp.min_samples;
+        settle.on = 1;
+        jp.settled = true;
+      }
       launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap,
-                            hist_sampled ? offs32 : nullptr, fin);
+                            hist_sampled ? offs32 : nullptr, fin, settle);
     } else {
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));

@@ -32,11 +32,14 @@ __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63; }
 // (M2 from sums shifted by the key's first value; only the exact stddev_samp column of emitted rows follows Spark's
 // streaming order, k_emit<4>).
 // ------------------------------------------------------------------------------------------------
+// REDO_ONLY: Stage 0's pass C ran in settle mode and has done this kernel's work for every key it could see whole (SettleArgs,
+// tad_stage0_part.hip); only keys it marked kSettleRedo (split partitions, overflow-list records) are walked here.
+template <bool REDO_ONLY>
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, int min_samples, DbscanStats st,
                                                          uint32_t *__restrict__ list, unsigned int *__restrict__ count) {
   const uint64_t k = (uint64_t)blockIdx.x * kDbBlock + threadIdx.x;
   bool slow = false;
-  if (k < g.K) {
+  if (k < g.K && (!REDO_ONLY || st.n_pts[k] == kSettleRedo)) {
     uint32_t n = 0;
     double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
     walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
@@ -319,13 +322,17 @@ size_t dbscan_scratch_bytes(Grid g) {
 
 bool dbscan_uses_list(Grid g) { return list_fits_lds(g.T); }
 
-int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch, DbscanStats st) {
+int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch, DbscanStats st, bool settled_by_stage0) {
   if (g.K == 0 || g.T == 0) return 0;
   if (!list_fits_lds(g.T)) return -1;
   unsigned int *count = static_cast<unsigned int *>(scratch);
   uint32_t *list = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + 64);
-  hipMemsetAsync(count, 0, sizeof(unsigned int), s);
-  hipLaunchKernelGGL(k_dbscan_scan, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+  if (settled_by_stage0) {   // the list was started by pass C (its counter zeroed before Stage 0)
+    hipLaunchKernelGGL(k_dbscan_scan<true>, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+  } else {
+    hipMemsetAsync(count, 0, sizeof(unsigned int), s);
+    hipLaunchKernelGGL(k_dbscan_scan<false>, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+  }
   uint64_t blocks = g.K < 2048 ? g.K : 2048;   // grid-stride over the (device-side) list length
   if (g.T <= 256) {   // a wavefront's registers hold the whole series
 #define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom)

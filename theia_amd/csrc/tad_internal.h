@@ -195,10 +195,26 @@ struct DbscanStats {
   uint32_t *n_pts, *n_anom;
   double *key_mean, *key_m2;
 };
+// DBSCAN job, Stage 0 pass C in SETTLE mode (round 3): a partition's rounds split it by KEY sub-range (kt keys x ALL buckets per LDS
+// tile) instead of by bucket range, so that every tile holds whole series; the tile pass then does k_dbscan_scan's work itself —
+// per-key count / min / max / shifted moments in the same sequential order — and writes the grid columns of UNSETTLED keys only
+// (a key is settled iff it has no points, or >= min_samples points all within eps of each other: no noise, nothing reads its
+// column again).  Unsettled keys go to the detector's work list.  Tiles that cannot decide (a split partition merges several
+// slices; overflow-list records are folded in later) write every column and leave n_pts[k] = kSettleRedo for k_dbscan_scan.
+struct SettleArgs {
+  DbscanStats st;            // all four arrays, K entries
+  uint32_t *list;            // work list of the detector (dbscan scratch + 64)
+  unsigned int *count;       // its length (dbscan scratch), zeroed before pass C
+  double eps;
+  int32_t min_samples;
+  uint32_t on;               // 0: plain pass C
+};
+static constexpr uint32_t kSettleRedo = 0xFFFFFFFFu;
 size_t dbscan_scratch_bytes(Grid g);
 bool dbscan_uses_list(Grid g);
+// settled_by_stage0: pass C ran in settle mode (SettleArgs): the scan only walks keys marked kSettleRedo, the list is already started
 int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch,
-                  DbscanStats st = DbscanStats{nullptr, nullptr, nullptr, nullptr});
+                  DbscanStats st = DbscanStats{nullptr, nullptr, nullptr, nullptr}, bool settled_by_stage0 = false);
 int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch);
 // DBSCAN job (statistics from the scan, sigma computed at emit): the rows from the work list launch_dbscan left in `scratch`,
 // one wavefront per listed key.  false: not applicable (series longer than a wavefront's registers hold) -> launch_emit(kind 4)
@@ -230,6 +246,7 @@ struct PartPlan {
   int rpt;             // rows per thread per tile in pass B
   int cell_bits;       // record = value << cell_bits | partition-local cell
   uint32_t tb, n_chunks;  // pass C: buckets per LDS round, rounds per partition
+  uint32_t settle_kt;     // pass C in settle mode: keys per tile (0 = bucket rounds); then n_chunks = ceil(KP / settle_kt) key rounds, tb = T
   uint32_t wc_cap;        // write-combining pass B: queue slots per partition (0 = use the sort-by-tile pass B)
   uint32_t wc_sec, wc_rpt;  // wc: records per emitted piece (8 or 16), rows per thread per tile (2 or 4)
   uint64_t pad_slots;     // wc: upper bound of the filler slots (regions rounded up to whole 64-byte sectors)
@@ -264,7 +281,9 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl);
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
                            const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32 = nullptr,
-                           const uint32_t *fin = nullptr);
+                           const uint32_t *fin = nullptr, SettleArgs settle = SettleArgs{{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, 0.0, 0, 0});
+// whether pass C can run in settle mode for this plan (whole series of >= 8 keys fit an LDS tile; same number of rounds or fewer than 2x)
+bool part_plan_settle(uint64_t T, PartPlan *pl);
 
 // ---- Stage 0 for sparse tables: sort by (key, time), reduce, rank grid (tad_sparse.hip) ----
 size_t sparse_sort_temp_bytes(uint64_t slots);

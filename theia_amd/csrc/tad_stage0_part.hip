@@ -897,13 +897,15 @@ struct TileGeom {
   uint32_t n_chunks;  // ceil(T / tb)
   uint32_t par_rounds;  // 1: every round of a slice is its own workgroup (grid = slices x rounds), see k_tile_aggregate
   uint32_t slice_len;   // record slots per slice (kSliceRecords; twice that when the regions carry the slack of a sampled histogram)
+  uint32_t kt;          // settle mode: keys per tile (rounds split the partition by key sub-range); 0 = bucket rounds
 };
 
-template <bool OPMAX>
+template <bool OPMAX, bool SETTLE = false>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
                                                                  SliceTable st, TileGeom tg, Grid g, int phase,
-                                                                 const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G) {
+                                                                 const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G,
+                                                                 SettleArgs sa, const unsigned long long *__restrict__ ovf_count_in) {
   // Rounds as workgroups: a partition whose KP x T block needs R > 1 LDS tiles is read by R workgroups, one per bucket
   // round, instead of R times by one.  The R workgroups of a slice get block ids x + 8 * (R * j + r): the same XCD
   // (blocks are dealt round-robin over the 8 XCDs) and adjacent in dispatch order, so they stream the same records at
@@ -934,25 +936,34 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
     return;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_nlist, s_lbase;
   const uint32_t cell_none = (1u << tg.cell_bits) - 1u;
   const unsigned long long plo = part_start[p], phi = part_start[p + 1];
   const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * tg.slice_len;
   const unsigned long long hi = lo + tg.slice_len < phi ? lo + tg.slice_len : phi;
   for (uint32_t chunk = r_lo; chunk < r_hi; ++chunk) {
-    const uint32_t b_lo = chunk * tg.tb;
-    const uint32_t nb = b_lo + tg.tb <= T ? tg.tb : T - b_lo;
-    const uint32_t cells = nb << shift_part;
+    // SETTLE: round `chunk` holds the keys [chunk * kt, (chunk + 1) * kt) of the partition with ALL their buckets — tile cell =
+    // bucket * kt + key within the sub-range — instead of all keys with the buckets [b_lo, b_lo + nb)
+    const uint32_t KT = SETTLE ? tg.kt : KP;                       // keys per tile row
+    const uint32_t kt0 = SETTLE ? chunk * KT : 0u;                  // first key of the tile within the partition
+    const uint32_t b_lo = SETTLE ? 0u : chunk * tg.tb;
+    const uint32_t nb = SETTLE ? T : (b_lo + tg.tb <= T ? tg.tb : T - b_lo);
+    const uint32_t cells = SETTLE ? nb * KT : nb << shift_part;
     const uint32_t c_lo = b_lo << shift_part;  // first partition-local cell of this round
     unsigned long long *vals = reinterpret_cast<unsigned long long *>(smem);
-    uint8_t *flags = smem + (size_t)(tg.tb << shift_part) * 8;
+    uint8_t *flags = smem + (size_t)(SETTLE ? tg.tb * KT : tg.tb << shift_part) * 8;
     if (chunk != r_lo) __syncthreads();  // the previous round's tile has been written out
     for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
     for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
     __syncthreads();
     auto apply = [&](unsigned long long r) {
       const uint32_t cg = (uint32_t)r & cell_none;
-      const uint32_t c = cg - c_lo;  // wraps for cells before this round: the unsigned compare rejects them
-      if (cg == cell_none || c >= cells) return;
+      uint32_t c = cg - c_lo;  // wraps for cells before this round: the unsigned compare rejects them
+      if (SETTLE) {
+        const uint32_t kk = (cg & (KP - 1u)) - kt0;               // wraps for keys before this round
+        if (cg == cell_none || kk >= KT) return;
+        c = __umul24(cg >> shift_part, KT) + kk;   // (bucket < 2^16, KT <= 256: the 24-bit multiply issues at full rate, v_mul_lo_u32 at a quarter)
+      } else if (cg == cell_none || c >= cells) return;
       const unsigned long long v = r >> tg.cell_bits;
       if (OPMAX) atomicMax(&vals[c], v);
       else atomicAdd(&vals[c], v);
@@ -1014,18 +1025,104 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
       for (int u = 0; u < U; ++u) apply(r[u]);
     }
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
-      const uint32_t b = b_lo + (c >> shift_part), kk = c & (KP - 1);
-      const uint64_t k = k0 + kk;
-      if (k >= g.K) continue;
-      const uint64_t gc = (uint64_t)b * g.K + k;
-      if (!split) {
-        g.val[gc] = vals[c];
-        g.flag[gc] = flags[c];
-      } else if (flags[c]) {
-        if (OPMAX) __hip_atomic_fetch_max(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_add(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        g.flag[gc] = FLAG_PRESENT;
+    // SETTLE: k_dbscan_scan's per-key pass on the LDS tile (one thread per key, buckets in order: the same operations in the
+    // same order, so n / mean / M2 are that kernel's bits), then only the columns of unsettled keys are written
+    uint8_t *settled = flags + (((size_t)(SETTLE ? tg.tb * KT : 0u)) + 3 & ~(size_t)3);   // [KT] u8, then the tile's listed keys [KT] u32
+    uint32_t *tile_list = reinterpret_cast<uint32_t *>(settled + ((KT + 3u) & ~3u));
+    bool skip_cols = false;
+    if (SETTLE) {
+      skip_cols = !split && *ovf_count_in == 0ull;
+      if (threadIdx.x == 0) { s_nlist = 0; }
+      __syncthreads();
+      // Four threads per key (adjacent lanes), each over every fourth bucket with its own first value as the shift of its sums;
+      // the partials meet in two xor-shuffles (sums re-based onto lane 0's shift: exact algebra, no division).  One thread per key
+      // was a 100-step FP64 dependency chain on 3 of the workgroup's 16 wavefronts: +0.26 ms on pass C at C4.
+      for (uint32_t w = threadIdx.x; w < ((KT + 15u) & ~15u) * 4u; w += kPartThreads) {
+        const uint32_t kk = w >> 2, part = w & 3u;
+        const uint64_t k = k0 + kt0 + kk;
+        const bool live = kk < KT && kt0 + kk < KP && k < g.K;
+        uint32_t n = 0;
+        double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (live && skip_cols) {
+          for (uint32_t b = part; b < nb; b += 4u) {
+            const uint32_t c = __umul24(b, KT) + kk;
+            if (flags[c] & FLAG_PRESENT) {
+              const double x = (double)vals[c];
+              if (n == 0) { mn = x; mx = x; x0 = x; }
+              mn = fmin(mn, x);
+              mx = fmax(mx, x);
+              const double d = x - x0;
+              s1 += d;
+              s2 += d * d;
+              n++;
+            }
+          }
+        }
+#pragma unroll
+        for (int d = 1; d <= 2; d <<= 1) {       // merge with the partner's partial; the lower lane's shift is kept
+          const uint32_t on = __shfl_xor(n, d);
+          const double omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d), ox0 = __shfl_xor(x0, d), os1 = __shfl_xor(s1, d), os2 = __shfl_xor(s2, d);
+          const bool low = (part & (uint32_t)d) == 0;
+          const uint32_t na = low ? n : on, nb2 = low ? on : n;                   // a = the lower lane's partial, b = the higher one's
+          const double amn = low ? mn : omn, amx = low ? mx : omx, ax0 = low ? x0 : ox0, as1 = low ? s1 : os1, as2 = low ? s2 : os2;
+          const double bmn = low ? omn : mn, bmx = low ? omx : mx, bx0 = low ? ox0 : x0, bs1 = low ? os1 : s1, bs2 = low ? os2 : s2;
+          if (na == 0) { n = nb2; mn = bmn; mx = bmx; x0 = bx0; s1 = bs1; s2 = bs2; }
+          else if (nb2 == 0) { n = na; mn = amn; mx = amx; x0 = ax0; s1 = as1; s2 = as2; }
+          else {
+            const double sh = bx0 - ax0, dnb = (double)nb2;                        // b's values are (its d) + sh relative to a's shift
+            n = na + nb2; mn = fmin(amn, bmn); mx = fmax(amx, bmx); x0 = ax0;
+            s1 = as1 + (bs1 + dnb * sh);
+            s2 = as2 + (bs2 + 2.0 * sh * bs1 + dnb * (sh * sh));
+          }
+        }
+        if (part != 0 || kk >= KT) continue;
+        if (!live) { settled[kk] = 1; continue; }
+        if (!skip_cols) { sa.st.n_pts[k] = kSettleRedo; settled[kk] = 0; continue; }
+        const bool slow = n > 0 && (!(mx - mn <= sa.eps) || n < (uint32_t)sa.min_samples);
+        sa.st.n_pts[k] = n;
+        sa.st.n_anom[k] = 0;
+        const double dn = (double)(n ? n : 1);
+        sa.st.key_mean[k] = n ? x0 + s1 / dn : 0.0;
+        sa.st.key_m2[k] = n ? fmax(s2 - s1 * (s1 / dn), 0.0) : 0.0;
+        settled[kk] = slow ? 0 : 1;
+        if (slow) tile_list[atomicAdd(&s_nlist, 1u)] = (uint32_t)k;   // ~2 % of the keys: a few per tile (LDS)
+      }
+      __syncthreads();
+      if (threadIdx.x == 0 && s_nlist) s_lbase = atomicAdd(sa.count, s_nlist);   // one global reservation per tile
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < s_nlist; i += kPartThreads) sa.list[s_lbase + i] = tile_list[i];
+    }
+    if (SETTLE) {   // 256 lanes per bucket row (KT <= 256 of them hold a key), four bucket rows per trip: no division by KT
+      const uint32_t kk = threadIdx.x & 255u;
+      const uint64_t k = k0 + kt0 + kk;
+      if (kk < KT && kt0 + kk < KP && k < g.K && !(skip_cols && settled[kk])) {
+        for (uint32_t b = threadIdx.x >> 8; b < nb; b += kPartThreads / 256) {
+          const uint32_t c = __umul24(b, KT) + kk;
+          const uint64_t gc = (uint64_t)b * g.K + k;
+          if (!split) {
+            g.val[gc] = vals[c];
+            g.flag[gc] = flags[c];
+          } else if (flags[c]) {
+            if (OPMAX) __hip_atomic_fetch_max(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g.flag[gc] = FLAG_PRESENT;
+          }
+        }
+      }
+    } else {
+      for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) {  // consecutive lanes -> consecutive keys of one bucket
+        const uint32_t b = b_lo + (c >> shift_part), kk = c & (KP - 1);
+        const uint64_t k = k0 + kk;
+        if (k >= g.K) continue;
+        const uint64_t gc = (uint64_t)b * g.K + k;
+        if (!split) {
+          g.val[gc] = vals[c];
+          g.flag[gc] = flags[c];
+        } else if (flags[c]) {
+          if (OPMAX) __hip_atomic_fetch_max(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else __hip_atomic_fetch_add(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          g.flag[gc] = FLAG_PRESENT;
+        }
       }
     }
   }
@@ -1124,6 +1221,27 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
     if (slots * 10 + fixed <= kLdsBudget) { pl->rpt = r; pl->part_lds = (slots * 10 + fixed + 15) & ~(size_t)15; break; }
   }
   return pl->rpt != 0;
+}
+
+// Settle mode of pass C (DBSCAN jobs): kt = the most keys whose WHOLE series fit one LDS tile (9 B per cell + 5 B per key of
+// settle bookkeeping); the partition's rounds then split it by key sub-range.  Adopted when that does not take more rounds than the
+// bucket rounds it replaces (every round streams the partition's records again).
+bool part_plan_settle(uint64_t T, PartPlan *pl) {
+  pl->settle_kt = 0;
+  if (T == 0) return false;
+  uint32_t kt = (uint32_t)((kLdsBudget - 64) / (T * 9 + 5));
+  if (kt > pl->KP) kt = pl->KP;
+  if (kt > 256) kt = 256;     // (the write-out maps 256 lanes to a bucket row)
+  if (kt < 8) return false;
+  const uint32_t rounds = (pl->KP + kt - 1) / kt;
+  if (rounds > pl->n_chunks + 1 && rounds > 1) return false;
+  kt = (pl->KP + rounds - 1) / rounds;             // balanced rounds
+  pl->settle_kt = kt;
+  pl->n_chunks = rounds;
+  pl->tb = (uint32_t)T;
+  pl->agg_lds = (((size_t)T * kt * 9 + 3) & ~(size_t)3) + (((size_t)kt + 3) & ~(size_t)3) + (size_t)kt * 4 + 16;
+  pl->agg_lds = (pl->agg_lds + 15) & ~(size_t)15;
+  return true;
 }
 
 static bool aligned16(const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1265,30 +1383,34 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl) {
 
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
-                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin) {
+                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, SettleArgs settle) {
   const unsigned long long *rr = static_cast<const unsigned long long *>(recs);
   const uint32_t max_slices = (uint32_t)((size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1);
   SliceTable st;
   st.slice_part = static_cast<uint32_t *>(slice_mem);
   st.slice_first = st.slice_part + max_slices;
   st.n_slices = st.slice_first + pl.nparts;
-  allow_big_lds(reinterpret_cast<const void *>(op_max ? k_tile_aggregate<true> : k_tile_aggregate<false>), kLdsBudget);
   // regions sized from a sampled histogram hold ~2x the slots of their records: slices twice as long keep one slice per
   // partition for uniform tables (a split partition merges into the grid with atomics instead of plain stores)
   const uint32_t slice_len = fin != nullptr ? 2 * kSliceRecords : kSliceRecords;
   hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st, slice_len);
   const bool may_split = slots > slice_len;  // some partition could exceed one slice
-  // the bucket rounds of a partition run as parallel workgroups on one XCD (measured: C2 pass C 0.39 -> 0.29 ms against sequential rounds)
+  // the rounds of a partition run as parallel workgroups on one XCD (measured: C2 pass C 0.39 -> 0.29 ms against sequential rounds)
   const uint32_t par = pl.n_chunks > 1 ? 1u : 0u;
-  TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len};
+  const bool settle_on = settle.on != 0 && pl.settle_kt != 0;
+  TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len, settle_on ? pl.settle_kt : 0u};
   const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
-#define TAD_TA(OPMAX)                                                                                                                                                     \
+  const SettleArgs none{{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, 0.0, 0, 0};
+#define TAD_TA(OPMAX, SET)                                                                                                                                                 \
   do {                                                                                                                                                                    \
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G);            \
-    hipLaunchKernelGGL((k_tile_aggregate<OPMAX>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G);                    \
+    allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, SET>), kLdsBudget);                                                                              \
+    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX, SET>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none, ovf_count); \
+    hipLaunchKernelGGL((k_tile_aggregate<OPMAX, SET>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G,                \
+                       SET ? settle : none, ovf_count);                                                                                                                   \
     hipLaunchKernelGGL((k_apply_overflow<OPMAX>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);                                                                 \
   } while (0)
-  if (op_max) TAD_TA(true); else TAD_TA(false);
+  if (settle_on) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }
+  else { if (op_max) TAD_TA(true, false); else TAD_TA(false, false); }
 #undef TAD_TA
 }
 

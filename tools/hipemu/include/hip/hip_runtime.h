@@ -108,6 +108,7 @@ template <typename P> inline int __all(P pred, HIPEMU_SITE) { return hipemu::wav
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline unsigned int __umul24(unsigned int a, unsigned int b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
