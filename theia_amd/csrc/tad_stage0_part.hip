@@ -963,7 +963,7 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
         const uint32_t kk = (cg & (KP - 1u)) - kt0;               // wraps for keys before this round
         if (cg == cell_none || kk >= KT) return;
         c = __umul24(cg >> shift_part, KT) + kk;   // (bucket < 2^16, KT <= 256: the 24-bit multiply issues at full rate, v_mul_lo_u32 at a quarter)
-      } else if (cg == cell_none || c >= cells) return;
+      } else if (c >= cells) return;   // (also rejects `no cell`: the all-ones cell is >= KP * T, plan_tiles reserves it)
       const unsigned long long v = r >> tg.cell_bits;
       if (OPMAX) atomicMax(&vals[c], v);
       else atomicAdd(&vals[c], v);
@@ -1008,21 +1008,30 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
         }
       }
     }
-    unsigned long long i = fin != nullptr ? hi : lo + threadIdx.x;
-    for (; i + (U - 1) * kPartThreads < hi; i += U * kPartThreads) {
-      unsigned long long r[U];
+    // exact regions: the slice is one contiguous run of records.  A wavefront takes chunks of 512 consecutive records (its eight
+    // loads cover one contiguous 4 KB, immediate offsets off one address) instead of eight rows 8 KB apart of a workgroup-wide
+    // stride: C4 pass C 0.75 -> 0.70 ms, same box alternating (profiles/r3_v6_passC_wave_chunks_ab.log).  Fewer instructions per
+    // record are NOT what that bought: scalar region bounds (-40 % instructions in the walk above) and dropping the flag write for
+    // `max` changed nothing (profiles/r3_v6_passC_fewer_instructions_ab.log) — the pass follows the bytes it pulls through L2.
+    if (fin == nullptr) {
+      const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+      constexpr unsigned long long kChunk = 64ull * U;
+      unsigned long long i = lo + (unsigned long long)wave * kChunk + lane;
+      for (; i + (U - 1) * 64 < hi; i += kChunk * (kPartThreads / 64)) {
+        const unsigned long long *q = recs + i;
+        unsigned long long r[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) r[u] = recs[i + u * kPartThreads];
+        for (int u = 0; u < U; ++u) r[u] = q[u * 64];
 #pragma unroll
-      for (int u = 0; u < U; ++u) apply(r[u]);
-    }
-    if (i < hi) {   // the last, ragged batch: all its loads in flight at once too (`no cell` for the slots past the end) — a
-                    // load-apply-load chain here cost small partitions (two-level plan: ~12k records) more than the full batches
-      unsigned long long r[U];
+        for (int u = 0; u < U; ++u) apply(r[u]);
+      }
+      if (i < hi) {   // this wavefront's last, ragged chunk (`no cell` for the slots past the end)
+        unsigned long long r[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) r[u] = i + u * kPartThreads < hi ? recs[i + u * kPartThreads] : ~0ull;
+        for (int u = 0; u < U; ++u) r[u] = i + u * 64 < hi ? recs[i + u * 64] : ~0ull;
 #pragma unroll
-      for (int u = 0; u < U; ++u) apply(r[u]);
+        for (int u = 0; u < U; ++u) apply(r[u]);
+      }
     }
     __syncthreads();
     // SETTLE: k_dbscan_scan's per-key pass on the LDS tile (one thread per key, buckets in order: the same operations in the
