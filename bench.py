@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
 FLOP_PER_KALMAN_STEP_3STATE = 60   # SURVEY.md 8d's model (one predict + update of the textbook three-state filter): rounds 1-2 priced on it
-# the contract since round 3 (tad_arima.hip:kfc_step4_nc, the collapsed recursion): 15 add/mul per chain and step plus a quarter
+# the contract since round 3 (tad_arima.hip:kfc_step4, the collapsed recursion): 15 add/mul per chain and step plus a quarter
 # of the batched inversion (9 multiplications + 1 division per four chains) are what is EXECUTED; `frac` is priced on those
 # flops, the 60-flop-equivalent fraction is reported next to it so that the rounds stay comparable
 FLOP_PER_KALMAN_STEP = 18

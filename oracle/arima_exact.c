@@ -237,9 +237,9 @@ static double arima_nll_general(const double u[3], const double *y, long n, doub
  * renormalised after every fourth step (t & 3 == 0), the convergence test is |p_t - p_t+1| < sqrt(1e-19) — expression for
  * expression what tad_arima.hip:kfc_step4 executes. */
 static void arima_nll4_collapsed(const double u4[4][3], const double *y, long n, double nll[4], double *forecast) {
-  double phi[4], q12[4], qs[4], p[4], a1[4], F[4], r[4], g[4], prod[4], q[4], yprev = 0.0;
-  int esum[4], conv[4], c;
-  long nconv[4], t;
+  double phi[4], q12[4], qs[4], p[4], a1[4], prod[4], q[4], yprev = 0.0;
+  int esum[4], c;
+  long t;
   for (c = 0; c < 4; ++c) {
     const double ph = -(u4[c][0] / sqrt(1.0 + u4[c][0] * u4[c][0]));
     const double theta = u4[c][1] / sqrt(1.0 + u4[c][1] * u4[c][1]);
@@ -250,45 +250,41 @@ static void arima_nll4_collapsed(const double u4[4][3], const double *y, long n,
     const double m = DIFFUSE * (p11 * r0), c12 = DIFFUSE * (q12c * r0), c22 = q22 - (q12c * r0) * q12c;
     phi[c] = ph; q12[c] = q12c; qs[c] = q11 + q22;
     p[c] = ph * (ph * m + c12) + (ph * c12 + c22) + q11;          /* predicted p11 for t = 1 */
-    a1[c] = 0.0; F[c] = p11; r[c] = r0; g[c] = 0.0; prod[c] = 1.0; q[c] = 0.0;
-    esum[c] = 0; conv[c] = 0; nconv[c] = 0;
+    a1[c] = 0.0; prod[c] = 1.0; q[c] = 0.0;
+    esum[c] = 0;
     if (n >= 1) {                                                 /* t = 0: burned (loglikelihood_burn = 1) */
-      const double w0 = r[c] * y[0];
-      a1[c] = ph * (F[c] * w0) + q12c * w0;
+      const double w0 = r0 * y[0];
+      a1[c] = ph * (p11 * w0) + q12c * w0;
     }
   }
   if (n >= 1) yprev = y[0];
   for (t = 1; t < n; ++t) {
     const double d = y[t] - yprev;
     const int renorm = (t & 3) == 0;      /* the product is renormalised after every fourth step (exact scaling by 2^-e) */
-    double Fn[4], rn[4];
-    for (c = 0; c < 4; ++c) Fn[c] = conv[c] ? F[c] : p[c];
-    {
-      const double t12 = Fn[0] * Fn[1], t34 = Fn[2] * Fn[3];
+    double r[4];
+    {                                     /* the four reciprocals 1 / F_t (F_t = p_t) from ONE division */
+      const double t12 = p[0] * p[1], t34 = p[2] * p[3];
       const double inv = 1.0 / (t12 * t34);
       const double i12 = inv * t34, i34 = inv * t12;
-      rn[0] = i12 * Fn[1]; rn[1] = i12 * Fn[0]; rn[2] = i34 * Fn[3]; rn[3] = i34 * Fn[2];
+      r[0] = i12 * p[1]; r[1] = i12 * p[0]; r[2] = i34 * p[3]; r[3] = i34 * p[2];
     }
     for (c = 0; c < 4; ++c) {
-      const double v = d - a1[c];
-      double w;
-      if (!conv[c]) { F[c] = Fn[c]; r[c] = rn[c]; g[c] = q12[c] * r[c]; }
-      w = r[c] * v;
+      const double v = d - a1[c], g = q12[c] * r[c], w = r[c] * v;
+      double pn;
       q[c] = fma(v, w, q[c]);
-      if (!conv[c]) prod[c] = prod[c] * F[c];
-      else nconv[c]++;
+      prod[c] = prod[c] * p[c];
       if (renorm) { int e; prod[c] = tad_det_frexp(prod[c], &e); esum[c] += e; }
-      a1[c] = fma(g[c], v, phi[c] * (a1[c] + v));
-      if (!conv[c]) {
-        const double pn = fma(-q12[c], g[c], qs[c]), dp = p[c] - pn;
-        conv[c] = fabs(dp) < CONV_TOL_ABS;
-        p[c] = pn;
-      }
+      a1[c] = fma(g, v, phi[c] * (a1[c] + v));
+      pn = fma(-q12[c], g, qs[c]);
+      /* covariance frozen from the step that detects convergence on (statsmodels reuses that step's F): p moves only by
+       * steps of at least the tolerance; its log keeps entering the product, 1 / F and the gain are recomputed from the
+       * frozen p, so the test keeps holding (no flag, no second code path) */
+      p[c] = fabs(p[c] - pn) < CONV_TOL_ABS ? p[c] : pn;
     }
     yprev = y[t];
   }
   g_steps += 4 * n;
-  for (c = 0; c < 4; ++c) nll[c] = nll_finish(u4[c], prod[c], esum[c], nconv[c], F[c], q[c], n);
+  for (c = 0; c < 4; ++c) nll[c] = nll_finish(u4[c], prod[c], esum[c], 0, 1.0, q[c], n);
   if (forecast) *forecast = yprev + a1[0];
 }
 

@@ -262,15 +262,12 @@ TAD_HD inline double kf_frexp(double x, int *e) {
 
 struct KfStateC {
   double phi, q12, qs;       // model: qs = q11 + q22
-  double p, a1;              // predicted p11 and AR state
-  double F, r, g;            // frozen once converged (before the t = 0 step: p11_0, 1 / (1e6 + p11_0), unused)
-  double prod, q;
+  double p, a1;              // predicted p11 (= F of the coming step; frozen once converged) and AR state
+  double prod, q;            // running product of the F_t (mantissa; exponents in esum), sum of v^2 / F
   int esum;
-  uint32_t nconv;
-  bool conv;
 };
 
-TAD_HD inline void kfc_init(KfStateC &s, double u0, double u1, double u2) {
+TAD_HD inline void kfc_init(KfStateC &s, double u0, double u1, double u2, double *p11_out, double *r0_out) {
   const double phi = -(u0 / sqrt(1.0 + u0 * u0));   // statsmodels' convention: constrain_stationary_univariate returns -r,
   const double theta = u1 / sqrt(1.0 + u1 * u1);     // SARIMAX.transform_params negates it once more for the MA block
   const double s2 = u2 * u2;
@@ -281,15 +278,15 @@ TAD_HD inline void kfc_init(KfStateC &s, double u0, double u1, double u2) {
   s.phi = phi; s.q12 = q12; s.qs = q11 + q22;
   s.p = phi * (phi * m + c12) + (phi * c12 + c22) + q11;
   s.a1 = 0.0;
-  s.F = p11; s.r = r0; s.g = 0.0;
   s.prod = 1.0; s.q = 0.0;
-  s.esum = 0; s.nconv = 0; s.conv = false;
+  s.esum = 0;
+  *p11_out = p11; *r0_out = r0;
 }
 
-// t = 0 (burned: no likelihood term)
-TAD_HD inline void kfc_first(KfStateC &s, double y0) {
-  const double w0 = s.r * y0;
-  s.a1 = s.phi * (s.F * w0) + s.q12 * w0;
+// t = 0 (burned: no likelihood term); p11 and r0 = 1 / (1e6 + p11) from kfc_init
+TAD_HD inline void kfc_first(KfStateC &s, double y0, double p11, double r0) {
+  const double w0 = r0 * y0;
+  s.a1 = s.phi * (p11 * w0) + s.q12 * w0;
 }
 
 // The optimiser always needs the objective at x and at the three forward-difference points together, so the contract runs
@@ -306,9 +303,16 @@ TAD_HD inline void kfc_recip4(const double (&F)[4], double (&r)[4]) {
 // states the same expressions): the three multiply-adds of a chain are FUSED (IEEE fma: q, a1, p'), the running product of
 // the F_t is renormalised after every fourth step only (t & 3 == 0: an exact scaling by a power of two, so the product's bits
 // are those of renormalising every step as long as four factors stay in range) and the convergence test
-// ||P_t - P_t+1||_F^2 < 1e-19 is taken as |p_t - p_t+1| < sqrt(1e-19) (only p11 evolves).  115 -> 78 instructions per step.
+// ||P_t - P_t+1||_F^2 < 1e-19 is taken as |p_t - p_t+1| < sqrt(1e-19) (only p11 evolves).
+// Convergence is ONE select, not a flag and a second code path: p moves only by steps of at least the tolerance.  From the
+// step that detects convergence on, p stays (statsmodels reuses that step's F); its log keeps entering the running product and
+// 1 / F, the gain and p' are recomputed from the frozen p, so the test keeps holding.  The first version froze F, r, g in extra
+// state, stopped the product and counted the converged steps: per lane 10 % of the steps are converged ones, but a wavefront
+// took the predicated path as soon as ANY chain of ANY lane had converged — 76 % of all steps at C3 ran ~120 instructions with
+// five scratch reloads instead of 78 (measured on the oracle's convergence times grouped 64 by 64).  Now every step is 78 + 12
+// instructions and a chain's state is 7 doubles instead of 10.
 // RENORM = (t & 3) == 0: a constant in every unrolled step of the device loop (the 8-step stages start at multiples of 8).
-TAD_HD inline void kfc_step4_nc(KfStateC (&s)[4], double d, const bool RENORM) {   // no chain of any lane of the wavefront has converged
+TAD_HD inline void kfc_step4(KfStateC (&s)[4], double d, const bool RENORM) {
   double F[4], r[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) F[c] = s[c].p;
@@ -316,45 +320,19 @@ TAD_HD inline void kfc_step4_nc(KfStateC (&s)[4], double d, const bool RENORM) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const double v = d - s[c].a1;
-    s[c].F = F[c]; s[c].r = r[c]; s[c].g = s[c].q12 * s[c].r;
-    const double w = s[c].r * v;
+    const double g = s[c].q12 * r[c];
+    const double w = r[c] * v;
     s[c].q = fma(v, w, s[c].q);
-    s[c].prod = s[c].prod * s[c].F;
+    s[c].prod = s[c].prod * F[c];
     if (RENORM) { int e; s[c].prod = kf_frexp(s[c].prod, &e); s[c].esum += e; }
-    s[c].a1 = fma(s[c].g, v, s[c].phi * (s[c].a1 + v));
-    const double pn = fma(-s[c].q12, s[c].g, s[c].qs), dp = s[c].p - pn;
-    s[c].conv = fabs(dp) < kConvTolAbs;
-    s[c].p = pn;
-  }
-}
-
-// the same step with per-chain predication (a converged chain keeps F, r, g; its frozen F still enters the joint inversion)
-TAD_HD inline void kfc_step4(KfStateC (&s)[4], double d, const bool RENORM) {
-  double F[4], r[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) F[c] = s[c].conv ? s[c].F : s[c].p;
-  kfc_recip4(F, r);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const double v = d - s[c].a1;
-    if (!s[c].conv) { s[c].F = F[c]; s[c].r = r[c]; s[c].g = s[c].q12 * s[c].r; }
-    const double w = s[c].r * v;
-    s[c].q = fma(v, w, s[c].q);
-    if (!s[c].conv) s[c].prod = s[c].prod * s[c].F;
-    else s[c].nconv++;
-    if (RENORM) { int e; s[c].prod = kf_frexp(s[c].prod, &e); s[c].esum += e; }   // (a converged chain's product is already a mantissa: e = 0)
-    s[c].a1 = fma(s[c].g, v, s[c].phi * (s[c].a1 + v));
-    if (!s[c].conv) {
-      const double pn = fma(-s[c].q12, s[c].g, s[c].qs), dp = s[c].p - pn;
-      s[c].conv = fabs(dp) < kConvTolAbs;
-      s[c].p = pn;
-    }
+    s[c].a1 = fma(g, v, s[c].phi * (s[c].a1 + v));
+    const double pn = fma(-s[c].q12, g, s[c].qs);
+    s[c].p = fabs(s[c].p - pn) < kConvTolAbs ? s[c].p : pn;
   }
 }
 
 TAD_HD inline KfOut kfc_finish(const KfStateC &s, uint32_t n, double ylast) {
-  double sumlog = tad_det_log(s.prod) + (double)s.esum * TAD_DM_LN2;
-  if (s.nconv) sumlog += (double)s.nconv * tad_det_log(s.F);
+  const double sumlog = tad_det_log(s.prod) + (double)s.esum * TAD_DM_LN2;
   const double llf = -0.5 * ((double)(n - 1) * kLog2Pi + sumlog) - 0.5 * s.q;
   KfOut o;
   o.nll = -llf / (double)n;
@@ -366,11 +344,12 @@ TAD_HD inline KfOut kfc_finish(const KfStateC &s, uint32_t n, double ylast) {
 TAD_HD void arima_nll4_collapsed(const double (&xe)[4][3], const double *__restrict__ y, size_t stride, uint32_t n, double (&nll)[4],
                                  double &forecast) {
   KfStateC s4[4];
-  for (int c = 0; c < 4; ++c) kfc_init(s4[c], xe[c][0], xe[c][1], xe[c][2]);
+  double p11[4], r0[4];
+  for (int c = 0; c < 4; ++c) kfc_init(s4[c], xe[c][0], xe[c][1], xe[c][2], &p11[c], &r0[c]);
   double yprev = 0.0;
   if (n >= 1) {
     yprev = y[0];
-    for (int c = 0; c < 4; ++c) kfc_first(s4[c], yprev);
+    for (int c = 0; c < 4; ++c) kfc_first(s4[c], yprev, p11[c], r0[c]);
   }
   for (uint32_t t = 1; t < n; ++t) {
     const double yt = y[(size_t)t * stride];
@@ -918,12 +897,17 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
   // one pass over the series: the four recursions of the contract (the difference y_t - y_t-1 is shared by them)
   auto evaluate4 = [&](const double (&xe)[4][3], double (&nll)[4], double &fc) {
     KfStateC s4[4];
+    double yprev;
+    {   // t = 0 (burned) up front, from the lane's own first value: p11 and r0 are not carried through the loop
+      const double y0 = ws.ysk[(size_t)(busy ? k : 0ull) * ws.Tpad];
+      yprev = y0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      kfc_init(s4[c], xe[c][0], xe[c][1], xe[c][2]);
-      if (!busy) s4[c].conv = true;   // an idle lane must not keep the wavefront in the covariance-updating loop
+      for (int c = 0; c < 4; ++c) {
+        double p11, r0;
+        kfc_init(s4[c], xe[c][0], xe[c][1], xe[c][2], &p11, &r0);
+        kfc_first(s4[c], y0, p11, r0);
+      }
     }
-    double yprev = 0.0;
     // The rows of the NEXT stage are requested before this stage's steps run (two register sets of 4 x 16 B): the recursion
     // used to wait out a full memory round trip every eight steps.  The barriers order LDS only (one wavefront per workgroup;
     // __syncthreads() would also wait for the loads just issued).
@@ -945,24 +929,17 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
         d[0] = v[j].x; d[1] = v[j].y;
       }
       lds_only_barrier();
+      const uint32_t nb = p - t0 < (uint32_t)kStage ? p - t0 : (uint32_t)kStage;   // wave-uniform
       double yv[kStage];
 #pragma unroll
       for (int i = 0; i < kStage; ++i) yv[i] = buf[(size_t)lane * (kStage + 1) + i];
-      const uint32_t nb = p - t0 < (uint32_t)kStage ? p - t0 : (uint32_t)kStage;
       // compile-time indices into yv (a runtime-indexed array would live in scratch memory); nb is wave-uniform
 #pragma unroll
       for (int i = 0; i < kStage; ++i)
         if ((uint32_t)i < nb) {
           const double d = yv[i] - yprev;
           yprev = yv[i];
-          if (i == 0 && t0 == 0) {   // wave-uniform
-#pragma unroll
-            for (int c = 0; c < 4; ++c) kfc_first(s4[c], yv[0]);
-          } else {
-            const bool any_conv = __any(s4[0].conv || s4[1].conv || s4[2].conv || s4[3].conv);
-            if (!any_conv) kfc_step4_nc(s4, d, (i & 3) == 0);   // t = t0 + i with t0 a multiple of 8: t & 3 == i & 3
-            else kfc_step4(s4, d, (i & 3) == 0);
-          }
+          if (i != 0 || t0 != 0) kfc_step4(s4, d, (i & 3) == 0);   // (t = 0 is done; t = t0 + i with t0 a multiple of 8: t & 3 == i & 3)
         }
     }
 #pragma unroll
@@ -1018,10 +995,12 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
 #endif
 }
 
-// Two wavefronts per SIMD (256 VGPRs each): measured at C3 on MI355X 0.53 s against 0.63 s at three (168 VGPRs) and 1.43 s at
-// four (128 VGPRs: the step loop spills) — profiles/r3_v0_queued_ab_c3.log.
+// ONE wavefront per SIMD, the whole register file (318 VGPRs, nothing spilled): C3 0.342 s against 0.361 s at two wavefronts
+// (256 VGPRs, 131 of the optimiser step's values spilled to scratch) — profiles/r3_v7_arima_single_path_ab.log; the eight-step
+// blocks carry enough independent work (four chains, covariance chain of the next step) to cover the FP64 latency alone.
+// (Round 3 began at two against three / four: 0.53 / 0.63 / 1.43 s, profiles/r3_v0_queued_ab_c3.log.)
 #if !defined(TAD_ARIMA_WAVES)
-#define TAD_ARIMA_WAVES 2
+#define TAD_ARIMA_WAVES 1
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAD_ARIMA_WAVES, TAD_ARIMA_WAVES))) void k_arima_fit(
     Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,

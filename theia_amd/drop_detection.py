@@ -44,9 +44,9 @@ class DropDetection:
             return
         mean, std, verdict = out
         job_type, detection_id, endpoint, direction = self._partition
-        head = (job_type, detection_id or str(uuid.uuid4()))
-        for i in np.flatnonzero(verdict):
-            yield head + (datetime.datetime.now(), endpoint, direction, mean, std, self._dates[i], self._drops[i])
+        for i in np.flatnonzero(verdict):   # a fresh id PER ROW when none was given, as Result.__init__ does (ref:8-11)
+            yield (job_type, detection_id or str(uuid.uuid4()), datetime.datetime.now(), endpoint, direction, mean, std,
+                   self._dates[i], self._drops[i])
 
 
 def drop_detection_table(endpoint, direction, date, drop_number, detection_id=None, job_type="initial", engine=None):
@@ -64,7 +64,6 @@ def drop_detection_table(endpoint, direction, date, drop_number, detection_id=No
     # one lattice bucket per day; Stage 0 sums the drop numbers of equal (key, day)
     res = eng.run("DROP", codes.astype(np.uint64), day, np.asarray(drop_number, dtype=np.uint64), max(len(uniq), 1),
                   agg_flow="svc", value_op="sum")
-    det = detection_id if detection_id else str(uuid.uuid4())
     now = datetime.datetime.now()
     host = res.to_host()
     rows = []
@@ -72,5 +71,5 @@ def drop_detection_table(endpoint, direction, date, drop_number, detection_id=No
                                   host["algo_calc"].tolist(), host["stddev"].tolist()):
         ep, di = uniq[int(k)]
         dd = str(np.datetime64(int(t), "D")) if d.dtype.kind in "USO" else int(t)
-        rows.append((job_type, det, now, ep, di, mean, std, dd, int(x)))
+        rows.append((job_type, detection_id or str(uuid.uuid4()), now, ep, di, mean, std, dd, int(x)))   # (ref:8-11: id per row)
     return rows

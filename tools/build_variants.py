@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build extra variants of libtad_mi355x.so with compile-time defines for same-box A/B runs (bench.py / tests load one through
 TAD_LIBRARY_PATH).  Measurement aid: the shipped library is theia_amd/lib/libtad_mi355x.so, built by theia_amd/build.py.
-usage: python tools/build_variants.py name:DEF1,DEF2 [name2:DEF ...]   ->  theia_amd/lib/variants/libtad_<name>.so"""
+usage: python tools/build_variants.py name:DEF1,DEF2,-rawflag [name2:DEF ...]   ->  theia_amd/lib/variants/libtad_<name>.so"""
 import os
 import subprocess
 import sys
@@ -17,7 +17,7 @@ def build_variant(name, defines):
     obj_dir = os.path.join("/tmp", "tad_variants", "obj_" + name)   # (objects stay out of the tree: they would travel to the GPU box)
     os.makedirs(obj_dir, exist_ok=True)
     os.makedirs(out_dir, exist_ok=True)
-    flags = [f for f in b.FLAGS if f != "-shared"] + ["-D" + d for d in defines if d]
+    flags = [f for f in b.FLAGS if f != "-shared"] + [d if d.startswith("-") else "-D" + d for d in defines if d]   # (an entry starting with "-" is a raw compiler flag)
 
     def cc(src):
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
