@@ -571,7 +571,7 @@ struct Lbfgs {
   // element c of s / y of physical slot i at hist[((i * 2 + {0, 1}) * 3 + c) * hstride].  On the device that is a per-wavefront
   // block of global memory with the lanes interleaved (hstride = 64: every access a coalesced 512-byte line) — as registers the
   // history pushed ~100 VGPRs of spills into the optimiser step (measured: a third of k_arima_fit's time went into that step);
-  // lbfgs_load_hist fetches all of it in ONE batch of independent loads right before the direction is computed.
+  // lbfgs_direction fetches it in two halves right where the two-loop recursion needs it.
   double *hist;
   uint32_t hstride;
   double *park;       // where lbfgs_park / lbfgs_unpark keep the rest of this struct between steps (kParkDoubles values, element stride pstride)
@@ -583,45 +583,74 @@ struct Lbfgs {
 
 TAD_HD inline double &lbfgs_hist(const Lbfgs &o, int slot, int which, int c) { return o.hist[(size_t)((slot * 2 + which) * 3 + c) * o.hstride]; }
 
-struct LbfgsHist { double S[kLbfgsM][3], Y[kLbfgsM][3]; };   // the pairs in LOGICAL order (0 = oldest), registers
+// Five pairs of the history in LOGICAL order (0 = oldest), registers.  The two-loop recursion walks the ten pairs newest to oldest
+// and back: it fetches them in halves — [5, 10), [0, 5), (forward: [0, 5) is still there), [5, 10) — each a batch of 30 independent
+// loads, predicated on j < col.  All ten at once were 120 VGPRs next to the line search's state: at 256 VGPRs (two wavefronts per
+// SIMD) the optimiser step spilled 131 of them.
+static constexpr int kLbfgsHalf = kLbfgsM / 2;
+struct LbfgsHalf { double S[kLbfgsHalf][3], Y[kLbfgsHalf][3]; };
 
-// all m slots, independent loads, no branches (slots beyond col hold stale values that the `j < col` predicates never use)
-TAD_HD inline void lbfgs_load_hist(const Lbfgs &o, LbfgsHist &h) {
+TAD_HD inline void lbfgs_load_half(const Lbfgs &o, int j0, LbfgsHalf &h) {
 #pragma unroll
-  for (int j = 0; j < kLbfgsM; ++j) {
+  for (int jj = 0; jj < kLbfgsHalf; ++jj) {
+    const int j = j0 + jj;
     int slot = o.head + j;
     if (slot >= kLbfgsM) slot -= kLbfgsM;
+    const bool live = j < o.col;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { h.S[j][c] = lbfgs_hist(o, slot, 0, c); h.Y[j][c] = lbfgs_hist(o, slot, 1, c); }
+    for (int c = 0; c < 3; ++c) {
+      h.S[jj][c] = live ? lbfgs_hist(o, slot, 0, c) : 0.0;
+      h.Y[jj][c] = live ? lbfgs_hist(o, slot, 1, c) : 0.0;
+    }
   }
 }
 
-// -H g by the two-loop recursion, H0 = I / theta
-TAD_HD void lbfgs_direction(Lbfgs &o, const LbfgsHist &h) {
+// -H g by the two-loop recursion, H0 = I / theta (the history is read from memory: the pair the update has just written included)
+TAD_HD void lbfgs_direction(Lbfgs &o) {
   if (o.col == 0) {
     for (int i = 0; i < 3; ++i) o.d[i] = -o.g[i];  // Cauchy point with B = theta I, theta = 1
     return;
   }
   double q[3] = {o.g[0], o.g[1], o.g[2]}, alpha[kLbfgsM];
+  LbfgsHalf h;
 #pragma unroll
-  for (int j = kLbfgsM - 1; j >= 0; --j) {
-    alpha[j] = 0.0;
-    if (j < o.col) {
-      const double sy = h.S[j][0] * h.Y[j][0] + h.S[j][1] * h.Y[j][1] + h.S[j][2] * h.Y[j][2];
-      alpha[j] = (h.S[j][0] * q[0] + h.S[j][1] * q[1] + h.S[j][2] * q[2]) / sy;
+  for (int half = 1; half >= 0; --half) {
+    const int j0 = half * kLbfgsHalf;
+    if (o.col > j0) {
+      lbfgs_load_half(o, j0, h);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) q[c] -= alpha[j] * h.Y[j][c];
+      for (int jj = kLbfgsHalf - 1; jj >= 0; --jj) {
+        const int j = j0 + jj;
+        alpha[j] = 0.0;
+        if (j < o.col) {
+          const double sy = h.S[jj][0] * h.Y[jj][0] + h.S[jj][1] * h.Y[jj][1] + h.S[jj][2] * h.Y[jj][2];
+          alpha[j] = (h.S[jj][0] * q[0] + h.S[jj][1] * q[1] + h.S[jj][2] * q[2]) / sy;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) q[c] -= alpha[j] * h.Y[jj][c];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < kLbfgsHalf; ++jj) alpha[j0 + jj] = 0.0;
     }
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) q[c] /= o.theta;
 #pragma unroll
-  for (int j = 0; j < kLbfgsM; ++j) {
-    if (j < o.col) {
-      const double sy = h.S[j][0] * h.Y[j][0] + h.S[j][1] * h.Y[j][1] + h.S[j][2] * h.Y[j][2];
-      const double beta = (h.Y[j][0] * q[0] + h.Y[j][1] * q[1] + h.Y[j][2] * q[2]) / sy;
+  for (int half = 0; half < 2; ++half) {
+    const int j0 = half * kLbfgsHalf;
+    if (o.col > j0) {
+      if (half == 1) lbfgs_load_half(o, j0, h);   // (half 0 is what the backward loop loaded last)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) q[c] += h.S[j][c] * (alpha[j] - beta);
+      for (int jj = 0; jj < kLbfgsHalf; ++jj) {
+        const int j = j0 + jj;
+        if (j < o.col) {
+          const double sy = h.S[jj][0] * h.Y[jj][0] + h.S[jj][1] * h.Y[jj][1] + h.S[jj][2] * h.Y[jj][2];
+          const double beta = (h.Y[jj][0] * q[0] + h.Y[jj][1] * q[1] + h.Y[jj][2] * q[2]) / sy;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) q[c] += h.S[jj][c] * (alpha[j] - beta);
+        }
+      }
     }
   }
   for (int c = 0; c < 3; ++c) o.d[c] = -q[c];
@@ -677,9 +706,9 @@ TAD_HD inline double fd_point(double x0, double *dx) {
 }
 
 // begin a line search from the current (x, f, g); sets the first trial point in x
-TAD_HD void lbfgs_begin_ls(Lbfgs &o, const LbfgsHist &h) {
+TAD_HD void lbfgs_begin_ls(Lbfgs &o) {
   for (;;) {
-    lbfgs_direction(o, h);
+    lbfgs_direction(o);
     const double dtd = o.d[0] * o.d[0] + o.d[1] * o.d[1] + o.d[2] * o.d[2];
     const double dnorm = sqrt(dtd);
     o.stp = o.iter == 0 ? fmin(1.0 / dnorm, 1e10) : 1.0;
@@ -704,12 +733,12 @@ TAD_HD void lbfgs_begin_ls(Lbfgs &o, const LbfgsHist &h) {
 }
 
 // (the inner function; lbfgs_deliver below wraps it in the unpark / park of the state)
-TAD_HD void lbfgs_deliver_core(Lbfgs &o, LbfgsHist &h, int maxiter) {
+TAD_HD void lbfgs_deliver_core(Lbfgs &o, int maxiter) {
   const double pgtol = 1e-5, factr = 1e7;
   if (!o.in_ls) {  // first evaluation
     const double sbg = fmax(fabs(o.g[0]), fmax(fabs(o.g[1]), fabs(o.g[2])));
     if (sbg <= pgtol) { o.done = true; return; }
-    lbfgs_begin_ls(o, h);
+    lbfgs_begin_ls(o);
     return;
   }
   o.gd = o.g[0] * o.d[0] + o.g[1] * o.d[1] + o.g[2] * o.d[2];
@@ -724,7 +753,7 @@ TAD_HD void lbfgs_deliver_core(Lbfgs &o, LbfgsHist &h, int maxiter) {
       if (o.col == 0) { o.done = true; return; }
       o.col = 0; o.head = 0; o.theta = 1.0;
       o.in_ls = false;  // restart from the restored iterate
-      lbfgs_begin_ls(o, h);
+      lbfgs_begin_ls(o);
       return;
     }
     for (int i = 0; i < 3; ++i) o.x[i] = o.stp == 1.0 ? o.t[i] + o.d[i] : o.stp * o.d[i] + o.t[i];
@@ -738,7 +767,6 @@ TAD_HD void lbfgs_deliver_core(Lbfgs &o, LbfgsHist &h, int maxiter) {
   if (sbg <= pgtol) { o.done = true; return; }
   const double ddum0 = fmax(fabs(o.fold), fmax(fabs(o.f), 1.0));
   if ((o.fold - o.f) <= kEpsMch * factr * ddum0) { o.done = true; return; }
-  lbfgs_load_hist(o, h);   // (here, not at the start of the step: the 60 values are not live during the line-search arithmetic above)
   // BFGS update
   double rr = 0.0;
   for (int i = 0; i < 3; ++i) { o.r[i] = o.g[i] - o.r[i]; rr += o.r[i] * o.r[i]; }
@@ -751,23 +779,14 @@ TAD_HD void lbfgs_deliver_core(Lbfgs &o, LbfgsHist &h, int maxiter) {
     else {   // full: the oldest pair is overwritten; the logical order moves up by one
       slot = o.head;
       o.head = o.head + 1 == kLbfgsM ? 0 : o.head + 1;
-#pragma unroll
-      for (int j = 0; j + 1 < kLbfgsM; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { h.S[j][i] = h.S[j + 1][i]; h.Y[j][i] = h.Y[j + 1][i]; }
       o.col = kLbfgsM - 1;
     }
     for (int i = 0; i < 3; ++i) { lbfgs_hist(o, slot, 0, i) = o.d[i]; lbfgs_hist(o, slot, 1, i) = o.r[i]; }
-#pragma unroll
-    for (int j = 0; j < kLbfgsM; ++j)
-      if (j == o.col)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { h.S[j][i] = o.d[i]; h.Y[j][i] = o.r[i]; }
     o.col++;
     o.theta = rr / dr;
   }
   o.in_ls = false;
-  lbfgs_begin_ls(o, h);
+  lbfgs_begin_ls(o);
 }
 
 // What a lane keeps in REGISTERS between optimiser steps (across the likelihood pass): the point to evaluate, the history's
@@ -799,12 +818,11 @@ TAD_HD inline void lbfgs_reset(LbfgsLive &L, double u0, double u1, double u2) {
 // batch of independent loads; the step's state goes back (the new (s, y) pair is written by the update itself).
 TAD_HD void lbfgs_deliver(LbfgsLive &L, double f, const double (&g)[3], double fc, int maxiter) {
   Lbfgs o;
-  LbfgsHist h;
   o.hist = L.hist; o.hstride = L.hstride; o.park = L.park; o.pstride = L.pstride; o.col = L.col; o.head = L.head; o.done = false;
   lbfgs_unpark(o);
   for (int i = 0; i < 3; ++i) { o.x[i] = L.x[i]; o.g[i] = g[i]; }
   o.f = f; o.fc = fc;
-  lbfgs_deliver_core(o, h, maxiter);
+  lbfgs_deliver_core(o, maxiter);
   lbfgs_park(o);
   for (int i = 0; i < 3; ++i) L.x[i] = o.x[i];
   L.fc = o.fc; L.col = o.col; L.head = o.head; L.done = o.done;
@@ -995,12 +1013,13 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
 #endif
 }
 
-// ONE wavefront per SIMD, the whole register file (318 VGPRs, nothing spilled): C3 0.342 s against 0.361 s at two wavefronts
-// (256 VGPRs, 131 of the optimiser step's values spilled to scratch) — profiles/r3_v7_arima_single_path_ab.log; the eight-step
-// blocks carry enough independent work (four chains, covariance chain of the next step) to cover the FP64 latency alone.
-// (Round 3 began at two against three / four: 0.53 / 0.63 / 1.43 s, profiles/r3_v0_queued_ab_c3.log.)
+// Two wavefronts per SIMD (223 VGPRs, nothing spilled since the two-loop recursion fetches the history in halves): C3 0.293 s
+// against 0.325 s at one — profiles/r3_v7_arima_history_halves_ab.log.  One wavefront issues an FP64 instruction every 5.2-6.5
+// clocks whatever its instruction-level parallelism (55-70 % of the SIMD's rate), two reach 84 %
+// (tools/probes/fp64_issue_probe.hip).  With all ten pairs in registers the step spilled 131 VGPRs at 256 and one wavefront with
+// the whole register file was the faster configuration (0.342 against 0.361 s, profiles/r3_v7_arima_single_path_ab.log).
 #if !defined(TAD_ARIMA_WAVES)
-#define TAD_ARIMA_WAVES 1
+#define TAD_ARIMA_WAVES 2
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAD_ARIMA_WAVES, TAD_ARIMA_WAVES))) void k_arima_fit(
     Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,
