@@ -54,6 +54,7 @@ struct ArimaWs {
   double *lam;     // [K]
   uint8_t *state;  // [K] 0 = ok, 1 = no result
   double *hist;    // [wavefronts of k_arima_fit][kHistDoubles][64] every lane's L-BFGS (s, y) history (struct Lbfgs)
+  unsigned long long *cursor;   // [T] next key of series position p not yet handed to a lane (k_arima_fit)
   uint32_t Tpad;
 };
 
@@ -873,12 +874,10 @@ __device__ unsigned long long g_arima_prof[8];
 __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double *__restrict__ sigma,
                                                const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax, uint32_t chunk,
                                                double *__restrict__ calc, DevCounters *ctr, double *buf, double *park) {
-  const uint32_t nchunks = (uint32_t)((g.K + chunk - 1) / chunk);
+  const uint32_t nchunks = (uint32_t)((g.K + chunk - 1) / chunk);   // wavefronts per position
   const uint32_t p = pmax - 1 - blockIdx.x / nchunks;           // heaviest (longest history) positions first
-  const uint64_t c0 = (uint64_t)(blockIdx.x % nchunks) * chunk;
-  const uint64_t c1 = c0 + chunk < g.K ? c0 + chunk : g.K;
   const unsigned lane = threadIdx.x;
-  uint64_t next = c0;                                           // wave-uniform
+  bool dry = false;                                             // wave-uniform: position p has no key left to hand out
   uint64_t k = 0;
   bool busy = false;
   unsigned long long steps = 0, fits = 0, nanfits = 0;
@@ -895,12 +894,18 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
   size_t row[4] = {0, 0, 0, 0};                                 // element offset of the rows this lane loads for the wavefront
 
   auto refill = [&]() {
-    for (;;) {
+    // The wavefronts of one position share ONE cursor over its keys (a global atomic per refill): with a private chunk of 4096
+    // keys per wavefront the lanes of a chunk run dry one after the other while its slowest fits (up to 370 evaluations against a
+    // mean of 81) finish — now a position's wavefronts all end together.  Which lane fits which key does not enter the results.
+    while (!dry) {
       const unsigned long long m = __ballot(!busy);
-      if (m == 0 || next >= c1) break;
-      const uint64_t cand = next + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-      next += (uint64_t)__popcll(m);
-      if (!busy && cand < c1 && ws.state[cand] == 0 && n_pts[cand] > p) {
+      if (m == 0) break;
+      unsigned long long first = 0;
+      if (lane == 0) first = atomicAdd(&ws.cursor[p], (unsigned long long)__popcll(m));
+      first = __shfl(first, 0);
+      if (first >= g.K) { dry = true; break; }
+      const uint64_t cand = first + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (!busy && cand < g.K && ws.state[cand] == 0 && n_pts[cand] > p) {
         k = cand;
         busy = true;
         const size_t c = (size_t)p * g.K + k;
@@ -1036,8 +1041,9 @@ static uint64_t arima_fit_blocks(Grid g) { return g.T > 3 ? ((g.K + kArimaChunk 
 
 size_t arima_workspace_bytes(Grid g) {
   const size_t cells = (size_t)g.K * g.T;
-  return cells * (8 * 3 + 8 * 3 + 4) + (size_t)g.K * arima_tpad(g.T) * 8 + (size_t)g.K * 9 + 512 +
-         (size_t)arima_fit_blocks(g) * (kHistDoubles * 64 * 8) + 512;   // + the L-BFGS history block of every wavefront of k_arima_fit (30 KB each)
+  return cells * (8 * 3 + 8 * 3 + 4) + (size_t)g.K * arima_tpad(g.T) * 8 + (size_t)g.K * 9 + 1024 +
+         (size_t)arima_fit_blocks(g) * (kHistDoubles * 64 * 8) + 512 +   // + the L-BFGS history block of every wavefront of k_arima_fit (30 KB each)
+         (size_t)g.T * 8 + 512;                                          // + the per-position key cursors
 }
 
 int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc,
@@ -1055,14 +1061,18 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
   ws.ysk = reinterpret_cast<double *>(w); w += (size_t)g.K * ws.Tpad * 8;
   ws.lam = reinterpret_cast<double *>(w); w += (size_t)g.K * 8;
   ws.tpos = reinterpret_cast<uint32_t *>(w); w += cells * 4;
-  ws.state = w; w += ((size_t)g.K + 511) & ~(size_t)511;
-  ws.hist = reinterpret_cast<double *>(w);
+  ws.state = w; w += (size_t)g.K;
+  auto align512 = [](unsigned char *q) { return reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(q) + 511) & ~(uintptr_t)511); };
+  w = align512(w);   // (tpos is 4 bytes per cell: with an odd cell count everything after it was 4-byte aligned only — fatal for the 64-bit atomics on the cursors)
+  ws.hist = reinterpret_cast<double *>(w); w = align512(w + (size_t)arima_fit_blocks(g) * (kHistDoubles * 64 * 8));
+  ws.cursor = reinterpret_cast<unsigned long long *>(w);
   hipLaunchKernelGGL(k_arima_prep, dim3((unsigned)((g.K + 255) / 256)), dim3(256), 0, s, g, ws, sigma, calc, ctr);
   if (g.T > 3) {
     const uint64_t kblocks = (g.K + 63) / 64;
     if (kblocks * (g.T - 3) > 0x7FFFFFFFull) return -1;
     hipLaunchKernelGGL(k_arima_start, dim3((unsigned)(kblocks * (g.T - 3))), dim3(64), 0, s, g, ws, n_pts, (uint32_t)g.T);
     const uint32_t chunk = kArimaChunk;
+    hipMemsetAsync(ws.cursor, 0, (size_t)g.T * 8, s);
     const uint64_t blocks = arima_fit_blocks(g);
     if (blocks > 0x7FFFFFFFull) return -1;
     hipLaunchKernelGGL(k_arima_fit, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, chunk, calc, ctr);

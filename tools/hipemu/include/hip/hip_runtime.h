@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 
@@ -120,17 +121,24 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 
 // atomics: workgroups run one after another on one OS thread, so plain read-modify-write would do; the builtins keep the
 // door open for running workgroups on several threads
-template <typename T, typename U> inline T atomicAdd(T *p, U v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED); }
+// (x86 performs misaligned atomics; gfx950 raises a memory fault on them — a 64-bit cursor behind a 4-byte-per-cell array once did
+// exactly that on the GPU only — so the emulator checks the natural alignment of every atomic's address)
+template <typename T> inline void hipemu_check_atomic(const T *p) {
+  if (reinterpret_cast<uintptr_t>(p) % sizeof(T) != 0) { std::fprintf(stderr, "hipemu: %zu-byte atomic on misaligned address %p\n", sizeof(T), (const void *)p); std::abort(); }
+}
+template <typename T, typename U> inline T atomicAdd(T *p, U v) { hipemu_check_atomic(p); return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> inline T atomicSub(T *p, U v) { return __atomic_fetch_sub(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> inline T atomicOr(T *p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> inline T atomicAnd(T *p, U v) { return __atomic_fetch_and(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> inline T atomicExch(T *p, U v) { return __atomic_exchange_n(p, (T)v, __ATOMIC_RELAXED); }
 template <typename T, typename U> inline T atomicMax(T *p, U v) {
+  hipemu_check_atomic(p);
   T old = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (old < (T)v && !__atomic_compare_exchange_n(p, &old, (T)v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return old;
 }
 template <typename T, typename U> inline T atomicMin(T *p, U v) {
+  hipemu_check_atomic(p);
   T old = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (old > (T)v && !__atomic_compare_exchange_n(p, &old, (T)v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return old;
