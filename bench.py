@@ -41,10 +41,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
 FLOP_PER_KALMAN_STEP_3STATE = 60   # SURVEY.md 8d's model (one predict + update of the textbook three-state filter): rounds 1-2 priced on it
-# the contract since round 3 (tad_arima.hip:kfc_step4, the collapsed recursion): 15 add/mul per chain and step plus a quarter
-# of the batched inversion (9 multiplications + 1 division per four chains) are what is EXECUTED; `frac` is priced on those
-# flops, the 60-flop-equivalent fraction is reported next to it so that the rounds stay comparable
-FLOP_PER_KALMAN_STEP = 18
+# the contract since round 3 (tad_arima.hip:kfc_step4, the collapsed recursion): 13 flops per chain and step (v, g, w, q fma, product,
+# a1 = add + mul + fma, p' fma, p - p') plus a quarter of the batched inversion (9 multiplications + 1 division per four chains) are
+# what is EXECUTED; `frac` is priced on those flops, the 60-flop-equivalent fraction is reported next to it so that the rounds
+# stay comparable
+FLOP_PER_KALMAN_STEP = 16
 BYTES_PER_ROW = 24      # key_id u64 + flow_end_s i64 + value u64, read once
 BYTES_PER_ANOMALY = 40  # key_id, flow_end_s, throughput, algo_calc, stddev
 
@@ -386,7 +387,7 @@ def main():
             d["baseline_config"] = name
             if name == "c4":     # PMC passes of `bench.py --config c4` (profiles/README.md)
                 d["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(r["stats"][0]["stage0_path"], "k_scatter"),
-                                                       "r3_v6_pmc_c4.json")
+                                                       "r3_v8_pmc_c4.json")
             if not args.no_cpu_baseline:
                 cr, ck, sr = cpu_sample(c["algos"][0], c["rows"], c["keys"], cores)
                 try:
