@@ -1274,7 +1274,7 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, int partition_pass, P
   if (per < 18 + 8 * 9) return;
   uint32_t cap = (uint32_t)((per - 18) / 8);
   if (cap > 64) cap = 64;
-  uint32_t sec = cap >= 22 ? 16 : 8;   // 15 leftovers + room for a tile's arrivals
+  uint32_t sec = cap >= 22 ? 16 : 8;   // 15 leftovers + room for a tile's arrivals (18 slots at C4's 977 partitions: pass B 0.80 -> 0.99 ms, the spills cost more than the lines save: profiles/r3_v8_c4_line18_ab.log)
   if (sec == 8 && cap > 16) cap = 16;
   // the sort-by-tile pass writes runs of (tile slots / partitions) records: long runs beat 64-byte sectors
   const bool forced = partition_pass == 2;
