@@ -406,17 +406,38 @@ TAD_HD void arima_start_params(const double *__restrict__ y, size_t stride, uint
   double phi0 = 0.0, theta0 = 0.0, var0 = 0.0;
   bool fallback = m <= 2 || m - 2 <= 1;  // lagmat(endog, 2) / lagmat(residuals, 1) raise ValueError
   if (!fallback) {
+    // The passes below visit the rows in order, and row i needs y[i .. i + 4]: a sliding window of five values in registers, ONE
+    // load per row instead of the 6 - 10 the expressions name (k_arima_start is bound by those re-reads: every (key, position)
+    // lane streams its prefix five times).  The same differences of the same values: the bits do not change.
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0;
+    uint32_t at = 0xFFFFFFFFu;
+    auto Y = [&](uint32_t i) { return i < n ? y[(size_t)i * stride] : 0.0; };
+    auto window = [&](uint32_t i) {   // afterwards w0 .. w4 = y[i .. i + 4] (0 past the end: never used)
+      if (i == at + 1u && at != 0xFFFFFFFFu) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = Y(i + 4); }
+      else if (i != at) { w0 = Y(i); w1 = Y(i + 1); w2 = Y(i + 2); w3 = Y(i + 3); w4 = Y(i + 4); }
+      at = i;
+    };
     // AR(2) by pinv-OLS: e_t on (e_{t-1}, e_{t-2}), t = 2..m-1
-    const Ls2 ar = pinv2_solve(m - 2, [&](uint32_t i, double &c1, double &c2, double &yy) { c1 = e(i + 1); c2 = e(i); yy = e(i + 2); });
-    auto res = [&](uint32_t j) { return e(j + 2) - (e(j + 1) * ar.a + e(j) * ar.b); };  // residual of t = j + 2
-    // ARMA(1,1) by pinv-OLS: e_t on (e_{t-1}, res_{t-1}), t = 3..m-1
+    const Ls2 ar = pinv2_solve(m - 2, [&](uint32_t i, double &c1, double &c2, double &yy) {
+      window(i);
+      c1 = w2 - w1; c2 = w1 - w0; yy = w3 - w2;   // e(i + 1), e(i), e(i + 2)
+    });
+    // ARMA(1,1) by pinv-OLS: e_t on (e_{t-1}, res_{t-1}), t = 3..m-1;  res(j) = e(j + 2) - (e(j + 1) a + e(j) b): residual of t = j + 2
     const uint32_t rows = m - 3;
-    const Ls2 am = pinv2_solve(rows, [&](uint32_t i, double &c1, double &c2, double &yy) { c1 = e(i + 2); c2 = res(i); yy = e(i + 3); });
+    const Ls2 am = pinv2_solve(rows, [&](uint32_t i, double &c1, double &c2, double &yy) {
+      window(i);
+      c1 = w3 - w2; c2 = (w3 - w2) - ((w2 - w1) * ar.a + (w1 - w0) * ar.b); yy = w4 - w3;   // e(i + 2), res(i), e(i + 3)
+    });
     phi0 = am.a;
     theta0 = am.b;
     if (rows > 1) {
       double s = 0.0;
-      for (uint32_t i = 1; i < rows; ++i) { const double r2 = e(i + 3) - (e(i + 2) * am.a + res(i) * am.b); s += r2 * r2; }
+      for (uint32_t i = 1; i < rows; ++i) {
+        window(i);
+        const double resi = (w3 - w2) - ((w2 - w1) * ar.a + (w1 - w0) * ar.b);
+        const double r2 = (w4 - w3) - ((w3 - w2) * am.a + resi * am.b);
+        s += r2 * r2;
+      }
       var0 = s / (double)(rows - 1);
     } else {
       double mean = 0.0;
