@@ -3,7 +3,7 @@
 cd /root/repo
 O=gpurun_out/${1:-arab}; mkdir -p $O
 V=$PWD/theia_amd/lib/variants
-line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$1', round(d['ms_per_step'],1), 'ms; kernel', round(r.get('avg_kernel_ms',0),1), 'frac', round(r['frac'],3), 'nan_fits', r.get('nan_fits'), 'anomalies', d['result']['anomalies'])"; }
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$1', round(d['ms_per_step'],1), 'ms; kernel', round(r.get('avg_kernel_ms',0),1), 'frac', round(r['frac'],3), 'nan_fits', d.get('arima',{}).get('nan_fits'), 'anomalies', d['result']['anomalies'])"; }
 {
 ( timeout 900 python -m pytest tests/test_gpu_arima.py tests/test_gpu_job.py tests/test_gpu_multirank.py -m gpu -x -q 2>&1 | cut -c1-300 | tail -8 )
 for r in 1 2; do
