@@ -146,7 +146,8 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list(Grid g, double eps, in
 // here four keys are in flight per workgroup and nothing waits for anything.
 template <int PPL>
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double eps, int min_samples, const uint32_t *__restrict__ list,
-                                                              const unsigned int *__restrict__ count, uint32_t *__restrict__ n_anom) {
+                                                              const unsigned int *__restrict__ count, uint32_t *__restrict__ n_anom,
+                                                              double *__restrict__ sg_e, unsigned long long *__restrict__ am_e) {
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x >> 6;
   const unsigned total = *count;
@@ -188,25 +189,48 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
         for (int i = 0; i < PPL; ++i) reach[i] = reach[i] || fabs(x[i] - xj) <= eps;
       }
     uint32_t noise = 0;
+    unsigned long long am[PPL];
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
       const bool nz = p[i] && !core[i] && !reach[i];
       if (nz) g.flag[(uint64_t)(lane + 64u * (unsigned)i) * g.K + k] = FLAG_PRESENT | FLAG_ANOMALY;
-      noise += (uint32_t)__popcll(__ballot(nz));
+      am[i] = __ballot(nz);
+      noise += (uint32_t)__popcll(am[i]);
     }
     if (lane == 0 && n_anom != nullptr) n_anom[k] = noise;
+    // What the job's emit needs of a key with noise points, left next to the list entry: its noise masks and its stddev_samp
+    // (Spark CentralMomentAgg in time order: an IEEE division = the bits of div_by_count; every lane computes the same
+    // recurrence over the present points by readlane) — the series is in registers HERE; k_emit_dbscan_wave used to fetch the
+    // key's whole column (one 64-byte sector per bucket for 8 useful bytes: 238 MB at C4) a second time for these two things.
+    if (sg_e != nullptr && noise) {   // wavefront-uniform
+      double cn = 0.0, avg = 0.0, m2 = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < PPL; ++jj)
+        for (unsigned long long m = pm[jj]; m; m &= m - 1) {
+          const double xv = __shfl(x[jj], __ffsll((long long)m) - 1);
+          cn = cn + 1.0;
+          const double d = xv - avg;
+          const double dn = d / cn;
+          avg = avg + dn;
+          m2 = m2 + d * (d - dn);
+        }
+      if (lane == 0) {
+        sg_e[e] = cn >= 2.0 ? sqrt(m2 / (cn - 1.0)) : 0.0;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) am_e[(size_t)e * PPL + i] = am[i];
+      }
+    }
   }
 }
 
-// k_emit_dbscan_wave — the DBSCAN job's emit from the detector's
-// WORK LIST instead of a walk over all keys: only listed keys can have noise points, and there are few of them (C4: 1.8 % of
-// the keys, 14 488 rows).  One wavefront per listed key, lane l holds the buckets l, l + 64, ...: one load round instead of a
-// T-step walk with one or two useful lanes per wavefront (k_emit<4>, 0.11 ms at C4); stddev_samp in Spark's streaming order
-// by a readlane loop over the present points (every lane computes the same recurrence); the rows of the key go to
-// off[k] + rank in time order.
+// k_emit_dbscan_wave — the DBSCAN job's emit from the detector's WORK LIST instead of a walk over all keys: only listed keys can
+// have noise points, and there are few of them (C4: 1.8 % of the keys, 14 488 rows).  One wavefront per listed key with noise:
+// the noise masks and the key's stddev_samp come from the list entry (k_dbscan_list_wave), the lanes of the noise points fetch
+// their value from the grid; the rows of the key go to off[k] + rank in time order.
 template <int PPL>
 __global__ __launch_bounds__(kDbBlock) void k_emit_dbscan_wave(Grid g, Lattice L, const uint32_t *__restrict__ list,
                                                               const unsigned int *__restrict__ count, const uint32_t *__restrict__ n_anom,
+                                                              const double *__restrict__ sg_e, const unsigned long long *__restrict__ am_e,
                                                               const unsigned long long *__restrict__ off, OutRows out) {
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x >> 6;
@@ -215,42 +239,21 @@ __global__ __launch_bounds__(kDbBlock) void k_emit_dbscan_wave(Grid g, Lattice L
   for (unsigned e = blockIdx.x * kDbWaves + wave; e < total; e += gridDim.x * kDbWaves) {   // wavefront-uniform
     const uint64_t k = list[e];
     if (n_anom[k] == 0) continue;
-    double x[PPL];
-    unsigned long long pm[PPL], am[PPL];
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) {
-      const uint64_t t = lane + 64u * (unsigned)j;
-      const uint8_t fl = t < g.T ? g.flag[t * g.K + k] : (uint8_t)0;
-      x[j] = (fl & FLAG_PRESENT) ? (double)g.val[t * g.K + k] : 0.0;
-      pm[j] = __ballot((fl & FLAG_PRESENT) != 0);
-      am[j] = __ballot((fl & FLAG_ANOMALY) != 0);
-    }
-    // stddev_samp, Spark CentralMomentAgg in time order (k_emit<4>: an IEEE division = the bits of div_by_count)
-    double cnt = 0.0, avg = 0.0, m2 = 0.0;
-#pragma unroll
-    for (int jj = 0; jj < PPL; ++jj)
-      for (unsigned long long m = pm[jj]; m; m &= m - 1) {
-        const double xv = __shfl(x[jj], __ffsll((long long)m) - 1);
-        cnt = cnt + 1.0;
-        const double d = xv - avg;
-        const double dn = d / cnt;
-        avg = avg + dn;
-        m2 = m2 + d * (d - dn);
-      }
-    const double sg = cnt >= 2.0 ? sqrt(m2 / (cnt - 1.0)) : 0.0;
+    const double sg = sg_e[e];              // k_dbscan_list_wave left both for every listed key with noise points
     unsigned long long at = off[k];
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
-      if ((am[j] >> lane) & 1ull) {
+      const unsigned long long am = am_e[(size_t)e * PPL + j];
+      if ((am >> lane) & 1ull) {
         const uint64_t t = lane + 64u * (unsigned)j;
-        const unsigned long long r = at + (unsigned long long)__popcll(am[j] & lt_mask);
+        const unsigned long long r = at + (unsigned long long)__popcll(am & lt_mask);
         out.key_id[r] = k;
         out.flow_end_s[r] = g.times != nullptr ? g.times[t * g.K + k] : (long long)(L.t0 + (int64_t)t * L.step);
-        out.throughput[r] = x[j];
+        out.throughput[r] = (double)g.val[t * g.K + k];
         out.algo_calc[r] = 0.0;
         out.stddev[r] = sg;
       }
-      at += (unsigned long long)__popcll(am[j]);
+      at += (unsigned long long)__popcll(am);
     }
   }
 }
@@ -316,9 +319,16 @@ static bool list_fits_lds(uint64_t T) { return T * 13 + 64 <= 150 * 1024; }
 // bytes of device scratch the DBSCAN launch needs: the work list (4 B per key + a counter) when a series fits an LDS row,
 // else the global rows of the long-series kernel
 size_t dbscan_scratch_bytes(Grid g) {
+  if (g.T <= 256) return 64 + (((size_t)g.K * 4 + 63) & ~(size_t)63) + (size_t)g.K * (8 + 8 * 4);   // + per list entry: stddev, noise masks (wave list)
   if (list_fits_lds(g.T)) return (size_t)g.K * 4 + 64;
   return (size_t)g.K * g.T * (8 + 4 + 1);
 }
+
+// scratch of the wave list (T <= 256): count | list[K] u32 | sg[K] f64 | am[K * 4] u64
+static double *wave_list_sg(const void *scratch, Grid g) {
+  return reinterpret_cast<double *>(const_cast<unsigned char *>(static_cast<const unsigned char *>(scratch)) + 64 + (((size_t)g.K * 4 + 63) & ~(size_t)63));
+}
+static unsigned long long *wave_list_am(const void *scratch, Grid g) { return reinterpret_cast<unsigned long long *>(wave_list_sg(scratch, g) + g.K); }
 
 bool dbscan_uses_list(Grid g) { return list_fits_lds(g.T); }
 
@@ -335,7 +345,7 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   }
   uint64_t blocks = g.K < 2048 ? g.K : 2048;   // grid-stride over the (device-side) list length
   if (g.T <= 256) {   // a wavefront's registers hold the whole series
-#define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom)
+#define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom, wave_list_sg(scratch, g), wave_list_am(scratch, g))
     if (g.T <= 64) TAD_DBW(1); else if (g.T <= 128) TAD_DBW(2); else if (g.T <= 192) TAD_DBW(3); else TAD_DBW(4);
 #undef TAD_DBW
     return 0;
@@ -353,7 +363,7 @@ bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scr
   const unsigned int *count = static_cast<const unsigned int *>(scratch);
   const uint32_t *list = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(scratch) + 64);
   const uint64_t blocks = g.K < 2048 ? g.K : 2048;
-#define TAD_DBE(PPL) hipLaunchKernelGGL((k_emit_dbscan_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, lat, list, count, n_anom, off, out)
+#define TAD_DBE(PPL) hipLaunchKernelGGL((k_emit_dbscan_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, lat, list, count, n_anom, wave_list_sg(scratch, g), wave_list_am(scratch, g), off, out)
   if (g.T <= 64) TAD_DBE(1); else if (g.T <= 128) TAD_DBE(2); else if (g.T <= 192) TAD_DBE(3); else TAD_DBE(4);
 #undef TAD_DBE
   return true;
