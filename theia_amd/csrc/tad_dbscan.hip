@@ -343,7 +343,10 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
     hipMemsetAsync(count, 0, sizeof(unsigned int), s);
     hipLaunchKernelGGL(k_dbscan_scan<false>, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
   }
-  uint64_t blocks = g.K < 2048 ? g.K : 2048;   // grid-stride over the (device-side) list length
+  // grid-stride over the (device-side) list length: 8192 workgroups of four wavefronts give every one of C4's ~2e4 listed keys its
+  // own wavefront (2048: 2-3 keys per wavefront one after the other; detect + emit 0.179 -> 0.174 ms, 32768 the same:
+  // profiles/r3_v9_c4_list_blocks_ab.log)
+  uint64_t blocks = g.K < 8192 ? g.K : 8192;
   if (g.T <= 256) {   // a wavefront's registers hold the whole series
 #define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom, wave_list_sg(scratch, g), wave_list_am(scratch, g))
     if (g.T <= 64) TAD_DBW(1); else if (g.T <= 128) TAD_DBW(2); else if (g.T <= 192) TAD_DBW(3); else TAD_DBW(4);
