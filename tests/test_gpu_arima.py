@@ -132,6 +132,15 @@ def test_job_arima_c3_table_sample(engine):
     assert res.stats["kalman_steps"] == want["kalman_steps"]
 
 
+def test_job_arima_many_keys_share_the_position_cursor(engine):
+    """9 000 keys x 9 buckets: three wavefronts per series position pull their keys from ONE cursor (k_arima_fit's refill, a
+    64-bit global atomic); which lane fits which key must not enter the results — every prediction against the oracle."""
+    k, t, v = orc.synth_rows(0, 9000 * 9 * 2, 9000, 9)
+    want, res = check_job(engine, k, t, v, 9000)
+    assert want["n_keys"] > 8900
+    assert res.stats["kalman_steps"] == want["kalman_steps"]
+
+
 def test_job_arima_keys_without_result(engine):
     # key 0: 3 points (n <= 3), key 1: constant, key 2: contains a zero, key 3: a real series
     key = np.repeat(np.arange(4, dtype=np.uint64), [3, 6, 6, 30])
