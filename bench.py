@@ -351,7 +351,7 @@ def main():
                                 "achieved_tflops": flops / sec / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                                 "frac": flops / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "ms_detect": a["ms_detect"] / steps,
                                 "tflops_60flop_equivalent": eq60, "frac_60flop_equivalent": eq60 / FP64_VECTOR_PEAK_TFLOPS,
-                                "flop_model": "18 flop per time-step of the collapsed recursion (executed) x the engine's kalman_steps counter; "
+                                "flop_model": "16 flop per time-step of the collapsed recursion (executed) x the engine's kalman_steps counter; "
                                               "60-flop-equivalent = SURVEY.md 8d's three-state model on the same counter (rounds 1-2 reported that)"}
                 if len(algos) == 1:     # the detector, not Stage 0, is this config's dominant kernel
                     out["roofline"] = {"bound": "fp64-vector", "kernel": "k_arima_fit (per-lane L-BFGS-B over the ARIMA(1,1,1) likelihood, four recursions per lane)",
