@@ -212,7 +212,7 @@ def test_job_sparse_live_rows_in_an_unsampled_stretch(engine, stage0):
 
 def test_job_sampled_histogram_too_optimistic_falls_back_to_exact(engine, stage0):
     # Stage-0 v2 sizes pass B's (workgroup, partition) regions from a SAMPLE of the key column (one 8192-row iteration in
-    # eight of every workgroup's chunk + the chunk ends).  Here 16 keys occur ONLY in stretches the sample skips: their
+    # sixteen of every workgroup's chunk + the chunk ends; eight until late in round 3).  Here 16 keys occur ONLY in stretches the sample skips: their
     # regions are sized for nothing, pass B finds them full (DEV_ERR_REGION_FULL) and the job must be redone with the exact
     # histogram — same rows as the oracle, bit for bit.
     if stage0 == "v1":

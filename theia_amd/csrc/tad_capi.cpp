@@ -597,7 +597,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   const bool force_v2 = plan.stage0 == 2;
   const bool has2 = cols->key_id2 != nullptr;
   bool force_v1_retry = false;
-  // pass A may histogram a SAMPLE of the rows (1/8 of the key column instead of all of it): pass B's regions are then sized from
+  // pass A may histogram a SAMPLE of the rows (1/16 of the key column, plus the chunk ends, instead of all of it): pass B's regions are then sized from
   // the estimate with 6 sigma of slack; a region that still turns out too small (keys arriving in bursts the sample missed)
   // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  tad_plan.histogram = 1 disables it.
   bool force_exact_hist = plan.histogram == 1;

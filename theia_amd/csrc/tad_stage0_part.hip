@@ -29,7 +29,7 @@
 //
 // Sampled lattice: every thread of pass A feeds only its first kGcdSamples kept rows into the gcd (a 64-bit
 // modulo per row would make the pass ALU-bound) and, when no time-window filter is set, reads the time column
-// for one iteration in eight plus both ends of its chunk.  The sampled step is a multiple of the true one and the
+// for one iteration in sixteen plus both ends of its chunk.  The sampled step is a multiple of the true one and the
 // sampled [min, max] lies inside the true range.  Pass B checks EVERY row against the lattice; a row off it
 // (between lattice points, or outside the range) raises DEV_ERR_OFF_LATTICE and the host reruns with the exact
 // derivation over all rows (tad_kernels.hip:k_meta).  Results are therefore never computed on a wrong lattice.
@@ -163,6 +163,12 @@ __device__ __forceinline__ void hist_row(MetaAcc &a, uint32_t *hist, uint64_t k1
   }
 }
 
+// Pass A reads one iteration (8192 rows of a workgroup's chunk) in kSampleMask + 1, plus both ends of the chunk.  One in eight until
+// late in round 3; one in sixteen: pass A 0.106 -> 0.083 ms at C2, regions 2.4x instead of 2x their records (6 sigma of a noisier
+// estimate: address space, never touched), pass B and pass C unchanged once a slice is long enough to keep a partition whole
+// (profiles/r3_v9_passA_sample16_ab.log; with slices of 2x the records every partition split in two and merged through atomics: +0.13 ms).
+static constexpr uint32_t kSampleMask = 15;
+
 template <bool VEC, bool HAS2, bool SAMPLE_H>
 __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__restrict__ key,
                                                             const uint64_t *__restrict__ key2,
@@ -189,13 +195,13 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
     const longlong2 *tv = reinterpret_cast<const longlong2 *>(t_end + lo);
     constexpr int U = 4;
     // Without a time-window filter the time column is only needed for (min, max, sampled gcd): read it for one
-    // iteration in eight plus both ends of the chunk (time-ordered tables have their extremes there) and let the
+    // iteration in sixteen plus both ends of the chunk (time-ordered tables have their extremes there) and let the
     // partition pass, which checks every row against the lattice, catch a missed extreme (-> exact re-derivation).
     const bool sample_t = f.end_time == 0 && !has_ts;
     uint64_t i = threadIdx.x;
     uint32_t it = 0;
     for (; i + (U - 1) * kPartThreads < npair; i += U * kPartThreads, ++it) {
-      const bool with_t = !sample_t || (it & 7) == 0 || (i - threadIdx.x) + 2 * U * kPartThreads >= npair;  // workgroup-uniform
+      const bool with_t = !sample_t || (it & kSampleMask) == 0 || (i - threadIdx.x) + 2 * U * kPartThreads >= npair;  // workgroup-uniform
       if (SAMPLE_H && !with_t) continue;   // sampled histogram: the unsampled iterations are not read at all
       seen += 2 * U;
       ulonglong2 k[U], k2[U];
@@ -1315,7 +1321,7 @@ bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 
 // 6 sigma of every region summed by Cauchy-Schwarz over R = G * nparts regions whose estimates total <= slots
 uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl) {
-  const double R = (double)pl.G * (double)pl.nparts, scale = 9.0;   // sampling ratio 1/8 plus the chunk ends
+  const double R = (double)pl.G * (double)pl.nparts, scale = (double)(kSampleMask + 2);   // sampling ratio 1/16 plus the chunk ends
   return slots + (uint64_t)(6.0 * sqrt(scale * R * (double)slots) + R * (8.0 * scale + 16.0 + 16.0)) + 1024;
 }
 
@@ -1399,9 +1405,9 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   st.slice_part = static_cast<uint32_t *>(slice_mem);
   st.slice_first = st.slice_part + max_slices;
   st.n_slices = st.slice_first + pl.nparts;
-  // regions sized from a sampled histogram hold ~2x the slots of their records: slices twice as long keep one slice per
+  // regions sized from a sampled histogram hold ~2.4x the slots of their records: slices three times as long keep one slice per
   // partition for uniform tables (a split partition merges into the grid with atomics instead of plain stores)
-  const uint32_t slice_len = fin != nullptr ? 2 * kSliceRecords : kSliceRecords;
+  const uint32_t slice_len = fin != nullptr ? 3 * kSliceRecords : kSliceRecords;
   hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st, slice_len);
   const bool may_split = slots > slice_len;  // some partition could exceed one slice
   // the rounds of a partition run as parallel workgroups on one XCD (measured: C2 pass C 0.39 -> 0.29 ms against sequential rounds)
