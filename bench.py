@@ -387,7 +387,7 @@ def main():
             d["baseline_config"] = name
             if name == "c4":     # PMC passes of `bench.py --config c4` (profiles/README.md)
                 d["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(r["stats"][0]["stage0_path"], "k_scatter"),
-                                                       "r3_v9_pmc_c4.json")
+                                                       "r3_v10_pmc_c4.json")
             if not args.no_cpu_baseline:
                 cr, ck, sr = cpu_sample(c["algos"][0], c["rows"], c["keys"], cores)
                 try:
