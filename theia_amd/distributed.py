@@ -119,17 +119,21 @@ class JobReducer:
     WIDTH = len(STAT_FIELDS) + 3
 
     class Pending:
-        def __init__(self, owner, slot, work):
-            self.owner, self.slot, self.work = owner, slot, work
+        def __init__(self, owner, slot, work, event=None):
+            self.owner, self.slot, self.work, self.event = owner, slot, work, event
 
         def result(self):
             o = self.owner
-            if self.work is not None:
-                self.work.wait()
-            if o.collective:
-                rows = o.gathered[self.slot].view(o.world, o.WIDTH).tolist()
+            if self.event is not None:      # device path: the gathered rows are already on their way to pinned host memory
+                self.event.synchronize()
+                rows = o._host_np[self.slot].reshape(o.world, o.WIDTH).tolist()
             else:
-                rows = [o.payload[self.slot].tolist()]
+                if self.work is not None:
+                    self.work.wait()
+                if o.collective:
+                    rows = o.gathered[self.slot].view(o.world, o.WIDTH).tolist()
+                else:
+                    rows = [o.payload[self.slot].tolist()]
             nf = len(STAT_FIELDS)
             out = {f: int(sum(int(r[i]) for r in rows)) for i, f in enumerate(STAT_FIELDS)}
             n, mean, m2 = chan_merge([tuple(r[nf:nf + 3]) for r in rows])
@@ -149,6 +153,13 @@ class JobReducer:
         self.payload = [torch.zeros(self.WIDTH, dtype=torch.float64, device=device) for _ in range(2)]
         self.gathered = [torch.zeros(self.world * self.WIDTH, dtype=torch.float64, device=device) for _ in range(2)]
         self._stage = [torch.zeros(self.WIDTH, dtype=torch.float64).pin_memory() for _ in range(2)] if on_gpu else None
+        # device path: nothing of the per-job collective waits on the host — the payload goes up from pinned memory, the gathered
+        # rows come down into pinned memory right behind the all-gather (stream-ordered), result() waits for an event that has
+        # normally long fired (the next job ran in between).  Measured with a one-rank RCCL group: 75 us of host work per job before.
+        self._stage_np = [t.numpy() for t in self._stage] if on_gpu else None
+        self._host = [torch.zeros(self.world * self.WIDTH, dtype=torch.float64).pin_memory() for _ in range(2)] if on_gpu else None
+        self._host_np = [t.numpy() for t in self._host] if on_gpu else None
+        self._events = [torch.cuda.Event() for _ in range(2)] if on_gpu else None
         self._next = 0
 
     def start(self, stats):
@@ -158,13 +169,19 @@ class JobReducer:
         vals = [float(int(stats.get(f, 0))) for f in STAT_FIELDS] + \
                [float(stats.get("n_points", 0)), float(stats.get("pts_mean", 0.0)), float(stats.get("pts_m2", 0.0))]
         if self._stage is not None:
-            self._stage[slot].copy_(torch.tensor(vals, dtype=torch.float64))
+            self._stage_np[slot][:] = vals
             self.payload[slot].copy_(self._stage[slot], non_blocking=True)
         else:
             self.payload[slot].copy_(torch.tensor(vals, dtype=torch.float64))
         work = None
         if self.collective:
             work = dist.all_gather_into_tensor(self.gathered[slot], self.payload[slot], group=self.group, async_op=True)
+        if self._host is not None:
+            if work is not None:
+                work.wait()              # (RCCL: orders the current stream behind the collective; the host does not block)
+            self._host[slot].copy_(self.gathered[slot] if self.collective else self.payload[slot], non_blocking=True)
+            self._events[slot].record()
+            return JobReducer.Pending(self, slot, None, self._events[slot])
         return JobReducer.Pending(self, slot, work)
 
     def reduce(self, stats):
