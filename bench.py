@@ -229,10 +229,16 @@ def main():
 
         dump = {}
 
+        prepared = {}   # the device-resident job of a step, its two C structs built once (TadEngine.prepare): a step = the bare tad_run call
+
         def one_job(algo, k_, t_, v_):
             if host_input:
                 return eng.run(algo, hkey, htend, hval, K, agg_flow=agg, lattice=lattice, out="host")
-            return eng.run(algo, k_, t_, v_, K, agg_flow=agg, lattice=lattice, out="host" if dump.get("on") else "device")
+            if dump.get("on") or ingest == "rows":
+                return eng.run(algo, k_, t_, v_, K, agg_flow=agg, lattice=lattice, out="host" if dump.get("on") else "device")
+            if algo not in prepared:
+                prepared[algo] = eng.prepare(algo, k_, t_, v_, K, agg_flow=agg, lattice=lattice, out="device")
+            return prepared[algo].run()
 
         def step():
             stats, glob = [], None

@@ -9,6 +9,7 @@ import pytest
 
 from oracle import arima_oracle as ao
 from oracle import job_oracle as jo
+from oracle import tad_oracle as orc
 from theia_amd import anomaly_detection as ad
 
 from test_host_job import CASES, canon
@@ -133,3 +134,16 @@ def test_e2e_result_map(engine, golden, algo, mode):
         # pod modes aggregate the inbound and the outbound half of every flow separately: same series twice
         assert ("%e" % r["throughput"])[:5] in E2E_RESULT_MAP[algo], r
     assert len({len(r) for r in rows}) == 1      # one row shape per aggregation mode
+
+
+def test_prepared_job_is_the_same_call(engine):
+    """TadEngine.prepare builds tad_job / tad_columns once; every PreparedJob.run() is a full tad_run over the live columns."""
+    k, t, v = orc.synth_rows(0, 300_000, 300, 40)
+    want = engine.run("EWMA", k, t, v, 300, agg_flow="svc")
+    job = engine.prepare("EWMA", k, t, v, 300, agg_flow="svc")
+    for _ in range(3):
+        got = job.run()
+        assert got.n_rows == want.n_rows and got.stats["rows_used"] == 300_000
+        for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+            assert (got[f] == want[f]).all(), f
+

@@ -81,6 +81,20 @@ def _as_column(x, dtype, n_expected=None):
     return a.ctypes.data, a.size, False, a
 
 
+class PreparedJob:
+    """TadEngine.prepare(...): one job over one set of live columns, ready to be submitted any number of times."""
+
+    def __init__(self, engine, job, cols, out_memory, keep):
+        self._engine, self._job, self._cols, self._out, self._keep = engine, job, cols, out_memory, keep
+        self._jref, self._cref = C.byref(job), C.byref(cols)
+
+    def run(self):
+        res = C.POINTER(capi.Result)()
+        e = self._engine
+        e._check(e._lib.tad_run(e._h, self._jref, self._cref, self._out, C.byref(res)))
+        return TadResult(e, res)
+
+
 class TadResult:
     """Anomalous points ordered by (key_id, flow_end_s) + the run's counters and stage timings."""
 
@@ -299,7 +313,7 @@ class TadEngine:
     # ---- the job (anomaly_detection.py:647-710) ----
     def run(self, algo, key_id, flow_end_s, value, num_keys, agg_flow="", value_op="auto", key_id2=None,
             flow_start_s=None, start_time=0, end_time=0, lattice=None, emit_all=False, out="host", job_id="",
-            alpha=0.0, eps=0.0, min_samples=0, maxiter=0, drop_nsigma=0.0, drop_min_samples=0):
+            alpha=0.0, eps=0.0, min_samples=0, maxiter=0, drop_nsigma=0.0, drop_min_samples=0, _prepare_only=False):
         if algo not in capi.TAD_ALGO:
             raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "algo must be EWMA, ARIMA, DBSCAN or DROP")
         if agg_flow not in capi.TAD_AGG:
@@ -322,12 +336,21 @@ class TadEngine:
                             num_keys=int(num_keys), memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
         if lattice is not None:
             cols.t0, cols.step, cols.n_buckets = int(lattice[0]), int(lattice[1]), int(lattice[2])
+        if _prepare_only:
+            return PreparedJob(self, job, cols, capi.TAD_MEM_DEVICE if out == "device" else capi.TAD_MEM_HOST,
+                               (keep1, keep2, keep3, keep4, keep5))
         res = C.POINTER(capi.Result)()
         rc = self._lib.tad_run(self._h, C.byref(job), C.byref(cols),
                                capi.TAD_MEM_DEVICE if out == "device" else capi.TAD_MEM_HOST, C.byref(res))
         del keep1, keep2, keep3, keep4, keep5
         self._check(rc)
         return TadResult(self, res)
+
+    def prepare(self, *args, **kw):
+        """Same arguments as run(): the tad_job / tad_columns structs built ONCE, for a host that submits the same job over the
+        same (live) columns repeatedly — PreparedJob.run() is then the bare tad_run call (a cgo host pays no more either; building
+        the two structs and inspecting five column objects in Python costs ~15 us per call, 1 % of a C2 job)."""
+        return self.run(*args, _prepare_only=True, **kw)
 
     # ---- streaming EWMA: one new batch against the per-key running state ----
     def state_create(self, num_keys):
