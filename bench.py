@@ -10,7 +10,8 @@ buckets, sum(throughput) (mode svc), the deterministic synthetic table of SURVEY
 `other_configs`: C4 (configs[3]: DBSCAN, 1e6 keys x 100 buckets, max(throughput) = mode None) and C3 (configs[2]: ARIMA
 on the C2 table), each timed the same way (W warm-up steps, K timed steps bracketed by synchronisation) with its own
 roofline — so that those rates are measured by whoever runs this file, not quoted.
-N>1 (torchrun, one rank per GPU): weak scaling — every rank owns the key shard `key mod N == rank`
+N>1 (`python bench.py --gpus N` starts the N ranks itself; under an external torchrun — WORLD_SIZE set — it is one of them;
+one rank per GPU): weak scaling — every rank owns the key shard `key mod N == rank`
 (1e8 rows / 1e5 keys per rank, pre-sharded by key as SURVEY.md §8e allows), no data-path collective;
 per step ONE RCCL all-gather of 9 doubles per rank: the counters [anomalies, keys, points, rows, ...] (the global
 `count() == 0` sentinel decision, anomaly_detection.py:395) and the (n, mean, M2) moments (global sigma).
@@ -135,6 +136,23 @@ def pmc_traffic(kernel, name="pmc_latest.json"):
         return None
 
 
+def launch_ranks(n):
+    """Run this same command line as `n` ranks of one node (python -m torch.distributed.run, one process per GPU) and return
+    the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +183,12 @@ def main():
                                                      "(GLOBAL key ids) to <path>.rank<r>.npz — used by the N-rank == 1-rank parity test")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks here (one process per GPU under
+        # torch.distributed.run, RCCL rendezvous on 127.0.0.1) and hand the same command line to each of them; the ranks inherit
+        # stdout, rank 0 alone prints the JSON line, last.  Under an external torchrun WORLD_SIZE is set and this is skipped.
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from theia_amd import TadEngine
@@ -176,6 +200,9 @@ def main():
     # backend "nccl" is RCCL on ROCm.  TAD_BENCH_BACKEND=gloo exists to exercise the N>1 code path on a box with
     # fewer GPUs than ranks (ranks then share devices and the collectives run on host tensors).
     backend = os.environ.get("TAD_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > max(1, torch.cuda.device_count()):
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s): RCCL needs one device per rank (TAD_BENCH_BACKEND=gloo lets ranks "
+                         "share a device for testing the N>1 code path)" % (world, torch.cuda.device_count()))
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -386,15 +413,23 @@ def main():
     if world == 1 and headline_is_c2 and not args.no_other_configs and not args.host_input and args.ingest == "keys":
         # BASELINE.json configs[3] and configs[2], measured in the same run (their tables replace the C2 table in HBM)
         others = {}
-        for name, steps, warmup in (("c4", 5, 2), ("c3", 1, 1)):
+        # C5 at N = 1 is the strong-scaling base of BASELINE.json configs[4] (the whole 1e9-row / 1e6-key table on one GPU)
+        for name, steps, warmup in (("c4", 5, 2), ("c3", 1, 1), ("c5", 1, 1)):
             c = CONFIGS[name]
-            r = run_config(c["algos"], c["rows"], c["keys"], c["buckets"], c["agg"], steps, warmup)
+            try:
+                r = run_config(c["algos"], c["rows"], c["keys"], c["buckets"], c["agg"], steps, warmup)
+            except Exception as exc:      # the headline line must still be printed
+                others[name] = {"baseline_config": name, "error": repr(exc)[:300]}
+                torch.cuda.empty_cache()
+                continue
             d = describe(r)
             d["baseline_config"] = name
             if name == "c4":     # PMC passes of `bench.py --config c4` (profiles/README.md)
                 d["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(r["stats"][0]["stage0_path"], "k_scatter"),
                                                        "r3_v10_pmc_c4.json")
-            if not args.no_cpu_baseline:
+            if name == "c5":
+                d["scaling"] = "strong (this is the N = 1 base: `bench.py --config c5 --gpus N` splits the same table over N ranks)"
+            elif not args.no_cpu_baseline:
                 cr, ck, sr = cpu_sample(c["algos"][0], c["rows"], c["keys"], cores)
                 try:
                     d["cpu_baseline"] = cpu_baseline(c["algos"][0], cr, ck, c["buckets"], c["agg"], sr)

@@ -90,7 +90,7 @@ def test_shard_rows_buckets_by_owner(engine):
 
 
 def test_default_config_key_sharded_two_ranks(tmp_path):
-    # the weak-scaling path the driver launches (`bench.py --gpus N`, key-sharded, one all-gather per job), reduced in size,
+    # the weak-scaling path under an EXTERNAL torchrun (`bench.py --gpus N`, key-sharded, one all-gather per job), reduced in size,
     # two ranks on one GPU: the line must describe the whole job (both ranks' rows), and the reduced counters must add up
     env = dict(os.environ, TAD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -102,6 +102,33 @@ def test_default_config_key_sharded_two_ranks(tmp_path):
     assert d["result"]["rows_used"] == 2 * 3_000_000 and d["result"]["keys"] == 2 * 3000
     assert abs(d["value"] - 2 * 3_000_000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9       # whole-job rate over both ranks
     assert "other_configs" not in d and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+
+
+def _self_launched(extra):
+    """`python bench.py --gpus 2 ...` with NO launcher around it and no WORLD_SIZE in the environment — the form the driver uses."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["TAD_BENCH_BACKEND"] = "gloo"          # two ranks share this box's one GPU
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert sum(1 for l in lines if l.startswith("{")) == 1 and lines[-1].startswith("{"), r.stdout[-2000:]   # ONE line, last, rank 0's
+    return json.loads(lines[-1])
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    d = _self_launched(["--rows", "3000000", "--keys", "3000", "--steps", "3", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["result"]["rows_used"] == 2 * 3_000_000 and d["result"]["keys"] == 2 * 3000
+    assert abs(d["value"] - 2 * 3_000_000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    assert "other_configs" not in d
+
+
+def test_bench_c5_gpus_2_row_sharded_starts_two_ranks_by_itself():
+    d = _self_launched(["--config", "c5", "--rows", "300000", "--keys", "300", "--buckets", "60", "--steps", "1", "--warmup", "0",
+                        "--ingest", "rows"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["algo"] == "EWMA+ARIMA"
+    assert "row-sharded x2" in d["config"]["parallelism"] and d["result"]["keys"] == 600
 
 
 def test_rccl_one_rank_group_runs_the_collectives_on_device_tensors(tmp_path):
