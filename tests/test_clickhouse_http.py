@@ -257,3 +257,27 @@ def test_query_columns_unifies_the_dictionaries_of_the_record_batches(server):
     assert isinstance(enc["s"], ad.DictColumn) and sorted(enc["s"].values.tolist()) == ["", "a", "b", "c"]
     assert enc["s"].materialise().tolist() == plain["s"].tolist() == ["b", "a", "b", "", "c", "a", "c"]
     assert enc["n"].tolist() == [1, 2, 3, 4, 5, 6, 7]
+
+
+def test_query_columns_accepts_server_side_dictionaries_bools_dates_and_decimals(server):
+    """LowCardinality columns arrive as Arrow dictionaries when output_format_arrow_low_cardinality_as_dictionary is on: the
+    indices are remapped like a batch-local dictionary (no re-encode); non-string columns pass through and get no vocabulary."""
+    import datetime
+    import decimal
+    s1 = pa.DictionaryArray.from_arrays(pa.array([1, 0, 1, 2], pa.int8()), pa.array(["a", "b", ""]))
+    s2 = pa.DictionaryArray.from_arrays(pa.array([0, 0, None], pa.int8()), pa.array(["c", "a"]))
+    def tab(s, n0):
+        k = len(s)
+        return pa.table({"s": s, "flag": pa.array([True, False, True, True][:k]), "d": pa.array([datetime.date(2022, 8, 11)] * k, pa.date32()),
+                         "x": pa.array([decimal.Decimal("1.5")] * k, pa.decimal128(10, 2)), "n": pa.array(list(range(n0, n0 + k)), pa.uint16())})
+    server.responses["SELECT q"] = pa.concat_tables([tab(s1, 0), tab(s2, 4)])
+    client = ch.ClickHouseHTTP(server.url, user="", password="")
+    plain = client.query_columns("SELECT q")
+    enc = client.query_columns("SELECT q", dict_strings=True)
+    assert plain["s"].tolist() == ["b", "a", "b", "", "c", "c", ""]
+    assert isinstance(enc["s"], ad.DictColumn) and enc["s"].materialise().tolist() == plain["s"].tolist()
+    for name in ("flag", "d", "x", "n"):
+        assert not isinstance(enc[name], ad.DictColumn), name
+        assert np.array_equal(np.asarray(enc[name]), np.asarray(plain[name])), name
+    assert enc["flag"].tolist() == [True, False, True, True, True, False, True] and enc["x"].tolist() == [1.5] * 7
+    assert enc["d"].tolist() == [1660176000] * 7 and enc["n"].tolist() == list(range(7))

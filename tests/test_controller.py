@@ -85,7 +85,8 @@ def test_argument_vector_is_the_spark_applications():
     # the argument vector is what the job's own command line accepts (anomaly_detection.py:781-870)
     from theia_amd import anomaly_detection as ad
     assert ad.RESULT_TABLE_NAME.endswith(ctl.RESULT_TABLE)
-    assert ctl.cleanup_query(jid) == "ALTER TABLE tadetector ON CLUSTER '{cluster}' DELETE WHERE id = (" + jid + ");"   # controller.go:396
+    assert ctl.reference_cleanup_query(jid) == "ALTER TABLE tadetector ON CLUSTER '{cluster}' DELETE WHERE id = (" + jid + ");"   # controller.go:396, verbatim
+    assert ctl.cleanup_query(jid) == "ALTER TABLE tadetector ON CLUSTER '{cluster}' DELETE WHERE id = ('" + jid + "');"   # what is sent: the id quoted
 
 
 def test_states_progress_end_time_and_cleanup():
@@ -186,13 +187,119 @@ def test_job_walks_the_states_on_the_gpu_engine(engine, algo, agg):
         want = jo.run(flows, algo, tad_id=t.name[4:], **kw)
         got = [r for _, rows in server.inserted for r in rows]
         assert len(got) == len(want) and len(got) > 0
-        assert sorted(float(r["throughput"]) for r in got) == sorted(float(r["throughput"]) for r in want)
-        assert sorted(float(r["algoCalc"]) for r in got) == sorted(float(r["algoCalc"]) for r in want)
+        # whole rows, every column of the tadetector schema, in (key columns, time) order: a key-decoding mistake cannot hide
+        # behind equal multisets of numbers
+        def canon(rows):
+            out = []
+            for r in rows:
+                d = {k: (float(v) if k in ("throughput", "algoCalc", "throughputStandardDeviation") else
+                         (int(v) if k == "flowEndSeconds" else str(v))) for k, v in r.items()}
+                out.append(d)
+            return sorted(out, key=lambda d: tuple(str(d[k]) for k in sorted(d) if k not in ("throughput", "algoCalc", "throughputStandardDeviation")) +
+                          (d["flowEndSeconds"],))
+        cg, cw = canon(got), canon(want)
+        assert [sorted(d) for d in cg] == [sorted(d) for d in cw]
+        for a, b in zip(cg, cw):
+            assert a == b, (a, b)
         assert all(r["id"] == t.name[4:] and r["algoType"] == algo for r in got)
-        assert all(r["anomaly"] == w["anomaly"] for r, w in zip(got[:1], want[:1]))
         c.delete(NS, t.name)
         assert server.commands == [ctl.cleanup_query(t.name[4:])]
     finally:
         if c is not None:
             c.shutdown()
         server.close()
+
+
+def test_delete_while_the_job_runs_writes_nothing_and_cleans_up_again():
+    """cleanupTADetector stops the application before it can write (controller.go:385-398): a job body that is still running when
+    its resource is deleted is cancelled — run_engine_job asks `cancelled()` before the INSERT — and the cleanup statement is
+    issued once more when the body returns, so nothing it wrote can stay behind."""
+    started, release, commands, wrote = threading.Event(), threading.Event(), [], []
+
+    class FakeCH:
+        def command(self, sql):
+            commands.append(sql)
+
+    c = ctl.AnomalyDetectorController(clickhouse=FakeCH())
+
+    def job(args, t):          # what run_engine_job does around the engine call: check the tombstone, then write
+        started.set()
+        release.wait(10)
+        if c._is_cancelled(t.name[4:]):
+            raise ctl.JobCancelled(t.name[4:])
+        wrote.append(t.name)
+
+    c._run_job = job
+    try:
+        t = tad(jobType="EWMA", aggFlow="svc")
+        c.create(t)
+        assert started.wait(10)
+        c.delete(NS, t.name)
+        assert commands == [ctl.cleanup_query(t.name[4:])]
+        release.set()
+        for _ in range(500):
+            if len(commands) == 2:
+                break
+            threading.Event().wait(0.01)
+        assert commands == [ctl.cleanup_query(t.name[4:])] * 2 and wrote == []
+        assert not c._is_cancelled(t.name[4:]) and c.list(NS) == []
+    finally:
+        c.shutdown()
+
+
+def test_job_bodies_run_on_a_bounded_pool_and_cleanup_errors_do_not_escape():
+    lock, running, peak, gate = threading.Lock(), [0], [0], threading.Event()
+
+    class BrokenCH:
+        def command(self, sql):
+            raise RuntimeError("server says no")
+
+    def job(args, t):
+        with lock:
+            running[0] += 1
+            peak[0] = max(peak[0], running[0])
+        gate.wait(10)
+        with lock:
+            running[0] -= 1
+
+    c = ctl.AnomalyDetectorController(clickhouse=BrokenCH(), run_job=job, workers=2)
+    try:
+        names = []
+        for _ in range(6):
+            t = tad(jobType="EWMA")
+            names.append(t.name)
+            c.create(t)
+        for _ in range(300):
+            with lock:
+                if running[0] == 2:
+                    break
+            threading.Event().wait(0.01)
+        threading.Event().wait(0.1)
+        assert peak[0] == 2                                   # never more bodies than workers
+        gate.set()
+        for n in names:
+            assert c.wait(NS, n, timeout=15).status.state == ctl.STATE_COMPLETED
+        c.delete(NS, names[0])                                # the DELETE fails on the server: logged, not raised (controller.go:262-280)
+        assert isinstance(c._last_error, RuntimeError) and len(c.list(NS)) == 5
+    finally:
+        c.shutdown()
+
+
+def test_a_progress_update_cannot_undo_a_completed_state():
+    c = ctl.AnomalyDetectorController(run_job=lambda a, t: None, progress=lambda: (1, 4))
+    try:
+        t = tad(jobType="EWMA")
+        c.create(t)
+        done = c.wait(NS, t.name, timeout=10)
+        assert done.status.state == ctl.STATE_COMPLETED
+        key = (NS, t.name)
+        c._update_status(key, only_if_state=(ctl.STATE_SCHEDULED, ctl.STATE_RUNNING), state=ctl.STATE_RUNNING, completedStages=1)
+        assert c.get(NS, t.name).status.state == ctl.STATE_COMPLETED
+        # a stale snapshot in RUNNING state synced late: update_progress must leave COMPLETED and endTime alone
+        stale = c.get(NS, t.name)
+        stale.status.state = ctl.STATE_RUNNING
+        c.update_progress(key, stale)
+        after = c.get(NS, t.name)
+        assert after.status.state == ctl.STATE_COMPLETED and after.status.endTime == done.status.endTime
+    finally:
+        c.shutdown()

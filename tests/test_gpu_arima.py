@@ -49,7 +49,7 @@ def test_series_arima_golden_series(engine, golden):
     assert verdict.tolist() == golden["expected_anomaly_list_arima"]
     five = [int(str(float(v))[:5]) for v in got]
     hits = sum(a == b for a, b in zip(five, golden["expected_arima_row_list"]))
-    assert hits >= 76, hits                      # measured 78 / 90 (the reference's own two lists agree at 78 / 90)
+    assert hits >= 80, hits                      # measured 81 / 90, the CPU gate of tests/test_oracle_arima.py (the reference's own two lists agree at 78 / 90)
     # reported, not gated: distance to the reference's unasserted full-precision list (:288-318)
     full = np.array(golden["expanded_arima_row_list"])
     rel = rel_err(got, full)

@@ -147,7 +147,8 @@ def test_job_arima_exact_vs_scipy_driven():
     kb = {(r["destinationServicePortName"], r["flowEndSeconds"]): r for r in b if r["anomaly"] == "true"}
     assert len(ka) > 20
     both = set(ka) & set(kb)
-    assert len(both) >= 0.9 * max(len(ka), len(kb)), (len(ka), len(kb), len(both))           # verdict flips stay a small minority
+    # gated at what it measures (39 vs 39 rows, 38 in common; median 3.6e-7, 37 of 38 within 1.1e-4, one flat-likelihood outlier)
+    assert len(ka) == len(kb) and len(both) >= len(ka) - 1, (len(ka), len(kb), len(both))     # at most one verdict flip
     rel = np.array([abs(ka[k]["algoCalc"] - kb[k]["algoCalc"]) / abs(kb[k]["algoCalc"]) for k in both])
-    assert (rel < 1e-3).mean() >= 0.9 and np.median(rel) < 1e-5, (np.median(rel), (rel < 1e-3).mean())
+    assert np.median(rel) <= 1e-6 and (rel < 2e-4).sum() >= len(both) - 1 and (rel < 1e-6).mean() >= 0.6, (np.median(rel), np.sort(rel)[-3:])
     assert all(ka[k]["throughput"] == kb[k]["throughput"] and ka[k]["throughputStandardDeviation"] == kb[k]["throughputStandardDeviation"] for k in both)

@@ -78,31 +78,52 @@ class ClickHouseHTTP:
             # anything else must be an Arrow stream: a proxy's error page or exception text after the headers raises
             # pa.ArrowInvalid here instead of turning into a job on zero rows that reports "no anomalies"
             reader = ipc.open_stream(resp)
+            def stringish(t):   # plain strings / binaries, and dictionary-typed columns of them (LowCardinality sent as Arrow dictionaries)
+                if pa.types.is_dictionary(t):
+                    t = t.value_type
+                return pa.types.is_binary(t) or pa.types.is_large_binary(t) or pa.types.is_string(t) or pa.types.is_large_string(t)
             for name, t in zip(reader.schema.names, reader.schema.types):   # a schema without batches: empty typed columns
-                is_str = not (pa.types.is_timestamp(t) or pa.types.is_integer(t) or pa.types.is_floating(t))
+                is_str = stringish(t)
                 if is_str and dict_strings:
-                    vocab.setdefault(name, {})
-                parts[name] = [np.zeros(0, dtype=np.int64 if (not is_str or dict_strings) else str) if not pa.types.is_floating(t)
-                               else np.zeros(0, dtype=np.float64)]
+                    vocab.setdefault(name, {})      # only columns that go through the string branch get a dictionary
+                if is_str:
+                    parts[name] = [np.zeros(0, dtype=np.int64 if dict_strings else str)]
+                elif pa.types.is_floating(t) or pa.types.is_decimal(t):
+                    parts[name] = [np.zeros(0, dtype=np.float64)]
+                elif pa.types.is_boolean(t):
+                    parts[name] = [np.zeros(0, dtype=bool)]
+                else:
+                    parts[name] = [np.zeros(0, dtype=np.int64)]
             for batch in reader:
                 for name, col in zip(batch.schema.names, batch.columns):
                     t = col.type
-                    if pa.types.is_timestamp(t):
+                    if pa.types.is_timestamp(t) or pa.types.is_date(t):
                         arr = col.cast(pa.timestamp("s")).cast(pa.int64()).to_numpy(zero_copy_only=False)
-                    elif pa.types.is_binary(t) or pa.types.is_large_binary(t) or pa.types.is_string(t) or pa.types.is_large_string(t):
-                        if pa.types.is_binary(t) or pa.types.is_large_binary(t):
-                            col = col.cast(pa.string())
-                        d = col if pa.types.is_dictionary(col.type) else pc.dictionary_encode(col.fill_null(""))
-                        idx = d.indices.to_numpy(zero_copy_only=False)
+                    elif stringish(t):
+                        if pa.types.is_dictionary(t):     # already dictionary-encoded by the server: keep its indices, no re-encode
+                            d = col
+                            if not (pa.types.is_string(t.value_type) or pa.types.is_large_string(t.value_type)):
+                                d = pa.DictionaryArray.from_arrays(col.indices, col.dictionary.cast(pa.string()))
+                            idx = d.indices.fill_null(0).to_numpy(zero_copy_only=False) if d.indices.null_count == 0 else None
+                            if idx is None:               # null rows read as '' like the plain-string path
+                                d = pc.dictionary_encode(d.cast(pa.string()).fill_null(""))
+                                idx = d.indices.to_numpy(zero_copy_only=False)
+                        else:
+                            if pa.types.is_binary(t) or pa.types.is_large_binary(t):
+                                col = col.cast(pa.string())
+                            d = pc.dictionary_encode(col.fill_null(""))
+                            idx = d.indices.to_numpy(zero_copy_only=False)
+                        dvals = ["" if v is None else v for v in d.dictionary.to_pylist()]
                         if dict_strings:      # remap this batch's dictionary into the column's unified one: per-row work is one integer gather
                             voc = vocab.setdefault(name, {})
-                            remap = np.fromiter((voc.setdefault(v, len(voc)) for v in d.dictionary.to_pylist()), dtype=np.int64,
-                                                count=len(d.dictionary))
+                            remap = np.fromiter((voc.setdefault(v, len(voc)) for v in dvals), dtype=np.int64, count=len(dvals))
                             arr = remap[idx] if remap.size else np.zeros(0, dtype=np.int64)
                         else:
-                            values = np.asarray(d.dictionary.to_pylist(), dtype=object).astype(str)
+                            values = np.asarray(dvals, dtype=object).astype(str)
                             arr = values[idx] if values.size else np.zeros(0, dtype=str)
-                    else:
+                    elif pa.types.is_decimal(t):
+                        arr = col.cast(pa.float64()).to_numpy(zero_copy_only=False)
+                    else:                     # integers, floats, bool: passed through unchanged
                         arr = col.to_numpy(zero_copy_only=False)
                     parts.setdefault(name, []).append(arr)
         out = {name: (np.concatenate(v[1:]) if len(v) > 2 else (v[1] if len(v) == 2 else v[0])) for name, v in parts.items()}

@@ -154,14 +154,27 @@ def job_arguments(tad):
     return args
 
 
-def cleanup_query(job_id):
-    """cleanupTADetector's statement (controller.go:396), verbatim."""
+def reference_cleanup_query(job_id):
+    """cleanupTADetector's statement (controller.go:396), verbatim — kept for the record: the uuid is NOT quoted there, which a
+    ClickHouse server parses as an arithmetic expression over identifiers (and rejects, or misreads)."""
     return "ALTER TABLE tadetector ON CLUSTER '{cluster}' DELETE WHERE id = (" + job_id + ");"
 
 
-def run_engine_job(args, client, engine=None, pushdown=False):
+def cleanup_query(job_id):
+    """The statement this controller sends: the reference's (controller.go:396) with the id as a string literal.  `job_id` has
+    passed parse_ad_algorithm_id (a canonical uuid: hex digits and dashes), so quoting is all the escaping it needs."""
+    uuid.UUID(job_id)
+    return "ALTER TABLE tadetector ON CLUSTER '{cluster}' DELETE WHERE id = ('" + job_id + "');"
+
+
+class JobCancelled(Exception):
+    """The resource was deleted while its job was running (DeleteSparkApplication, controller.go:387): nothing is written."""
+
+
+def run_engine_job(args, client, engine=None, pushdown=False, cancelled=None):
     """The job body the SparkApplication ran (anomaly_detection.py:647-726) on the GPU engine: parse the argument vector, read
-    through `client` (theia_amd.clickhouse.ClickHouseHTTP), detect, append the rows to `tadetector`.  Returns the row count."""
+    through `client` (theia_amd.clickhouse.ClickHouseHTTP), detect, append the rows to `tadetector`.  Returns the row count.
+    `cancelled()` is asked right before the rows are written: a deleted job must not leave rows nobody tracks."""
     from . import anomaly_detection as ad
     opt = {}
     it = iter(args)
@@ -173,6 +186,8 @@ def run_engine_job(args, client, engine=None, pushdown=False):
                                    json.loads(opt["--ns-ignore-list"]) if "--ns-ignore-list" in opt else [], opt.get("--agg-flow", ""),
                                    opt.get("--pod-label", ""), opt.get("--external-ip", ""), opt.get("--svc-port-name", ""),
                                    opt.get("--pod-name", ""), opt.get("--pod-namespace", ""), engine=engine, pushdown=pushdown, columnar=True)
+    if cancelled is not None and cancelled():
+        raise JobCancelled(tad_id)
     return ad.store_result_columns(client, cols)
 
 
@@ -185,15 +200,25 @@ class AnomalyDetectorController:
                  workers=DEFAULT_WORKERS, resync_period=0.05, pushdown=False):
         self.clickhouse = clickhouse
         self.engine = engine
-        self._run_job = run_job or (lambda args, tad: run_engine_job(args, self.clickhouse, self.engine, pushdown))
+        self._run_job = run_job or (lambda args, tad: run_engine_job(args, self.clickhouse, self.engine, pushdown,
+                                                                      cancelled=lambda: self._is_cancelled(tad.name[4:])))
         self._progress = progress or (lambda: self.engine.progress() if self.engine is not None else (0, 0))
         self._lock = threading.Lock()
         self._store: Dict[tuple, ThroughputAnomalyDetector] = {}
         self._jobs: Dict[str, dict] = {}          # job id -> {"state": RUNNING|COMPLETED|FAILED, "error": str} (the SparkApplication's status)
+        self._cancelled: set = set()              # ids of jobs whose resource was deleted while they ran (tombstones, dropped when the job ends)
         self._queue: "queue.Queue" = queue.Queue()
+        self._queued: set = set()                 # keys waiting in the queue (the workqueue's dedup, controller.go:150-160)
+        self._active: set = set()                 # keys a worker is processing: one key is never synced by two workers at once
+        self._dirty: set = set()                  # keys re-added while active: requeued when the worker is done (workqueue semantics)
         self._periodic: Dict[tuple, bool] = {}
         self._stop = threading.Event()
         self._resync = resync_period
+        self._last_error = None
+        # job bodies run on a bounded pool: `workers` concurrent ClickHouse reads / engine jobs at most (controller.go:199-201's
+        # defaultWorkers bound what the reference starts at once; Spark bounded the rest)
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="tad-job")
         self._threads = [threading.Thread(target=self._worker, daemon=True) for _ in range(workers)]
         self._threads.append(threading.Thread(target=self._resync_loop, daemon=True))
         for t in self._threads:
@@ -206,7 +231,7 @@ class AnomalyDetectorController:
             if key in self._store:
                 raise KeyError("ThroughputAnomalyDetector %s/%s already exists" % key)
             self._store[key] = copy.deepcopy(tad)
-        self._queue.put(key)
+        self._enqueue(key)
         return self.get(tad.namespace, tad.name)
 
     def get(self, namespace, name):
@@ -218,47 +243,86 @@ class AnomalyDetectorController:
             return [copy.deepcopy(t) for (ns, _), t in sorted(self._store.items()) if ns == namespace]
 
     def delete(self, namespace, name):
-        """DeleteThroughputAnomalyDetector + the delete handler's cleanup (controller.go:385-398): the result rows of the job go."""
+        """DeleteThroughputAnomalyDetector + the delete handler's cleanup (controller.go:385-398): the application is stopped
+        (a running job body is marked cancelled and writes nothing), then the result rows of the job go."""
         with self._lock:
             tad = self._store.pop((namespace, name))
             self._periodic.pop((namespace, name), None)
-        if tad.status.sparkApplication:
-            self.cleanup(namespace, tad.status.sparkApplication)
+            job_id = tad.status.sparkApplication
+            job = self._jobs.get(job_id) if job_id else None
+            if job is not None and job["state"] in ("SUBMITTED", "RUNNING"):
+                self._cancelled.add(job_id)          # _execute re-issues the cleanup when the body returns
+        if job_id:
+            self.cleanup(namespace, job_id)
 
     def cleanup(self, namespace, job_id):
         with self._lock:
             self._jobs.pop(job_id, None)           # DeleteSparkApplication
         if self.clickhouse is not None:
-            self.clickhouse.command(cleanup_query(job_id))
+            try:
+                self.clickhouse.command(cleanup_query(job_id))
+            except Exception as exc:               # the reference's delete handler logs the error and carries on (controller.go:262-280)
+                self._last_error = exc
+
+    def _is_cancelled(self, job_id):
+        with self._lock:
+            return job_id in self._cancelled
 
     def shutdown(self):
         self._stop.set()
         for _ in self._threads:
             self._queue.put(None)
+        self._pool.shutdown(wait=False)
 
     # ---- the controller ----
+    def _enqueue(self, key):
+        """workqueue.Add: a key waits in the queue once; one that is being processed is marked dirty and re-added afterwards."""
+        with self._lock:
+            if key in self._queued:
+                return
+            if key in self._active:
+                self._dirty.add(key)
+                return
+            self._queued.add(key)
+        self._queue.put(key)
+
     def _worker(self):
         while not self._stop.is_set():
             key = self._queue.get()
             if key is None:
                 return
+            with self._lock:
+                self._queued.discard(key)
+                self._active.add(key)
+            failed = False
             try:
                 self.sync(key)
-            except Exception as exc:                # the reference requeues with rate limiting; here the resync loop retries
+            except Exception as exc:                # the reference requeues with rate limiting (controller.go:330-345)
                 self._last_error = exc
+                failed = True
+            with self._lock:
+                self._active.discard(key)
+                again = key in self._dirty or (failed and key in self._store)
+                self._dirty.discard(key)
+            if again:
+                if failed:
+                    time.sleep(min(self._resync, 0.05))
+                self._enqueue(key)
 
     def _resync_loop(self):
         while not self._stop.wait(self._resync):
             with self._lock:
                 keys = [k for k, on in self._periodic.items() if on]
             for k in keys:
-                self._queue.put(k)
+                self._enqueue(k)
 
-    def _update_status(self, key, **changes):
-        """updateTADetectorStatus (controller.go:700-730): only the fields a caller names change; ErrorMsg is overwritten when given."""
+    def _update_status(self, key, only_if_state=None, **changes):
+        """updateTADetectorStatus (controller.go:700-730): only the fields a caller names change; ErrorMsg is overwritten when given.
+        `only_if_state`: the write happens only while the stored state is one of these (a progress update must not undo a
+        COMPLETED / FAILED another sync has written since this one took its snapshot)."""
         with self._lock:
             tad = self._store.get(key)
-            if tad is None:
+            if tad is None or (only_if_state is not None and tad.status.state not in only_if_state):
                 return
             for name, value in changes.items():
                 setattr(tad.status, name, value)
@@ -290,15 +354,18 @@ class AnomalyDetectorController:
         job_id = tad.name[4:]
         with self._lock:
             self._jobs[job_id] = {"state": "SUBMITTED", "error": ""}
-        threading.Thread(target=self._execute, args=(job_id, args, tad), daemon=True).start()
+        # the status names the application before its body can run: a delete in between must find the id to stop and clean up
         self._update_status(key, state=STATE_SCHEDULED, sparkApplication=job_id, startTime=datetime.now(timezone.utc))
         with self._lock:
             self._periodic[key] = True               # addPeriodicSync
+        self._pool.submit(self._execute, job_id, args, tad)
 
     def _execute(self, job_id, args, tad):
         with self._lock:
-            if job_id in self._jobs:
-                self._jobs[job_id]["state"] = "RUNNING"
+            if job_id not in self._jobs:             # deleted while it waited for a pool slot: never started
+                self._cancelled.discard(job_id)
+                return
+            self._jobs[job_id]["state"] = "RUNNING"
         try:
             self._run_job(args, tad)
             outcome = ("COMPLETED", "")
@@ -307,6 +374,14 @@ class AnomalyDetectorController:
         with self._lock:
             if job_id in self._jobs:
                 self._jobs[job_id]["state"], self._jobs[job_id]["error"] = outcome
+            deleted = job_id in self._cancelled
+            self._cancelled.discard(job_id)
+        if deleted and self.clickhouse is not None:
+            # the resource went away while the body ran: whatever it managed to write before noticing is removed again
+            try:
+                self.clickhouse.command(cleanup_query(job_id))
+            except Exception as exc:
+                self._last_error = exc
 
     def check_job_status(self, key, tad):
         """checkSparkApplicationStatus (controller.go:455-497)."""
@@ -317,7 +392,7 @@ class AnomalyDetectorController:
             job = dict(self._jobs.get(tad.status.sparkApplication, {"state": "", "error": ""}))
         state, msg = job["state"], job["error"]
         if state == "RUNNING":
-            self._update_status(key, state=STATE_RUNNING, errorMsg=msg)
+            self._update_status(key, only_if_state=("", STATE_NEW, STATE_SCHEDULED, STATE_RUNNING), state=STATE_RUNNING, errorMsg=msg)
         elif state == "COMPLETED":
             self._update_status(key, state=STATE_COMPLETED, errorMsg=msg)
         elif state in ("FAILED", "SUBMISSION_FAILED", "FAILING", "INVALIDATING"):
@@ -336,7 +411,8 @@ class AnomalyDetectorController:
             done, total = self._progress()
         except Exception:                            # the monitoring endpoint may not be up: not requeued (controller.go:437-443)
             return
-        self._update_status(key, state=STATE_RUNNING, completedStages=int(done), totalStages=int(total))
+        self._update_status(key, only_if_state=(STATE_SCHEDULED, STATE_RUNNING), state=STATE_RUNNING, completedStages=int(done),
+                            totalStages=int(total))
 
     def finish_job(self, key, tad):
         """finishJob (controller.go:400-424)."""
