@@ -65,12 +65,47 @@ def test_series_functions_equal_reference_outputs(engine, ref_outputs):
             assert mine == orc.stddev_samp_series(orc.u64_to_f64(x)), name
 
 
-def test_series_long_dbscan_uses_fallback_kernel(engine):
+def test_series_long_dbscan_sorted_windows(engine):
+    """Series of more than 256 points take k_dbscan_sorted (windows on the sorted values): in LDS up to 4096 points, in a global
+    scratch row above (9000 and 20 000 points).  The verdicts must be those of the pair tests, point for point."""
     rng = np.random.default_rng(5)
-    x = (4_000_000_000 + rng.integers(-900_000_000, 900_000_000, size=9000)).astype(np.uint64)
-    x[::1000] *= np.uint64(4)
-    assert (engine.series_dbscan_anomaly(x) == orc.dbscan_noise_1d(orc.u64_to_f64(x))).all()
-    assert engine.series_ewma(x).tolist() == orc.calculate_ewma(x.tolist())
+    for n in (300, 4096, 9000, 20000):
+        x = (4_000_000_000 + rng.integers(-900_000_000, 900_000_000, size=n)).astype(np.uint64)
+        x[::1000] *= np.uint64(4)
+        assert (engine.series_dbscan_anomaly(x) == orc.dbscan_noise_1d(orc.u64_to_f64(x))).all(), n
+    assert engine.series_ewma(x[:9000]).tolist() == orc.calculate_ewma(x[:9000].tolist())
+
+
+def test_series_dbscan_sorted_windows_adversarial(engine):
+    """What a window formulation can get wrong: points EXACTLY eps apart (inclusive <=), chains of them, differences that only
+    round to eps (values beyond 2^53 are not exact in double: the predicate is on fl(x_i - x_j) of the rounded values), duplicates,
+    clusters of exactly min_samples - 1 / min_samples points, a non-core point whose window holds only non-core points."""
+    eps = 250_000_000
+    base = 10_000_000_000
+    cases = []
+    # a chain 0, eps, 2 eps, ... : every interior point has 3 neighbours (not core with min_samples 4), with 4 duplicates it turns core
+    cases.append(np.array([base + i * eps for i in range(300)], dtype=np.uint64))
+    cases.append(np.array([base + (i // 2) * eps for i in range(600)], dtype=np.uint64))
+    # exactly eps and eps + 1 apart, alternating gaps; clusters of 3 and 4
+    gaps = np.where(np.arange(400) % 3 == 0, eps + 1, np.where(np.arange(400) % 3 == 1, eps, 1))
+    cases.append((base + np.cumsum(gaps)).astype(np.uint64))
+    # beyond 2^53: neighbours whose exact integer distance is eps + 1 .. eps + 1024 but whose doubles differ by exactly eps (and the reverse)
+    big = (1 << 62) + np.arange(0, 500, dtype=np.uint64) * np.uint64(eps) + np.tile(np.array([0, 700, 1023, 1, 2047], dtype=np.uint64), 100)
+    cases.append(big.astype(np.uint64))
+    # duplicates only / two far groups of min_samples - 1 and min_samples points / one outlier among many equal values
+    cases.append(np.full(700, base, dtype=np.uint64))
+    cases.append(np.concatenate([np.full(3, base), np.full(4, base + 10 * eps), np.full(400, base + 30 * eps)]).astype(np.uint64))
+    cases.append(np.concatenate([np.full(999, base), [base + 5 * eps]]).astype(np.uint64))
+    # a non-core point within eps of non-core points only, next to a dense cluster just out of reach
+    cases.append(np.concatenate([np.full(300, base), [base + eps + 1, base + 2 * eps + 1, base + 3 * eps + 1], np.full(5, base + 4 * eps + 1)]).astype(np.uint64))
+    rng = np.random.default_rng(11)
+    for i, x in enumerate(cases):
+        x = x[rng.permutation(x.size)]      # time order is arbitrary with respect to the values
+        want = orc.dbscan_noise_1d(orc.u64_to_f64(x))
+        assert (engine.series_dbscan_anomaly(x) == want).all(), i
+        for ms in (1, 2, 7):
+            assert (engine.series_dbscan_anomaly(x, min_samples=ms) == orc.dbscan_noise_1d(orc.u64_to_f64(x), min_samples=ms)).all(), (i, ms)
+        assert (engine.series_dbscan_anomaly(x, eps=1.0) == orc.dbscan_noise_1d(orc.u64_to_f64(x), eps=1.0)).all(), i
 
 
 # ------------------------------------------------------------------ (c) whole job vs oracle

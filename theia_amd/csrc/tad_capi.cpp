@@ -391,7 +391,7 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
       if (launch_dbscan(s, g, jp.eps, jp.min_samples, e->aux.p, dst, jp.settled && db_fused) != 0)
         return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
     } else {
-      launch_dbscan_long(s, g, jp.eps, jp.min_samples, e->aux.p);
+      return fail(e, TAD_ERR_GRID_TOO_LARGE, "DBSCAN: series of %llu buckets are not supported", (unsigned long long)g.T);
     }
   } else if (jp.algo == TAD_ALGO_ARIMA) {
     if ((rc = ensure(e, e->calc, g.K * g.T * sizeof(double))) != TAD_OK) return rc;
@@ -696,24 +696,19 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       HIP_TRY(e, hipMemsetAsync(d_runs, 0, 16, s));
       HIP_TRY(e, hipEventRecord(e->ev[2], s));
       unsigned long long *ucomp = static_cast<unsigned long long *>(e->sp_comp_a.p), *uval = static_cast<unsigned long long *>(e->sp_val_a.p);
+      // (the sort covers bit_width(span) time bits: a row beyond the lattice's last bucket raises DEV_ERR_OFF_LATTICE like a row before t0)
+      const uint64_t span = L.nb ? (L.nb - 1) * (uint64_t)L.step : 0;
       if (launch_sparse_group(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
-                              rf, L.t0, op_max, ucomp, uval, static_cast<unsigned long long *>(e->sp_comp_b.p),
+                              rf, L.t0, span, op_max, ucomp, uval, static_cast<unsigned long long *>(e->sp_comp_b.p),
                               static_cast<unsigned long long *>(e->sp_val_b.p), e->sp_temp.p, tb, d_runs, ctr) != 0)
         return fail(e, TAD_ERR_HIP, "sparse Stage 0: sort / reduce failed");
-      unsigned long long runs = 0, last = 0;
-      HIP_TRY(e, hipMemcpyAsync(&runs, d_runs, 8, hipMemcpyDeviceToHost, s));
+      // first[] / the longest series from the device-resident point count; then ONE round trip for both numbers
+      launch_sparse_tmax(s, ucomp, slots_all, d_runs, static_cast<uint32_t *>(e->sp_first.p), reinterpret_cast<unsigned int *>(d_runs + 1));
+      unsigned long long runs_tmax[2] = {0, 0};
+      HIP_TRY(e, hipMemcpyAsync(runs_tmax, d_runs, 16, hipMemcpyDeviceToHost, s));
       HIP_TRY(e, hipStreamSynchronize(s));
-      if (runs) {
-        HIP_TRY(e, hipMemcpyAsync(&last, ucomp + (runs - 1), 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipStreamSynchronize(s));
-      }
-      const uint64_t P = runs - ((runs && last == ~0ull) ? 1 : 0);    // the filtered-out slots form the last run
-      unsigned int tmax = 0;
-      if (P) {
-        launch_sparse_tmax(s, ucomp, P, static_cast<uint32_t *>(e->sp_first.p), reinterpret_cast<unsigned int *>(d_runs + 1));
-        HIP_TRY(e, hipMemcpyAsync(&tmax, d_runs + 1, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipStreamSynchronize(s));
-      }
+      const uint64_t P = runs_tmax[0];    // the filtered-out slots sort last and the reduction drops them
+      const unsigned int tmax = (unsigned int)runs_tmax[1];
       cells = K * (uint64_t)tmax;
       need = cells * 17 + (jp.algo == TAD_ALGO_ARIMA ? cells * 76 + (1ull << 22) : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
       // Skewed series lengths (one key with a day of seconds next to many short-lived ones): K x Tmax does not fit although the
@@ -1484,11 +1479,7 @@ int tad_series_dbscan_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, doub
   if (rc != TAD_OK || n == 0) return rc;
   JobParams jp = series_params(TAD_ALGO_DBSCAN, 0, eps, min_samples, 0);
   if ((rc = ensure(e, e->aux, dbscan_scratch_bytes(g))) != TAD_OK) return rc;
-  if (dbscan_uses_list(g)) {
-    if (launch_dbscan(e->stream, g, jp.eps, jp.min_samples, e->aux.p) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
-  } else {
-    launch_dbscan_long(e->stream, g, jp.eps, jp.min_samples, e->aux.p);
-  }
+  if (launch_dbscan(e->stream, g, jp.eps, jp.min_samples, e->aux.p) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
   return series_emit_all(e, g, jp, false, 0.0, nullptr, verdict);
 }
 

@@ -7,10 +7,11 @@
 // Distances are FP64 on correctly rounded uint64 -> double values: pure comparisons, so verdicts
 // are exact.
 //
-// Two kernels: k_dbscan_scan (one lane per key, one coalesced walk over the time-major grid) settles every key whose
-// values all lie within eps of each other and lists the rest; the exact pair tests for the listed keys run with one
-// wavefront per key (k_dbscan_list_wave, series of up to 256 buckets held in registers) or one workgroup per key
-// (k_dbscan_list: points compacted into LDS, lanes = points i, LDS-broadcast x_j stream) for longer series.
+// Two kernels: k_dbscan_scan (one lane per key, one coalesced walk over the time-major grid; a wavefront per key for long series on
+// few keys) settles every key whose values all lie within eps of each other and lists the rest; the exact predicate for the listed
+// keys runs with one wavefront per key (k_dbscan_list_wave: series of up to 256 buckets held in registers, pair tests by readlane)
+// or, for longer series, one workgroup per key on SORTED values (k_dbscan_sorted: in one dimension the eps-neighbourhood of a point
+// is a window of the sorted series, so core / noise are window counts — O(n log n), no pair tests).
 #include <cstdlib>
 
 #include "tad_internal.h"
@@ -27,22 +28,39 @@ __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63; }
 // and shifted moments of the values.  If max - min <= eps every pair of the key's points is within eps (|x_i - x_j| <=
 // max - min, and FP subtraction is monotone): with >= min_samples points all are core (no noise), which settles the key
 // here — the common case by far (a flow's throughput rarely spreads over more than eps = 250 MB/s).  Every other key
-// (wide spread, or fewer than min_samples points) goes to a work list for the exact pair tests (k_dbscan_list).
-// st (optional): per-key n_pts, n_anom (0 here; k_dbscan_list overwrites its keys) and (mean, M2) for the job telemetry
+// (wide spread, or fewer than min_samples points) goes to a work list for the exact predicate (k_dbscan_list_wave / k_dbscan_sorted).
+// st (optional): per-key n_pts, n_anom (0 here; the list kernels overwrite their keys) and (mean, M2) for the job telemetry
 // (M2 from sums shifted by the key's first value; only the exact stddev_samp column of emitted rows follows Spark's
 // streaming order, k_emit<4>).
 // ------------------------------------------------------------------------------------------------
 // REDO_ONLY: Stage 0's pass C ran in settle mode and has done this kernel's work for every key it could see whole (SettleArgs,
 // tad_stage0_part.hip); only keys it marked kSettleRedo (split partitions, overflow-list records) are walked here.
-template <bool REDO_ONLY>
+// partial statistics of a set of points, sums shifted by x0 (a value of the set)
+struct ScanPart { uint32_t n; double mn, mx, x0, s1, s2; };
+// a (its shift is kept) + b: b's values are (its d) + sh relative to a's shift — exact algebra, no division
+__device__ __forceinline__ ScanPart scan_merge(const ScanPart &a, const ScanPart &b) {
+  if (a.n == 0) return b;
+  if (b.n == 0) return a;
+  const double sh = b.x0 - a.x0, dnb = (double)b.n;
+  ScanPart r;
+  r.n = a.n + b.n; r.mn = fmin(a.mn, b.mn); r.mx = fmax(a.mx, b.mx); r.x0 = a.x0;
+  r.s1 = a.s1 + (b.s1 + dnb * sh);
+  r.s2 = a.s2 + (b.s2 + 2.0 * sh * b.s1 + dnb * (sh * sh));
+  return r;
+}
+
+// COOP: one wavefront per key (long series on few keys, tad_internal.h:coop_shape): every statistic of the scan is associative, so
+// the lanes take the buckets in strides of 64 and merge their partials in a fixed xor tree (lower lane first).
+template <bool REDO_ONLY, bool COOP = false>
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, int min_samples, DbscanStats st,
                                                          uint32_t *__restrict__ list, unsigned int *__restrict__ count) {
-  const uint64_t k = (uint64_t)blockIdx.x * kDbBlock + threadIdx.x;
+  const uint64_t gtid = (uint64_t)blockIdx.x * kDbBlock + threadIdx.x;
+  const uint64_t k = COOP ? gtid >> 6 : gtid;
   bool slow = false;
   if (k < g.K && (!REDO_ONLY || st.n_pts[k] == kSettleRedo)) {
     uint32_t n = 0;
     double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
-    walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
+    auto point = [&](uint8_t fl, unsigned long long raw) {
       if (fl & FLAG_PRESENT) {
         const double x = (double)raw;
         if (n == 0) { mn = x; mx = x; x0 = x; }
@@ -53,15 +71,27 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, in
         s2 += d * d;
         n++;
       }
-    });
+    };
+    if (COOP) {
+      for (uint64_t t = lane_id(); t < g.T; t += 64) point(g.flag[t * g.K + k], g.val[t * g.K + k]);
+      ScanPart a{n, mn, mx, x0, s1, s2};
+      for (int d = 1; d < 64; d <<= 1) {
+        ScanPart o{__shfl_xor(a.n, d), __shfl_xor(a.mn, d), __shfl_xor(a.mx, d), __shfl_xor(a.x0, d), __shfl_xor(a.s1, d), __shfl_xor(a.s2, d)};
+        a = (lane_id() & (unsigned)d) ? scan_merge(o, a) : scan_merge(a, o);   // both partners compute the same value
+      }
+      n = a.n; mn = a.mn; mx = a.mx; x0 = a.x0; s1 = a.s1; s2 = a.s2;
+    } else {
+      walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) { point(fl, raw); });
+    }
     slow = n > 0 && (!(mx - mn <= eps) || n < (uint32_t)min_samples);
-    if (st.n_pts != nullptr) {
+    if (st.n_pts != nullptr && (!COOP || lane_id() == 0)) {
       st.n_pts[k] = n;
       st.n_anom[k] = 0;
       const double dn = (double)(n ? n : 1);
       st.key_mean[k] = n ? x0 + s1 / dn : 0.0;
       st.key_m2[k] = n ? fmax(s2 - s1 * (s1 / dn), 0.0) : 0.0;
     }
+    if (COOP && lane_id() != 0) slow = false;   // one list entry per key
   }
   const unsigned long long m = __ballot(slow);
   if (m) {
@@ -74,26 +104,53 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_dbscan_list — the exact noise predicate for the listed keys: one workgroup per key (grid-stride over the list), the
-// key's present points compacted into LDS, pair tests with lanes = points i and an LDS-broadcast x_j stream.
-// LDS carve: xs[T] f64 | ct[T] u32 | core[T] u8
+// k_dbscan_sorted — the exact noise predicate for listed keys with series of more than 256 buckets, on SORTED values.
+// |x_i - x_j| <= eps is evaluated as the FP64 difference of the two correctly rounded values (what sklearn's distance computes);
+// IEEE subtraction is monotone in each operand, so for a fixed x_i the predicate is true exactly on a WINDOW [lo_i, hi_i] of the
+// series sorted by value.  core(i) <=> hi_i - lo_i + 1 >= min_samples (self counted); noise(i) <=> not core and no core point in
+// the window (a prefix sum of the core flags over the sorted order).  The window ends are found by binary search with the very
+// predicate of the pair test (fl(x_i - x_j) <= eps on the sorted pair), so the verdicts are those of the O(n^2) pair tests, exactly
+// — including chains of points exactly eps apart (tests/test_gpu_parity.py, tests/test_gpu_sparse.py).
+// One workgroup per listed key (grid-stride over the list): the present points are compacted in time order, sorted by value with a
+// bitonic network (padded to a power of two with +inf), windows, core prefix, verdicts scattered back through the points' buckets.
+// Working set per key: x f64 | bucket u32 | lo u32 | hi u32 | core prefix u32 = 24 B per point — in LDS for up to kSortLdsPoints
+// points, else in a per-workgroup row of global scratch (L2-resident: 32 768 points = 768 KB).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kDbBlock) void k_dbscan_list(Grid g, double eps, int min_samples, const uint32_t *__restrict__ list,
-                                                         const unsigned int *__restrict__ count, uint32_t *__restrict__ n_anom) {
+static constexpr uint32_t kSortLdsPoints = 4096;
+
+struct SortRows {   // per-workgroup rows of global scratch (stride = cap points), or all NULL: LDS
+  double *x;
+  uint32_t *bk, *lo, *hi, *cp;
+  uint32_t cap;
+};
+
+__global__ __launch_bounds__(kDbBlock) void k_dbscan_sorted(Grid g, double eps, int min_samples, const uint32_t *__restrict__ list,
+                                                           const unsigned int *__restrict__ count, uint32_t *__restrict__ n_anom, SortRows rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint64_t T = g.T;
-  double *xs = reinterpret_cast<double *>(smem);
-  uint32_t *ct = reinterpret_cast<uint32_t *>(smem + T * 8);
-  uint8_t *core = reinterpret_cast<uint8_t *>(ct + T);
+  double *xs;
+  uint32_t *bk, *lo, *hi, *cp;
+  uint32_t cap;
+  if (rows.x != nullptr) {
+    cap = rows.cap;
+    xs = rows.x + (size_t)blockIdx.x * cap;
+    bk = rows.bk + (size_t)blockIdx.x * cap; lo = rows.lo + (size_t)blockIdx.x * cap;
+    hi = rows.hi + (size_t)blockIdx.x * cap; cp = rows.cp + (size_t)blockIdx.x * cap;
+  } else {
+    cap = kSortLdsPoints;
+    xs = reinterpret_cast<double *>(smem);
+    bk = reinterpret_cast<uint32_t *>(xs + cap); lo = bk + cap; hi = lo + cap; cp = hi + cap;
+  }
   __shared__ uint32_t s_wave[kDbWaves];
-  __shared__ uint32_t s_n, s_noise;
+  __shared__ uint32_t s_n, s_noise, s_carry;
   const unsigned lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const unsigned total = *count;
   for (unsigned e = blockIdx.x; e < total; e += gridDim.x) {
     const uint64_t k = list[e];
-    if (threadIdx.x == 0) { s_n = 0; s_noise = 0; }
+    if (threadIdx.x == 0) { s_n = 0; s_noise = 0; s_carry = 0; }
     __syncthreads();
+    // ---- compaction of the present points, in time order ----
     for (uint64_t c0 = 0; c0 < T; c0 += kDbBlock) {
       const uint64_t t = c0 + threadIdx.x;
       const bool p = t < T && (g.flag[t * g.K + k] & FLAG_PRESENT);
@@ -105,7 +162,7 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list(Grid g, double eps, in
       if (p) {
         const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
         xs[pos] = (double)g.val[t * g.K + k];
-        ct[pos] = (uint32_t)t;
+        bk[pos] = (uint32_t)t;
       }
       __syncthreads();
       if (threadIdx.x == 0) {
@@ -116,21 +173,66 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list(Grid g, double eps, in
       __syncthreads();
     }
     const uint32_t n = s_n;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = n + threadIdx.x; i < np2; i += kDbBlock) { xs[i] = __builtin_huge_val(); bk[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    // ---- bitonic sort by value (ties in any order: the predicates only see values) ----
+    for (uint32_t kk = 2; kk <= np2; kk <<= 1)
+      for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = threadIdx.x; i < np2; i += kDbBlock) {
+          const uint32_t l = i ^ j;
+          if (l > i) {
+            const double a = xs[i], b = xs[l];
+            const bool up = (i & kk) == 0;
+            if (up ? a > b : a < b) {
+              xs[i] = b; xs[l] = a;
+              const uint32_t ta = bk[i]; bk[i] = bk[l]; bk[l] = ta;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    // ---- windows: lo = first j <= i with x_i - x_j <= eps, hi = last j >= i with x_j - x_i <= eps; core flag ----
     for (uint32_t i = threadIdx.x; i < n; i += kDbBlock) {
       const double xi = xs[i];
-      int cnt = 0;
-#pragma unroll 4
-      for (uint32_t j = 0; j < n; ++j) cnt += fabs(xi - xs[j]) <= eps ? 1 : 0;
-      core[i] = cnt >= min_samples ? 1 : 0;
+      uint32_t a = 0, b = i;                 // the predicate holds at i and is monotone: false ... false true ... true on [0, i]
+      while (a < b) { const uint32_t mid = (a + b) >> 1; if (fabs(xi - xs[mid]) <= eps) b = mid; else a = mid + 1; }
+      const uint32_t l = a;
+      a = i; b = n - 1;                      // true ... true false ... false on [i, n)
+      while (a < b) { const uint32_t mid = (a + b + 1) >> 1; if (fabs(xi - xs[mid]) <= eps) a = mid; else b = mid - 1; }
+      lo[i] = l; hi[i] = a;
+      cp[i] = (a - l + 1 >= (uint32_t)min_samples) ? 1u : 0u;
     }
     __syncthreads();
+    // ---- inclusive prefix of the core flags over the sorted order (chunks of the workgroup, running carry) ----
+    for (uint32_t c0 = 0; c0 < n; c0 += kDbBlock) {
+      const uint32_t i = c0 + threadIdx.x;
+      const uint32_t v = i < n ? cp[i] : 0u;
+      uint32_t incl = v;
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= (unsigned)d) incl += y; }
+      if (lane == 63) s_wave[wave] = incl;
+      __syncthreads();
+      uint32_t base = s_carry;
+      for (int w = 0; w < wave; ++w) base += s_wave[w];
+      if (i < n) cp[i] = base + incl;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < kDbWaves; ++w) tot += s_wave[w];
+        s_carry += tot;
+      }
+      __syncthreads();
+    }
+    // ---- noise: not core and no core point in the window ----
     uint32_t noise = 0;
     for (uint32_t i = threadIdx.x; i < n; i += kDbBlock) {
-      if (core[i]) continue;
-      const double xi = xs[i];
-      bool reach = false;
-      for (uint32_t j = 0; j < n && !reach; ++j) reach = core[j] && fabs(xi - xs[j]) <= eps;
-      if (!reach) { g.flag[(uint64_t)ct[i] * g.K + k] = FLAG_PRESENT | FLAG_ANOMALY; noise++; }
+      const uint32_t before = i ? cp[i - 1] : 0u;
+      const bool core = cp[i] != before;
+      if (core) continue;
+      const uint32_t l = lo[i], h = hi[i];
+      const uint32_t in_window = cp[h] - (l ? cp[l - 1] : 0u);
+      if (in_window == 0) { g.flag[(uint64_t)bk[i] * g.K + k] = FLAG_PRESENT | FLAG_ANOMALY; noise++; }
     }
     if (noise) atomicAdd(&s_noise, noise);
     __syncthreads();
@@ -258,90 +360,48 @@ __global__ __launch_bounds__(kDbBlock) void k_emit_dbscan_wave(Grid g, Lattice L
   }
 }
 
-// Fallback for series too long for an LDS row: one workgroup per key, points compacted into a global
-// scratch row, x_j streamed from L1/L2 (every lane reads the same address -> one fetch per wave).
-__global__ __launch_bounds__(kDbBlock) void k_dbscan_long(Grid g, double eps, int min_samples,
-                                                          double *__restrict__ scratch_x,
-                                                          uint32_t *__restrict__ scratch_t,
-                                                          uint8_t *__restrict__ scratch_core) {
-  const uint64_t k = blockIdx.x;
-  const uint64_t T = g.T;
-  double *xs = scratch_x + k * T;
-  uint32_t *ct = scratch_t + k * T;
-  uint8_t *core = scratch_core + k * T;
-  __shared__ uint32_t s_wave[kDbWaves];
-  __shared__ uint32_t s_n;
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  const unsigned lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  for (uint64_t c0 = 0; c0 < T; c0 += kDbBlock) {
-    const uint64_t t = c0 + threadIdx.x;
-    const bool p = t < T && (g.flag[t * g.K + k] & FLAG_PRESENT);
-    const unsigned long long m = __ballot(p);
-    if (lane == 0) s_wave[wave] = __popcll(m);
-    __syncthreads();
-    uint32_t base = s_n;
-    for (int w = 0; w < wave; ++w) base += s_wave[w];
-    if (p) {
-      const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-      xs[pos] = (double)g.val[t * g.K + k];
-      ct[pos] = (uint32_t)t;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t tot = 0;
-      for (int w = 0; w < kDbWaves; ++w) tot += s_wave[w];
-      s_n += tot;
-    }
-    __syncthreads();
-  }
-  const uint32_t n = s_n;
-  __threadfence_block();
-  for (uint32_t i = threadIdx.x; i < n; i += kDbBlock) {
-    const double xi = xs[i];
-    int cnt = 0;
-    for (uint32_t j = 0; j < n; ++j) cnt += fabs(xi - xs[j]) <= eps ? 1 : 0;
-    core[i] = cnt >= min_samples ? 1 : 0;
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += kDbBlock) {
-    if (core[i]) continue;
-    const double xi = xs[i];
-    bool reach = false;
-    for (uint32_t j = 0; j < n && !reach; ++j) reach = core[j] && fabs(xi - xs[j]) <= eps;
-    if (!reach) g.flag[(uint64_t)ct[i] * g.K + k] = FLAG_PRESENT | FLAG_ANOMALY;
-  }
+// Scratch of one DBSCAN launch: count (64 B) | list[K] u32 | then, by series length,
+//   T <= 256                : sg[K] f64 | am[K * 4] u64          (what k_dbscan_list_wave leaves for the emit)
+//   T <= kSortLdsPoints     : nothing (k_dbscan_sorted works in LDS)
+//   longer                  : per-workgroup rows of k_dbscan_sorted, 24 B per point, cap = T rounded up to a power of two
+static size_t list_bytes(Grid g) { return 64 + (((size_t)g.K * 4 + 63) & ~(size_t)63); }
+static uint32_t sort_cap(uint64_t T) { uint32_t c = 1; while (c < T) c <<= 1; return c; }
+static uint32_t sort_blocks(Grid g) {   // workgroups of the long-series form: bounded scratch (256 MB), at least one
+  const uint64_t per = (uint64_t)sort_cap(g.T) * 24;
+  uint64_t b = (256ull << 20) / per;
+  if (b > 1024) b = 1024;
+  if (b > g.K) b = g.K;
+  return (uint32_t)(b ? b : 1);
 }
 
-static bool list_fits_lds(uint64_t T) { return T * 13 + 64 <= 150 * 1024; }
-
-// bytes of device scratch the DBSCAN launch needs: the work list (4 B per key + a counter) when a series fits an LDS row,
-// else the global rows of the long-series kernel
 size_t dbscan_scratch_bytes(Grid g) {
-  if (g.T <= 256) return 64 + (((size_t)g.K * 4 + 63) & ~(size_t)63) + (size_t)g.K * (8 + 8 * 4);   // + per list entry: stddev, noise masks (wave list)
-  if (list_fits_lds(g.T)) return (size_t)g.K * 4 + 64;
-  return (size_t)g.K * g.T * (8 + 4 + 1);
+  if (g.T <= 256) return list_bytes(g) + (size_t)g.K * (8 + 8 * 4);
+  if (g.T <= kSortLdsPoints) return list_bytes(g);
+  return list_bytes(g) + (size_t)sort_blocks(g) * sort_cap(g.T) * 24 + 64;
 }
 
 // scratch of the wave list (T <= 256): count | list[K] u32 | sg[K] f64 | am[K * 4] u64
 static double *wave_list_sg(const void *scratch, Grid g) {
-  return reinterpret_cast<double *>(const_cast<unsigned char *>(static_cast<const unsigned char *>(scratch)) + 64 + (((size_t)g.K * 4 + 63) & ~(size_t)63));
+  return reinterpret_cast<double *>(const_cast<unsigned char *>(static_cast<const unsigned char *>(scratch)) + list_bytes(g));
 }
 static unsigned long long *wave_list_am(const void *scratch, Grid g) { return reinterpret_cast<unsigned long long *>(wave_list_sg(scratch, g) + g.K); }
 
-bool dbscan_uses_list(Grid g) { return list_fits_lds(g.T); }
+bool dbscan_uses_list(Grid g) { return g.T < (1ull << 31); }   // every series length goes through scan + work list since round 4
 
 int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch, DbscanStats st, bool settled_by_stage0) {
   if (g.K == 0 || g.T == 0) return 0;
-  if (!list_fits_lds(g.T)) return -1;
+  if (!dbscan_uses_list(g)) return -1;
   unsigned int *count = static_cast<unsigned int *>(scratch);
   uint32_t *list = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + 64);
+  const unsigned lane_blocks = (unsigned)((g.K + kDbBlock - 1) / kDbBlock);
   if (settled_by_stage0) {   // the list was started by pass C (its counter zeroed before Stage 0)
-    hipLaunchKernelGGL(k_dbscan_scan<true>, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+    hipLaunchKernelGGL((k_dbscan_scan<true, false>), dim3(lane_blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
   } else {
     hipMemsetAsync(count, 0, sizeof(unsigned int), s);
-    hipLaunchKernelGGL(k_dbscan_scan<false>, dim3((unsigned)((g.K + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+    if (coop_shape(g))   // long series on few keys: a wavefront per key
+      hipLaunchKernelGGL((k_dbscan_scan<false, true>), dim3((unsigned)((g.K * 64 + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+    else
+      hipLaunchKernelGGL((k_dbscan_scan<false, false>), dim3(lane_blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
   }
   // grid-stride over the (device-side) list length: 8192 workgroups of four wavefronts give every one of C4's ~2e4 listed keys its
   // own wavefront (2048: 2-3 keys per wavefront one after the other; detect + emit 0.179 -> 0.174 ms, 32768 the same:
@@ -353,16 +413,31 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
 #undef TAD_DBW
     return 0;
   }
-  const size_t lds = (size_t)((g.T * 13 + 15) & ~(uint64_t)15);
-  allow_big_lds(reinterpret_cast<const void *>(k_dbscan_list), 152 * 1024);
-  hipLaunchKernelGGL(k_dbscan_list, dim3((unsigned)blocks), dim3(kDbBlock), lds, s, g, eps, min_samples, list, count, st.n_anom);
+  SortRows rows{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  size_t lds = (size_t)kSortLdsPoints * 24;
+  if (g.T > kSortLdsPoints) {
+    const uint32_t cap = sort_cap(g.T), nb = sort_blocks(g);
+    unsigned char *base = static_cast<unsigned char *>(scratch) + list_bytes(g);
+    rows.x = reinterpret_cast<double *>(base);
+    rows.bk = reinterpret_cast<uint32_t *>(rows.x + (size_t)nb * cap);
+    rows.lo = rows.bk + (size_t)nb * cap;
+    rows.hi = rows.lo + (size_t)nb * cap;
+    rows.cp = rows.hi + (size_t)nb * cap;
+    rows.cap = cap;
+    blocks = nb;
+    lds = 0;
+  } else if (blocks > 2048) {
+    blocks = 2048;
+  }
+  allow_big_lds(reinterpret_cast<const void *>(k_dbscan_sorted), 152 * 1024);
+  hipLaunchKernelGGL(k_dbscan_sorted, dim3((unsigned)blocks), dim3(kDbBlock), lds, s, g, eps, min_samples, list, count, st.n_anom, rows);
   return 0;
 }
 
 // the DBSCAN job's emit from the work list launch_dbscan left in `scratch` (false: shape not supported, use launch_emit kind 4)
 bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scratch, const uint32_t *n_anom, const unsigned long long *off,
                              OutRows out) {
-  if (g.K == 0 || g.T == 0 || g.T > 256 || !list_fits_lds(g.T)) return false;
+  if (g.K == 0 || g.T == 0 || g.T > 256) return false;
   const unsigned int *count = static_cast<const unsigned int *>(scratch);
   const uint32_t *list = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(scratch) + 64);
   const uint64_t blocks = g.K < 2048 ? g.K : 2048;
@@ -370,15 +445,6 @@ bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scr
   if (g.T <= 64) TAD_DBE(1); else if (g.T <= 128) TAD_DBE(2); else if (g.T <= 192) TAD_DBE(3); else TAD_DBE(4);
 #undef TAD_DBE
   return true;
-}
-
-int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch) {
-  unsigned char *p = static_cast<unsigned char *>(scratch);
-  double *sx = reinterpret_cast<double *>(p);
-  uint32_t *st = reinterpret_cast<uint32_t *>(p + (size_t)g.K * g.T * 8);
-  uint8_t *sc = p + (size_t)g.K * g.T * 12;
-  hipLaunchKernelGGL(k_dbscan_long, dim3((unsigned)g.K), dim3(kDbBlock), 0, s, g, eps, min_samples, sx, st, sc);
-  return 0;
 }
 
 }  // namespace tad

@@ -139,6 +139,42 @@ __device__ __forceinline__ void walk_series(const Grid &g, uint64_t k, Step step
   for (uint64_t t = nfull * kWalkChunk; t < T; ++t) step(t, g.flag[t * g.K + k], g.val[t * g.K + k]);
 }
 
+// Long series on few keys (the rank grid of a sparse table's longest class: two keys of 20 000 points): one lane per key leaves the
+// chip empty and every 8-bucket chunk of the walk is one exposed memory round trip (~2.5 us: 320 ns per step measured).  Here a whole
+// WAVEFRONT walks ONE key: lane l fetches bucket 64 c + l of block c (one wave-wide load covers 64 time steps, the next two blocks are in
+// flight while one is consumed), then every lane runs the step for the 64 buckets in time order on values broadcast by readlane — the same
+// sequential recurrence in all 64 lanes, identical bits, lane 0 (or any lane) owns the outputs.  step(t, flag, raw) as walk_series.
+static constexpr uint64_t kCoopMinT = 512, kCoopMaxK = 8192;   // used when T >= kCoopMinT and K <= kCoopMaxK (launchers: coop_shape)
+inline bool coop_shape(const Grid &g) { return g.T >= kCoopMinT && g.K <= kCoopMaxK; }
+
+template <typename Step>
+__device__ __forceinline__ void walk_series_coop(const Grid &g, uint64_t k, Step step) {
+  const uint64_t T = g.T;
+  const unsigned lane = threadIdx.x & 63u;
+  const uint64_t nblk = (T + 63) / 64;
+  auto load = [&](uint64_t c, uint32_t &f, unsigned long long &v) {
+    const uint64_t t = c * 64 + lane;
+    const bool in = c < nblk && t < T;
+    f = in ? (uint32_t)g.flag[t * g.K + k] : 0u;
+    v = in ? g.val[t * g.K + k] : 0ull;
+  };
+  uint32_t f0, f1, f2;
+  unsigned long long v0, v1, v2;
+  load(0, f0, v0);
+  load(1, f1, v1);
+  for (uint64_t c = 0; c < nblk; ++c) {
+    load(c + 2, f2, v2);
+    const uint64_t t0 = c * 64;
+    const unsigned long long present = __ballot((f0 & FLAG_PRESENT) != 0);   // absent buckets are skipped without a step call
+    for (unsigned long long m = present; m; m &= m - 1) {
+      const int u = __ffsll((long long)m) - 1;                 // wavefront-uniform
+      step(t0 + (uint64_t)u, (uint8_t)__shfl(f0, u), __shfl(v0, u));
+    }
+    f0 = f1; v0 = v1;
+    f1 = f2; v1 = v2;
+  }
+}
+
 // Chan et al. pairwise merge of (n, mean, M2)
 __device__ __forceinline__ Moments chan_merge(Moments a, Moments b) {
   if (b.n == 0.0) return a;
@@ -189,7 +225,7 @@ void launch_stream(hipStream_t s, Grid g, Lattice lat, double alpha, bool all_po
 void launch_ewma_values(hipStream_t s, Grid g, double alpha, double *calc);
 
 // DBSCAN: sets FLAG_ANOMALY on noise points.  scratch = dbscan_scratch_bytes(g) bytes of device memory.
-// dbscan_uses_list: the series fit an LDS row -> launch_dbscan (scan + work list); otherwise launch_dbscan_long.
+// dbscan_uses_list: launch_dbscan (scan + work list) handles the shape — every series length since round 4 (sorted windows).
 // st (all pointers NULL = not wanted): per-key point / anomaly counts and (mean, M2) moments
 struct DbscanStats {
   uint32_t *n_pts, *n_anom;
@@ -215,7 +251,6 @@ bool dbscan_uses_list(Grid g);
 // settled_by_stage0: pass C ran in settle mode (SettleArgs): the scan only walks keys marked kSettleRedo, the list is already started
 int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scratch,
                   DbscanStats st = DbscanStats{nullptr, nullptr, nullptr, nullptr}, bool settled_by_stage0 = false);
-int launch_dbscan_long(hipStream_t s, Grid g, double eps, int min_samples, void *scratch);
 // DBSCAN job (statistics from the scan, sigma computed at emit): the rows from the work list launch_dbscan left in `scratch`,
 // one wavefront per listed key.  false: not applicable (series longer than a wavefront's registers hold) -> launch_emit(kind 4)
 bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scratch, const uint32_t *n_anom, const unsigned long long *off,
@@ -288,10 +323,11 @@ bool part_plan_settle(uint64_t T, PartPlan *pl);
 // ---- Stage 0 for sparse tables: sort by (key, time), reduce, rank grid (tad_sparse.hip) ----
 size_t sparse_sort_temp_bytes(uint64_t slots);
 int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end, const int64_t *t_start,
-                        const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, int64_t t0, bool op_max, unsigned long long *comp_a,
+                        const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, int64_t t0, uint64_t span, bool op_max, unsigned long long *comp_a,
                         unsigned long long *val_a, unsigned long long *comp_b, unsigned long long *val_b, void *temp, size_t temp_bytes,
                         unsigned long long *num_runs, DevCounters *ctr);
-void launch_sparse_tmax(hipStream_t s, const unsigned long long *ucomp, uint64_t P, uint32_t *first, unsigned int *tmax);
+// slots: upper bound of the points (grid size); the point count itself is read on the device (*P_dev)
+void launch_sparse_tmax(hipStream_t s, const unsigned long long *ucomp, uint64_t slots, const unsigned long long *P_dev, uint32_t *first, unsigned int *tmax);
 void launch_sparse_place(hipStream_t s, const unsigned long long *ucomp, const unsigned long long *uval, uint64_t P, const uint32_t *first,
                          int64_t t0, Grid g, long long *times);
 // length classes for skewed sparse tables (tad_sparse.hip; orchestration: tad_capi.cpp:run_sparse_classes)

@@ -243,12 +243,15 @@ static constexpr int kUnroll = 16;  // independent loads in flight per lane (k_e
 // RCP_LDS: the reciprocal table (T + 1 doubles) is copied to LDS first.  A table lookup from global memory inside the
 // step would be a vector-memory load YOUNGER than the prefetched chunk of the walk, and vmcnt retires in order: waiting
 // for it waits for the whole prefetch, which serialises the walk into one memory round trip per chunk (127 -> 101 us).
-template <bool EWMA_COUNT, bool RCP_LDS>
+// COOP: one WAVEFRONT per key (walk_series_coop: long series on few keys); every lane runs the same recurrence, lane 0 writes.
+template <bool EWMA_COUNT, bool RCP_LDS, bool COOP = false>
 __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, const double *__restrict__ rcp_g, double *__restrict__ sigma,
                                                       uint32_t *__restrict__ n_pts,
                                                       uint32_t *__restrict__ n_anom, DevCounters *ctr,
                                                       double *__restrict__ key_mean, double *__restrict__ key_m2) {
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t k = COOP ? gtid >> 6 : gtid;
+  const bool writer = !COOP || (threadIdx.x & 63) == 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_rcp[];
   const double *rcp = rcp_g;
   if (RCP_LDS) {
@@ -262,38 +265,44 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, cons
   if (k < g.K) {
     double cnt = 0.0, avg = 0.0, m2 = 0.0;
     uint32_t n = 0;
-    walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
+    auto sigma_step = [&](uint64_t, uint8_t fl, unsigned long long raw) {
       if (fl & FLAG_PRESENT) {
         const double x = (double)raw;
         cnt = cnt + 1.0;
         n++;
         const double d = x - avg;
-        const double dn = div_by_count(d, cnt, rcp[n]);  // == d / cnt, bit for bit
+        // == d / cnt, bit for bit.  Without the table in LDS (series of more than 4095 buckets) the lookup would be a global load on the
+        // step's dependency chain, younger than the walk's prefetched blocks (vmcnt retires in order): the IEEE division is cheaper
+        const double dn = RCP_LDS ? div_by_count(d, cnt, rcp[n]) : d / cnt;
         avg = avg + dn;
         m2 = m2 + d * (d - dn);
       }
-    });
+    };
+    if (COOP) walk_series_coop(g, k, sigma_step); else walk_series(g, k, sigma_step);
     const bool has_sigma = n >= 2;
     const double sg = has_sigma ? sqrt(m2 / (cnt - 1.0)) : 0.0;
-    sigma[k] = sg;
-    n_pts[k] = n;
-    if (key_mean != nullptr) { key_mean[k] = avg; key_m2[k] = m2; }
-    my_pts = n;
-    my_key = n > 0;
+    if (writer) {
+      sigma[k] = sg;
+      n_pts[k] = n;
+      if (key_mean != nullptr) { key_mean[k] = avg; key_m2[k] = m2; }
+      my_pts = n;
+      my_key = n > 0;
+    }
     if (EWMA_COUNT) {
       uint32_t a = 0;
       if (has_sigma) {
         const double one_minus = 1.0 - alpha;
         double e = 0.0;
-        walk_series(g, k, [&](uint64_t, uint8_t fl, unsigned long long raw) {
+        auto ewma_step = [&](uint64_t, uint8_t fl, unsigned long long raw) {
           if (fl & FLAG_PRESENT) {
             const double x = (double)raw;
             e = one_minus * e + alpha * x;
             a += fabs(x - e) > sg ? 1u : 0u;
           }
-        });
+        };
+        if (COOP) walk_series_coop(g, k, ewma_step); else walk_series(g, k, ewma_step);
       }
-      n_anom[k] = a;
+      if (writer) n_anom[k] = a;
     }
   }
   for (int d = 32; d >= 1; d >>= 1) {
@@ -309,9 +318,17 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, cons
 void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, const double *rcp, double *sigma,
                       uint32_t *n_pts, uint32_t *n_anom, DevCounters *ctr, double *key_mean, double *key_m2) {
   if (g.K == 0) return;
-  const int blocks = (int)((g.K + kBlock - 1) / kBlock);
   const size_t lds = (size_t)(g.T + 1) * 8;
   const bool in_lds = lds <= 32768;
+  if (coop_shape(g)) {   // long series on few keys: a wavefront per key
+    const int cblocks = (int)((g.K * 64 + kBlock - 1) / kBlock);
+#define TAD_KSC(EC, RL) hipLaunchKernelGGL((k_key_sigma<EC, RL, true>), dim3(cblocks), dim3(kBlock), RL ? lds : 0, s, g, alpha, rcp, sigma, n_pts, n_anom, ctr, key_mean, key_m2)
+    if (ewma_count) { if (in_lds) TAD_KSC(true, true); else TAD_KSC(true, false); }
+    else { if (in_lds) TAD_KSC(false, true); else TAD_KSC(false, false); }
+#undef TAD_KSC
+    return;
+  }
+  const int blocks = (int)((g.K + kBlock - 1) / kBlock);
 #define TAD_KS(EC, RL) hipLaunchKernelGGL((k_key_sigma<EC, RL>), dim3(blocks), dim3(kBlock), RL ? lds : 0, s, g, alpha, rcp, sigma, n_pts, n_anom, ctr, key_mean, key_m2)
   if (ewma_count) { if (in_lds) TAD_KS(true, true); else TAD_KS(true, false); }
   else { if (in_lds) TAD_KS(false, true); else TAD_KS(false, false); }
@@ -387,8 +404,23 @@ __global__ __launch_bounds__(kBlock) void k_count_flags(Grid g, bool all_points,
   n_anom[k] = a;
 }
 
+// the same with a wavefront per key (long series on few keys): the lanes take the buckets in strides of 64
+__global__ __launch_bounds__(kBlock) void k_count_flags_coop(Grid g, bool all_points, uint32_t *__restrict__ n_anom) {
+  const uint64_t k = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  if (k >= g.K) return;   // wavefront-uniform
+  const uint8_t want = all_points ? FLAG_PRESENT : (uint8_t)(FLAG_PRESENT | FLAG_ANOMALY);
+  uint32_t a = 0;
+  for (uint64_t t = threadIdx.x & 63; t < g.T; t += 64) a += (g.flag[t * g.K + k] & want) == want ? 1u : 0u;
+  for (int d = 32; d >= 1; d >>= 1) a += __shfl_down(a, d);
+  if ((threadIdx.x & 63) == 0) n_anom[k] = a;
+}
+
 void launch_count_flags(hipStream_t s, Grid g, bool all_points, uint32_t *n_anom) {
   if (g.K == 0) return;
+  if (coop_shape(g)) {
+    hipLaunchKernelGGL(k_count_flags_coop, dim3((unsigned)((g.K * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, g, all_points, n_anom);
+    return;
+  }
   const int blocks = (int)((g.K + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_count_flags, dim3(blocks), dim3(kBlock), 0, s, g, all_points, n_anom);
 }
@@ -480,13 +512,16 @@ void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, ui
 // KIND 1: verdict bits + calc[] written by a detector kernel (ARIMA);
 // KIND 2: verdict bits, algoCalc = 0.0 (DBSCAN placeholder, :312-322).
 // ------------------------------------------------------------------------------------------------
-template <int KIND, bool ALL>
+// COOP: one wavefront per key (walk_series_coop); all lanes run the recurrences, lane 0 stores the rows.
+template <int KIND, bool ALL, bool COOP = false>
 __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha,
                                                  const double *__restrict__ sigma,
                                                  const uint32_t *__restrict__ n_pts,
                                                  const double *__restrict__ calc,
                                                  const unsigned long long *__restrict__ off, OutRows out) {
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t k = COOP ? gtid >> 6 : gtid;
+  const bool writer = !COOP || (threadIdx.x & 63) == 0;
   if (k >= g.K) return;
   unsigned long long pos = off[k];
   const unsigned long long end = off[k + 1];
@@ -505,6 +540,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
   uint8_t bv[4] = {0, 0, 0, 0};
   int nb = 0;
   auto write_row = [&](unsigned long long at, long long ts, double x, double a, bool verdict) {
+    if (!writer) return;
     out.key_id[at] = k;
     out.flow_end_s[at] = ts;
     out.throughput[at] = x;
@@ -541,7 +577,8 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (nb == i) { bt[i] = ts; bx[i] = x; ba[i] = a; if (ALL) bv[i] = verdict ? 1 : 0; }
-        if (++nb == 4) {  // four consecutive rows of every column = 32 aligned bytes: two 16-byte stores instead of four 8-byte ones
+        if (++nb == 4 && !writer) { pos += 4; nb = 0; }
+        else if (nb == 4) {  // four consecutive rows of every column = 32 aligned bytes: two 16-byte stores instead of four 8-byte ones
           const ulonglong2 kk = make_ulonglong2(k, k);
           reinterpret_cast<ulonglong2 *>(out.key_id + pos)[0] = kk;
           reinterpret_cast<ulonglong2 *>(out.key_id + pos)[1] = kk;
@@ -563,13 +600,14 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
       }
     }
   };
-  walk_series(g, k, step);
+  if (COOP) walk_series_coop(g, k, step); else walk_series(g, k, step);
 #pragma unroll
   for (int i = 0; i < 3; ++i)   // tail of the segment: fewer than four buffered rows
     if (i < nb) write_row(pos + i, bt[i], bx[i], ba[i], ALL && bv[i] != 0);
   if (LAZY) {
     sg = has_sigma ? sqrt(s_m2 / (s_cnt - 1.0)) : 0.0;
-    for (unsigned long long at = first; at < end; ++at) out.stddev[at] = sg;
+    if (COOP) { for (unsigned long long at = first + (threadIdx.x & 63); at < end; at += 64) out.stddev[at] = sg; }
+    else { for (unsigned long long at = first; at < end; ++at) out.stddev[at] = sg; }
   }
 }
 
@@ -662,6 +700,19 @@ void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, 
                  const double *sigma, const uint32_t *n_pts, const double *calc,
                  const unsigned long long *off, OutRows out, uint64_t rows_hint, int ewma_emit, uint32_t ewma_emit_rows) {
   if (g.K == 0) return;
+  if (coop_shape(g)) {   // long series on few keys: a wavefront per key (no staged variant: the rows of a key are written by one lane in time order)
+    const int cblocks = (int)((g.K * 64 + kBlock - 1) / kBlock);
+#define TAD_LAUNCH_EMIT_C(KIND, ALL) \
+  hipLaunchKernelGGL((k_emit<KIND, ALL, true>), dim3(cblocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out)
+    if (all_points) {
+      if (kind == 0) TAD_LAUNCH_EMIT_C(0, true); else if (kind == 1) TAD_LAUNCH_EMIT_C(1, true); else if (kind == 3) TAD_LAUNCH_EMIT_C(3, true); else TAD_LAUNCH_EMIT_C(2, true);
+    } else {
+      if (kind == 0) TAD_LAUNCH_EMIT_C(0, false); else if (kind == 1) TAD_LAUNCH_EMIT_C(1, false); else if (kind == 3) TAD_LAUNCH_EMIT_C(3, false);
+      else if (kind == 4) TAD_LAUNCH_EMIT_C(4, false); else TAD_LAUNCH_EMIT_C(2, false);
+    }
+#undef TAD_LAUNCH_EMIT_C
+    return;
+  }
   if (kind == 0 && !all_points && g.T < (1ull << kStageMarkTBits)) {
     if (const uint32_t cap = emit_stage_rows(g.K, rows_hint, ewma_emit, ewma_emit_rows)) {
       const unsigned blocks64 = (unsigned)((g.K + 63) / 64);

@@ -11,23 +11,18 @@
 // order: a K x Tmax grid, Tmax = the longest series, plus a parallel grid of the points' timestamps.  Every per-key
 // kernel downstream (stddev_samp, EWMA, DBSCAN, ARIMA, emit) only needs a key's points in time order, so they run
 // unchanged on the rank grid; emit takes the timestamps from the parallel grid instead of the lattice.
-#include <hipcub/hipcub.hpp>
-
 #include "tad_internal.h"
 
 namespace tad {
 
 static constexpr int kSpBlock = 256;
-static constexpr unsigned long long kInvalid = ~0ull;
 
-struct SumOp { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a + b; } };
-struct MaxOp { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
-
-// composite sort key of every (row, key) slot: key << 32 | (t - t0); rows that are filtered out get kInvalid (sorts last)
+// composite sort key of every (row, key) slot: key << 32 | (t - t0); slots that are filtered out get the key field K (one past the
+// last valid key: they sort behind every point and the reduction drops them)
 __global__ __launch_bounds__(kSpBlock) void k_sparse_keys(const uint64_t *__restrict__ key, const uint64_t *__restrict__ key2,
                                                          const int64_t *__restrict__ t_end, const int64_t *__restrict__ t_start,
                                                          const uint64_t *__restrict__ value, uint64_t n, uint64_t K, RowFilter f, int64_t t0,
-                                                         unsigned long long *__restrict__ comp, unsigned long long *__restrict__ vals,
+                                                         uint64_t span, unsigned long long *__restrict__ comp, unsigned long long *__restrict__ vals,
                                                          DevCounters *ctr) {
   const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
   uint32_t err = 0, used = 0;
@@ -41,10 +36,10 @@ __global__ __launch_bounds__(kSpBlock) void k_sparse_keys(const uint64_t *__rest
     const int nk = key2 != nullptr ? 2 : 1;
     for (int h = 0; h < nk; ++h) {
       const uint64_t k = h == 0 ? key[i] : key2[i];
-      unsigned long long c = kInvalid;
+      unsigned long long c = (unsigned long long)K << 32;
       if (kept && k != TAD_KEY_SKIP) {
         if (k >= K) err |= DEV_ERR_KEY_RANGE;
-        else if ((dt >> 32) != 0) err |= DEV_ERR_OFF_LATTICE;     // te < t0 or a span of more than 2^32 s: the caller's lattice hint was wrong
+        else if (dt > span) err |= DEV_ERR_OFF_LATTICE;     // te < t0 or beyond the lattice's last bucket (the sort covers bit_width(span) time bits): the lattice (hint / sample) was wrong
         else { c = ((unsigned long long)k << 32) | dt; used++; }
       }
       comp[i * nk + h] = c;
@@ -60,7 +55,11 @@ __global__ __launch_bounds__(kSpBlock) void k_sparse_keys(const uint64_t *__rest
 }
 
 // first[k] = index of the key's first point in the sorted unique list
-__global__ __launch_bounds__(kSpBlock) void k_sparse_first(const unsigned long long *__restrict__ ucomp, uint64_t P, uint32_t *__restrict__ first) {
+// (P_dev: the number of points, still on the device — the grid covers the slots, an upper bound — so that the host fetches the
+// point count and the longest series with ONE round trip)
+__global__ __launch_bounds__(kSpBlock) void k_sparse_first(const unsigned long long *__restrict__ ucomp, const unsigned long long *__restrict__ P_dev,
+                                                          uint32_t *__restrict__ first) {
+  const uint64_t P = *P_dev;
   const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
   if (i >= P) return;
   const uint32_t k = (uint32_t)(ucomp[i] >> 32);
@@ -68,8 +67,9 @@ __global__ __launch_bounds__(kSpBlock) void k_sparse_first(const unsigned long l
 }
 
 // longest series
-__global__ __launch_bounds__(kSpBlock) void k_sparse_tmax(const unsigned long long *__restrict__ ucomp, uint64_t P, const uint32_t *__restrict__ first,
-                                                         unsigned int *__restrict__ tmax) {
+__global__ __launch_bounds__(kSpBlock) void k_sparse_tmax(const unsigned long long *__restrict__ ucomp, const unsigned long long *__restrict__ P_dev,
+                                                         const uint32_t *__restrict__ first, unsigned int *__restrict__ tmax) {
+  const uint64_t P = *P_dev;
   const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
   unsigned int n = 0;
   if (i < P) {
@@ -177,38 +177,354 @@ __global__ __launch_bounds__(kSpBlock) void k_class_gather(OutRows src, uint64_t
   if (src.anomaly != nullptr) dst.anomaly[at] = src.anomaly[i];
 }
 
-size_t sparse_sort_temp_bytes(uint64_t slots) {
-  size_t a = 0, b = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                     (const unsigned long long *)nullptr, (unsigned long long *)nullptr, slots);
-  hipcub::DeviceReduce::ReduceByKey(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                    (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, SumOp(),
-                                    slots);
-  return (((a > b ? a : b) + 255) & ~(size_t)255) + 256;   // 256-byte multiple: the caller places two counters right behind it
+// ------------------------------------------------------------------------------------------------
+// The sort: least-significant-digit radix sort of the (comp, value) pairs, hand-written for gfx950.
+//
+// Only the bits that can differ are sorted: the virtual key of a slot is (key << tb) | (t - t0) with tb = bit_width(span) time
+// bits and kb = bit_width(K) key bits (K itself is the key field of the filtered-out slots), cut into ceil((kb + tb) / 8) digits of
+// <= 8 bits — 1e6 connections over a day of seconds: 37 bits, five passes, where a 64-bit library sort runs eight.
+// One pass = three steps, all of them plain streaming kernels without cross-workgroup waiting:
+//   k_rs_hist     per tile of 4096 slots: digit histogram in LDS (8 B/slot read) -> counts[digit][tile]
+//   launch_scan   exclusive scan of counts in digit-major order = the global position of every (digit, tile) run
+//   k_rs_scatter  per tile: every wavefront owns 512 consecutive slots and ranks them item by item — the lanes holding the same
+//                 digit find each other with one ballot per digit bit, a per-wavefront digit counter in LDS carries the rank from
+//                 item to item — then the tile is laid out by digit in LDS and copied out run by run with consecutive lanes on
+//                 consecutive slots (a digit's run of a tile is ~16 records: 128-byte pieces per column).  Ranks follow the slot
+//                 order (lane order inside an item, items in order, wavefronts in order, tiles in order), so every pass is
+//                 stable, which is what makes the digits compose.
+// 40 B per slot and pass (8 histogram + 16 in + 16 out).  Then the reduction of equal (key, time) runs:
+//   k_rs_heads    per tile: number of run heads among the valid slots -> launch_scan -> the output position of every run
+//   k_rs_zero     the (at most one per tile) output values that are assembled from several tiles start at the operator's identity
+//   k_rs_reduce   per tile in LDS: a head folds its run; a run that lies inside one tile is stored, the pieces of a run that
+//                 crosses tile boundaries meet in the output with 64-bit integer atomics (add wraps mod 2^64 / unsigned max: commutative,
+//                 so the aggregates are bit-identical to the dense path's and to ClickHouse's)
+// ------------------------------------------------------------------------------------------------
+static constexpr int kRsThreads = 512;                       // 8 wavefronts
+static constexpr int kRsWaves = kRsThreads / 64;
+static constexpr int kRsItems = 8;                           // slots per thread
+static constexpr uint32_t kRsTile = kRsThreads * kRsItems;   // 4096 slots per workgroup
+static constexpr uint32_t kRsRadix = 256;
+
+__device__ __forceinline__ uint32_t rs_digit(unsigned long long c, int tb, int shift, uint32_t mask) {
+  // (tb == 32: the composite key is the virtual key already; a 64-bit shift by 32 of the high half would be fine too, but keep it branch-free)
+  const unsigned long long v = ((c >> 32) << tb) | (c & 0xffffffffull);
+  return (uint32_t)(v >> shift) & mask;
 }
 
-// rows -> sorted unique (key, time) points with aggregated values: ucomp / uval (device), *num_runs (device)
+__global__ __launch_bounds__(kRsThreads) void k_rs_hist(const unsigned long long *__restrict__ comp, uint64_t N, int tb, int shift, uint32_t mask,
+                                                         uint32_t *__restrict__ counts, uint32_t NB) {
+  __shared__ uint32_t hist[kRsRadix];
+  if (threadIdx.x < kRsRadix) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * kRsTile;
+  unsigned long long c[kRsItems];
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i) {
+    const uint64_t j = base + (uint64_t)i * kRsThreads + threadIdx.x;
+    c[i] = j < N ? comp[j] : 0ull;
+  }
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i)
+    if (base + (uint64_t)i * kRsThreads + threadIdx.x < N) atomicAdd(&hist[rs_digit(c[i], tb, shift, mask)], 1u);
+  __syncthreads();
+  if (threadIdx.x <= mask) counts[(size_t)threadIdx.x * NB + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan of one value per thread over the workgroup (kRsThreads threads); s_w: kRsWaves + 1 words of LDS
+__device__ __forceinline__ uint32_t rs_block_excl_scan(uint32_t x, uint32_t *s_w, uint32_t *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = x;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(incl, d);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < kRsWaves; ++w) {
+    if (w < wave) base += s_w[w];
+    tot += s_w[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - x;
+}
+
+__global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const unsigned long long *__restrict__ comp_in, const unsigned long long *__restrict__ val_in,
+                                                            unsigned long long *__restrict__ comp_out, unsigned long long *__restrict__ val_out,
+                                                            uint64_t N, int tb, int shift, int width, const unsigned long long *__restrict__ off, uint32_t NB) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+  unsigned long long *s_comp = reinterpret_cast<unsigned long long *>(rs_smem);
+  unsigned long long *s_val = s_comp + kRsTile;
+  unsigned long long *s_gofs = s_val + kRsTile;                       // [256] global slot of the digit's run of this tile, minus its tile position
+  uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_gofs + kRsRadix); // [waves][256]: per-wavefront digit counters, then their exclusive prefix over the wavefronts
+  uint32_t *s_base = s_hist + kRsWaves * kRsRadix;                    // [256] first tile position of the digit
+  uint32_t *s_w = s_base + kRsRadix;                                  // scan scratch
+  const uint32_t mask = (1u << width) - 1u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t i = threadIdx.x; i < kRsWaves * kRsRadix; i += kRsThreads) s_hist[i] = 0;
+  const uint64_t base = (uint64_t)blockIdx.x * kRsTile;
+  const uint32_t n_tile = base + kRsTile <= N ? kRsTile : (uint32_t)(N - base);
+  unsigned long long c[kRsItems], v[kRsItems];
+  uint32_t rr[kRsItems];
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i) {   // wavefront w owns the slots [w * 512, w * 512 + 512) of the tile, item i its i-th 64
+    const uint32_t j = (uint32_t)wave * (64 * kRsItems) + (uint32_t)i * 64 + (uint32_t)lane;
+    const bool in = j < n_tile;
+    c[i] = in ? comp_in[base + j] : 0ull;
+    v[i] = in ? val_in[base + j] : 0ull;
+  }
+  __syncthreads();
+  uint32_t *my_hist = s_hist + wave * kRsRadix;
+  const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i) {
+    const uint32_t j = (uint32_t)wave * (64 * kRsItems) + (uint32_t)i * 64 + (uint32_t)lane;
+    const bool in = j < n_tile;
+    const uint32_t d = rs_digit(c[i], tb, shift, mask);
+    unsigned long long peers = __ballot(in);
+    for (int b = 0; b < width; ++b) {          // the lanes of this item that hold the same digit
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const uint32_t old = in ? my_hist[d] : 0u;            // the same word for all peers (LDS broadcast)
+    __builtin_amdgcn_wave_barrier();                      // every peer has read before the first of them adds the item's count
+    if (in && (peers & lt_mask) == 0ull) my_hist[d] = old + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    rr[i] = old + (uint32_t)__popcll(peers & lt_mask);
+  }
+  __syncthreads();
+  // per digit: counts of the wavefronts -> exclusive prefix over the wavefronts, tile total -> exclusive scan over the digits
+  uint32_t tot_d = 0;
+  if (threadIdx.x < kRsRadix) {
+    for (int w = 0; w < kRsWaves; ++w) {
+      const uint32_t t = s_hist[w * kRsRadix + threadIdx.x];
+      s_hist[w * kRsRadix + threadIdx.x] = tot_d;
+      tot_d += t;
+    }
+  }
+  uint32_t tile_total;
+  const uint32_t ex = rs_block_excl_scan(tot_d, s_w, &tile_total);
+  if (threadIdx.x < kRsRadix) {
+    s_base[threadIdx.x] = ex;
+    s_gofs[threadIdx.x] = threadIdx.x <= mask ? off[(size_t)threadIdx.x * NB + blockIdx.x] - ex : 0ull;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i) {
+    const uint32_t j = (uint32_t)wave * (64 * kRsItems) + (uint32_t)i * 64 + (uint32_t)lane;
+    if (j < n_tile) {
+      const uint32_t d = rs_digit(c[i], tb, shift, mask);
+      const uint32_t pos = s_base[d] + my_hist[d] + rr[i];
+      s_comp[pos] = c[i];
+      s_val[pos] = v[i];
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < n_tile; j += kRsThreads) {   // consecutive lanes -> consecutive slots of a digit's run
+    const unsigned long long cc = s_comp[j];
+    const unsigned long long dst = s_gofs[rs_digit(cc, tb, shift, mask)] + j;
+    comp_out[dst] = cc;
+    val_out[dst] = s_val[j];
+  }
+}
+
+// run heads among the valid slots of each tile (valid: key field < K; the filtered-out slots carry K and sort last)
+__global__ __launch_bounds__(kRsThreads) void k_rs_heads(const unsigned long long *__restrict__ comp, uint64_t N, uint64_t K, uint32_t *__restrict__ cnt) {
+  __shared__ uint32_t s_w[kRsWaves];
+  const uint64_t base = (uint64_t)blockIdx.x * kRsTile;
+  uint32_t h = 0;
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i) {
+    const uint64_t j = base + (uint64_t)i * kRsThreads + threadIdx.x;
+    if (j < N) {
+      const unsigned long long c = comp[j];
+      if ((c >> 32) < K && (j == 0 || comp[j - 1] != c)) ++h;
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) h += __shfl_down(h, d);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < kRsWaves; ++w) t += s_w[w];
+    cnt[blockIdx.x] = t;
+  }
+}
+
+// a run that continues into the next tile is assembled in the output by atomics: its value starts at 0 (the identity of wrapping add
+// and of unsigned max).  off[b + 1] - 1 = the run the last slot of tile b belongs to.
+__global__ __launch_bounds__(256) void k_rs_zero(const unsigned long long *__restrict__ comp, uint64_t N, uint64_t K, const unsigned long long *__restrict__ off,
+                                                  uint32_t NB, unsigned long long *__restrict__ out_val, unsigned long long *__restrict__ num_runs) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b == 0) *num_runs = off[NB];
+  if (b >= NB) return;
+  const uint64_t end = (uint64_t)(b + 1) * kRsTile;
+  if (end >= N) return;
+  const unsigned long long c = comp[end - 1];
+  if ((c >> 32) < K && comp[end] == c) out_val[off[b + 1] - 1] = 0ull;
+}
+
+template <bool OPMAX>
+__global__ __launch_bounds__(kRsThreads) void k_rs_reduce(const unsigned long long *__restrict__ comp, const unsigned long long *__restrict__ val, uint64_t N,
+                                                           uint64_t K, const unsigned long long *__restrict__ off, unsigned long long *__restrict__ out_comp,
+                                                           unsigned long long *__restrict__ out_val) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+  unsigned long long *s_comp = reinterpret_cast<unsigned long long *>(rs_smem);
+  unsigned long long *s_val = s_comp + kRsTile;
+  __shared__ uint32_t s_w[kRsWaves + 1];
+  const uint64_t base = (uint64_t)blockIdx.x * kRsTile;
+  const uint32_t n_tile = base + kRsTile <= N ? kRsTile : (uint32_t)(N - base);
+  for (uint32_t j = threadIdx.x; j < n_tile; j += kRsThreads) { s_comp[j] = comp[base + j]; s_val[j] = val[base + j]; }
+  const unsigned long long prev = base ? comp[base - 1] : 0ull;
+  const bool has_next = base + n_tile < N;
+  const unsigned long long next = has_next ? comp[base + n_tile] : 0ull;
+  __syncthreads();
+  auto is_head = [&](uint32_t j) -> bool {
+    const unsigned long long c = s_comp[j];
+    if ((c >> 32) >= K) return false;
+    return j ? s_comp[j - 1] != c : (base == 0 || prev != c);
+  };
+  // thread t owns the slots [t * 8, t * 8 + 8): heads before them in the tile
+  const uint32_t j0 = threadIdx.x * kRsItems;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i)
+    if (j0 + i < n_tile && is_head(j0 + i)) ++mine;
+  uint32_t total;
+  uint32_t before = rs_block_excl_scan(mine, s_w, &total);
+  const unsigned long long o0 = off[blockIdx.x];
+  auto fold = [&](uint32_t j, uint32_t *end) -> unsigned long long {   // the run piece that starts at slot j of this tile
+    const unsigned long long c = s_comp[j];
+    unsigned long long acc = s_val[j];
+    uint32_t k = j + 1;
+    for (; k < n_tile && s_comp[k] == c; ++k) acc = OPMAX ? (s_val[k] > acc ? s_val[k] : acc) : acc + s_val[k];
+    *end = k;
+    return acc;
+  };
+  auto combine = [&](unsigned long long idx, unsigned long long acc) {
+    if (OPMAX) __hip_atomic_fetch_max(out_val + idx, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_fetch_add(out_val + idx, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i) {
+    const uint32_t j = j0 + i;
+    if (j < n_tile && is_head(j)) {
+      uint32_t end;
+      const unsigned long long acc = fold(j, &end);
+      const unsigned long long idx = o0 + before;
+      ++before;
+      out_comp[idx] = s_comp[j];
+      if (end == n_tile && has_next && next == s_comp[j]) combine(idx, acc);   // continues in the next tile (k_rs_zero prepared the word)
+      else out_val[idx] = acc;
+    }
+  }
+  // the tile starts inside a run that began in an earlier tile: its piece joins that run's output word
+  if (threadIdx.x == 0 && base != 0 && n_tile != 0 && (s_comp[0] >> 32) < K && prev == s_comp[0]) {
+    uint32_t end;
+    const unsigned long long acc = fold(0, &end);
+    combine(o0 - 1, acc);
+  }
+}
+
+static inline int bit_width64(uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
+
+struct RsPlan {
+  int tb, np;
+  int shift[8], width[8];
+  uint32_t NB;
+};
+
+static RsPlan rs_plan(uint64_t slots, uint64_t K, uint64_t span) {
+  RsPlan p{};
+  p.tb = bit_width64(span);
+  if (p.tb > 32) p.tb = 32;
+  const int bits = p.tb + bit_width64(K);   // K itself must sort (the filtered-out slots)
+  p.np = (bits + 7) / 8;
+  if (p.np < 1) p.np = 1;
+  int at = 0, left = bits;
+  for (int i = 0; i < p.np; ++i) {
+    int w = (left + (p.np - i) - 1) / (p.np - i);   // balanced digit widths
+    if (w < 1) w = 1;
+    p.shift[i] = at; p.width[i] = w;
+    at += w; left -= w;
+  }
+  p.NB = (uint32_t)((slots + kRsTile - 1) / kRsTile);
+  return p;
+}
+
+// temp: counts u32 [256 * NB] | off u64 [256 * NB + 1] | scan scratch | head counts u32 [NB] | head offsets u64 [NB + 1]
+struct RsTemp { size_t counts, off, scratch, hcnt, hoff, total; };
+static RsTemp rs_temp_layout(uint64_t slots) {
+  const size_t NB = (size_t)((slots + kRsTile - 1) / kRsTile);
+  const size_t m = (size_t)kRsRadix * NB;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  RsTemp t;
+  size_t at = 0;
+  t.counts = at; at = up(at + m * 4);
+  t.off = at; at = up(at + (m + 1) * 8);
+  t.scratch = at; at = up(at + scan_scratch_elems(m ? m : 1) * 8);
+  t.hcnt = at; at = up(at + (NB ? NB : 1) * 4);
+  t.hoff = at; at = up(at + (NB + 1) * 8);
+  t.total = at;
+  return t;
+}
+
+size_t sparse_sort_temp_bytes(uint64_t slots) { return rs_temp_layout(slots).total + 256; }   // 256-byte multiple: the caller places two counters right behind it
+
+// rows -> sorted unique (key, time) points with aggregated values in comp_a / val_a (device), their number in *num_runs (device).
+// span = the largest t - t0 the lattice allows ((n_buckets - 1) * step): rows beyond it raise DEV_ERR_OFF_LATTICE.
 int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end, const int64_t *t_start,
-                        const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, int64_t t0, bool op_max, unsigned long long *comp_a,
+                        const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, int64_t t0, uint64_t span, bool op_max, unsigned long long *comp_a,
                         unsigned long long *val_a, unsigned long long *comp_b, unsigned long long *val_b, void *temp, size_t temp_bytes,
                         unsigned long long *num_runs, DevCounters *ctr) {
   const uint64_t slots = n * (key2 != nullptr ? 2 : 1);
+  if (slots == 0 || slots >= (1ull << 32) || K > 0xFFFFFFFFull) return -1;
+  if (span > 0xFFFFFFFFull) span = 0xFFFFFFFFull;
+  const RsPlan pl = rs_plan(slots, K, span);
+  const RsTemp tl = rs_temp_layout(slots);
+  if (temp_bytes < tl.total) return -1;
+  unsigned char *tp = static_cast<unsigned char *>(temp);
+  uint32_t *counts = reinterpret_cast<uint32_t *>(tp + tl.counts);
+  unsigned long long *off = reinterpret_cast<unsigned long long *>(tp + tl.off);
+  unsigned long long *scratch = reinterpret_cast<unsigned long long *>(tp + tl.scratch);
+  uint32_t *hcnt = reinterpret_cast<uint32_t *>(tp + tl.hcnt);
+  unsigned long long *hoff = reinterpret_cast<unsigned long long *>(tp + tl.hoff);
+  // an odd number of moves (the passes + the reduction) ends in the a buffers: start in a when the number of passes is odd
+  unsigned long long *ca = (pl.np & 1) ? comp_a : comp_b, *va = (pl.np & 1) ? val_a : val_b;
+  unsigned long long *cb = (pl.np & 1) ? comp_b : comp_a, *vb = (pl.np & 1) ? val_b : val_a;
   hipLaunchKernelGGL(k_sparse_keys, dim3((unsigned)((n + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, key, key2, t_end, t_start, value, n, K,
-                     f, t0, comp_a, val_a, ctr);
-  size_t tb = temp_bytes;
-  if (hipcub::DeviceRadixSort::SortPairs(temp, tb, comp_a, comp_b, val_a, val_b, slots, 0, 64, s) != hipSuccess) return -1;
-  tb = temp_bytes;
-  hipError_t r;
-  if (op_max) r = hipcub::DeviceReduce::ReduceByKey(temp, tb, comp_b, comp_a, val_b, val_a, num_runs, MaxOp(), slots, s);
-  else r = hipcub::DeviceReduce::ReduceByKey(temp, tb, comp_b, comp_a, val_b, val_a, num_runs, SumOp(), slots, s);
-  return r == hipSuccess ? 0 : -1;
+                     f, t0, span, ca, va, ctr);
+  const size_t lds = (size_t)kRsTile * 16 + kRsRadix * 8 + (size_t)kRsWaves * kRsRadix * 4 + kRsRadix * 4 + 64;
+  allow_big_lds(reinterpret_cast<const void *>(k_rs_scatter), lds);
+  for (int p = 0; p < pl.np; ++p) {
+    const uint32_t mask = (1u << pl.width[p]) - 1u;
+    hipLaunchKernelGGL(k_rs_hist, dim3(pl.NB), dim3(kRsThreads), 0, s, ca, slots, pl.tb, pl.shift[p], mask, counts, pl.NB);
+    launch_scan(s, counts, off, (uint64_t)(mask + 1) * pl.NB, scratch);
+    hipLaunchKernelGGL(k_rs_scatter, dim3(pl.NB), dim3(kRsThreads), lds, s, ca, va, cb, vb, slots, pl.tb, pl.shift[p], pl.width[p], off, pl.NB);
+    unsigned long long *t = ca; ca = cb; cb = t;
+    t = va; va = vb; vb = t;
+  }
+  hipLaunchKernelGGL(k_rs_heads, dim3(pl.NB), dim3(kRsThreads), 0, s, ca, slots, K, hcnt);
+  launch_scan(s, hcnt, hoff, pl.NB, scratch);
+  hipLaunchKernelGGL(k_rs_zero, dim3((pl.NB + 255) / 256), dim3(256), 0, s, ca, slots, K, hoff, pl.NB, vb, num_runs);
+  const size_t rlds = (size_t)kRsTile * 16;
+  if (op_max) {
+    allow_big_lds(reinterpret_cast<const void *>(k_rs_reduce<true>), rlds);
+    hipLaunchKernelGGL(k_rs_reduce<true>, dim3(pl.NB), dim3(kRsThreads), rlds, s, ca, va, slots, K, hoff, cb, vb);
+  } else {
+    allow_big_lds(reinterpret_cast<const void *>(k_rs_reduce<false>), rlds);
+    hipLaunchKernelGGL(k_rs_reduce<false>, dim3(pl.NB), dim3(kRsThreads), rlds, s, ca, va, slots, K, hoff, cb, vb);
+  }
+  return (cb == comp_a && hipGetLastError() == hipSuccess) ? 0 : -1;
 }
 
-void launch_sparse_tmax(hipStream_t s, const unsigned long long *ucomp, uint64_t P, uint32_t *first, unsigned int *tmax) {
-  if (P == 0) return;
-  const unsigned blocks = (unsigned)((P + kSpBlock - 1) / kSpBlock);
-  hipLaunchKernelGGL(k_sparse_first, dim3(blocks), dim3(kSpBlock), 0, s, ucomp, P, first);
-  hipLaunchKernelGGL(k_sparse_tmax, dim3(blocks), dim3(kSpBlock), 0, s, ucomp, P, first, tmax);
+void launch_sparse_tmax(hipStream_t s, const unsigned long long *ucomp, uint64_t slots, const unsigned long long *P_dev, uint32_t *first, unsigned int *tmax) {
+  if (slots == 0) return;
+  const unsigned blocks = (unsigned)((slots + kSpBlock - 1) / kSpBlock);
+  hipLaunchKernelGGL(k_sparse_first, dim3(blocks), dim3(kSpBlock), 0, s, ucomp, P_dev, first);
+  hipLaunchKernelGGL(k_sparse_tmax, dim3(blocks), dim3(kSpBlock), 0, s, ucomp, P_dev, first, tmax);
 }
 
 void launch_sparse_place(hipStream_t s, const unsigned long long *ucomp, const unsigned long long *uval, uint64_t P, const uint32_t *first,
