@@ -192,8 +192,8 @@ def test_job_walks_the_states_on_the_gpu_engine(engine, algo, agg):
         def canon(rows):
             out = []
             for r in rows:
-                d = {k: (float(v) if k in ("throughput", "algoCalc", "throughputStandardDeviation") else
-                         (int(v) if k == "flowEndSeconds" else str(v))) for k, v in r.items()}
+                d = {k: (None if v is None else float(v)) if k in ("throughput", "algoCalc", "throughputStandardDeviation") else
+                         (int(v) if k == "flowEndSeconds" else str(v)) for k, v in r.items()}
                 out.append(d)
             return sorted(out, key=lambda d: tuple(str(d[k]) for k in sorted(d) if k not in ("throughput", "algoCalc", "throughputStandardDeviation")) +
                           (d["flowEndSeconds"],))
