@@ -368,6 +368,7 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_ROW * n, "avg_kernel_ms": scatter_ms},
             "pipeline": {"ms_meta": a0["ms_meta"] / steps, "ms_stage0_clear_plus_scatter": a0["ms_stage0"] / steps,
                          "ms_detect_and_emit": sum(a["ms_detect"] for a in r["acc"]) / steps, "ms_device_total": dev_ms,
+                         "host_syncs_per_job": [st.get("host_syncs") for st in r["stats"]],
                          "hbm_frac_whole_job": (len(algos) * BYTES_PER_ROW * n + BYTES_PER_ANOMALY * A) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         g = r["glob"]

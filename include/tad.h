@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 7
+#define TAD_ABI_VERSION 8
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -82,7 +82,7 @@ typedef struct {
   int32_t sparse_classes;    /* 1 = always run a sparse table as length classes of keys */
   int32_t ewma_emit;         /* 1 = lane-per-key emit for the EWMA job instead of the LDS-staged one */
   uint32_t ewma_emit_rows;   /* LDS rows per wavefront of the staged EWMA emit (<= 4096); 0 = sized from the row count */
-  int32_t reserved;          /* 0 */
+  int32_t one_sync;          /* 1 = never run a job in the one-synchronisation form (ABI 8; see tad_stats.host_syncs) */
 } tad_plan;
 
 typedef struct {
@@ -165,7 +165,11 @@ typedef struct {
   int32_t stage0_attempts; /* times Stage 0 ran before it settled: 1 normally; more after a wrong lattice hint, a sampled lattice or
                               a sampled histogram that proved too optimistic (every fallback is exact), an overflow-list fallback */
   int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/8 of pass A's reads) */
-  int32_t reserved;        /* 0 (ABI 6: detect_path of the fused EWMA kernel — measured no faster than the separate kernels, removed) */
+  int32_t host_syncs;      /* ABI 8: host synchronisations of the attempt that produced the result.  3 = lattice derivation, row count,
+                              result; 1 = the one-synchronisation form: a job of the same shape (rows, keys, algorithm, filters) as the
+                              engine's previous one, device-resident in and out, is issued with that job's lattice and row capacity while
+                              the device checks both (the lattice against pass A's own derivation, the row total against the block) —
+                              a miss discards the output and reruns the 3-synchronisation form (stage0_attempts counts it) */
 } tad_stats;
 
 /* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).

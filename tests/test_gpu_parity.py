@@ -155,6 +155,30 @@ def test_job_ewma_emit_staged_rows_overflow_and_direct_variants(engine, stage0, 
     assert want["n_anomalies"] > 64 * 16
 
 
+@pytest.mark.parametrize("algo", ["EWMA", "DBSCAN", "ARIMA"])
+@pytest.mark.parametrize("K,T", [(3, 700), (70, 1300)])
+def test_job_long_series_on_few_keys_wavefront_per_key(engine, algo, K, T):
+    """T >= 512 buckets on K <= 8192 keys: the per-key kernels run with a WAVEFRONT per key (walk_series_coop: cooperative block
+    loads, readlane broadcast, reciprocals per block) instead of a lane per key.  Same recurrences in the same order: sigma, EWMA
+    values, verdicts and rows must be the oracle's bits; holes in the series and a one-point key included."""
+    if algo == "ARIMA" and T > 700:
+        pytest.skip("ARIMA on 1300-point series: minutes of oracle time for nothing the 700-point case does not cover")
+    k, t, v = orc.synth_rows(11, 40 * K * T // 10, K, T)
+    keep = (orc.mix64(k * np.uint64(977) + t.astype(np.uint64)) % np.uint64(5)) != 0      # holes: a fifth of the (key, time) cells absent
+    keep &= ~((k == 1) & (t != t.min()))                                                  # key 1: a single point (no sigma)
+    k, t, v = k[keep], t[keep], v[keep]
+    if algo == "ARIMA":      # (keys without a result yield no rows: compare the job's rows; the fit kernels are not lane-per-key walkers,
+        want = orc.run_job(algo, k, t, v, agg_flow="svc")      # the flag count and the emit are)
+        res = engine.run(algo, k, t, v, K, agg_flow="svc")
+        assert res.n_rows == want["n_anomalies"] > 0
+        for f in ("key_id", "flow_end_s", "throughput", "stddev"):
+            assert (res[f] == want[f]).all(), f
+        assert np.array_equal(res["algo_calc"], want["algo_calc"], equal_nan=True)
+    else:
+        res, want = check_job(engine, algo, k, t, v, K, agg_flow="svc")
+    assert res.stats["n_buckets"] >= 512
+
+
 @pytest.mark.parametrize("algo", ["EWMA", "DBSCAN"])
 def test_job_max_mode_per_connection(engine, algo):
     k, t, v = orc.synth_rows(0, 200000, 5000, 100)      # mode None: max(throughput), ~0.4 rows/point

@@ -42,7 +42,7 @@ struct tad_engine {
   std::string err;
   std::atomic<int32_t> done{0}, total{0};
   // grow-only device scratch
-  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2, moments;
+  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2;   // counters: the job tail (kTailBytes)
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
   DevBuf rcp_table;           // rcp_table[n] = RN(1/n), n = 0..rcp_n-1
   uint64_t rcp_n = 0;
@@ -53,13 +53,37 @@ struct tad_engine {
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
-  DevCounters *ctr_host = nullptr;     // pinned
-  unsigned long long *total_host = nullptr;  // pinned
-  Moments *moments_host = nullptr;           // pinned
+  // The job's tail — what the host reads when a job's kernels are done — is ONE block on the device (e->counters: DevCounters |
+  // row total | overflow-list count | pad to 128 B | kMomentBlocks moment partials) and ONE pinned block here: one copy per job.
+  unsigned char *tail_host = nullptr;        // pinned, kTailBytes
+  DevCounters *ctr_host = nullptr;           // = tail_host
+  unsigned long long *total_host = nullptr;  // = tail_host + 64
+  Moments *moments_host = nullptr;           // = tail_host + 128
+  // Speculation state of the one-synchronisation job (run_job_locked): the lattice and the row count of the last job of this shape.
+  struct Spec {
+    bool valid = false;
+    uint64_t n = 0, K = 0;
+    bool has2 = false;
+    int algo = 0, agg = 0, op = 0;
+    uint32_t flags = 0;
+    int64_t start = 0, end = 0;
+    Lattice L{};
+    uint64_t rows = 0;
+    bool exact_hist = false;   // the sampled histogram proved too optimistic for this table: go straight to the exact one
+  } spec;
 };
 
 // per-key running state of the streaming EWMA detector: two copies (the count pass writes the candidate next state,
 // it becomes current only when the batch succeeds)
+namespace {
+constexpr size_t kTailCtr = 0, kTailTotal = 64, kTailOvfCount = 72, kTailMoments = 128;
+constexpr size_t kTailBytes = kTailMoments + sizeof(Moments) * kMomentBlocks;
+inline DevCounters *dev_ctr(tad_engine *e) { return static_cast<DevCounters *>(e->counters.p); }
+inline unsigned long long *dev_total(tad_engine *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailTotal); }
+inline unsigned long long *dev_ovf_count(tad_engine *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailOvfCount); }
+inline Moments *dev_moments(tad_engine *e) { return reinterpret_cast<Moments *>(static_cast<unsigned char *>(e->counters.p) + kTailMoments); }
+}  // namespace
+
 struct tad_state {
   uint64_t K = 0;
   void *block[2] = {nullptr, nullptr};
@@ -73,7 +97,7 @@ constexpr int kSampleBlockShift = 7;   // (C4 with 1024-key blocks and a sampled
 
 bool plan_ok(const tad_plan &p) {
   return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 2 && p.histogram >= 0 && p.histogram <= 1 && p.sparse >= 0 &&
-         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096;
+         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.one_sync >= 0 && p.one_sync <= 1;
 }
 constexpr uint32_t kOverflowCap = 1u << 20;  // Stage 0 v2: rows with a value >= 2^49 per run before falling back to v1
 
@@ -230,10 +254,12 @@ int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
   if (opts) e->plan = opts->plan;
   for (auto &ev : e->ev) hipEventCreate(&ev);
   hipHostMalloc(reinterpret_cast<void **>(&e->meta_host), sizeof(MetaPartial) * kMetaBlocks, hipHostMallocDefault);
-  hipHostMalloc(reinterpret_cast<void **>(&e->ctr_host), sizeof(DevCounters), hipHostMallocDefault);
-  hipHostMalloc(reinterpret_cast<void **>(&e->total_host), sizeof(unsigned long long), hipHostMallocDefault);
-  hipHostMalloc(reinterpret_cast<void **>(&e->moments_host), sizeof(Moments) * kMomentBlocks, hipHostMallocDefault);
-  if (!e->meta_host || !e->ctr_host || !e->total_host || !e->moments_host) { tad_engine_destroy(e); return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "pinned host allocation failed"); }
+  hipHostMalloc(reinterpret_cast<void **>(&e->tail_host), kTailBytes, hipHostMallocDefault);
+  if (!e->meta_host || !e->tail_host) { tad_engine_destroy(e); return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "pinned host allocation failed"); }
+  memset(e->tail_host, 0, kTailBytes);
+  e->ctr_host = reinterpret_cast<DevCounters *>(e->tail_host + kTailCtr);
+  e->total_host = reinterpret_cast<unsigned long long *>(e->tail_host + kTailTotal);
+  e->moments_host = reinterpret_cast<Moments *>(e->tail_host + kTailMoments);
   *out = e;
   return TAD_OK;
 }
@@ -243,16 +269,14 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->moments, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part_fin, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part_fin, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
   for (auto &ev : e->ev)
     if (ev) hipEventDestroy(ev);
   if (e->meta_host) hipHostFree(e->meta_host);
-  if (e->ctr_host) hipHostFree(e->ctr_host);
-  if (e->total_host) hipHostFree(e->total_host);
-  if (e->moments_host) hipHostFree(e->moments_host);
+  if (e->tail_host) hipHostFree(e->tail_host);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -353,13 +377,13 @@ int ensure_key_buffers(tad_engine *e, uint64_t K) {
   if ((rc = ensure(e, e->scan_scratch, scan_scratch_elems(k) * sizeof(unsigned long long))) != TAD_OK) return rc;
   if ((rc = ensure(e, e->key_mean, k * sizeof(double))) != TAD_OK) return rc;
   if ((rc = ensure(e, e->key_m2, k * sizeof(double))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->moments, kMomentBlocks * sizeof(Moments))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->counters, kTailBytes)) != TAD_OK) return rc;
   return TAD_OK;
 }
 
 // Runs sigma + detector + scan on grid g.  On return *rows = number of rows emit will write.
 // stats_done: Stage 0 v2's tile pass already produced sigma / n_pts / (EWMA) n_anom / moments inputs / counters.
-int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_t *rows, bool stats_done = false) {
+int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_t *rows, bool stats_done = false, bool defer_tail = false) {
   hipStream_t s = e->stream;
   int rc;
   if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
@@ -401,30 +425,29 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
       return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
   }
   launch_moments(s, g.K, n_pts, static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
-                 static_cast<Moments *>(e->moments.p), db_fused ? ctr : nullptr);
+                 dev_moments(e), db_fused ? ctr : nullptr);
   const uint32_t *cnt = n_anom;
   if (jp.all_points && jp.algo != TAD_ALGO_ARIMA && !drop) cnt = n_pts;
   else if (db_fused) {}                                                             // the tile kernel counted the noise points
   else if (!ewma || jp.all_points) launch_count_flags(s, g, jp.all_points, n_anom);  // ARIMA / DROP all_points: skips no-result keys
-  launch_scan(s, cnt, off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
-  HIP_TRY(e, hipMemcpyAsync(e->total_host, off + g.K, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
-  HIP_TRY(e, hipMemcpyAsync(e->moments_host, e->moments.p, kMomentBlocks * sizeof(Moments), hipMemcpyDeviceToHost, s));
+  launch_scan(s, cnt, off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p), dev_total(e));
+  if (defer_tail) return TAD_OK;   // the one-synchronisation job: the tail is fetched once, after the emit
+  HIP_TRY(e, hipMemcpyAsync(e->tail_host, e->counters.p, kTailBytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipStreamSynchronize(s));
   HIP_TRY(e, hipGetLastError());
   *rows = *e->total_host;
   return TAD_OK;
 }
 
-void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows out, uint64_t rows = 0) {
+void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows out, uint64_t rows = 0, EmitGuard guard = EmitGuard{nullptr, 0, nullptr}) {
   const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : (jp.algo == TAD_ALGO_DROP ? 3 : (jp.lazy_sigma ? 4 : 2)));
   // DBSCAN job: only keys of the detector's work list (still in e->aux) can have rows
   if (kind == 4 && !jp.all_points &&
-      launch_emit_dbscan_list(e->stream, g, L, e->aux.p, static_cast<const uint32_t *>(e->n_anom.p), static_cast<const unsigned long long *>(e->off.p), out))
+      launch_emit_dbscan_list(e->stream, g, L, e->aux.p, static_cast<const uint32_t *>(e->n_anom.p), static_cast<const unsigned long long *>(e->off.p), out, guard))
     return;
   launch_emit(e->stream, g, L, kind, jp.all_points, jp.alpha, static_cast<const double *>(e->sigma.p),
               static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(kind == 3 ? e->key_mean.p : e->calc.p),
-              static_cast<const unsigned long long *>(e->off.p), out, rows, e->plan.ewma_emit, e->plan.ewma_emit_rows);
+              static_cast<const unsigned long long *>(e->off.p), out, rows, e->plan.ewma_emit, e->plan.ewma_emit_rows, guard);
 }
 
 int make_result(tad_engine *e, uint64_t rows, bool with_anomaly, tad_mem out_memory, ResultPriv **out, OutRows *dev_rows,
@@ -580,7 +603,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   if ((rc = stage_column(e, e->in_ts, cols->flow_start_s, n, cols->memory, &d_ts)) != TAD_OK) return rc;
   if ((rc = stage_column(e, e->in_val, cols->value, n, cols->memory, &d_val)) != TAD_OK) return rc;
 
-  if ((rc = ensure(e, e->counters, sizeof(DevCounters))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->counters, kTailBytes)) != TAD_OK) return rc;
   DevCounters *ctr = static_cast<DevCounters *>(e->counters.p);
 
   HIP_TRY(e, hipEventRecord(e->ev[0], s));
@@ -601,11 +624,23 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   // the estimate with 6 sigma of slack; a region that still turns out too small (keys arriving in bursts the sample missed)
   // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  tad_plan.histogram = 1 disables it.
   bool force_exact_hist = plan.histogram == 1;
+  // The one-synchronisation form.  A job normally synchronises with the host three times: for the lattice (pass A's partials), for
+  // the row count (the result block is sized from it) and at the end.  A job of the SAME SHAPE as the engine's previous one — rows,
+  // keys, algorithm, filters; device-resident in and out — is instead issued in one go with that job's lattice and a result block
+  // sized from that job's rows, while the device checks both: k_lattice_check derives the lattice from this job's pass A exactly as
+  // the host would, the emit kernels compare the row total with the block.  A miss (DEV_ERR_SPEC, or any other device error) throws
+  // the output away and the job runs again in the three-synchronisation form, which also refreshes the remembered shape.
+  const tad_engine::Spec &sp = e->spec;
+  bool spec_ok = depth == 0 && plan.one_sync != 1 && !points_mode && !stream && out_memory == TAD_MEM_DEVICE && cols->memory == TAD_MEM_DEVICE &&
+                 !jp.all_points && cols->n_buckets == 0 && (jp.algo == TAD_ALGO_EWMA || jp.algo == TAD_ALGO_DBSCAN) && sp.valid && sp.n == n &&
+                 sp.K == K && sp.has2 == has2 && sp.algo == (int)job->algo && sp.agg == (int)job->agg_flow && sp.op == (int)op_max && sp.flags == job->flags &&
+                 sp.start == job->start_time && sp.end == job->end_time;
+  if (spec_ok && sp.exact_hist) force_exact_hist = true;
   // retries: wrong hint -> derive (0 -> 1); sampled lattice too coarse / saw no live row -> exact (1 -> 2); overflow list
-  // full -> Stage 0 v1.  Each transition happens at most once, so 5 attempts cover every path.
-  for (int attempt = 0; attempt < 7; ++attempt) {
+  // full -> Stage 0 v1; a missed speculation -> the plain form.  Each transition happens at most once, so 8 attempts cover every path.
+  for (int attempt = 0; attempt < 8; ++attempt) {
     const bool hinted = lat_mode == 0;
-    HIP_TRY(e, hipMemsetAsync(ctr, 0, sizeof(DevCounters), s));
+    HIP_TRY(e, hipMemsetAsync(ctr, 0, kTailMoments, s));    // counters, row total, overflow-list count
     jp.settled = false;
     PartPlan pl{};
     bool v2 = !empty && !force_v1 && !force_v1_retry && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
@@ -631,7 +666,11 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       launch_meta(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, rf,
                   static_cast<MetaPartial *>(e->meta.p), meta_blocks);
     }
-    if (!hinted && !empty) {
+    const bool spec = spec_ok && v2 && lat_mode == 1 && !empty;
+    if (spec) {   // the remembered lattice, verified on the device against this job's own pass A
+      L = sp.L;
+      launch_lattice_check(s, static_cast<const MetaPartial *>(e->meta.p), meta_blocks, L, ctr);
+    } else if (!hinted && !empty) {
       HIP_TRY(e, hipMemcpyAsync(e->meta_host, e->meta.p, sizeof(MetaPartial) * meta_blocks, hipMemcpyDeviceToHost, s));
       HIP_TRY(e, hipStreamSynchronize(s));
       int64_t tmin = 0, tmax = 0, tref = 0;
@@ -772,9 +811,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       if ((rc = ensure(e, e->part_offs32, (size_t)pl.G * pl.nparts * 4)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->ovf, 16 + (size_t)kOverflowCap * sizeof(OverflowRec))) != TAD_OK) return rc;
-      unsigned long long *ovf_count = static_cast<unsigned long long *>(e->ovf.p);
+      unsigned long long *ovf_count = dev_ovf_count(e);     // in the job tail: zeroed with the counters, one fill per attempt
       OverflowRec *ovf = reinterpret_cast<OverflowRec *>(static_cast<unsigned char *>(e->ovf.p) + 16);
-      HIP_TRY(e, hipMemsetAsync(ovf_count, 0, 8, s));
       if ((rc = ensure_key_buffers(e, K)) != TAD_OK) return rc;
       if ((rc = ensure_rcp_table(e, L.nb)) != TAD_OK) return rc;
       uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
@@ -832,12 +870,10 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
                        static_cast<uint32_t *>(e->n_pts.p), static_cast<uint32_t *>(e->n_anom.p), ctr, static_cast<double *>(e->key_mean.p),
                        static_cast<double *>(e->key_m2.p));
       launch_moments(s, g.K, static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(e->key_mean.p),
-                     static_cast<const double *>(e->key_m2.p), static_cast<Moments *>(e->moments.p));
+                     static_cast<const double *>(e->key_m2.p), dev_moments(e));
       unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
-      launch_scan(s, static_cast<const uint32_t *>(e->n_pts.p), off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
-      HIP_TRY(e, hipMemcpyAsync(e->total_host, off + g.K, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-      HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
-      HIP_TRY(e, hipMemcpyAsync(e->moments_host, e->moments.p, kMomentBlocks * sizeof(Moments), hipMemcpyDeviceToHost, s));
+      launch_scan(s, static_cast<const uint32_t *>(e->n_pts.p), off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p), dev_total(e));
+      HIP_TRY(e, hipMemcpyAsync(e->tail_host, e->counters.p, kTailBytes, hipMemcpyDeviceToHost, s));
       HIP_TRY(e, hipStreamSynchronize(s));
       HIP_TRY(e, hipGetLastError());
       rows = *e->total_host;
@@ -846,17 +882,18 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       launch_stream(s, g, L, jp.alpha, jp.all_points, false, state_view(stream, stream->cur), state_view(stream, stream->cur ^ 1),
                     static_cast<uint32_t *>(e->n_anom.p), nullptr, OutRows{}, ctr);
       unsigned long long *off = static_cast<unsigned long long *>(e->off.p);
-      launch_scan(s, static_cast<const uint32_t *>(e->n_anom.p), off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p));
-      HIP_TRY(e, hipMemcpyAsync(e->total_host, off + g.K, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-      HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
+      launch_scan(s, static_cast<const uint32_t *>(e->n_anom.p), off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p), dev_total(e));
+      HIP_TRY(e, hipMemcpyAsync(e->tail_host, e->counters.p, kTailBytes, hipMemcpyDeviceToHost, s));
       HIP_TRY(e, hipStreamSynchronize(s));
       HIP_TRY(e, hipGetLastError());
       rows = *e->total_host;
       for (int b = 0; b < kMomentBlocks; ++b) e->moments_host[b] = Moments{0.0, 0.0, 0.0};
     } else {
-      if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) return rc;
+      if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done, spec)) != TAD_OK) return rc;
+      if (spec) rows = sp.rows + sp.rows / 8 + 4096;    // the CAPACITY of the result block until the tail arrives
     }
-    const DevCounters c = *e->ctr_host;
+    DevCounters c = *e->ctr_host;
+    if (spec) c = DevCounters{};                         // (not fetched yet: checked after the emit)
     if (c.err & DEV_ERR_KEY_RANGE)
       return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
     if (c.err & DEV_ERR_LATE_ROW)
@@ -955,7 +992,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       launch_stream(s, g, L, jp.alpha, jp.all_points, true, state_view(stream, stream->cur), state_view(stream, stream->cur ^ 1),
                     nullptr, static_cast<const unsigned long long *>(e->off.p), dev_rows, ctr);
     else if (rows)
-      emit_rows(e, g, L, jp, dev_rows, rows);
+      emit_rows(e, g, L, jp, dev_rows, spec ? sp.rows : rows, spec ? EmitGuard{dev_total(e), rows, ctr} : EmitGuard{nullptr, 0, nullptr});
     {
       const hipError_t er = hipEventRecord(e->ev[4], s);
       if (er != hipSuccess) {
@@ -965,9 +1002,21 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       }
     }
     if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
-    hipError_t le = hipStreamSynchronize(s);
+    hipError_t le = spec ? hipMemcpyAsync(e->tail_host, e->counters.p, kTailBytes, hipMemcpyDeviceToHost, s) : hipSuccess;   // the job's ONE round trip
+    if (le == hipSuccess) le = hipStreamSynchronize(s);
     if (le == hipSuccess) le = hipGetLastError();
     if (le != hipSuccess) { result_free_locked(e, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
+    if (spec) {
+      c = *e->ctr_host;
+      if (c.err != 0 || *e->total_host > rows) {   // the lattice or the capacity did not hold, or Stage 0 raised something: the plain form sorts it out
+        result_free_locked(e, &rp->pub);
+        e->spec.valid = false;
+        spec_ok = false;
+        continue;
+      }
+      rows = *e->total_host;
+      rp->pub.n_rows = rows;
+    }
 
     tad_stats &st = rp->pub.stats;
     st.rows_in = n;
@@ -1017,7 +1066,15 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     st.stage0_path = sparse ? 4 : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
     st.stage0_attempts = attempt + 1;
     st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
+    st.host_syncs = spec ? 1 : ((hinted || empty) ? 2 : 3);
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
+    // remember the shape for the next job (only what the device can re-verify: a lattice derived from pass A's sample, the v2 path)
+    if (depth == 0 && !points_mode && !stream && !jp.all_points) {
+      tad_engine::Spec &w = e->spec;
+      w.valid = v2 && !sparse && lat_mode == 1 && !force_v1_retry && !empty;
+      w.n = n; w.K = K; w.has2 = has2; w.algo = (int)job->algo; w.agg = (int)job->agg_flow; w.op = (int)op_max; w.flags = job->flags;
+      w.start = job->start_time; w.end = job->end_time; w.L = L; w.rows = rows; w.exact_hist = force_exact_hist && plan.histogram != 1;
+    }
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)
     if (depth == 0) e->done.store(4);
@@ -1033,7 +1090,7 @@ int sparse_points_direct(tad_engine *e, uint64_t n_rows_in, uint64_t rows_used, 
                          tad_points **points_out) {
   hipStream_t s = e->stream;
   int rc;
-  if ((rc = ensure(e, e->moments, kMomentBlocks * sizeof(Moments))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->counters, kTailBytes)) != TAD_OK) return rc;
   PointsPriv *pp = new (std::nothrow) PointsPriv();
   if (!pp) return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
   memset(pp, 0, sizeof *pp);
@@ -1043,9 +1100,8 @@ int sparse_points_direct(tad_engine *e, uint64_t n_rows_in, uint64_t rows_used, 
   unsigned char *d = static_cast<unsigned char *>(blk.base);
   launch_sparse_points_out(s, static_cast<const unsigned long long *>(e->sp_comp_a.p), static_cast<const unsigned long long *>(e->sp_val_a.p), P, L.t0,
                            reinterpret_cast<unsigned long long *>(d), reinterpret_cast<long long *>(d + P * 8),
-                           reinterpret_cast<unsigned long long *>(d + P * 16), static_cast<Moments *>(e->moments.p), ctr);
-  hipError_t hr = hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s);
-  if (hr == hipSuccess) hr = hipMemcpyAsync(e->moments_host, e->moments.p, kMomentBlocks * sizeof(Moments), hipMemcpyDeviceToHost, s);
+                           reinterpret_cast<unsigned long long *>(d + P * 16), dev_moments(e), ctr);
+  hipError_t hr = hipMemcpyAsync(e->tail_host, e->counters.p, kTailBytes, hipMemcpyDeviceToHost, s);
   if (hr == hipSuccess) hr = hipEventRecord(e->ev[7], s);
   void *h = nullptr;
   if (hr == hipSuccess && out_memory == TAD_MEM_HOST) {
@@ -1366,7 +1422,7 @@ int series_grid(tad_engine *e, const uint64_t *x, uint64_t n, Grid *g) {
   int rc;
   if ((rc = ensure(e, e->grid_val, (n ? n : 1) * 8)) != TAD_OK) return rc;
   if ((rc = ensure(e, e->grid_flag, n ? n : 1)) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->counters, sizeof(DevCounters))) != TAD_OK) return rc;
+  if ((rc = ensure(e, e->counters, kTailBytes)) != TAD_OK) return rc;
   if (n) {
     HIP_TRY(e, hipMemcpyAsync(e->grid_val.p, x, n * 8, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->grid_flag.p, FLAG_PRESENT, n, e->stream));

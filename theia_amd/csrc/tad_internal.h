@@ -30,7 +30,8 @@ struct Grid {
 };
 
 enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u, DEV_ERR_LATE_ROW = 8u,
-                  DEV_ERR_REGION_FULL = 16u };  // Stage 0 v2 with a SAMPLED histogram: a (workgroup, partition) region was sized too small
+                  DEV_ERR_REGION_FULL = 16u,   // Stage 0 v2 with a SAMPLED histogram: a (workgroup, partition) region was sized too small
+                  DEV_ERR_SPEC = 32u };        // the one-synchronisation job: the speculated lattice / result capacity did not hold (the job is redone)
 enum : uint8_t { FLAG_PRESENT = 1, FLAG_ANOMALY = 2 };
 
 // Per-block partial of the lattice-derivation pass.
@@ -57,6 +58,14 @@ struct DevCounters {
 struct RowFilter {
   int64_t start_time;  // 0 = unset
   int64_t end_time;    // 0 = unset
+};
+
+// The one-synchronisation job sizes the result block from the last job's row count before this job's count exists on the host:
+// the emit kernels read the total on the device and write nothing when it does not fit (cap == 0: no guard).
+struct EmitGuard {
+  const unsigned long long *total;
+  unsigned long long cap;
+  DevCounters *ctr;
 };
 
 struct OutRows {
@@ -147,8 +156,19 @@ __device__ __forceinline__ void walk_series(const Grid &g, uint64_t k, Step step
 static constexpr uint64_t kCoopMinT = 512, kCoopMaxK = 8192;   // used when T >= kCoopMinT and K <= kCoopMaxK (launchers: coop_shape)
 inline bool coop_shape(const Grid &g) { return g.T >= kCoopMinT && g.K <= kCoopMaxK; }
 
-template <typename Step>
-__device__ __forceinline__ void walk_series_coop(const Grid &g, uint64_t k, Step step) {
+// (v_readlane with a wavefront-uniform lane: __shfl would go through the LDS crossbar — ds_bpermute, ~100 clocks on the step's chain)
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned long long r = ((unsigned long long)readlane_u32((uint32_t)(b >> 32), l) << 32) | readlane_u32((uint32_t)b, l);
+  return __longlong_as_double((long long)r);
+}
+
+// block(c): once per 64-bucket block, before its steps (wavefront-uniform; per-lane values the steps then pick up by readlane_*);
+// step(t, flag, x, ord): x = the value as double (converted by the lane that loaded it), ord = ordinal of the point among the
+// present points of its block.  Only present buckets get a step call.
+template <typename Block, typename Step>
+__device__ __forceinline__ void walk_series_coop(const Grid &g, uint64_t k, Block block, Step step) {
   const uint64_t T = g.T;
   const unsigned lane = threadIdx.x & 63u;
   const uint64_t nblk = (T + 63) / 64;
@@ -165,10 +185,13 @@ __device__ __forceinline__ void walk_series_coop(const Grid &g, uint64_t k, Step
   for (uint64_t c = 0; c < nblk; ++c) {
     load(c + 2, f2, v2);
     const uint64_t t0 = c * 64;
+    const double x0 = (double)v0;                                            // every lane converts its own bucket
     const unsigned long long present = __ballot((f0 & FLAG_PRESENT) != 0);   // absent buckets are skipped without a step call
-    for (unsigned long long m = present; m; m &= m - 1) {
-      const int u = __ffsll((long long)m) - 1;                 // wavefront-uniform
-      step(t0 + (uint64_t)u, (uint8_t)__shfl(f0, u), __shfl(v0, u));
+    block(c);
+    int ord = 0;
+    for (unsigned long long m = present; m; m &= m - 1, ++ord) {
+      const int u = __ffsll((long long)m) - 1;                 // wavefront-uniform (scalar)
+      step(t0 + (uint64_t)u, (uint8_t)readlane_u32(f0, u), readlane_f64(x0, u), ord);
     }
     f0 = f1; v0 = v1;
     f1 = f2; v1 = v2;
@@ -198,16 +221,17 @@ static constexpr int kMomentBlocks = 128;
 void launch_moments(hipStream_t s, uint64_t K, const uint32_t *n_pts, const double *key_mean,
                     const double *key_m2, Moments *partials, DevCounters *ctr = nullptr);
 void launch_count_flags(hipStream_t s, Grid g, bool all_points, uint32_t *n_anom);
-// exclusive scan of cnt[K] into off[K], total in off[K]
+// exclusive scan of cnt[K] into off[K], total in off[K] (and in *total_copy, if given)
 void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K,
-                 unsigned long long *scratch);
+                 unsigned long long *scratch, unsigned long long *total_copy = nullptr);
 size_t scan_scratch_elems(uint64_t K);
 // kind: 0 EWMA (recompute), 1 flags + calc array, 2 flags with calc = 0, 3 flags with calc = per-key value calc[k],
 // 4 = 2 with the stddev column computed here (Spark's streaming update over the key's series) for the keys that have rows
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
                  const unsigned long long *off, OutRows out, uint64_t rows_hint = 0,   // rows_hint: off[K] if the caller knows it
-                 int ewma_emit = 0, uint32_t ewma_emit_rows = 0);   // tad_plan: 1 = lane-per-key k_emit for the EWMA job; LDS rows per wavefront of the staged emit
+                 int ewma_emit = 0, uint32_t ewma_emit_rows = 0,   // tad_plan: 1 = lane-per-key k_emit for the EWMA job; LDS rows per wavefront of the staged emit
+                 EmitGuard guard = EmitGuard{nullptr, 0, nullptr});
 void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long long *off, unsigned long long *out_key,
                         long long *out_t, unsigned long long *out_val);
 // streaming EWMA: per-key running state (tad_state); k_stream continues the recurrences over the new grid
@@ -254,7 +278,7 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
 // DBSCAN job (statistics from the scan, sigma computed at emit): the rows from the work list launch_dbscan left in `scratch`,
 // one wavefront per listed key.  false: not applicable (series longer than a wavefront's registers hold) -> launch_emit(kind 4)
 bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scratch, const uint32_t *n_anom, const unsigned long long *off,
-                             OutRows out);
+                             OutRows out, EmitGuard guard = EmitGuard{nullptr, 0, nullptr});
 
 // drop detector (tad_drop.hip): sigma / n_pts / key_mean / key_m2 / counters + FLAG_ANOMALY; ws = K * T doubles
 void launch_drop(hipStream_t s, Grid g, double n_sigma, int min_samples, double *ws, double *sigma, uint32_t *n_pts,
@@ -298,6 +322,8 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
 bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, uint64_t n, uint64_t K, RowFilter f, const PartPlan &pl,
                       MetaPartial *partials, uint32_t *binhist, DevCounters *ctr, bool sample_hist);
+// the speculated lattice against pass A's partials, on the device (DEV_ERR_SPEC when they differ)
+void launch_lattice_check(hipStream_t s, const MetaPartial *partials, int n_partials, Lattice L, DevCounters *ctr);
 // offs32[G][nparts] (exclusive per-workgroup prefix inside each partition), total[nparts], part_start[nparts + 1]
 // sampled: the histogram is a sample -> region capacities (estimate + 6 sigma + margin); partials carry the sampling ratios
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,

@@ -278,7 +278,23 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, cons
         m2 = m2 + d * (d - dn);
       }
     };
-    if (COOP) walk_series_coop(g, k, sigma_step); else walk_series(g, k, sigma_step);
+    if (COOP) {
+      // the reciprocals of a block's 64 possible counts, one IEEE division per lane and block (= RN(1 / count), what div_by_count
+      // needs), picked up by readlane: the step itself is 5 FMAs instead of a division on the one wavefront's issue-bound chain
+      double rl = 0.0;
+      walk_series_coop(g, k,
+                       [&](uint64_t) { rl = 1.0 / (double)(n + 1u + (threadIdx.x & 63u)); },
+                       [&](uint64_t, uint8_t, double x, int ord) {
+                         cnt = cnt + 1.0;
+                         n++;
+                         const double d = x - avg;
+                         const double dn = div_by_count(d, cnt, readlane_f64(rl, ord));
+                         avg = avg + dn;
+                         m2 = m2 + d * (d - dn);
+                       });
+    } else {
+      walk_series(g, k, sigma_step);
+    }
     const bool has_sigma = n >= 2;
     const double sg = has_sigma ? sqrt(m2 / (cnt - 1.0)) : 0.0;
     if (writer) {
@@ -300,7 +316,11 @@ __global__ __launch_bounds__(kBlock) void k_key_sigma(Grid g, double alpha, cons
             a += fabs(x - e) > sg ? 1u : 0u;
           }
         };
-        if (COOP) walk_series_coop(g, k, ewma_step); else walk_series(g, k, ewma_step);
+        if (COOP) walk_series_coop(g, k, [](uint64_t) {}, [&](uint64_t, uint8_t, double x, int) {
+                    e = one_minus * e + alpha * x;
+                    a += fabs(x - e) > sg ? 1u : 0u;
+                  });
+        else walk_series(g, k, ewma_step);
       }
       if (writer) n_anom[k] = a;
     }
@@ -464,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t *__restri
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan_top(unsigned long long *bsum, uint64_t nb,
-                                                     unsigned long long *total_out) {
+                                                     unsigned long long *total_out, unsigned long long *total_copy) {
   unsigned long long carry = 0;
   for (uint64_t base = 0; base < nb; base += kBlock) {
     const uint64_t i = base + threadIdx.x;
@@ -474,7 +494,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_top(unsigned long long *bsum, u
     if (i < nb) bsum[i] = carry + ex;
     carry += tot;
   }
-  if (threadIdx.x == 0) *total_out = carry;
+  if (threadIdx.x == 0) {
+    *total_out = carry;
+    if (total_copy != nullptr) *total_copy = carry;   // the job tail (one device-to-host copy per job)
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restrict__ cnt, uint64_t K,
@@ -498,11 +521,15 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restric
 size_t scan_scratch_elems(uint64_t K) { return (size_t)((K + kScanTile - 1) / kScanTile) + 1; }
 
 void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K,
-                 unsigned long long *scratch) {
-  if (K == 0) { hipMemsetAsync(off, 0, sizeof(unsigned long long), s); return; }
+                 unsigned long long *scratch, unsigned long long *total_copy) {
+  if (K == 0) {
+    hipMemsetAsync(off, 0, sizeof(unsigned long long), s);
+    if (total_copy != nullptr) hipMemsetAsync(total_copy, 0, sizeof(unsigned long long), s);
+    return;
+  }
   const uint64_t nb = (K + kScanTile - 1) / kScanTile;
   hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(kBlock), 0, s, cnt, K, scratch);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, scratch, nb, off + K);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, scratch, nb, off + K, total_copy);
   hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kBlock), 0, s, cnt, K, scratch, off);
 }
 
@@ -513,15 +540,23 @@ void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, ui
 // KIND 2: verdict bits, algoCalc = 0.0 (DBSCAN placeholder, :312-322).
 // ------------------------------------------------------------------------------------------------
 // COOP: one wavefront per key (walk_series_coop); all lanes run the recurrences, lane 0 stores the rows.
+// the result block was sized before the row count was known on the host: write nothing when the rows do not fit (workgroup-uniform)
+__device__ __forceinline__ bool emit_blocked(const EmitGuard &guard, bool reporter) {
+  if (guard.cap == 0 || *guard.total <= guard.cap) return false;
+  if (reporter) atomicOr(&guard.ctr->err, DEV_ERR_SPEC);
+  return true;
+}
+
 template <int KIND, bool ALL, bool COOP = false>
 __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha,
                                                  const double *__restrict__ sigma,
                                                  const uint32_t *__restrict__ n_pts,
                                                  const double *__restrict__ calc,
-                                                 const unsigned long long *__restrict__ off, OutRows out) {
+                                                 const unsigned long long *__restrict__ off, OutRows out, EmitGuard guard) {
   const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint64_t k = COOP ? gtid >> 6 : gtid;
   const bool writer = !COOP || (threadIdx.x & 63) == 0;
+  if (emit_blocked(guard, gtid == 0)) return;
   if (k >= g.K) return;
   unsigned long long pos = off[k];
   const unsigned long long end = off[k + 1];
@@ -548,9 +583,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
     if (!LAZY) out.stddev[at] = sg;
     if (ALL) out.anomaly[at] = verdict ? 1 : 0;
   };
-  auto step = [&](uint64_t t, uint8_t fl, unsigned long long raw) {
-    if (!(fl & FLAG_PRESENT)) return;
-    const double x = (double)raw;
+  auto point = [&](uint64_t t, uint8_t fl, double x) {
     if (LAZY) {   // Spark CentralMomentAgg, as k_key_sigma (an IEEE division = the bits of div_by_count)
       s_cnt = s_cnt + 1.0;
       const double d = x - s_avg;
@@ -600,7 +633,8 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
       }
     }
   };
-  if (COOP) walk_series_coop(g, k, step); else walk_series(g, k, step);
+  if (COOP) walk_series_coop(g, k, [](uint64_t) {}, [&](uint64_t t, uint8_t fl, double x, int) { point(t, fl, x); });
+  else walk_series(g, k, [&](uint64_t t, uint8_t fl, unsigned long long raw) { if (fl & FLAG_PRESENT) point(t, fl, (double)raw); });
 #pragma unroll
   for (int i = 0; i < 3; ++i)   // tail of the segment: fewer than four buffered rows
     if (i < nb) write_row(pos + i, bt[i], bx[i], ba[i], ALL && bv[i] != 0);
@@ -623,8 +657,9 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
 static constexpr int kStageMarkTBits = 26;   // marker = lane << 26 | t
 __global__ __launch_bounds__(64) void k_emit_staged(Grid g, Lattice L, double alpha, const double *__restrict__ sigma,
                                                     const uint32_t *__restrict__ n_pts,
-                                                    const unsigned long long *__restrict__ off, OutRows out, uint32_t cap) {
+                                                    const unsigned long long *__restrict__ off, OutRows out, uint32_t cap, EmitGuard guard) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_stage[];
+  if (emit_blocked(guard, blockIdx.x == 0 && threadIdx.x == 0)) return;
   double *s_e = reinterpret_cast<double *>(smem_stage);                       // [cap]
   double *s_sg = s_e + cap;                                                   // [64]
   uint32_t *s_m = reinterpret_cast<uint32_t *>(s_sg + 64);                    // [cap]
@@ -698,12 +733,12 @@ static uint32_t emit_stage_rows(uint64_t K, uint64_t rows_hint, int ewma_emit, u
 
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
-                 const unsigned long long *off, OutRows out, uint64_t rows_hint, int ewma_emit, uint32_t ewma_emit_rows) {
+                 const unsigned long long *off, OutRows out, uint64_t rows_hint, int ewma_emit, uint32_t ewma_emit_rows, EmitGuard guard) {
   if (g.K == 0) return;
   if (coop_shape(g)) {   // long series on few keys: a wavefront per key (no staged variant: the rows of a key are written by one lane in time order)
     const int cblocks = (int)((g.K * 64 + kBlock - 1) / kBlock);
 #define TAD_LAUNCH_EMIT_C(KIND, ALL) \
-  hipLaunchKernelGGL((k_emit<KIND, ALL, true>), dim3(cblocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out)
+  hipLaunchKernelGGL((k_emit<KIND, ALL, true>), dim3(cblocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out, guard)
     if (all_points) {
       if (kind == 0) TAD_LAUNCH_EMIT_C(0, true); else if (kind == 1) TAD_LAUNCH_EMIT_C(1, true); else if (kind == 3) TAD_LAUNCH_EMIT_C(3, true); else TAD_LAUNCH_EMIT_C(2, true);
     } else {
@@ -716,13 +751,13 @@ void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, 
   if (kind == 0 && !all_points && g.T < (1ull << kStageMarkTBits)) {
     if (const uint32_t cap = emit_stage_rows(g.K, rows_hint, ewma_emit, ewma_emit_rows)) {
       const unsigned blocks64 = (unsigned)((g.K + 63) / 64);
-      hipLaunchKernelGGL(k_emit_staged, dim3(blocks64), dim3(64), (size_t)cap * 12 + 64 * 8, s, g, lat, alpha, sigma, n_pts, off, out, cap);
+      hipLaunchKernelGGL(k_emit_staged, dim3(blocks64), dim3(64), (size_t)cap * 12 + 64 * 8, s, g, lat, alpha, sigma, n_pts, off, out, cap, guard);
       return;
     }
   }
   const int blocks = (int)((g.K + kBlock - 1) / kBlock);
 #define TAD_LAUNCH_EMIT(KIND, ALL) \
-  hipLaunchKernelGGL((k_emit<KIND, ALL>), dim3(blocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out)
+  hipLaunchKernelGGL((k_emit<KIND, ALL>), dim3(blocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out, guard)
   if (all_points) {
     if (kind == 0) TAD_LAUNCH_EMIT(0, true); else if (kind == 1) TAD_LAUNCH_EMIT(1, true); else if (kind == 3) TAD_LAUNCH_EMIT(3, true); else TAD_LAUNCH_EMIT(2, true);
   } else {

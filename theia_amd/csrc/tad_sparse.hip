@@ -24,16 +24,18 @@ __global__ __launch_bounds__(kSpBlock) void k_sparse_keys(const uint64_t *__rest
                                                          const uint64_t *__restrict__ value, uint64_t n, uint64_t K, RowFilter f, int64_t t0,
                                                          uint64_t span, unsigned long long *__restrict__ comp, unsigned long long *__restrict__ vals,
                                                          DevCounters *ctr) {
-  const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
-  uint32_t err = 0, used = 0;
-  if (i < n) {
+  uint32_t err = 0;
+  unsigned long long used = 0;
+  const int nk = key2 != nullptr ? 2 : 1;
+  // grid-stride: the job counter gets ONE atomic per workgroup — one per wavefront of a 1e8-row table is 1.5e6 atomics on one address,
+  // which serialise at ~12 ns each (the kernel took 18.8 ms for 4 GB of traffic, profiles/r4_v2_sparse_scale_kernel_stats.csv)
+  for (uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kSpBlock) {
     const int64_t te = t_end[i];
     bool kept = true;
     if (f.end_time != 0 && !(te < f.end_time)) kept = false;                                       // anomaly_detection.py:584-586
     if (f.start_time != 0 && t_start != nullptr && !(t_start[i] >= f.start_time)) kept = false;    // :581-583
     const uint64_t dt = (uint64_t)te - (uint64_t)t0;
     const uint64_t v = value[i];
-    const int nk = key2 != nullptr ? 2 : 1;
     for (int h = 0; h < nk; ++h) {
       const uint64_t k = h == 0 ? key[i] : key2[i];
       unsigned long long c = (unsigned long long)K << 32;
@@ -46,38 +48,50 @@ __global__ __launch_bounds__(kSpBlock) void k_sparse_keys(const uint64_t *__rest
       vals[i * nk + h] = v;
     }
   }
-  unsigned long long u = used;
-  for (int d = 32; d >= 1; d >>= 1) { u += __shfl_down(u, d); err |= __shfl_down(err, d); }
-  if ((threadIdx.x & 63) == 0) {
-    if (u) atomicAdd(&ctr->rows_used, u);
+  for (int d = 32; d >= 1; d >>= 1) { used += __shfl_down(used, d); err |= __shfl_down(err, d); }
+  __shared__ unsigned long long s_used[kSpBlock / 64];
+  __shared__ uint32_t s_err[kSpBlock / 64];
+  if ((threadIdx.x & 63) == 0) { s_used[threadIdx.x >> 6] = used; s_err[threadIdx.x >> 6] = err; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kSpBlock / 64; ++w) { used += s_used[w]; err |= s_err[w]; }
+    if (used) atomicAdd(&ctr->rows_used, used);
     if (err) atomicOr(&ctr->err, err);
   }
 }
 
 // first[k] = index of the key's first point in the sorted unique list
-// (P_dev: the number of points, still on the device — the grid covers the slots, an upper bound — so that the host fetches the
-// point count and the longest series with ONE round trip)
+// (P_dev: the number of points, still on the device, so that the host fetches the point count and the longest series with ONE
+// round trip; grid-stride loops over a bounded grid)
 __global__ __launch_bounds__(kSpBlock) void k_sparse_first(const unsigned long long *__restrict__ ucomp, const unsigned long long *__restrict__ P_dev,
                                                           uint32_t *__restrict__ first) {
   const uint64_t P = *P_dev;
-  const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
-  if (i >= P) return;
-  const uint32_t k = (uint32_t)(ucomp[i] >> 32);
-  if (i == 0 || (uint32_t)(ucomp[i - 1] >> 32) != k) first[k] = (uint32_t)i;
+  for (uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x; i < P; i += (uint64_t)gridDim.x * kSpBlock) {
+    const uint32_t k = (uint32_t)(ucomp[i] >> 32);
+    if (i == 0 || (uint32_t)(ucomp[i - 1] >> 32) != k) first[k] = (uint32_t)i;
+  }
 }
 
-// longest series
+// longest series (one atomic per workgroup: one per wavefront made this kernel 6 ms at 3.3e7 points)
 __global__ __launch_bounds__(kSpBlock) void k_sparse_tmax(const unsigned long long *__restrict__ ucomp, const unsigned long long *__restrict__ P_dev,
                                                          const uint32_t *__restrict__ first, unsigned int *__restrict__ tmax) {
   const uint64_t P = *P_dev;
-  const uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x;
   unsigned int n = 0;
-  if (i < P) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kSpBlock + threadIdx.x; i < P; i += (uint64_t)gridDim.x * kSpBlock) {
     const uint32_t k = (uint32_t)(ucomp[i] >> 32);
-    if (i + 1 == P || (uint32_t)(ucomp[i + 1] >> 32) != k) n = (unsigned int)(i - first[k] + 1);
+    if (i + 1 == P || (uint32_t)(ucomp[i + 1] >> 32) != k) {
+      const unsigned int len = (unsigned int)(i - first[k] + 1);
+      n = len > n ? len : n;
+    }
   }
   for (int d = 32; d >= 1; d >>= 1) { const unsigned int o = __shfl_down(n, d); n = o > n ? o : n; }
-  if ((threadIdx.x & 63) == 0 && n) atomicMax(tmax, n);
+  __shared__ unsigned int s_n[kSpBlock / 64];
+  if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kSpBlock / 64; ++w) n = s_n[w] > n ? s_n[w] : n;
+    if (n) atomicMax(tmax, n);
+  }
 }
 
 // point i -> cell (rank in its key's series, key) of the rank grid
@@ -494,7 +508,8 @@ int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2
   // an odd number of moves (the passes + the reduction) ends in the a buffers: start in a when the number of passes is odd
   unsigned long long *ca = (pl.np & 1) ? comp_a : comp_b, *va = (pl.np & 1) ? val_a : val_b;
   unsigned long long *cb = (pl.np & 1) ? comp_b : comp_a, *vb = (pl.np & 1) ? val_b : val_a;
-  hipLaunchKernelGGL(k_sparse_keys, dim3((unsigned)((n + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, key, key2, t_end, t_start, value, n, K,
+  const uint64_t kb = (n + kSpBlock - 1) / kSpBlock;
+  hipLaunchKernelGGL(k_sparse_keys, dim3((unsigned)(kb < 8192 ? kb : 8192)), dim3(kSpBlock), 0, s, key, key2, t_end, t_start, value, n, K,
                      f, t0, span, ca, va, ctr);
   const size_t lds = (size_t)kRsTile * 16 + kRsRadix * 8 + (size_t)kRsWaves * kRsRadix * 4 + kRsRadix * 4 + 64;
   allow_big_lds(reinterpret_cast<const void *>(k_rs_scatter), lds);
@@ -522,7 +537,8 @@ int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2
 
 void launch_sparse_tmax(hipStream_t s, const unsigned long long *ucomp, uint64_t slots, const unsigned long long *P_dev, uint32_t *first, unsigned int *tmax) {
   if (slots == 0) return;
-  const unsigned blocks = (unsigned)((slots + kSpBlock - 1) / kSpBlock);
+  const uint64_t need = (slots + kSpBlock - 1) / kSpBlock;
+  const unsigned blocks = (unsigned)(need < 8192 ? need : 8192);
   hipLaunchKernelGGL(k_sparse_first, dim3(blocks), dim3(kSpBlock), 0, s, ucomp, P_dev, first);
   hipLaunchKernelGGL(k_sparse_tmax, dim3(blocks), dim3(kSpBlock), 0, s, ucomp, P_dev, first, tmax);
 }

@@ -287,6 +287,49 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
 }
 
 // ------------------------------------------------------------------------------------------------
+// The one-synchronisation job (tad_capi.cpp): the host issues the whole job with the lattice of the LAST job of the same shape
+// instead of waiting for pass A's partials; this kernel derives the lattice from the partials exactly as the host would (min,
+// max, gcd of the sampled differences, gcd with the span and the reference offset) and raises DEV_ERR_SPEC when it is not the
+// speculated one — the host then discards the job's output and redoes it with the host-derived lattice.  (Every row is still
+// checked against the lattice by pass B: a speculated lattice that merely CONTAINS the rows would give the same anomaly rows,
+// but not the same tad_stats; equality with the derivation keeps the two paths indistinguishable.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lattice_check(const MetaPartial *__restrict__ partials, int n_partials, Lattice L, DevCounters *ctr) {
+  PMeta m{0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < n_partials; b += 256) {
+    const MetaPartial p = partials[b];
+    PMeta o{p.tmin, p.tmax, p.tref, p.g, p.used};
+    m = pmeta_merge(m, o);
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    PMeta o;
+    o.tmin = __shfl_down((long long)m.tmin, d);
+    o.tmax = __shfl_down((long long)m.tmax, d);
+    o.tref = __shfl_down((long long)m.tref, d);
+    o.g = __shfl_down((unsigned long long)m.g, d);
+    o.used = __shfl_down((unsigned long long)m.used, d);
+    m = pmeta_merge(m, o);
+  }
+  __shared__ PMeta s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int w = 1; w < 4; ++w) m = pmeta_merge(m, s_m[w]);
+  bool same = m.used != 0;
+  if (same) {
+    const uint64_t span = (uint64_t)m.tmax - (uint64_t)m.tmin;
+    uint64_t step = p_gcd_u64(p_gcd_u64(m.g, span), (uint64_t)m.tref - (uint64_t)m.tmin);
+    if (step == 0) step = 1;
+    same = L.t0 == m.tmin && (uint64_t)L.step == step && L.nb == span / step + 1;
+  }
+  if (!same) atomicOr(&ctr->err, DEV_ERR_SPEC);
+}
+
+void launch_lattice_check(hipStream_t s, const MetaPartial *partials, int n_partials, Lattice L, DevCounters *ctr) {
+  hipLaunchKernelGGL(k_lattice_check, dim3(1), dim3(256), 0, s, partials, n_partials, L, ctr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // offsets: cnt[g][p] (row reduce of the bins) -> column-wise exclusive prefix over g -> part_start[p]
 // ------------------------------------------------------------------------------------------------
 // Capacity of a (workgroup, partition) region from a SAMPLED count s at sampling ratio 1 / scale: the estimate s * scale
@@ -365,6 +408,22 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scan1(const uint32_t *__r
   for (uint32_t j = 0; j < per; ++j)
     if (b0 + j < nparts) { part_start[b0 + j] = run; run += total[b0 + j]; }
   if (threadIdx.x == 0) part_start[nparts] = tot;
+}
+
+// rows_used / error bits of a workgroup: ONE atomic per workgroup.  One per wavefront was 4096 atomics on one address at the very
+// end of pass B, when all workgroups finish together — contended atomics serialise at ~10 ns each.
+__device__ __forceinline__ void block_count_rows(uint32_t used, uint32_t err, DevCounters *ctr) {
+  __shared__ unsigned long long s_u[kPartThreads / 64];
+  __shared__ uint32_t s_e[kPartThreads / 64];
+  unsigned long long u = used;
+  for (int d = 32; d >= 1; d >>= 1) { u += __shfl_down(u, d); err |= __shfl_down(err, d); }
+  if ((threadIdx.x & 63) == 0) { s_u[threadIdx.x >> 6] = u; s_e[threadIdx.x >> 6] = err; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kPartThreads / 64; ++w) { u += s_u[w]; err |= s_e[w]; }
+    if (u) atomicAdd(&ctr->rows_used, u);
+    if (err) atomicOr(&ctr->err, err);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -619,12 +678,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) { fo[2 * p] = gcur[p]; fo[2 * p + 1] = gend[p]; }
     if (s_full) err |= DEV_ERR_REGION_FULL;
   }
-  unsigned long long u = used;
-  for (int d = 32; d >= 1; d >>= 1) { u += __shfl_down(u, d); err |= __shfl_down(err, d); }
-  if ((threadIdx.x & 63) == 0) {
-    if (u) atomicAdd(&A.ctr->rows_used, u);
-    if (err) atomicOr(&A.ctr->err, err);
-  }
+  block_count_rows(used, err, A.ctr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -824,12 +878,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       for (g += c; g < e; ++g) A.recs[g] = ~0ull;
     }
   }
-  unsigned long long u = used;
-  for (int d = 32; d >= 1; d >>= 1) { u += __shfl_down(u, d); err |= __shfl_down(err, d); }
-  if ((threadIdx.x & 63) == 0) {
-    if (u) atomicAdd(&A.ctr->rows_used, u);
-    if (err) atomicOr(&A.ctr->err, err);
-  }
+  block_count_rows(used, err, A.ctr);
 }
 
 // ------------------------------------------------------------------------------------------------

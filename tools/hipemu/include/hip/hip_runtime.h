@@ -116,6 +116,9 @@ static inline unsigned long long __umul64hi(unsigned long long a, unsigned long 
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 // compiler-level wavefront barrier on the device (no instruction); here the lanes really have to meet
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::wave_op(hipemu::OP_BALLOT, 1u, 0, reinterpret_cast<uintptr_t>(__FILE__) * 1000003u + (unsigned)__LINE__))
+#define __builtin_amdgcn_readlane(v, l) __shfl((int)(v), (int)(l))
+static inline long long __double_as_longlong(double v) { long long r; __builtin_memcpy(&r, &v, 8); return r; }
+static inline double __longlong_as_double(long long v) { double r; __builtin_memcpy(&r, &v, 8); return r; }
 #define __builtin_amdgcn_frexp_mant(x) hipemu::frexp_mant(x)
 #define __builtin_amdgcn_frexp_exp(x) hipemu::frexp_exp(x)
 
