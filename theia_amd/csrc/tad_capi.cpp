@@ -76,11 +76,12 @@ struct tad_engine {
 // per-key running state of the streaming EWMA detector: two copies (the count pass writes the candidate next state,
 // it becomes current only when the batch succeeds)
 namespace {
-constexpr size_t kTailCtr = 0, kTailTotal = 64, kTailOvfCount = 72, kTailMoments = 128;
+constexpr size_t kTailCtr = 0, kTailTotal = 64, kTailOvfCount = 72, kTailTickets = 80, kTailMoments = 128;   // tickets: two u32 (k_part_offsets, k_tile_aggregate)
 constexpr size_t kTailBytes = kTailMoments + sizeof(Moments) * kMomentBlocks;
 inline DevCounters *dev_ctr(tad_engine *e) { return static_cast<DevCounters *>(e->counters.p); }
 inline unsigned long long *dev_total(tad_engine *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailTotal); }
 inline unsigned long long *dev_ovf_count(tad_engine *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailOvfCount); }
+inline unsigned int *dev_ticket(tad_engine *e, int i) { return reinterpret_cast<unsigned int *>(static_cast<unsigned char *>(e->counters.p) + kTailTickets) + i; }
 inline Moments *dev_moments(tad_engine *e) { return reinterpret_cast<Moments *>(static_cast<unsigned char *>(e->counters.p) + kTailMoments); }
 }  // namespace
 
@@ -817,15 +818,15 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       if ((rc = ensure_rcp_table(e, L.nb)) != TAD_OK) return rc;
       uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
       unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
+      if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
       launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start,
-                          hist_sampled, static_cast<const MetaPartial *>(e->meta.p), n);
+                          hist_sampled, static_cast<const MetaPartial *>(e->meta.p), n, slots, e->slices.p, g, dev_ticket(e, 0));
       HIP_TRY(e, hipEventRecord(e->ev[2], s));
       launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
                        (const uint64_t *)d_val, n, K, rf, L, pl, offs32, part_start, e->recs.p, ovf, ovf_count, kOverflowCap, ctr, fin);
       HIP_TRY(e, hipEventRecord(e->ev[3], s));
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
-      if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
       // DBSCAN job: pass C in settle mode — key rounds, the detector's per-key pass on the LDS tile, grid columns of unsettled keys only
       SettleArgs settle{{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, 0.0, 0, 0};
       jp.settled = false;
@@ -843,7 +844,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         jp.settled = true;
       }
       launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap,
-                            hist_sampled ? offs32 : nullptr, fin, settle);
+                            hist_sampled ? offs32 : nullptr, fin, settle, dev_ticket(e, 1));
     } else {
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));

@@ -326,8 +326,11 @@ bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 void launch_lattice_check(hipStream_t s, const MetaPartial *partials, int n_partials, Lattice L, DevCounters *ctr);
 // offs32[G][nparts] (exclusive per-workgroup prefix inside each partition), total[nparts], part_start[nparts + 1]
 // sampled: the histogram is a sample -> region capacities (estimate + 6 sigma + margin); partials carry the sampling ratios
+// ONE launch (k_part_offsets): also builds the slice table of pass C in slice_mem (slice_table_bytes(slots, pl)) and zeroes the grid
+// tile of every partition that will be split into several slices; ticket: a zeroed word (the job tail)
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
-                         unsigned long long *part_start, bool sampled = false, const MetaPartial *partials = nullptr, uint64_t n = 0);
+                         unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n, uint64_t slots, void *slice_mem,
+                         Grid g, unsigned int *ticket);
 // upper bound of the record slots pass B may be given when the regions are sized from a sampled histogram
 uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl);
 // fin != NULL (sampled regions): no fillers; fin[(g * nparts + p) * 2 + {0, 1}] = end of the records written upwards /
@@ -341,8 +344,8 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 size_t slice_table_bytes(uint64_t slots, const PartPlan &pl);
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
-                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32 = nullptr,
-                           const uint32_t *fin = nullptr, SettleArgs settle = SettleArgs{{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, 0.0, 0, 0});
+                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, SettleArgs settle,
+                           unsigned int *ticket);   // ticket: a zeroed word; the workgroup that finishes last folds the overflow list into the grid
 // whether pass C can run in settle mode for this plan (whole series of >= 8 keys fit an LDS tile; same number of rounds or fewer than 2x)
 bool part_plan_settle(uint64_t T, PartPlan *pl);
 

@@ -341,73 +341,138 @@ __device__ __forceinline__ uint32_t sampled_capacity(uint32_t s, double scale) {
   return (uint32_t)(est + 6.0 * sqrt(est * scale) + 8.0 * scale + 16.0);
 }
 
-__global__ __launch_bounds__(256) void k_part_rows(const uint32_t *__restrict__ binhist, uint32_t nbins,
-                                                   uint32_t bins_per_part, uint32_t nparts, uint32_t *__restrict__ cnt,
-                                                   uint32_t round_mask, const MetaPartial *__restrict__ partials, uint64_t n, uint64_t chunk) {
-  const uint32_t *row = binhist + (size_t)blockIdx.x * nbins;
-  uint32_t *out = cnt + (size_t)blockIdx.x * nparts;
-  double scale = 0.0;   // 0: exact histogram
-  if (partials != nullptr) {
-    const uint64_t lo = (uint64_t)blockIdx.x * chunk;
-    const uint64_t rows = lo < n ? (lo + chunk < n ? chunk : n - lo) : 0;
-    const uint64_t seen = partials[blockIdx.x].seen;
-    scale = seen ? (double)rows / (double)seen : 1.0;
-    if (scale < 1.0) scale = 1.0;
-  }
-  for (uint32_t p = threadIdx.x; p < nparts; p += 256) {
-    const uint32_t b0 = p * bins_per_part;
-    const uint32_t b1 = b0 + bins_per_part < nbins ? b0 + bins_per_part : nbins;
-    uint32_t s = 0;
-    for (uint32_t b = b0; b < b1; ++b) s += row[b];
-    if (scale != 0.0) s = sampled_capacity(s, scale);
-    out[p] = (s + round_mask) & ~round_mask;  // write-combining pass B: every (workgroup, partition) region is whole sectors
-  }
-}
+// Work unit of pass C = a SLICE of at most slice_len record slots of one partition (k_tile_aggregate).
+struct SliceTable {
+  uint32_t *slice_part;          // [max_slices] partition of each slice
+  uint32_t *slice_first;         // [nparts] index of the partition's first slice
+  uint32_t *n_slices;            // [1]
+};
 
-// one thread per partition: offs32[g][p] = sum_{g' < g} cnt[g'][p] (in place), total[p] = column sum
-__global__ __launch_bounds__(256) void k_part_colscan(uint32_t *__restrict__ cnt, int G, uint32_t nparts,
-                                                      uint32_t *__restrict__ total) {
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= nparts) return;
-  uint32_t run = 0;
-  int g = 0;
-  for (; g + 8 <= G; g += 8) {
-    uint32_t c[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) c[u] = cnt[(size_t)(g + u) * nparts + p];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { cnt[(size_t)(g + u) * nparts + p] = run; run += c[u]; }
-  }
-  for (; g < G; ++g) { const uint32_t c = cnt[(size_t)g * nparts + p]; cnt[(size_t)g * nparts + p] = run; run += c; }
-  total[p] = run;  // v2 requires n_rows * 2 < 2^32 (checked on the host)
-}
+struct OffsetsArgs {
+  const uint32_t *binhist;       // [G][nbins] pass A's per-workgroup histogram of rows per key bin
+  uint32_t nbins, bins_per_part, nparts, round_mask;
+  int G;
+  const MetaPartial *partials;   // sampled histogram: the sampling ratios (seen rows per workgroup); NULL = exact histogram
+  uint64_t n, chunk;
+  uint32_t *offs32;              // out [G][nparts]: exclusive prefix of workgroup g inside partition p
+  uint32_t *total;               // out [nparts]
+  unsigned long long *part_start;  // out [nparts + 1]
+  SliceTable st;                 // out
+  uint32_t slice_len;
+  Grid g;                        // the grid tile of a partition that will be split into several slices is zeroed here
+  int shift_part;
+  unsigned int *ticket;          // zeroed per job (the job tail)
+};
 
-// single workgroup: exclusive scan of total[0..nparts) into part_start[0..nparts]
-__global__ __launch_bounds__(kPartThreads) void k_part_scan1(const uint32_t *__restrict__ total, uint32_t nparts,
-                                                             unsigned long long *__restrict__ part_start) {
-  __shared__ unsigned long long s_wave[kPartThreads / 64];
-  const uint32_t per = (nparts + kPartThreads - 1) / kPartThreads;
-  const uint32_t b0 = threadIdx.x * per;
-  unsigned long long sum = 0;
-  for (uint32_t j = 0; j < per; ++j)
-    if (b0 + j < nparts) sum += total[b0 + j];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long incl = sum;
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned long long y = __shfl_up(incl, d);
-    if (lane >= d) incl += y;
+// ONE launch for everything between pass A and pass B (round 4; five launches before: k_part_rows, k_part_colscan, k_part_scan1,
+// k_build_slices and the pre-zero launch of pass C).  A wavefront per partition p: the G per-workgroup counts of p (bins reduced,
+// capacities from a sampled histogram, regions rounded to whole sectors) are scanned across the lanes (lane l holds the workgroups
+// G/64 * l ...), offs32[g][p] written, the total kept; a partition that will not fit one slice gets its grid tile zeroed (its slices merge
+// with atomics).  The workgroup that finishes LAST (a ticket; nobody waits) scans the totals into part_start and builds the slice table.
+__global__ __launch_bounds__(256) void k_part_offsets(OffsetsArgs A) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t p = blockIdx.x * 4u + wave;
+  const uint32_t per = (uint32_t)(A.G + 63) / 64u;                 // workgroups per lane (4 at G = 256)
+  if (p < A.nparts) {   // wavefront-uniform
+    const uint32_t b0 = p * A.bins_per_part;
+    const uint32_t b1 = b0 + A.bins_per_part < A.nbins ? b0 + A.bins_per_part : A.nbins;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t gi = lane * per + j;
+      if (gi < (uint32_t)A.G) {
+        const uint32_t *row = A.binhist + (size_t)gi * A.nbins;
+        uint32_t c = 0;
+        for (uint32_t b = b0; b < b1; ++b) c += row[b];
+        if (A.partials != nullptr) {
+          const uint64_t lo = (uint64_t)gi * A.chunk;
+          const uint64_t rows = lo < A.n ? (lo + A.chunk < A.n ? A.chunk : A.n - lo) : 0;
+          const uint64_t seen = A.partials[gi].seen;
+          double scale = seen ? (double)rows / (double)seen : 1.0;
+          if (scale < 1.0) scale = 1.0;
+          c = sampled_capacity(c, scale);
+        }
+        sum += (c + A.round_mask) & ~A.round_mask;
+      }
+    }
+    uint32_t incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += y; }
+    uint32_t run = incl - sum;
+    const uint32_t tot = __shfl(incl, 63);
+    for (uint32_t j = 0; j < per; ++j) {      // (the counts are recomputed instead of kept: `per` is not a compile-time constant)
+      const uint32_t gi = lane * per + j;
+      if (gi < (uint32_t)A.G) {
+        const uint32_t *row = A.binhist + (size_t)gi * A.nbins;
+        uint32_t c = 0;
+        for (uint32_t b = b0; b < b1; ++b) c += row[b];
+        if (A.partials != nullptr) {
+          const uint64_t lo = (uint64_t)gi * A.chunk;
+          const uint64_t rows = lo < A.n ? (lo + A.chunk < A.n ? A.chunk : A.n - lo) : 0;
+          const uint64_t seen = A.partials[gi].seen;
+          double scale = seen ? (double)rows / (double)seen : 1.0;
+          if (scale < 1.0) scale = 1.0;
+          c = sampled_capacity(c, scale);
+        }
+        A.offs32[(size_t)gi * A.nparts + p] = run;
+        run += (c + A.round_mask) & ~A.round_mask;
+      }
+    }
+    if (lane == 0) A.total[p] = tot;   // v2 requires n_rows * 2 < 2^32 (checked on the host)
+    if (tot > A.slice_len) {           // split partition: its slices merge into the pre-zeroed tile
+      const uint32_t KP = 1u << A.shift_part;
+      const uint64_t k0 = (uint64_t)p << A.shift_part, cells_all = (uint64_t)KP * A.g.T;
+      for (uint64_t c = lane; c < cells_all; c += 64) {
+        const uint64_t b = c >> A.shift_part, k = k0 + (c & (KP - 1));
+        if (k < A.g.K) { A.g.val[b * A.g.K + k] = 0ull; A.g.flag[b * A.g.K + k] = 0; }
+      }
+    }
   }
-  if (lane == 63) s_wave[wave] = incl;
+  __shared__ uint32_t s_last, s_wave[4];
+  __threadfence();
   __syncthreads();
-  unsigned long long base = 0, tot = 0;
-  for (int w = 0; w < kPartThreads / 64; ++w) {
-    if (w < wave) base += s_wave[w];
-    tot += s_wave[w];
+  if (threadIdx.x == 0) s_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // ---- the last workgroup: part_start = exclusive scan of the totals; slices ----
+  const uint32_t F = A.nparts;
+  const uint32_t each = (F + 255u) / 256u;
+  const uint32_t f0 = threadIdx.x * each;
+  auto total_of = [&](uint32_t q) -> uint32_t { return __hip_atomic_load(A.total + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto nsl = [&](uint32_t q) -> uint32_t { const uint32_t k = (uint32_t)(((unsigned long long)total_of(q) + A.slice_len - 1) / A.slice_len); return k ? k : 1u; };
+  unsigned long long rsum = 0;
+  uint32_t ssum = 0;
+  for (uint32_t j = 0; j < each; ++j)
+    if (f0 + j < F) { rsum += total_of(f0 + j); ssum += nsl(f0 + j); }
+  unsigned long long rincl = rsum;
+  uint32_t sincl = ssum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long y = __shfl_up(rincl, d);
+    const uint32_t z = __shfl_up(sincl, d);
+    if (lane >= (uint32_t)d) { rincl += y; sincl += z; }
   }
-  unsigned long long run = base + incl - sum;
-  for (uint32_t j = 0; j < per; ++j)
-    if (b0 + j < nparts) { part_start[b0 + j] = run; run += total[b0 + j]; }
-  if (threadIdx.x == 0) part_start[nparts] = tot;
+  __shared__ unsigned long long s_r[4];
+  if (lane == 63) { s_r[wave] = rincl; s_wave[wave] = sincl; }
+  __syncthreads();
+  unsigned long long rbase = 0, rtot = 0;
+  uint32_t sbase = 0, stot = 0;
+  for (uint32_t w = 0; w < 4; ++w) {
+    if (w < wave) { rbase += s_r[w]; sbase += s_wave[w]; }
+    rtot += s_r[w]; stot += s_wave[w];
+  }
+  unsigned long long rrun = rbase + rincl - rsum;
+  uint32_t srun = sbase + sincl - ssum;
+  for (uint32_t j = 0; j < each; ++j) {
+    const uint32_t q = f0 + j;
+    if (q < F) {
+      A.part_start[q] = rrun;
+      rrun += total_of(q);
+      const uint32_t k = nsl(q);
+      A.st.slice_first[q] = srun;
+      for (uint32_t i = 0; i < k; ++i) A.st.slice_part[srun + i] = q;
+      srun += k;
+    }
+  }
+  if (threadIdx.x == 0) { A.part_start[F] = rtot; *A.st.n_slices = stot; }
 }
 
 // rows_used / error bits of a workgroup: ONE atomic per workgroup.  One per wavefront was 4096 atomics on one address at the very
@@ -893,52 +958,6 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
 // ------------------------------------------------------------------------------------------------
 static constexpr uint32_t kSliceRecords = 1u << 17;
 
-struct SliceTable {
-  uint32_t *slice_part;          // [max_slices] partition of each slice
-  uint32_t *slice_first;         // [nparts] index of the partition's first slice
-  uint32_t *n_slices;            // [1]
-};
-
-// single workgroup: nsl[p] = max(1, ceil(cnt[p] / kSliceRecords)); exclusive scan -> slice_first; fill slice_part
-__global__ __launch_bounds__(kPartThreads) void k_build_slices(const unsigned long long *__restrict__ part_start, uint32_t nparts,
-                                                               SliceTable st, uint32_t slice_len) {
-  __shared__ uint32_t s_wave[kPartThreads / 64];
-  const uint32_t per = (nparts + kPartThreads - 1) / kPartThreads;
-  const uint32_t b0 = threadIdx.x * per;
-  auto nsl = [&](uint32_t p) -> uint32_t {
-    const unsigned long long c = part_start[p + 1] - part_start[p];
-    const uint32_t k = (uint32_t)((c + slice_len - 1) / slice_len);
-    return k ? k : 1u;
-  };
-  uint32_t sum = 0;
-  for (uint32_t j = 0; j < per; ++j)
-    if (b0 + j < nparts) sum += nsl(b0 + j);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = sum;
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t y = __shfl_up(incl, d);
-    if (lane >= d) incl += y;
-  }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-  for (int w = 0; w < kPartThreads / 64; ++w) {
-    if (w < wave) base += s_wave[w];
-    tot += s_wave[w];
-  }
-  uint32_t run = base + incl - sum;
-  for (uint32_t j = 0; j < per; ++j) {
-    const uint32_t p = b0 + j;
-    if (p < nparts) {
-      const uint32_t k = nsl(p);
-      st.slice_first[p] = run;
-      for (uint32_t i = 0; i < k; ++i) st.slice_part[run + i] = p;
-      run += k;
-    }
-  }
-  if (threadIdx.x == 0) *st.n_slices = tot;
-}
-
 // Geometry of pass C, decided by the plan: a partition is KP = 2^shift_part keys x T buckets; its cells are processed
 // in n_chunks rounds of TB buckets (TB * KP <= kTileCells cells per LDS tile).  n_chunks == 1 whenever the whole
 // KP x T tile fits (C2); wide grids (many keys and/or many buckets) take larger key blocks — so that pass B keeps a
@@ -955,18 +974,18 @@ struct TileGeom {
   uint32_t kt;          // settle mode: keys per tile (rounds split the partition by key sub-range); 0 = bucket rounds
 };
 
-template <bool OPMAX, bool SETTLE = false>
-__global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
-                                                                 const unsigned long long *__restrict__ part_start,
-                                                                 SliceTable st, TileGeom tg, Grid g, int phase,
-                                                                 const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G,
-                                                                 SettleArgs sa, const unsigned long long *__restrict__ ovf_count_in) {
+template <bool OPMAX, bool SETTLE>
+__device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__restrict__ recs,
+                                                    const unsigned long long *__restrict__ part_start,
+                                                    SliceTable st, TileGeom tg, Grid g,
+                                                    const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G,
+                                                    SettleArgs sa, const unsigned long long *__restrict__ ovf_count_in) {
   // Rounds as workgroups: a partition whose KP x T block needs R > 1 LDS tiles is read by R workgroups, one per bucket
   // round, instead of R times by one.  The R workgroups of a slice get block ids x + 8 * (R * j + r): the same XCD
   // (blocks are dealt round-robin over the 8 XCDs) and adjacent in dispatch order, so they stream the same records at
   // the same time and all but the first reader hit that XCD's L2.
   uint32_t s_idx = blockIdx.x, r_lo = 0, r_hi = tg.n_chunks;
-  if (phase != 0 && tg.par_rounds && tg.n_chunks > 1) {
+  if (tg.par_rounds && tg.n_chunks > 1) {
     const uint32_t x = blockIdx.x & 7u, y = blockIdx.x >> 3;
     r_lo = y % tg.n_chunks;
     r_hi = r_lo + 1;
@@ -981,15 +1000,7 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
   const uint32_t KP = 1u << shift_part;
   const uint32_t T = (uint32_t)g.T;
   const uint64_t k0 = (uint64_t)p << shift_part;
-  if (phase == 0) {  // pre-zero the grid tile of every split partition (first slice does it)
-    if (!split || s_idx != first) return;
-    const uint64_t cells_all = (uint64_t)KP * T;
-    for (uint64_t c = threadIdx.x; c < cells_all; c += kPartThreads) {
-      const uint64_t b = c >> shift_part, k = k0 + (c & (KP - 1));
-      if (k < g.K) { g.val[b * g.K + k] = 0ull; g.flag[b * g.K + k] = 0; }
-    }
-    return;
-  }
+  // (the grid tile of a split partition was zeroed by k_part_offsets: its slices merge with atomics)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_nlist, s_lbase;
   const uint32_t cell_none = (1u << tg.cell_bits) - 1u;
@@ -1192,13 +1203,27 @@ __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned 
   }
 }
 
-// records whose value did not fit the packed form: fold them into the finished grid (agent-scope integer atomics)
-template <bool OPMAX>
-__global__ __launch_bounds__(256) void k_apply_overflow(const OverflowRec *__restrict__ ovf,
-                                                        const unsigned long long *__restrict__ ovf_count, uint32_t cap, Grid g) {
-  unsigned long long n = *ovf_count;
-  if (n > cap) n = cap;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+// The kernel: the tile pass of this workgroup's slice / round, then — by whichever workgroup finishes LAST (a ticket; nobody waits) —
+// the records whose value did not fit the packed form are folded into the finished grid with agent-scope integer atomics (the list is
+// empty for ordinary tables; it was a launch of its own until round 4).
+template <bool OPMAX, bool SETTLE = false>
+__global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
+                                                                 const unsigned long long *__restrict__ part_start,
+                                                                 SliceTable st, TileGeom tg, Grid g,
+                                                                 const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G,
+                                                                 SettleArgs sa, const OverflowRec *__restrict__ ovf,
+                                                                 const unsigned long long *__restrict__ ovf_count, uint32_t ovf_cap, unsigned int *ticket) {
+  tile_aggregate_body<OPMAX, SETTLE>(recs, part_start, st, tg, g, offs32, fin, G, sa, ovf_count);
+  __shared__ uint32_t s_last_wg;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last_wg = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_last_wg) return;
+  __threadfence();
+  unsigned long long n = __hip_atomic_load(ovf_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (n > ovf_cap) n = ovf_cap;
+  for (unsigned long long i = threadIdx.x; i < n; i += kPartThreads) {
     const OverflowRec r = ovf[i];
     if (OPMAX) __hip_atomic_fetch_max(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_fetch_add(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1374,13 +1399,31 @@ uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl) {
   return slots + (uint64_t)(6.0 * sqrt(scale * R * (double)slots) + R * (8.0 * scale + 16.0 + 16.0)) + 1024;
 }
 
+// slice table inside slice_mem: slice_part[max_slices] | slice_first[nparts] | n_slices
+static SliceTable slice_table(void *slice_mem, uint64_t slots, const PartPlan &pl) {
+  const uint32_t max_slices = (uint32_t)((size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1);
+  SliceTable st;
+  st.slice_part = static_cast<uint32_t *>(slice_mem);
+  st.slice_first = st.slice_part + max_slices;
+  st.n_slices = st.slice_first + pl.nparts;
+  return st;
+}
+// regions sized from a sampled histogram hold ~2.4x the slots of their records: slices three times as long keep one slice per
+// partition for uniform tables (a split partition merges into the grid with atomics instead of plain stores)
+static uint32_t slice_len_of(bool sampled) { return sampled ? 3 * kSliceRecords : kSliceRecords; }
+
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
-                         unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n) {
+                         unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n, uint64_t slots, void *slice_mem,
+                         Grid g, unsigned int *ticket) {
+  OffsetsArgs A;
+  A.binhist = binhist; A.nbins = pl.nbins; A.bins_per_part = pl.bins_per_part; A.nparts = pl.nparts;
   // sampled regions are rounded to 16 records (128-byte lines) whatever pass B runs, so that they start line-aligned
-  hipLaunchKernelGGL(k_part_rows, dim3(pl.G), dim3(256), 0, s, binhist, pl.nbins, pl.bins_per_part, pl.nparts, offs32,
-                     sampled ? 15u : (pl.wc_cap ? pl.wc_sec - 1u : 0u), sampled ? partials : nullptr, n, pl.chunk);
-  hipLaunchKernelGGL(k_part_colscan, dim3((pl.nparts + 255) / 256), dim3(256), 0, s, offs32, pl.G, pl.nparts, total);
-  hipLaunchKernelGGL(k_part_scan1, dim3(1), dim3(kPartThreads), 0, s, total, pl.nparts, part_start);
+  A.round_mask = sampled ? 15u : (pl.wc_cap ? pl.wc_sec - 1u : 0u);
+  A.G = pl.G; A.partials = sampled ? partials : nullptr; A.n = n; A.chunk = pl.chunk;
+  A.offs32 = offs32; A.total = total; A.part_start = part_start;
+  A.st = slice_table(slice_mem, slots, pl); A.slice_len = slice_len_of(sampled);
+  A.g = g; A.shift_part = pl.shift_part; A.ticket = ticket;
+  hipLaunchKernelGGL(k_part_offsets, dim3((pl.nparts + 3) / 4), dim3(256), 0, s, A);
 }
 
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
@@ -1447,31 +1490,23 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl) {
 
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
-                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, SettleArgs settle) {
+                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, SettleArgs settle,
+                           unsigned int *ticket) {
   const unsigned long long *rr = static_cast<const unsigned long long *>(recs);
   const uint32_t max_slices = (uint32_t)((size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1);
-  SliceTable st;
-  st.slice_part = static_cast<uint32_t *>(slice_mem);
-  st.slice_first = st.slice_part + max_slices;
-  st.n_slices = st.slice_first + pl.nparts;
-  // regions sized from a sampled histogram hold ~2.4x the slots of their records: slices three times as long keep one slice per
-  // partition for uniform tables (a split partition merges into the grid with atomics instead of plain stores)
-  const uint32_t slice_len = fin != nullptr ? 3 * kSliceRecords : kSliceRecords;
-  hipLaunchKernelGGL(k_build_slices, dim3(1), dim3(kPartThreads), 0, s, part_start, pl.nparts, st, slice_len);
-  const bool may_split = slots > slice_len;  // some partition could exceed one slice
+  const SliceTable st = slice_table(slice_mem, slots, pl);   // built by k_part_offsets (with the pre-zeroed tiles of split partitions)
+  const uint32_t slice_len = slice_len_of(fin != nullptr);
   // the rounds of a partition run as parallel workgroups on one XCD (measured: C2 pass C 0.39 -> 0.29 ms against sequential rounds)
   const uint32_t par = pl.n_chunks > 1 ? 1u : 0u;
   const bool settle_on = settle.on != 0 && pl.settle_kt != 0;
   TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len, settle_on ? pl.settle_kt : 0u};
   const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
   const SettleArgs none{{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, 0.0, 0, 0};
-#define TAD_TA(OPMAX, SET)                                                                                                                                                 \
-  do {                                                                                                                                                                    \
-    allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, SET>), kLdsBudget);                                                                              \
-    if (may_split) hipLaunchKernelGGL((k_tile_aggregate<OPMAX, SET>), dim3(max_slices), dim3(kPartThreads), 0, s, rr, part_start, st, tg, g, 0, offs32, fin, pl.G, none, ovf_count); \
-    hipLaunchKernelGGL((k_tile_aggregate<OPMAX, SET>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, 1, offs32, fin, pl.G,                \
-                       SET ? settle : none, ovf_count);                                                                                                                   \
-    hipLaunchKernelGGL((k_apply_overflow<OPMAX>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);                                                                 \
+#define TAD_TA(OPMAX, SET)                                                                                                                            \
+  do {                                                                                                                                               \
+    allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, SET>), kLdsBudget);                                                         \
+    hipLaunchKernelGGL((k_tile_aggregate<OPMAX, SET>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, offs32, fin, pl.G, \
+                       SET ? settle : none, ovf, ovf_count, ovf_cap, ticket);                                                                         \
   } while (0)
   if (settle_on) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }
   else { if (op_max) TAD_TA(true, false); else TAD_TA(false, false); }
