@@ -232,6 +232,29 @@ void tad_points_free(tad_engine *e, tad_points *p);
 int tad_shard_rows(tad_engine *e, const tad_columns *cols, uint32_t world, uint64_t *out_key_id, int64_t *out_flow_end_s,
                    uint64_t *out_value, uint64_t *counts);
 
+/* ---- ingest: the GROUP BY key tuples of the job factorised on the GPU (ABI 8) ----
+ * The reference groups in ClickHouse over string / integer columns (anomaly_detection.py:52-137, 507-614); the engine wants dense
+ * key ids.  The host evaluates the SQL's string predicates on the distinct values of each string column (keep masks) and hands the
+ * rows' key TUPLES over as n_cols (<= 8) columns of 8-byte integers: dictionary codes of the string columns, ports, protocol,
+ * flowStartSeconds.  Out: key_id[i] = dense id of row i's tuple, ids in order of FIRST APPEARANCE (what pandas.factorize gives:
+ * the GPU path and the host path of theia_amd/anomaly_detection.py:prepare_columns produce identical ids and key tables),
+ * TAD_KEY_SKIP where keep[i] == 0; first_row[k] (k < first_row_cap) = the virtual row where key k first appears — the host reads
+ * the key's column values there; *num_keys.
+ * Pod mode (the UNION ALL of the inbound and the outbound view, :556-565) passes a second tuple per row (cols_b / keep_b, ids into
+ * key_id2): ids are assigned over the virtual rows [side a: 0 .. n) ++ [side b: n .. 2n) and the side is part of the tuple.
+ * n_rows * sides must be < 2^32 - 1.  All arrays (inputs and outputs) live in kc->memory. */
+typedef struct {
+  uint64_t n_rows;
+  int32_t n_cols;                /* 1..8 */
+  const int64_t *const *cols_a;  /* n_cols pointers to n_rows values each */
+  const uint8_t *keep_a;         /* NULL = every row */
+  const int64_t *const *cols_b;  /* NULL = one tuple per row */
+  const uint8_t *keep_b;
+  tad_mem memory;
+} tad_key_columns;
+int tad_factorize(tad_engine *e, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row,
+                  uint64_t first_row_cap, uint64_t *num_keys);
+
 /* ---- streaming EWMA: per-key running state kept in HBM between batches ----
  * The batch job re-reads the whole window and judges every point against the stddev_samp of the WHOLE series
  * (anomaly_detection.py:664-684, 168-212).  A long-running detector appends: tad_state holds, per key, Spark's streaming

@@ -41,6 +41,12 @@ def make_plan(**kw):
     return p
 
 
+class KeyColumns(C.Structure):
+    """tad_key_columns: the key tuples of a batch for tad_factorize (up to 8 int64 columns, optional keep masks, optional second side)."""
+    _fields_ = [("n_rows", u64), ("n_cols", i32), ("cols_a", C.POINTER(C.c_void_p)), ("keep_a", C.c_void_p),
+                ("cols_b", C.POINTER(C.c_void_p)), ("keep_b", C.c_void_p), ("memory", C.c_int)]
+
+
 class EngineOpts(C.Structure):
     _fields_ = [("device", i32), ("stream", C.c_void_p), ("workspace_limit", u64), ("plan", Plan)]
 
@@ -93,6 +99,7 @@ SYMBOLS = {
     "tad_aggregate": (C.c_int, [C.c_void_p, C.POINTER(Job), C.POINTER(Columns), C.c_int, C.POINTER(C.POINTER(Points))]),
     "tad_points_free": (None, [C.c_void_p, C.POINTER(Points)]),
     "tad_shard_rows": (C.c_int, [C.c_void_p, C.POINTER(Columns), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tad_factorize": (C.c_int, [C.c_void_p, C.POINTER(KeyColumns), C.c_void_p, C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]),
     "tad_progress": (C.c_int, [C.c_void_p, C.POINTER(i32), C.POINTER(i32)]),
     "tad_series_ewma": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_void_p]),
     "tad_series_ewma_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, f64, C.c_void_p]),

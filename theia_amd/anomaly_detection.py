@@ -302,9 +302,48 @@ def _factorize(columns):
     return np.asarray(codes, dtype=np.int64), uniq_cols
 
 
+def _int_codes(col):
+    """a key column as int64 per row: DictColumn codes, integers as they are, plain strings through their sorted distinct values"""
+    if isinstance(col, DictColumn):
+        return np.ascontiguousarray(col.codes, dtype=np.int64), col.values
+    a = np.asarray(col)
+    if a.dtype.kind in "iub":
+        return np.ascontiguousarray(a, dtype=np.int64), None
+    values, inv = np.unique(a.astype(str), return_inverse=True)
+    return np.ascontiguousarray(inv, dtype=np.int64), values
+
+
+def _factorize_gpu(engine, cols_a, keep_a, cols_b=None, keep_b=None):
+    """_factorize on the GPU (tad_factorize, include/tad.h): the rows' key tuples as int64 columns -> ids in order of first
+    appearance over [kept rows of side a ++ kept rows of side b], TAD_KEY_SKIP elsewhere; the key table is read back from the rows
+    where the keys first appear.  Same ids and tables as the pandas path (tests/test_gpu_factorize.py)."""
+    enc_a = [_int_codes(c) for c in cols_a]
+    enc_b = [_int_codes(c) for c in cols_b] if cols_b is not None else None
+    n = enc_a[0][0].size
+    key1, key2, first = engine.factorize([e[0] for e in enc_a], keep_a, [e[0] for e in enc_b] if enc_b else None, keep_b)
+    side_b = first >= np.uint64(n)
+    row = (first - np.where(side_b, np.uint64(n), np.uint64(0))).astype(np.int64)
+    uniq = []
+    for c in range(len(enc_a)):
+        codes = enc_a[c][0][row]
+        if enc_b is not None and side_b.any():
+            codes = np.where(side_b, enc_b[c][0][row], codes)
+        if enc_a[c][1] is None:
+            uniq.append(codes)
+        elif enc_b is None or not side_b.any():
+            uniq.append(enc_a[c][1][codes] if enc_a[c][1].size else np.zeros(0, dtype=str))
+        else:   # every side decodes with its own dictionary
+            out = np.empty(codes.size, dtype=object)
+            out[~side_b] = enc_a[c][1][codes[~side_b]]
+            out[side_b] = enc_b[c][1][codes[side_b]]
+            uniq.append(out.astype(str))
+    return key1, key2, uniq, side_b
+
+
 def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_flow="", pod_label="", external_ip="",
-                    svc_port_name="", pod_name="", pod_namespace=""):
-    """The host half of generate_tad_sql_query (ref:507-614): same predicates, same GROUP BY keys."""
+                    svc_port_name="", pod_name="", pod_namespace="", engine=None):
+    """The host half of generate_tad_sql_query (ref:507-614): same predicates, same GROUP BY keys.  engine (a TadEngine): the
+    key tuples are factorised on the GPU (tad_factorize) instead of with pandas — same ids, same key tables."""
     n = len(flows["flowEndSeconds"])
     flow_end = np.asarray(flows["flowEndSeconds"], dtype=np.int64)
     value = np.asarray(flows["throughput"], dtype=np.uint64)
@@ -332,6 +371,11 @@ def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_fl
             else:                                              # ref:544-548
                 ok = ~_eq(col, "")
             sides.append((ok & keep, ns, col, direction))
+        mode = "podname" if by_name else "pod"
+        if engine is not None and n:
+            key_id, key_id2, uniq, side_b = _factorize_gpu(engine, [sides[0][1], sides[0][2]], sides[0][0], [sides[1][1], sides[1][2]], sides[1][0])
+            uniq.append(np.where(side_b, sides[1][3], sides[0][3]))
+            return PreparedColumns(mode, key_id, key_id2, flow_end, None, value, dict(zip(KEY_COLUMNS[mode], uniq)), 0, 0)
         sel = [np.flatnonzero(s[0]) for s in sides]
         codes, uniq = _factorize([_concat([_take(sides[i][1], sel[i]) for i in range(2)]),
                                   _concat([_take(sides[i][2], sel[i]) for i in range(2)]),
@@ -340,7 +384,6 @@ def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_fl
         key_id2 = np.full(n, skip, dtype=np.uint64)
         key_id[sel[0]] = codes[:sel[0].size].astype(np.uint64)
         key_id2[sel[1]] = codes[sel[0].size:].astype(np.uint64)
-        mode = "podname" if by_name else "pod"
         table = dict(zip(KEY_COLUMNS[mode], uniq))
         # the pod SQL carries no flowStartSeconds / flowEndSeconds predicate (ref:556-565)
         return PreparedColumns(mode, key_id, key_id2, flow_end, None, value, table, 0, 0)
@@ -360,11 +403,14 @@ def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_fl
                 np.asarray(flows["protocolIdentifier"]).astype(np.int64), np.asarray(flows["flowStartSeconds"], dtype=np.int64)]
     else:
         raise ValueError("aggregated flow type should be 'pod' or 'external' or 'svc'")
-    sel = np.flatnonzero(keep)
-    codes, uniq = _factorize([_take(c, sel) for c in cols])
-    key_id = np.full(n, skip, dtype=np.uint64)
-    key_id[sel] = codes.astype(np.uint64)
     mode = agg_flow or ""
+    if engine is not None and n:
+        key_id, _, uniq, _ = _factorize_gpu(engine, cols, keep)
+    else:
+        sel = np.flatnonzero(keep)
+        codes, uniq = _factorize([_take(c, sel) for c in cols])
+        key_id = np.full(n, skip, dtype=np.uint64)
+        key_id[sel] = codes.astype(np.uint64)
     table = dict(zip(KEY_COLUMNS[mode], uniq))
     flow_start = np.asarray(flows["flowStartSeconds"], dtype=np.int64) if start_time else None
     return PreparedColumns(mode, key_id, None, flow_end, flow_start, value, table, _epoch(start_time), _epoch(end_time))
@@ -463,9 +509,9 @@ def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_i
             start_time, end_time, ns_ignore_list = "", "", ()   # ClickHouse has applied them already
         else:
             flows = ch.fetch_flows(flows, *args)
-    prep = prepare_columns(flows, start_time or "", end_time or "", ns_ignore_list or (), agg_flow, pod_label or "",
-                           external_ip or "", svc_port_name or "", pod_name or "", pod_namespace or "")
     eng = engine or get_engine()
+    prep = prepare_columns(flows, start_time or "", end_time or "", ns_ignore_list or (), agg_flow, pod_label or "",
+                           external_ip or "", svc_port_name or "", pod_name or "", pod_namespace or "", engine=eng)   # key tuples factorised on the GPU
     res = eng.run(algo_type, prep.key_id, prep.flow_end_s, prep.value, max(prep.num_keys, 1), agg_flow=agg_flow,
                   key_id2=prep.key_id2, flow_start_s=prep.flow_start_s, start_time=prep.start_time,
                   end_time=prep.end_time, job_id=str(tad_id_input or ""))

@@ -1394,6 +1394,69 @@ int tad_shard_rows(tad_engine *e, const tad_columns *cols, uint32_t world, uint6
   return TAD_OK;
 }
 
+int tad_factorize(tad_engine *e, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row, uint64_t first_row_cap,
+                  uint64_t *num_keys) {
+  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: engine is NULL");
+  if (!kc || !num_keys || kc->n_cols < 1 || kc->n_cols > kFzMaxCols || !kc->cols_a || (kc->n_rows && !key_id) || (kc->cols_b && kc->n_rows && !key_id2) ||
+      (first_row_cap && !first_row))
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: bad arguments (1..%d key columns, key_id / key_id2 / first_row buffers)", kFzMaxCols);
+  const uint64_t n = kc->n_rows;
+  const uint32_t sides = kc->cols_b ? 2 : 1;
+  *num_keys = 0;
+  if (n == 0) return TAD_OK;
+  if (n * sides >= 0xFFFFFFFFull) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: %llu virtual rows do not fit 32-bit row indices", (unsigned long long)(n * sides));
+  for (int c = 0; c < kc->n_cols; ++c)
+    if (!kc->cols_a[c] || (kc->cols_b && !kc->cols_b[c])) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: key column %d is NULL", c);
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  const bool host = kc->memory == TAD_MEM_HOST;
+  const size_t tb = factorize_temp_bytes(n * sides);
+  // host inputs are staged behind the table in the same scratch block: columns, masks, outputs
+  const size_t col_bytes = (n * 8 + 255) & ~(size_t)255, mask_bytes = (n + 255) & ~(size_t)255, fr_bytes = (first_row_cap * 8 + 255) & ~(size_t)255;
+  const size_t stage = host ? (size_t)kc->n_cols * sides * col_bytes + 2 * mask_bytes + sides * col_bytes + fr_bytes : 0;
+  if (tb + stage + 64 > e->ws_limit)
+    return fail(e, TAD_ERR_GRID_TOO_LARGE, "tad_factorize needs %llu bytes of scratch > workspace limit %llu", (unsigned long long)(tb + stage), (unsigned long long)e->ws_limit);
+  int rc;
+  if ((rc = ensure(e, e->sp_temp, tb + stage + 64)) != TAD_OK) return rc;
+  unsigned char *base = static_cast<unsigned char *>(e->sp_temp.p);
+  unsigned long long *nk_dev = reinterpret_cast<unsigned long long *>(base + tb);
+  const long long *ca[kFzMaxCols] = {}, *cb[kFzMaxCols] = {};
+  const uint8_t *ka = kc->keep_a, *kb = kc->keep_b;
+  uint64_t *d_key = key_id, *d_key2 = key_id2, *d_fr = first_row;
+  if (host) {
+    unsigned char *p = base + tb + 64;
+    for (int c = 0; c < kc->n_cols; ++c) {
+      HIP_TRY(e, hipMemcpyAsync(p, kc->cols_a[c], n * 8, hipMemcpyHostToDevice, s)); ca[c] = reinterpret_cast<const long long *>(p); p += col_bytes;
+      if (sides == 2) { HIP_TRY(e, hipMemcpyAsync(p, kc->cols_b[c], n * 8, hipMemcpyHostToDevice, s)); cb[c] = reinterpret_cast<const long long *>(p); p += col_bytes; }
+    }
+    if (ka) { HIP_TRY(e, hipMemcpyAsync(p, ka, n, hipMemcpyHostToDevice, s)); ka = p; }
+    p += mask_bytes;
+    if (kb) { HIP_TRY(e, hipMemcpyAsync(p, kb, n, hipMemcpyHostToDevice, s)); kb = p; }
+    p += mask_bytes;
+    d_key = reinterpret_cast<uint64_t *>(p); p += col_bytes;
+    if (sides == 2) { d_key2 = reinterpret_cast<uint64_t *>(p); p += col_bytes; }
+    d_fr = reinterpret_cast<uint64_t *>(p);
+  } else {
+    for (int c = 0; c < kc->n_cols; ++c) { ca[c] = reinterpret_cast<const long long *>(kc->cols_a[c]); if (sides == 2) cb[c] = reinterpret_cast<const long long *>(kc->cols_b[c]); }
+  }
+  launch_factorize(s, ca, ka, sides == 2 ? cb : nullptr, kb, n, kc->n_cols, base, d_key, d_key2, d_fr, first_row_cap, nk_dev);
+  unsigned long long nk = 0;
+  HIP_TRY(e, hipMemcpyAsync(&nk, nk_dev, 8, hipMemcpyDeviceToHost, s));
+  if (host) {
+    HIP_TRY(e, hipMemcpyAsync(key_id, d_key, n * 8, hipMemcpyDeviceToHost, s));
+    if (sides == 2) HIP_TRY(e, hipMemcpyAsync(key_id2, d_key2, n * 8, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(e, hipStreamSynchronize(s));
+  HIP_TRY(e, hipGetLastError());
+  if (host && first_row_cap) {
+    const uint64_t m = nk < first_row_cap ? nk : first_row_cap;
+    if (m) HIP_TRY(e, hipMemcpy(first_row, d_fr, m * 8, hipMemcpyDeviceToHost));
+  }
+  *num_keys = nk;
+  return TAD_OK;
+}
+
 void tad_points_free(tad_engine *e, tad_points *p) {
   if (!p) return;
   PointsPriv *pp = reinterpret_cast<PointsPriv *>(p);

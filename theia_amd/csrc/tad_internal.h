@@ -381,6 +381,13 @@ void launch_shard_count(hipStream_t s, const uint64_t *key, uint64_t n, uint32_t
 void launch_shard_scatter(hipStream_t s, const uint64_t *key, const int64_t *t_end, const uint64_t *value, uint64_t n, uint32_t world,
                           unsigned long long *cursor, uint64_t *out_key, int64_t *out_t, uint64_t *out_val);
 
+// ---- ingest: key tuples -> dense ids in order of first appearance (tad_factorize.hip) ----
+static constexpr int kFzMaxCols = 8;
+uint64_t factorize_table_slots(uint64_t virtual_rows);
+size_t factorize_temp_bytes(uint64_t virtual_rows);
+void launch_factorize(hipStream_t s, const long long *const *cols_a, const uint8_t *keep_a, const long long *const *cols_b, const uint8_t *keep_b, uint64_t n,
+                      int n_cols, void *temp, uint64_t *key_a, uint64_t *key_b, uint64_t *first_row, uint64_t first_row_cap, unsigned long long *num_keys_dev);
+
 void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                   uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,
                   uint64_t *value);

@@ -393,6 +393,68 @@ class TadEngine:
         self._check(rc)
         return outs, [int(c) for c in counts]
 
+    # ---- ingest: key tuples -> dense ids in order of first appearance (tad_factorize) ----
+    def factorize(self, cols_a, keep_a=None, cols_b=None, keep_b=None, max_keys=None):
+        """cols_a: list of 1..8 equally long int64 arrays (numpy on the host, or DeviceArray / device pointers all on the device) —
+        the key tuple of every row; keep_a: bool / uint8 mask (None = every row); cols_b / keep_b: the second tuple of every row
+        (pod mode).  Returns (key_id u64[n], key_id2 u64[n] or None, first_row u64[num_keys]) — ids in order of first appearance over
+        the virtual rows [side a ++ side b], TAD_KEY_SKIP where the mask is 0 — in the memory the inputs live in."""
+        ncol = len(cols_a)
+        if not 1 <= ncol <= 8 or (cols_b is not None and len(cols_b) != ncol):
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "factorize: 1..8 key columns, the same number on both sides")
+        keepalive = []
+
+        def col(x, dtype):
+            p, n, dev, keep = _as_column(x, dtype)
+            keepalive.append(keep)
+            return p, n, dev
+
+        pa = [col(c, np.int64) for c in cols_a]
+        n, dev = pa[0][1], pa[0][2]
+        pb = [col(c, np.int64) for c in cols_b] if cols_b is not None else None
+        if any(q[1] != n or q[2] != dev for q in pa + (pb or [])):
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "factorize: columns must have equal length and live in the same memory")
+
+        def mask(m):
+            if m is None:
+                return None
+            if isinstance(m, DeviceArray):
+                return m.ptr
+            a = np.ascontiguousarray(np.asarray(m).astype(np.uint8, copy=False))
+            if a.size != n:
+                raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "factorize: mask length")
+            if dev:
+                d = DeviceArray.from_host(self, np.frombuffer(a.tobytes() + b"\0" * (-a.size % 8), dtype=np.uint64))
+                keepalive.append(d)
+                return d.ptr
+            keepalive.append(a)
+            return a.ctypes.data
+
+        ka, kb = mask(keep_a), mask(keep_b)
+        arr_a = (C.c_void_p * ncol)(*[q[0] for q in pa])
+        arr_b = (C.c_void_p * ncol)(*[q[0] for q in pb]) if pb is not None else None
+        sides = 2 if pb is not None else 1
+        cap = int(max_keys) if max_keys is not None else n * sides
+        kc = capi.KeyColumns(n_rows=n, n_cols=ncol, cols_a=arr_a, keep_a=ka, cols_b=arr_b, keep_b=kb,
+                             memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
+        nk = capi.u64()
+        if dev:
+            key1 = DeviceArray(self, n, np.uint64)
+            key2 = DeviceArray(self, n, np.uint64) if pb is not None else None
+            first = DeviceArray(self, max(cap, 1), np.uint64)
+            rc = self._lib.tad_factorize(self._h, C.byref(kc), key1.ptr, key2.ptr if key2 is not None else None, first.ptr, cap, C.byref(nk))
+            del keepalive
+            self._check(rc)
+            first.n = min(int(nk.value), cap)
+            return key1, key2, first
+        key1 = np.empty(n, dtype=np.uint64)
+        key2 = np.empty(n, dtype=np.uint64) if pb is not None else None
+        first = np.empty(max(cap, 1), dtype=np.uint64)
+        rc = self._lib.tad_factorize(self._h, C.byref(kc), key1.ctypes.data, key2.ctypes.data if key2 is not None else None, first.ctypes.data, cap, C.byref(nk))
+        del keepalive
+        self._check(rc)
+        return key1, key2, first[:min(int(nk.value), cap)]
+
     # ---- Stage 0 alone: the GROUP BY (anomaly_detection.py:507-614) ----
     def aggregate(self, key_id, flow_end_s, value, num_keys, agg_flow="", value_op="auto", key_id2=None, flow_start_s=None,
                   start_time=0, end_time=0, lattice=None, out="host"):

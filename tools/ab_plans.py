@@ -46,8 +46,7 @@ for item in args.variants.split(";"):
 
 eng0 = TadEngine(device=0)
 n, K, T = cfg["rows"], cfg["keys"], cfg["buckets"]
-cols = [DeviceArray(eng0, n, np.uint64), DeviceArray(eng0, n, np.int64), DeviceArray(eng0, n, np.uint64)]
-eng0.synth(0, n, K, T, into=tuple(cols))
+cols = eng0.synth(0, n, K, T)
 engines = [(name, TadEngine(device=0, plan=plan)) for name, plan in variants]
 jobs = [(name, e.prepare(cfg["algo"], cols[0], cols[1], cols[2], K, agg_flow=cfg["agg"], out="device")) for name, e in engines]
 times = {name: [] for name, _ in jobs}
