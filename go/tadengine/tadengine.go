@@ -57,8 +57,31 @@ func (e IllegalArgument) Error() string { return e.Msg }
 // (controller.go:199-201); calls on one engine serialise inside the library.
 type Engine struct{ h *C.tad_engine }
 
-func NewEngine(device int) (*Engine, error) {
-	opts := C.tad_engine_opts{device: C.int32_t(device)}
+// Plan mirrors tad_plan (tad.h, ABI 8): plan overrides of an engine, every field 0 = the engine decides — what the controller
+// uses.  Tests and A/B measurements force a strategy with it; the library reads no environment variable.  A Go struct, not
+// C.tad_plan: cgo types are private to this package, callers in other packages could not construct one.
+type Plan struct {
+	Stage0        int32  // 1 = direct atomic scatter, 2 = partition + LDS tiles whatever the batch size
+	PartitionPass int32  // 1 = sort-by-tile pass B, 2 = write-combining pass B
+	Histogram     int32  // 1 = exact per-workgroup histogram in pass A
+	Sparse        int32  // 1 = never, 2 = always the sort-based Stage 0 for sparse tables
+	SparseClasses int32  // 1 = always run a sparse table as length classes of keys
+	EwmaEmit      int32  // 1 = lane-per-key emit for the EWMA job
+	EwmaEmitRows  uint32 // LDS rows per wavefront of the staged EWMA emit (<= 4096)
+	OneSync       int32  // 1 = never run a job in the one-synchronisation form
+}
+
+func (p Plan) c() C.tad_plan {
+	return C.tad_plan{stage0: C.int32_t(p.Stage0), partition_pass: C.int32_t(p.PartitionPass), histogram: C.int32_t(p.Histogram),
+		sparse: C.int32_t(p.Sparse), sparse_classes: C.int32_t(p.SparseClasses), ewma_emit: C.int32_t(p.EwmaEmit),
+		ewma_emit_rows: C.uint32_t(p.EwmaEmitRows), one_sync: C.int32_t(p.OneSync)}
+}
+
+func NewEngine(device int) (*Engine, error) { return NewEngineWithPlan(device, Plan{}) }
+
+// NewEngineWithPlan creates the engine with plan overrides in tad_engine_opts.plan.
+func NewEngineWithPlan(device int, plan Plan) (*Engine, error) {
+	opts := C.tad_engine_opts{device: C.int32_t(device), plan: plan.c()}
 	var h *C.tad_engine
 	if rc := C.tad_engine_create(&opts, &h); rc != C.TAD_OK {
 		return nil, fmt.Errorf("tad_engine_create: %s (code %d)", C.GoString(C.tad_last_error(nil)), int(rc))
@@ -68,10 +91,10 @@ func NewEngine(device int) (*Engine, error) {
 	return e, nil
 }
 
-// SetPlan replaces the engine's plan overrides (tad.h: tad_plan, ABI 7; the zero value = the engine decides, which is what
-// the controller uses).  Tests and A/B measurements force a strategy with it; the library reads no environment variable.
-func (e *Engine) SetPlan(p C.tad_plan) error {
-	if rc := C.tad_engine_set_plan(e.h, &p); rc != C.TAD_OK {
+// SetPlan replaces the engine's plan overrides; takes effect with the next job.
+func (e *Engine) SetPlan(p Plan) error {
+	cp := p.c()
+	if rc := C.tad_engine_set_plan(e.h, &cp); rc != C.TAD_OK {
 		return fmt.Errorf("tad_engine_set_plan: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
 	}
 	return nil
@@ -117,6 +140,7 @@ type Stats struct {
 	ArimaNanFits                                             uint64 // ARIMA fits voided by a non-finite likelihood (tad.h: tad_stats.arima_nan_fits)
 	MsTotal                                                  float32
 	Stage0Path                                               int32 // how Stage 0 ran (tad.h: tad_stats.stage0_path), for the controller's logs
+	HostSyncs                                                int32 // 1 = the one-synchronisation form (tad.h: tad_stats.host_syncs, ABI 8)
 }
 
 // cColumn copies a Go slice into C memory: cgo forbids handing Go pointers nested in a C struct, and the
@@ -196,7 +220,7 @@ func (e *Engine) Run(job Job, cols Columns) ([]Row, Stats, error) {
 	}
 	st = Stats{uint64(res.stats.rows_in), uint64(res.stats.rows_used), uint64(res.stats.n_keys), uint64(res.stats.n_points),
 		uint64(res.stats.n_anomalies), uint64(res.stats.keys_no_result), uint64(res.stats.arima_nan_fits), float32(res.stats.ms_total),
-		int32(res.stats.stage0_path)}
+		int32(res.stats.stage0_path), int32(res.stats.host_syncs)}
 	return rows, st, nil
 }
 
@@ -270,6 +294,86 @@ func (e *Engine) ShardRows(key, flowEnd, value unsafe.Pointer, n uint64, world u
 		return nil, fmt.Errorf("tad_shard_rows: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
 	}
 	return counts, nil
+}
+
+// Factorize turns the rows' GROUP BY key tuples — dictionary codes of the string columns, ports, protocol, flowStartSeconds: up to
+// eight int64 columns (anomaly_detection.py:52-137) — into dense key ids in order of first appearance on the GPU (tad_factorize).
+// keep (nil = every row) marks the rows the SQL's predicates accept; the others get KeySkip.  colsB / keepB: the second tuple of
+// every row in pod mode (the outbound view of the UNION ALL, :556-565), ids into the second return value.  firstRow[k] = the virtual
+// row (i for side a, n + i for side b) where key k first appears: the caller reads the key's column values there.
+func (e *Engine) Factorize(colsA [][]int64, keepA []byte, colsB [][]int64, keepB []byte) (keyID, keyID2, firstRow []uint64, err error) {
+	if len(colsA) < 1 || len(colsA) > 8 || (colsB != nil && len(colsB) != len(colsA)) {
+		return nil, nil, nil, errors.New("tadengine: 1..8 key columns, the same number on both sides")
+	}
+	n := len(colsA[0])
+	sides := 1
+	if colsB != nil {
+		sides = 2
+	}
+	var bufs []unsafe.Pointer
+	defer func() {
+		for _, p := range bufs {
+			if p != nil {
+				C.free(p)
+			}
+		}
+	}()
+	ptrs := func(cols [][]int64) *unsafe.Pointer {
+		arr := (*[8]unsafe.Pointer)(C.malloc(C.size_t(8 * unsafe.Sizeof(unsafe.Pointer(nil)))))
+		bufs = append(bufs, unsafe.Pointer(arr))
+		for c, col := range cols {
+			if len(col) != n {
+				return nil
+			}
+			arr[c] = cColumn(col)
+			bufs = append(bufs, arr[c])
+		}
+		return &arr[0]
+	}
+	mask := func(m []byte) unsafe.Pointer {
+		if m == nil {
+			return nil
+		}
+		p := C.CBytes(m)
+		bufs = append(bufs, p)
+		return p
+	}
+	var kc C.tad_key_columns
+	kc.n_rows = C.uint64_t(n)
+	kc.n_cols = C.int32_t(len(colsA))
+	kc.memory = C.TAD_MEM_HOST
+	pa := ptrs(colsA)
+	if pa == nil || (keepA != nil && len(keepA) != n) || (keepB != nil && len(keepB) != n) {
+		return nil, nil, nil, errors.New("tadengine: key columns and masks differ in length")
+	}
+	kc.cols_a = (**C.int64_t)(unsafe.Pointer(pa))
+	kc.keep_a = (*C.uint8_t)(mask(keepA))
+	if colsB != nil {
+		pb := ptrs(colsB)
+		if pb == nil {
+			return nil, nil, nil, errors.New("tadengine: key columns differ in length")
+		}
+		kc.cols_b = (**C.int64_t)(unsafe.Pointer(pb))
+		kc.keep_b = (*C.uint8_t)(mask(keepB))
+	}
+	keyID = make([]uint64, n)
+	firstRow = make([]uint64, n*sides)
+	var k2 *C.uint64_t
+	if colsB != nil {
+		keyID2 = make([]uint64, n)
+		if n > 0 {
+			k2 = (*C.uint64_t)(unsafe.Pointer(&keyID2[0]))
+		}
+	}
+	if n == 0 {
+		return keyID, keyID2, firstRow[:0], nil
+	}
+	var nk C.uint64_t
+	if rc := C.tad_factorize(e.h, &kc, (*C.uint64_t)(unsafe.Pointer(&keyID[0])), k2, (*C.uint64_t)(unsafe.Pointer(&firstRow[0])),
+		C.uint64_t(len(firstRow)), &nk); rc != C.TAD_OK {
+		return nil, nil, nil, fmt.Errorf("tad_factorize: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return keyID, keyID2, firstRow[:int(nk)], nil
 }
 
 // Progress feeds Status.CompletedStages / TotalStages (controller.go:426-453).

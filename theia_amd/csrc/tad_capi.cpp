@@ -76,7 +76,7 @@ struct tad_engine {
 // per-key running state of the streaming EWMA detector: two copies (the count pass writes the candidate next state,
 // it becomes current only when the batch succeeds)
 namespace {
-constexpr size_t kTailCtr = 0, kTailTotal = 64, kTailOvfCount = 72, kTailTickets = 80, kTailMoments = 128;   // tickets: two u32 (k_part_offsets, k_tile_aggregate)
+constexpr size_t kTailCtr = 0, kTailTotal = 64, kTailOvfCount = 72, kTailTickets = 80, kTailMoments = 128;   // tickets: one u32 (k_part_offsets)
 constexpr size_t kTailBytes = kTailMoments + sizeof(Moments) * kMomentBlocks;
 inline DevCounters *dev_ctr(tad_engine *e) { return static_cast<DevCounters *>(e->counters.p); }
 inline unsigned long long *dev_total(tad_engine *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailTotal); }
@@ -844,7 +844,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         jp.settled = true;
       }
       launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap,
-                            hist_sampled ? offs32 : nullptr, fin, settle, dev_ticket(e, 1));
+                            hist_sampled ? offs32 : nullptr, fin, settle);
     } else {
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(g.val, 0, cells * 8, s));

@@ -344,8 +344,7 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 size_t slice_table_bytes(uint64_t slots, const PartPlan &pl);
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
-                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, SettleArgs settle,
-                           unsigned int *ticket);   // ticket: a zeroed word; the workgroup that finishes last folds the overflow list into the grid
+                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, SettleArgs settle);
 // whether pass C can run in settle mode for this plan (whole series of >= 8 keys fit an LDS tile; same number of rounds or fewer than 2x)
 bool part_plan_settle(uint64_t T, PartPlan *pl);
 

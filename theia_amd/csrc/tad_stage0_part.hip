@@ -1203,27 +1203,25 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
   }
 }
 
-// The kernel: the tile pass of this workgroup's slice / round, then — by whichever workgroup finishes LAST (a ticket; nobody waits) —
-// the records whose value did not fit the packed form are folded into the finished grid with agent-scope integer atomics (the list is
-// empty for ordinary tables; it was a launch of its own until round 4).
 template <bool OPMAX, bool SETTLE = false>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
                                                                  SliceTable st, TileGeom tg, Grid g,
                                                                  const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G,
-                                                                 SettleArgs sa, const OverflowRec *__restrict__ ovf,
-                                                                 const unsigned long long *__restrict__ ovf_count, uint32_t ovf_cap, unsigned int *ticket) {
+                                                                 SettleArgs sa, const unsigned long long *__restrict__ ovf_count) {
   tile_aggregate_body<OPMAX, SETTLE>(recs, part_start, st, tg, g, offs32, fin, G, sa, ovf_count);
-  __shared__ uint32_t s_last_wg;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last_wg = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-  __syncthreads();
-  if (!s_last_wg) return;
-  __threadfence();
-  unsigned long long n = __hip_atomic_load(ovf_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (n > ovf_cap) n = ovf_cap;
-  for (unsigned long long i = threadIdx.x; i < n; i += kPartThreads) {
+}
+
+// records whose value did not fit the packed form: fold them into the finished grid (agent-scope integer atomics).
+// (Round 4 tried to let the LAST workgroup of the tile pass do this — a ticket behind a device-scope fence in every workgroup — to
+// save the launch: on this multi-XCD chip an agent-scope release writes the XCD's dirty L2 lines back, and ~1600 workgroups doing
+// that with the grid tiles in flight took the C2 job from 1.28 to 3.0 ms (profiles/r4_v5_ab_c2.log).  A launch of its own it stays.)
+template <bool OPMAX>
+__global__ __launch_bounds__(256) void k_apply_overflow(const OverflowRec *__restrict__ ovf,
+                                                        const unsigned long long *__restrict__ ovf_count, uint32_t cap, Grid g) {
+  unsigned long long n = *ovf_count;
+  if (n > cap) n = cap;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
     const OverflowRec r = ovf[i];
     if (OPMAX) __hip_atomic_fetch_max(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_fetch_add(g.val + r.gcell, r.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1490,8 +1488,7 @@ size_t slice_table_bytes(uint64_t slots, const PartPlan &pl) {
 
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
-                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, SettleArgs settle,
-                           unsigned int *ticket) {
+                           const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, SettleArgs settle) {
   const unsigned long long *rr = static_cast<const unsigned long long *>(recs);
   const uint32_t max_slices = (uint32_t)((size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1);
   const SliceTable st = slice_table(slice_mem, slots, pl);   // built by k_part_offsets (with the pre-zeroed tiles of split partitions)
@@ -1506,7 +1503,8 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   do {                                                                                                                                               \
     allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, SET>), kLdsBudget);                                                         \
     hipLaunchKernelGGL((k_tile_aggregate<OPMAX, SET>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, offs32, fin, pl.G, \
-                       SET ? settle : none, ovf, ovf_count, ovf_cap, ticket);                                                                         \
+                       SET ? settle : none, ovf_count);                                                                                               \
+    hipLaunchKernelGGL((k_apply_overflow<OPMAX>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);                                             \
   } while (0)
   if (settle_on) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }
   else { if (op_max) TAD_TA(true, false); else TAD_TA(false, false); }
