@@ -322,15 +322,14 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
 bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, uint64_t n, uint64_t K, RowFilter f, const PartPlan &pl,
                       MetaPartial *partials, uint32_t *binhist, DevCounters *ctr, bool sample_hist);
-// the speculated lattice against pass A's partials, on the device (DEV_ERR_SPEC when they differ)
-void launch_lattice_check(hipStream_t s, const MetaPartial *partials, int n_partials, Lattice L, DevCounters *ctr);
 // offs32[G][nparts] (exclusive per-workgroup prefix inside each partition), total[nparts], part_start[nparts + 1]
 // sampled: the histogram is a sample -> region capacities (estimate + 6 sigma + margin); partials carry the sampling ratios
-// ONE launch (k_part_offsets): also builds the slice table of pass C in slice_mem (slice_table_bytes(slots, pl)) and zeroes the grid
-// tile of every partition that will be split into several slices; ticket: a zeroed word (the job tail)
+// TWO launches (k_part_offsets, k_part_tail): also build the slice table of pass C in slice_mem (slice_table_bytes(slots, pl)) and zero
+// the grid tile of every partition that will be split into several slices.  spec_L != NULL (the one-synchronisation job): one extra
+// workgroup checks the speculated lattice against pass A's spec_n partials (DEV_ERR_SPEC into spec_ctr when they differ).
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
                          unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n, uint64_t slots, void *slice_mem,
-                         Grid g, unsigned int *ticket);
+                         Grid g, const Lattice *spec_L = nullptr, int spec_n = 0, DevCounters *spec_ctr = nullptr);
 // upper bound of the record slots pass B may be given when the regions are sized from a sampled histogram
 uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl);
 // fin != NULL (sampled regions): no fillers; fin[(g * nparts + p) * 2 + {0, 1}] = end of the records written upwards /

@@ -290,11 +290,12 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
 // The one-synchronisation job (tad_capi.cpp): the host issues the whole job with the lattice of the LAST job of the same shape
 // instead of waiting for pass A's partials; this kernel derives the lattice from the partials exactly as the host would (min,
 // max, gcd of the sampled differences, gcd with the span and the reference offset) and raises DEV_ERR_SPEC when it is not the
-// speculated one — the host then discards the job's output and redoes it with the host-derived lattice.  (Every row is still
+// speculated one — the host then discards the job's output and redoes it with the host-derived lattice.  It runs as ONE EXTRA WORKGROUP
+// of k_part_offsets (which never reads the lattice), next to that kernel's own work: no launch, nothing on the critical path.  (Every row is still
 // checked against the lattice by pass B: a speculated lattice that merely CONTAINS the rows would give the same anomaly rows,
 // but not the same tad_stats; equality with the derivation keeps the two paths indistinguishable.)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lattice_check(const MetaPartial *__restrict__ partials, int n_partials, Lattice L, DevCounters *ctr) {
+__device__ __forceinline__ void lattice_check_block(const MetaPartial *__restrict__ partials, int n_partials, const Lattice &L, DevCounters *ctr) {
   PMeta m{0, 0, 0, 0, 0};
   for (int b = threadIdx.x; b < n_partials; b += 256) {
     const MetaPartial p = partials[b];
@@ -325,9 +326,6 @@ __global__ __launch_bounds__(256) void k_lattice_check(const MetaPartial *__rest
   if (!same) atomicOr(&ctr->err, DEV_ERR_SPEC);
 }
 
-void launch_lattice_check(hipStream_t s, const MetaPartial *partials, int n_partials, Lattice L, DevCounters *ctr) {
-  hipLaunchKernelGGL(k_lattice_check, dim3(1), dim3(256), 0, s, partials, n_partials, L, ctr);
-}
 
 // ------------------------------------------------------------------------------------------------
 // offsets: cnt[g][p] (row reduce of the bins) -> column-wise exclusive prefix over g -> part_start[p]
@@ -361,15 +359,25 @@ struct OffsetsArgs {
   uint32_t slice_len;
   Grid g;                        // the grid tile of a partition that will be split into several slices is zeroed here
   int shift_part;
-  unsigned int *ticket;          // zeroed per job (the job tail)
+  // the one-synchronisation job: the speculated lattice, checked by one extra workgroup against pass A's partials (spec_ctr NULL = off)
+  const MetaPartial *spec_partials;
+  int spec_n;
+  Lattice spec_L;
+  DevCounters *spec_ctr;
 };
 
-// ONE launch for everything between pass A and pass B (round 4; five launches before: k_part_rows, k_part_colscan, k_part_scan1,
-// k_build_slices and the pre-zero launch of pass C).  A wavefront per partition p: the G per-workgroup counts of p (bins reduced,
-// capacities from a sampled histogram, regions rounded to whole sectors) are scanned across the lanes (lane l holds the workgroups
-// G/64 * l ...), offs32[g][p] written, the total kept; a partition that will not fit one slice gets its grid tile zeroed (its slices merge
-// with atomics).  The workgroup that finishes LAST (a ticket; nobody waits) scans the totals into part_start and builds the slice table.
+// TWO launches for everything between pass A and pass B (round 4; five before: k_part_rows, k_part_colscan — 256 dependent steps per
+// thread —, k_part_scan1, k_build_slices and the pre-zero launch of pass C).  k_part_offsets, a wavefront per partition p: the G
+// per-workgroup counts of p (bins reduced, capacities from a sampled histogram, regions rounded to whole sectors) are scanned across the
+// lanes (lane l holds the workgroups G/64 * l ...), offs32[g][p] written, the total kept; a partition that will not fit one slice gets
+// its grid tile zeroed (its slices merge with atomics).  k_part_tail, one workgroup: totals -> part_start, slice table.
+// (A ticket that let the last workgroup of the first kernel do the tail was measured: the device-scope fences and the agent-scope
+// loads it needs made the one kernel slower — 40 us — than the two.)
 __global__ __launch_bounds__(256) void k_part_offsets(OffsetsArgs A) {
+  if (blockIdx.x == gridDim.x - 1 && A.spec_ctr != nullptr) {   // the extra workgroup: lattice check of the one-synchronisation job
+    lattice_check_block(A.spec_partials, A.spec_n, A.spec_L, A.spec_ctr);
+    return;
+  }
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t p = blockIdx.x * 4u + wave;
   const uint32_t per = (uint32_t)(A.G + 63) / 64u;                 // workgroups per lane (4 at G = 256)
@@ -426,23 +434,23 @@ __global__ __launch_bounds__(256) void k_part_offsets(OffsetsArgs A) {
       }
     }
   }
-  __shared__ uint32_t s_last, s_wave[4];
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(A.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  // ---- the last workgroup: part_start = exclusive scan of the totals; slices ----
+}
+
+__global__ __launch_bounds__(256) void k_part_tail(OffsetsArgs A) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  __shared__ uint32_t s_wave[4];
   const uint32_t F = A.nparts;
-  const uint32_t each = (F + 255u) / 256u;
-  const uint32_t f0 = threadIdx.x * each;
-  auto total_of = [&](uint32_t q) -> uint32_t { return __hip_atomic_load(A.total + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto nsl = [&](uint32_t q) -> uint32_t { const uint32_t k = (uint32_t)(((unsigned long long)total_of(q) + A.slice_len - 1) / A.slice_len); return k ? k : 1u; };
+  constexpr uint32_t kEach = 8;                                   // kMaxParts / 256
+  const uint32_t f0 = threadIdx.x * kEach;
+  uint32_t tot[kEach];
+#pragma unroll
+  for (uint32_t j = 0; j < kEach; ++j) tot[j] = f0 + j < F ? A.total[f0 + j] : 0u;
+  auto nsl = [&](uint32_t t) -> uint32_t { const uint32_t k = (uint32_t)(((unsigned long long)t + A.slice_len - 1) / A.slice_len); return k ? k : 1u; };
   unsigned long long rsum = 0;
   uint32_t ssum = 0;
-  for (uint32_t j = 0; j < each; ++j)
-    if (f0 + j < F) { rsum += total_of(f0 + j); ssum += nsl(f0 + j); }
+#pragma unroll
+  for (uint32_t j = 0; j < kEach; ++j)
+    if (f0 + j < F) { rsum += tot[j]; ssum += nsl(tot[j]); }
   unsigned long long rincl = rsum;
   uint32_t sincl = ssum;
   for (int d = 1; d < 64; d <<= 1) {
@@ -461,12 +469,13 @@ __global__ __launch_bounds__(256) void k_part_offsets(OffsetsArgs A) {
   }
   unsigned long long rrun = rbase + rincl - rsum;
   uint32_t srun = sbase + sincl - ssum;
-  for (uint32_t j = 0; j < each; ++j) {
+#pragma unroll
+  for (uint32_t j = 0; j < kEach; ++j) {
     const uint32_t q = f0 + j;
     if (q < F) {
       A.part_start[q] = rrun;
-      rrun += total_of(q);
-      const uint32_t k = nsl(q);
+      rrun += tot[j];
+      const uint32_t k = nsl(tot[j]);
       A.st.slice_first[q] = srun;
       for (uint32_t i = 0; i < k; ++i) A.st.slice_part[srun + i] = q;
       srun += k;
@@ -1412,7 +1421,8 @@ static uint32_t slice_len_of(bool sampled) { return sampled ? 3 * kSliceRecords 
 
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
                          unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n, uint64_t slots, void *slice_mem,
-                         Grid g, unsigned int *ticket) {
+                         Grid g, const Lattice *spec_L, int spec_n, DevCounters *spec_ctr) {
+  static_assert(kMaxParts <= 8 * 256, "k_part_tail holds 8 partitions per thread");
   OffsetsArgs A;
   A.binhist = binhist; A.nbins = pl.nbins; A.bins_per_part = pl.bins_per_part; A.nparts = pl.nparts;
   // sampled regions are rounded to 16 records (128-byte lines) whatever pass B runs, so that they start line-aligned
@@ -1420,8 +1430,10 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
   A.G = pl.G; A.partials = sampled ? partials : nullptr; A.n = n; A.chunk = pl.chunk;
   A.offs32 = offs32; A.total = total; A.part_start = part_start;
   A.st = slice_table(slice_mem, slots, pl); A.slice_len = slice_len_of(sampled);
-  A.g = g; A.shift_part = pl.shift_part; A.ticket = ticket;
-  hipLaunchKernelGGL(k_part_offsets, dim3((pl.nparts + 3) / 4), dim3(256), 0, s, A);
+  A.g = g; A.shift_part = pl.shift_part;
+  A.spec_partials = partials; A.spec_n = spec_n; A.spec_L = spec_L != nullptr ? *spec_L : Lattice{}; A.spec_ctr = spec_L != nullptr ? spec_ctr : nullptr;
+  hipLaunchKernelGGL(k_part_offsets, dim3((pl.nparts + 3) / 4 + (A.spec_ctr != nullptr ? 1 : 0)), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(k_part_tail, dim3(1), dim3(256), 0, s, A);
 }
 
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
