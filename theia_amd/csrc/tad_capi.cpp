@@ -425,13 +425,12 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
     if (launch_arima(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, wsb) != 0)
       return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
   }
-  launch_moments(s, g.K, n_pts, static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p),
-                 dev_moments(e), db_fused ? ctr : nullptr);
   const uint32_t *cnt = n_anom;
   if (jp.all_points && jp.algo != TAD_ALGO_ARIMA && !drop) cnt = n_pts;
   else if (db_fused) {}                                                             // the tile kernel counted the noise points
   else if (!ewma || jp.all_points) launch_count_flags(s, g, jp.all_points, n_anom);  // ARIMA / DROP all_points: skips no-result keys
-  launch_scan(s, cnt, off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p), dev_total(e));
+  launch_scan_moments(s, cnt, off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p), dev_total(e), n_pts,
+                      static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p), dev_moments(e), db_fused ? ctr : nullptr);
   if (defer_tail) return TAD_OK;   // the one-synchronisation job: the tail is fetched once, after the emit
   HIP_TRY(e, hipMemcpyAsync(e->tail_host, e->counters.p, kTailBytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipStreamSynchronize(s));

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
 #pragma unroll
     for (int jj = 0; jj < PPL; ++jj)
       for (unsigned long long m = pm[jj]; m; m &= m - 1) {
-        const double xj = __shfl(x[jj], __ffsll((long long)m) - 1);
+        const double xj = readlane_f64(x[jj], __ffsll((long long)m) - 1);
 #pragma unroll
         for (int i = 0; i < PPL; ++i) cnt[i] += fabs(x[i] - xj) <= eps ? 1 : 0;
       }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
 #pragma unroll
     for (int jj = 0; jj < PPL; ++jj)
       for (unsigned long long m = cm[jj]; m; m &= m - 1) {
-        const double xj = __shfl(x[jj], __ffsll((long long)m) - 1);
+        const double xj = readlane_f64(x[jj], __ffsll((long long)m) - 1);
 #pragma unroll
         for (int i = 0; i < PPL; ++i) reach[i] = reach[i] || fabs(x[i] - xj) <= eps;
       }
@@ -305,14 +305,25 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
     // recurrence over the present points by readlane) — the series is in registers HERE; k_emit_dbscan_wave used to fetch the
     // key's whole column (one 64-byte sector per bucket for 8 useful bytes: 238 MB at C4) a second time for these two things.
     if (sg_e != nullptr && noise) {   // wavefront-uniform
+      // the reciprocals of the counts 1 .. 64 PPL, one IEEE division per lane and register (= RN(1 / count), what div_by_count needs),
+      // picked up by readlane: the step is 5 FMAs instead of a ~30-instruction division on a kernel that is issue-bound
+      // (C4: ~70 % of a noisy key's instructions were this division)
+      double rl[PPL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) rl[j] = 1.0 / (double)(lane + 64u * (unsigned)j + 1u);
       double cn = 0.0, avg = 0.0, m2 = 0.0;
+      int ord = 0;   // points seen so far: the next count is ord + 1 -> reciprocal in register ord / 64, lane ord % 64
 #pragma unroll
       for (int jj = 0; jj < PPL; ++jj)
-        for (unsigned long long m = pm[jj]; m; m &= m - 1) {
-          const double xv = __shfl(x[jj], __ffsll((long long)m) - 1);
+        for (unsigned long long m = pm[jj]; m; m &= m - 1, ++ord) {
+          const double xv = readlane_f64(x[jj], __ffsll((long long)m) - 1);
+          double rc = readlane_f64(rl[0], ord & 63);
+#pragma unroll
+          for (int j = 1; j < PPL; ++j)
+            if ((ord >> 6) == j) rc = readlane_f64(rl[j], ord & 63);
           cn = cn + 1.0;
           const double d = xv - avg;
-          const double dn = d / cn;
+          const double dn = div_by_count(d, cn, rc);     // == d / cn, bit for bit
           avg = avg + dn;
           m2 = m2 + d * (d - dn);
         }

@@ -225,6 +225,10 @@ void launch_count_flags(hipStream_t s, Grid g, bool all_points, uint32_t *n_anom
 void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K,
                  unsigned long long *scratch, unsigned long long *total_copy = nullptr);
 size_t scan_scratch_elems(uint64_t K);
+// launch_scan + launch_moments with the moments merge riding in the scan's first launch
+void launch_scan_moments(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K, unsigned long long *scratch,
+                         unsigned long long *total_copy, const uint32_t *n_pts, const double *key_mean, const double *key_m2, Moments *partials,
+                         DevCounters *ctr);
 // kind: 0 EWMA (recompute), 1 flags + calc array, 2 flags with calc = 0, 3 flags with calc = per-key value calc[k],
 // 4 = 2 with the stddev column computed here (Spark's streaming update over the key's series) for the keys that have rows
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,

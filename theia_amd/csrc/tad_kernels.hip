@@ -361,18 +361,27 @@ void launch_key_sigma(hipStream_t s, Grid g, double alpha, bool ewma_count, cons
 // The host merges the kMomentBlocks partials, and the multi-GPU host merges shards the same way.
 // ------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kBlock) void k_moments(uint64_t K, const uint32_t *__restrict__ n_pts,
-                                                    const double *__restrict__ key_mean,
-                                                    const double *__restrict__ key_m2,
-                                                    Moments *__restrict__ partials, DevCounters *ctr) {
+struct MomentsArgs {
+  uint64_t K;
+  const uint32_t *n_pts;
+  const double *key_mean, *key_m2;
+  Moments *partials;
+  DevCounters *ctr;
+};
+
+// block `mb` of kMomentBlocks (a launch of its own, or the trailing blocks of the scan's first launch: launch_scan_moments)
+__device__ __forceinline__ void moments_block(uint32_t mb, uint64_t K, const uint32_t *__restrict__ n_pts,
+                                              const double *__restrict__ key_mean,
+                                              const double *__restrict__ key_m2,
+                                              Moments *__restrict__ partials, DevCounters *ctr) {
   Moments acc{0.0, 0.0, 0.0};
   unsigned long long pts = 0, keys = 0;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const uint64_t stride = (uint64_t)kMomentBlocks * kBlock;
   // The merge order is fixed (strided per thread); the loads are not part of that chain: eight keys' triples are fetched
   // together, then merged in order — at 1e6 keys a thread has ~30 keys and the loop was 30 dependent memory round trips
   // (C4: detect + emit 0.50 -> 0.48 ms).
   constexpr int kMU = 8;
-  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < K; k += stride * kMU) {
+  for (uint64_t k = (uint64_t)mb * kBlock + threadIdx.x; k < K; k += stride * kMU) {
     uint32_t n[kMU];
     double mean[kMU], m2[kMU];
 #pragma unroll
@@ -405,13 +414,17 @@ __global__ __launch_bounds__(kBlock) void k_moments(uint64_t K, const uint32_t *
   if (threadIdx.x == 0) {
     Moments a = s_m[0];
     for (int w = 1; w < kBlock / 64; ++w) a = chan_merge(a, s_m[w]);
-    partials[blockIdx.x] = a;
+    partials[mb] = a;
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_moments(MomentsArgs M) {
+  moments_block(blockIdx.x, M.K, M.n_pts, M.key_mean, M.key_m2, M.partials, M.ctr);
 }
 
 void launch_moments(hipStream_t s, uint64_t K, const uint32_t *n_pts, const double *key_mean,
                     const double *key_m2, Moments *partials, DevCounters *ctr) {
-  hipLaunchKernelGGL(k_moments, dim3(kMomentBlocks), dim3(kBlock), 0, s, K, n_pts, key_mean, key_m2, partials, ctr);
+  hipLaunchKernelGGL(k_moments, dim3(kMomentBlocks), dim3(kBlock), 0, s, MomentsArgs{K, n_pts, key_mean, key_m2, partials, ctr});
 }
 
 // per-key count of points flagged by a detector kernel (DBSCAN / ARIMA), or of all points
@@ -472,8 +485,14 @@ __device__ __forceinline__ unsigned long long block_exclusive_scan(unsigned long
   return base + incl - x;
 }
 
+// MOMENTS: the blocks behind the scan's nb blocks are the kMomentBlocks blocks of the moments merge (same inputs' producer, one launch)
+template <bool MOMENTS>
 __global__ __launch_bounds__(kBlock) void k_scan_reduce(const uint32_t *__restrict__ cnt, uint64_t K,
-                                                        unsigned long long *__restrict__ bsum) {
+                                                        unsigned long long *__restrict__ bsum, uint32_t nb, MomentsArgs M) {
+  if (MOMENTS && blockIdx.x >= nb) {   // workgroup-uniform
+    moments_block(blockIdx.x - nb, M.K, M.n_pts, M.key_mean, M.key_m2, M.partials, M.ctr);
+    return;
+  }
   const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
   unsigned long long s = 0;
   for (int j = 0; j < kScanItems; ++j)
@@ -500,9 +519,13 @@ __global__ __launch_bounds__(kBlock) void k_scan_top(unsigned long long *bsum, u
   }
 }
 
+// OWN_BASE: bsum holds the raw block sums (no k_scan_top launch): every block adds up the sums before it itself — at most
+// kScanOwnBaseBlocks values — and block 0 writes the total (off[K] and the job tail)
+static constexpr uint64_t kScanOwnBaseBlocks = 4096;
+template <bool OWN_BASE>
 __global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restrict__ cnt, uint64_t K,
                                                        const unsigned long long *__restrict__ bsum,
-                                                       unsigned long long *__restrict__ off) {
+                                                       unsigned long long *__restrict__ off, uint32_t nb, unsigned long long *total_copy) {
   const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
   uint32_t c[kScanItems];
   unsigned long long s = 0;
@@ -510,8 +533,27 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restric
     c[j] = base + j < K ? cnt[base + j] : 0u;
     s += c[j];
   }
+  unsigned long long bbase;
+  if (OWN_BASE) {
+    unsigned long long before = 0, all = 0;
+    for (uint32_t i = threadIdx.x; i < nb; i += kBlock) {
+      const unsigned long long v = bsum[i];
+      all += v;
+      if (i < blockIdx.x) before += v;
+    }
+    unsigned long long t1, t2;
+    block_exclusive_scan(before, &t1);
+    block_exclusive_scan(all, &t2);
+    bbase = t1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      off[K] = t2;
+      if (total_copy != nullptr) *total_copy = t2;
+    }
+  } else {
+    bbase = bsum[blockIdx.x];
+  }
   unsigned long long tot;
-  unsigned long long ex = block_exclusive_scan(s, &tot) + bsum[blockIdx.x];
+  unsigned long long ex = block_exclusive_scan(s, &tot) + bbase;
   for (int j = 0; j < kScanItems; ++j) {
     if (base + j < K) off[base + j] = ex;
     ex += c[j];
@@ -520,6 +562,20 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const uint32_t *__restric
 
 size_t scan_scratch_elems(uint64_t K) { return (size_t)((K + kScanTile - 1) / kScanTile) + 1; }
 
+static void scan_launches(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K, unsigned long long *scratch,
+                          unsigned long long *total_copy, const MomentsArgs *M) {
+  const uint64_t nb = (K + kScanTile - 1) / kScanTile;
+  const MomentsArgs none{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (M != nullptr) hipLaunchKernelGGL(k_scan_reduce<true>, dim3((unsigned)nb + kMomentBlocks), dim3(kBlock), 0, s, cnt, K, scratch, (uint32_t)nb, *M);
+  else hipLaunchKernelGGL(k_scan_reduce<false>, dim3((unsigned)nb), dim3(kBlock), 0, s, cnt, K, scratch, (uint32_t)nb, none);
+  if (nb <= kScanOwnBaseBlocks) {   // two launches: the blocks of the second one derive their own base from the raw block sums
+    hipLaunchKernelGGL(k_scan_apply<true>, dim3((unsigned)nb), dim3(kBlock), 0, s, cnt, K, scratch, off, (uint32_t)nb, total_copy);
+    return;
+  }
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, scratch, nb, off + K, total_copy);
+  hipLaunchKernelGGL(k_scan_apply<false>, dim3((unsigned)nb), dim3(kBlock), 0, s, cnt, K, scratch, off, (uint32_t)nb, total_copy);
+}
+
 void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K,
                  unsigned long long *scratch, unsigned long long *total_copy) {
   if (K == 0) {
@@ -527,10 +583,20 @@ void launch_scan(hipStream_t s, const uint32_t *cnt, unsigned long long *off, ui
     if (total_copy != nullptr) hipMemsetAsync(total_copy, 0, sizeof(unsigned long long), s);
     return;
   }
-  const uint64_t nb = (K + kScanTile - 1) / kScanTile;
-  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(kBlock), 0, s, cnt, K, scratch);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, s, scratch, nb, off + K, total_copy);
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kBlock), 0, s, cnt, K, scratch, off);
+  scan_launches(s, cnt, off, K, scratch, total_copy, nullptr);
+}
+
+// the scan of the per-key row counts and the moments merge of the same per-key arrays in the scan's launches (one launch fewer)
+void launch_scan_moments(hipStream_t s, const uint32_t *cnt, unsigned long long *off, uint64_t K, unsigned long long *scratch,
+                         unsigned long long *total_copy, const uint32_t *n_pts, const double *key_mean, const double *key_m2, Moments *partials,
+                         DevCounters *ctr) {
+  if (K == 0) {
+    launch_scan(s, cnt, off, K, scratch, total_copy);
+    launch_moments(s, K, n_pts, key_mean, key_m2, partials, ctr);
+    return;
+  }
+  const MomentsArgs M{K, n_pts, key_mean, key_m2, partials, ctr};
+  scan_launches(s, cnt, off, K, scratch, total_copy, &M);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -384,44 +384,49 @@ __global__ __launch_bounds__(256) void k_part_offsets(OffsetsArgs A) {
   if (p < A.nparts) {   // wavefront-uniform
     const uint32_t b0 = p * A.bins_per_part;
     const uint32_t b1 = b0 + A.bins_per_part < A.nbins ? b0 + A.bins_per_part : A.nbins;
+    auto count_of = [&](uint32_t gi) -> uint32_t {   // record slots of workgroup gi in partition p
+      const uint32_t *row = A.binhist + (size_t)gi * A.nbins;
+      uint32_t c = 0;
+      for (uint32_t b = b0; b < b1; ++b) c += row[b];
+      if (A.partials != nullptr) {
+        const uint64_t lo = (uint64_t)gi * A.chunk;
+        const uint64_t rows = lo < A.n ? (lo + A.chunk < A.n ? A.chunk : A.n - lo) : 0;
+        const uint64_t seen = A.partials[gi].seen;
+        double scale = seen ? (double)rows / (double)seen : 1.0;
+        if (scale < 1.0) scale = 1.0;
+        c = sampled_capacity(c, scale);
+      }
+      return (c + A.round_mask) & ~A.round_mask;
+    };
+    constexpr uint32_t kKeep = 4;                      // G <= 256: the lane's counts stay in registers between the two loops
+    uint32_t kept[kKeep] = {0, 0, 0, 0};
     uint32_t sum = 0;
-    for (uint32_t j = 0; j < per; ++j) {
-      const uint32_t gi = lane * per + j;
-      if (gi < (uint32_t)A.G) {
-        const uint32_t *row = A.binhist + (size_t)gi * A.nbins;
-        uint32_t c = 0;
-        for (uint32_t b = b0; b < b1; ++b) c += row[b];
-        if (A.partials != nullptr) {
-          const uint64_t lo = (uint64_t)gi * A.chunk;
-          const uint64_t rows = lo < A.n ? (lo + A.chunk < A.n ? A.chunk : A.n - lo) : 0;
-          const uint64_t seen = A.partials[gi].seen;
-          double scale = seen ? (double)rows / (double)seen : 1.0;
-          if (scale < 1.0) scale = 1.0;
-          c = sampled_capacity(c, scale);
-        }
-        sum += (c + A.round_mask) & ~A.round_mask;
+    if (per <= kKeep) {
+#pragma unroll
+      for (uint32_t j = 0; j < kKeep; ++j) {
+        const uint32_t gi = lane * per + j;
+        if (j < per && gi < (uint32_t)A.G) { kept[j] = count_of(gi); sum += kept[j]; }
+      }
+    } else {
+      for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t gi = lane * per + j;
+        if (gi < (uint32_t)A.G) sum += count_of(gi);
       }
     }
     uint32_t incl = sum;
     for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += y; }
     uint32_t run = incl - sum;
     const uint32_t tot = __shfl(incl, 63);
-    for (uint32_t j = 0; j < per; ++j) {      // (the counts are recomputed instead of kept: `per` is not a compile-time constant)
-      const uint32_t gi = lane * per + j;
-      if (gi < (uint32_t)A.G) {
-        const uint32_t *row = A.binhist + (size_t)gi * A.nbins;
-        uint32_t c = 0;
-        for (uint32_t b = b0; b < b1; ++b) c += row[b];
-        if (A.partials != nullptr) {
-          const uint64_t lo = (uint64_t)gi * A.chunk;
-          const uint64_t rows = lo < A.n ? (lo + A.chunk < A.n ? A.chunk : A.n - lo) : 0;
-          const uint64_t seen = A.partials[gi].seen;
-          double scale = seen ? (double)rows / (double)seen : 1.0;
-          if (scale < 1.0) scale = 1.0;
-          c = sampled_capacity(c, scale);
-        }
-        A.offs32[(size_t)gi * A.nparts + p] = run;
-        run += (c + A.round_mask) & ~A.round_mask;
+    if (per <= kKeep) {
+#pragma unroll
+      for (uint32_t j = 0; j < kKeep; ++j) {
+        const uint32_t gi = lane * per + j;
+        if (j < per && gi < (uint32_t)A.G) { A.offs32[(size_t)gi * A.nparts + p] = run; run += kept[j]; }
+      }
+    } else {
+      for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t gi = lane * per + j;
+        if (gi < (uint32_t)A.G) { A.offs32[(size_t)gi * A.nparts + p] = run; run += count_of(gi); }
       }
     }
     if (lane == 0) A.total[p] = tot;   // v2 requires n_rows * 2 < 2^32 (checked on the host)
