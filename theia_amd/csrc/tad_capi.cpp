@@ -827,7 +827,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
       // DBSCAN job: pass C in settle mode — key rounds, the detector's per-key pass on the LDS tile, grid columns of unsettled keys only
-      SettleArgs settle{{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, 0.0, 0, 0};
+      SettleArgs settle{};
       jp.settled = false;
       if (jp.algo == TAD_ALGO_DBSCAN && !jp.all_points && !points_mode && !stream && dbscan_uses_list(g) && part_plan_settle(L.nb, &pl)) {
         if ((rc = ensure(e, e->aux, dbscan_scratch_bytes(g))) != TAD_OK) return rc;
@@ -840,6 +840,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         settle.eps = jp.eps;
         settle.min_samples = jp.min_samples;
         settle.on = 1;
+        dbscan_compact_series(g, e->aux.p, &settle.cs_val, &settle.cs_flag, &settle.cs_has, &settle.cs_cap);
         jp.settled = true;
       }
       launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap,

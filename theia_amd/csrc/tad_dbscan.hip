@@ -53,7 +53,8 @@ __device__ __forceinline__ ScanPart scan_merge(const ScanPart &a, const ScanPart
 // the lanes take the buckets in strides of 64 and merge their partials in a fixed xor tree (lower lane first).
 template <bool REDO_ONLY, bool COOP = false>
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, int min_samples, DbscanStats st,
-                                                         uint32_t *__restrict__ list, unsigned int *__restrict__ count) {
+                                                         uint32_t *__restrict__ list, unsigned int *__restrict__ count, uint8_t *__restrict__ cs_has,
+                                                         uint32_t cs_cap) {
   const uint64_t gtid = (uint64_t)blockIdx.x * kDbBlock + threadIdx.x;
   const uint64_t k = COOP ? gtid >> 6 : gtid;
   bool slow = false;
@@ -99,7 +100,11 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, in
     unsigned base = 0;
     if (lane == 0) base = atomicAdd(count, (unsigned)__popcll(m));
     base = __shfl(base, 0);
-    if (slow) list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)k;
+    if (slow) {
+      const unsigned e = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+      list[e] = (uint32_t)k;
+      if (cs_has != nullptr && e < cs_cap) cs_has[e] = 0;     // no contiguous series for this entry: the list kernel gathers from the grid
+    }
   }
 }
 
@@ -249,7 +254,9 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_sorted(Grid g, double eps, 
 template <int PPL>
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double eps, int min_samples, const uint32_t *__restrict__ list,
                                                               const unsigned int *__restrict__ count, uint32_t *__restrict__ n_anom,
-                                                              double *__restrict__ sg_e, unsigned long long *__restrict__ am_e) {
+                                                              double *__restrict__ sg_e, unsigned long long *__restrict__ am_e,
+                                                              const unsigned long long *__restrict__ cs_val, const uint8_t *__restrict__ cs_flag,
+                                                              const uint8_t *__restrict__ cs_has, uint32_t cs_cap) {
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x >> 6;
   const unsigned total = *count;
@@ -258,11 +265,17 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
     double x[PPL];
     bool p[PPL];
     unsigned long long pm[PPL];
+    const bool compact = cs_has != nullptr && e < cs_cap && cs_has[e] != 0;   // wavefront-uniform: the series lies contiguous behind the list
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const uint64_t t = lane + 64u * (unsigned)j;
-      p[j] = t < g.T && (g.flag[t * g.K + k] & FLAG_PRESENT);
-      x[j] = p[j] ? (double)g.val[t * g.K + k] : 0.0;
+      if (compact) {
+        p[j] = t < g.T && (cs_flag[(size_t)e * g.T + t] & FLAG_PRESENT);
+        x[j] = p[j] ? (double)cs_val[(size_t)e * g.T + t] : 0.0;
+      } else {
+        p[j] = t < g.T && (g.flag[t * g.K + k] & FLAG_PRESENT);
+        x[j] = p[j] ? (double)g.val[t * g.K + k] : 0.0;
+      }
       pm[j] = __ballot(p[j]);
     }
     int cnt[PPL];
@@ -389,8 +402,24 @@ static uint32_t sort_blocks(Grid g) {   // workgroups of the long-series form: b
   return (uint32_t)(b ? b : 1);
 }
 
+// contiguous series of the listed keys (T <= 256): cs_cap entries of T values + T flags, + one byte per entry
+static uint32_t compact_cap(Grid g) { const uint64_t c = g.K / 8 > 4096 ? g.K / 8 : 4096; return (uint32_t)(c < g.K ? c : g.K); }
+static size_t wave_list_bytes(Grid g) { return list_bytes(g) + (((size_t)g.K * (8 + 8 * 4) + 63) & ~(size_t)63); }
+static size_t compact_bytes(Grid g) { const size_t c = compact_cap(g); return ((c * g.T * 8 + 63) & ~(size_t)63) + ((c * g.T + 63) & ~(size_t)63) + ((c + 63) & ~(size_t)63); }
+
+void dbscan_compact_series(Grid g, void *scratch, unsigned long long **cs_val, uint8_t **cs_flag, uint8_t **cs_has, uint32_t *cs_cap) {
+  *cs_val = nullptr; *cs_flag = nullptr; *cs_has = nullptr; *cs_cap = 0;
+  if (g.T == 0 || g.T > 256 || g.K == 0) return;
+  const size_t c = compact_cap(g);
+  unsigned char *p = static_cast<unsigned char *>(scratch) + wave_list_bytes(g);
+  *cs_val = reinterpret_cast<unsigned long long *>(p); p += (c * g.T * 8 + 63) & ~(size_t)63;
+  *cs_flag = p; p += (c * g.T + 63) & ~(size_t)63;
+  *cs_has = p;
+  *cs_cap = (uint32_t)c;
+}
+
 size_t dbscan_scratch_bytes(Grid g) {
-  if (g.T <= 256) return list_bytes(g) + (size_t)g.K * (8 + 8 * 4);
+  if (g.T <= 256) return wave_list_bytes(g) + compact_bytes(g);
   if (g.T <= kSortLdsPoints) return list_bytes(g);
   return list_bytes(g) + (size_t)sort_blocks(g) * sort_cap(g.T) * 24 + 64;
 }
@@ -409,21 +438,24 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   unsigned int *count = static_cast<unsigned int *>(scratch);
   uint32_t *list = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + 64);
   const unsigned lane_blocks = (unsigned)((g.K + kDbBlock - 1) / kDbBlock);
-  if (settled_by_stage0) {   // the list was started by pass C (its counter zeroed before Stage 0)
-    hipLaunchKernelGGL((k_dbscan_scan<true, false>), dim3(lane_blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+  unsigned long long *cs_val; uint8_t *cs_flag, *cs_has; uint32_t cs_cap;
+  dbscan_compact_series(g, scratch, &cs_val, &cs_flag, &cs_has, &cs_cap);
+  if (settled_by_stage0) {   // the list was started by pass C (its counter zeroed before Stage 0), with the listed keys' series contiguous behind it
+    hipLaunchKernelGGL((k_dbscan_scan<true, false>), dim3(lane_blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, cs_has, cs_cap);
   } else {
+    cs_has = nullptr;        // nobody wrote contiguous series
     hipMemsetAsync(count, 0, sizeof(unsigned int), s);
     if (coop_shape(g))   // long series on few keys: a wavefront per key
-      hipLaunchKernelGGL((k_dbscan_scan<false, true>), dim3((unsigned)((g.K * 64 + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+      hipLaunchKernelGGL((k_dbscan_scan<false, true>), dim3((unsigned)((g.K * 64 + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, cs_has, cs_cap);
     else
-      hipLaunchKernelGGL((k_dbscan_scan<false, false>), dim3(lane_blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count);
+      hipLaunchKernelGGL((k_dbscan_scan<false, false>), dim3(lane_blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, cs_has, cs_cap);
   }
   // grid-stride over the (device-side) list length: 8192 workgroups of four wavefronts give every one of C4's ~2e4 listed keys its
   // own wavefront (2048: 2-3 keys per wavefront one after the other; detect + emit 0.179 -> 0.174 ms, 32768 the same:
   // profiles/r3_v9_c4_list_blocks_ab.log)
   uint64_t blocks = g.K < 8192 ? g.K : 8192;
   if (g.T <= 256) {   // a wavefront's registers hold the whole series
-#define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom, wave_list_sg(scratch, g), wave_list_am(scratch, g))
+#define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom, wave_list_sg(scratch, g), wave_list_am(scratch, g), cs_val, cs_flag, cs_has, cs_cap)
     if (g.T <= 64) TAD_DBW(1); else if (g.T <= 128) TAD_DBW(2); else if (g.T <= 192) TAD_DBW(3); else TAD_DBW(4);
 #undef TAD_DBW
     return 0;

@@ -1180,6 +1180,20 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
       if (threadIdx.x == 0 && s_nlist) s_lbase = atomicAdd(sa.count, s_nlist);   // one global reservation per tile
       __syncthreads();
       for (uint32_t i = threadIdx.x; i < s_nlist; i += kPartThreads) sa.list[s_lbase + i] = tile_list[i];
+      if (sa.cs_val != nullptr) {   // the listed keys' series, contiguous per list entry: a wavefront per key, lanes over the buckets
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        for (uint32_t i = wave; i < s_nlist; i += kPartThreads / 64) {
+          const uint32_t e = s_lbase + i;
+          if (e >= sa.cs_cap) continue;
+          const uint32_t kk = tile_list[i] - (uint32_t)(k0 + kt0);
+          for (uint32_t b = lane; b < nb; b += 64) {
+            const uint32_t c = __umul24(b, KT) + kk;
+            sa.cs_val[(size_t)e * nb + b] = vals[c];
+            sa.cs_flag[(size_t)e * nb + b] = flags[c];
+          }
+          if (lane == 0) sa.cs_has[e] = 1;
+        }
+      }
     }
     if (SETTLE) {   // 256 lanes per bucket row (KT <= 256 of them hold a key), four bucket rows per trip: no division by KT
       const uint32_t kk = threadIdx.x & 255u;
@@ -1515,7 +1529,7 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   const bool settle_on = settle.on != 0 && pl.settle_kt != 0;
   TileGeom tg{pl.shift_part, pl.cell_bits, pl.nparts, pl.tb, pl.n_chunks, par, slice_len, settle_on ? pl.settle_kt : 0u};
   const uint32_t blocks1 = par ? ((max_slices + 7u) / 8u) * 8u * pl.n_chunks : max_slices;
-  const SettleArgs none{{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, 0.0, 0, 0};
+  const SettleArgs none{};
 #define TAD_TA(OPMAX, SET)                                                                                                                            \
   do {                                                                                                                                               \
     allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<OPMAX, SET>), kLdsBudget);                                                         \
