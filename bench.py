@@ -125,13 +125,16 @@ def cpu_sample(algo, rows, keys, cores):
 
 
 def pmc_traffic(kernel, name="pmc_latest.json"):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes), or None."""
+    """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes), or None.  `job_*`: the sum over
+    every kernel of the job (each launches once per job since round 4; the table generator k_synth is not part of it)."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
         k = d["kernels"][kernel]
+        jf = sum(v["fetch_bytes"] for a, v in d["kernels"].items() if a != "k_synth")
+        jw = sum(v["write_bytes"] for a, v in d["kernels"].items() if a != "k_synth")
         return {"bytes": k["fetch_bytes"] + k["write_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
-                "source": d["source"]}
+                "job_bytes": jf + jw, "job_fetch_bytes": jf, "job_write_bytes": jw, "source": d["source"]}
     except Exception:
         return None
 
@@ -427,7 +430,7 @@ def main():
             d["baseline_config"] = name
             if name == "c4":     # PMC passes of `bench.py --config c4` (profiles/README.md)
                 d["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(r["stats"][0]["stage0_path"], "k_scatter"),
-                                                       "r3_v10_pmc_c4.json")
+                                                       "r4_m1_pmc_c4.json")
             if name == "c5":
                 d["scaling"] = "strong (this is the N = 1 base: `bench.py --config c5 --gpus N` splits the same table over N ranks)"
             elif not args.no_cpu_baseline:
