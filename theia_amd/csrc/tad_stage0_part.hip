@@ -790,6 +790,14 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
   uint32_t *nsp = gend + F;   // records spilled to the top of the region, downward from gend (a counter: it cannot wrap)
   uint16_t *jobs = reinterpret_cast<uint16_t *>(nsp + F);
   __shared__ uint32_t s_njobs;
+  // Records that find their queue full are PARKED here during the append phase and stored in the emit phase (round 4).  They used to be
+  // stored straight away — a global store between the LDS appends, for which the compiler drains the prefetched rows of the next tiles
+  // (vmcnt counts stores too on gfx9): with ~1 % of the records spilling three quarters of all wavefront-tiles took that drain, which is
+  // why whole 128-byte lines at 18 queue slots had measured 0.99 against 0.80 ms (profiles/r3_v8_c4_line18_ab.log).
+  constexpr uint32_t kSpillSlots = 288;
+  __shared__ unsigned long long s_spill_rec[kSpillSlots];
+  __shared__ uint32_t s_spill_at[kSpillSlots];
+  __shared__ uint32_t s_nspill;
 
   {
     const uint32_t *my = A.offs32 + (size_t)blockIdx.x * F;
@@ -802,7 +810,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       gcur[p] = ps + my[p];
       gend[p] = last ? (uint32_t)A.part_start[p + 1] : ps + nx[p];
     }
-    if (threadIdx.x == 0) s_njobs = 0;
+    if (threadIdx.x == 0) { s_njobs = 0; s_nspill = 0; }
   }
 
   const uint64_t lo = (uint64_t)blockIdx.x * A.chunk;
@@ -887,8 +895,12 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
           if (pos < cap) q[p * cap + pos] = rec;
           else {  // queue full (a burst, or a hot key): top of the region
             const uint32_t k = atomicAdd(&nsp[p], 1u);
-            if (k < gend[p] - gcur[p]) A.recs[gend[p] - 1u - k] = rec;   // (gcur only moves in the emit phase)
-            else err |= DEV_ERR_REGION_FULL;                              // sampled regions only: the region is full
+            if (k < gend[p] - gcur[p]) {                                  // (gcur only moves in the emit phase)
+              const uint32_t at = gend[p] - 1u - k;
+              const uint32_t sl = atomicAdd(&s_nspill, 1u);
+              if (sl < kSpillSlots) { s_spill_rec[sl] = rec; s_spill_at[sl] = at; }   // stored in the emit phase
+              else A.recs[at] = rec;                                       // a hot key: more spills in one tile than the buffer holds
+            } else err |= DEV_ERR_REGION_FULL;                             // sampled regions only: the region is full
           }
         }
       }
@@ -928,8 +940,12 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       if (mv) qp[sl] = tail;  // (one wavefront, LDS in order: every lane has read before any lane writes)
       if (sl == 0) { cnt[p] = c - whole; gcur[p] = g + whole; }
     }
+    {   // the parked spills of this tile
+      const uint32_t ns = s_nspill < kSpillSlots ? s_nspill : kSpillSlots;
+      for (uint32_t i = threadIdx.x; i < ns; i += kPartThreads) A.recs[s_spill_at[i]] = s_spill_rec[i];
+    }
     lds_barrier();
-    if (threadIdx.x == 0) s_njobs = 0;  // next used after the next tile's first barrier
+    if (threadIdx.x == 0) { s_njobs = 0; s_nspill = 0; }  // next used after the next tile's first barrier
   };
 
   Rows R0, R1;
@@ -1380,10 +1396,12 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, int partition_pass, P
   if (per < 18 + 8 * 9) return;
   uint32_t cap = (uint32_t)((per - 18) / 8);
   if (cap > 64) cap = 64;
-  uint32_t sec = cap >= 22 ? 16 : 8;   // 15 leftovers + room for a tile's arrivals (18 slots at C4's 977 partitions: pass B 0.80 -> 0.99 ms, the spills cost more than the lines save: profiles/r3_v8_c4_line18_ab.log)
+  // whole 128-byte lines need 15 leftovers + room for a tile's arrivals: 22 slots by the round-3 measurement; with the spills parked in LDS
+  // (round 4) partition_pass 3 asks for lines from 18 slots on, for the A/B at C4's 977 partitions
+  uint32_t sec = cap >= (partition_pass == 3 ? 18u : 22u) ? 16 : 8;   // (18 slots at C4's 977 partitions: pass B 0.80 -> 0.99 ms, the spills cost more than the lines save: profiles/r3_v8_c4_line18_ab.log)
   if (sec == 8 && cap > 16) cap = 16;
   // the sort-by-tile pass writes runs of (tile slots / partitions) records: long runs beat 64-byte sectors
-  const bool forced = partition_pass == 2;
+  const bool forced = partition_pass >= 2;
   if (!forced && sec == 8 && (uint64_t)pl->rpt * kPartThreads * (has2 ? 2 : 1) / pl->nparts >= 24) return;
   // few, large partitions: a tile brings more records per partition than a queue can take (and the sort pass writes long runs)
   if (!forced && 2.0 * kPartThreads * (has2 ? 2 : 1) / (double)pl->nparts > 0.5 * (double)(cap - (sec - 1))) return;
