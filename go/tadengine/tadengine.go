@@ -62,7 +62,7 @@ type Engine struct{ h *C.tad_engine }
 // C.tad_plan: cgo types are private to this package, callers in other packages could not construct one.
 type Plan struct {
 	Stage0        int32  // 1 = direct atomic scatter, 2 = partition + LDS tiles whatever the batch size
-	PartitionPass int32  // 1 = sort-by-tile pass B, 2 = write-combining pass B
+	PartitionPass int32  // 1 = sort-by-tile pass B, 2 = write-combining pass B, 3 = write-combining with 64-byte sectors only
 	Histogram     int32  // 1 = exact per-workgroup histogram in pass A
 	Sparse        int32  // 1 = never, 2 = always the sort-based Stage 0 for sparse tables
 	SparseClasses int32  // 1 = always run a sparse table as length classes of keys

@@ -76,7 +76,7 @@ typedef struct tad_engine tad_engine; /* opaque; one per GPU */
  * or an engine; since ABI 7 the library reads no environment variable at all. */
 typedef struct {
   int32_t stage0;            /* 1 = direct atomic scatter into the grid, 2 = partition + LDS tiles whatever the batch size */
-  int32_t partition_pass;    /* 1 = sort-by-tile pass B, 2 = write-combining pass B whenever its queues fit LDS, 3 = as 2 with whole 128-byte lines from 18 queue slots on (A/B) */
+  int32_t partition_pass;    /* 1 = sort-by-tile pass B, 2 = write-combining pass B whenever its queues fit LDS, 3 = as 2 but 64-byte sectors even where whole 128-byte lines fit (A/B) */
   int32_t histogram;         /* 1 = exact per-workgroup histogram in pass A (regions of pass B never sized from a sample) */
   int32_t sparse;            /* 1 = never, 2 = always the sort-based Stage 0 for sparse tables */
   int32_t sparse_classes;    /* 1 = always run a sparse table as length classes of keys */

@@ -1303,14 +1303,14 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   while (((K + (1ull << sp) - 1) >> sp) > kMaxParts && sp < 13) ++sp;
   if (((K + (1ull << sp) - 1) >> sp) > kMaxParts) return false;
   while (sp > pl->shift_bin && (1ull << (sp - 1)) >= K) --sp;  // no wider than the key space
-  // Whole 128-byte lines from the write-combining pass B need >= 22 queue slots per partition in LDS (part_plan_wc):
+  // Whole 128-byte lines from the write-combining pass B need >= 18 queue slots per partition in LDS (part_plan_wc):
   // widen the key block until the partitions are few enough, if pass C then needs at most twice the bucket rounds
   // (they run as parallel workgroups sharing an XCD's L2, k_tile_aggregate) and no more than 4.  C2: 1563 partitions of
   // 64 keys -> 782 of 128 keys, 2 rounds: partition pass 0.715 -> 0.59 ms, pass C 0.26 -> 0.29 ms.
   {
     auto parts_of = [&](int c) { return (K + (1ull << c) - 1) >> c; };
     auto rounds_of = [&](int c) { const uint64_t tb = kTileCells >> c; return tb ? (T + tb - 1) / tb : (uint64_t)1 << 30; };
-    const uint64_t line_parts = kLdsBudget / (8 * 22 + 18);
+    const uint64_t line_parts = kLdsBudget / (8 * 18 + 18);   // (18 slots: part_plan_wc)
     if (parts_of(sp) > line_parts) {
       int c = sp;
       while (c < 13 && parts_of(c) > line_parts) ++c;
@@ -1381,8 +1381,8 @@ bool columns_aligned16(const void *key, const void *key2, const void *t_end, con
   return aligned16(key) && aligned16(key2) && aligned16(t_end) && aligned16(value);
 }
 
-// write-combining pass B: F * (8 * cap + 14) bytes of LDS.  With >= 28 slots per partition the queues emit whole
-// 128-byte lines (16 records), with 9..21 slots 64-byte sectors; below 9 slots (more than ~1800 partitions) and for
+// write-combining pass B: F * (8 * cap + 18) bytes of LDS.  With >= 18 slots per partition the queues emit whole
+// 128-byte lines (16 records), with 9..17 slots 64-byte sectors; below 9 slots (more than ~1800 partitions) and for
 // tables with so few partitions that the sort-by-tile pass already writes long runs, the old pass runs.
 // partition_pass (tad_plan): 1 = always the sort-by-tile pass, 2 = the write-combining pass whenever its queues fit LDS.
 void part_plan_wc(uint64_t slots, bool aligned, bool has2, int partition_pass, PartPlan *pl) {
@@ -1396,9 +1396,11 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, int partition_pass, P
   if (per < 18 + 8 * 9) return;
   uint32_t cap = (uint32_t)((per - 18) / 8);
   if (cap > 64) cap = 64;
-  // whole 128-byte lines need 15 leftovers + room for a tile's arrivals: 22 slots by the round-3 measurement; with the spills parked in LDS
-  // (round 4) partition_pass 3 asks for lines from 18 slots on, for the A/B at C4's 977 partitions
-  uint32_t sec = cap >= (partition_pass == 3 ? 18u : 22u) ? 16 : 8;   // (18 slots at C4's 977 partitions: pass B 0.80 -> 0.99 ms, the spills cost more than the lines save: profiles/r3_v8_c4_line18_ab.log)
+  // Whole 128-byte lines: 15 leftovers + room for a tile's arrivals.  Round 3 asked for 22 slots (at C4's 977 partitions = 18 slots lines measured
+  // 0.99 against 0.80 ms for 64-byte sectors); that loss was the global store of the ~1 % spilled records between the LDS appends draining the
+  // prefetch, not the spills themselves: with the spills parked in LDS (round 4) lines win from 18 slots on — C4 pass B 0.797 -> 0.707 ms, job
+  // 1.867 -> 1.772 ms, same box alternating (profiles/r4_v10_ab_c4_lines18.log).  partition_pass 3 keeps the 64-byte sectors for the A/B.
+  uint32_t sec = (cap >= 18 && partition_pass != 3) ? 16 : 8;
   if (sec == 8 && cap > 16) cap = 16;
   // the sort-by-tile pass writes runs of (tile slots / partitions) records: long runs beat 64-byte sectors
   const bool forced = partition_pass >= 2;
