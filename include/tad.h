@@ -77,7 +77,7 @@ typedef struct tad_engine tad_engine; /* opaque; one per GPU */
 typedef struct {
   int32_t stage0;            /* 1 = direct atomic scatter into the grid, 2 = partition + LDS tiles whatever the batch size */
   int32_t partition_pass;    /* 1 = sort-by-tile pass B, 2 = write-combining pass B whenever its queues fit LDS, 3 = as 2 but 64-byte sectors even where whole 128-byte lines fit (A/B) */
-  int32_t histogram;         /* 1 = exact per-workgroup histogram in pass A (regions of pass B never sized from a sample) */
+  int32_t histogram;         /* 1 = exact per-workgroup histogram in pass A (regions of pass B never sized from a sample), 2 = sampled wherever possible (A/B) */
   int32_t sparse;            /* 1 = never, 2 = always the sort-based Stage 0 for sparse tables */
   int32_t sparse_classes;    /* 1 = always run a sparse table as length classes of keys */
   int32_t ewma_emit;         /* 1 = lane-per-key emit for the EWMA job instead of the LDS-staged one */

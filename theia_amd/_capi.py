@@ -25,7 +25,7 @@ class Plan(C.Structure):
 
 
 PLAN_VALUES = {   # symbolic values accepted by TadEngine(plan=...) / TadEngine.plan(...)
-    "stage0": {"auto": 0, "v1": 1, "v2": 2}, "partition_pass": {"auto": 0, "sort": 1, "wc": 2, "wc_sectors": 3}, "histogram": {"auto": 0, "exact": 1},
+    "stage0": {"auto": 0, "v1": 1, "v2": 2}, "partition_pass": {"auto": 0, "sort": 1, "wc": 2, "wc_sectors": 3}, "histogram": {"auto": 0, "exact": 1, "sampled": 2},
     "sparse": {"auto": 0, "never": 1, "always": 2}, "sparse_classes": {"auto": 0, "always": 1}, "ewma_emit": {"auto": 0, "staged": 0, "lane": 1}, "one_sync": {"auto": 0, "never": 1},
 }
 

@@ -97,7 +97,7 @@ constexpr int kMetaBlocks = 2048;
 constexpr int kSampleBlockShift = 7;   // (C4 with 1024-key blocks and a sampled histogram: pass A 0.21 -> 0.10 ms but pass C 0.68 -> 0.86 ms, profiles/r3_v2_c4_keyblock_ab.log)
 
 bool plan_ok(const tad_plan &p) {
-  return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 3 && p.histogram >= 0 && p.histogram <= 1 && p.sparse >= 0 &&
+  return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 3 && p.histogram >= 0 && p.histogram <= 2 && p.sparse >= 0 &&
          p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.one_sync >= 0 && p.one_sync <= 1;
 }
 constexpr uint32_t kOverflowCap = 1u << 20;  // Stage 0 v2: rows with a value >= 2^49 per run before falling back to v1
@@ -657,7 +657,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
                                       // 128-key block is expected to hold a few hundred records
                                       // (lat_mode 2 re-derives the lattice with k_meta, which reuses the partials buffer the sampling ratios live in)
                                       !force_exact_hist && lat_mode != 2 && sampled_slots_bound(n * (has2 ? 2 : 1), pl) < (1ull << 32) &&
-                                          n * (has2 ? 2 : 1) / ((uint64_t)pl.G * ((K >> kSampleBlockShift) ? (K >> kSampleBlockShift) : 1)) >= 384);
+                                          (plan.histogram == 2 ||      // (A/B: sampled wherever it is possible at all)
+                                           n * (has2 ? 2 : 1) / ((uint64_t)pl.G * ((K >> kSampleBlockShift) ? (K >> kSampleBlockShift) : 1)) >= 384));
       meta_blocks = pl.G;
     }
     if (!hinted && !empty && (!v2 || lat_mode == 2)) {

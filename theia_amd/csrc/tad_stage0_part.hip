@@ -1406,7 +1406,9 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, int partition_pass, P
   const bool forced = partition_pass >= 2;
   if (!forced && sec == 8 && (uint64_t)pl->rpt * kPartThreads * (has2 ? 2 : 1) / pl->nparts >= 24) return;
   // few, large partitions: a tile brings more records per partition than a queue can take (and the sort pass writes long runs)
-  if (!forced && 2.0 * kPartThreads * (has2 ? 2 : 1) / (double)pl->nparts > 0.5 * (double)(cap - (sec - 1))) return;
+  // (the mean arrivals of a tile must fit the room behind SEC - 1 leftovers; what exceeds it now and then is parked in LDS and stored in
+  // the emit phase — until round 4 the rule asked for twice the room, because a spill was a global store between the LDS appends)
+  if (!forced && 2.0 * kPartThreads * (has2 ? 2 : 1) / (double)pl->nparts > (double)(cap - (sec - 1))) return;
   // rows per thread: 4 when a queue holding SEC - 1 leftovers still has room for twice the expected arrivals of a tile
   const double lam4 = 4.0 * kPartThreads * (has2 ? 2 : 1) / (double)pl->nparts;
   const uint32_t rpt = !has2 && (double)(cap - (sec - 1)) >= 2.0 * lam4 + 4.0 ? 4 : 2;
