@@ -2,6 +2,8 @@
 """Host-side cost of the job OUTSIDE tad_run: prepare_columns (string predicates + dictionary encoding of the key columns,
 theia_amd/anomaly_detection.py) on a svc-mode table with C2's shape.  The numbers go into DESIGN.md section 5 next to the
 kernel times: with a real ClickHouse ingest this, not the 1.4 ms of GPU time, is what an operator waits for.
+With a GPU (round 4) the same calls are repeated with engine=TadEngine: the key tuples are factorised by tad_factorize instead of pandas (host
+columns: the copies to and from the GPU are inside the timing), and the default mode's six key columns are timed both ways.
 usage: python tools/host_prepare_timing.py [rows] [keys]"""
 import os
 import sys
@@ -52,3 +54,31 @@ for label, kw in (("svc, no filters", dict(agg_flow="svc")), ("svc, ns-ignore-li
     dt = time.perf_counter() - t0
     print("prepare_columns [%s]: %d rows / %d keys in %.2f s = %.2e rows/s on one host core (%d distinct keys found); table generation %.1f s"
           % (label, rows, keys, dt, rows / dt, prep.num_keys, t_gen))
+
+# ---- round 4: the same with the GPU factorisation (tad_factorize), if there is a GPU ----
+try:
+    from theia_amd import TadEngine
+    eng = TadEngine(device=0)
+except Exception as exc:      # no GPU here: the host figures above are all there is
+    print("no engine (%s): GPU factorisation not timed" % exc)
+    sys.exit(0)
+ad.prepare_columns(enc, agg_flow="svc", engine=eng)       # warm-up: scratch buffers
+for label, kw in (("svc, no filters", dict(agg_flow="svc")), ("svc, ns-ignore-list + time window", dict(agg_flow="svc", ns_ignore_list=["kube-system"],
+                                                                                                       start_time="2022-08-11 00:00:00", end_time="2022-08-12 00:00:00"))):
+    t0 = time.perf_counter()
+    prep = ad.prepare_columns(enc, engine=eng, **kw)
+    dt = time.perf_counter() - t0
+    print("dictionary-encoded columns, GPU factorisation: prepare_columns [%s]: %.2f s = %.2e rows/s (host columns: PCIe copies included), %d keys" % (label, dt, rows / dt, prep.num_keys))
+# the default mode (agg_flow None): six key columns per row (anomaly_detection.py:52-61)
+conn = rng.integers(0, max(1, rows // 100), size=rows)
+ips = np.array(["10.%d.%d.%d" % (i >> 16 & 255, i >> 8 & 255, i & 255) for i in range(4096)])
+none_flows = {"sourceIP": ad.DictColumn(conn % 4096, ips), "destinationIP": ad.DictColumn((conn * 7 + 3) % 4096, ips),
+              "sourceTransportPort": 1024 + conn % 50000, "destinationTransportPort": 80 + conn % 7, "protocolIdentifier": 6 + (conn % 2) * 11,
+              "flowStartSeconds": 1660200000 + conn // 16, "flowEndSeconds": flows["flowEndSeconds"], "throughput": flows["throughput"],
+              "sourcePodNamespace": enc["sourcePodNamespace"], "destinationPodNamespace": enc["destinationPodNamespace"]}
+for label, e in (("pandas MultiIndex, one core", None), ("GPU factorisation", eng)):
+    t0 = time.perf_counter()
+    prep = ad.prepare_columns(none_flows, agg_flow="", engine=e)
+    dt = time.perf_counter() - t0
+    print("default mode, six key columns [%s]: %.2f s = %.2e rows/s, %d keys" % (label, dt, rows / dt, prep.num_keys))
+eng.close()
