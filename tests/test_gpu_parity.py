@@ -547,7 +547,7 @@ def test_job_present_cells_that_aggregate_to_zero(engine, stage0, agg):
     assert (pv[pk == 3] == 0).all() and (pk == 3).sum() == 40
 
 
-@pytest.mark.parametrize("variant", ["plain", "hot_key", "overflow_values", "short_and_empty_keys"])
+@pytest.mark.parametrize("variant", ["plain", "hot_key", "overflow_values", "short_and_empty_keys", "values_around_2_32", "most_values_beyond_2_32"])
 def test_job_dbscan_settled_in_the_tile_pass(engine, stage0, variant):
     """DBSCAN jobs on the partition path run pass C in settle mode (tad_stage0_part.hip:k_tile_aggregate<.., true>): the tile pass
     decides per key whether it can have noise points and writes the grid columns of undecided keys only.  The cases it cannot see
@@ -563,6 +563,17 @@ def test_job_dbscan_settled_in_the_tile_pass(engine, stage0, variant):
     elif variant == "overflow_values":
         sel = rng.random(v.size) < 0.003
         v[sel] = rng.integers(2**50, 2**63, size=int(sel.sum()), dtype=np.uint64)       # overflow list -> whole job takes the redo walk
+    elif variant == "values_around_2_32":
+        # `max` jobs keep value + 1 in 32-bit tile cells (round 4): 2^32 - 2 is the largest value a cell holds, 2^32 - 1 and beyond take the
+        # overflow list and ONLY their keys are left to the redo walk (bitmap of keys); both kinds of keys, settled and listed ones
+        edge = np.array([2**32 - 3, 2**32 - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**33, 2**40 + 7], dtype=np.uint64)
+        sel = (k % np.uint64(7) == 2) & (rng.random(v.size) < 0.02)
+        v[sel] = edge[rng.integers(0, edge.size, size=int(sel.sum()))]
+        near = k % np.uint64(7) == 3                                                    # whole keys just below the limit: stay in the tile
+        v[near] = np.uint64(2**32 - 2) - (v[near] % np.uint64(1000))
+    elif variant == "most_values_beyond_2_32":
+        v = v + np.uint64(2**33)              # more than 2^20 values beyond the cell range: the overflow list fills up -> 8-byte cells (a retry)
+        k, t, v = np.tile(k, 2), np.concatenate([t, t]), np.concatenate([v, v + np.uint64(5)])
     elif variant == "short_and_empty_keys":
         keep = (k % np.uint64(50) != 3) | (rng.random(k.size) < 0.01)                    # keys with 0..3 points: every point is noise
         k, t, v = k[keep], t[keep], v[keep]
@@ -574,3 +585,7 @@ def test_job_dbscan_settled_in_the_tile_pass(engine, stage0, variant):
     assert res.stats["n_keys"] == want["n_keys"] and res.stats["n_points"] == want["n_points"]
     if stage0 != "v1":
         assert res.stats["stage0_path"] in (2, 3)
+        if variant == "most_values_beyond_2_32":
+            assert res.stats["stage0_attempts"] == 2          # 32-bit cells first, then 8-byte cells
+        if variant in ("values_around_2_32", "plain"):
+            assert res.stats["stage0_attempts"] == 1

@@ -50,6 +50,7 @@ struct tad_engine {
   DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
   DevBuf sp_cls;                                                                  // Stage 0 sparse, length classes: per-key class arrays
   DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
+  DevBuf ovf_keys;                                                                // Stage 0 v2, settle mode: bitmap of the keys with a value on the overflow list
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
@@ -70,6 +71,7 @@ struct tad_engine {
     Lattice L{};
     uint64_t rows = 0;
     bool exact_hist = false;   // the sampled histogram proved too optimistic for this table: go straight to the exact one
+    bool wide_tiles = false;   // 32-bit tile cells overflowed the list for this table: go straight to 8-byte cells
   } spec;
 };
 
@@ -270,7 +272,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part_fin, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part_fin, &e->ovf_keys, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -620,6 +622,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   const bool force_v2 = plan.stage0 == 2;
   const bool has2 = cols->key_id2 != nullptr;
   bool force_v1_retry = false;
+  bool force_wide_tiles = false;   // set when the overflow list filled up under 32-bit tile cells (many values >= 2^32 - 1): 8-byte cells next
   // pass A may histogram a SAMPLE of the rows (1/16 of the key column, plus the chunk ends, instead of all of it): pass B's regions are then sized from
   // the estimate with 6 sigma of slack; a region that still turns out too small (keys arriving in bursts the sample missed)
   // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  tad_plan.histogram = 1 disables it.
@@ -636,12 +639,14 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
                  sp.K == K && sp.has2 == has2 && sp.algo == (int)job->algo && sp.agg == (int)job->agg_flow && sp.op == (int)op_max && sp.flags == job->flags &&
                  sp.start == job->start_time && sp.end == job->end_time;
   if (spec_ok && sp.exact_hist) force_exact_hist = true;
+  if (spec_ok && sp.wide_tiles) force_wide_tiles = true;
   // retries: wrong hint -> derive (0 -> 1); sampled lattice too coarse / saw no live row -> exact (1 -> 2); overflow list
   // full -> Stage 0 v1; a missed speculation -> the plain form.  Each transition happens at most once, so 8 attempts cover every path.
-  for (int attempt = 0; attempt < 8; ++attempt) {
+  for (int attempt = 0; attempt < 9; ++attempt) {
     const bool hinted = lat_mode == 0;
     HIP_TRY(e, hipMemsetAsync(ctr, 0, kTailMoments, s));    // counters, row total, overflow-list count
     jp.settled = false;
+    bool narrow_tiles = false;
     PartPlan pl{};
     bool v2 = !empty && !force_v1 && !force_v1_retry && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
     if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
@@ -821,17 +826,19 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
       launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start,
                           hist_sampled, static_cast<const MetaPartial *>(e->meta.p), n, slots, e->slices.p, g, spec ? &L : nullptr, meta_blocks, ctr);
-      HIP_TRY(e, hipEventRecord(e->ev[2], s));
-      launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
-                       (const uint64_t *)d_val, n, K, rf, L, pl, offs32, part_start, e->recs.p, ovf, ovf_count, kOverflowCap, ctr, fin);
-      HIP_TRY(e, hipEventRecord(e->ev[3], s));
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
-      // DBSCAN job: pass C in settle mode — key rounds, the detector's per-key pass on the LDS tile, grid columns of unsettled keys only
+      // DBSCAN job: pass C in settle mode — key rounds, the detector's per-key pass on the LDS tile, grid columns of unsettled keys only.
+      // Decided BEFORE pass B: with `max` the tile cells are 32-bit words (value + 1; three key rounds instead of six at C4) and pass B keeps
+      // values >= 2^32 - 1 out of the records (overflow list + a bitmap of their keys, which alone are left to k_dbscan_scan).
       SettleArgs settle{};
       jp.settled = false;
-      if (jp.algo == TAD_ALGO_DBSCAN && !jp.all_points && !points_mode && !stream && dbscan_uses_list(g) && part_plan_settle(L.nb, &pl)) {
+      uint32_t *ovf_keys = nullptr;
+      if (jp.algo == TAD_ALGO_DBSCAN && !jp.all_points && !points_mode && !stream && dbscan_uses_list(g) && part_plan_settle(L.nb, &pl, op_max && !force_wide_tiles)) {
         if ((rc = ensure(e, e->aux, dbscan_scratch_bytes(g))) != TAD_OK) return rc;
+        if ((rc = ensure(e, e->ovf_keys, ((size_t)(K + 31) / 32) * 4 + 64)) != TAD_OK) return rc;
+        ovf_keys = static_cast<uint32_t *>(e->ovf_keys.p);
+        HIP_TRY(e, hipMemsetAsync(ovf_keys, 0, ((size_t)(K + 31) / 32) * 4, s));
         unsigned int *cnt = static_cast<unsigned int *>(e->aux.p);
         HIP_TRY(e, hipMemsetAsync(cnt, 0, sizeof(unsigned int), s));
         settle.st = DbscanStats{static_cast<uint32_t *>(e->n_pts.p), static_cast<uint32_t *>(e->n_anom.p), static_cast<double *>(e->key_mean.p),
@@ -841,9 +848,15 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         settle.eps = jp.eps;
         settle.min_samples = jp.min_samples;
         settle.on = 1;
+        settle.ovf_keys = ovf_keys;
         dbscan_compact_series(g, e->aux.p, &settle.cs_val, &settle.cs_flag, &settle.cs_has, &settle.cs_cap);
         jp.settled = true;
+        narrow_tiles = pl.narrow;
       }
+      HIP_TRY(e, hipEventRecord(e->ev[2], s));
+      launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
+                       (const uint64_t *)d_val, n, K, rf, L, pl, offs32, part_start, e->recs.p, ovf, ovf_count, kOverflowCap, ctr, fin, ovf_keys);
+      HIP_TRY(e, hipEventRecord(e->ev[3], s));
       launch_tile_aggregate(s, e->recs.p, part_start, pl, slots, e->slices.p, g, op_max, ovf, ovf_count, kOverflowCap,
                             hist_sampled ? offs32 : nullptr, fin, settle);
     } else {
@@ -905,6 +918,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       return fail(e, TAD_ERR_HIP, "internal error: a partition region overflowed with an exact histogram");
     }
     if (c.err & DEV_ERR_OVERFLOW_LIST) {  // more than kOverflowCap values >= 2^49: the packed records do not pay off, use v1
+      if (narrow_tiles && !force_wide_tiles) { force_wide_tiles = true; continue; }   // (... or >= 2^32 - 1 under 32-bit tile cells: 8-byte cells first)
       if (!force_v1_retry) { force_v1_retry = true; continue; }
       return fail(e, TAD_ERR_HIP, "internal error: overflow list full on the v1 path");
     }
@@ -1076,6 +1090,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       w.valid = v2 && !sparse && lat_mode == 1 && !force_v1_retry && !empty;
       w.n = n; w.K = K; w.has2 = has2; w.algo = (int)job->algo; w.agg = (int)job->agg_flow; w.op = (int)op_max; w.flags = job->flags;
       w.start = job->start_time; w.end = job->end_time; w.L = L; w.rows = rows; w.exact_hist = force_exact_hist && plan.histogram != 1;
+      w.wide_tiles = force_wide_tiles;
     }
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)

@@ -279,6 +279,7 @@ struct SettleArgs {
   uint8_t *cs_flag;
   uint8_t *cs_has;
   uint32_t cs_cap;
+  const uint32_t *ovf_keys;  // bitmap of the keys with a value on the overflow list (pass B): only THOSE keys are left to the scan; NULL: any overflow record sends every key there
 };
 // where launch_dbscan keeps the contiguous series inside its scratch (series of <= 256 buckets; cs_cap entries)
 void dbscan_compact_series(Grid g, void *scratch, unsigned long long **cs_val, uint8_t **cs_flag, uint8_t **cs_has, uint32_t *cs_cap);
@@ -319,6 +320,7 @@ struct PartPlan {
   int cell_bits;       // record = value << cell_bits | partition-local cell
   uint32_t tb, n_chunks;  // pass C: buckets per LDS round, rounds per partition
   uint32_t settle_kt;     // pass C in settle mode: keys per tile (0 = bucket rounds); then n_chunks = ceil(KP / settle_kt) key rounds, tb = T
+  bool narrow;            // settle mode with 32-bit tile cells (value + 1; `max` only): values >= 2^32 - 1 take the overflow list
   uint32_t wc_cap;        // write-combining pass B: queue slots per partition (0 = use the sort-by-tile pass B)
   uint32_t wc_sec, wc_rpt;  // wc: records per emitted piece (8 or 16), rows per thread per tile (2 or 4)
   uint64_t pad_slots;     // wc: upper bound of the filler slots (regions rounded up to whole 64-byte sectors)
@@ -351,14 +353,14 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f,
                       Lattice L, const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start,
                       void *recs, OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr,
-                      uint32_t *fin = nullptr);
+                      uint32_t *fin = nullptr, uint32_t *ovf_keys = nullptr);   // ovf_keys: bitmap (K bits, zeroed) of the keys with a value on the overflow list
 // slots = record slots of the run (rows x keys per row); slice_mem = slice_table_bytes(slots, pl) bytes of device scratch
 size_t slice_table_bytes(uint64_t slots, const PartPlan &pl);
 void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long long *part_start, const PartPlan &pl,
                            uint64_t slots, void *slice_mem, Grid g, bool op_max, const OverflowRec *ovf,
                            const unsigned long long *ovf_count, uint32_t ovf_cap, const uint32_t *offs32, const uint32_t *fin, SettleArgs settle);
 // whether pass C can run in settle mode for this plan (whole series of >= 8 keys fit an LDS tile; same number of rounds or fewer than 2x)
-bool part_plan_settle(uint64_t T, PartPlan *pl);
+bool part_plan_settle(uint64_t T, PartPlan *pl, bool narrow = false);
 
 // ---- Stage 0 for sparse tables: sort by (key, time), reduce, rank grid (tad_sparse.hip) ----
 size_t sparse_sort_temp_bytes(uint64_t slots);

@@ -530,6 +530,8 @@ struct PartArgs {
   DevCounters *ctr;
   uint32_t *fin;      // sampled regions (NULL = exact regions): [(g * nparts + p) * 2] = {end of the upward records, start of the spilled ones}
   int G;
+  unsigned long long value_limit;   // values >= this go to the overflow list: 2^(64 - cell_bits), or 2^32 - 1 for pass C's 32-bit tiles
+  uint32_t *ovf_keys;               // bitmap of the keys with a value on the overflow list (NULL = not kept)
 };
 
 // in-place exclusive scan of a[0..n) held in LDS by the whole workgroup; a[n] = total
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
   const bool has_ts = GENERIC && A.t_start != nullptr && A.f.start_time != 0;
   const uint32_t KP = A.kp_mask + 1u;
   const uint32_t cell_none = (1u << A.cell_bits) - 1u;
-  const unsigned long long value_limit = 1ull << (64 - A.cell_bits);
+  const unsigned long long value_limit = A.value_limit;
   uint32_t err = 0, used = 0;
 
   uint64_t pk[RPT], pk2[HAS2 ? RPT : 1], pv[RPT];
@@ -707,6 +709,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
               const unsigned long long o = atomicAdd(A.ovf_count, 1ull);
               if (o < A.ovf_cap) { A.ovf[o].val = pv[j]; A.ovf[o].gcell = (unsigned long long)bucket * A.K + k; }
               else err |= DEV_ERR_OVERFLOW_LIST;
+              if (A.ovf_keys != nullptr) atomicOr(A.ovf_keys + (k >> 5), 1u << (k & 31u));
             }
           } else {
             err |= DEV_ERR_OFF_LATTICE;  // wrong lattice hint, or the sampled gcd missed a residue: host re-derives
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
   const bool has_ts = GENERIC && A.t_start != nullptr && A.f.start_time != 0;
   const uint32_t KP = A.kp_mask + 1u;
   const uint32_t cell_none = (1u << A.cell_bits) - 1u;
-  const unsigned long long value_limit = 1ull << (64 - A.cell_bits);
+  const unsigned long long value_limit = A.value_limit;
   uint32_t err = 0, used = 0;
   const uint64_t nfull = hi > lo ? (hi - lo) / TILE : 0;
   const uint64_t ntiles = hi > lo ? (hi - lo + TILE - 1) / TILE : 0;
@@ -885,6 +888,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
               const unsigned long long o = atomicAdd(A.ovf_count, 1ull);
               if (o < A.ovf_cap) { A.ovf[o].val = r.v[j]; A.ovf[o].gcell = (unsigned long long)bucket * A.K + k; }
               else err |= DEV_ERR_OVERFLOW_LIST;
+              if (A.ovf_keys != nullptr) atomicOr(A.ovf_keys + (k >> 5), 1u << (k & 31u));
             }
           } else {
             err |= DEV_ERR_OFF_LATTICE;
@@ -1004,7 +1008,12 @@ struct TileGeom {
   uint32_t kt;          // settle mode: keys per tile (rounds split the partition by key sub-range); 0 = bucket rounds
 };
 
-template <bool OPMAX, bool SETTLE>
+// NARROW (settle mode with `max`, round 4): a tile cell is ONE 32-bit word, value + 1 (0 = absent) instead of 8 bytes + a flag byte: 2.25x the
+// keys per tile, three key rounds instead of six at C4 (1024 keys x 100 buckets) — every round streams the partition's records again, so the
+// pass costs what its rounds cost.  Values >= 2^32 - 1 do not fit: pass B sends them to the overflow list (as it does values that do not fit a
+// packed record) and marks their keys in a bitmap; the tile leaves exactly those keys to k_dbscan_scan (kSettleRedo), the fold adds the values to
+// the grid.  `max` only: a sum can outgrow 32 bits without any operand doing so.
+template <bool OPMAX, bool SETTLE, bool NARROW>
 __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__restrict__ recs,
                                                     const unsigned long long *__restrict__ part_start,
                                                     SliceTable st, TileGeom tg, Grid g,
@@ -1047,10 +1056,17 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
     const uint32_t cells = SETTLE ? nb * KT : nb << shift_part;
     const uint32_t c_lo = b_lo << shift_part;  // first partition-local cell of this round
     unsigned long long *vals = reinterpret_cast<unsigned long long *>(smem);
-    uint8_t *flags = smem + (size_t)(SETTLE ? tg.tb * KT : tg.tb << shift_part) * 8;
+    uint32_t *vals32 = reinterpret_cast<uint32_t *>(smem);          // NARROW: value + 1, 0 = absent
+    uint8_t *flags = smem + (size_t)(SETTLE ? tg.tb * KT : tg.tb << shift_part) * (NARROW ? 4 : 8);   // (NARROW: no flag bytes; the settle bookkeeping starts here)
+    auto cell_present = [&](uint32_t c) -> bool { return NARROW ? vals32[c] != 0u : (flags[c] & FLAG_PRESENT) != 0; };
+    auto cell_value = [&](uint32_t c) -> unsigned long long { return NARROW ? (unsigned long long)(vals32[c] - 1u) : vals[c]; };   // (of a present cell)
     if (chunk != r_lo) __syncthreads();  // the previous round's tile has been written out
-    for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
-    for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
+    if (NARROW) {
+      for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals32[c] = 0u;
+    } else {
+      for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
+      for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
+    }
     __syncthreads();
     auto apply = [&](unsigned long long r) {
       const uint32_t cg = (uint32_t)r & cell_none;
@@ -1061,6 +1077,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         c = __umul24(cg >> shift_part, KT) + kk;   // (bucket < 2^16, KT <= 256: the 24-bit multiply issues at full rate, v_mul_lo_u32 at a quarter)
       } else if (c >= cells) return;   // (also rejects `no cell`: the all-ones cell is >= KP * T, plan_tiles reserves it)
       const unsigned long long v = r >> tg.cell_bits;
+      if (NARROW) { atomicMax(&vals32[c], (uint32_t)v + 1u); return; }     // (pass B kept values >= 2^32 - 1 out of the records)
       if (OPMAX) atomicMax(&vals[c], v);
       else atomicAdd(&vals[c], v);
       flags[c] = FLAG_PRESENT;
@@ -1132,11 +1149,12 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
     __syncthreads();
     // SETTLE: k_dbscan_scan's per-key pass on the LDS tile (one thread per key, buckets in order: the same operations in the
     // same order, so n / mean / M2 are that kernel's bits), then only the columns of unsettled keys are written
-    uint8_t *settled = flags + (((size_t)(SETTLE ? tg.tb * KT : 0u)) + 3 & ~(size_t)3);   // [KT] u8, then the tile's listed keys [KT] u32
+    uint8_t *settled = flags + (((size_t)((SETTLE && !NARROW) ? tg.tb * KT : 0u)) + 3 & ~(size_t)3);   // [KT] u8, then the tile's listed keys [KT] u32
     uint32_t *tile_list = reinterpret_cast<uint32_t *>(settled + ((KT + 3u) & ~3u));
     bool skip_cols = false;
     if (SETTLE) {
-      skip_cols = !split && *ovf_count_in == 0ull;
+      // (without the per-key bitmap any record on the overflow list sends the whole job to the redo path)
+      skip_cols = !split && (sa.ovf_keys != nullptr || *ovf_count_in == 0ull);
       if (threadIdx.x == 0) { s_nlist = 0; }
       __syncthreads();
       // Four threads per key (adjacent lanes), each over every fourth bucket with its own first value as the shift of its sums;
@@ -1151,8 +1169,8 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         if (live && skip_cols) {
           for (uint32_t b = part; b < nb; b += 4u) {
             const uint32_t c = __umul24(b, KT) + kk;
-            if (flags[c] & FLAG_PRESENT) {
-              const double x = (double)vals[c];
+            if (cell_present(c)) {
+              const double x = (double)cell_value(c);
               if (n == 0) { mn = x; mx = x; x0 = x; }
               mn = fmin(mn, x);
               mx = fmax(mx, x);
@@ -1182,7 +1200,9 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         }
         if (part != 0 || kk >= KT) continue;
         if (!live) { settled[kk] = 1; continue; }
-        if (!skip_cols) { sa.st.n_pts[k] = kSettleRedo; settled[kk] = 0; continue; }
+        // a key with a value on the overflow list is incomplete in the tile: its column is written, the fold completes it, the scan redoes it
+        const bool key_ovf = sa.ovf_keys != nullptr && ((sa.ovf_keys[k >> 5] >> (k & 31u)) & 1u) != 0;
+        if (!skip_cols || key_ovf) { sa.st.n_pts[k] = kSettleRedo; settled[kk] = 0; continue; }
         const bool slow = n > 0 && (!(mx - mn <= sa.eps) || n < (uint32_t)sa.min_samples);
         sa.st.n_pts[k] = n;
         sa.st.n_anom[k] = 0;
@@ -1204,27 +1224,31 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
           const uint32_t kk = tile_list[i] - (uint32_t)(k0 + kt0);
           for (uint32_t b = lane; b < nb; b += 64) {
             const uint32_t c = __umul24(b, KT) + kk;
-            sa.cs_val[(size_t)e * nb + b] = vals[c];
-            sa.cs_flag[(size_t)e * nb + b] = flags[c];
+            const bool pr = cell_present(c);
+            sa.cs_val[(size_t)e * nb + b] = pr ? cell_value(c) : 0ull;
+            sa.cs_flag[(size_t)e * nb + b] = pr ? FLAG_PRESENT : 0;
           }
           if (lane == 0) sa.cs_has[e] = 1;
         }
       }
     }
-    if (SETTLE) {   // 256 lanes per bucket row (KT <= 256 of them hold a key), four bucket rows per trip: no division by KT
-      const uint32_t kk = threadIdx.x & 255u;
-      const uint64_t k = k0 + kt0 + kk;
-      if (kk < KT && kt0 + kk < KP && k < g.K && !(skip_cols && settled[kk])) {
-        for (uint32_t b = threadIdx.x >> 8; b < nb; b += kPartThreads / 256) {
-          const uint32_t c = __umul24(b, KT) + kk;
-          const uint64_t gc = (uint64_t)b * g.K + k;
-          if (!split) {
-            g.val[gc] = vals[c];
-            g.flag[gc] = flags[c];
-          } else if (flags[c]) {
-            if (OPMAX) __hip_atomic_fetch_max(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else __hip_atomic_fetch_add(g.val + gc, vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g.flag[gc] = FLAG_PRESENT;
+    if (SETTLE) {   // 256 lanes per bucket row (every 256th key of the tile per lane), four bucket rows per trip: no division by KT
+      for (uint32_t kk = threadIdx.x & 255u; kk < KT; kk += 256u) {
+        const uint64_t k = k0 + kt0 + kk;
+        if (kt0 + kk < KP && k < g.K && !(skip_cols && settled[kk])) {
+          for (uint32_t b = threadIdx.x >> 8; b < nb; b += kPartThreads / 256) {
+            const uint32_t c = __umul24(b, KT) + kk;
+            const uint64_t gc = (uint64_t)b * g.K + k;
+            const bool pr = cell_present(c);
+            const unsigned long long cv = pr ? cell_value(c) : 0ull;
+            if (!split) {
+              g.val[gc] = cv;
+              g.flag[gc] = pr ? FLAG_PRESENT : 0;
+            } else if (pr) {
+              if (OPMAX) __hip_atomic_fetch_max(g.val + gc, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else __hip_atomic_fetch_add(g.val + gc, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              g.flag[gc] = FLAG_PRESENT;
+            }
           }
         }
       }
@@ -1247,13 +1271,14 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
   }
 }
 
-template <bool OPMAX, bool SETTLE = false>
+template <bool OPMAX, bool SETTLE = false, bool NARROW = false>
 __global__ __launch_bounds__(kPartThreads) void k_tile_aggregate(const unsigned long long *__restrict__ recs,
                                                                  const unsigned long long *__restrict__ part_start,
                                                                  SliceTable st, TileGeom tg, Grid g,
                                                                  const uint32_t *__restrict__ offs32, const uint32_t *__restrict__ fin, int G,
                                                                  SettleArgs sa, const unsigned long long *__restrict__ ovf_count) {
-  tile_aggregate_body<OPMAX, SETTLE>(recs, part_start, st, tg, g, offs32, fin, G, sa, ovf_count);
+  static_assert(!NARROW || (OPMAX && SETTLE), "32-bit tile cells: settle mode with max only");
+  tile_aggregate_body<OPMAX, SETTLE, NARROW>(recs, part_start, st, tg, g, offs32, fin, G, sa, ovf_count);
 }
 
 // records whose value did not fit the packed form: fold them into the finished grid (agent-scope integer atomics).
@@ -1357,12 +1382,14 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
 // Settle mode of pass C (DBSCAN jobs): kt = the most keys whose WHOLE series fit one LDS tile (9 B per cell + 5 B per key of
 // settle bookkeeping); the partition's rounds then split it by key sub-range.  Adopted when that does not take more rounds than the
 // bucket rounds it replaces (every round streams the partition's records again).
-bool part_plan_settle(uint64_t T, PartPlan *pl) {
+bool part_plan_settle(uint64_t T, PartPlan *pl, bool narrow) {
   pl->settle_kt = 0;
+  pl->narrow = false;
   if (T == 0) return false;
-  uint32_t kt = (uint32_t)((kLdsBudget - 64) / (T * 9 + 5));
+  const size_t cell = narrow ? 4 : 9;     // narrow: one 32-bit word per cell (value + 1), `max` only
+  uint32_t kt = (uint32_t)((kLdsBudget - 64) / (T * cell + 5));
   if (kt > pl->KP) kt = pl->KP;
-  if (kt > 256) kt = 256;     // (the write-out maps 256 lanes to a bucket row)
+  if (kt > 1024) kt = 1024;
   if (kt < 8) return false;
   const uint32_t rounds = (pl->KP + kt - 1) / kt;
   if (rounds > pl->n_chunks + 1 && rounds > 1) return false;
@@ -1370,8 +1397,9 @@ bool part_plan_settle(uint64_t T, PartPlan *pl) {
   pl->settle_kt = kt;
   pl->n_chunks = rounds;
   pl->tb = (uint32_t)T;
-  pl->agg_lds = (((size_t)T * kt * 9 + 3) & ~(size_t)3) + (((size_t)kt + 3) & ~(size_t)3) + (size_t)kt * 4 + 16;
+  pl->agg_lds = (((size_t)T * kt * cell + 3) & ~(size_t)3) + (((size_t)kt + 3) & ~(size_t)3) + (size_t)kt * 4 + 16;
   pl->agg_lds = (pl->agg_lds + 15) & ~(size_t)15;
+  pl->narrow = narrow;
   return true;
 }
 
@@ -1480,9 +1508,12 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, Lattice L,
                       const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start, void *recs,
-                      OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr, uint32_t *fin) {
+                      OverflowRec *ovf, unsigned long long *ovf_count, uint32_t ovf_cap, DevCounters *ctr, uint32_t *fin, uint32_t *ovf_keys) {
   PartArgs A;
   A.fin = fin; A.G = pl.G;
+  A.value_limit = 1ull << (64 - pl.cell_bits);
+  if (pl.narrow && A.value_limit > 0xFFFFFFFFull) A.value_limit = 0xFFFFFFFFull;   // pass C keeps value + 1 in 32 bits
+  A.ovf_keys = ovf_keys;
   A.key = key; A.key2 = key2; A.t_end = t_end; A.t_start = t_start; A.value = value;
   A.n = n; A.chunk = pl.chunk; A.K = K; A.f = f; A.L = L;
   A.shift_part = pl.shift_part; A.kp_mask = pl.KP - 1; A.nparts = pl.nparts; A.cell_bits = pl.cell_bits;
@@ -1559,7 +1590,11 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
                        SET ? settle : none, ovf_count);                                                                                               \
     hipLaunchKernelGGL((k_apply_overflow<OPMAX>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);                                             \
   } while (0)
-  if (settle_on) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }
+  if (settle_on && pl.narrow && op_max) {
+    allow_big_lds(reinterpret_cast<const void *>(k_tile_aggregate<true, true, true>), kLdsBudget);
+    hipLaunchKernelGGL((k_tile_aggregate<true, true, true>), dim3(blocks1), dim3(kPartThreads), pl.agg_lds, s, rr, part_start, st, tg, g, offs32, fin, pl.G, settle, ovf_count);
+    hipLaunchKernelGGL((k_apply_overflow<true>), dim3(64), dim3(256), 0, s, ovf, ovf_count, ovf_cap, g);
+  } else if (settle_on) { if (op_max) TAD_TA(true, true); else TAD_TA(false, true); }
   else { if (op_max) TAD_TA(true, false); else TAD_TA(false, false); }
 #undef TAD_TA
 }
