@@ -69,12 +69,13 @@ type Plan struct {
 	EwmaEmit      int32  // 1 = lane-per-key emit for the EWMA job
 	EwmaEmitRows  uint32 // LDS rows per wavefront of the staged EWMA emit (<= 4096)
 	OneSync       int32  // 1 = never run a job in the one-synchronisation form
+	TileCells     int32  // 1 = 8-byte tile cells in the settle mode of DBSCAN jobs with max
 }
 
 func (p Plan) c() C.tad_plan {
 	return C.tad_plan{stage0: C.int32_t(p.Stage0), partition_pass: C.int32_t(p.PartitionPass), histogram: C.int32_t(p.Histogram),
 		sparse: C.int32_t(p.Sparse), sparse_classes: C.int32_t(p.SparseClasses), ewma_emit: C.int32_t(p.EwmaEmit),
-		ewma_emit_rows: C.uint32_t(p.EwmaEmitRows), one_sync: C.int32_t(p.OneSync)}
+		ewma_emit_rows: C.uint32_t(p.EwmaEmitRows), one_sync: C.int32_t(p.OneSync), tile_cells: C.int32_t(p.TileCells)}
 }
 
 func NewEngine(device int) (*Engine, error) { return NewEngineWithPlan(device, Plan{}) }

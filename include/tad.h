@@ -83,6 +83,8 @@ typedef struct {
   int32_t ewma_emit;         /* 1 = lane-per-key emit for the EWMA job instead of the LDS-staged one */
   uint32_t ewma_emit_rows;   /* LDS rows per wavefront of the staged EWMA emit (<= 4096); 0 = sized from the row count */
   int32_t one_sync;          /* 1 = never run a job in the one-synchronisation form (ABI 8; see tad_stats.host_syncs) */
+  int32_t tile_cells;        /* 1 = 8-byte tile cells in the settle mode of DBSCAN jobs with `max` (ABI 8; default: 32-bit cells, value + 1) */
+  int32_t reserved;          /* 0 */
 } tad_plan;
 
 typedef struct {

@@ -100,7 +100,7 @@ constexpr int kSampleBlockShift = 7;   // (C4 with 1024-key blocks and a sampled
 
 bool plan_ok(const tad_plan &p) {
   return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 3 && p.histogram >= 0 && p.histogram <= 2 && p.sparse >= 0 &&
-         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.one_sync >= 0 && p.one_sync <= 1;
+         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.one_sync >= 0 && p.one_sync <= 1 && p.tile_cells >= 0 && p.tile_cells <= 1 && p.reserved == 0;
 }
 constexpr uint32_t kOverflowCap = 1u << 20;  // Stage 0 v2: rows with a value >= 2^49 per run before falling back to v1
 
@@ -622,7 +622,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   const bool force_v2 = plan.stage0 == 2;
   const bool has2 = cols->key_id2 != nullptr;
   bool force_v1_retry = false;
-  bool force_wide_tiles = false;   // set when the overflow list filled up under 32-bit tile cells (many values >= 2^32 - 1): 8-byte cells next
+  bool force_wide_tiles = plan.tile_cells == 1;   // set when the overflow list filled up under 32-bit tile cells (many values >= 2^32 - 1): 8-byte cells next
   // pass A may histogram a SAMPLE of the rows (1/16 of the key column, plus the chunk ends, instead of all of it): pass B's regions are then sized from
   // the estimate with 6 sigma of slack; a region that still turns out too small (keys arriving in bursts the sample missed)
   // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  tad_plan.histogram = 1 disables it.
@@ -840,7 +840,9 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         ovf_keys = static_cast<uint32_t *>(e->ovf_keys.p);
         HIP_TRY(e, hipMemsetAsync(ovf_keys, 0, ((size_t)(K + 31) / 32) * 4, s));
         unsigned int *cnt = static_cast<unsigned int *>(e->aux.p);
-        HIP_TRY(e, hipMemsetAsync(cnt, 0, sizeof(unsigned int), s));
+        HIP_TRY(e, hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), s));    // work-list and redo-list lengths
+        settle.redo_list = dbscan_redo_list(g, e->aux.p);
+        settle.redo_count = cnt + 1;
         settle.st = DbscanStats{static_cast<uint32_t *>(e->n_pts.p), static_cast<uint32_t *>(e->n_anom.p), static_cast<double *>(e->key_mean.p),
                                 static_cast<double *>(e->key_m2.p)};
         settle.list = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(e->aux.p) + 64);
@@ -1090,7 +1092,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       w.valid = v2 && !sparse && lat_mode == 1 && !force_v1_retry && !empty;
       w.n = n; w.K = K; w.has2 = has2; w.algo = (int)job->algo; w.agg = (int)job->agg_flow; w.op = (int)op_max; w.flags = job->flags;
       w.start = job->start_time; w.end = job->end_time; w.L = L; w.rows = rows; w.exact_hist = force_exact_hist && plan.histogram != 1;
-      w.wide_tiles = force_wide_tiles;
+      w.wide_tiles = force_wide_tiles && plan.tile_cells != 1;
     }
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
     if (stream && g.K) stream->cur ^= 1;   // the batch succeeded: the candidate state becomes current (an empty batch wrote none)

@@ -108,6 +108,48 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, in
   }
 }
 
+// k_dbscan_scan_redo — k_dbscan_scan for the keys of the REDO LIST only (settle mode: the keys the tile pass could not decide), a wavefront
+// per key: the lanes take the buckets in strides of 64, partial statistics merged in a fixed xor tree (the COOP form of k_dbscan_scan).
+__global__ __launch_bounds__(kDbBlock) void k_dbscan_scan_redo(Grid g, double eps, int min_samples, DbscanStats st, const uint32_t *__restrict__ redo,
+                                                              const unsigned int *__restrict__ redo_count, uint32_t *__restrict__ list,
+                                                              unsigned int *__restrict__ count, uint8_t *__restrict__ cs_has, uint32_t cs_cap) {
+  const unsigned lane = lane_id();
+  const unsigned total = *redo_count;
+  for (unsigned e = blockIdx.x * kDbWaves + (threadIdx.x >> 6); e < total; e += gridDim.x * kDbWaves) {   // wavefront-uniform
+    const uint64_t k = redo[e];
+    ScanPart a{0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (uint64_t t = lane; t < g.T; t += 64) {
+      if (g.flag[t * g.K + k] & FLAG_PRESENT) {
+        const double x = (double)g.val[t * g.K + k];
+        if (a.n == 0) { a.mn = x; a.mx = x; a.x0 = x; }
+        a.mn = fmin(a.mn, x);
+        a.mx = fmax(a.mx, x);
+        const double d = x - a.x0;
+        a.s1 += d;
+        a.s2 += d * d;
+        a.n++;
+      }
+    }
+    for (int d = 1; d < 64; d <<= 1) {
+      ScanPart o{__shfl_xor(a.n, d), __shfl_xor(a.mn, d), __shfl_xor(a.mx, d), __shfl_xor(a.x0, d), __shfl_xor(a.s1, d), __shfl_xor(a.s2, d)};
+      a = (lane & (unsigned)d) ? scan_merge(o, a) : scan_merge(a, o);
+    }
+    if (lane == 0) {
+      const bool slow = a.n > 0 && (!(a.mx - a.mn <= eps) || a.n < (uint32_t)min_samples);
+      st.n_pts[k] = a.n;
+      st.n_anom[k] = 0;
+      const double dn = (double)(a.n ? a.n : 1);
+      st.key_mean[k] = a.n ? a.x0 + a.s1 / dn : 0.0;
+      st.key_m2[k] = a.n ? fmax(a.s2 - a.s1 * (a.s1 / dn), 0.0) : 0.0;
+      if (slow) {
+        const unsigned at = atomicAdd(count, 1u);
+        list[at] = (uint32_t)k;
+        if (cs_has != nullptr && at < cs_cap) cs_has[at] = 0;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_dbscan_sorted — the exact noise predicate for listed keys with series of more than 256 buckets, on SORTED values.
 // |x_i - x_j| <= eps is evaluated as the FP64 difference of the two correctly rounded values (what sklearn's distance computes);
@@ -388,11 +430,13 @@ __global__ __launch_bounds__(kDbBlock) void k_emit_dbscan_wave(Grid g, Lattice L
   }
 }
 
-// Scratch of one DBSCAN launch: count (64 B) | list[K] u32 | then, by series length,
+// Scratch of one DBSCAN launch: counters (64 B: work-list length, redo-list length) | list[K] u32 | redo list[K] u32 | then, by series length,
 //   T <= 256                : sg[K] f64 | am[K * 4] u64          (what k_dbscan_list_wave leaves for the emit)
 //   T <= kSortLdsPoints     : nothing (k_dbscan_sorted works in LDS)
 //   longer                  : per-workgroup rows of k_dbscan_sorted, 24 B per point, cap = T rounded up to a power of two
-static size_t list_bytes(Grid g) { return 64 + (((size_t)g.K * 4 + 63) & ~(size_t)63); }
+static size_t one_list_bytes(Grid g) { return ((size_t)g.K * 4 + 63) & ~(size_t)63; }
+static size_t list_bytes(Grid g) { return 64 + 2 * one_list_bytes(g); }     // counters | work list | redo list
+uint32_t *dbscan_redo_list(Grid g, void *scratch) { return reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + 64 + one_list_bytes(g)); }
 static uint32_t sort_cap(uint64_t T) { uint32_t c = 1; while (c < T) c <<= 1; return c; }
 static uint32_t sort_blocks(Grid g) {   // workgroups of the long-series form: bounded scratch (256 MB), at least one
   const uint64_t per = (uint64_t)sort_cap(g.T) * 24;
@@ -440,8 +484,11 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   const unsigned lane_blocks = (unsigned)((g.K + kDbBlock - 1) / kDbBlock);
   unsigned long long *cs_val; uint8_t *cs_flag, *cs_has; uint32_t cs_cap;
   dbscan_compact_series(g, scratch, &cs_val, &cs_flag, &cs_has, &cs_cap);
-  if (settled_by_stage0) {   // the list was started by pass C (its counter zeroed before Stage 0), with the listed keys' series contiguous behind it
-    hipLaunchKernelGGL((k_dbscan_scan<true, false>), dim3(lane_blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, st, list, count, cs_has, cs_cap);
+  if (settled_by_stage0) {   // the list was started by pass C (its counters zeroed before Stage 0), with the listed keys' series contiguous behind it;
+    // the keys it could not decide are on the redo list
+    const uint64_t rb = g.K < 4096 ? g.K : 4096;
+    hipLaunchKernelGGL(k_dbscan_scan_redo, dim3((unsigned)rb), dim3(kDbBlock), 0, s, g, eps, min_samples, st, dbscan_redo_list(g, scratch), count + 1, list, count,
+                       cs_has, cs_cap);
   } else {
     cs_has = nullptr;        // nobody wrote contiguous series
     hipMemsetAsync(count, 0, sizeof(unsigned int), s);

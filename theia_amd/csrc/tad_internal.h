@@ -279,10 +279,14 @@ struct SettleArgs {
   uint8_t *cs_flag;
   uint8_t *cs_has;
   uint32_t cs_cap;
+  uint32_t *redo_list;       // keys the tile pass could not decide (split partition, a value on the overflow list): walked by k_dbscan_scan_redo,
+  unsigned int *redo_count;  //   a wavefront per listed key (a lane-per-key pass over ALL keys to find 1 % of them cost a whole scan: 122 us at C4)
   const uint32_t *ovf_keys;  // bitmap of the keys with a value on the overflow list (pass B): only THOSE keys are left to the scan; NULL: any overflow record sends every key there
 };
 // where launch_dbscan keeps the contiguous series inside its scratch (series of <= 256 buckets; cs_cap entries)
 void dbscan_compact_series(Grid g, void *scratch, unsigned long long **cs_val, uint8_t **cs_flag, uint8_t **cs_has, uint32_t *cs_cap);
+// the redo list inside launch_dbscan's scratch: its counter is the second word of the scratch (zeroed with the list counter: 8 bytes)
+uint32_t *dbscan_redo_list(Grid g, void *scratch);
 static constexpr uint32_t kSettleRedo = 0xFFFFFFFFu;
 size_t dbscan_scratch_bytes(Grid g);
 bool dbscan_uses_list(Grid g);

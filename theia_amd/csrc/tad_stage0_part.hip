@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
   const uint64_t k0 = (uint64_t)p << shift_part;
   // (the grid tile of a split partition was zeroed by k_part_offsets: its slices merge with atomics)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t s_nlist, s_lbase;
+  __shared__ uint32_t s_nlist, s_lbase, s_nredo, s_rbase;
   const uint32_t cell_none = (1u << tg.cell_bits) - 1u;
   const unsigned long long plo = part_start[p], phi = part_start[p + 1];
   const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * tg.slice_len;
@@ -1151,11 +1151,12 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
     // same order, so n / mean / M2 are that kernel's bits), then only the columns of unsettled keys are written
     uint8_t *settled = flags + (((size_t)((SETTLE && !NARROW) ? tg.tb * KT : 0u)) + 3 & ~(size_t)3);   // [KT] u8, then the tile's listed keys [KT] u32
     uint32_t *tile_list = reinterpret_cast<uint32_t *>(settled + ((KT + 3u) & ~3u));
+    uint32_t *tile_redo = tile_list + KT;                            // [KT] the tile's keys for the redo list
     bool skip_cols = false;
     if (SETTLE) {
       // (without the per-key bitmap any record on the overflow list sends the whole job to the redo path)
       skip_cols = !split && (sa.ovf_keys != nullptr || *ovf_count_in == 0ull);
-      if (threadIdx.x == 0) { s_nlist = 0; }
+      if (threadIdx.x == 0) { s_nlist = 0; s_nredo = 0; }
       __syncthreads();
       // Four threads per key (adjacent lanes), each over every fourth bucket with its own first value as the shift of its sums;
       // the partials meet in two xor-shuffles (sums re-based onto lane 0's shift: exact algebra, no division).  One thread per key
@@ -1202,7 +1203,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         if (!live) { settled[kk] = 1; continue; }
         // a key with a value on the overflow list is incomplete in the tile: its column is written, the fold completes it, the scan redoes it
         const bool key_ovf = sa.ovf_keys != nullptr && ((sa.ovf_keys[k >> 5] >> (k & 31u)) & 1u) != 0;
-        if (!skip_cols || key_ovf) { sa.st.n_pts[k] = kSettleRedo; settled[kk] = 0; continue; }
+        if (!skip_cols || key_ovf) { sa.st.n_pts[k] = kSettleRedo; settled[kk] = 0; tile_redo[atomicAdd(&s_nredo, 1u)] = (uint32_t)k; continue; }
         const bool slow = n > 0 && (!(mx - mn <= sa.eps) || n < (uint32_t)sa.min_samples);
         sa.st.n_pts[k] = n;
         sa.st.n_anom[k] = 0;
@@ -1214,8 +1215,10 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
       }
       __syncthreads();
       if (threadIdx.x == 0 && s_nlist) s_lbase = atomicAdd(sa.count, s_nlist);   // one global reservation per tile
+      if (threadIdx.x == 64 && s_nredo) s_rbase = atomicAdd(sa.redo_count, s_nredo);
       __syncthreads();
       for (uint32_t i = threadIdx.x; i < s_nlist; i += kPartThreads) sa.list[s_lbase + i] = tile_list[i];
+      for (uint32_t i = threadIdx.x; i < s_nredo; i += kPartThreads) sa.redo_list[s_rbase + i] = tile_redo[i];
       if (sa.cs_val != nullptr) {   // the listed keys' series, contiguous per list entry: a wavefront per key, lanes over the buckets
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         for (uint32_t i = wave; i < s_nlist; i += kPartThreads / 64) {
@@ -1387,7 +1390,7 @@ bool part_plan_settle(uint64_t T, PartPlan *pl, bool narrow) {
   pl->narrow = false;
   if (T == 0) return false;
   const size_t cell = narrow ? 4 : 9;     // narrow: one 32-bit word per cell (value + 1), `max` only
-  uint32_t kt = (uint32_t)((kLdsBudget - 64) / (T * cell + 5));
+  uint32_t kt = (uint32_t)((kLdsBudget - 64) / (T * cell + 9));   // + settled u8, work-list u32, redo-list u32 per key
   if (kt > pl->KP) kt = pl->KP;
   if (kt > 1024) kt = 1024;
   if (kt < 8) return false;
@@ -1397,7 +1400,7 @@ bool part_plan_settle(uint64_t T, PartPlan *pl, bool narrow) {
   pl->settle_kt = kt;
   pl->n_chunks = rounds;
   pl->tb = (uint32_t)T;
-  pl->agg_lds = (((size_t)T * kt * cell + 3) & ~(size_t)3) + (((size_t)kt + 3) & ~(size_t)3) + (size_t)kt * 4 + 16;
+  pl->agg_lds = (((size_t)T * kt * cell + 3) & ~(size_t)3) + (((size_t)kt + 3) & ~(size_t)3) + (size_t)kt * 8 + 16;
   pl->agg_lds = (pl->agg_lds + 15) & ~(size_t)15;
   pl->narrow = narrow;
   return true;
