@@ -564,8 +564,8 @@ def test_job_dbscan_settled_in_the_tile_pass(engine, stage0, variant):
         sel = rng.random(v.size) < 0.003
         v[sel] = rng.integers(2**50, 2**63, size=int(sel.sum()), dtype=np.uint64)       # overflow list -> whole job takes the redo walk
     elif variant == "values_around_2_32":
-        # `max` jobs keep value + 1 in 32-bit tile cells (round 4): 2^32 - 2 is the largest value a cell holds, 2^32 - 1 and beyond take the
-        # overflow list and ONLY their keys are left to the redo walk (bitmap of keys); both kinds of keys, settled and listed ones
+        # `max` jobs keep value + 1 in 32-bit tile cells (round 4): 2^32 - 3 is the largest value a cell holds, 2^32 - 2 and beyond go through the
+        # tile's side list of big values (keys stay decided in the tile); both kinds of keys, settled and listed ones
         edge = np.array([2**32 - 3, 2**32 - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**33, 2**40 + 7], dtype=np.uint64)
         sel = (k % np.uint64(7) == 2) & (rng.random(v.size) < 0.02)
         v[sel] = edge[rng.integers(0, edge.size, size=int(sel.sum()))]

@@ -1010,9 +1010,12 @@ struct TileGeom {
 
 // NARROW (settle mode with `max`, round 4): a tile cell is ONE 32-bit word, value + 1 (0 = absent) instead of 8 bytes + a flag byte: 2.25x the
 // keys per tile, three key rounds instead of six at C4 (1024 keys x 100 buckets) — every round streams the partition's records again, so the
-// pass costs what its rounds cost.  Values >= 2^32 - 1 do not fit: pass B sends them to the overflow list (as it does values that do not fit a
-// packed record) and marks their keys in a bitmap; the tile leaves exactly those keys to k_dbscan_scan (kSettleRedo), the fold adds the values to
-// the grid.  `max` only: a sum can outgrow 32 bits without any operand doing so.
+// pass costs what its rounds cost.  A value >= 2^32 - 2 does not fit a cell: the cell takes the all-ones word and the (cell, value) pair goes to a
+// small side list of the tile (kBigCap entries in LDS; with `max` the cell's aggregate IS the largest of its big values, whatever else it
+// received), which the per-key pass and the write-out consult for all-ones cells.  A tile with more big values than the list holds raises
+// DEV_ERR_NARROW_TILE and the job is redone with 8-byte cells (remembered for the next job of the same shape).  `max` only: a sum can outgrow 32
+// bits without any operand doing so.
+static constexpr uint32_t kBigCap = 192;
 template <bool OPMAX, bool SETTLE, bool NARROW>
 __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__restrict__ recs,
                                                     const unsigned long long *__restrict__ part_start,
@@ -1042,6 +1045,8 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
   // (the grid tile of a split partition was zeroed by k_part_offsets: its slices merge with atomics)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_nlist, s_lbase, s_nredo, s_rbase;
+  __shared__ uint32_t s_nbig, s_big_cell[NARROW ? kBigCap : 1];
+  __shared__ unsigned long long s_big_val[NARROW ? kBigCap : 1];
   const uint32_t cell_none = (1u << tg.cell_bits) - 1u;
   const unsigned long long plo = part_start[p], phi = part_start[p + 1];
   const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * tg.slice_len;
@@ -1059,10 +1064,20 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
     uint32_t *vals32 = reinterpret_cast<uint32_t *>(smem);          // NARROW: value + 1, 0 = absent
     uint8_t *flags = smem + (size_t)(SETTLE ? tg.tb * KT : tg.tb << shift_part) * (NARROW ? 4 : 8);   // (NARROW: no flag bytes; the settle bookkeeping starts here)
     auto cell_present = [&](uint32_t c) -> bool { return NARROW ? vals32[c] != 0u : (flags[c] & FLAG_PRESENT) != 0; };
-    auto cell_value = [&](uint32_t c) -> unsigned long long { return NARROW ? (unsigned long long)(vals32[c] - 1u) : vals[c]; };   // (of a present cell)
+    auto cell_value = [&](uint32_t c) -> unsigned long long {   // (of a present cell)
+      if (!NARROW) return vals[c];
+      const uint32_t w = vals32[c];
+      if (w != 0xFFFFFFFFu) return (unsigned long long)(w - 1u);
+      unsigned long long m = 0;                                   // a big value: the largest one the side list holds for this cell
+      const uint32_t nbig = s_nbig < kBigCap ? s_nbig : kBigCap;
+      for (uint32_t i = 0; i < nbig; ++i)
+        if (s_big_cell[i] == c && s_big_val[i] > m) m = s_big_val[i];
+      return m;
+    };
     if (chunk != r_lo) __syncthreads();  // the previous round's tile has been written out
     if (NARROW) {
       for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals32[c] = 0u;
+      if (threadIdx.x == 0) s_nbig = 0;
     } else {
       for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
       for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
@@ -1077,7 +1092,13 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         c = __umul24(cg >> shift_part, KT) + kk;   // (bucket < 2^16, KT <= 256: the 24-bit multiply issues at full rate, v_mul_lo_u32 at a quarter)
       } else if (c >= cells) return;   // (also rejects `no cell`: the all-ones cell is >= KP * T, plan_tiles reserves it)
       const unsigned long long v = r >> tg.cell_bits;
-      if (NARROW) { atomicMax(&vals32[c], (uint32_t)v + 1u); return; }     // (pass B kept values >= 2^32 - 1 out of the records)
+      if (NARROW) {
+        if (v < 0xFFFFFFFEull) { atomicMax(&vals32[c], (uint32_t)v + 1u); return; }   // (value + 1 must stay below the all-ones word)
+        const uint32_t i = atomicAdd(&s_nbig, 1u);                 // rare: C4 has 3 such values per tile
+        if (i < kBigCap) { s_big_cell[i] = c; s_big_val[i] = v; }
+        atomicMax(&vals32[c], 0xFFFFFFFFu);
+        return;
+      }
       if (OPMAX) atomicMax(&vals[c], v);
       else atomicAdd(&vals[c], v);
       flags[c] = FLAG_PRESENT;
@@ -1153,6 +1174,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
     uint32_t *tile_list = reinterpret_cast<uint32_t *>(settled + ((KT + 3u) & ~3u));
     uint32_t *tile_redo = tile_list + KT;                            // [KT] the tile's keys for the redo list
     bool skip_cols = false;
+    if (NARROW && threadIdx.x == 0 && s_nbig > kBigCap) atomicOr(&sa.ctr->err, DEV_ERR_NARROW_TILE);   // the job is redone with 8-byte cells
     if (SETTLE) {
       // (without the per-key bitmap any record on the overflow list sends the whole job to the redo path)
       skip_cols = !split && (sa.ovf_keys != nullptr || *ovf_count_in == 0ull);
@@ -1515,7 +1537,6 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   PartArgs A;
   A.fin = fin; A.G = pl.G;
   A.value_limit = 1ull << (64 - pl.cell_bits);
-  if (pl.narrow && A.value_limit > 0xFFFFFFFFull) A.value_limit = 0xFFFFFFFFull;   // pass C keeps value + 1 in 32 bits
   A.ovf_keys = ovf_keys;
   A.key = key; A.key2 = key2; A.t_end = t_end; A.t_start = t_start; A.value = value;
   A.n = n; A.chunk = pl.chunk; A.K = K; A.f = f; A.L = L;
