@@ -1083,6 +1083,12 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
       for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
     }
     __syncthreads();
+    uint32_t big_c = 0xFFFFFFFFu;              // NARROW: this thread's parked big value (cell, value), none
+    unsigned long long big_v = 0;
+    auto append_big = [&](uint32_t c, unsigned long long v) {
+      const uint32_t i = atomicAdd(&s_nbig, 1u);
+      if (i < kBigCap) { s_big_cell[i] = c; s_big_val[i] = v; }
+    };
     auto apply = [&](unsigned long long r) {
       const uint32_t cg = (uint32_t)r & cell_none;
       uint32_t c = cg - c_lo;  // wraps for cells before this round: the unsigned compare rejects them
@@ -1093,10 +1099,14 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
       } else if (c >= cells) return;   // (also rejects `no cell`: the all-ones cell is >= KP * T, plan_tiles reserves it)
       const unsigned long long v = r >> tg.cell_bits;
       if (NARROW) {
-        if (v < 0xFFFFFFFEull) { atomicMax(&vals32[c], (uint32_t)v + 1u); return; }   // (value + 1 must stay below the all-ones word)
-        const uint32_t i = atomicAdd(&s_nbig, 1u);                 // rare: C4 has 3 such values per tile
-        if (i < kBigCap) { s_big_cell[i] = c; s_big_val[i] = v; }
-        atomicMax(&vals32[c], 0xFFFFFFFFu);
+        // (value + 1 must stay below the all-ones word.)  A big value is PARKED in two registers of the thread and appended to the side list
+        // after the stream — the hot loop gets a compare and two selects, not a branch around LDS atomics (that form cost pass C +0.09 ms);
+        // a thread that meets a second big value appends the parked one right away (rare: C4 has 3 big values per TILE)
+        const bool big = v >= 0xFFFFFFFEull;
+        atomicMax(&vals32[c], big ? 0xFFFFFFFFu : (uint32_t)v + 1u);
+        if (big && big_c != 0xFFFFFFFFu) append_big(big_c, big_v);
+        big_c = big ? c : big_c;
+        big_v = big ? v : big_v;
         return;
       }
       if (OPMAX) atomicMax(&vals[c], v);
@@ -1167,6 +1177,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         for (int u = 0; u < U; ++u) apply(r[u]);
       }
     }
+    if (NARROW && big_c != 0xFFFFFFFFu) append_big(big_c, big_v);
     __syncthreads();
     // SETTLE: k_dbscan_scan's per-key pass on the LDS tile (one thread per key, buckets in order: the same operations in the
     // same order, so n / mean / M2 are that kernel's bits), then only the columns of unsettled keys are written
