@@ -1200,11 +1200,14 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         const bool live = kk < KT && kt0 + kk < KP && k < g.K;
         uint32_t n = 0;
         double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
+        bool saw_big = false;     // NARROW: an all-ones cell among mine (its value is in the tile's side list): the key is recomputed below
         if (live && skip_cols) {
           for (uint32_t b = part; b < nb; b += 4u) {
             const uint32_t c = __umul24(b, KT) + kk;
             if (cell_present(c)) {
-              const double x = (double)cell_value(c);
+              // (NARROW: no side-list lookup in this loop — a compare and an OR per cell; the 1 % of keys with a big value are redone)
+              const double x = NARROW ? (double)(vals32[c] - 1u) : (double)vals[c];
+              if (NARROW) saw_big |= vals32[c] == 0xFFFFFFFFu;
               if (n == 0) { mn = x; mx = x; x0 = x; }
               mn = fmin(mn, x);
               mx = fmax(mx, x);
@@ -1214,6 +1217,10 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
               n++;
             }
           }
+        }
+        if (NARROW) {   // the key's four threads agree on whether one of them met a big value; thread 0 of the key then walks all its cells with the lookup
+          saw_big = __shfl_xor((int)saw_big, 1) || saw_big;
+          saw_big = __shfl_xor((int)saw_big, 2) || saw_big;
         }
 #pragma unroll
         for (int d = 1; d <= 2; d <<= 1) {       // merge with the partner's partial; the lower lane's shift is kept
@@ -1234,6 +1241,22 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         }
         if (part != 0 || kk >= KT) continue;
         if (!live) { settled[kk] = 1; continue; }
+        if (NARROW && saw_big && skip_cols) {   // rare: exact statistics of a key with big values, sequentially over its buckets
+          n = 0; mn = mx = x0 = s1 = s2 = 0.0;
+          for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t c = __umul24(b, KT) + kk;
+            if (cell_present(c)) {
+              const double x = (double)cell_value(c);
+              if (n == 0) { mn = x; mx = x; x0 = x; }
+              mn = fmin(mn, x);
+              mx = fmax(mx, x);
+              const double d = x - x0;
+              s1 += d;
+              s2 += d * d;
+              n++;
+            }
+          }
+        }
         // a key with a value on the overflow list is incomplete in the tile: its column is written, the fold completes it, the scan redoes it
         const bool key_ovf = sa.ovf_keys != nullptr && ((sa.ovf_keys[k >> 5] >> (k & 31u)) & 1u) != 0;
         if (!skip_cols || key_ovf) { sa.st.n_pts[k] = kSettleRedo; settled[kk] = 0; tile_redo[atomicAdd(&s_nredo, 1u)] = (uint32_t)k; continue; }
