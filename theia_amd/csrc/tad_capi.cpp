@@ -829,9 +829,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
       // DBSCAN job: pass C in settle mode — key rounds, the detector's per-key pass on the LDS tile, grid columns of unsettled keys only.
-      // With `max` the tile cells are 32-bit words (value + 1; three key rounds instead of six at C4); values >= 2^32 - 1 go through a small side
-      // list of the tile.  Pass B marks the keys of values that do not even fit a record (overflow list) in a bitmap: they alone are left to the
-      // redo walk.
+      // Decided BEFORE pass B: with `max` the tile cells are 32-bit words (value + 1; three key rounds instead of six at C4) and pass B keeps
+      // values >= 2^32 - 1 out of the records (overflow list + a bitmap of their keys, which alone are left to k_dbscan_scan).
       SettleArgs settle{};
       jp.settled = false;
       uint32_t *ovf_keys = nullptr;
@@ -852,8 +851,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         settle.min_samples = jp.min_samples;
         settle.on = 1;
         settle.ovf_keys = ovf_keys;
-        settle.ctr = ctr;
         dbscan_compact_series(g, e->aux.p, &settle.cs_val, &settle.cs_flag, &settle.cs_has, &settle.cs_cap);
+        dbscan_redo_series(g, e->aux.p, &settle.rs_val, &settle.rs_flag, &settle.rs_has, &settle.rs_cap);
         jp.settled = true;
         narrow_tiles = pl.narrow;
       }
@@ -921,11 +920,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       if (!force_exact_hist) { force_exact_hist = true; continue; }
       return fail(e, TAD_ERR_HIP, "internal error: a partition region overflowed with an exact histogram");
     }
-    if (c.err & DEV_ERR_NARROW_TILE) {   // a tile of the settle pass met more values >= 2^32 - 1 than its side list holds: 8-byte cells
-      if (narrow_tiles && !force_wide_tiles) { force_wide_tiles = true; continue; }
-      return fail(e, TAD_ERR_HIP, "internal error: narrow-tile overflow without narrow tiles");
-    }
     if (c.err & DEV_ERR_OVERFLOW_LIST) {  // more than kOverflowCap values >= 2^49: the packed records do not pay off, use v1
+      if (narrow_tiles && !force_wide_tiles) { force_wide_tiles = true; continue; }   // (... or >= 2^32 - 1 under 32-bit tile cells: 8-byte cells first)
       if (!force_v1_retry) { force_v1_retry = true; continue; }
       return fail(e, TAD_ERR_HIP, "internal error: overflow list full on the v1 path");
     }

@@ -112,15 +112,30 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan(Grid g, double eps, in
 // per key: the lanes take the buckets in strides of 64, partial statistics merged in a fixed xor tree (the COOP form of k_dbscan_scan).
 __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan_redo(Grid g, double eps, int min_samples, DbscanStats st, const uint32_t *__restrict__ redo,
                                                               const unsigned int *__restrict__ redo_count, uint32_t *__restrict__ list,
-                                                              unsigned int *__restrict__ count, uint8_t *__restrict__ cs_has, uint32_t cs_cap) {
+                                                              unsigned int *__restrict__ count, uint8_t *__restrict__ cs_has, uint32_t cs_cap,
+                                                              const unsigned long long *__restrict__ rs_val, const uint8_t *__restrict__ rs_flag,
+                                                              const uint8_t *__restrict__ rs_has, uint32_t rs_cap) {
   const unsigned lane = lane_id();
   const unsigned total = *redo_count;
   for (unsigned e = blockIdx.x * kDbWaves + (threadIdx.x >> 6); e < total; e += gridDim.x * kDbWaves) {   // wavefront-uniform
     const uint64_t k = redo[e];
     ScanPart a{0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    // the tile pass left the key's series contiguous behind the redo list (rs_has 1): read it coalesced and fetch from the grid — where the
+    // fold has put the real aggregates — only the cells flagged as "on the overflow list"; otherwise gather the whole column (one 64-byte
+    // sector per bucket: 1e4 redo keys at C4 were 2e6 random sectors, 0.15 ms)
+    const bool compact = rs_has != nullptr && e < rs_cap && rs_has[e] == 1;   // wavefront-uniform
     for (uint64_t t = lane; t < g.T; t += 64) {
-      if (g.flag[t * g.K + k] & FLAG_PRESENT) {
-        const double x = (double)g.val[t * g.K + k];
+      uint8_t fl;
+      unsigned long long raw;
+      if (compact) {
+        fl = rs_flag[(size_t)e * g.T + t];
+        raw = (fl & 2) ? g.val[t * g.K + k] : rs_val[(size_t)e * g.T + t];
+      } else {
+        fl = g.flag[t * g.K + k];
+        raw = (fl & FLAG_PRESENT) ? g.val[t * g.K + k] : 0ull;
+      }
+      if (fl & FLAG_PRESENT) {
+        const double x = (double)raw;
         if (a.n == 0) { a.mn = x; a.mx = x; a.x0 = x; }
         a.mn = fmin(a.mn, x);
         a.mx = fmax(a.mx, x);
@@ -462,8 +477,19 @@ void dbscan_compact_series(Grid g, void *scratch, unsigned long long **cs_val, u
   *cs_cap = (uint32_t)c;
 }
 
+void dbscan_redo_series(Grid g, void *scratch, unsigned long long **rs_val, uint8_t **rs_flag, uint8_t **rs_has, uint32_t *rs_cap) {
+  *rs_val = nullptr; *rs_flag = nullptr; *rs_has = nullptr; *rs_cap = 0;
+  if (g.T == 0 || g.T > 256 || g.K == 0) return;
+  const size_t c = compact_cap(g);
+  unsigned char *p = static_cast<unsigned char *>(scratch) + wave_list_bytes(g) + compact_bytes(g);
+  *rs_val = reinterpret_cast<unsigned long long *>(p); p += (c * g.T * 8 + 63) & ~(size_t)63;
+  *rs_flag = p; p += (c * g.T + 63) & ~(size_t)63;
+  *rs_has = p;
+  *rs_cap = (uint32_t)c;
+}
+
 size_t dbscan_scratch_bytes(Grid g) {
-  if (g.T <= 256) return wave_list_bytes(g) + compact_bytes(g);
+  if (g.T <= 256) return wave_list_bytes(g) + 2 * compact_bytes(g);
   if (g.T <= kSortLdsPoints) return list_bytes(g);
   return list_bytes(g) + (size_t)sort_blocks(g) * sort_cap(g.T) * 24 + 64;
 }
@@ -487,8 +513,10 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   if (settled_by_stage0) {   // the list was started by pass C (its counters zeroed before Stage 0), with the listed keys' series contiguous behind it;
     // the keys it could not decide are on the redo list
     const uint64_t rb = g.K < 4096 ? g.K : 4096;
+    unsigned long long *rs_val; uint8_t *rs_flag, *rs_has; uint32_t rs_cap;
+    dbscan_redo_series(g, scratch, &rs_val, &rs_flag, &rs_has, &rs_cap);
     hipLaunchKernelGGL(k_dbscan_scan_redo, dim3((unsigned)rb), dim3(kDbBlock), 0, s, g, eps, min_samples, st, dbscan_redo_list(g, scratch), count + 1, list, count,
-                       cs_has, cs_cap);
+                       cs_has, cs_cap, rs_val, rs_flag, rs_has, rs_cap);
   } else {
     cs_has = nullptr;        // nobody wrote contiguous series
     hipMemsetAsync(count, 0, sizeof(unsigned int), s);

@@ -31,8 +31,7 @@ struct Grid {
 
 enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u, DEV_ERR_LATE_ROW = 8u,
                   DEV_ERR_REGION_FULL = 16u,   // Stage 0 v2 with a SAMPLED histogram: a (workgroup, partition) region was sized too small
-                  DEV_ERR_SPEC = 32u,          // the one-synchronisation job: the speculated lattice / result capacity did not hold (the job is redone)
-                  DEV_ERR_NARROW_TILE = 64u }; // settle mode with 32-bit tile cells: a tile met more values >= 2^32 - 2 than its side list holds (redone with 8-byte cells)
+                  DEV_ERR_SPEC = 32u };        // the one-synchronisation job: the speculated lattice / result capacity did not hold (the job is redone)
 enum : uint8_t { FLAG_PRESENT = 1, FLAG_ANOMALY = 2 };
 
 // Per-block partial of the lattice-derivation pass.
@@ -282,13 +281,18 @@ struct SettleArgs {
   uint32_t cs_cap;
   uint32_t *redo_list;       // keys the tile pass could not decide (split partition, a value on the overflow list): walked by k_dbscan_scan_redo,
   unsigned int *redo_count;  //   a wavefront per listed key (a lane-per-key pass over ALL keys to find 1 % of them cost a whole scan: 122 us at C4)
+  // the redo keys' series, contiguous per redo entry like cs_* (rs_has: 0 = not kept, 1 = kept, cells flagged 2 must be read from the grid)
+  unsigned long long *rs_val;
+  uint8_t *rs_flag;
+  uint8_t *rs_has;
+  uint32_t rs_cap;
   const uint32_t *ovf_keys;  // bitmap of the keys with a value on the overflow list (pass B): only THOSE keys are left to the scan; NULL: any overflow record sends every key there
-  DevCounters *ctr;          // DEV_ERR_NARROW_TILE
 };
 // where launch_dbscan keeps the contiguous series inside its scratch (series of <= 256 buckets; cs_cap entries)
 void dbscan_compact_series(Grid g, void *scratch, unsigned long long **cs_val, uint8_t **cs_flag, uint8_t **cs_has, uint32_t *cs_cap);
 // the redo list inside launch_dbscan's scratch: its counter is the second word of the scratch (zeroed with the list counter: 8 bytes)
 uint32_t *dbscan_redo_list(Grid g, void *scratch);
+void dbscan_redo_series(Grid g, void *scratch, unsigned long long **rs_val, uint8_t **rs_flag, uint8_t **rs_has, uint32_t *rs_cap);
 static constexpr uint32_t kSettleRedo = 0xFFFFFFFFu;
 size_t dbscan_scratch_bytes(Grid g);
 bool dbscan_uses_list(Grid g);
@@ -326,7 +330,7 @@ struct PartPlan {
   int cell_bits;       // record = value << cell_bits | partition-local cell
   uint32_t tb, n_chunks;  // pass C: buckets per LDS round, rounds per partition
   uint32_t settle_kt;     // pass C in settle mode: keys per tile (0 = bucket rounds); then n_chunks = ceil(KP / settle_kt) key rounds, tb = T
-  bool narrow;            // settle mode with 32-bit tile cells (value + 1; `max` only): a value >= 2^32 - 1 goes to the tile's side list
+  bool narrow;            // settle mode with 32-bit tile cells (value + 1; `max` only): values >= 2^32 - 2 take the overflow list, a sentinel record marks their cell
   uint32_t wc_cap;        // write-combining pass B: queue slots per partition (0 = use the sort-by-tile pass B)
   uint32_t wc_sec, wc_rpt;  // wc: records per emitted piece (8 or 16), rows per thread per tile (2 or 4)
   uint64_t pad_slots;     // wc: upper bound of the filler slots (regions rounded up to whole 64-byte sectors)

@@ -530,7 +530,10 @@ struct PartArgs {
   DevCounters *ctr;
   uint32_t *fin;      // sampled regions (NULL = exact regions): [(g * nparts + p) * 2] = {end of the upward records, start of the spilled ones}
   int G;
-  unsigned long long value_limit;   // values >= this go to the overflow list: 2^(64 - cell_bits), or 2^32 - 1 for pass C's 32-bit tiles
+  unsigned long long value_limit;   // values >= this do not fit a record (2^(64 - cell_bits)): overflow list
+  unsigned long long narrow_limit;  // pass C with 32-bit tile cells (0 = off): values >= this (2^32 - 2) go to the overflow list too, but
+                                    // their record stays in the stream with THIS value in the value field: the tile cell becomes the all-ones
+                                    // word, which tells the tile pass that the cell's aggregate is on the overflow list
   uint32_t *ovf_keys;               // bitmap of the keys with a value on the overflow list (NULL = not kept)
 };
 
@@ -674,6 +677,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     const int next_kind = tile + 1 < nfull ? 1 : (tile + 1 < ntiles ? 2 : 0);  // workgroup-uniform
     // ---- phase 1: partition + tile-local cell of every row, ranked inside its partition (LDS atomic) ----
     uint32_t r_cell[NSLOT], r_pr[NSLOT];  // cell; partition << 16 | rank (rank < S <= 2^14... stored in 16 bits)
+    uint32_t r_big = 0;                   // slots whose record carries the sentinel value (32-bit tile cells)
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
       const int64_t te = pt[j];
@@ -703,13 +707,14 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
           uint32_t cell = cell_none;
           if (on_lattice) {
             used++;
-            if (pv[j] < value_limit) {
-              cell = bucket * KP + ((uint32_t)k & A.kp_mask);
-            } else {  // rare: the value needs more than 49 bits -> overflow list, the stream slot stays empty
+            const bool big = pv[j] >= value_limit || (A.narrow_limit != 0 && pv[j] >= A.narrow_limit);
+            if (!big || A.narrow_limit != 0) cell = bucket * KP + ((uint32_t)k & A.kp_mask);
+            if (big) {  // rare: the value does not fit the record (or the 32-bit tile cell) -> overflow list
               const unsigned long long o = atomicAdd(A.ovf_count, 1ull);
               if (o < A.ovf_cap) { A.ovf[o].val = pv[j]; A.ovf[o].gcell = (unsigned long long)bucket * A.K + k; }
               else err |= DEV_ERR_OVERFLOW_LIST;
               if (A.ovf_keys != nullptr) atomicOr(A.ovf_keys + (k >> 5), 1u << (k & 31u));
+              if (A.narrow_limit != 0) r_big |= 1u << slot;      // the record stays, with the sentinel value
             }
           } else {
             err |= DEV_ERR_OFF_LATTICE;  // wrong lattice hint, or the sampled gcd missed a residue: host re-derives
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     for (int slot = 0; slot < NSLOT; ++slot) {
       if (r_pr[slot] != 0xFFFFFFFFu) {
         const uint32_t pos = off[r_pr[slot] >> 16] + (r_pr[slot] & 0xFFFFu);
-        rec[pos] = (pv[slot / (HAS2 ? 2 : 1)] << A.cell_bits) | r_cell[slot];
+        rec[pos] = (((r_big >> slot) & 1u ? A.narrow_limit : pv[slot / (HAS2 ? 2 : 1)]) << A.cell_bits) | r_cell[slot];
         part[pos] = (uint16_t)(r_pr[slot] >> 16);
       }
     }
@@ -880,21 +885,23 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
         const uint64_t k = h == 0 ? r.k[j] : r.k2[HAS2 ? j : 0];
         if (kept && k != TAD_KEY_SKIP && k < A.K) {  // same predicate as pass A: the slot is reserved
           uint32_t cell = cell_none;
+          unsigned long long vrec = r.v[j];
           if (on_lattice) {
             used++;
-            if (r.v[j] < value_limit) {
-              cell = bucket * KP + ((uint32_t)k & A.kp_mask);
-            } else {
+            const bool big = r.v[j] >= value_limit || (A.narrow_limit != 0 && r.v[j] >= A.narrow_limit);
+            if (!big || A.narrow_limit != 0) cell = bucket * KP + ((uint32_t)k & A.kp_mask);
+            if (big) {
               const unsigned long long o = atomicAdd(A.ovf_count, 1ull);
               if (o < A.ovf_cap) { A.ovf[o].val = r.v[j]; A.ovf[o].gcell = (unsigned long long)bucket * A.K + k; }
               else err |= DEV_ERR_OVERFLOW_LIST;
               if (A.ovf_keys != nullptr) atomicOr(A.ovf_keys + (k >> 5), 1u << (k & 31u));
+              if (A.narrow_limit != 0) vrec = A.narrow_limit;   // the record stays, with the sentinel value: the tile cell becomes all ones
             }
           } else {
             err |= DEV_ERR_OFF_LATTICE;
           }
           const uint32_t p = (uint32_t)(k >> A.shift_part);
-          const unsigned long long rec = (r.v[j] << A.cell_bits) | cell;
+          const unsigned long long rec = (vrec << A.cell_bits) | cell;
           const uint32_t pos = atomicAdd(&cnt[p], 1u);
           if (pos < cap) q[p * cap + pos] = rec;
           else {  // queue full (a burst, or a hot key): top of the region
@@ -1010,12 +1017,12 @@ struct TileGeom {
 
 // NARROW (settle mode with `max`, round 4): a tile cell is ONE 32-bit word, value + 1 (0 = absent) instead of 8 bytes + a flag byte: 2.25x the
 // keys per tile, three key rounds instead of six at C4 (1024 keys x 100 buckets) — every round streams the partition's records again, so the
-// pass costs what its rounds cost.  A value >= 2^32 - 2 does not fit a cell: the cell takes the all-ones word and the (cell, value) pair goes to a
-// small side list of the tile (kBigCap entries in LDS; with `max` the cell's aggregate IS the largest of its big values, whatever else it
-// received), which the per-key pass and the write-out consult for all-ones cells.  A tile with more big values than the list holds raises
-// DEV_ERR_NARROW_TILE and the job is redone with 8-byte cells (remembered for the next job of the same shape).  `max` only: a sum can outgrow 32
-// bits without any operand doing so.
-static constexpr uint32_t kBigCap = 192;
+// pass costs what its rounds cost.  A value >= 2^32 - 2 does not fit a cell.  Pass B sends it to the overflow list (as it does values that do
+// not fit a packed record), marks its key in a bitmap and leaves a record with the SENTINEL value 2^32 - 2 in the stream, so that the cell
+// becomes the all-ones word without a single extra instruction in this kernel's hot loop (a compare + branch there was measured: +0.09 ms).
+// The tile leaves exactly the marked keys to k_dbscan_scan_redo — with their series contiguous behind the redo list, the all-ones cells flagged:
+// the redo pass reads those few cells from the grid once the fold has put the real values there, instead of gathering the whole column.
+// `max` only: a sum can outgrow 32 bits without any operand doing so.
 template <bool OPMAX, bool SETTLE, bool NARROW>
 __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__restrict__ recs,
                                                     const unsigned long long *__restrict__ part_start,
@@ -1045,8 +1052,6 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
   // (the grid tile of a split partition was zeroed by k_part_offsets: its slices merge with atomics)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_nlist, s_lbase, s_nredo, s_rbase;
-  __shared__ uint32_t s_nbig, s_big_cell[NARROW ? kBigCap : 1];
-  __shared__ unsigned long long s_big_val[NARROW ? kBigCap : 1];
   const uint32_t cell_none = (1u << tg.cell_bits) - 1u;
   const unsigned long long plo = part_start[p], phi = part_start[p + 1];
   const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * tg.slice_len;
@@ -1064,31 +1069,15 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
     uint32_t *vals32 = reinterpret_cast<uint32_t *>(smem);          // NARROW: value + 1, 0 = absent
     uint8_t *flags = smem + (size_t)(SETTLE ? tg.tb * KT : tg.tb << shift_part) * (NARROW ? 4 : 8);   // (NARROW: no flag bytes; the settle bookkeeping starts here)
     auto cell_present = [&](uint32_t c) -> bool { return NARROW ? vals32[c] != 0u : (flags[c] & FLAG_PRESENT) != 0; };
-    auto cell_value = [&](uint32_t c) -> unsigned long long {   // (of a present cell)
-      if (!NARROW) return vals[c];
-      const uint32_t w = vals32[c];
-      if (w != 0xFFFFFFFFu) return (unsigned long long)(w - 1u);
-      unsigned long long m = 0;                                   // a big value: the largest one the side list holds for this cell
-      const uint32_t nbig = s_nbig < kBigCap ? s_nbig : kBigCap;
-      for (uint32_t i = 0; i < nbig; ++i)
-        if (s_big_cell[i] == c && s_big_val[i] > m) m = s_big_val[i];
-      return m;
-    };
+    auto cell_value = [&](uint32_t c) -> unsigned long long { return NARROW ? (unsigned long long)(vals32[c] - 1u) : vals[c]; };   // (of a present cell)
     if (chunk != r_lo) __syncthreads();  // the previous round's tile has been written out
     if (NARROW) {
       for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals32[c] = 0u;
-      if (threadIdx.x == 0) s_nbig = 0;
     } else {
       for (uint32_t c = threadIdx.x; c < cells; c += kPartThreads) vals[c] = 0ull;
       for (uint32_t c = threadIdx.x; c < (cells + 3) / 4; c += kPartThreads) reinterpret_cast<uint32_t *>(flags)[c] = 0u;
     }
     __syncthreads();
-    uint32_t big_c = 0xFFFFFFFFu;              // NARROW: this thread's parked big value (cell, value), none
-    unsigned long long big_v = 0;
-    auto append_big = [&](uint32_t c, unsigned long long v) {
-      const uint32_t i = atomicAdd(&s_nbig, 1u);
-      if (i < kBigCap) { s_big_cell[i] = c; s_big_val[i] = v; }
-    };
     auto apply = [&](unsigned long long r) {
       const uint32_t cg = (uint32_t)r & cell_none;
       uint32_t c = cg - c_lo;  // wraps for cells before this round: the unsigned compare rejects them
@@ -1098,17 +1087,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         c = __umul24(cg >> shift_part, KT) + kk;   // (bucket < 2^16, KT <= 256: the 24-bit multiply issues at full rate, v_mul_lo_u32 at a quarter)
       } else if (c >= cells) return;   // (also rejects `no cell`: the all-ones cell is >= KP * T, plan_tiles reserves it)
       const unsigned long long v = r >> tg.cell_bits;
-      if (NARROW) {
-        // (value + 1 must stay below the all-ones word.)  A big value is PARKED in two registers of the thread and appended to the side list
-        // after the stream — the hot loop gets a compare and two selects, not a branch around LDS atomics (that form cost pass C +0.09 ms);
-        // a thread that meets a second big value appends the parked one right away (rare: C4 has 3 big values per TILE)
-        const bool big = v >= 0xFFFFFFFEull;
-        atomicMax(&vals32[c], big ? 0xFFFFFFFFu : (uint32_t)v + 1u);
-        if (big && big_c != 0xFFFFFFFFu) append_big(big_c, big_v);
-        big_c = big ? c : big_c;
-        big_v = big ? v : big_v;
-        return;
-      }
+      if (NARROW) { atomicMax(&vals32[c], (uint32_t)v + 1u); return; }     // (pass B kept values >= 2^32 - 1 out of the records)
       if (OPMAX) atomicMax(&vals[c], v);
       else atomicAdd(&vals[c], v);
       flags[c] = FLAG_PRESENT;
@@ -1177,7 +1156,6 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         for (int u = 0; u < U; ++u) apply(r[u]);
       }
     }
-    if (NARROW && big_c != 0xFFFFFFFFu) append_big(big_c, big_v);
     __syncthreads();
     // SETTLE: k_dbscan_scan's per-key pass on the LDS tile (one thread per key, buckets in order: the same operations in the
     // same order, so n / mean / M2 are that kernel's bits), then only the columns of unsettled keys are written
@@ -1185,7 +1163,6 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
     uint32_t *tile_list = reinterpret_cast<uint32_t *>(settled + ((KT + 3u) & ~3u));
     uint32_t *tile_redo = tile_list + KT;                            // [KT] the tile's keys for the redo list
     bool skip_cols = false;
-    if (NARROW && threadIdx.x == 0 && s_nbig > kBigCap) atomicOr(&sa.ctr->err, DEV_ERR_NARROW_TILE);   // the job is redone with 8-byte cells
     if (SETTLE) {
       // (without the per-key bitmap any record on the overflow list sends the whole job to the redo path)
       skip_cols = !split && (sa.ovf_keys != nullptr || *ovf_count_in == 0ull);
@@ -1200,14 +1177,11 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         const bool live = kk < KT && kt0 + kk < KP && k < g.K;
         uint32_t n = 0;
         double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
-        bool saw_big = false;     // NARROW: an all-ones cell among mine (its value is in the tile's side list): the key is recomputed below
         if (live && skip_cols) {
           for (uint32_t b = part; b < nb; b += 4u) {
             const uint32_t c = __umul24(b, KT) + kk;
             if (cell_present(c)) {
-              // (NARROW: no side-list lookup in this loop — a compare and an OR per cell; the 1 % of keys with a big value are redone)
-              const double x = NARROW ? (double)(vals32[c] - 1u) : (double)vals[c];
-              if (NARROW) saw_big |= vals32[c] == 0xFFFFFFFFu;
+              const double x = (double)cell_value(c);
               if (n == 0) { mn = x; mx = x; x0 = x; }
               mn = fmin(mn, x);
               mx = fmax(mx, x);
@@ -1217,10 +1191,6 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
               n++;
             }
           }
-        }
-        if (NARROW) {   // the key's four threads agree on whether one of them met a big value; thread 0 of the key then walks all its cells with the lookup
-          saw_big = __shfl_xor((int)saw_big, 1) || saw_big;
-          saw_big = __shfl_xor((int)saw_big, 2) || saw_big;
         }
 #pragma unroll
         for (int d = 1; d <= 2; d <<= 1) {       // merge with the partner's partial; the lower lane's shift is kept
@@ -1241,22 +1211,6 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         }
         if (part != 0 || kk >= KT) continue;
         if (!live) { settled[kk] = 1; continue; }
-        if (NARROW && saw_big && skip_cols) {   // rare: exact statistics of a key with big values, sequentially over its buckets
-          n = 0; mn = mx = x0 = s1 = s2 = 0.0;
-          for (uint32_t b = 0; b < nb; ++b) {
-            const uint32_t c = __umul24(b, KT) + kk;
-            if (cell_present(c)) {
-              const double x = (double)cell_value(c);
-              if (n == 0) { mn = x; mx = x; x0 = x; }
-              mn = fmin(mn, x);
-              mx = fmax(mx, x);
-              const double d = x - x0;
-              s1 += d;
-              s2 += d * d;
-              n++;
-            }
-          }
-        }
         // a key with a value on the overflow list is incomplete in the tile: its column is written, the fold completes it, the scan redoes it
         const bool key_ovf = sa.ovf_keys != nullptr && ((sa.ovf_keys[k >> 5] >> (k & 31u)) & 1u) != 0;
         if (!skip_cols || key_ovf) { sa.st.n_pts[k] = kSettleRedo; settled[kk] = 0; tile_redo[atomicAdd(&s_nredo, 1u)] = (uint32_t)k; continue; }
@@ -1275,6 +1229,24 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
       __syncthreads();
       for (uint32_t i = threadIdx.x; i < s_nlist; i += kPartThreads) sa.list[s_lbase + i] = tile_list[i];
       for (uint32_t i = threadIdx.x; i < s_nredo; i += kPartThreads) sa.redo_list[s_rbase + i] = tile_redo[i];
+      if (sa.rs_val != nullptr && s_nredo) {   // the redo keys' series, contiguous per redo entry (whole series only: not for a split partition)
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        for (uint32_t i = wave; i < s_nredo; i += kPartThreads / 64) {
+          const uint32_t e = s_rbase + i;
+          if (e >= sa.rs_cap) continue;
+          if (skip_cols) {
+            const uint32_t kk = tile_redo[i] - (uint32_t)(k0 + kt0);
+            for (uint32_t b = lane; b < nb; b += 64) {
+              const uint32_t c = __umul24(b, KT) + kk;
+              const bool pr = cell_present(c);
+              sa.rs_val[(size_t)e * nb + b] = pr ? cell_value(c) : 0ull;
+              // bit 1: the cell's aggregate is on the overflow list (NARROW: the all-ones word) -> read it from the grid after the fold
+              sa.rs_flag[(size_t)e * nb + b] = pr ? (uint8_t)(FLAG_PRESENT | ((NARROW && vals32[c] == 0xFFFFFFFFu) ? 2 : 0)) : 0;
+            }
+          }
+          if (lane == 0) sa.rs_has[e] = skip_cols ? (NARROW ? 1 : 2) : 0;   // 2: values beyond the record range are absent from the tile altogether
+        }
+      }
       if (sa.cs_val != nullptr) {   // the listed keys' series, contiguous per list entry: a wavefront per key, lanes over the buckets
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         for (uint32_t i = wave; i < s_nlist; i += kPartThreads / 64) {
@@ -1571,6 +1543,7 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   PartArgs A;
   A.fin = fin; A.G = pl.G;
   A.value_limit = 1ull << (64 - pl.cell_bits);
+  A.narrow_limit = pl.narrow ? 0xFFFFFFFEull : 0ull;     // (value + 1 of every in-range value stays below the all-ones word)
   A.ovf_keys = ovf_keys;
   A.key = key; A.key2 = key2; A.t_end = t_end; A.t_start = t_start; A.value = value;
   A.n = n; A.chunk = pl.chunk; A.K = K; A.f = f; A.L = L;
