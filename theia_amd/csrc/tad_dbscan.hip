@@ -115,14 +115,21 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan_redo(Grid g, double ep
                                                               unsigned int *__restrict__ count, uint8_t *__restrict__ cs_has, uint32_t cs_cap,
                                                               const unsigned long long *__restrict__ rs_val, const uint8_t *__restrict__ rs_flag,
                                                               const uint8_t *__restrict__ rs_has, uint32_t rs_cap) {
+  // The keys that turn out "slow" join the work list.  Most redo keys do (a value beyond 2^32 next to ordinary ones is a wide spread), and one
+  // atomic per key on the list counter is a serial queue of ~12 ns each (144 us for C4's 1e4 redo keys): the workgroup collects its slow keys
+  // in LDS and reserves their list slots with ONE atomic.
+  constexpr uint32_t kSlowCap = 256;
+  __shared__ uint32_t s_slow[kSlowCap];
+  __shared__ uint32_t s_nslow, s_base;
+  if (threadIdx.x == 0) s_nslow = 0;
+  __syncthreads();
   const unsigned lane = lane_id();
   const unsigned total = *redo_count;
   for (unsigned e = blockIdx.x * kDbWaves + (threadIdx.x >> 6); e < total; e += gridDim.x * kDbWaves) {   // wavefront-uniform
     const uint64_t k = redo[e];
     ScanPart a{0, 0.0, 0.0, 0.0, 0.0, 0.0};
     // the tile pass left the key's series contiguous behind the redo list (rs_has 1): read it coalesced and fetch from the grid — where the
-    // fold has put the real aggregates — only the cells flagged as "on the overflow list"; otherwise gather the whole column (one 64-byte
-    // sector per bucket: 1e4 redo keys at C4 were 2e6 random sectors, 0.15 ms)
+    // fold has put the real aggregates — only the cells flagged as "on the overflow list"; otherwise gather the whole column
     const bool compact = rs_has != nullptr && e < rs_cap && rs_has[e] == 1;   // wavefront-uniform
     for (uint64_t t = lane; t < g.T; t += 64) {
       uint8_t fl;
@@ -157,11 +164,23 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan_redo(Grid g, double ep
       st.key_mean[k] = a.n ? a.x0 + a.s1 / dn : 0.0;
       st.key_m2[k] = a.n ? fmax(a.s2 - a.s1 * (a.s1 / dn), 0.0) : 0.0;
       if (slow) {
-        const unsigned at = atomicAdd(count, 1u);
-        list[at] = (uint32_t)k;
-        if (cs_has != nullptr && at < cs_cap) cs_has[at] = 0;
+        const uint32_t i = atomicAdd(&s_nslow, 1u);
+        if (i < kSlowCap) s_slow[i] = (uint32_t)k;
+        else {   // (more slow keys in one workgroup than the LDS list holds: straight to the list)
+          const unsigned at = atomicAdd(count, 1u);
+          list[at] = (uint32_t)k;
+          if (cs_has != nullptr && at < cs_cap) cs_has[at] = 0;
+        }
       }
     }
+  }
+  __syncthreads();
+  const uint32_t ns = s_nslow < kSlowCap ? s_nslow : kSlowCap;
+  if (threadIdx.x == 0 && ns) s_base = atomicAdd(count, ns);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < ns; i += kDbBlock) {
+    list[s_base + i] = s_slow[i];
+    if (cs_has != nullptr && s_base + i < cs_cap) cs_has[s_base + i] = 0;
   }
 }
 
@@ -512,7 +531,7 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   dbscan_compact_series(g, scratch, &cs_val, &cs_flag, &cs_has, &cs_cap);
   if (settled_by_stage0) {   // the list was started by pass C (its counters zeroed before Stage 0), with the listed keys' series contiguous behind it;
     // the keys it could not decide are on the redo list
-    const uint64_t rb = g.K < 4096 ? g.K : 4096;
+    const uint64_t rb = g.K < 1024 ? g.K : 1024;     // (grid-stride over the device-side redo count)
     unsigned long long *rs_val; uint8_t *rs_flag, *rs_has; uint32_t rs_cap;
     dbscan_redo_series(g, scratch, &rs_val, &rs_flag, &rs_has, &rs_cap);
     hipLaunchKernelGGL(k_dbscan_scan_redo, dim3((unsigned)rb), dim3(kDbBlock), 0, s, g, eps, min_samples, st, dbscan_redo_list(g, scratch), count + 1, list, count,
