@@ -114,12 +114,12 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan_redo(Grid g, double ep
                                                               const unsigned int *__restrict__ redo_count, uint32_t *__restrict__ list,
                                                               unsigned int *__restrict__ count, uint8_t *__restrict__ cs_has, uint32_t cs_cap,
                                                               const unsigned long long *__restrict__ rs_val, const uint8_t *__restrict__ rs_flag,
-                                                              const uint8_t *__restrict__ rs_has, uint32_t rs_cap) {
+                                                              const uint8_t *__restrict__ rs_has, uint32_t rs_cap, uint32_t *__restrict__ cs_src) {
   // The keys that turn out "slow" join the work list.  Most redo keys do (a value beyond 2^32 next to ordinary ones is a wide spread), and one
   // atomic per key on the list counter is a serial queue of ~12 ns each (144 us for C4's 1e4 redo keys): the workgroup collects its slow keys
   // in LDS and reserves their list slots with ONE atomic.
   constexpr uint32_t kSlowCap = 256;
-  __shared__ uint32_t s_slow[kSlowCap];
+  __shared__ uint32_t s_slow[kSlowCap], s_slow_e[kSlowCap];
   __shared__ uint32_t s_nslow, s_base;
   if (threadIdx.x == 0) s_nslow = 0;
   __syncthreads();
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan_redo(Grid g, double ep
       st.key_m2[k] = a.n ? fmax(a.s2 - a.s1 * (a.s1 / dn), 0.0) : 0.0;
       if (slow) {
         const uint32_t i = atomicAdd(&s_nslow, 1u);
-        if (i < kSlowCap) s_slow[i] = (uint32_t)k;
+        if (i < kSlowCap) { s_slow[i] = (uint32_t)k; s_slow_e[i] = compact ? e : 0xFFFFFFFFu; }
         else {   // (more slow keys in one workgroup than the LDS list holds: straight to the list)
           const unsigned at = atomicAdd(count, 1u);
           list[at] = (uint32_t)k;
@@ -180,7 +180,10 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_scan_redo(Grid g, double ep
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < ns; i += kDbBlock) {
     list[s_base + i] = s_slow[i];
-    if (cs_has != nullptr && s_base + i < cs_cap) cs_has[s_base + i] = 0;
+    if (cs_has != nullptr && s_base + i < cs_cap) {   // the key's series lies contiguous behind the REDO list: the list kernel reads it there (2)
+      cs_has[s_base + i] = s_slow_e[i] != 0xFFFFFFFFu ? 2 : 0;
+      cs_src[s_base + i] = s_slow_e[i];
+    }
   }
 }
 
@@ -332,7 +335,8 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
                                                               const unsigned int *__restrict__ count, uint32_t *__restrict__ n_anom,
                                                               double *__restrict__ sg_e, unsigned long long *__restrict__ am_e,
                                                               const unsigned long long *__restrict__ cs_val, const uint8_t *__restrict__ cs_flag,
-                                                              const uint8_t *__restrict__ cs_has, uint32_t cs_cap) {
+                                                              const uint8_t *__restrict__ cs_has, uint32_t cs_cap, const uint32_t *__restrict__ cs_src,
+                                                              const unsigned long long *__restrict__ rs_val, const uint8_t *__restrict__ rs_flag) {
   const unsigned lane = lane_id();
   const unsigned wave = threadIdx.x >> 6;
   const unsigned total = *count;
@@ -341,13 +345,20 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
     double x[PPL];
     bool p[PPL];
     unsigned long long pm[PPL];
-    const bool compact = cs_has != nullptr && e < cs_cap && cs_has[e] != 0;   // wavefront-uniform: the series lies contiguous behind the list
+    // wavefront-uniform: 1 = the series lies contiguous behind this list, 2 = behind the redo list (entry cs_src[e]; cells flagged 2 — their
+    // aggregate came from the overflow list — are read from the grid), 0 = gather the key's column from the grid
+    const uint8_t has = (cs_has != nullptr && e < cs_cap) ? cs_has[e] : (uint8_t)0;
+    const size_t src = has == 2 ? (size_t)cs_src[e] * g.T : (size_t)e * g.T;
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const uint64_t t = lane + 64u * (unsigned)j;
-      if (compact) {
-        p[j] = t < g.T && (cs_flag[(size_t)e * g.T + t] & FLAG_PRESENT);
-        x[j] = p[j] ? (double)cs_val[(size_t)e * g.T + t] : 0.0;
+      if (has == 1) {
+        p[j] = t < g.T && (cs_flag[src + t] & FLAG_PRESENT);
+        x[j] = p[j] ? (double)cs_val[src + t] : 0.0;
+      } else if (has == 2) {
+        const uint8_t fl = t < g.T ? rs_flag[src + t] : (uint8_t)0;
+        p[j] = (fl & FLAG_PRESENT) != 0;
+        x[j] = p[j] ? (double)((fl & 2) ? g.val[t * g.K + k] : rs_val[src + t]) : 0.0;
       } else {
         p[j] = t < g.T && (g.flag[t * g.K + k] & FLAG_PRESENT);
         x[j] = p[j] ? (double)g.val[t * g.K + k] : 0.0;
@@ -483,7 +494,15 @@ static uint32_t sort_blocks(Grid g) {   // workgroups of the long-series form: b
 // contiguous series of the listed keys (T <= 256): cs_cap entries of T values + T flags, + one byte per entry
 static uint32_t compact_cap(Grid g) { const uint64_t c = g.K / 8 > 4096 ? g.K / 8 : 4096; return (uint32_t)(c < g.K ? c : g.K); }
 static size_t wave_list_bytes(Grid g) { return list_bytes(g) + (((size_t)g.K * (8 + 8 * 4) + 63) & ~(size_t)63); }
-static size_t compact_bytes(Grid g) { const size_t c = compact_cap(g); return ((c * g.T * 8 + 63) & ~(size_t)63) + ((c * g.T + 63) & ~(size_t)63) + ((c + 63) & ~(size_t)63); }
+static size_t compact_bytes(Grid g) {   // values | flags | has | src (the redo entry a work-list entry's series lives in: cs_has == 2)
+  const size_t c = compact_cap(g);
+  return ((c * g.T * 8 + 63) & ~(size_t)63) + ((c * g.T + 63) & ~(size_t)63) + ((c + 63) & ~(size_t)63) + ((c * 4 + 63) & ~(size_t)63);
+}
+static uint32_t *compact_src(Grid g, void *scratch) {
+  const size_t c = compact_cap(g);
+  return reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(scratch) + wave_list_bytes(g) + ((c * g.T * 8 + 63) & ~(size_t)63) + ((c * g.T + 63) & ~(size_t)63) +
+                                      ((c + 63) & ~(size_t)63));
+}
 
 void dbscan_compact_series(Grid g, void *scratch, unsigned long long **cs_val, uint8_t **cs_flag, uint8_t **cs_has, uint32_t *cs_cap) {
   *cs_val = nullptr; *cs_flag = nullptr; *cs_has = nullptr; *cs_cap = 0;
@@ -529,13 +548,13 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   const unsigned lane_blocks = (unsigned)((g.K + kDbBlock - 1) / kDbBlock);
   unsigned long long *cs_val; uint8_t *cs_flag, *cs_has; uint32_t cs_cap;
   dbscan_compact_series(g, scratch, &cs_val, &cs_flag, &cs_has, &cs_cap);
+  unsigned long long *rs_val = nullptr; uint8_t *rs_flag = nullptr, *rs_has = nullptr; uint32_t rs_cap = 0;
   if (settled_by_stage0) {   // the list was started by pass C (its counters zeroed before Stage 0), with the listed keys' series contiguous behind it;
     // the keys it could not decide are on the redo list
     const uint64_t rb = g.K < 1024 ? g.K : 1024;     // (grid-stride over the device-side redo count)
-    unsigned long long *rs_val; uint8_t *rs_flag, *rs_has; uint32_t rs_cap;
     dbscan_redo_series(g, scratch, &rs_val, &rs_flag, &rs_has, &rs_cap);
     hipLaunchKernelGGL(k_dbscan_scan_redo, dim3((unsigned)rb), dim3(kDbBlock), 0, s, g, eps, min_samples, st, dbscan_redo_list(g, scratch), count + 1, list, count,
-                       cs_has, cs_cap, rs_val, rs_flag, rs_has, rs_cap);
+                       cs_has, cs_cap, rs_val, rs_flag, rs_has, rs_cap, compact_src(g, scratch));
   } else {
     cs_has = nullptr;        // nobody wrote contiguous series
     hipMemsetAsync(count, 0, sizeof(unsigned int), s);
@@ -549,7 +568,7 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   // profiles/r3_v9_c4_list_blocks_ab.log)
   uint64_t blocks = g.K < 8192 ? g.K : 8192;
   if (g.T <= 256) {   // a wavefront's registers hold the whole series
-#define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom, wave_list_sg(scratch, g), wave_list_am(scratch, g), cs_val, cs_flag, cs_has, cs_cap)
+#define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom, wave_list_sg(scratch, g), wave_list_am(scratch, g), cs_val, cs_flag, cs_has, cs_cap, compact_src(g, scratch), rs_val, rs_flag)
     if (g.T <= 64) TAD_DBW(1); else if (g.T <= 128) TAD_DBW(2); else if (g.T <= 192) TAD_DBW(3); else TAD_DBW(4);
 #undef TAD_DBW
     return 0;
