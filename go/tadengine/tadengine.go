@@ -57,7 +57,7 @@ func (e IllegalArgument) Error() string { return e.Msg }
 // (controller.go:199-201); calls on one engine serialise inside the library.
 type Engine struct{ h *C.tad_engine }
 
-// Plan mirrors tad_plan (tad.h, ABI 8): plan overrides of an engine, every field 0 = the engine decides — what the controller
+// Plan mirrors tad_plan (tad.h, ABI 9): plan overrides of an engine, every field 0 = the engine decides — what the controller
 // uses.  Tests and A/B measurements force a strategy with it; the library reads no environment variable.  A Go struct, not
 // C.tad_plan: cgo types are private to this package, callers in other packages could not construct one.
 type Plan struct {
@@ -70,12 +70,14 @@ type Plan struct {
 	EwmaEmitRows  uint32 // LDS rows per wavefront of the staged EWMA emit (<= 4096)
 	OneSync       int32  // 1 = never run a job in the one-synchronisation form
 	TileCells     int32  // 1 = 8-byte tile cells in the settle mode of DBSCAN jobs with max
+	SparseSort    int32  // sparse tables: 1 = always the LSD radix sort, 2 = the partition pass + LDS sort wherever its plan fits (ABI 9)
 }
 
 func (p Plan) c() C.tad_plan {
 	return C.tad_plan{stage0: C.int32_t(p.Stage0), partition_pass: C.int32_t(p.PartitionPass), histogram: C.int32_t(p.Histogram),
 		sparse: C.int32_t(p.Sparse), sparse_classes: C.int32_t(p.SparseClasses), ewma_emit: C.int32_t(p.EwmaEmit),
-		ewma_emit_rows: C.uint32_t(p.EwmaEmitRows), one_sync: C.int32_t(p.OneSync), tile_cells: C.int32_t(p.TileCells)}
+		ewma_emit_rows: C.uint32_t(p.EwmaEmitRows), one_sync: C.int32_t(p.OneSync), tile_cells: C.int32_t(p.TileCells),
+		sparse_sort: C.int32_t(p.SparseSort)}
 }
 
 func NewEngine(device int) (*Engine, error) { return NewEngineWithPlan(device, Plan{}) }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 8
+#define TAD_ABI_VERSION 9
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -84,7 +84,8 @@ typedef struct {
   uint32_t ewma_emit_rows;   /* LDS rows per wavefront of the staged EWMA emit (<= 4096); 0 = sized from the row count */
   int32_t one_sync;          /* 1 = never run a job in the one-synchronisation form (ABI 8; see tad_stats.host_syncs) */
   int32_t tile_cells;        /* 1 = 8-byte tile cells in the settle mode of DBSCAN jobs with `max` (ABI 8; default: 32-bit cells, value + 1) */
-  int32_t reserved;          /* 0 */
+  int32_t sparse_sort;       /* sparse tables (ABI 9; was `reserved`): 1 = always the LSD radix sort, 2 = the partition pass + LDS sort wherever its plan fits
+                                (0: when pass A ran with its key-bin histogram, i.e. >= 2^22 rows) */
 } tad_plan;
 
 typedef struct {
@@ -163,7 +164,9 @@ typedef struct {
                               (5 was the two-level partition of ABI 6: measured no faster than the single-level plan, removed)
                               6 = sparse table with skewed series lengths: as 4, then one job per length class of keys (<= 16, <= 64, ... points),
                                   rows merged back in key order (the K x longest-series rank grid would not fit the workspace),
-                              7 = tad_aggregate on such a table: the sorted unique points are the result, no grid at all */
+                              7 = tad_aggregate on such a table: the sorted unique points are the result, no grid at all,
+                              8 / 9 / 10 (ABI 9) = as 4 / 6 / 7 with the rows sorted through the key-block partition pass + one LDS sort per key sub-range
+                                  instead of the LSD radix sort (big sparse tables: the columns are read once, 8-byte records move through HBM once) */
   int32_t stage0_attempts; /* times Stage 0 ran before it settled: 1 normally; more after a wrong lattice hint, a sampled lattice or
                               a sampled histogram that proved too optimistic (every fallback is exact), an overflow-list fallback */
   int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/8 of pass A's reads) */

@@ -6,7 +6,7 @@ from . import build as _build
 
 u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
 
-TAD_ABI_VERSION = 8
+TAD_ABI_VERSION = 9
 TAD_KEY_SKIP = (1 << 64) - 1
 TAD_OK = 0
 TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
@@ -21,19 +21,20 @@ TAD_FLAG_EMIT_ALL_POINTS = 1
 class Plan(C.Structure):
     """tad_plan: plan overrides, every field 0 = the engine decides (tests and A/B measurements set them)."""
     _fields_ = [("stage0", i32), ("partition_pass", i32), ("histogram", i32), ("sparse", i32), ("sparse_classes", i32),
-                ("ewma_emit", i32), ("ewma_emit_rows", u32), ("one_sync", i32), ("tile_cells", i32), ("reserved", i32)]
+                ("ewma_emit", i32), ("ewma_emit_rows", u32), ("one_sync", i32), ("tile_cells", i32), ("sparse_sort", i32)]
 
 
 PLAN_VALUES = {   # symbolic values accepted by TadEngine(plan=...) / TadEngine.plan(...)
     "stage0": {"auto": 0, "v1": 1, "v2": 2}, "partition_pass": {"auto": 0, "sort": 1, "wc": 2, "wc_sectors": 3}, "histogram": {"auto": 0, "exact": 1, "sampled": 2},
     "sparse": {"auto": 0, "never": 1, "always": 2}, "sparse_classes": {"auto": 0, "always": 1}, "ewma_emit": {"auto": 0, "staged": 0, "lane": 1}, "one_sync": {"auto": 0, "never": 1}, "tile_cells": {"auto": 0, "wide": 1},
+    "sparse_sort": {"auto": 0, "lsd": 1, "partition": 2},
 }
 
 
 def make_plan(**kw):
     p = Plan()
     for name, v in kw.items():
-        if name not in dict((f[0], 1) for f in Plan._fields_) or name == "reserved":
+        if name not in dict((f[0], 1) for f in Plan._fields_):
             raise ValueError("unknown tad_plan field %r" % name)
         if isinstance(v, str):
             v = PLAN_VALUES[name][v]

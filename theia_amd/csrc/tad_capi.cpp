@@ -49,6 +49,7 @@ struct tad_engine {
   DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
   DevBuf sp_cls;                                                                  // Stage 0 sparse, length classes: per-key class arrays
+  bool sp_by_partition = false;   // the running job's sparse Stage 0 went through the partition pass + LDS sort (stage0_path 8 / 9 / 10 instead of 4 / 6 / 7)
   DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
   DevBuf ovf_keys;                                                                // Stage 0 v2, settle mode: bitmap of the keys with a value on the overflow list
   hipEvent_t ev[8] = {};
@@ -100,7 +101,7 @@ constexpr int kSampleBlockShift = 7;   // (C4 with 1024-key blocks and a sampled
 
 bool plan_ok(const tad_plan &p) {
   return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 3 && p.histogram >= 0 && p.histogram <= 2 && p.sparse >= 0 &&
-         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.one_sync >= 0 && p.one_sync <= 1 && p.tile_cells >= 0 && p.tile_cells <= 1 && p.reserved == 0;
+         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.one_sync >= 0 && p.one_sync <= 1 && p.tile_cells >= 0 && p.tile_cells <= 1 && p.sparse_sort >= 0 && p.sparse_sort <= 2;
 }
 constexpr uint32_t kOverflowCap = 1u << 20;  // Stage 0 v2: rows with a value >= 2^49 per run before falling back to v1
 
@@ -627,6 +628,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   // the estimate with 6 sigma of slack; a region that still turns out too small (keys arriving in bursts the sample missed)
   // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  tad_plan.histogram = 1 disables it.
   bool force_exact_hist = plan.histogram == 1;
+  bool sparse_lsd = plan.sparse_sort == 1;   // set when the partition + LDS-sort form of the sparse Stage 0 met a heavy key bin or a value too wide for its records
   // The one-synchronisation form.  A job normally synchronises with the host three times: for the lattice (pass A's partials), for
   // the row count (the result block is sized from it) and at the end.  A job of the SAME SHAPE as the engine's previous one — rows,
   // keys, algorithm, filters; device-resident in and out — is instead issued in one go with that job's lattice and a result block
@@ -642,7 +644,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   if (spec_ok && sp.wide_tiles) force_wide_tiles = true;
   // retries: wrong hint -> derive (0 -> 1); sampled lattice too coarse / saw no live row -> exact (1 -> 2); overflow list
   // full -> Stage 0 v1; a missed speculation -> the plain form.  Each transition happens at most once, so 8 attempts cover every path.
-  for (int attempt = 0; attempt < 9; ++attempt) {
+  for (int attempt = 0; attempt < 11; ++attempt) {
     const bool hinted = lat_mode == 0;
     HIP_TRY(e, hipMemsetAsync(ctr, 0, kTailMoments, s));    // counters, row total, overflow-list count
     jp.settled = false;
@@ -724,13 +726,27 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
                   (plan.sparse == 2 ||
                    (plan.sparse != 1 && (cells_overflow || need > e->ws_limit || (cells >= (1ull << 24) && slots_all < cells / 8))));
     Grid sparse_grid{};
+    bool sp_part = false;
     if (sparse) {
+      // Big sparse tables (pass A ran with its key-bin histogram): the dense path's partition pass brings every key block's rows together as
+      // 8-byte records, a workgroup per key sub-range sorts them in LDS (tad_sparse.hip: launch_sparse_sort) — the columns are read once and
+      // the records move through HBM once, where the LSD sort moves 16-byte pairs once per digit.  Needs the exact histogram.
+      PartPlan spl = pl;
+      sp_part = v2 && !sparse_lsd && part_plan_sparse(K, L.nb, has2, &spl);
+      if (sp_part) {
+        part_plan_wc(slots_all, columns_aligned16(d_key, d_key2, d_te, d_val), has2, 2, &spl);
+        if (spl.wc_cap == 0 || slots_all + spl.pad_slots >= (1ull << 32)) sp_part = false;
+      }
+      if (sp_part && hist_sampled) { force_exact_hist = true; continue; }
       v2 = false;
       if ((rc = ensure(e, e->sp_comp_a, slots_all * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->sp_comp_b, slots_all * 8)) != TAD_OK) return rc;
+      // (the b buffers are the staging area of the partition sort: a round's stage starts at its block's record offset, fillers of pass B included)
+      const uint64_t stage_slots = slots_all + (sp_part ? spl.pad_slots : 0);
+      if ((rc = ensure(e, e->sp_comp_b, stage_slots * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->sp_val_a, slots_all * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->sp_val_b, slots_all * 8)) != TAD_OK) return rc;
-      const size_t tb = sparse_sort_temp_bytes(slots_all);
+      if ((rc = ensure(e, e->sp_val_b, stage_slots * 8)) != TAD_OK) return rc;
+      size_t tb = sparse_sort_temp_bytes(slots_all);
+      if (sp_part && sparse_part_temp_bytes(spl) > tb) tb = sparse_part_temp_bytes(spl);
       if ((uint64_t)slots_all * 32 + tb > e->ws_limit)   // the four sort buffers count against the workspace too: fail cleanly, not in hipMalloc
         return fail(e, TAD_ERR_GRID_TOO_LARGE, "sparse Stage 0 needs %llu bytes of sort buffers for %llu row slots > workspace limit %llu",
                     (unsigned long long)(slots_all * 32 + tb), (unsigned long long)slots_all, (unsigned long long)e->ws_limit);
@@ -742,15 +758,44 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       unsigned long long *ucomp = static_cast<unsigned long long *>(e->sp_comp_a.p), *uval = static_cast<unsigned long long *>(e->sp_val_a.p);
       // (the sort covers bit_width(span) time bits: a row beyond the lattice's last bucket raises DEV_ERR_OFF_LATTICE like a row before t0)
       const uint64_t span = L.nb ? (L.nb - 1) * (uint64_t)L.step : 0;
-      if (launch_sparse_group(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
-                              rf, L.t0, span, op_max, ucomp, uval, static_cast<unsigned long long *>(e->sp_comp_b.p),
-                              static_cast<unsigned long long *>(e->sp_val_b.p), e->sp_temp.p, tb, d_runs, ctr) != 0)
+      if (sp_part) {
+        const uint64_t slots = slots_all + spl.pad_slots;
+        if ((rc = ensure(e, e->part_total, (size_t)spl.nparts * 4)) != TAD_OK) return rc;
+        if ((rc = ensure(e, e->part_start, ((size_t)spl.nparts + 1) * 8)) != TAD_OK) return rc;
+        if ((rc = ensure(e, e->part_offs32, (size_t)spl.G * spl.nparts * 4)) != TAD_OK) return rc;
+        if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
+        if ((rc = ensure(e, e->slices, slice_table_bytes(slots, spl))) != TAD_OK) return rc;
+        uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
+        unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
+        launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), spl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start, false,
+                            static_cast<const MetaPartial *>(e->meta.p), n, slots, e->slices.p, Grid{});
+        // (no overflow list: a value that does not fit the record raises DEV_ERR_OVERFLOW_LIST and the LSD sort redoes the job)
+        launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
+                         rf, L, spl, offs32, part_start, e->recs.p, nullptr, dev_ovf_count(e), 0, ctr, nullptr, nullptr);
+        launch_sparse_sort(s, e->recs.p, part_start, static_cast<const uint32_t *>(e->binhist.p), spl, K, L.step, op_max,
+                           static_cast<unsigned long long *>(e->sp_comp_b.p), static_cast<unsigned long long *>(e->sp_val_b.p), ucomp, uval, e->sp_temp.p,
+                           d_runs, ctr);
+      } else if (launch_sparse_group(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
+                                     rf, L.t0, span, op_max, ucomp, uval, static_cast<unsigned long long *>(e->sp_comp_b.p),
+                                     static_cast<unsigned long long *>(e->sp_val_b.p), e->sp_temp.p, tb, d_runs, ctr) != 0)
         return fail(e, TAD_ERR_HIP, "sparse Stage 0: sort / reduce failed");
+      if (depth == 0) e->sp_by_partition = sp_part;
       // first[] / the longest series from the device-resident point count; then ONE round trip for both numbers
       launch_sparse_tmax(s, ucomp, slots_all, d_runs, static_cast<uint32_t *>(e->sp_first.p), reinterpret_cast<unsigned int *>(d_runs + 1));
       unsigned long long runs_tmax[2] = {0, 0};
       HIP_TRY(e, hipMemcpyAsync(runs_tmax, d_runs, 16, hipMemcpyDeviceToHost, s));
+      if (sp_part) HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
       HIP_TRY(e, hipStreamSynchronize(s));
+      if (sp_part) {
+        const uint32_t er = e->ctr_host->err;
+        if (er & DEV_ERR_KEY_RANGE)
+          return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
+        if (er & DEV_ERR_OFF_LATTICE) {
+          if (lat_mode < 2) { lat_mode = (lat_mode == 0) ? 1 : 2; continue; }
+          return fail(e, TAD_ERR_HIP, "internal error: a row fell off the derived time lattice");
+        }
+        if (er & (DEV_ERR_OVERFLOW_LIST | DEV_ERR_SPARSE_ROUND)) { sparse_lsd = true; continue; }   // a heavy key bin / a value wider than the record
+      }
       const uint64_t P = runs_tmax[0];    // the filtered-out slots sort last and the reduction drops them
       const unsigned int tmax = (unsigned int)runs_tmax[1];
       cells = K * (uint64_t)tmax;
@@ -997,7 +1042,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
       hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
       hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
-      st.stage0_path = sparse ? 4 : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
+      st.stage0_path = sparse ? (sp_part ? 8 : 4) : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
       st.stage0_attempts = attempt + 1;
       st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
       e->done.store(4);
@@ -1082,7 +1127,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     hipEventElapsedTime(&st.ms_stage0, e->ev[1], e->ev[5]);
     hipEventElapsedTime(&st.ms_scatter, e->ev[2], e->ev[3]);
     hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
-    st.stage0_path = sparse ? 4 : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
+    st.stage0_path = sparse ? (sp_part ? 8 : 4) : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
     st.stage0_attempts = attempt + 1;
     st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
     st.host_syncs = spec ? 1 : ((hinted || empty) ? 2 : 3);
@@ -1167,7 +1212,7 @@ int sparse_points_direct(tad_engine *e, uint64_t n_rows_in, uint64_t rows_used, 
   st.pts_mean = mean; st.pts_m2 = m2;
   hipEventElapsedTime(&st.ms_total, e->ev[6], e->ev[7]);
   st.ms_stage0 = st.ms_total;
-  st.stage0_path = 7;
+  st.stage0_path = e->sp_by_partition ? 10 : 7;
   st.stage0_attempts = 1;
   e->done.store(4);
   *points_out = &pp->pub;
@@ -1311,7 +1356,7 @@ int run_sparse_classes(tad_engine *e, const tad_job *job, const JobParams &jp, b
   hipEventElapsedTime(&st.ms_total, e->ev[6], e->ev[7]);
   st.ms_detect = ms_classes;                       // the class jobs, each with its own (small) Stage 0
   st.ms_stage0 = st.ms_total - ms_classes;         // sort + reduce + class tables + merge
-  st.stage0_path = 6;
+  st.stage0_path = e->sp_by_partition ? 9 : 6;
   st.stage0_attempts = 1;
   strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
   release();

@@ -31,7 +31,8 @@ struct Grid {
 
 enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u, DEV_ERR_LATE_ROW = 8u,
                   DEV_ERR_REGION_FULL = 16u,   // Stage 0 v2 with a SAMPLED histogram: a (workgroup, partition) region was sized too small
-                  DEV_ERR_SPEC = 32u };        // the one-synchronisation job: the speculated lattice / result capacity did not hold (the job is redone)
+                  DEV_ERR_SPEC = 32u,          // the one-synchronisation job: the speculated lattice / result capacity did not hold (the job is redone)
+                  DEV_ERR_SPARSE_ROUND = 64u };  // sparse Stage 0 through the partition pass: one key bin holds more records than a workgroup sorts in LDS (the LSD sort takes over)
 enum : uint8_t { FLAG_PRESENT = 1, FLAG_ANOMALY = 2 };
 
 // Per-block partial of the lattice-derivation pass.
@@ -334,6 +335,7 @@ struct PartPlan {
   uint32_t wc_cap;        // write-combining pass B: queue slots per partition (0 = use the sort-by-tile pass B)
   uint32_t wc_sec, wc_rpt;  // wc: records per emitted piece (8 or 16), rows per thread per tile (2 or 4)
   uint64_t pad_slots;     // wc: upper bound of the filler slots (regions rounded up to whole 64-byte sectors)
+  int sp_tbits;           // sparse tables through the partition pass (part_plan_sparse): bit_width(T); cell_bits = shift_part + sp_tbits
 };
 // decide whether pass B runs as the write-combining variant (sets wc_cap / pad_slots; needs 16-byte aligned columns)
 // partition_pass: tad_plan.partition_pass (0 = decide from the shape, 1 = sort-by-tile, 2 = write-combining whenever it fits)
@@ -341,6 +343,9 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, int partition_pass, P
 bool columns_aligned16(const void *key, const void *key2, const void *t_end, const void *value);
 bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl);
 bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
+// sparse tables (tad_sparse.hip, launch_sparse_sort): key blocks for the partition pass alone — no LDS tile has to hold a block's buckets;
+// false = the shape does not fit the 8-byte records (too many keys / too long a lattice): the LSD sort runs
+bool part_plan_sparse(uint64_t K, uint64_t T, bool has2, PartPlan *pl);
 // sample_hist: histogram only the rows whose time is sampled too (one iteration in eight + the chunk ends): pass A then
 // reads 1/8 of the key column; the regions of pass B are SIZED from the estimate (launch_part_offsets) instead of counted.
 // Returns whether the histogram is sampled (only without a time-window filter and with 16-byte aligned columns).
@@ -374,6 +379,13 @@ bool part_plan_settle(uint64_t T, PartPlan *pl, bool narrow = false);
 
 // ---- Stage 0 for sparse tables: sort by (key, time), reduce, rank grid (tad_sparse.hip) ----
 size_t sparse_sort_temp_bytes(uint64_t slots);
+// The sparse Stage 0 of big tables: pass B's records (key blocks, launch_partition) -> per key sub-range of a block one workgroup gathers the
+// records, sorts them in LDS by (key, bucket), folds equal runs and stages the unique points; a scan + copy compacts the stages into
+// comp_out / val_out (sorted unique (key << 32 | t - t0, aggregate)), their number in *num_runs (device).  stage_comp / stage_val: `slots` words each.
+size_t sparse_part_temp_bytes(const PartPlan &pl);
+void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long long *part_start, const uint32_t *binhist, const PartPlan &pl, uint64_t K,
+                        int64_t step, bool op_max, unsigned long long *stage_comp, unsigned long long *stage_val, unsigned long long *comp_out,
+                        unsigned long long *val_out, void *temp, unsigned long long *num_runs, DevCounters *ctr);
 int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end, const int64_t *t_start,
                         const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, int64_t t0, uint64_t span, bool op_max, unsigned long long *comp_a,
                         unsigned long long *val_a, unsigned long long *comp_b, unsigned long long *val_b, void *temp, size_t temp_bytes,

@@ -535,6 +535,318 @@ int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2
   return (cb == comp_a && hipGetLastError() == hipSuccess) ? 0 : -1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Big sparse tables: partition by key block, then sort in LDS (round 4).  The LSD sort above moves every 16-byte (composite, value) pair
+// through HBM once per digit — five passes for 1e6 connections over a day of seconds, ~290 B per row.  Here the rows go through the dense
+// path's passes A and B first (exact histogram per key bin, write-combining partition pass: 8-byte records value << cell_bits |
+// (bucket * KP + key-in-block), tad_stage0_part.hip), which leaves every key block's records contiguous, and then
+//   k_ss_plan   a wavefront per key block: the block's bin totals (pass A's histogram summed over its workgroups) are grouped greedily
+//               into ROUNDS of <= kSsCap records — whole bins, so that every key's records are in exactly one round
+//   k_ss_sort   a workgroup per (block, round): streams the block's records (the rounds of a block run side by side on one XCD and share
+//               its L2), keeps those of its key sub-range in LDS as value << cell_bits | (key-in-round << tbits | bucket), sorts them
+//               there by that key — least-significant-digit passes with the ballot ranking of k_rs_scatter, the items in registers between
+//               the passes —, folds the runs of equal (key, bucket) with the job's operator (wrapping add / unsigned max) and writes the unique
+//               points of the round, in order, to a staging area at (block start + records of the earlier bins): coalesced, through LDS
+//   scan + k_ss_compact   the rounds' point counts -> positions; every round's stage is copied to its place in the final sorted list.
+// The columns are read once (24 B/row), the records written and read once more through HBM (8 + 8 B/row; the rounds' re-reads hit L2).
+// A bin that alone exceeds a round (a heavy key), a value that does not fit the record, or a shape the plan refuses: the LSD sort runs.
+// ------------------------------------------------------------------------------------------------
+static constexpr int kSsThreads = 1024;
+static constexpr int kSsWaves = kSsThreads / 64;
+static constexpr int kSsItems = 14;
+static constexpr uint32_t kSsCap = kSsThreads * kSsItems;       // 14336 records (112 KB of LDS)
+static constexpr uint32_t kSsSlice = 64 * kSsItems;             // slots a wavefront owns in a sorting pass
+
+struct SsRound { uint32_t key0, key1, n, stage; };             // key-in-block range, records (from the histogram), staging offset
+
+struct SsArgs {
+  const unsigned long long *recs;
+  const unsigned long long *part_start;
+  const uint32_t *binhist;      // [G][nbins]
+  uint32_t nbins, bins_per_part, nparts;
+  int G, shift_bin, shift_part, cell_bits, tbits;
+  uint64_t K;
+  unsigned long long step;
+  SsRound *rounds;              // [nparts][bins_per_part]
+  uint32_t *n_rounds;           // [nparts]
+  uint32_t *seg_count;          // [nparts * bins_per_part] unique points of the round (0 = no such round)
+  unsigned long long *stage_comp, *stage_val;
+  DevCounters *ctr;
+};
+
+__global__ __launch_bounds__(256) void k_ss_plan(SsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ss_plan_smem[];
+  uint32_t *ss_tot = reinterpret_cast<uint32_t *>(ss_plan_smem);   // [4][bins_per_part]
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t p = blockIdx.x * 4u + wave;
+  if (p >= A.nparts) return;                                   // (wavefront-uniform; no workgroup barrier below)
+  uint32_t *tot = ss_tot + (size_t)wave * A.bins_per_part;
+  const uint32_t b0 = p * A.bins_per_part;
+  for (uint32_t b = lane; b < A.bins_per_part; b += 64) {
+    uint32_t c = 0;
+    if (b0 + b < A.nbins)
+      for (int g = 0; g < A.G; ++g) c += A.binhist[(size_t)g * A.nbins + b0 + b];
+    tot[b] = c;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  if (lane != 0) return;
+  SsRound *out = A.rounds + (size_t)p * A.bins_per_part;
+  const uint32_t base = (uint32_t)A.part_start[p];
+  uint32_t r = 0, acc = 0, first = 0, before = 0, err = 0;
+  for (uint32_t b = 0; b < A.bins_per_part; ++b) {
+    const uint32_t c = tot[b];
+    if (c > kSsCap) err = DEV_ERR_SPARSE_ROUND;
+    if (acc != 0 && acc + c > kSsCap) {
+      out[r++] = SsRound{first << A.shift_bin, b << A.shift_bin, acc, base + before};
+      before += acc; acc = 0;
+    }
+    if (acc == 0) first = b;
+    acc += c;
+  }
+  if (acc != 0) out[r++] = SsRound{first << A.shift_bin, A.bins_per_part << A.shift_bin, acc, base + before};
+  A.n_rounds[p] = r;
+  if (err) atomicOr(&A.ctr->err, err);
+}
+
+template <bool OPMAX>
+__global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
+  unsigned long long *rec = reinterpret_cast<unsigned long long *>(ss_smem);             // [kSsCap]
+  uint32_t *s_hist = reinterpret_cast<uint32_t *>(rec + kSsCap);                         // [waves][256]
+  uint32_t *s_base = s_hist + kSsWaves * kRsRadix;                                       // [256]
+  __shared__ uint32_t s_w[kSsWaves + 1];
+  __shared__ uint32_t s_n;
+  // the rounds of a key block on ONE XCD (workgroups are dealt round-robin to the 8 XCDs): they stream the same records
+  const uint32_t R = A.bins_per_part;
+  const uint32_t slot = blockIdx.x >> 3;
+  const uint32_t p = (slot / R) * 8u + (blockIdx.x & 7u), r = slot % R;
+  if (p >= A.nparts || r >= A.n_rounds[p]) return;
+  const SsRound rd = A.rounds[(size_t)p * R + r];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  // ---- gather the round's records ----
+  const uint32_t cell_mask = (1u << A.cell_bits) - 1u, kp_mask = (1u << A.shift_part) - 1u;
+  const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+  {
+    const uint64_t lo = A.part_start[p], hi = A.part_start[p + 1];
+    constexpr int kU = 4;
+    for (uint64_t i0 = lo; i0 < hi; i0 += (uint64_t)kSsThreads * kU) {          // workgroup-uniform trip count (ballots inside)
+      unsigned long long x[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint64_t i = i0 + (uint64_t)u * kSsThreads + threadIdx.x;
+        x[u] = i < hi ? A.recs[i] : ~0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t cell = (uint32_t)x[u] & cell_mask;
+        const uint32_t kl = cell & kp_mask;
+        const bool take = x[u] != ~0ull && cell != cell_mask && kl >= rd.key0 && kl < rd.key1;
+        const unsigned long long m = __ballot(take);
+        if (m) {
+          uint32_t at = 0;
+          if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(m));
+          at = __shfl(at, 0) + (uint32_t)__popcll(m & lt_mask);
+          if (take && at < kSsCap)
+            rec[at] = ((x[u] >> A.cell_bits) << A.cell_bits) | ((unsigned long long)(kl - rd.key0) << A.tbits) | (cell >> A.shift_part);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t n = s_n;
+  if (n > kSsCap) {   // cannot happen: the plan counted the bins (every record of a bin was counted by pass A)
+    if (threadIdx.x == 0) atomicOr(&A.ctr->err, DEV_ERR_SPARSE_ROUND);
+    n = kSsCap;
+  }
+  // ---- sort by (key-in-round, bucket): LSD passes over the bits in use ----
+  int kbits = 0;
+  while (((rd.key1 - rd.key0 - 1u) >> kbits) != 0) ++kbits;
+  const int bits = A.tbits + kbits;
+  const int np = bits > 0 ? (bits + 7) / 8 : 0;
+  int shift = 0, left = bits;
+  unsigned long long c[kSsItems];
+  uint32_t rr[kSsItems];
+  uint32_t *my_hist = s_hist + wave * kRsRadix;
+  for (int ps = 0; ps < np; ++ps) {
+    const int width = (left + (np - ps) - 1) / (np - ps);
+    const uint32_t mask = (1u << width) - 1u;
+    for (uint32_t i = threadIdx.x; i < kSsWaves * kRsRadix; i += kSsThreads) s_hist[i] = 0;
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i) {
+      const uint32_t j = (uint32_t)wave * kSsSlice + (uint32_t)i * 64 + (uint32_t)lane;
+      c[i] = j < n ? rec[j] : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i) {
+      const uint32_t j = (uint32_t)wave * kSsSlice + (uint32_t)i * 64 + (uint32_t)lane;
+      const bool in = j < n;
+      const uint32_t d = (uint32_t)(c[i] >> shift) & mask;
+      unsigned long long peers = __ballot(in);
+      for (int b = 0; b < width; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      const uint32_t old = in ? my_hist[d] : 0u;
+      __builtin_amdgcn_wave_barrier();
+      if (in && (peers & lt_mask) == 0ull) my_hist[d] = old + (uint32_t)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      rr[i] = old + (uint32_t)__popcll(peers & lt_mask);
+    }
+    __syncthreads();
+    uint32_t tot_d = 0;
+    if (threadIdx.x < kRsRadix) {
+      for (int w = 0; w < kSsWaves; ++w) {
+        const uint32_t t = s_hist[w * kRsRadix + threadIdx.x];
+        s_hist[w * kRsRadix + threadIdx.x] = tot_d;
+        tot_d += t;
+      }
+    }
+    {   // exclusive scan of the digit totals (the first 256 threads = 4 wavefronts hold one each)
+      uint32_t incl = tot_d;
+      for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
+      if (lane == 63) s_w[wave] = incl;
+      __syncthreads();
+      uint32_t before = 0;
+      for (int w = 0; w < 4; ++w) if (w < wave) before += s_w[w];
+      if (threadIdx.x < kRsRadix) s_base[threadIdx.x] = before + incl - tot_d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i) {
+      const uint32_t j = (uint32_t)wave * kSsSlice + (uint32_t)i * 64 + (uint32_t)lane;
+      if (j < n) {
+        const uint32_t d = (uint32_t)(c[i] >> shift) & mask;
+        rec[s_base[d] + my_hist[d] + rr[i]] = c[i];
+      }
+    }
+    __syncthreads();
+    shift += width; left -= width;
+  }
+  // ---- fold the runs of equal (key, bucket): thread t owns the sorted slots [t * kSsItems, ...) ----
+  const unsigned long long sk_mask = (1ull << A.cell_bits) - 1ull;
+  const uint32_t j0 = threadIdx.x * kSsItems;
+  uint32_t head_bits = 0;
+  unsigned long long hv[kSsItems];
+  uint32_t hk[kSsItems];
+#pragma unroll
+  for (int i = 0; i < kSsItems; ++i) {
+    const uint32_t j = j0 + i;
+    hv[i] = 0; hk[i] = 0;
+    if (j < n) {
+      const unsigned long long x = rec[j];
+      const uint32_t sk = (uint32_t)(x & sk_mask);
+      if (j == 0 || (uint32_t)(rec[j - 1] & sk_mask) != sk) {
+        unsigned long long acc = x >> A.cell_bits;
+        for (uint32_t k = j + 1; k < n; ++k) {
+          const unsigned long long y = rec[k];
+          if ((uint32_t)(y & sk_mask) != sk) break;
+          const unsigned long long v = y >> A.cell_bits;
+          acc = OPMAX ? (v > acc ? v : acc) : acc + v;
+        }
+        head_bits |= 1u << i;
+        hv[i] = acc; hk[i] = sk;
+      }
+    }
+  }
+  uint32_t mine = (uint32_t)__popc(head_bits), incl = mine;
+  for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
+  __syncthreads();                       // every run is folded: the record area is free
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t before = incl - mine, U = 0;
+  for (int w = 0; w < kSsWaves; ++w) { if (w < wave) before += s_w[w]; U += s_w[w]; }
+  // ---- the round's unique points, in order, through LDS: composites, then values ----
+  const unsigned long long key_base = ((unsigned long long)p << A.shift_part) + rd.key0;
+  const uint32_t t_mask = (1u << A.tbits) - 1u;
+  {
+    uint32_t at = before;
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i)
+      if (head_bits & (1u << i)) rec[at++] = ((key_base + (hk[i] >> A.tbits)) << 32) | ((unsigned long long)(hk[i] & t_mask) * A.step);
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_comp[(size_t)rd.stage + j] = rec[j];
+  __syncthreads();
+  {
+    uint32_t at = before;
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i)
+      if (head_bits & (1u << i)) rec[at++] = hv[i];
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_val[(size_t)rd.stage + j] = rec[j];
+  if (threadIdx.x == 0) A.seg_count[(size_t)p * R + r] = U;
+}
+
+// every round's stage to its place in the sorted list (off = exclusive scan of seg_count in (block, round) order)
+__global__ __launch_bounds__(256) void k_ss_compact(SsArgs A, const unsigned long long *__restrict__ off, unsigned long long *__restrict__ comp_out,
+                                                     unsigned long long *__restrict__ val_out) {
+  const uint32_t seg = blockIdx.x;
+  const uint32_t cnt = A.seg_count[seg];
+  if (cnt == 0) return;
+  const size_t src = A.rounds[seg].stage;
+  const unsigned long long dst = off[seg];
+  for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
+    comp_out[dst + j] = A.stage_comp[src + j];
+    val_out[dst + j] = A.stage_val[src + j];
+  }
+}
+
+// temp: rounds [nparts * bpp] | n_rounds [nparts] | seg_count [nparts * bpp] | off u64 [nparts * bpp + 1] | scan scratch
+struct SsTemp { size_t rounds, n_rounds, seg_count, off, scratch, total; };
+static SsTemp ss_temp_layout(const PartPlan &pl) {
+  const size_t m = (size_t)pl.nparts * pl.bins_per_part;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  SsTemp t;
+  size_t at = 0;
+  t.rounds = at; at = up(at + m * sizeof(SsRound));
+  t.n_rounds = at; at = up(at + (size_t)pl.nparts * 4);
+  t.seg_count = at; at = up(at + m * 4);
+  t.off = at; at = up(at + (m + 1) * 8);
+  t.scratch = at; at = up(at + scan_scratch_elems(m ? m : 1) * 8);
+  t.total = at;
+  return t;
+}
+
+size_t sparse_part_temp_bytes(const PartPlan &pl) { return ss_temp_layout(pl).total + 256; }
+
+void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long long *part_start, const uint32_t *binhist, const PartPlan &pl, uint64_t K,
+                        int64_t step, bool op_max, unsigned long long *stage_comp, unsigned long long *stage_val, unsigned long long *comp_out,
+                        unsigned long long *val_out, void *temp, unsigned long long *num_runs, DevCounters *ctr) {
+  const SsTemp tl = ss_temp_layout(pl);
+  unsigned char *tp = static_cast<unsigned char *>(temp);
+  SsArgs A{};
+  A.recs = static_cast<const unsigned long long *>(recs); A.part_start = part_start; A.binhist = binhist;
+  A.nbins = pl.nbins; A.bins_per_part = pl.bins_per_part; A.nparts = pl.nparts;
+  A.G = pl.G; A.shift_bin = pl.shift_bin; A.shift_part = pl.shift_part; A.cell_bits = pl.cell_bits; A.tbits = pl.sp_tbits;
+  A.K = K; A.step = (unsigned long long)step;
+  A.rounds = reinterpret_cast<SsRound *>(tp + tl.rounds);
+  A.n_rounds = reinterpret_cast<uint32_t *>(tp + tl.n_rounds);
+  A.seg_count = reinterpret_cast<uint32_t *>(tp + tl.seg_count);
+  A.stage_comp = stage_comp; A.stage_val = stage_val; A.ctr = ctr;
+  unsigned long long *off = reinterpret_cast<unsigned long long *>(tp + tl.off);
+  unsigned long long *scratch = reinterpret_cast<unsigned long long *>(tp + tl.scratch);
+  const size_t m = (size_t)pl.nparts * pl.bins_per_part;
+  hipMemsetAsync(A.seg_count, 0, m * 4, s);
+  hipLaunchKernelGGL(k_ss_plan, dim3((pl.nparts + 3) / 4), dim3(256), (size_t)4 * pl.bins_per_part * 4, s, A);
+  const size_t lds = (size_t)kSsCap * 8 + (size_t)kSsWaves * kRsRadix * 4 + kRsRadix * 4;
+  const unsigned blocks = (unsigned)(((pl.nparts + 7u) / 8u) * 8u * pl.bins_per_part);
+  if (op_max) {
+    allow_big_lds(reinterpret_cast<const void *>(k_ss_sort<true>), lds);
+    hipLaunchKernelGGL(k_ss_sort<true>, dim3(blocks), dim3(kSsThreads), lds, s, A);
+  } else {
+    allow_big_lds(reinterpret_cast<const void *>(k_ss_sort<false>), lds);
+    hipLaunchKernelGGL(k_ss_sort<false>, dim3(blocks), dim3(kSsThreads), lds, s, A);
+  }
+  launch_scan(s, A.seg_count, off, m, scratch, num_runs);
+  hipLaunchKernelGGL(k_ss_compact, dim3((unsigned)m), dim3(256), 0, s, A, off, comp_out, val_out);
+}
+
 void launch_sparse_tmax(hipStream_t s, const unsigned long long *ucomp, uint64_t slots, const unsigned long long *P_dev, uint32_t *first, unsigned int *tmax) {
   if (slots == 0) return;
   const uint64_t need = (slots + kSpBlock - 1) / kSpBlock;

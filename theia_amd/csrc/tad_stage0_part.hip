@@ -1410,6 +1410,36 @@ bool part_plan_tiles(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
   return pl->rpt != 0;
 }
 
+// Sparse tables (second-resolution lattices, per-connection keys: tad_sparse.hip) use passes A and B only: the records of a key block are
+// sorted by (key, bucket) in LDS afterwards, no tile has to hold the block's buckets.  The key block is the smallest that leaves the
+// write-combining pass its queues (64-byte sectors: <= ~1770 partitions) — the sort streams a partition once per LDS round, so small
+// partitions are cheap ones.  Record = value << cell_bits | (bucket * KP + key-in-block) with cell_bits = log2(KP) + bit_width(T): the sort's key
+// (key-in-block << bit_width(T) | bucket) fits the same bits.  At most 28 cell bits (>= 36 value bits: wider values raise
+// DEV_ERR_OVERFLOW_LIST and the job is redone by the LSD sort, like every shape this plan refuses).
+bool part_plan_sparse(uint64_t K, uint64_t T, bool has2, PartPlan *pl) {
+  (void)has2;
+  if (T == 0 || T >= (1ull << 32) || K == 0) return false;
+  int tbits = 0;
+  while ((T >> tbits) != 0) ++tbits;
+  auto parts_of = [&](int c) { return (K + (1ull << c) - 1) >> c; };
+  const uint64_t sector_parts = kLdsBudget / (8 * 9 + 18);
+  int sp = pl->shift_bin;
+  while (sp < 13 && parts_of(sp) > sector_parts) ++sp;
+  if (parts_of(sp) > sector_parts) return false;
+  int cb = sp + tbits;
+  if (cb > 28) return false;
+  if (cb < kMinCellBits) cb = kMinCellBits;
+  pl->shift_part = sp;
+  pl->KP = 1u << sp;
+  pl->nparts = (uint32_t)parts_of(sp);
+  pl->bins_per_part = 1u << (sp - pl->shift_bin);
+  pl->cell_bits = cb;
+  pl->sp_tbits = tbits;
+  pl->tb = 0; pl->n_chunks = 0; pl->settle_kt = 0; pl->narrow = false; pl->agg_lds = 0;
+  pl->rpt = 0; pl->part_lds = 0;     // (the sort-by-tile pass B is not used: without the write-combining queues the LSD sort runs)
+  return true;
+}
+
 // Settle mode of pass C (DBSCAN jobs): kt = the most keys whose WHOLE series fit one LDS tile (9 B per cell + 5 B per key of
 // settle bookkeeping); the partition's rounds then split it by key sub-range.  Adopted when that does not take more rounds than the
 // bucket rounds it replaces (every round streams the partition's records again).
@@ -1529,7 +1559,8 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
   A.round_mask = sampled ? 15u : (pl.wc_cap ? pl.wc_sec - 1u : 0u);
   A.G = pl.G; A.partials = sampled ? partials : nullptr; A.n = n; A.chunk = pl.chunk;
   A.offs32 = offs32; A.total = total; A.part_start = part_start;
-  A.st = slice_table(slice_mem, slots, pl); A.slice_len = slice_len_of(sampled);
+  A.st = slice_table(slice_mem, slots, pl);
+  A.slice_len = g.val == nullptr ? 0xFFFFFFFFu : slice_len_of(sampled);   // (no grid: the sparse sort reads whole partitions, nothing is split or pre-zeroed)
   A.g = g; A.shift_part = pl.shift_part;
   A.spec_partials = partials; A.spec_n = spec_n; A.spec_L = spec_L != nullptr ? *spec_L : Lattice{}; A.spec_ctr = spec_L != nullptr ? spec_ctr : nullptr;
   hipLaunchKernelGGL(k_part_offsets, dim3((pl.nparts + 3) / 4 + (A.spec_ctr != nullptr ? 1 : 0)), dim3(256), 0, s, A);

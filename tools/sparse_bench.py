@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Timing of the sparse Stage-0 path (stage0_path 4 / 6: hand-written LSD radix sort + reduction, tad_sparse.hip), device-resident
+"""Timing of the sparse Stage-0 path (stage0_path 4 / 6: hand-written LSD radix sort + reduction; 8 / 9: key-block partition pass + LDS sorts, big tables; tad_sparse.hip), device-resident
 columns.  Default shapes = those of tests/test_gpu_sparse.py: (a) 3e6 rows / 2e4 keys with second-resolution timestamps over a day
 (gcd 1: the dense grid would be 15.6 GB), (b) the same with two keys of 20 000 points under a 256 MB workspace (length classes).
 `--rows N` adds the scale run of the reference's default mode (agg_flow=None keys per connection, anomaly_detection.py:52-61,
 109-116): N rows = N/100 connections x ~33 second-resolution points x 3 rows per point.  Run under rocprofv3 by
 tools/gpu_measure_r4.sh for the kernel stats / HBM counters under profiles/.
-usage: python tools/sparse_bench.py [--steps S] [--rows N] [--only-scale]"""
+usage: python tools/sparse_bench.py [--steps S] [--rows N] [--only-scale] [--sorts auto,lsd,partition]"""
 import argparse
 import os
 import sys
@@ -22,6 +22,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--rows", type=int, default=0, help="rows of the scale run (0 = none), e.g. 100000000")
 ap.add_argument("--only-scale", action="store_true")
 ap.add_argument("--algos", default="EWMA,DBSCAN")
+ap.add_argument("--sorts", default="auto", help="comma list of tad_plan.sparse_sort values for the scale run: auto, lsd, partition")
 args = ap.parse_args()
 
 
@@ -87,6 +88,7 @@ if not args.only_scale:
         eng.close()
 if args.rows:
     k, t, v, K = connection_table(args.rows, seed=7)
-    eng = TadEngine(device=0)
-    time_jobs("per-connection keys: %d connections x ~33 second-resolution points x 3 rows" % K, eng, k, t, v, K)
-    eng.close()
+    for sort in args.sorts.split(","):
+        eng = TadEngine(device=0, plan={} if sort == "auto" else {"sparse_sort": sort})
+        time_jobs("per-connection keys [sparse_sort %s]: %d connections x ~33 second-resolution points x 3 rows" % (sort, K), eng, k, t, v, K)
+        eng.close()
