@@ -773,15 +773,15 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
                          rf, L, spl, offs32, part_start, e->recs.p, nullptr, dev_ovf_count(e), 0, ctr, nullptr, nullptr);
         launch_sparse_sort(s, e->recs.p, part_start, static_cast<const uint32_t *>(e->binhist.p), spl, K, L.step, op_max,
-                           static_cast<unsigned long long *>(e->sp_comp_b.p), static_cast<unsigned long long *>(e->sp_val_b.p), ucomp, uval, e->sp_temp.p,
-                           d_runs, ctr);
+                           static_cast<unsigned long long *>(e->sp_comp_b.p), static_cast<unsigned long long *>(e->sp_val_b.p), e->sp_temp.p, d_runs, ctr);
       } else if (launch_sparse_group(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
                                      rf, L.t0, span, op_max, ucomp, uval, static_cast<unsigned long long *>(e->sp_comp_b.p),
                                      static_cast<unsigned long long *>(e->sp_val_b.p), e->sp_temp.p, tb, d_runs, ctr) != 0)
         return fail(e, TAD_ERR_HIP, "sparse Stage 0: sort / reduce failed");
       if (depth == 0) e->sp_by_partition = sp_part;
       // first[] / the longest series from the device-resident point count; then ONE round trip for both numbers
-      launch_sparse_tmax(s, ucomp, slots_all, d_runs, static_cast<uint32_t *>(e->sp_first.p), reinterpret_cast<unsigned int *>(d_runs + 1));
+      // (the partition sort counted both itself and leaves its points in the stages: the sorted list is only built for those who read it)
+      if (!sp_part) launch_sparse_tmax(s, ucomp, slots_all, d_runs, static_cast<uint32_t *>(e->sp_first.p), reinterpret_cast<unsigned int *>(d_runs + 1));
       unsigned long long runs_tmax[2] = {0, 0};
       HIP_TRY(e, hipMemcpyAsync(runs_tmax, d_runs, 16, hipMemcpyDeviceToHost, s));
       if (sp_part) HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
@@ -803,6 +803,10 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       // Skewed series lengths (one key with a day of seconds next to many short-lived ones): K x Tmax does not fit although the
       // points do.  The keys are split into length classes that run as jobs of their own (run_sparse_classes).
       if (P && depth == 0 && (need > e->ws_limit || plan.sparse_classes == 1)) {
+        if (sp_part) {
+          launch_sparse_compact(s, spl, e->sp_temp.p, static_cast<const unsigned long long *>(e->sp_comp_b.p), static_cast<const unsigned long long *>(e->sp_val_b.p), ucomp, uval);
+          launch_sparse_tmax(s, ucomp, slots_all, d_runs, static_cast<uint32_t *>(e->sp_first.p), reinterpret_cast<unsigned int *>(d_runs + 1));
+        }
         HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
         const DevCounters c0 = *e->ctr_host;
@@ -825,7 +829,11 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
                          static_cast<const long long *>(e->sp_times.p)};
       if (cells) {
         HIP_TRY(e, hipMemsetAsync(sparse_grid.flag, 0, cells, s));
-        launch_sparse_place(s, ucomp, uval, P, static_cast<const uint32_t *>(e->sp_first.p), L.t0, sparse_grid, static_cast<long long *>(e->sp_times.p));
+        if (sp_part)
+          launch_sparse_place_staged(s, spl, e->sp_temp.p, static_cast<const unsigned long long *>(e->sp_comp_b.p), static_cast<const unsigned long long *>(e->sp_val_b.p),
+                                     L.t0, sparse_grid, static_cast<long long *>(e->sp_times.p));
+        else
+          launch_sparse_place(s, ucomp, uval, P, static_cast<const uint32_t *>(e->sp_first.p), L.t0, sparse_grid, static_cast<long long *>(e->sp_times.p));
       }
       HIP_TRY(e, hipEventRecord(e->ev[3], s));
     }

@@ -571,6 +571,8 @@ struct SsArgs {
   uint32_t *n_rounds;           // [nparts]
   uint32_t *seg_count;          // [nparts * bins_per_part] unique points of the round (0 = no such round)
   unsigned long long *stage_comp, *stage_val;
+  unsigned long long *num_runs;  // += the round's unique points
+  unsigned int *tmax;            // max= the longest series of the round (all of a key's points are in one round)
   DevCounters *ctr;
 };
 
@@ -584,8 +586,17 @@ __global__ __launch_bounds__(256) void k_ss_plan(SsArgs A) {
   const uint32_t b0 = p * A.bins_per_part;
   for (uint32_t b = lane; b < A.bins_per_part; b += 64) {
     uint32_t c = 0;
-    if (b0 + b < A.nbins)
-      for (int g = 0; g < A.G; ++g) c += A.binhist[(size_t)g * A.nbins + b0 + b];
+    if (b0 + b < A.nbins) {      // batches of independent loads (one at a time: 256 memory round trips per lane, 98 us)
+      int g = 0;
+      for (; g + 8 <= A.G; g += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = A.binhist[(size_t)(g + u) * A.nbins + b0 + b];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c += v[u];
+      }
+      for (; g < A.G; ++g) c += A.binhist[(size_t)g * A.nbins + b0 + b];
+    }
     tot[b] = c;
   }
   __builtin_amdgcn_wave_barrier();
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
   uint32_t *s_hist = reinterpret_cast<uint32_t *>(rec + kSsCap);                         // [waves][256]
   uint32_t *s_base = s_hist + kSsWaves * kRsRadix;                                       // [256]
   __shared__ uint32_t s_w[kSsWaves + 1];
-  __shared__ uint32_t s_n;
+  __shared__ uint32_t s_n, s_best;
   // the rounds of a key block on ONE XCD (workgroups are dealt round-robin to the 8 XCDs): they stream the same records
   const uint32_t R = A.bins_per_part;
   const uint32_t slot = blockIdx.x >> 3;
@@ -624,35 +635,60 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
   if (p >= A.nparts || r >= A.n_rounds[p]) return;
   const SsRound rd = A.rounds[(size_t)p * R + r];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_n = 0;
+  if (threadIdx.x == 0) { s_n = 0; s_best = 0; }
   __syncthreads();
   // ---- gather the round's records ----
+  // Sets of 8 records per thread (four 16-byte loads; the regions of pass B start and end on whole sectors), two sets in flight: with one batch
+  // of loads at a time the 25 trips of a 1e5-record block each waited a full memory round trip (85 us per round, profiles/r4_v23_*).
+  // One LDS atomic per wavefront and set reserves the places of its records.
   const uint32_t cell_mask = (1u << A.cell_bits) - 1u, kp_mask = (1u << A.shift_part) - 1u;
   const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
   {
     const uint64_t lo = A.part_start[p], hi = A.part_start[p + 1];
-    constexpr int kU = 4;
-    for (uint64_t i0 = lo; i0 < hi; i0 += (uint64_t)kSsThreads * kU) {          // workgroup-uniform trip count (ballots inside)
-      unsigned long long x[kU];
+    constexpr int kL = 4;
+    constexpr uint32_t kSet = (uint32_t)kSsThreads * 2u * kL;
+    const uint32_t sets = (uint32_t)((hi - lo + kSet - 1) / kSet);
+    auto load_set = [&](ulonglong2 (&x)[kL], uint32_t set) {
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const uint64_t i = i0 + (uint64_t)u * kSsThreads + threadIdx.x;
-        x[u] = i < hi ? A.recs[i] : ~0ull;
+      for (int u = 0; u < kL; ++u) {
+        const uint64_t i = lo + (uint64_t)set * kSet + (uint64_t)u * (2u * kSsThreads) + 2u * threadIdx.x;
+        x[u] = (set < sets && i < hi) ? *reinterpret_cast<const ulonglong2 *>(A.recs + i) : ulonglong2{~0ull, ~0ull};
       }
+    };
+    auto process = [&](const ulonglong2 (&x)[kL]) {
+      unsigned long long m[2 * kL];
+      uint32_t kl[2 * kL], total = 0;
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const uint32_t cell = (uint32_t)x[u] & cell_mask;
-        const uint32_t kl = cell & kp_mask;
-        const bool take = x[u] != ~0ull && cell != cell_mask && kl >= rd.key0 && kl < rd.key1;
-        const unsigned long long m = __ballot(take);
-        if (m) {
-          uint32_t at = 0;
-          if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(m));
-          at = __shfl(at, 0) + (uint32_t)__popcll(m & lt_mask);
-          if (take && at < kSsCap)
-            rec[at] = ((x[u] >> A.cell_bits) << A.cell_bits) | ((unsigned long long)(kl - rd.key0) << A.tbits) | (cell >> A.shift_part);
+      for (int u = 0; u < 2 * kL; ++u) {
+        const unsigned long long r = (u & 1) ? x[u >> 1].y : x[u >> 1].x;
+        const uint32_t cell = (uint32_t)r & cell_mask;
+        kl[u] = cell & kp_mask;
+        const bool take = r != ~0ull && cell != cell_mask && kl[u] >= rd.key0 && kl[u] < rd.key1;
+        m[u] = __ballot(take);
+        total += (uint32_t)__popcll(m[u]);
+      }
+      if (total == 0) return;                                  // wavefront-uniform
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(&s_n, total);
+      at = __shfl(at, 0);
+#pragma unroll
+      for (int u = 0; u < 2 * kL; ++u) {
+        const unsigned long long r = (u & 1) ? x[u >> 1].y : x[u >> 1].x;
+        const uint32_t mine = at + (uint32_t)__popcll(m[u] & lt_mask);
+        if (((m[u] >> lane) & 1ull) && mine < kSsCap) {
+          const uint32_t cell = (uint32_t)r & cell_mask;
+          rec[mine] = ((r >> A.cell_bits) << A.cell_bits) | ((unsigned long long)(kl[u] - rd.key0) << A.tbits) | (cell >> A.shift_part);
         }
+        at += (uint32_t)__popcll(m[u]);
       }
+    };
+    ulonglong2 xa[kL], xb[kL];
+    load_set(xa, 0);
+    for (uint32_t set = 0; set < sets; set += 2) {
+      load_set(xb, set + 1);
+      process(xa);
+      load_set(xa, set + 2);
+      if (set + 1 < sets) process(xb);
     }
   }
   __syncthreads();
@@ -771,6 +807,34 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
   }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_comp[(size_t)rd.stage + j] = rec[j];
+  {   // the longest series of the round: a point's place in its key's series = its index - the index of the key's first point (max-scan over the threads)
+    uint32_t start_bits = 0, last1 = 0, u = before;
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i)
+      if (head_bits & (1u << i)) {
+        if (u == 0 || (rec[u - 1] >> 32) != (rec[u] >> 32)) { start_bits |= 1u << i; last1 = u + 1; }
+        ++u;
+      }
+    uint32_t sc = last1;
+    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(sc, dd); if (lane >= dd && y > sc) sc = y; }
+    uint32_t carry = __shfl_up(sc, 1);
+    if (lane == 0) carry = 0;
+    if (lane == 63) s_hist[wave] = sc;             // (the histogram area is free)
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) { const uint32_t y = s_hist[w]; if (y > carry) carry = y; }
+    uint32_t best = 0;
+    u = before;
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i)
+      if (head_bits & (1u << i)) {
+        if (start_bits & (1u << i)) carry = u + 1;
+        const uint32_t len = u + 2 - carry;
+        best = len > best ? len : best;
+        ++u;
+      }
+    for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t y = __shfl_down(best, dd); best = y > best ? y : best; }
+    if (lane == 0 && best) atomicMax(&s_best, best);
+  }
   __syncthreads();
   {
     uint32_t at = before;
@@ -780,7 +844,42 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
   }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_val[(size_t)rd.stage + j] = rec[j];
-  if (threadIdx.x == 0) A.seg_count[(size_t)p * R + r] = U;
+  if (threadIdx.x == 0) {
+    A.seg_count[(size_t)p * R + r] = U;
+    if (U) { atomicAdd(A.num_runs, (unsigned long long)U); atomicMax(A.tmax, s_best); }
+  }
+}
+
+// The rank grid straight from the stages (no sorted list in between): a workgroup per round, a point's rank in its key's series = its index in
+// the stage - the index of the key's first point (every key lies inside one round).  cell(rank, key) = rank * K + key like k_sparse_place.
+__global__ __launch_bounds__(256) void k_ss_place(SsArgs A, int64_t t0, Grid g, long long *__restrict__ times) {
+  const uint32_t seg = blockIdx.x;
+  const uint32_t cnt = A.seg_count[seg];
+  if (cnt == 0) return;
+  const unsigned long long *comp = A.stage_comp + A.rounds[seg].stage, *val = A.stage_val + A.rounds[seg].stage;
+  __shared__ uint32_t s_c[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t carry = 0;                                    // index + 1 of the last key start before this chunk
+  for (uint32_t j0 = 0; j0 < cnt; j0 += 256) {          // workgroup-uniform
+    const uint32_t j = j0 + threadIdx.x;
+    const bool in = j < cnt;
+    const unsigned long long c = in ? comp[j] : 0ull;
+    const uint32_t k = (uint32_t)(c >> 32);
+    uint32_t sc = (in && (j == 0 || (uint32_t)(comp[j - 1] >> 32) != k)) ? j + 1 : 0u;
+    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(sc, dd); if (lane >= dd && y > sc) sc = y; }
+    if (lane == 63) s_c[wave] = sc;
+    __syncthreads();
+    uint32_t st = sc > carry ? sc : carry, all = carry;
+    for (int w = 0; w < 4; ++w) { const uint32_t y = s_c[w]; if (w < wave && y > st) st = y; if (y > all) all = y; }
+    __syncthreads();
+    carry = all;
+    if (in) {
+      const uint64_t cell = (uint64_t)(j + 1 - st) * g.K + k;
+      g.val[cell] = val[j];
+      g.flag[cell] = FLAG_PRESENT;
+      times[cell] = (long long)(t0 + (int64_t)(c & 0xffffffffull));
+    }
+  }
 }
 
 // every round's stage to its place in the sorted list (off = exclusive scan of seg_count in (block, round) order)
@@ -815,22 +914,27 @@ static SsTemp ss_temp_layout(const PartPlan &pl) {
 
 size_t sparse_part_temp_bytes(const PartPlan &pl) { return ss_temp_layout(pl).total + 256; }
 
-void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long long *part_start, const uint32_t *binhist, const PartPlan &pl, uint64_t K,
-                        int64_t step, bool op_max, unsigned long long *stage_comp, unsigned long long *stage_val, unsigned long long *comp_out,
-                        unsigned long long *val_out, void *temp, unsigned long long *num_runs, DevCounters *ctr) {
+static SsArgs ss_args(const PartPlan &pl, void *temp, unsigned long long *stage_comp, unsigned long long *stage_val) {
   const SsTemp tl = ss_temp_layout(pl);
   unsigned char *tp = static_cast<unsigned char *>(temp);
   SsArgs A{};
-  A.recs = static_cast<const unsigned long long *>(recs); A.part_start = part_start; A.binhist = binhist;
   A.nbins = pl.nbins; A.bins_per_part = pl.bins_per_part; A.nparts = pl.nparts;
   A.G = pl.G; A.shift_bin = pl.shift_bin; A.shift_part = pl.shift_part; A.cell_bits = pl.cell_bits; A.tbits = pl.sp_tbits;
-  A.K = K; A.step = (unsigned long long)step;
   A.rounds = reinterpret_cast<SsRound *>(tp + tl.rounds);
   A.n_rounds = reinterpret_cast<uint32_t *>(tp + tl.n_rounds);
   A.seg_count = reinterpret_cast<uint32_t *>(tp + tl.seg_count);
-  A.stage_comp = stage_comp; A.stage_val = stage_val; A.ctr = ctr;
-  unsigned long long *off = reinterpret_cast<unsigned long long *>(tp + tl.off);
-  unsigned long long *scratch = reinterpret_cast<unsigned long long *>(tp + tl.scratch);
+  A.stage_comp = stage_comp; A.stage_val = stage_val;
+  return A;
+}
+
+// num_runs[0] = unique points, num_runs[1] (as unsigned int) = the longest series; both zeroed by the caller
+void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long long *part_start, const uint32_t *binhist, const PartPlan &pl, uint64_t K,
+                        int64_t step, bool op_max, unsigned long long *stage_comp, unsigned long long *stage_val, void *temp, unsigned long long *num_runs,
+                        DevCounters *ctr) {
+  SsArgs A = ss_args(pl, temp, stage_comp, stage_val);
+  A.recs = static_cast<const unsigned long long *>(recs); A.part_start = part_start; A.binhist = binhist;
+  A.K = K; A.step = (unsigned long long)step; A.ctr = ctr;
+  A.num_runs = num_runs; A.tmax = reinterpret_cast<unsigned int *>(num_runs + 1);
   const size_t m = (size_t)pl.nparts * pl.bins_per_part;
   hipMemsetAsync(A.seg_count, 0, m * 4, s);
   hipLaunchKernelGGL(k_ss_plan, dim3((pl.nparts + 3) / 4), dim3(256), (size_t)4 * pl.bins_per_part * 4, s, A);
@@ -843,7 +947,25 @@ void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long lon
     allow_big_lds(reinterpret_cast<const void *>(k_ss_sort<false>), lds);
     hipLaunchKernelGGL(k_ss_sort<false>, dim3(blocks), dim3(kSsThreads), lds, s, A);
   }
-  launch_scan(s, A.seg_count, off, m, scratch, num_runs);
+}
+
+// the stages -> the rank grid (the job's normal way on)
+void launch_sparse_place_staged(hipStream_t s, const PartPlan &pl, void *temp, const unsigned long long *stage_comp, const unsigned long long *stage_val,
+                                int64_t t0, Grid g, long long *times) {
+  SsArgs A = ss_args(pl, temp, const_cast<unsigned long long *>(stage_comp), const_cast<unsigned long long *>(stage_val));
+  hipLaunchKernelGGL(k_ss_place, dim3((unsigned)((size_t)pl.nparts * pl.bins_per_part)), dim3(256), 0, s, A, t0, g, times);
+}
+
+// the stages -> the sorted unique list comp_out / val_out (length classes, tad_aggregate: they read the list itself)
+void launch_sparse_compact(hipStream_t s, const PartPlan &pl, void *temp, const unsigned long long *stage_comp, const unsigned long long *stage_val,
+                           unsigned long long *comp_out, unsigned long long *val_out) {
+  SsArgs A = ss_args(pl, temp, const_cast<unsigned long long *>(stage_comp), const_cast<unsigned long long *>(stage_val));
+  const SsTemp tl = ss_temp_layout(pl);
+  unsigned char *tp = static_cast<unsigned char *>(temp);
+  unsigned long long *off = reinterpret_cast<unsigned long long *>(tp + tl.off);
+  unsigned long long *scratch = reinterpret_cast<unsigned long long *>(tp + tl.scratch);
+  const size_t m = (size_t)pl.nparts * pl.bins_per_part;
+  launch_scan(s, A.seg_count, off, m, scratch);
   hipLaunchKernelGGL(k_ss_compact, dim3((unsigned)m), dim3(256), 0, s, A, off, comp_out, val_out);
 }
 
