@@ -739,11 +739,12 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       }
       if (sp_part && hist_sampled) { force_exact_hist = true; continue; }
       v2 = false;
-      if ((rc = ensure(e, e->sp_comp_a, slots_all * 8)) != TAD_OK) return rc;
-      // (the b buffers are the staging area of the partition sort: a round's stage starts at its block's record offset, fillers of pass B included)
+      // (the partition sort: comp_a = the records by round, val_a = the staged ranks until the sorted list — if anyone needs it — takes their place;
+      //  the b buffers = the staged points; a round's place is its block's record offset, fillers of pass B included)
       const uint64_t stage_slots = slots_all + (sp_part ? spl.pad_slots : 0);
+      if ((rc = ensure(e, e->sp_comp_a, stage_slots * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->sp_comp_b, stage_slots * 8)) != TAD_OK) return rc;
-      if ((rc = ensure(e, e->sp_val_a, slots_all * 8)) != TAD_OK) return rc;
+      if ((rc = ensure(e, e->sp_val_a, stage_slots * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->sp_val_b, stage_slots * 8)) != TAD_OK) return rc;
       size_t tb = sparse_sort_temp_bytes(slots_all);
       if (sp_part && sparse_part_temp_bytes(spl) > tb) tb = sparse_part_temp_bytes(spl);
@@ -773,7 +774,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
                          rf, L, spl, offs32, part_start, e->recs.p, nullptr, dev_ovf_count(e), 0, ctr, nullptr, nullptr);
         launch_sparse_sort(s, e->recs.p, part_start, static_cast<const uint32_t *>(e->binhist.p), spl, K, L.step, op_max,
-                           static_cast<unsigned long long *>(e->sp_comp_b.p), static_cast<unsigned long long *>(e->sp_val_b.p), e->sp_temp.p, d_runs, ctr);
+                           ucomp, static_cast<unsigned long long *>(e->sp_comp_b.p), static_cast<unsigned long long *>(e->sp_val_b.p),
+                           reinterpret_cast<uint32_t *>(uval), e->sp_temp.p, d_runs, ctr);
       } else if (launch_sparse_group(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
                                      rf, L.t0, span, op_max, ucomp, uval, static_cast<unsigned long long *>(e->sp_comp_b.p),
                                      static_cast<unsigned long long *>(e->sp_val_b.p), e->sp_temp.p, tb, d_runs, ctr) != 0)
@@ -831,7 +833,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         HIP_TRY(e, hipMemsetAsync(sparse_grid.flag, 0, cells, s));
         if (sp_part)
           launch_sparse_place_staged(s, spl, e->sp_temp.p, static_cast<const unsigned long long *>(e->sp_comp_b.p), static_cast<const unsigned long long *>(e->sp_val_b.p),
-                                     L.t0, sparse_grid, static_cast<long long *>(e->sp_times.p));
+                                     reinterpret_cast<const uint32_t *>(uval), L.t0, sparse_grid, static_cast<long long *>(e->sp_times.p));
         else
           launch_sparse_place(s, ucomp, uval, P, static_cast<const uint32_t *>(e->sp_first.p), L.t0, sparse_grid, static_cast<long long *>(e->sp_times.p));
       }

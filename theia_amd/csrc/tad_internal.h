@@ -379,17 +379,18 @@ bool part_plan_settle(uint64_t T, PartPlan *pl, bool narrow = false);
 
 // ---- Stage 0 for sparse tables: sort by (key, time), reduce, rank grid (tad_sparse.hip) ----
 size_t sparse_sort_temp_bytes(uint64_t slots);
-// The sparse Stage 0 of big tables: pass B's records (key blocks, launch_partition) -> per key sub-range of a block one workgroup gathers the
-// records, sorts them in LDS by (key, bucket), folds equal runs and STAGES the unique points (stage_comp / stage_val: slots + pad words each);
-// num_runs[0] += unique points, (unsigned int &)num_runs[1] max= the longest series (both zeroed by the caller).  From the stages either the
-// rank grid directly (launch_sparse_place_staged) or, for the consumers of the sorted list itself (length classes, tad_aggregate), the
-// compacted list (launch_sparse_compact: comp_out / val_out as launch_sparse_group leaves them).
+// The sparse Stage 0 of big tables: pass B's records (key blocks, launch_partition) -> split by round into recs2 (a round = a key sub-range of a
+// block whose records fit LDS) -> one workgroup per round sorts its records in LDS by (key, bucket), folds equal runs and STAGES the unique
+// points (stage_comp / stage_val / stage_rank, recs2: slots + pad words each); num_runs[0] += unique points, (unsigned int &)num_runs[1] max=
+// the longest series (both zeroed by the caller).  From the stages either the rank grid directly (launch_sparse_place_staged) or, for the
+// consumers of the sorted list itself (length classes, tad_aggregate), the compacted list (launch_sparse_compact: comp_out / val_out as
+// launch_sparse_group leaves them).
 size_t sparse_part_temp_bytes(const PartPlan &pl);
 void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long long *part_start, const uint32_t *binhist, const PartPlan &pl, uint64_t K,
-                        int64_t step, bool op_max, unsigned long long *stage_comp, unsigned long long *stage_val, void *temp, unsigned long long *num_runs,
-                        DevCounters *ctr);
+                        int64_t step, bool op_max, unsigned long long *recs2, unsigned long long *stage_comp, unsigned long long *stage_val,
+                        uint32_t *stage_rank, void *temp, unsigned long long *num_runs, DevCounters *ctr);
 void launch_sparse_place_staged(hipStream_t s, const PartPlan &pl, void *temp, const unsigned long long *stage_comp, const unsigned long long *stage_val,
-                                int64_t t0, Grid g, long long *times);
+                                const uint32_t *stage_rank, int64_t t0, Grid g, long long *times);
 void launch_sparse_compact(hipStream_t s, const PartPlan &pl, void *temp, const unsigned long long *stage_comp, const unsigned long long *stage_val,
                            unsigned long long *comp_out, unsigned long long *val_out);
 int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end, const int64_t *t_start,

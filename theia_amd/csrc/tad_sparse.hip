@@ -542,13 +542,16 @@ int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2
 // (bucket * KP + key-in-block), tad_stage0_part.hip), which leaves every key block's records contiguous, and then
 //   k_ss_plan   a wavefront per key block: the block's bin totals (pass A's histogram summed over its workgroups) are grouped greedily
 //               into ROUNDS of <= kSsCap records — whole bins, so that every key's records are in exactly one round
-//   k_ss_sort   a workgroup per (block, round): streams the block's records (the rounds of a block run side by side on one XCD and share
-//               its L2), keeps those of its key sub-range in LDS as value << cell_bits | (key-in-round << tbits | bucket), sorts them
+//   k_ss_split  a workgroup per key block: one more stream over the block's records moves each to its round's place in a second
+//               record buffer (the rounds' sizes are known: exact positions, one LDS cursor per round, the lanes of a wavefront that
+//               hold the same round take their places together).  The first form had every round's workgroup filter the whole block
+//               instead: eight reads of the block, of which L2 caught too few (k_ss_sort 2.5 ms, profiles/r4_v24_*)
+//   k_ss_sort   a workgroup per (block, round): loads its records into LDS as value << cell_bits | (key-in-round << tbits | bucket), sorts them
 //               there by that key — least-significant-digit passes with the ballot ranking of k_rs_scatter, the items in registers between
 //               the passes —, folds the runs of equal (key, bucket) with the job's operator (wrapping add / unsigned max) and writes the unique
 //               points of the round, in order, to a staging area at (block start + records of the earlier bins): coalesced, through LDS
 //   scan + k_ss_compact   the rounds' point counts -> positions; every round's stage is copied to its place in the final sorted list.
-// The columns are read once (24 B/row), the records written and read once more through HBM (8 + 8 B/row; the rounds' re-reads hit L2).
+// The columns are read once (24 B/row), the records written and read twice more through HBM (2 x (8 + 8) B/row).
 // A bin that alone exceeds a round (a heavy key), a value that does not fit the record, or a shape the plan refuses: the LSD sort runs.
 // ------------------------------------------------------------------------------------------------
 static constexpr int kSsThreads = 1024;
@@ -569,6 +572,10 @@ struct SsArgs {
   unsigned long long step;
   SsRound *rounds;              // [nparts][bins_per_part]
   uint32_t *n_rounds;           // [nparts]
+  uint8_t *bin_round;           // [nparts][bins_per_part] round of every bin (k_ss_plan; needs <= 256 rounds per block: checked)
+  uint32_t *round_fill;         // [nparts * bins_per_part] records k_ss_split placed (the histogram also counts rows off the lattice)
+  unsigned long long *recs2;    // the records by round: round (p, r) at [rounds[p][r].stage, + fill)
+  uint32_t *stage_rank;         // place of every staged point in its key's series
   uint32_t *seg_count;          // [nparts * bins_per_part] unique points of the round (0 = no such round)
   unsigned long long *stage_comp, *stage_val;
   unsigned long long *num_runs;  // += the round's unique points
@@ -603,6 +610,7 @@ __global__ __launch_bounds__(256) void k_ss_plan(SsArgs A) {
   __threadfence_block();
   if (lane != 0) return;
   SsRound *out = A.rounds + (size_t)p * A.bins_per_part;
+  uint8_t *br = A.bin_round + (size_t)p * A.bins_per_part;
   const uint32_t base = (uint32_t)A.part_start[p];
   uint32_t r = 0, acc = 0, first = 0, before = 0, err = 0;
   for (uint32_t b = 0; b < A.bins_per_part; ++b) {
@@ -614,10 +622,75 @@ __global__ __launch_bounds__(256) void k_ss_plan(SsArgs A) {
     }
     if (acc == 0) first = b;
     acc += c;
+    br[b] = (uint8_t)r;
+    if (r > 255u) err = DEV_ERR_SPARSE_ROUND;
   }
   if (acc != 0) out[r++] = SsRound{first << A.shift_bin, A.bins_per_part << A.shift_bin, acc, base + before};
   A.n_rounds[p] = r;
   if (err) atomicOr(&A.ctr->err, err);
+}
+
+__global__ __launch_bounds__(kSsThreads) void k_ss_split(SsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ss_split_smem[];
+  const uint32_t R = A.bins_per_part;
+  uint32_t *s_cur = reinterpret_cast<uint32_t *>(ss_split_smem);     // [R] records placed per round
+  uint32_t *s_at = s_cur + R;                                          // [R] the round's place in recs2
+  uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_at + R);              // [R] bin -> round
+  const uint32_t p = blockIdx.x;
+  const uint32_t nr = A.n_rounds[p];
+  for (uint32_t i = threadIdx.x; i < R; i += kSsThreads) {
+    s_cur[i] = 0;
+    s_at[i] = i < nr ? A.rounds[(size_t)p * R + i].stage : 0u;
+    s_tab[i] = A.bin_round[(size_t)p * R + i];
+  }
+  __syncthreads();
+  int rbits = 0;
+  while (nr > 1 && ((nr - 1u) >> rbits) != 0) ++rbits;
+  const int lane = threadIdx.x & 63;
+  const uint32_t cell_mask = (1u << A.cell_bits) - 1u, kp_mask = (1u << A.shift_part) - 1u;
+  const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+  const uint64_t lo = A.part_start[p], hi = A.part_start[p + 1];
+  constexpr int kL = 4;
+  constexpr uint32_t kSet = (uint32_t)kSsThreads * 2u * kL;
+  const uint32_t sets = (uint32_t)((hi - lo + kSet - 1) / kSet);
+  auto load_set = [&](ulonglong2 (&x)[kL], uint32_t set) {
+#pragma unroll
+    for (int u = 0; u < kL; ++u) {
+      const uint64_t i = lo + (uint64_t)set * kSet + (uint64_t)u * (2u * kSsThreads) + 2u * threadIdx.x;
+      x[u] = (set < sets && i < hi) ? *reinterpret_cast<const ulonglong2 *>(A.recs + i) : ulonglong2{~0ull, ~0ull};
+    }
+  };
+  auto process = [&](const ulonglong2 (&x)[kL]) {
+#pragma unroll
+    for (int u = 0; u < 2 * kL; ++u) {
+      const unsigned long long rc = (u & 1) ? x[u >> 1].y : x[u >> 1].x;
+      const uint32_t cell = (uint32_t)rc & cell_mask;
+      const bool take = rc != ~0ull && cell != cell_mask;
+      const uint32_t r = take ? s_tab[(cell & kp_mask) >> A.shift_bin] : 0u;
+      unsigned long long peers = __ballot(take);
+      if (peers == 0ull) continue;                            // wavefront-uniform
+      for (int b = 0; b < rbits; ++b) {                        // the lanes that hold the same round
+        const bool bit = (r >> b) & 1u;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      const int leader = __ffsll((long long)peers) - 1;        // (lanes that do not take: their own `peers` is never used)
+      uint32_t at = 0;
+      if (take && lane == leader) at = atomicAdd(&s_cur[r], (uint32_t)__popcll(peers));
+      at = __shfl(at, take ? leader : lane);
+      if (take) A.recs2[(size_t)s_at[r] + at + (uint32_t)__popcll(peers & lt_mask)] = rc;
+    }
+  };
+  ulonglong2 xa[kL], xb[kL];
+  load_set(xa, 0);
+  for (uint32_t set = 0; set < sets; set += 2) {
+    load_set(xb, set + 1);
+    process(xa);
+    load_set(xa, set + 2);
+    if (set + 1 < sets) process(xb);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nr; i += kSsThreads) A.round_fill[(size_t)p * R + i] = s_cur[i];
 }
 
 template <bool OPMAX>
@@ -637,59 +710,27 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) { s_n = 0; s_best = 0; }
   __syncthreads();
-  // ---- gather the round's records ----
-  // Sets of 8 records per thread (four 16-byte loads; the regions of pass B start and end on whole sectors), two sets in flight: with one batch
-  // of loads at a time the 25 trips of a 1e5-record block each waited a full memory round trip (85 us per round, profiles/r4_v23_*).
-  // One LDS atomic per wavefront and set reserves the places of its records.
+  // ---- the round's records (k_ss_split brought them together) ----
   const uint32_t cell_mask = (1u << A.cell_bits) - 1u, kp_mask = (1u << A.shift_part) - 1u;
   const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
   {
-    const uint64_t lo = A.part_start[p], hi = A.part_start[p + 1];
-    constexpr int kL = 4;
-    constexpr uint32_t kSet = (uint32_t)kSsThreads * 2u * kL;
-    const uint32_t sets = (uint32_t)((hi - lo + kSet - 1) / kSet);
-    auto load_set = [&](ulonglong2 (&x)[kL], uint32_t set) {
+    const uint32_t fill = A.round_fill[(size_t)p * R + r];
+    const unsigned long long *src = A.recs2 + rd.stage;
+    unsigned long long x[kSsItems];
 #pragma unroll
-      for (int u = 0; u < kL; ++u) {
-        const uint64_t i = lo + (uint64_t)set * kSet + (uint64_t)u * (2u * kSsThreads) + 2u * threadIdx.x;
-        x[u] = (set < sets && i < hi) ? *reinterpret_cast<const ulonglong2 *>(A.recs + i) : ulonglong2{~0ull, ~0ull};
-      }
-    };
-    auto process = [&](const ulonglong2 (&x)[kL]) {
-      unsigned long long m[2 * kL];
-      uint32_t kl[2 * kL], total = 0;
-#pragma unroll
-      for (int u = 0; u < 2 * kL; ++u) {
-        const unsigned long long r = (u & 1) ? x[u >> 1].y : x[u >> 1].x;
-        const uint32_t cell = (uint32_t)r & cell_mask;
-        kl[u] = cell & kp_mask;
-        const bool take = r != ~0ull && cell != cell_mask && kl[u] >= rd.key0 && kl[u] < rd.key1;
-        m[u] = __ballot(take);
-        total += (uint32_t)__popcll(m[u]);
-      }
-      if (total == 0) return;                                  // wavefront-uniform
-      uint32_t at = 0;
-      if (lane == 0) at = atomicAdd(&s_n, total);
-      at = __shfl(at, 0);
-#pragma unroll
-      for (int u = 0; u < 2 * kL; ++u) {
-        const unsigned long long r = (u & 1) ? x[u >> 1].y : x[u >> 1].x;
-        const uint32_t mine = at + (uint32_t)__popcll(m[u] & lt_mask);
-        if (((m[u] >> lane) & 1ull) && mine < kSsCap) {
-          const uint32_t cell = (uint32_t)r & cell_mask;
-          rec[mine] = ((r >> A.cell_bits) << A.cell_bits) | ((unsigned long long)(kl[u] - rd.key0) << A.tbits) | (cell >> A.shift_part);
-        }
-        at += (uint32_t)__popcll(m[u]);
-      }
-    };
-    ulonglong2 xa[kL], xb[kL];
-    load_set(xa, 0);
-    for (uint32_t set = 0; set < sets; set += 2) {
-      load_set(xb, set + 1);
-      process(xa);
-      load_set(xa, set + 2);
-      if (set + 1 < sets) process(xb);
+    for (int i = 0; i < kSsItems; ++i) {
+      const uint32_t j = (uint32_t)i * kSsThreads + threadIdx.x;
+      x[i] = j < fill ? src[j] : 0ull;
     }
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i) {
+      const uint32_t j = (uint32_t)i * kSsThreads + threadIdx.x;
+      if (j < fill) {
+        const uint32_t cell = (uint32_t)x[i] & cell_mask;
+        rec[j] = ((x[i] >> A.cell_bits) << A.cell_bits) | ((unsigned long long)((cell & kp_mask) - rd.key0) << A.tbits) | (cell >> A.shift_part);
+      }
+    }
+    if (threadIdx.x == 0) s_n = fill;
   }
   __syncthreads();
   uint32_t n = s_n;
@@ -830,6 +871,7 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
         if (start_bits & (1u << i)) carry = u + 1;
         const uint32_t len = u + 2 - carry;
         best = len > best ? len : best;
+        hk[i] = len - 1u;                         // (the composite is staged: hk now carries the point's place in its series)
         ++u;
       }
     for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t y = __shfl_down(best, dd); best = y > best ? y : best; }
@@ -844,41 +886,38 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
   }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_val[(size_t)rd.stage + j] = rec[j];
+  __syncthreads();
+  {
+    uint32_t *rk = reinterpret_cast<uint32_t *>(rec);
+    uint32_t at = before;
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i)
+      if (head_bits & (1u << i)) rk[at++] = hk[i];
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_rank[(size_t)rd.stage + j] = rk[j];
+  }
   if (threadIdx.x == 0) {
     A.seg_count[(size_t)p * R + r] = U;
     if (U) { atomicAdd(A.num_runs, (unsigned long long)U); atomicMax(A.tmax, s_best); }
   }
 }
 
-// The rank grid straight from the stages (no sorted list in between): a workgroup per round, a point's rank in its key's series = its index in
-// the stage - the index of the key's first point (every key lies inside one round).  cell(rank, key) = rank * K + key like k_sparse_place.
+// The rank grid straight from the stages (no sorted list in between): cell(rank, key) = rank * K + key like k_sparse_place, the rank staged by
+// k_ss_sort.  A workgroup per round, independent loads and stores (a first form derived the ranks here with a max-scan per 256 points: two
+// barriers per chunk, 1.08 ms at 3.3e7 points — more than the list + k_sparse_place it replaced).
 __global__ __launch_bounds__(256) void k_ss_place(SsArgs A, int64_t t0, Grid g, long long *__restrict__ times) {
   const uint32_t seg = blockIdx.x;
   const uint32_t cnt = A.seg_count[seg];
   if (cnt == 0) return;
-  const unsigned long long *comp = A.stage_comp + A.rounds[seg].stage, *val = A.stage_val + A.rounds[seg].stage;
-  __shared__ uint32_t s_c[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t carry = 0;                                    // index + 1 of the last key start before this chunk
-  for (uint32_t j0 = 0; j0 < cnt; j0 += 256) {          // workgroup-uniform
-    const uint32_t j = j0 + threadIdx.x;
-    const bool in = j < cnt;
-    const unsigned long long c = in ? comp[j] : 0ull;
-    const uint32_t k = (uint32_t)(c >> 32);
-    uint32_t sc = (in && (j == 0 || (uint32_t)(comp[j - 1] >> 32) != k)) ? j + 1 : 0u;
-    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(sc, dd); if (lane >= dd && y > sc) sc = y; }
-    if (lane == 63) s_c[wave] = sc;
-    __syncthreads();
-    uint32_t st = sc > carry ? sc : carry, all = carry;
-    for (int w = 0; w < 4; ++w) { const uint32_t y = s_c[w]; if (w < wave && y > st) st = y; if (y > all) all = y; }
-    __syncthreads();
-    carry = all;
-    if (in) {
-      const uint64_t cell = (uint64_t)(j + 1 - st) * g.K + k;
-      g.val[cell] = val[j];
-      g.flag[cell] = FLAG_PRESENT;
-      times[cell] = (long long)(t0 + (int64_t)(c & 0xffffffffull));
-    }
+  const size_t at = A.rounds[seg].stage;
+  const unsigned long long *comp = A.stage_comp + at, *val = A.stage_val + at;
+  const uint32_t *rank = A.stage_rank + at;
+  for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
+    const unsigned long long c = comp[j];
+    const uint64_t cell = (uint64_t)rank[j] * g.K + (c >> 32);
+    g.val[cell] = val[j];
+    g.flag[cell] = FLAG_PRESENT;
+    times[cell] = (long long)(t0 + (int64_t)(c & 0xffffffffull));
   }
 }
 
@@ -897,7 +936,7 @@ __global__ __launch_bounds__(256) void k_ss_compact(SsArgs A, const unsigned lon
 }
 
 // temp: rounds [nparts * bpp] | n_rounds [nparts] | seg_count [nparts * bpp] | off u64 [nparts * bpp + 1] | scan scratch
-struct SsTemp { size_t rounds, n_rounds, seg_count, off, scratch, total; };
+struct SsTemp { size_t rounds, n_rounds, bin_round, round_fill, seg_count, off, scratch, total; };
 static SsTemp ss_temp_layout(const PartPlan &pl) {
   const size_t m = (size_t)pl.nparts * pl.bins_per_part;
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -905,6 +944,8 @@ static SsTemp ss_temp_layout(const PartPlan &pl) {
   size_t at = 0;
   t.rounds = at; at = up(at + m * sizeof(SsRound));
   t.n_rounds = at; at = up(at + (size_t)pl.nparts * 4);
+  t.bin_round = at; at = up(at + m);
+  t.round_fill = at; at = up(at + m * 4);
   t.seg_count = at; at = up(at + m * 4);
   t.off = at; at = up(at + (m + 1) * 8);
   t.scratch = at; at = up(at + scan_scratch_elems(m ? m : 1) * 8);
@@ -923,21 +964,25 @@ static SsArgs ss_args(const PartPlan &pl, void *temp, unsigned long long *stage_
   A.rounds = reinterpret_cast<SsRound *>(tp + tl.rounds);
   A.n_rounds = reinterpret_cast<uint32_t *>(tp + tl.n_rounds);
   A.seg_count = reinterpret_cast<uint32_t *>(tp + tl.seg_count);
+  A.bin_round = reinterpret_cast<uint8_t *>(tp + tl.bin_round);
+  A.round_fill = reinterpret_cast<uint32_t *>(tp + tl.round_fill);
   A.stage_comp = stage_comp; A.stage_val = stage_val;
   return A;
 }
 
 // num_runs[0] = unique points, num_runs[1] (as unsigned int) = the longest series; both zeroed by the caller
 void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long long *part_start, const uint32_t *binhist, const PartPlan &pl, uint64_t K,
-                        int64_t step, bool op_max, unsigned long long *stage_comp, unsigned long long *stage_val, void *temp, unsigned long long *num_runs,
-                        DevCounters *ctr) {
+                        int64_t step, bool op_max, unsigned long long *recs2, unsigned long long *stage_comp, unsigned long long *stage_val,
+                        uint32_t *stage_rank, void *temp, unsigned long long *num_runs, DevCounters *ctr) {
   SsArgs A = ss_args(pl, temp, stage_comp, stage_val);
   A.recs = static_cast<const unsigned long long *>(recs); A.part_start = part_start; A.binhist = binhist;
   A.K = K; A.step = (unsigned long long)step; A.ctr = ctr;
+  A.recs2 = recs2; A.stage_rank = stage_rank;
   A.num_runs = num_runs; A.tmax = reinterpret_cast<unsigned int *>(num_runs + 1);
   const size_t m = (size_t)pl.nparts * pl.bins_per_part;
   hipMemsetAsync(A.seg_count, 0, m * 4, s);
   hipLaunchKernelGGL(k_ss_plan, dim3((pl.nparts + 3) / 4), dim3(256), (size_t)4 * pl.bins_per_part * 4, s, A);
+  hipLaunchKernelGGL(k_ss_split, dim3(pl.nparts), dim3(kSsThreads), (((size_t)pl.bins_per_part * 9 + 15) & ~(size_t)15), s, A);
   const size_t lds = (size_t)kSsCap * 8 + (size_t)kSsWaves * kRsRadix * 4 + kRsRadix * 4;
   const unsigned blocks = (unsigned)(((pl.nparts + 7u) / 8u) * 8u * pl.bins_per_part);
   if (op_max) {
@@ -951,8 +996,9 @@ void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long lon
 
 // the stages -> the rank grid (the job's normal way on)
 void launch_sparse_place_staged(hipStream_t s, const PartPlan &pl, void *temp, const unsigned long long *stage_comp, const unsigned long long *stage_val,
-                                int64_t t0, Grid g, long long *times) {
+                                const uint32_t *stage_rank, int64_t t0, Grid g, long long *times) {
   SsArgs A = ss_args(pl, temp, const_cast<unsigned long long *>(stage_comp), const_cast<unsigned long long *>(stage_val));
+  A.stage_rank = const_cast<uint32_t *>(stage_rank);
   hipLaunchKernelGGL(k_ss_place, dim3((unsigned)((size_t)pl.nparts * pl.bins_per_part)), dim3(256), 0, s, A, t0, g, times);
 }
 
