@@ -630,6 +630,16 @@ __global__ __launch_bounds__(256) void k_ss_plan(SsArgs A) {
   if (err) atomicOr(&A.ctr->err, err);
 }
 
+#if defined(TAD_SS_PROF)
+// profiling build (tools/build_variants.py ssprof:TAD_SS_PROF; never the shipped library): shader-clock cycles of thread 0 per phase of k_ss_sort
+__device__ unsigned long long g_ss_prof[8];
+#define SS_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define SS_ADD(slot, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_ss_prof[slot], (b) - (a)); } while (0)
+#else
+#define SS_T(v)
+#define SS_ADD(slot, a, b)
+#endif
+
 __global__ __launch_bounds__(kSsThreads) void k_ss_split(SsArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ss_split_smem[];
   const uint32_t R = A.bins_per_part;
@@ -693,214 +703,331 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_split(SsArgs A) {
   for (uint32_t i = threadIdx.x; i < nr; i += kSsThreads) A.round_fill[(size_t)p * R + i] = s_cur[i];
 }
 
+// LDS barrier: LDS traffic only (the kernel's global stores are never read back by the workgroup; __syncthreads() would wait for them:
+// the three store phases of the output each cost a memory round trip, profiles/r4_v26_ss_sort_phases.log)
+__device__ __forceinline__ void ss_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+static constexpr uint32_t kSsMsdBits = 12;                       // 4096 buckets of ~3.5 records in a full round
+static constexpr uint32_t kSsMaxBucket = 32;                     // a larger bucket (many points of one key inside one time window): the stable LSD passes sort the round
+
 template <bool OPMAX>
 __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
   unsigned long long *rec = reinterpret_cast<unsigned long long *>(ss_smem);             // [kSsCap]
-  uint32_t *s_hist = reinterpret_cast<uint32_t *>(rec + kSsCap);                         // [waves][256]
+  uint32_t *s_hist = reinterpret_cast<uint32_t *>(rec + kSsCap);                         // [waves][256] = [4096]
   uint32_t *s_base = s_hist + kSsWaves * kRsRadix;                                       // [256]
   __shared__ uint32_t s_w[kSsWaves + 1];
-  __shared__ uint32_t s_n, s_best;
-  // the rounds of a key block on ONE XCD (workgroups are dealt round-robin to the 8 XCDs): they stream the same records
+  __shared__ uint32_t s_best, s_maxb;
+  // the rounds of a key block side by side (workgroups are dealt round-robin to the 8 XCDs)
   const uint32_t R = A.bins_per_part;
   const uint32_t slot = blockIdx.x >> 3;
   const uint32_t p = (slot / R) * 8u + (blockIdx.x & 7u), r = slot % R;
   if (p >= A.nparts || r >= A.n_rounds[p]) return;
   const SsRound rd = A.rounds[(size_t)p * R + r];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) { s_n = 0; s_best = 0; }
-  __syncthreads();
-  // ---- the round's records (k_ss_split brought them together) ----
+  if (threadIdx.x == 0) { s_best = 0; s_maxb = 0; }
+  SS_T(t_0);
+  // ---- the round's records (k_ss_split brought them together): LDS as value << cell_bits | (key-in-round << tbits | bucket) ----
   const uint32_t cell_mask = (1u << A.cell_bits) - 1u, kp_mask = (1u << A.shift_part) - 1u;
+  const unsigned long long sk_mask = (1ull << A.cell_bits) - 1ull;
   const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-  {
-    const uint32_t fill = A.round_fill[(size_t)p * R + r];
-    const unsigned long long *src = A.recs2 + rd.stage;
-    unsigned long long x[kSsItems];
-#pragma unroll
-    for (int i = 0; i < kSsItems; ++i) {
-      const uint32_t j = (uint32_t)i * kSsThreads + threadIdx.x;
-      x[i] = j < fill ? src[j] : 0ull;
-    }
-#pragma unroll
-    for (int i = 0; i < kSsItems; ++i) {
-      const uint32_t j = (uint32_t)i * kSsThreads + threadIdx.x;
-      if (j < fill) {
-        const uint32_t cell = (uint32_t)x[i] & cell_mask;
-        rec[j] = ((x[i] >> A.cell_bits) << A.cell_bits) | ((unsigned long long)((cell & kp_mask) - rd.key0) << A.tbits) | (cell >> A.shift_part);
-      }
-    }
-    if (threadIdx.x == 0) s_n = fill;
-  }
-  __syncthreads();
-  uint32_t n = s_n;
-  if (n > kSsCap) {   // cannot happen: the plan counted the bins (every record of a bin was counted by pass A)
-    if (threadIdx.x == 0) atomicOr(&A.ctr->err, DEV_ERR_SPARSE_ROUND);
-    n = kSsCap;
-  }
-  // ---- sort by (key-in-round, bucket): LSD passes over the bits in use ----
+  const uint32_t n = A.round_fill[(size_t)p * R + r] < kSsCap ? A.round_fill[(size_t)p * R + r] : kSsCap;   // (<= the histogram's count <= kSsCap by the plan)
   int kbits = 0;
   while (((rd.key1 - rd.key0 - 1u) >> kbits) != 0) ++kbits;
   const int bits = A.tbits + kbits;
-  const int np = bits > 0 ? (bits + 7) / 8 : 0;
-  int shift = 0, left = bits;
+  const int mbits = bits < (int)kSsMsdBits ? bits : (int)kSsMsdBits;
+  const int mshift = bits - mbits;
   unsigned long long c[kSsItems];
-  uint32_t rr[kSsItems];
-  uint32_t *my_hist = s_hist + wave * kRsRadix;
-  for (int ps = 0; ps < np; ++ps) {
-    const int width = (left + (np - ps) - 1) / (np - ps);
-    const uint32_t mask = (1u << width) - 1u;
-    for (uint32_t i = threadIdx.x; i < kSsWaves * kRsRadix; i += kSsThreads) s_hist[i] = 0;
+  for (uint32_t i = threadIdx.x; i < (1u << kSsMsdBits); i += kSsThreads) s_hist[i] = 0;
+  {
+    const unsigned long long *src = A.recs2 + rd.stage;
 #pragma unroll
     for (int i = 0; i < kSsItems; ++i) {
-      const uint32_t j = (uint32_t)wave * kSsSlice + (uint32_t)i * 64 + (uint32_t)lane;
+      const uint32_t j = (uint32_t)i * kSsThreads + threadIdx.x;
+      c[i] = j < n ? src[j] : 0ull;
+    }
+    ss_barrier();                                               // the bucket counters are zero
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i) {
+      const uint32_t j = (uint32_t)i * kSsThreads + threadIdx.x;
+      if (j < n) {
+        const uint32_t cell = (uint32_t)c[i] & cell_mask;
+        const unsigned long long x = ((c[i] >> A.cell_bits) << A.cell_bits) | ((unsigned long long)((cell & kp_mask) - rd.key0) << A.tbits) | (cell >> A.shift_part);
+        rec[j] = x;                                             // (kept in LDS, not in registers, over the scan: 128 VGPRs at 1024 threads)
+        atomicAdd(&s_hist[(uint32_t)((x & sk_mask) >> mshift)], 1u);
+      }
+    }
+  }
+  ss_barrier();
+  SS_T(t_1);
+  SS_ADD(0, t_0, t_1);
+  // ---- sort by (key-in-round, bucket).  Most significant 12 bits first: a counting sort with LDS atomics (no order inside a bucket), then
+  // every bucket — ~3.5 records — is put in order by counting (below).  The stable LSD passes with the ballot ranking of
+  // k_rs_scatter cost 36 of a round's 57 us (240 VALU instructions per record); they remain for rounds with a crowded bucket. ----
+  {
+    // exclusive scan of the 4096 bucket counts, 4 per thread; the largest bucket
+    uint32_t b4[4], sum = 0, mx = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { b4[q] = s_hist[threadIdx.x * 4 + q]; sum += b4[q]; mx = b4[q] > mx ? b4[q] : mx; }
+    uint32_t incl = sum;
+    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
+    for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t y = __shfl_down(mx, dd); mx = y > mx ? y : mx; }
+    if (lane == 63) s_w[wave] = incl;
+    if (lane == 0 && mx) atomicMax(&s_maxb, mx);
+    ss_barrier();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_w[w];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s_hist[threadIdx.x * 4 + q] = run; run += b4[q]; }
+    ss_barrier();
+  }
+  if (s_maxb <= kSsMaxBucket || mshift == 0) {                  // workgroup-uniform
+#pragma unroll
+    for (int i = 0; i < kSsItems; ++i) {
+      const uint32_t j = (uint32_t)i * kSsThreads + threadIdx.x;
       c[i] = j < n ? rec[j] : 0ull;
     }
-    __syncthreads();
+    ss_barrier();
 #pragma unroll
     for (int i = 0; i < kSsItems; ++i) {
-      const uint32_t j = (uint32_t)wave * kSsSlice + (uint32_t)i * 64 + (uint32_t)lane;
-      const bool in = j < n;
-      const uint32_t d = (uint32_t)(c[i] >> shift) & mask;
-      unsigned long long peers = __ballot(in);
-      for (int b = 0; b < width; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long m = __ballot(bit);
-        peers &= bit ? m : ~m;
-      }
-      const uint32_t old = in ? my_hist[d] : 0u;
-      __builtin_amdgcn_wave_barrier();
-      if (in && (peers & lt_mask) == 0ull) my_hist[d] = old + (uint32_t)__popcll(peers);
-      __builtin_amdgcn_wave_barrier();
-      rr[i] = old + (uint32_t)__popcll(peers & lt_mask);
+      const uint32_t j = (uint32_t)i * kSsThreads + threadIdx.x;
+      if (j < n) rec[atomicAdd(&s_hist[(uint32_t)((c[i] & sk_mask) >> mshift)], 1u)] = c[i];     // (the counter of bucket d ends at the start of bucket d + 1)
     }
-    __syncthreads();
-    uint32_t tot_d = 0;
-    if (threadIdx.x < kRsRadix) {
-      for (int w = 0; w < kSsWaves; ++w) {
-        const uint32_t t = s_hist[w * kRsRadix + threadIdx.x];
-        s_hist[w * kRsRadix + threadIdx.x] = tot_d;
-        tot_d += t;
-      }
-    }
-    {   // exclusive scan of the digit totals (the first 256 threads = 4 wavefronts hold one each)
-      uint32_t incl = tot_d;
-      for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
-      if (lane == 63) s_w[wave] = incl;
-      __syncthreads();
-      uint32_t before = 0;
-      for (int w = 0; w < 4; ++w) if (w < wave) before += s_w[w];
-      if (threadIdx.x < kRsRadix) s_base[threadIdx.x] = before + incl - tot_d;
-    }
-    __syncthreads();
+    ss_barrier();
+    if (mshift != 0) {
+      // order inside the buckets by COUNTING: a record's place = the bucket's records with a smaller key (or the same key further left).
+      // One record per thread and step: the lanes of a wavefront walk buckets of similar sizes (an insertion sort per bucket, one thread per
+      // bucket, paid the square of the largest bucket of every 64: 143k cycles per round against the LSD passes' 76k)
+      uint32_t pos[kSsItems];
+      const uint32_t *rec32 = reinterpret_cast<const uint32_t *>(rec);
+      const uint32_t skm = (uint32_t)sk_mask;
 #pragma unroll
-    for (int i = 0; i < kSsItems; ++i) {
-      const uint32_t j = (uint32_t)wave * kSsSlice + (uint32_t)i * 64 + (uint32_t)lane;
-      if (j < n) {
+      for (int i = 0; i < kSsItems; ++i) {
+        const uint32_t j = (uint32_t)i * kSsThreads + threadIdx.x;
+        pos[i] = j;
+        if (j < n) {
+          c[i] = rec[j];
+          const uint32_t key = (uint32_t)c[i] & skm;
+          const uint32_t d = key >> mshift;
+          const uint32_t b0 = d ? s_hist[d - 1] : 0u, b1 = s_hist[d];
+          uint32_t rank = 0;
+          for (uint32_t k = b0; k < b1; ++k) {
+            const uint32_t y = rec32[2 * k] & skm;
+            rank += (y < key || (y == key && k < j)) ? 1u : 0u;
+          }
+          pos[i] = b0 + rank;
+        }
+      }
+      ss_barrier();
+#pragma unroll
+      for (int i = 0; i < kSsItems; ++i)
+        if ((uint32_t)i * kSsThreads + threadIdx.x < n) rec[pos[i]] = c[i];
+      ss_barrier();
+    }
+  } else {
+    // stable LSD passes over the bits in use (digits of <= 8 bits), the items in registers between the passes
+    const int np = (bits + 7) / 8;
+    int shift = 0, left = bits;
+    uint32_t rr[kSsItems];
+    uint32_t *my_hist = s_hist + wave * kRsRadix;
+    for (int ps = 0; ps < np; ++ps) {
+      const int width = (left + (np - ps) - 1) / (np - ps);
+      const uint32_t mask = (1u << width) - 1u;
+      for (uint32_t i = threadIdx.x; i < kSsWaves * kRsRadix; i += kSsThreads) s_hist[i] = 0;
+#pragma unroll
+      for (int i = 0; i < kSsItems; ++i) {
+        const uint32_t j = (uint32_t)wave * kSsSlice + (uint32_t)i * 64 + (uint32_t)lane;
+        c[i] = j < n ? rec[j] : 0ull;
+      }
+      ss_barrier();
+#pragma unroll
+      for (int i = 0; i < kSsItems; ++i) {
+        const uint32_t j = (uint32_t)wave * kSsSlice + (uint32_t)i * 64 + (uint32_t)lane;
+        const bool in = j < n;
         const uint32_t d = (uint32_t)(c[i] >> shift) & mask;
-        rec[s_base[d] + my_hist[d] + rr[i]] = c[i];
+        unsigned long long peers = __ballot(in);
+        for (int b = 0; b < width; ++b) {
+          const bool bit = (d >> b) & 1u;
+          const unsigned long long m = __ballot(bit);
+          peers &= bit ? m : ~m;
+        }
+        const uint32_t old = in ? my_hist[d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (in && (peers & lt_mask) == 0ull) my_hist[d] = old + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rr[i] = old + (uint32_t)__popcll(peers & lt_mask);
       }
+      ss_barrier();
+      uint32_t tot_d = 0;
+      if (threadIdx.x < kRsRadix) {
+        for (int w = 0; w < kSsWaves; ++w) {
+          const uint32_t t = s_hist[w * kRsRadix + threadIdx.x];
+          s_hist[w * kRsRadix + threadIdx.x] = tot_d;
+          tot_d += t;
+        }
+      }
+      {   // exclusive scan of the digit totals (the first 256 threads = 4 wavefronts hold one each)
+        uint32_t incl = tot_d;
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
+        if (lane == 63) s_w[wave] = incl;
+        ss_barrier();
+        uint32_t before = 0;
+        for (int w = 0; w < 4; ++w) if (w < wave) before += s_w[w];
+        if (threadIdx.x < kRsRadix) s_base[threadIdx.x] = before + incl - tot_d;
+      }
+      ss_barrier();
+#pragma unroll
+      for (int i = 0; i < kSsItems; ++i) {
+        const uint32_t j = (uint32_t)wave * kSsSlice + (uint32_t)i * 64 + (uint32_t)lane;
+        if (j < n) {
+          const uint32_t d = (uint32_t)(c[i] >> shift) & mask;
+          rec[s_base[d] + my_hist[d] + rr[i]] = c[i];
+        }
+      }
+      ss_barrier();
+      shift += width; left -= width;
     }
-    __syncthreads();
-    shift += width; left -= width;
   }
-  // ---- fold the runs of equal (key, bucket): thread t owns the sorted slots [t * kSsItems, ...) ----
-  const unsigned long long sk_mask = (1ull << A.cell_bits) - 1ull;
+  SS_T(t_2);
+  SS_ADD(1, t_1, t_2);
+  // ---- fold the runs of equal (key, bucket).  Thread t owns the sorted slots [t * kSsItems, ...): one pass over them in registers; the
+  // piece of a run that began in an earlier thread's slots (`lead`) is handed over through LDS and absorbed by the run's head ----
   const uint32_t j0 = threadIdx.x * kSsItems;
-  uint32_t head_bits = 0;
+  uint32_t head_bits = 0, start_bits = 0;      // heads of (key, bucket) runs; those that are their key's first point
   unsigned long long hv[kSsItems];
   uint32_t hk[kSsItems];
+  {
+    unsigned long long *s_lead = reinterpret_cast<unsigned long long *>(s_hist);          // [threads] (the bucket counters are done)
+    uint32_t *s_lflag = reinterpret_cast<uint32_t *>(s_lead + kSsThreads);                  // [threads] bit 0: a lead exists, bit 1: no head among the slots
 #pragma unroll
-  for (int i = 0; i < kSsItems; ++i) {
-    const uint32_t j = j0 + i;
-    hv[i] = 0; hk[i] = 0;
-    if (j < n) {
-      const unsigned long long x = rec[j];
-      const uint32_t sk = (uint32_t)(x & sk_mask);
-      if (j == 0 || (uint32_t)(rec[j - 1] & sk_mask) != sk) {
-        unsigned long long acc = x >> A.cell_bits;
-        for (uint32_t k = j + 1; k < n; ++k) {
-          const unsigned long long y = rec[k];
-          if ((uint32_t)(y & sk_mask) != sk) break;
-          const unsigned long long v = y >> A.cell_bits;
-          acc = OPMAX ? (v > acc ? v : acc) : acc + v;
+    for (int i = 0; i < kSsItems; ++i) c[i] = j0 + i < n ? rec[j0 + i] : 0ull;
+    const unsigned long long prev = (j0 != 0 && j0 < n) ? rec[j0 - 1] : 0ull;
+    // heads: a slot whose key differs from its predecessor's
+    {
+      uint32_t before_sk = (uint32_t)(prev & sk_mask);
+      bool have_prev = j0 != 0 && j0 < n;
+#pragma unroll
+      for (int i = 0; i < kSsItems; ++i) {
+        hv[i] = 0; hk[i] = 0;
+        if (j0 + i < n) {
+          const uint32_t sk = (uint32_t)(c[i] & sk_mask);
+          if (!have_prev || sk != before_sk) {
+            head_bits |= 1u << i; hk[i] = sk;
+            if (!have_prev || (sk >> A.tbits) != (before_sk >> A.tbits)) start_bits |= 1u << i;
+          }
+          before_sk = sk; have_prev = true;
         }
-        head_bits |= 1u << i;
-        hv[i] = acc; hk[i] = sk;
+      }
+    }
+    // backwards: the fold of every run's piece inside my slots lands on the piece's first slot (a head, or slot 0 = the lead)
+    unsigned long long racc = 0ull;
+#pragma unroll
+    for (int i = kSsItems - 1; i >= 0; --i) {
+      if (j0 + i < n) {
+        const unsigned long long v = c[i] >> A.cell_bits;
+        const bool last_of_piece = i == kSsItems - 1 || j0 + i + 1 >= n || (head_bits & (2u << i)) != 0;
+        racc = last_of_piece ? v : (OPMAX ? (v > racc ? v : racc) : v + racc);
+        if (head_bits & (1u << i)) hv[i] = racc;
+      }
+    }
+    const bool lead_has = j0 < n && (head_bits & 1u) == 0;
+    s_lead[threadIdx.x] = racc;                          // (slot 0's piece)
+    s_lflag[threadIdx.x] = (lead_has ? 1u : 0u) | (head_bits == 0 ? 2u : 0u);
+    ss_barrier();
+    if (head_bits != 0) {                                // my last head's run may go on in the following threads' slots
+      unsigned long long more = 0ull;
+      bool any = false;
+      for (uint32_t tt = threadIdx.x + 1; tt < kSsThreads && tt * kSsItems < n; ++tt) {
+        const uint32_t fl = s_lflag[tt];
+        if (fl & 1u) { const unsigned long long v = s_lead[tt]; more = any ? (OPMAX ? (v > more ? v : more) : more + v) : v; any = true; }
+        if (!(fl & 2u) || !(fl & 1u)) break;
+      }
+      if (any) {
+        const int h = 31 - __clz((int)head_bits);
+#pragma unroll
+        for (int q = 0; q < kSsItems; ++q)
+          if (q == h) hv[q] = OPMAX ? (more > hv[q] ? more : hv[q]) : hv[q] + more;
       }
     }
   }
+  // positions of my points in the round's list (sum scan) and the list index + 1 of the last key start before them (max scan)
   uint32_t mine = (uint32_t)__popc(head_bits), incl = mine;
   for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
-  __syncthreads();                       // every run is folded: the record area is free
   if (lane == 63) s_w[wave] = incl;
-  __syncthreads();
+  ss_barrier();                          // every thread has read its slots and the leads: the record area and the counter area are free
   uint32_t before = incl - mine, U = 0;
   for (int w = 0; w < kSsWaves; ++w) { if (w < wave) before += s_w[w]; U += s_w[w]; }
-  // ---- the round's unique points, in order, through LDS: composites, then values ----
-  const unsigned long long key_base = ((unsigned long long)p << A.shift_part) + rd.key0;
-  const uint32_t t_mask = (1u << A.tbits) - 1u;
+  uint32_t carry;
   {
-    uint32_t at = before;
+    uint32_t last1 = 0, u = before;
 #pragma unroll
     for (int i = 0; i < kSsItems; ++i)
-      if (head_bits & (1u << i)) rec[at++] = ((key_base + (hk[i] >> A.tbits)) << 32) | ((unsigned long long)(hk[i] & t_mask) * A.step);
-  }
-  __syncthreads();
-  for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_comp[(size_t)rd.stage + j] = rec[j];
-  {   // the longest series of the round: a point's place in its key's series = its index - the index of the key's first point (max-scan over the threads)
-    uint32_t start_bits = 0, last1 = 0, u = before;
-#pragma unroll
-    for (int i = 0; i < kSsItems; ++i)
-      if (head_bits & (1u << i)) {
-        if (u == 0 || (rec[u - 1] >> 32) != (rec[u] >> 32)) { start_bits |= 1u << i; last1 = u + 1; }
-        ++u;
-      }
+      if (head_bits & (1u << i)) { if (start_bits & (1u << i)) last1 = u + 1; ++u; }
     uint32_t sc = last1;
     for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(sc, dd); if (lane >= dd && y > sc) sc = y; }
-    uint32_t carry = __shfl_up(sc, 1);
+    carry = __shfl_up(sc, 1);
     if (lane == 0) carry = 0;
-    if (lane == 63) s_hist[wave] = sc;             // (the histogram area is free)
-    __syncthreads();
+    if (lane == 63) s_hist[wave] = sc;
+    ss_barrier();
     for (int w = 0; w < wave; ++w) { const uint32_t y = s_hist[w]; if (y > carry) carry = y; }
-    uint32_t best = 0;
-    u = before;
+  }
+  SS_T(t_3);
+  SS_ADD(2, t_2, t_3);
+  // ---- the round's unique points, in order, to the stage: composite, value, place in the key's series (= list index - index of the key's first
+  // point); through LDS so that consecutive lanes store consecutive words.  All three at once when they fit the record area (20 B per point) ----
+  const unsigned long long key_base = ((unsigned long long)p << A.shift_part) + rd.key0;
+  const uint32_t t_mask = (1u << A.tbits) - 1u;
+  const bool one_pass = (size_t)U * 20 <= (size_t)kSsCap * 8;        // workgroup-uniform
+  unsigned long long *l_val = rec + (one_pass ? U : 0u);
+  uint32_t *l_rank = reinterpret_cast<uint32_t *>(rec + (one_pass ? 2u * U : 0u));
+  uint32_t best = 0;
+  {
+    uint32_t u = before;
 #pragma unroll
     for (int i = 0; i < kSsItems; ++i)
       if (head_bits & (1u << i)) {
         if (start_bits & (1u << i)) carry = u + 1;
-        const uint32_t len = u + 2 - carry;
-        best = len > best ? len : best;
-        hk[i] = len - 1u;                         // (the composite is staged: hk now carries the point's place in its series)
+        const uint32_t rank = u + 1 - carry;
+        best = rank + 1 > best ? rank + 1 : best;
+        rec[u] = ((key_base + (hk[i] >> A.tbits)) << 32) | ((unsigned long long)(hk[i] & t_mask) * A.step);
+        if (one_pass) { l_val[u] = hv[i]; l_rank[u] = rank; }
+        hk[i] = rank;
         ++u;
       }
     for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t y = __shfl_down(best, dd); best = y > best ? y : best; }
     if (lane == 0 && best) atomicMax(&s_best, best);
   }
-  __syncthreads();
-  {
-    uint32_t at = before;
+  ss_barrier();
+  for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_comp[(size_t)rd.stage + j] = rec[j];
+  if (!one_pass) {
+    ss_barrier();
+    uint32_t u = before;
 #pragma unroll
     for (int i = 0; i < kSsItems; ++i)
-      if (head_bits & (1u << i)) rec[at++] = hv[i];
+      if (head_bits & (1u << i)) l_val[u++] = hv[i];
+    ss_barrier();
   }
-  __syncthreads();
-  for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_val[(size_t)rd.stage + j] = rec[j];
-  __syncthreads();
-  {
-    uint32_t *rk = reinterpret_cast<uint32_t *>(rec);
-    uint32_t at = before;
+  for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_val[(size_t)rd.stage + j] = l_val[j];
+  if (!one_pass) {
+    ss_barrier();
+    uint32_t u = before;
 #pragma unroll
     for (int i = 0; i < kSsItems; ++i)
-      if (head_bits & (1u << i)) rk[at++] = hk[i];
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_rank[(size_t)rd.stage + j] = rk[j];
+      if (head_bits & (1u << i)) l_rank[u++] = hk[i];
+    ss_barrier();
   }
+  for (uint32_t j = threadIdx.x; j < U; j += kSsThreads) A.stage_rank[(size_t)rd.stage + j] = l_rank[j];
+  SS_T(t_4);
+  SS_ADD(3, t_3, t_4);
   if (threadIdx.x == 0) {
+#if defined(TAD_SS_PROF)
+    atomicAdd(&g_ss_prof[4], 1ull);
+#endif
     A.seg_count[(size_t)p * R + r] = U;
     if (U) { atomicAdd(A.num_runs, (unsigned long long)U); atomicMax(A.tmax, s_best); }
   }
 }
+
 
 // The rank grid straight from the stages (no sorted list in between): cell(rank, key) = rank * K + key like k_sparse_place, the rank staged by
 // k_ss_sort.  A workgroup per round, independent loads and stores (a first form derived the ranks here with a max-scan per 256 points: two
@@ -992,6 +1119,17 @@ void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long lon
     allow_big_lds(reinterpret_cast<const void *>(k_ss_sort<false>), lds);
     hipLaunchKernelGGL(k_ss_sort<false>, dim3(blocks), dim3(kSsThreads), lds, s, A);
   }
+#if defined(TAD_SS_PROF)
+  {
+    hipStreamSynchronize(s);
+    unsigned long long h[8];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ss_prof), sizeof h);
+    const double w = h[4] ? (double)h[4] : 1.0;
+    fprintf(stderr, "ss prof: %llu rounds; cycles of the 100 MHz clock per round: load %.0f, sort %.0f, fold %.0f, output %.0f\n", h[4], h[0] / w, h[1] / w, h[2] / w, h[3] / w);
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ss_prof), z, sizeof z);
+  }
+#endif
 }
 
 // the stages -> the rank grid (the job's normal way on)
