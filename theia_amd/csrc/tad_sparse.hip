@@ -554,7 +554,11 @@ int launch_sparse_group(hipStream_t s, const uint64_t *key, const uint64_t *key2
 // The columns are read once (24 B/row), the records written and read twice more through HBM (2 x (8 + 8) B/row).
 // A bin that alone exceeds a round (a heavy key), a value that does not fit the record, or a shape the plan refuses: the LSD sort runs.
 // ------------------------------------------------------------------------------------------------
-static constexpr int kSsThreads = 1024;
+#if !defined(TAD_SS_THREADS)
+#define TAD_SS_THREADS 1024
+#endif
+static constexpr int kSsThreads = TAD_SS_THREADS;             // of k_ss_sort (a measurement build may halve the workgroup: two per CU)
+static constexpr int kSplitThreads = 1024;                     // of k_ss_split
 static constexpr int kSsWaves = kSsThreads / 64;
 static constexpr int kSsItems = 14;
 static constexpr uint32_t kSsCap = kSsThreads * kSsItems;       // 14336 records (112 KB of LDS)
@@ -640,7 +644,7 @@ __device__ unsigned long long g_ss_prof[8];
 #define SS_ADD(slot, a, b)
 #endif
 
-__global__ __launch_bounds__(kSsThreads) void k_ss_split(SsArgs A) {
+__global__ __launch_bounds__(kSplitThreads) void k_ss_split(SsArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ss_split_smem[];
   const uint32_t R = A.bins_per_part;
   uint32_t *s_cur = reinterpret_cast<uint32_t *>(ss_split_smem);     // [R] records placed per round
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_split(SsArgs A) {
   uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_at + R);              // [R] bin -> round
   const uint32_t p = blockIdx.x;
   const uint32_t nr = A.n_rounds[p];
-  for (uint32_t i = threadIdx.x; i < R; i += kSsThreads) {
+  for (uint32_t i = threadIdx.x; i < R; i += kSplitThreads) {
     s_cur[i] = 0;
     s_at[i] = i < nr ? A.rounds[(size_t)p * R + i].stage : 0u;
     s_tab[i] = A.bin_round[(size_t)p * R + i];
@@ -661,12 +665,12 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_split(SsArgs A) {
   const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
   const uint64_t lo = A.part_start[p], hi = A.part_start[p + 1];
   constexpr int kL = 4;
-  constexpr uint32_t kSet = (uint32_t)kSsThreads * 2u * kL;
+  constexpr uint32_t kSet = (uint32_t)kSplitThreads * 2u * kL;
   const uint32_t sets = (uint32_t)((hi - lo + kSet - 1) / kSet);
   auto load_set = [&](ulonglong2 (&x)[kL], uint32_t set) {
 #pragma unroll
     for (int u = 0; u < kL; ++u) {
-      const uint64_t i = lo + (uint64_t)set * kSet + (uint64_t)u * (2u * kSsThreads) + 2u * threadIdx.x;
+      const uint64_t i = lo + (uint64_t)set * kSet + (uint64_t)u * (2u * kSplitThreads) + 2u * threadIdx.x;
       x[u] = (set < sets && i < hi) ? *reinterpret_cast<const ulonglong2 *>(A.recs + i) : ulonglong2{~0ull, ~0ull};
     }
   };
@@ -700,14 +704,14 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_split(SsArgs A) {
     if (set + 1 < sets) process(xb);
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < nr; i += kSsThreads) A.round_fill[(size_t)p * R + i] = s_cur[i];
+  for (uint32_t i = threadIdx.x; i < nr; i += kSplitThreads) A.round_fill[(size_t)p * R + i] = s_cur[i];
 }
 
 // LDS barrier: LDS traffic only (the kernel's global stores are never read back by the workgroup; __syncthreads() would wait for them:
 // the three store phases of the output each cost a memory round trip, profiles/r4_v26_ss_sort_phases.log)
 __device__ __forceinline__ void ss_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-static constexpr uint32_t kSsMsdBits = 12;                       // 4096 buckets of ~3.5 records in a full round
+static constexpr uint32_t kSsMsdBits = 13;                       // 8192 buckets of ~1.8 records in a full round (12 bits: the ranks inside the buckets cost 45k of a round's 90k cycles)
 static constexpr uint32_t kSsMaxBucket = 32;                     // a larger bucket (many points of one key inside one time window): the stable LSD passes sort the round
 
 template <bool OPMAX>
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
   unsigned long long *rec = reinterpret_cast<unsigned long long *>(ss_smem);             // [kSsCap]
   uint32_t *s_hist = reinterpret_cast<uint32_t *>(rec + kSsCap);                         // [waves][256] = [4096]
-  uint32_t *s_base = s_hist + kSsWaves * kRsRadix;                                       // [256]
+  uint32_t *s_base = s_hist + (1u << kSsMsdBits);                                         // [256]
   __shared__ uint32_t s_w[kSsWaves + 1];
   __shared__ uint32_t s_best, s_maxb;
   // the rounds of a key block side by side (workgroups are dealt round-robin to the 8 XCDs)
@@ -766,9 +770,10 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
   // k_rs_scatter cost 36 of a round's 57 us (240 VALU instructions per record); they remain for rounds with a crowded bucket. ----
   {
     // exclusive scan of the 4096 bucket counts, 4 per thread; the largest bucket
-    uint32_t b4[4], sum = 0, mx = 0;
+    constexpr int kBk = (1 << kSsMsdBits) / kSsThreads;
+    uint32_t b4[kBk], sum = 0, mx = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { b4[q] = s_hist[threadIdx.x * 4 + q]; sum += b4[q]; mx = b4[q] > mx ? b4[q] : mx; }
+    for (int q = 0; q < kBk; ++q) { b4[q] = s_hist[threadIdx.x * kBk + q]; sum += b4[q]; mx = b4[q] > mx ? b4[q] : mx; }
     uint32_t incl = sum;
     for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
     for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t y = __shfl_down(mx, dd); mx = y > mx ? y : mx; }
@@ -778,9 +783,11 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
     uint32_t run = incl - sum;
     for (int w = 0; w < wave; ++w) run += s_w[w];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { s_hist[threadIdx.x * 4 + q] = run; run += b4[q]; }
+    for (int q = 0; q < kBk; ++q) { s_hist[threadIdx.x * kBk + q] = run; run += b4[q]; }
     ss_barrier();
   }
+  SS_T(t_1a);
+  SS_ADD(5, t_1, t_1a);
   if (s_maxb <= kSsMaxBucket || mshift == 0) {                  // workgroup-uniform
 #pragma unroll
     for (int i = 0; i < kSsItems; ++i) {
@@ -794,6 +801,8 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
       if (j < n) rec[atomicAdd(&s_hist[(uint32_t)((c[i] & sk_mask) >> mshift)], 1u)] = c[i];     // (the counter of bucket d ends at the start of bucket d + 1)
     }
     ss_barrier();
+    SS_T(t_1b);
+    SS_ADD(6, t_1a, t_1b);
     if (mshift != 0) {
       // order inside the buckets by COUNTING: a record's place = the bucket's records with a smaller key (or the same key further left).
       // One record per thread and step: the lanes of a wavefront walk buckets of similar sizes (an insertion sort per bucket, one thread per
@@ -810,15 +819,22 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
           const uint32_t key = (uint32_t)c[i] & skm;
           const uint32_t d = key >> mshift;
           const uint32_t b0 = d ? s_hist[d - 1] : 0u, b1 = s_hist[d];
+          const unsigned long long me = ((unsigned long long)key << 32) | j;
           uint32_t rank = 0;
-          for (uint32_t k = b0; k < b1; ++k) {
-            const uint32_t y = rec32[2 * k] & skm;
-            rank += (y < key || (y == key && k < j)) ? 1u : 0u;
+          for (uint32_t k = b0; k < b1; k += 4) {            // four independent LDS reads per trip (one at a time: a round trip each)
+            uint32_t y[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] = rec32[2 * (k + q < b1 ? k + q : b1 - 1)] & skm;
+            // (key, slot) pairs compared as one 64-bit number; a slot past the bucket's end compares as the largest
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rank += ((k + q < b1 ? (((unsigned long long)y[q] << 32) | (k + q)) : ~0ull) < me) ? 1u : 0u;
           }
           pos[i] = b0 + rank;
         }
       }
       ss_barrier();
+      SS_T(t_1c);
+      SS_ADD(7, t_1b, t_1c);
 #pragma unroll
       for (int i = 0; i < kSsItems; ++i)
         if ((uint32_t)i * kSsThreads + threadIdx.x < n) rec[pos[i]] = c[i];
@@ -1030,21 +1046,64 @@ __global__ __launch_bounds__(kSsThreads) void k_ss_sort(SsArgs A) {
 
 
 // The rank grid straight from the stages (no sorted list in between): cell(rank, key) = rank * K + key like k_sparse_place, the rank staged by
-// k_ss_sort.  A workgroup per round, independent loads and stores (a first form derived the ranks here with a max-scan per 256 points: two
-// barriers per chunk, 1.08 ms at 3.3e7 points — more than the list + k_sparse_place it replaced).
-__global__ __launch_bounds__(256) void k_ss_place(SsArgs A, int64_t t0, Grid g, long long *__restrict__ times) {
+// k_ss_sort.  The stage is key-major, the grid rank-major: written point by point every lane of a store hits its own 64-byte sector, and the
+// address unit handles those one at a time — 0.97 ms for 3.3e7 points (k_sparse_place pays the same 0.54 ms for the LSD path).  So the
+// transposition goes through LDS: a workgroup per round loads the stage in chunks of kSpChunk points (coalesced), notes per key where its
+// points start in the chunk (and at which rank: a long series spans chunks), then walks (rank, key) with the KEY fastest: consecutive lanes
+// store consecutive keys of one rank row.
+static constexpr int kSpThreads = 1024;
+static constexpr uint32_t kSpChunk = 4096;
+
+__global__ __launch_bounds__(kSpThreads) void k_ss_place(SsArgs A, int64_t t0, Grid g, long long *__restrict__ times) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
   const uint32_t seg = blockIdx.x;
   const uint32_t cnt = A.seg_count[seg];
   if (cnt == 0) return;
-  const size_t at = A.rounds[seg].stage;
-  const unsigned long long *comp = A.stage_comp + at, *val = A.stage_val + at;
-  const uint32_t *rank = A.stage_rank + at;
-  for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
-    const unsigned long long c = comp[j];
-    const uint64_t cell = (uint64_t)rank[j] * g.K + (c >> 32);
-    g.val[cell] = val[j];
-    g.flag[cell] = FLAG_PRESENT;
-    times[cell] = (long long)(t0 + (int64_t)(c & 0xffffffffull));
+  const SsRound rd = A.rounds[seg];
+  const uint32_t range = rd.key1 - rd.key0;
+  unsigned long long *l_val = reinterpret_cast<unsigned long long *>(sp_smem);        // [kSpChunk]
+  uint32_t *l_dt = reinterpret_cast<uint32_t *>(l_val + kSpChunk);                   // [kSpChunk]
+  uint32_t *l_start = l_dt + kSpChunk;                                               // [range] first point of the key in the chunk
+  uint32_t *l_rank0 = l_start + range;                                               // [range] its rank
+  uint32_t *l_len = l_rank0 + range;                                                 // [range] points of the key in the chunk
+  __shared__ uint32_t s_maxlen;
+  const unsigned long long *comp = A.stage_comp + rd.stage, *val = A.stage_val + rd.stage;
+  const uint32_t *rank = A.stage_rank + rd.stage;
+  const unsigned long long key_first = ((unsigned long long)(seg / A.bins_per_part) << A.shift_part) + rd.key0;
+  for (uint32_t c0 = 0; c0 < cnt; c0 += kSpChunk) {                                  // workgroup-uniform
+    const uint32_t m = cnt - c0 < kSpChunk ? cnt - c0 : kSpChunk;
+    for (uint32_t k = threadIdx.x; k < range; k += kSpThreads) l_len[k] = 0;
+    if (threadIdx.x == 0) s_maxlen = 0;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < m; j += kSpThreads) {
+      const unsigned long long c = comp[c0 + j];
+      const uint32_t rk = rank[c0 + j];
+      const uint32_t kl = (uint32_t)((c >> 32) - key_first);
+      l_val[j] = val[c0 + j];
+      l_dt[j] = (uint32_t)c;
+      if (j == 0 || rk == 0) { l_start[kl] = j; l_rank0[kl] = rk; }
+      if (j + 1 == m || rank[c0 + j + 1] == 0) {              // the key's last point in the chunk (ranks count up inside a key)
+        const uint32_t first = rk < j ? rk : j;               // points of the key before this one inside the chunk
+        l_len[kl] = first + 1;
+        atomicMax(&s_maxlen, first + 1);
+      }
+    }
+    __syncthreads();
+    const uint32_t maxlen = s_maxlen;
+    // (rank r, key k) = cell q of the maxlen x range rectangle, q = threadIdx.x + i * kSpThreads: advanced without a division per step
+    const uint32_t dr = kSpThreads / range, dk = kSpThreads % range;
+    uint32_t r = threadIdx.x / range, k = threadIdx.x % range;
+    for (; r < maxlen; r += dr, k += dk) {
+      if (k >= range) { k -= range; ++r; if (r >= maxlen) break; }
+      if (r < l_len[k]) {
+        const uint32_t j = l_start[k] + r;
+        const uint64_t cell = (uint64_t)(l_rank0[k] + r) * g.K + key_first + k;
+        g.val[cell] = l_val[j];
+        g.flag[cell] = FLAG_PRESENT;
+        times[cell] = (long long)(t0 + (int64_t)l_dt[j]);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1109,8 +1168,8 @@ void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long lon
   const size_t m = (size_t)pl.nparts * pl.bins_per_part;
   hipMemsetAsync(A.seg_count, 0, m * 4, s);
   hipLaunchKernelGGL(k_ss_plan, dim3((pl.nparts + 3) / 4), dim3(256), (size_t)4 * pl.bins_per_part * 4, s, A);
-  hipLaunchKernelGGL(k_ss_split, dim3(pl.nparts), dim3(kSsThreads), (((size_t)pl.bins_per_part * 9 + 15) & ~(size_t)15), s, A);
-  const size_t lds = (size_t)kSsCap * 8 + (size_t)kSsWaves * kRsRadix * 4 + kRsRadix * 4;
+  hipLaunchKernelGGL(k_ss_split, dim3(pl.nparts), dim3(kSplitThreads), (((size_t)pl.bins_per_part * 9 + 15) & ~(size_t)15), s, A);
+  const size_t lds = (size_t)kSsCap * 8 + ((size_t)1 << kSsMsdBits) * 4 + kRsRadix * 4;
   const unsigned blocks = (unsigned)(((pl.nparts + 7u) / 8u) * 8u * pl.bins_per_part);
   if (op_max) {
     allow_big_lds(reinterpret_cast<const void *>(k_ss_sort<true>), lds);
@@ -1125,7 +1184,7 @@ void launch_sparse_sort(hipStream_t s, const void *recs, const unsigned long lon
     unsigned long long h[8];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ss_prof), sizeof h);
     const double w = h[4] ? (double)h[4] : 1.0;
-    fprintf(stderr, "ss prof: %llu rounds; cycles of the 100 MHz clock per round: load %.0f, sort %.0f, fold %.0f, output %.0f\n", h[4], h[0] / w, h[1] / w, h[2] / w, h[3] / w);
+    fprintf(stderr, "ss prof: %llu rounds; shader-clock cycles per round: load + count %.0f, sort %.0f (bucket scan %.0f, scatter %.0f, ranks in the buckets %.0f), fold %.0f, output %.0f\n", h[4], h[0] / w, h[1] / w, h[5] / w, h[6] / w, h[7] / w, h[2] / w, h[3] / w);
     unsigned long long z[8] = {0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_ss_prof), z, sizeof z);
   }
@@ -1137,7 +1196,9 @@ void launch_sparse_place_staged(hipStream_t s, const PartPlan &pl, void *temp, c
                                 const uint32_t *stage_rank, int64_t t0, Grid g, long long *times) {
   SsArgs A = ss_args(pl, temp, const_cast<unsigned long long *>(stage_comp), const_cast<unsigned long long *>(stage_val));
   A.stage_rank = const_cast<uint32_t *>(stage_rank);
-  hipLaunchKernelGGL(k_ss_place, dim3((unsigned)((size_t)pl.nparts * pl.bins_per_part)), dim3(256), 0, s, A, t0, g, times);
+  const size_t lds = (size_t)kSpChunk * 12 + (size_t)pl.KP * 12;
+  allow_big_lds(reinterpret_cast<const void *>(k_ss_place), lds);
+  hipLaunchKernelGGL(k_ss_place, dim3((unsigned)((size_t)pl.nparts * pl.bins_per_part)), dim3(kSpThreads), lds, s, A, t0, g, times);
 }
 
 // the stages -> the sorted unique list comp_out / val_out (length classes, tad_aggregate: they read the list itself)

@@ -12,7 +12,7 @@ timeout 900 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err
 timeout 120 python bench.py --host-input --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs > $O/bench_host_input.json 2>/dev/null
 timeout 300 python tools/ab_plans.py --config c2 > $O/ab_c2_one_sync.log 2>&1
 timeout 300 python tools/ab_plans.py --config c4 > $O/ab_c4_one_sync.log 2>&1
-timeout 400 python tools/sparse_bench.py --steps 5 --rows 100000000 > $O/sparse_bench.log 2>&1
+timeout 400 python tools/sparse_bench.py --steps 5 --rows 100000000 --sorts lsd,auto > $O/sparse_bench.log 2>&1
 timeout 600 python tools/factorize_bench.py > $O/factorize_bench.log 2>&1
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-other-configs"
