@@ -52,6 +52,12 @@ class FakeClickHouse:
                 owner.queries.append(sql)
                 assert sql.endswith(" FORMAT ArrowStream")
                 key = sql[: -len(" FORMAT ArrowStream")]
+                if " FROM tadetector" in key:                          # the result table: answered from what has been inserted
+                    table = owner.select_tadetector(key, {k[6:]: v[0] for k, v in params.items() if k.startswith("param_")})
+                    sink = io.BytesIO()
+                    with ipc.new_stream(sink, table.schema) as w:
+                        w.write_table(table)
+                    self.send_response(200); self.end_headers(); self.wfile.write(sink.getvalue()); return
                 known = {k.rstrip(): v for k, v in owner.responses.items()}   # the client strips the SQL's trailing blank
                 if key not in known:
                     self.send_response(404); self.end_headers(); self.wfile.write(b"unknown query"); return
@@ -65,6 +71,30 @@ class FakeClickHouse:
         self.url = "http://127.0.0.1:%d" % self.httpd.server_address[1]
         self.thread = threading.Thread(target=self.httpd.serve_forever, daemon=True)
         self.thread.start()
+
+    def select_tadetector(self, sql, params):
+        """`SELECT <columns> FROM tadetector WHERE id = ({id:String})` / `SELECT DISTINCT id FROM tadetector` over the inserted rows, with
+        the column types of create_table.sh:363-384 (a column an INSERT did not name holds the type's default; rows a
+        `ALTER TABLE ... DELETE WHERE id = ('<id>')` named are gone)."""
+        deleted = {c.split("('")[1].split("')")[0] for c in self.commands if "DELETE WHERE id = ('" in c}
+        rows = [r for _, rs in self.inserted for r in rs if r.get("id") not in deleted]
+        if sql.startswith("SELECT DISTINCT id FROM tadetector"):
+            return pa.table({"id": pa.array(sorted({r["id"] for r in rows}), pa.string())})
+        cols = sql[len("SELECT "):sql.index(" FROM ")].split(", ")
+        assert sql.endswith("WHERE id = ({id:String})") and "id" in params, (sql, params)
+        rows = [r for r in rows if r.get("id") == params["id"]]
+        arrays = {}
+        for c in cols:
+            kind = ch.TADETECTOR_COLUMNS[c]
+            if kind == "datetime":
+                arrays[c] = pa.array(np.asarray([r.get(c) or 0 for r in rows], dtype="int64").astype("datetime64[s]"), pa.timestamp("s"))
+            elif kind == "f64":
+                arrays[c] = pa.array([float(r.get(c) or 0.0) for r in rows], pa.float64())
+            elif kind in ("u16", "u8"):
+                arrays[c] = pa.array([int(r.get(c) or 0) for r in rows], pa.uint16())
+            else:
+                arrays[c] = pa.array([str(r.get(c) or "") for r in rows], pa.string())
+        return pa.table(arrays)
 
     def close(self):
         self.httpd.shutdown()

@@ -1,0 +1,247 @@
+"""The read-back path (theia_amd/rest.py): tadetector rows -> ThroughputAnomalyDetectorStats -> the table `theia tad retrieve` prints.
+
+CPU: rest_test.go's Test_getTadetectorResult / TestREST_Get / _Create / _Delete restated (pkg/apiserver/registry/intelligence/
+throughputanomalydetector/rest_test.go:38-380), Go's string forms of the scanned columns, the garbage collection of stale rows
+(controller.go:232-276).  GPU: the reference's e2e retrieve check (test/e2e/throughputanomalydetection_test.go:222-300) on the rows a job
+of the MI355X engine wrote: run -> COMPLETED -> REST.get -> table -> the e2e's own field counts, indices and result map."""
+import uuid
+from datetime import datetime, timezone
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from theia_amd import controller as ctl
+from theia_amd import rest
+
+NS = rest.DEFAULT_NAMESPACE
+
+
+class StubClickHouse:
+    """query_columns answers with a prepared column dict (what sqlmock.NewRows does in rest_test.go); records statements."""
+
+    def __init__(self, columns=None, fail=None):
+        self.columns, self.fail, self.queries, self.commands = columns or {}, fail, [], []
+
+    def query_columns(self, sql, dict_strings=False, params=None):
+        self.queries.append((sql, params))
+        if self.fail:
+            raise IOError(self.fail)
+        return {k: np.asarray(v, dtype=object) for k, v in self.columns.items()}
+
+    def command(self, sql):
+        self.commands.append(sql)
+
+
+MOCK = {"id": "mock_Id", "sourceIP": "mock_SourceIP", "sourceTransportPort": "mock_SourceTransportPort", "destinationIP": "mock_DestinationIP",
+        "destinationTransportPort": "mock_DestinationTransportPort", "flowStartSeconds": "mock_FlowStartSeconds",
+        "flowEndSeconds": "mock_FlowEndSeconds", "throughput": "mock_Throughput", "aggType": "mock_AggType", "algoType": "mock_AlgoType",
+        "algoCalc": "mock_AlgoCalc", "anomaly": "mock_Anomaly", "podNamespace": "mock_PodNamespace", "podLabels": "mock_PodLabels",
+        "podName": "mock_PodName", "direction": "mock_Direction", "destinationServicePortName": "mock_DestinationServicePortName"}
+
+
+@pytest.mark.parametrize("agg_flow,pod_name,n_cols", [("", "", 12), ("external", "", 8), ("pod", "", 10), ("pod", "mock_PodName", 10), ("svc", "", 8)])
+def test_get_tad_result_scans_the_columns_of_its_query(agg_flow, pod_name, n_cols):
+    """Test_getTadetectorResult (rest_test.go:229-380): one mock row per query kind; exactly the selected fields are filled."""
+    cols = rest.result_columns(agg_flow, pod_name)
+    assert len(cols) == n_cols
+    client = StubClickHouse({c: [MOCK[c]] for c in cols})
+    stats = rest.get_tad_result(client, "mock_Id", agg_flow, pod_name)
+    assert len(stats) == 1
+    want = rest.ThroughputAnomalyDetectorStats(**{c: MOCK[c] for c in cols})
+    assert stats[0] == want
+    assert set(stats[0].to_json()) == {rest._STATS_JSON[c] for c in cols}          # omitempty
+    sql, params = client.queries[0]
+    assert params == {"id": "mock_Id"} and "mock_Id" not in sql
+    # the reference's statement, token for token (queryMap, rest.go:59-123), with its positional placeholder
+    assert sql.replace("({id:String})", "(?);") == rest.reference_result_query(agg_flow, pod_name)
+    assert sql.startswith("SELECT id, ") and sql.endswith("FROM tadetector WHERE id = ({id:String})")
+
+
+def test_reference_queries_column_for_column():
+    assert rest.reference_result_query("") == ("SELECT id, sourceIP, sourceTransportPort, destinationIP, destinationTransportPort, flowStartSeconds, "
+                                               "flowEndSeconds, throughput, aggType, algoType, algoCalc, anomaly FROM tadetector WHERE id = (?);")
+    assert rest.reference_result_query("pod", "p") == ("SELECT id, podNamespace, podName, direction, flowEndSeconds, throughput, aggType, algoType, "
+                                                       "algoCalc, anomaly FROM tadetector WHERE id = (?);")
+    assert rest.query_kind("pod", "") == "podLabel" and rest.query_kind("anything", "") == "tad"
+
+
+@pytest.mark.parametrize("v,want", [
+    # strconv.FormatFloat(v, 'g', -1, 64)
+    (4005703059.0, "4.005703059e+09"), (1e6, "1e+06"), (999999.0, "999999"), (100000.0, "100000"), (123456.5, "123456.5"), (1.5, "1.5"), (3.0, "3"),
+    (0.0001, "0.0001"), (0.00001234, "1.234e-05"), (12345678.9, "1.23456789e+07"), (1e21, "1e+21"), (4005277824.2, "4.0052778242e+09"),
+    (-2.5, "-2.5"), (0.0, "0"), (5e-324, "5e-324"), (1.7976931348623157e308, "1.7976931348623157e+308"), (float("nan"), "NaN"), (float("inf"), "+Inf"),
+    (1000000000.0, "1e+09"), (5000000000.0, "5e+09"), (2500000000.0, "2.5e+09")])
+def test_go_format_float(v, want):
+    assert rest.go_format_float(v) == want
+
+
+def test_go_string_of_the_column_types():
+    assert rest.go_string(np.uint16(5201)) == "5201" and rest.go_string(58076) == "58076"
+    assert rest.go_string(np.float64(4005703059)) == "4.005703059e+09"
+    assert rest.go_string(datetime(2022, 8, 11, 7, 26, 54, tzinfo=timezone.utc)) == "2022-08-11T07:26:54Z"
+    assert rest.go_string(np.datetime64("2022-08-11T07:26:54")) == "2022-08-11T07:26:54Z"
+    assert rest.go_string(b"abc") == "abc" and rest.go_string("x") == "x" and rest.go_string(None) == "" and rest.go_string(True) == "true"
+
+
+def new_tad(**spec):
+    return ctl.ThroughputAnomalyDetector(name="tad-" + str(uuid.uuid4()), namespace=NS, spec=ctl.ThroughputAnomalyDetectorSpec(**spec))
+
+
+def test_rest_verbs_and_their_messages():
+    """TestREST_Get / _Create / _Delete / _List (rest_test.go:38-227)."""
+    client = StubClickHouse({c: [v] for c, v in MOCK.items()})
+    c = ctl.AnomalyDetectorController(clickhouse=client, run_job=lambda args, t: None, progress=lambda: (4, 4), resync_period=0.01)
+    try:
+        api = rest.REST(c)
+        t = new_tad(jobType="EWMA")
+        assert api.create(t) == {"status": "Success"}
+        with pytest.raises(rest.BadRequest, match="ThroughputAnomalyDetection job exists, name: %s" % t.name):
+            api.create(t)
+        with pytest.raises(rest.BadRequest, match="not a ThroughputAnomalyDetector object"):
+            api.create("tad")
+        with pytest.raises(rest.NotFound):
+            api.get("tad-" + str(uuid.uuid4()))
+        c.wait(NS, t.name, timeout=10)
+        got = api.get(t.name)
+        assert got.name == t.name and got.type == "EWMA" and got.status.state == ctl.STATE_COMPLETED and got.status.sparkApplication == t.name[4:]
+        assert got.stats == [rest.ThroughputAnomalyDetectorStats(**{k: MOCK[k] for k in rest.result_columns("")})]
+        assert client.queries[-1][1] == {"id": t.name[4:]}
+        # the API type can be posted back (`theia tad run` builds it, rest.go:218-247)
+        t2 = rest.ThroughputAnomalyDetectorResult(name="tad-" + str(uuid.uuid4()), type="DBSCAN", aggFlow="svc", executorInstances=1,
+                                                  driverCoreRequest="200m", driverMemory="512M", executorCoreRequest="200m", executorMemory="512M")
+        api.create(t2)
+        c.wait(NS, t2.name, timeout=10)
+        listed = api.list()
+        assert sorted(x.name for x in listed) == sorted([t.name, t2.name]) and all(len(x.stats) == 1 for x in listed)
+        assert api.get(t2.name).aggFlow == "svc"
+        assert api.delete(t.name) == {"status": "Success"}
+        with pytest.raises(rest.BadRequest, match="ThroughputAnomalyDetector job doesn't exist, name: %s" % t.name):
+            api.delete(t.name)
+        assert client.commands == [ctl.cleanup_query(t.name[4:])]
+    finally:
+        c.shutdown()
+
+
+def test_a_completed_job_whose_rows_cannot_be_read_keeps_its_state_and_says_why():
+    """rest.go:142-146 (Get overwrites ErrorMsg) and :199-203 (List appends)."""
+    client = StubClickHouse(fail="connection refused")
+    c = ctl.AnomalyDetectorController(clickhouse=client, run_job=lambda args, t: None, progress=lambda: (4, 4), resync_period=0.01)
+    try:
+        api = rest.REST(c)
+        t = new_tad(jobType="ARIMA", aggFlow="external")
+        api.create(t)
+        c.wait(NS, t.name, timeout=10)
+        got = api.get(t.name)
+        job = t.name[4:]
+        assert got.status.state == ctl.STATE_COMPLETED and got.stats == []
+        assert got.status.errorMsg == ("Failed to get the result for completed Throughput Anomaly Detector with id %s, error: failed to get Throughput "
+                                       "Anomaly Detector results with id %s: connection refused" % (job, job))
+        assert api.list()[0].status.errorMsg.startswith("Failed to get the result for Throughput Anomaly Detector with id %s, error: " % job)
+        assert c.get(NS, t.name).status.errorMsg == ""            # the stored resource is untouched: the message lives in the response
+    finally:
+        c.shutdown()
+
+
+def test_stale_rows_are_collected_and_running_jobs_resynced():
+    """handleStaleResources (controller.go:232-276) + HandleStaleDbEntries (util.go:239-270)."""
+    import threading
+    gate = threading.Event()
+    orphan, broken = str(uuid.uuid4()), "not-a-uuid"
+    c = None
+    try:
+        client = StubClickHouse()
+        c = ctl.AnomalyDetectorController(clickhouse=client, run_job=lambda args, t: gate.wait(10), progress=lambda: (1, 4), resync_period=0.01)
+        t = new_tad(jobType="EWMA")
+        c.create(t)
+        c.wait(NS, t.name, states=(ctl.STATE_RUNNING,), timeout=10)
+        client.columns = {"id": [t.name[4:], orphan, broken]}
+        with c._lock:
+            c._periodic.clear()                                   # as after a restart of the manager
+        errors = c.handle_stale_resources(NS)
+        assert client.commands == [ctl.cleanup_query(orphan)]      # the live job's rows stay, the orphan's go
+        assert len(errors) == 1 and errors[0].startswith(broken)   # reported, did not stop the others
+        assert c._periodic == {(NS, t.name): True}
+        assert client.queries[-1][0] == "SELECT DISTINCT id FROM tadetector"
+        gate.set()
+        assert c.wait(NS, t.name, timeout=10).status.state == ctl.STATE_COMPLETED     # ... and the resync carries it to the end
+    finally:
+        gate.set()
+        if c is not None:
+            c.shutdown()
+
+
+def test_retrieve_table_per_aggregation_type_and_the_sentinel():
+    """anomaly_detection_retrieve.go:94-137."""
+    S = rest.ThroughputAnomalyDetectorStats
+    assert rest.retrieve_table([S(id="j", anomaly=rest.NO_ANOMALY, aggType="svc")]) == "No Anomaly found in id: j"
+    assert rest.table_output("No Anomaly found in id: j") == "No Anomaly found in id: j\n"
+    t = rest.retrieve_table([S(id="j", aggType="pod", podName="p", podNamespace="ns", direction="inbound", flowEndSeconds="2022-08-11T07:26:54Z",
+                               throughput="4.005703059e+09", algoType="EWMA", algoCalc="2.7e+09", anomaly="true")])
+    assert t[0] == ["id", "podNamespace", "podName", "direction", "flowEndSeconds", "throughput", "aggType", "algoType", "algoCalc", "anomaly"]
+    assert t[1] == ["j", "ns", "p", "inbound", "2022-08-11T07:26:54Z", "4.005703059e+09", "pod", "EWMA", "2.7e+09", "true"]
+    assert rest.retrieve_table([S(id="j", aggType="pod", podLabels="{a:b}")])[0][2] == "podLabels"
+    assert rest.retrieve_table([S(id="j", aggType="None")])[0] == rest.result_columns("")
+    assert rest.retrieve_table([S(id="j", aggType="external")])[0][1] == "destinationIP"
+    assert rest.retrieve_table([S(id="j", aggType="svc")])[0][1] == "destinationServicePortName"
+    out = rest.table_output(t)
+    assert [ln.split() for ln in out.splitlines()] == t
+
+
+# ---- the e2e retrieve test (throughputanomalydetection_test.go:191-300) on the engine's rows ----
+E2E_RESULT_MAP = {     # result_map (:192-221): throughput prefix -> "true"; "1.005" for ARIMA: tests/test_gpu_job.py:E2E_RESULT_MAP's note
+    "ARIMA": {"4.005", "1.000", "5.000", "2.500", "5.002", "2.003", "2.002", "1.005"},
+    "EWMA": {"4.004", "4.005", "4.006", "5.000", "2.002", "2.003", "2.500"},
+    "DBSCAN": {"1.000", "1.005", "5.000", "3.260", "2.058", "5.002", "5.027", "2.500", "1.029", "1.630"},
+}
+E2E_ASSERT = {         # assert_variable_map (:222-243)
+    "None": dict(n=12, anomaly=11, throughput=7), "podName": dict(n=10, anomaly=9, throughput=5), "podLabel": dict(n=9, anomaly=8, throughput=4),
+    "external": dict(n=8, anomaly=7, throughput=3), "svc": dict(n=8, anomaly=7, throughput=3)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["EWMA", "DBSCAN", "ARIMA"])
+@pytest.mark.parametrize("agg_type", ["None", "podName", "podLabel", "external", "svc"])
+def test_e2e_retrieve_on_the_engine(engine, golden, algo, agg_type):
+    """executeRetrieveTest: run the job, wait for COMPLETED, retrieve, split the printed table into fields and check count, verdict and the
+    throughput prefix of every line — here through ClickHouse's HTTP interface (in-process), the controller, `tad_run` on the GPU, the INSERT,
+    the REST handler's SELECT and Go's string forms."""
+    from theia_amd import clickhouse as ch
+    from test_clickhouse_http import FakeClickHouse, arrow_table
+    from test_gpu_job import e2e_flows
+    spec = {"None": {}, "podName": dict(aggFlow="pod", podName="test_podName"), "podLabel": dict(aggFlow="pod", podLabel="test_key"),
+            "external": dict(aggFlow="external"), "svc": dict(aggFlow="svc")}[agg_type]
+    server = FakeClickHouse()
+    c = None
+    try:
+        flows = e2e_flows(golden)
+        sql = ch.rows_query("", "", [], spec.get("aggFlow", ""), spec.get("podLabel", ""), "", "", spec.get("podName", ""), "")
+        cols = sql[len("SELECT "):sql.index(" FROM ")].split(", ")
+        server.responses[sql] = arrow_table({name: flows[name] for name in cols})
+        client = ch.ClickHouseHTTP(server.url, user="", password="")
+        c = ctl.AnomalyDetectorController(clickhouse=client, engine=engine)
+        api = rest.REST(c)
+        t = new_tad(jobType=algo, **spec)
+        api.create(t)
+        done = c.wait(NS, t.name, timeout=180)
+        assert done.status.state == ctl.STATE_COMPLETED, done.status.errorMsg
+        got = api.get(t.name)
+        assert got.status.errorMsg == "" and len(got.stats) >= 3
+        stdout = rest.table_output(rest.retrieve_table(got.stats))
+        lines = stdout.split("\n")
+        assert len(lines) >= 3 and "throughput" in stdout and "algoCalc" in stdout and "anomaly" in stdout
+        a = E2E_ASSERT[agg_type]
+        for ln in lines[1:]:
+            ln = ln.strip()
+            if ln == "":
+                continue
+            f = ln.replace("\t", " ").split()
+            assert len(f) == a["n"], f
+            assert f[a["throughput"]][:5] in E2E_RESULT_MAP[algo] and f[a["anomaly"]] == "true", f
+            assert f[0] == t.name[4:]
+        api.delete(t.name)
+        assert rest.get_tad_result(client, t.name[4:], spec.get("aggFlow", ""), spec.get("podName", "")) == []     # cleaned up
+    finally:
+        if c is not None:
+            c.shutdown()
+        server.close()

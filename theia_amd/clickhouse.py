@@ -59,8 +59,9 @@ class ClickHouseHTTP:
         with self._request(params, body) as resp:
             return resp.read()
 
-    def query_columns(self, sql, dict_strings=False):
-        """Run a SELECT, return {column name: numpy array}.  DateTime -> int64 epoch seconds, String -> str — or, with
+    def query_columns(self, sql, dict_strings=False, params=None):
+        """Run a SELECT, return {column name: numpy array}.  `params`: values of the statement's `{name:Type}` placeholders, sent as
+        `param_<name>` URL parameters (the HTTP interface's query parameters: the value never becomes SQL text).  DateTime -> int64 epoch seconds, String -> str — or, with
         dict_strings=True, String -> theia_amd.anomaly_detection.DictColumn (integer codes per row + the distinct values, one
         dictionary per column unified over the record batches): no Python object per row is ever created, which is what makes
         the host side of a 1e8-row job tractable (prepare_columns evaluates the string predicates on the distinct values).
@@ -72,7 +73,10 @@ class ClickHouseHTTP:
         import pyarrow.ipc as ipc
         parts = {}
         vocab = {}     # dict_strings: column -> {string: code}
-        with self._request({"output_format_arrow_string_as_string": 1}, (sql.rstrip() + " FORMAT ArrowStream").encode()) as resp:
+        settings = {"output_format_arrow_string_as_string": 1}
+        for pname, pvalue in (params or {}).items():
+            settings["param_" + pname] = pvalue
+        with self._request(settings, (sql.rstrip() + " FORMAT ArrowStream").encode()) as resp:
             if not resp.peek(1):           # a truly empty body: a result without rows carries no schema
                 return {}
             # anything else must be an Arrow stream: a proxy's error page or exception text after the headers raises

@@ -264,6 +264,36 @@ class AnomalyDetectorController:
             except Exception as exc:               # the reference's delete handler logs the error and carries on (controller.go:262-280)
                 self._last_error = exc
 
+    def handle_stale_resources(self, namespace="flow-visibility", add_resync=True, remove_stale_db_entries=True):
+        """handleStaleResources (controller.go:232-276), what the reference's garbage-collection worker runs once at start-up
+        (controller.go:188-192): SCHEDULED / RUNNING resources go back on the periodic resync list, and result rows whose job has no
+        resource any more are deleted (controllerutil.HandleStaleDbEntries, pkg/controller/util.go:239-270: `SELECT DISTINCT id FROM
+        tadetector`, then the cleanup statement for every id without a `tad-<id>` resource).  The third leg, stale SparkApplications,
+        has nothing to act on here — a job body dies with the process that ran it.  Returns the list of errors (the reference requeues
+        the key with the legs that failed; callers here may simply call again)."""
+        errors = []
+        if add_resync:
+            with self._lock:
+                for key, tad in self._store.items():
+                    if key[0] == namespace and tad.status.state in (STATE_SCHEDULED, STATE_RUNNING):
+                        self._periodic[key] = True
+        if remove_stale_db_entries and self.clickhouse is not None:
+            try:
+                got = self.clickhouse.query_columns("SELECT DISTINCT id FROM %s" % RESULT_TABLE)
+                ids = [str(v) for v in got.get("id", [])]
+            except Exception as exc:
+                return errors + ["failed to get %s ids from ClickHouse: %s" % (RESULT_TABLE, exc)]
+            for job_id in ids:
+                with self._lock:
+                    exists = (namespace, "tad-" + job_id) in self._store
+                if exists:
+                    continue
+                try:
+                    self.clickhouse.command(cleanup_query(job_id))
+                except Exception as exc:           # an id that is not a uuid, or a server error: reported, the other ids still go
+                    errors.append("%s: %s" % (job_id, exc))
+        return errors
+
     def _is_cancelled(self, job_id):
         with self._lock:
             return job_id in self._cancelled
