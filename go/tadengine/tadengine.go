@@ -57,7 +57,7 @@ func (e IllegalArgument) Error() string { return e.Msg }
 // (controller.go:199-201); calls on one engine serialise inside the library.
 type Engine struct{ h *C.tad_engine }
 
-// Plan mirrors tad_plan (tad.h, ABI 9): plan overrides of an engine, every field 0 = the engine decides — what the controller
+// Plan mirrors tad_plan (tad.h, ABI 10): plan overrides of an engine, every field 0 = the engine decides — what the controller
 // uses.  Tests and A/B measurements force a strategy with it; the library reads no environment variable.  A Go struct, not
 // C.tad_plan: cgo types are private to this package, callers in other packages could not construct one.
 type Plan struct {
@@ -377,6 +377,45 @@ func (e *Engine) Factorize(colsA [][]int64, keepA []byte, colsB [][]int64, keepB
 		return nil, nil, nil, fmt.Errorf("tad_factorize: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
 	}
 	return keyID, keyID2, firstRow[:int(nk)], nil
+}
+
+// EncodeStrings turns one string column of a batch — in Arrow's layout, what clickhouse-go's column-oriented block API and the
+// Arrow Go reader both hand out: n+1 offsets into a byte slice — into dictionary codes on the GPU (tad.h: tad_encode_strings, ABI 10):
+// codes[i] = id of row i's string in order of first appearance, firstRow[k] = the row where value k first appears (the host reads
+// the dictionary's strings there, evaluates the job's string predicates on them and passes the codes on to Factorize).
+// validity may be nil (no nulls); a null row encodes like "".
+func (e *Engine) EncodeStrings(offsets []int32, data []byte, validity []byte) (codes []int64, firstRow []uint64, err error) {
+	if len(offsets) == 0 {
+		return nil, nil, errors.New("tadengine: offsets hold n + 1 entries")
+	}
+	n := len(offsets) - 1
+	codes = make([]int64, n)
+	firstRow = make([]uint64, n)
+	if n == 0 {
+		return codes, firstRow, nil
+	}
+	// (Go memory handed to C for the duration of the call: allowed by the cgo pointer rules, none of it holds Go pointers)
+	var sc C.tad_string_column
+	sc.n_rows = C.uint64_t(n)
+	sc.offsets = unsafe.Pointer(&offsets[0])
+	sc.offset_bits = 32
+	if len(data) > 0 {
+		sc.data = (*C.uint8_t)(unsafe.Pointer(&data[0]))
+	}
+	sc.data_bytes = C.uint64_t(len(data))
+	if validity != nil {
+		if len(validity)*8 < n {
+			return nil, nil, errors.New("tadengine: validity bitmap shorter than the column")
+		}
+		sc.validity = (*C.uint8_t)(unsafe.Pointer(&validity[0]))
+	}
+	sc.memory = C.TAD_MEM_HOST
+	var nv C.uint64_t
+	if rc := C.tad_encode_strings(e.h, &sc, (*C.int64_t)(unsafe.Pointer(&codes[0])), (*C.uint64_t)(unsafe.Pointer(&firstRow[0])),
+		C.uint64_t(len(firstRow)), &nv); rc != C.TAD_OK {
+		return nil, nil, fmt.Errorf("tad_encode_strings: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return codes, firstRow[:int(nv)], nil
 }
 
 // Progress feeds Status.CompletedStages / TotalStages (controller.go:426-453).

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 9
+#define TAD_ABI_VERSION 10
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -259,6 +259,29 @@ typedef struct {
 } tad_key_columns;
 int tad_factorize(tad_engine *e, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row,
                   uint64_t first_row_cap, uint64_t *num_keys);
+
+/* ---- ingest, one step earlier (ABI 10): an Arrow string column -> dictionary codes on the GPU ----
+ * ClickHouse delivers the job's GROUP BY columns (sourcePodName, destinationPodName, pod labels, namespaces, destinationIP,
+ * destinationServicePortName: anomaly_detection.py:52-137, 507-614) as strings; tad_factorize above wants integer columns.  The host's
+ * dictionary encode (theia_amd/clickhouse.py:query_columns) was the slowest stage of a 1e8-row job.  In: one column in Arrow's layout —
+ * n_rows + 1 offsets (int32 for `string`, int64 for `large_string`; pass the pointer already advanced by a sliced array's offset) into
+ * `data`, an optional validity bitmap (a null row encodes like the empty string, which is what the host path did).  Out: codes[i] = id of
+ * row i's string, ids in order of FIRST APPEARANCE (what Arrow's dictionary_encode and pandas.factorize give: same codes and
+ * dictionaries as the host path); first_row[k] (k < first_row_cap) = the row where value k first appears — the host reads the
+ * dictionary's strings there; *num_values.  n_rows < 2^32 - 1.  All arrays live in col->memory.  Offsets that decrease or point beyond
+ * data_bytes are TAD_ERR_INVALID_ARGUMENT (checked on the device while the rows are read). */
+typedef struct {
+  uint64_t n_rows;
+  const void *offsets;        /* n_rows + 1 */
+  int32_t offset_bits;        /* 32 or 64 */
+  const uint8_t *data;
+  uint64_t data_bytes;        /* bytes behind `data` that offsets may address */
+  const uint8_t *validity;    /* NULL = no nulls; else bit (validity_offset + i) of the bitmap is row i */
+  uint64_t validity_offset;
+  tad_mem memory;
+} tad_string_column;
+int tad_encode_strings(tad_engine *e, const tad_string_column *col, int64_t *codes, uint64_t *first_row, uint64_t first_row_cap,
+                       uint64_t *num_values);
 
 /* ---- streaming EWMA: per-key running state kept in HBM between batches ----
  * The batch job re-reads the whole window and judges every point against the stddev_samp of the WHOLE series

@@ -311,3 +311,31 @@ def test_query_columns_accepts_server_side_dictionaries_bools_dates_and_decimals
         assert np.array_equal(np.asarray(enc[name]), np.asarray(plain[name])), name
     assert enc["flag"].tolist() == [True, False, True, True, True, False, True] and enc["x"].tolist() == [1.5] * 7
     assert enc["d"].tolist() == [1660176000] * 7 and enc["n"].tolist() == list(range(7))
+
+
+@pytest.mark.gpu
+def test_query_columns_encodes_string_columns_on_the_gpu_like_arrow_does(engine, server, monkeypatch):
+    """query_columns(dict_strings=True, engine=...): plain string columns go through tad_encode_strings chunk by chunk; codes, dictionaries
+    and their ORDER are those of the host path (Arrow's dictionary_encode per record batch, unified in order of appearance)."""
+    rng = np.random.default_rng(12)
+    tabs = []
+    for b in range(5):
+        n = 3000 + 700 * b
+        pods = np.char.add("pod-", rng.integers(0, 40 + 25 * b, n).astype(str))
+        ns = np.where(rng.random(n) < 0.3, "", np.char.add("ns", rng.integers(0, 5, n).astype(str)))
+        labels = pa.array([None if i % 97 == 0 else '{"app":"a%d"}' % (i % 13) for i in range(n)], pa.string())
+        tabs.append(pa.table({"p": pa.array(pods.tolist(), pa.string()), "ns": pa.array(ns.tolist(), pa.string()), "l": labels,
+                              "b": pa.array([("ip%d" % (i % 7)).encode() for i in range(n)], pa.binary()),
+                              "n": pa.array(rng.integers(0, 60000, n), pa.uint16())}))
+    server.responses["SELECT p, ns, l, b, n FROM x"] = pa.concat_tables(tabs)
+    client = ch.ClickHouseHTTP(server.url, user="", password="")
+    host = client.query_columns("SELECT p, ns, l, b, n FROM x", dict_strings=True)
+    for chunk in (ch.STRING_CHUNK_BYTES, 20000, 1):          # one chunk, several record batches per chunk, every batch its own chunk
+        monkeypatch.setattr(ch, "STRING_CHUNK_BYTES", chunk)
+        gpu = client.query_columns("SELECT p, ns, l, b, n FROM x", dict_strings=True, engine=engine)
+        assert set(gpu) == set(host)
+        for name in ("p", "ns", "l", "b"):
+            assert isinstance(gpu[name], ad.DictColumn)
+            assert (gpu[name].codes == host[name].codes).all(), name
+            assert gpu[name].values.tolist() == host[name].values.tolist(), name
+        assert (gpu["n"] == host["n"]).all()

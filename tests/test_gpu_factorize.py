@@ -110,3 +110,105 @@ def test_edge_cases(engine):
         engine.factorize([alld] * 9)
     with pytest.raises(TadError):
         engine.factorize([alld], None, [alld, alld])
+
+
+# ---- tad_encode_strings (ABI 10): an Arrow string column -> dictionary codes in order of first appearance ----
+def _want_codes(arr):
+    """pyarrow's own dictionary encode (first-appearance order), nulls as ''."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    a = arr.cast(pa.string()) if not (pa.types.is_string(arr.type) or pa.types.is_large_string(arr.type)) else arr
+    d = pc.dictionary_encode(a.fill_null(""))
+    codes = d.indices.to_numpy(zero_copy_only=False).astype(np.int64)
+    first = np.full(len(d.dictionary), -1, np.int64)
+    for i in range(codes.size - 1, -1, -1):
+        first[codes[i]] = i
+    return codes, first.astype(np.uint64), d.dictionary.to_pylist()
+
+
+def _random_strings(rng, n, distinct, max_len=40):
+    alphabet = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789-./:{}", dtype=np.uint8)
+    vocab = []
+    for i in range(distinct):
+        ln = int(rng.integers(0, max_len + 1))
+        vocab.append(bytes(rng.choice(alphabet, ln)).decode() + ("" if ln == 0 else "#%d" % i))     # distinct by construction (one may be "")
+    return [vocab[j] for j in rng.integers(0, distinct, n)]
+
+
+@pytest.mark.parametrize("kind", ["string", "large_string", "binary"])
+@pytest.mark.parametrize("n,distinct", [(1, 1), (7, 3), (5000, 40), (20000, 7000)])
+def test_encode_strings_equals_arrows_dictionary_encode(engine, kind, n, distinct):
+    import pyarrow as pa
+    rng = np.random.default_rng(n * 31 + distinct)
+    vals = _random_strings(rng, n, distinct)
+    t = {"string": pa.string(), "large_string": pa.large_string(), "binary": pa.binary()}[kind]
+    arr = pa.array([v.encode() for v in vals] if kind == "binary" else vals, t)
+    codes, first = engine.encode_strings(arr)
+    want_codes, want_first, dictionary = _want_codes(arr)
+    assert codes.dtype == np.int64 and (codes == want_codes).all()
+    assert (first == want_first).all()
+    # the dictionary the host builds from the first rows is Arrow's, value for value
+    got_dict = arr.take(pa.array(first.astype(np.int64))).to_pylist()
+    assert [g.decode() if isinstance(g, bytes) else g for g in got_dict] == dictionary
+
+
+def test_encode_strings_slices_nulls_and_strings_that_differ_only_in_their_tail(engine):
+    import pyarrow as pa
+    base = ["pod-%s" % ("x" * k) for k in range(0, 20)] + ["", None, "a", "ab", "abc", "abcdefgh", "abcdefghi", "abcdefgh\0", "abcdefg"]
+    vals = (base * 7)[3:]
+    arr = pa.array(vals, pa.string())
+    for sl in (arr, arr.slice(5), arr.slice(11, 60), arr.slice(len(arr) - 1)):
+        codes, first = engine.encode_strings(sl)
+        want_codes, want_first, _ = _want_codes(sl)
+        assert (codes == want_codes).all() and (first == want_first).all()
+    # an all-null / all-empty column: one value
+    codes, first = engine.encode_strings(pa.array([None, None, ""], pa.string()))
+    assert codes.tolist() == [0, 0, 0] and first.tolist() == [0]
+    # no rows
+    codes, first = engine.encode_strings(pa.array([], pa.string()))
+    assert codes.size == 0 and first.size == 0
+
+
+def test_encode_strings_grows_its_table_for_a_high_cardinality_column(engine):
+    """More distinct values than half the small (2^20-slot) table: the first attempt gives up on the device, the second uses 2 n slots."""
+    import pyarrow as pa
+    n = 1_300_000
+    ids = np.arange(n) % 700_000
+    rng = np.random.default_rng(3)
+    rng.shuffle(ids)
+    arr = pa.array(np.char.add("k", ids.astype(str)))
+    codes, first = engine.encode_strings(arr)
+    want_codes, want_first, _ = _want_codes(arr)
+    assert (codes == want_codes).all() and (first == want_first).all() and first.size == 700_000
+
+
+def test_encode_strings_on_device_resident_buffers_and_bad_offsets(engine):
+    import pyarrow as pa
+    from theia_amd import TadError
+    rng = np.random.default_rng(9)
+    vals = _random_strings(rng, 30000, 500)
+    arr = pa.array(vals, pa.string())
+    _, obuf, dbuf = arr.buffers()
+    offsets = np.frombuffer(obuf, dtype=np.int32)[: len(arr) + 1].copy()
+    data = np.frombuffer(dbuf, dtype=np.uint8).copy()
+    want_codes, want_first, _ = _want_codes(arr)
+    # host arrays
+    codes, first = engine.encode_strings((offsets, data))
+    assert (codes == want_codes).all() and (first == want_first).all()
+    # device arrays (the bytes padded to a whole number of 8-byte elements)
+    d_off = DeviceArray.from_host(engine, offsets)
+    d_data = DeviceArray.from_host(engine, np.concatenate([data, np.zeros(-data.size % 8, np.uint8)]))
+    dc, df = engine.encode_strings((d_off, d_data))
+    assert (dc.to_host() == want_codes).all() and (df.to_host() == want_first).all()
+    # int64 offsets
+    codes, first = engine.encode_strings((offsets.astype(np.int64), data))
+    assert (codes == want_codes).all()
+    # malformed offsets are refused, not read
+    bad = offsets.copy(); bad[100] = bad[101] + 5
+    with pytest.raises(TadError):
+        engine.encode_strings((bad, data))
+    bad = offsets.copy(); bad[-1] = data.size + 64
+    with pytest.raises(TadError):
+        engine.encode_strings((bad, data))
+    with pytest.raises(TadError):
+        engine.encode_strings(pa.array([1, 2, 3]))

@@ -6,7 +6,7 @@ from . import build as _build
 
 u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
 
-TAD_ABI_VERSION = 9
+TAD_ABI_VERSION = 10
 TAD_KEY_SKIP = (1 << 64) - 1
 TAD_OK = 0
 TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
@@ -46,6 +46,12 @@ class KeyColumns(C.Structure):
     """tad_key_columns: the key tuples of a batch for tad_factorize (up to 8 int64 columns, optional keep masks, optional second side)."""
     _fields_ = [("n_rows", u64), ("n_cols", i32), ("cols_a", C.POINTER(C.c_void_p)), ("keep_a", C.c_void_p),
                 ("cols_b", C.POINTER(C.c_void_p)), ("keep_b", C.c_void_p), ("memory", C.c_int)]
+
+
+class StringColumn(C.Structure):
+    """tad_string_column: one Arrow string column (offsets + bytes + optional validity bitmap) for tad_encode_strings."""
+    _fields_ = [("n_rows", u64), ("offsets", C.c_void_p), ("offset_bits", i32), ("data", C.c_void_p), ("data_bytes", u64),
+                ("validity", C.c_void_p), ("validity_offset", u64), ("memory", C.c_int)]
 
 
 class EngineOpts(C.Structure):
@@ -101,6 +107,7 @@ SYMBOLS = {
     "tad_points_free": (None, [C.c_void_p, C.POINTER(Points)]),
     "tad_shard_rows": (C.c_int, [C.c_void_p, C.POINTER(Columns), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tad_factorize": (C.c_int, [C.c_void_p, C.POINTER(KeyColumns), C.c_void_p, C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]),
+    "tad_encode_strings": (C.c_int, [C.c_void_p, C.POINTER(StringColumn), C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]),
     "tad_progress": (C.c_int, [C.c_void_p, C.POINTER(i32), C.POINTER(i32)]),
     "tad_series_ewma": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_void_p]),
     "tad_series_ewma_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, f64, C.c_void_p]),

@@ -508,7 +508,7 @@ def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_i
             flows = ch.fetch_points(flows, generate_tad_sql_query(*args), agg_flow, pod_name or "")
             start_time, end_time, ns_ignore_list = "", "", ()   # ClickHouse has applied them already
         else:
-            flows = ch.fetch_flows(flows, *args)
+            flows = ch.fetch_flows(flows, *args, engine=engine or get_engine())   # string columns dictionary-encoded on the GPU
     eng = engine or get_engine()
     prep = prepare_columns(flows, start_time or "", end_time or "", ns_ignore_list or (), agg_flow, pod_label or "",
                            external_ip or "", svc_port_name or "", pod_name or "", pod_namespace or "", engine=eng)   # key tuples factorised on the GPU

@@ -41,6 +41,9 @@ def jdbc_to_http(url):
     raise ValueError("Please provide a valid JDBC url for ClickHouse database")   # anomaly_detection.py:823-829
 
 
+STRING_CHUNK_BYTES = 256 << 20    # string-column bytes handed to one tad_encode_strings call (query_columns(engine=...))
+
+
 class ClickHouseHTTP:
     def __init__(self, url=DEFAULT_JDBC_URL, user=None, password=None, timeout=600):
         self.base = jdbc_to_http(url)
@@ -59,9 +62,12 @@ class ClickHouseHTTP:
         with self._request(params, body) as resp:
             return resp.read()
 
-    def query_columns(self, sql, dict_strings=False, params=None):
+    def query_columns(self, sql, dict_strings=False, params=None, engine=None):
         """Run a SELECT, return {column name: numpy array}.  `params`: values of the statement's `{name:Type}` placeholders, sent as
-        `param_<name>` URL parameters (the HTTP interface's query parameters: the value never becomes SQL text).  DateTime -> int64 epoch seconds, String -> str — or, with
+        `param_<name>` URL parameters (the HTTP interface's query parameters: the value never becomes SQL text).
+        `engine` (with dict_strings): plain string columns are dictionary-encoded ON THE GPU (TadEngine.encode_strings = tad_encode_strings,
+        include/tad.h) in chunks of ~STRING_CHUNK_BYTES of column bytes instead of by Arrow on one host core per record batch — the same
+        codes and dictionaries (first-appearance order per chunk, unified over the chunks exactly as the batch dictionaries are).  DateTime -> int64 epoch seconds, String -> str — or, with
         dict_strings=True, String -> theia_amd.anomaly_detection.DictColumn (integer codes per row + the distinct values, one
         dictionary per column unified over the record batches): no Python object per row is ever created, which is what makes
         the host side of a 1e8-row job tractable (prepare_columns evaluates the string predicates on the distinct values).
@@ -98,6 +104,17 @@ class ClickHouseHTTP:
                     parts[name] = [np.zeros(0, dtype=bool)]
                 else:
                     parts[name] = [np.zeros(0, dtype=np.int64)]
+            pending = {}   # engine: column -> [raw Arrow string arrays of the current chunk, their bytes]
+
+            def flush(name):
+                arrays, _ = pending.pop(name)
+                arr = arrays[0] if len(arrays) == 1 else pa.concat_arrays(arrays)
+                codes, first = engine.encode_strings(arr)
+                dvals = arr.take(pa.array(first.astype(np.int64))).fill_null("").to_pylist()
+                voc = vocab.setdefault(name, {})
+                remap = np.fromiter((voc.setdefault(v, len(voc)) for v in dvals), dtype=np.int64, count=len(dvals))
+                parts.setdefault(name, []).append(remap[codes] if remap.size else np.zeros(0, dtype=np.int64))
+
             for batch in reader:
                 for name, col in zip(batch.schema.names, batch.columns):
                     t = col.type
@@ -114,7 +131,16 @@ class ClickHouseHTTP:
                                 idx = d.indices.to_numpy(zero_copy_only=False)
                         else:
                             if pa.types.is_binary(t) or pa.types.is_large_binary(t):
-                                col = col.cast(pa.string())
+                                col = col.cast(pa.string() if pa.types.is_binary(t) else pa.large_string())
+                            if engine is not None and dict_strings:
+                                # raw offsets + bytes wait for the GPU: a chunk is encoded once it holds enough bytes (bounded host
+                                # memory, int32 offsets never overflow), its codes join the column's parts in row order
+                                pend = pending.setdefault(name, [[], 0])
+                                pend[0].append(col)
+                                pend[1] += col.nbytes
+                                if pend[1] >= STRING_CHUNK_BYTES:
+                                    flush(name)
+                                continue
                             d = pc.dictionary_encode(col.fill_null(""))
                             idx = d.indices.to_numpy(zero_copy_only=False)
                         dvals = ["" if v is None else v for v in d.dictionary.to_pylist()]
@@ -130,6 +156,8 @@ class ClickHouseHTTP:
                     else:                     # integers, floats, bool: passed through unchanged
                         arr = col.to_numpy(zero_copy_only=False)
                     parts.setdefault(name, []).append(arr)
+            for name in list(pending):
+                flush(name)
         out = {name: (np.concatenate(v[1:]) if len(v) > 2 else (v[1] if len(v) == 2 else v[0])) for name, v in parts.items()}
         if dict_strings:
             from .anomaly_detection import DictColumn
@@ -250,10 +278,12 @@ def rows_query(start_time, end_time, ns_ignore_list, agg_flow=None, pod_label=No
 
 
 def fetch_flows(client, start_time="", end_time="", ns_ignore_list=(), agg_flow="", pod_label="", external_ip="",
-                svc_port_name="", pod_name="", pod_namespace=""):
-    """Raw-rows read: the column dict theia_amd.anomaly_detection.prepare_columns expects."""
+                svc_port_name="", pod_name="", pod_namespace="", engine=None):
+    """Raw-rows read: the column dict theia_amd.anomaly_detection.prepare_columns expects.  With `engine` the string columns are
+    dictionary-encoded on the GPU (tad_encode_strings)."""
+    kw = {"engine": engine} if engine is not None else {}
     flows = client.query_columns(rows_query(start_time, end_time, list(ns_ignore_list), agg_flow, pod_label, external_ip,
-                                            svc_port_name, pod_name, pod_namespace), dict_strings=True)
+                                            svc_port_name, pod_name, pod_namespace), dict_strings=True, **kw)
     if not flows:   # empty result: ArrowStream carries no batch
         mode = agg_flow if agg_flow in ("pod", "external", "svc") else ""
         flows = {c: np.zeros(0, dtype=np.int64 if c.endswith("Seconds") or c in ("flowType", "throughput") else str)

@@ -1531,6 +1531,73 @@ int tad_factorize(tad_engine *e, const tad_key_columns *kc, uint64_t *key_id, ui
   return TAD_OK;
 }
 
+int tad_encode_strings(tad_engine *e, const tad_string_column *col, int64_t *codes, uint64_t *first_row, uint64_t first_row_cap, uint64_t *num_values) {
+  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: engine is NULL");
+  if (!col || !num_values || (col->offset_bits != 32 && col->offset_bits != 64) || (col->n_rows && (!col->offsets || !codes)) || (first_row_cap && !first_row) ||
+      (col->data_bytes && !col->data))
+    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: bad arguments (offsets of 32 or 64 bits, data, codes / first_row buffers)");
+  const uint64_t n = col->n_rows;
+  *num_values = 0;
+  if (n == 0) return TAD_OK;
+  if (n >= 0xFFFFFFFFull) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: %llu rows do not fit 32-bit row indices", (unsigned long long)n);
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  const bool host = col->memory == TAD_MEM_HOST;
+  const int off64 = col->offset_bits == 64;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  // host inputs are staged behind the table block: offsets, bytes (+ 8 of slack: the last aligned word), validity, codes, first rows
+  const size_t off_bytes = up((n + 1) * (off64 ? 8 : 4)), data_bytes = up(col->data_bytes + 8);
+  const size_t val_bytes = col->validity ? up((col->validity_offset + n + 7) / 8) : 0, code_bytes = up(n * 8), fr_bytes = up(first_row_cap * 8);
+  const size_t stage = host ? off_bytes + data_bytes + val_bytes + code_bytes + fr_bytes : 0;
+  uint64_t slots = encode_strings_small_slots(n);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const size_t tb = encode_strings_temp_bytes(n, slots);
+    if (tb + stage + 64 > e->ws_limit)
+      return fail(e, TAD_ERR_GRID_TOO_LARGE, "tad_encode_strings needs %llu bytes of scratch > workspace limit %llu", (unsigned long long)(tb + stage), (unsigned long long)e->ws_limit);
+    int rc;
+    if ((rc = ensure(e, e->sp_temp, tb + stage + 64)) != TAD_OK) return rc;
+    unsigned char *base = static_cast<unsigned char *>(e->sp_temp.p);
+    unsigned long long *nv_dev = reinterpret_cast<unsigned long long *>(base + tb);
+    const void *d_off = col->offsets;
+    const uint8_t *d_data = col->data, *d_valid = col->validity;
+    long long *d_codes = reinterpret_cast<long long *>(codes);
+    uint64_t *d_fr = first_row;
+    if (host) {
+      unsigned char *p = base + tb + 64;
+      HIP_TRY(e, hipMemcpyAsync(p, col->offsets, (n + 1) * (off64 ? 8 : 4), hipMemcpyHostToDevice, s)); d_off = p; p += off_bytes;
+      if (col->data_bytes) HIP_TRY(e, hipMemcpyAsync(p, col->data, col->data_bytes, hipMemcpyHostToDevice, s));
+      d_data = p; p += data_bytes;
+      if (col->validity) { HIP_TRY(e, hipMemcpyAsync(p, col->validity, (col->validity_offset + n + 7) / 8, hipMemcpyHostToDevice, s)); d_valid = p; p += val_bytes; }
+      d_codes = reinterpret_cast<long long *>(p); p += code_bytes;
+      d_fr = reinterpret_cast<uint64_t *>(p);
+    }
+    uint32_t *flags_dev = nullptr;
+    launch_encode_strings(s, d_off, off64, d_data, col->data_bytes, d_valid, col->validity_offset, n, slots, base, d_codes, d_fr, first_row_cap, nv_dev, &flags_dev);
+    unsigned long long nv = 0;
+    uint32_t flags = 0;
+    HIP_TRY(e, hipMemcpyAsync(&nv, nv_dev, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipMemcpyAsync(&flags, flags_dev, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    HIP_TRY(e, hipGetLastError());
+    if (flags & 2u) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: offsets decrease or point beyond data_bytes");
+    if (flags & 1u) {
+      if (attempt == 1 || slots == factorize_table_slots(n)) return fail(e, TAD_ERR_HIP, "tad_encode_strings: the full-size table filled up");
+      slots = factorize_table_slots(n);     // more distinct values than the small table takes: once more with 2 n slots
+      continue;
+    }
+    if (host) {
+      HIP_TRY(e, hipMemcpyAsync(codes, d_codes, n * 8, hipMemcpyDeviceToHost, s));
+      const uint64_t m = nv < first_row_cap ? nv : first_row_cap;
+      if (m) HIP_TRY(e, hipMemcpyAsync(first_row, d_fr, m * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipStreamSynchronize(s));
+    }
+    *num_values = nv;
+    return TAD_OK;
+  }
+  return fail(e, TAD_ERR_HIP, "tad_encode_strings: unreachable");
+}
+
 void tad_points_free(tad_engine *e, tad_points *p) {
   if (!p) return;
   PointsPriv *pp = reinterpret_cast<PointsPriv *>(p);

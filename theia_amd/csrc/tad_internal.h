@@ -430,6 +430,13 @@ size_t factorize_temp_bytes(uint64_t virtual_rows);
 void launch_factorize(hipStream_t s, const long long *const *cols_a, const uint8_t *keep_a, const long long *const *cols_b, const uint8_t *keep_b, uint64_t n,
                       int n_cols, void *temp, uint64_t *key_a, uint64_t *key_b, uint64_t *first_row, uint64_t first_row_cap, unsigned long long *num_keys_dev);
 
+// Arrow string column -> dictionary codes in order of first appearance (tad_factorize.hip, ABI 10)
+uint64_t encode_strings_small_slots(uint64_t n);
+size_t encode_strings_temp_bytes(uint64_t n, uint64_t slots);
+void launch_encode_strings(hipStream_t s, const void *offsets, int off64, const uint8_t *data, uint64_t data_bytes, const uint8_t *valid, uint64_t valid_off,
+                           uint64_t n, uint64_t slots, void *temp, long long *codes, uint64_t *first_row, uint64_t first_row_cap,
+                           unsigned long long *num_values_dev, uint32_t **flags_dev_out);
+
 void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                   uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,
                   uint64_t *value);

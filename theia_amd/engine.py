@@ -455,6 +455,74 @@ class TadEngine:
         self._check(rc)
         return key1, key2, first[:min(int(nk.value), cap)]
 
+    # ---- ingest, one step earlier: an Arrow string column -> dictionary codes (tad_encode_strings) ----
+    def encode_strings(self, column, max_values=None):
+        """column: a pyarrow string / large_string / binary / large_binary Array (host memory; slices and nulls are fine: a null encodes like
+        ""), or a tuple (offsets, data) / (offsets, data, validity, validity_offset) — numpy arrays on the host (offsets int32 or int64, data
+        uint8), or DeviceArrays on the device (offsets as int32 / int64 elements).  Returns (codes int64[n], first_row u64[num_values]): codes
+        in order of first appearance (pyarrow.compute.dictionary_encode's, pandas.factorize's), first_row[k] = the row where value k
+        first appears — in the memory the input lives in."""
+        keepalive = []
+        validity, voff = None, 0
+        if hasattr(column, "buffers") and hasattr(column, "type"):        # a pyarrow Array
+            import pyarrow as pa
+            t = column.type
+            if pa.types.is_string(t) or pa.types.is_binary(t):
+                bits = 32
+            elif pa.types.is_large_string(t) or pa.types.is_large_binary(t):
+                bits = 64
+            else:
+                raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "encode_strings: not a string / binary column: %s" % t)
+            vbuf, obuf, dbuf = column.buffers()
+            n, dev = len(column), False
+            off_ptr = obuf.address + column.offset * (bits // 8) if obuf is not None else None
+            data_ptr, data_bytes = (dbuf.address, dbuf.size) if dbuf is not None else (None, 0)
+            if vbuf is not None and column.null_count:
+                validity, voff = vbuf.address, column.offset
+            keepalive.append(column)
+            if n and off_ptr is None:
+                raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "encode_strings: the column has no offsets buffer")
+        else:
+            offsets, data = column[0], column[1]
+            if isinstance(offsets, DeviceArray):
+                dev, bits, n = True, offsets.dtype.itemsize * 8, offsets.n - 1
+                off_ptr, data_ptr, data_bytes = offsets.ptr, data.ptr, data.n * data.dtype.itemsize
+                if len(column) > 2 and column[2] is not None:
+                    validity, voff = column[2].ptr, int(column[3]) if len(column) > 3 else 0
+            else:
+                dev = False
+                offsets = np.ascontiguousarray(offsets)
+                if offsets.dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+                    raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "encode_strings: offsets must be int32 or int64")
+                data = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else data)
+                bits, n = offsets.dtype.itemsize * 8, offsets.size - 1
+                off_ptr, data_ptr, data_bytes = offsets.ctypes.data, (data.ctypes.data if data.size else None), data.size
+                if len(column) > 2 and column[2] is not None:
+                    v = np.ascontiguousarray(column[2], dtype=np.uint8)
+                    keepalive.append(v)
+                    validity, voff = v.ctypes.data, int(column[3]) if len(column) > 3 else 0
+            keepalive += [offsets, data]
+        if n < 0:
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "encode_strings: the offsets hold n + 1 entries")
+        cap = int(max_values) if max_values is not None else n
+        sc = capi.StringColumn(n_rows=n, offsets=off_ptr, offset_bits=bits, data=data_ptr, data_bytes=data_bytes, validity=validity,
+                               validity_offset=voff, memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
+        nv = capi.u64()
+        if dev:
+            codes = DeviceArray(self, max(n, 1), np.int64)
+            first = DeviceArray(self, max(cap, 1), np.uint64)
+            rc = self._lib.tad_encode_strings(self._h, C.byref(sc), codes.ptr, first.ptr, cap, C.byref(nv))
+            del keepalive
+            self._check(rc)
+            codes.n, first.n = n, min(int(nv.value), cap)
+            return codes, first
+        codes = np.empty(n, dtype=np.int64)
+        first = np.empty(max(cap, 1), dtype=np.uint64)
+        rc = self._lib.tad_encode_strings(self._h, C.byref(sc), codes.ctypes.data, first.ctypes.data, cap, C.byref(nv))
+        del keepalive
+        self._check(rc)
+        return codes, first[:min(int(nv.value), cap)]
+
     # ---- Stage 0 alone: the GROUP BY (anomaly_detection.py:507-614) ----
     def aggregate(self, key_id, flow_end_s, value, num_keys, agg_flow="", value_op="auto", key_id2=None, flow_start_s=None,
                   start_time=0, end_time=0, lattice=None, out="host"):
