@@ -212,3 +212,46 @@ def test_encode_strings_on_device_resident_buffers_and_bad_offsets(engine):
         engine.encode_strings((bad, data))
     with pytest.raises(TadError):
         engine.encode_strings(pa.array([1, 2, 3]))
+
+
+@pytest.mark.parametrize("n,keys", [(1_300_000, 700_000), (19_000_000, 9_000_000)], ids=["2^20->2^24", "2^24->full"])
+def test_factorize_grows_its_table_when_the_device_asks(engine, n, keys):
+    """The table starts at 2^20 slots and climbs 2^24 -> 2 n when a pass finds it filling up (tad_factorize.hip): ids and first rows must not
+    depend on how many attempts it took."""
+    import pandas as pd
+    rng = np.random.default_rng(keys)
+    a = rng.integers(0, keys, size=n).astype(np.int64)
+    b = (a * 7 + 3) % 1000
+    k1, _, first = engine.factorize([a, b])
+    codes, uniq = pd.factorize(a)
+    assert (k1 == codes.astype(np.uint64)).all()
+    assert first.size == uniq.size and (a[first.astype(np.int64)] == uniq).all()
+    assert (np.diff(first.astype(np.int64)) > 0).all()                 # order of first appearance
+
+
+def test_encode_strings_long_strings_take_the_global_path_and_mixed_blocks_both(engine):
+    """A block of 256 rows stages its bytes in LDS when they fit 24 KB; labels of hundreds of bytes do not, and a column may mix both kinds of
+    block.  Null rows whose bytes are still in the buffer (validity cleared after the fact) read as ''."""
+    import pyarrow as pa
+    rng = np.random.default_rng(21)
+    longs = ['{"app":"%s","tier":"%s"}' % ("x" * int(rng.integers(150, 400)), "y" * int(rng.integers(0, 90))) + str(i) for i in range(300)]
+    vals = [longs[j] for j in rng.integers(0, 300, 3000)]
+    arr = pa.array(vals, pa.string())
+    codes, first = engine.encode_strings(arr)
+    want_codes, want_first, _ = _want_codes(arr)
+    assert (codes == want_codes).all() and (first == want_first).all()
+    # short rows with a huge one every ~700 rows: some blocks staged, some not; the same strings must meet in the same slots
+    mixed = [("p%d" % (i % 37)) if i % 701 else ("L" * 30000 + str(i % 3)) for i in range(6000)]
+    arr = pa.array(mixed, pa.large_string())
+    codes, first = engine.encode_strings(arr)
+    want_codes, want_first, _ = _want_codes(arr)
+    assert (codes == want_codes).all() and (first == want_first).all()
+    # nulls that still own bytes
+    base = pa.array(["aa", "bbb", "aa", "cccc", "bbb", "dd"] * 50, pa.string())
+    _, obuf, dbuf = base.buffers()
+    valid = np.packbits(np.array([i % 4 != 1 for i in range(len(base))], dtype=np.uint8), bitorder="little")
+    holed = pa.Array.from_buffers(pa.string(), len(base), [pa.py_buffer(valid.tobytes()), obuf, dbuf])
+    assert holed.null_count == len(base) // 4
+    codes, first = engine.encode_strings(holed)
+    want_codes, want_first, _ = _want_codes(holed)
+    assert (codes == want_codes).all() and (first == want_first).all()

@@ -1485,50 +1485,61 @@ int tad_factorize(tad_engine *e, const tad_key_columns *kc, uint64_t *key_id, ui
   HIP_TRY(e, hipSetDevice(e->device));
   hipStream_t s = e->stream;
   const bool host = kc->memory == TAD_MEM_HOST;
-  const size_t tb = factorize_temp_bytes(n * sides);
-  // host inputs are staged behind the table in the same scratch block: columns, masks, outputs
+  // host inputs are staged behind the table block in the same scratch: columns, masks, outputs
   const size_t col_bytes = (n * 8 + 255) & ~(size_t)255, mask_bytes = (n + 255) & ~(size_t)255, fr_bytes = (first_row_cap * 8 + 255) & ~(size_t)255;
   const size_t stage = host ? (size_t)kc->n_cols * sides * col_bytes + 2 * mask_bytes + sides * col_bytes + fr_bytes : 0;
-  if (tb + stage + 64 > e->ws_limit)
-    return fail(e, TAD_ERR_GRID_TOO_LARGE, "tad_factorize needs %llu bytes of scratch > workspace limit %llu", (unsigned long long)(tb + stage), (unsigned long long)e->ws_limit);
-  int rc;
-  if ((rc = ensure(e, e->sp_temp, tb + stage + 64)) != TAD_OK) return rc;
-  unsigned char *base = static_cast<unsigned char *>(e->sp_temp.p);
-  unsigned long long *nk_dev = reinterpret_cast<unsigned long long *>(base + tb);
-  const long long *ca[kFzMaxCols] = {}, *cb[kFzMaxCols] = {};
-  const uint8_t *ka = kc->keep_a, *kb = kc->keep_b;
-  uint64_t *d_key = key_id, *d_key2 = key_id2, *d_fr = first_row;
-  if (host) {
-    unsigned char *p = base + tb + 64;
-    for (int c = 0; c < kc->n_cols; ++c) {
-      HIP_TRY(e, hipMemcpyAsync(p, kc->cols_a[c], n * 8, hipMemcpyHostToDevice, s)); ca[c] = reinterpret_cast<const long long *>(p); p += col_bytes;
-      if (sides == 2) { HIP_TRY(e, hipMemcpyAsync(p, kc->cols_b[c], n * 8, hipMemcpyHostToDevice, s)); cb[c] = reinterpret_cast<const long long *>(p); p += col_bytes; }
+  // the table starts small and grows when the device says so (tad_factorize.hip): 2^20 -> 2^24 -> 2 n slots
+  for (uint64_t slots = factorize_first_slots(n * sides);;) {
+    const size_t tb = factorize_temp_bytes(n * sides, slots);
+    if (tb + stage + 64 > e->ws_limit)
+      return fail(e, TAD_ERR_GRID_TOO_LARGE, "tad_factorize needs %llu bytes of scratch > workspace limit %llu", (unsigned long long)(tb + stage), (unsigned long long)e->ws_limit);
+    int rc;
+    if ((rc = ensure(e, e->sp_temp, tb + stage + 64)) != TAD_OK) return rc;
+    unsigned char *base = static_cast<unsigned char *>(e->sp_temp.p);
+    unsigned long long *nk_dev = reinterpret_cast<unsigned long long *>(base + tb);
+    const long long *ca[kFzMaxCols] = {}, *cb[kFzMaxCols] = {};
+    const uint8_t *ka = kc->keep_a, *kb = kc->keep_b;
+    uint64_t *d_key = key_id, *d_key2 = key_id2, *d_fr = first_row;
+    if (host) {
+      unsigned char *p = base + tb + 64;
+      for (int c = 0; c < kc->n_cols; ++c) {
+        HIP_TRY(e, hipMemcpyAsync(p, kc->cols_a[c], n * 8, hipMemcpyHostToDevice, s)); ca[c] = reinterpret_cast<const long long *>(p); p += col_bytes;
+        if (sides == 2) { HIP_TRY(e, hipMemcpyAsync(p, kc->cols_b[c], n * 8, hipMemcpyHostToDevice, s)); cb[c] = reinterpret_cast<const long long *>(p); p += col_bytes; }
+      }
+      if (ka) { HIP_TRY(e, hipMemcpyAsync(p, ka, n, hipMemcpyHostToDevice, s)); ka = p; }
+      p += mask_bytes;
+      if (kb) { HIP_TRY(e, hipMemcpyAsync(p, kb, n, hipMemcpyHostToDevice, s)); kb = p; }
+      p += mask_bytes;
+      d_key = reinterpret_cast<uint64_t *>(p); p += col_bytes;
+      if (sides == 2) { d_key2 = reinterpret_cast<uint64_t *>(p); p += col_bytes; }
+      d_fr = reinterpret_cast<uint64_t *>(p);
+    } else {
+      for (int c = 0; c < kc->n_cols; ++c) { ca[c] = reinterpret_cast<const long long *>(kc->cols_a[c]); if (sides == 2) cb[c] = reinterpret_cast<const long long *>(kc->cols_b[c]); }
     }
-    if (ka) { HIP_TRY(e, hipMemcpyAsync(p, ka, n, hipMemcpyHostToDevice, s)); ka = p; }
-    p += mask_bytes;
-    if (kb) { HIP_TRY(e, hipMemcpyAsync(p, kb, n, hipMemcpyHostToDevice, s)); kb = p; }
-    p += mask_bytes;
-    d_key = reinterpret_cast<uint64_t *>(p); p += col_bytes;
-    if (sides == 2) { d_key2 = reinterpret_cast<uint64_t *>(p); p += col_bytes; }
-    d_fr = reinterpret_cast<uint64_t *>(p);
-  } else {
-    for (int c = 0; c < kc->n_cols; ++c) { ca[c] = reinterpret_cast<const long long *>(kc->cols_a[c]); if (sides == 2) cb[c] = reinterpret_cast<const long long *>(kc->cols_b[c]); }
+    uint32_t *flags_dev = nullptr;
+    launch_factorize(s, ca, ka, sides == 2 ? cb : nullptr, kb, n, kc->n_cols, slots, base, d_key, d_key2, d_fr, first_row_cap, nk_dev, &flags_dev);
+    unsigned long long nk = 0;
+    uint32_t flags = 0;
+    HIP_TRY(e, hipMemcpyAsync(&nk, nk_dev, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipMemcpyAsync(&flags, flags_dev, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    HIP_TRY(e, hipGetLastError());
+    if (flags != 0) {      // more keys than this table takes: once more with the next size (a host batch is staged again: the block may have moved)
+      const uint64_t next = factorize_next_slots(n * sides, slots);
+      if (next == slots) return fail(e, TAD_ERR_HIP, "tad_factorize: the full-size table filled up");
+      slots = next;
+      continue;
+    }
+    if (host) {
+      HIP_TRY(e, hipMemcpyAsync(key_id, d_key, n * 8, hipMemcpyDeviceToHost, s));
+      if (sides == 2) HIP_TRY(e, hipMemcpyAsync(key_id2, d_key2, n * 8, hipMemcpyDeviceToHost, s));
+      const uint64_t m = nk < first_row_cap ? nk : first_row_cap;
+      if (m) HIP_TRY(e, hipMemcpyAsync(first_row, d_fr, m * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipStreamSynchronize(s));
+    }
+    *num_keys = nk;
+    return TAD_OK;
   }
-  launch_factorize(s, ca, ka, sides == 2 ? cb : nullptr, kb, n, kc->n_cols, base, d_key, d_key2, d_fr, first_row_cap, nk_dev);
-  unsigned long long nk = 0;
-  HIP_TRY(e, hipMemcpyAsync(&nk, nk_dev, 8, hipMemcpyDeviceToHost, s));
-  if (host) {
-    HIP_TRY(e, hipMemcpyAsync(key_id, d_key, n * 8, hipMemcpyDeviceToHost, s));
-    if (sides == 2) HIP_TRY(e, hipMemcpyAsync(key_id2, d_key2, n * 8, hipMemcpyDeviceToHost, s));
-  }
-  HIP_TRY(e, hipStreamSynchronize(s));
-  HIP_TRY(e, hipGetLastError());
-  if (host && first_row_cap) {
-    const uint64_t m = nk < first_row_cap ? nk : first_row_cap;
-    if (m) HIP_TRY(e, hipMemcpy(first_row, d_fr, m * 8, hipMemcpyDeviceToHost));
-  }
-  *num_keys = nk;
-  return TAD_OK;
 }
 
 int tad_encode_strings(tad_engine *e, const tad_string_column *col, int64_t *codes, uint64_t *first_row, uint64_t first_row_cap, uint64_t *num_values) {
@@ -1550,9 +1561,8 @@ int tad_encode_strings(tad_engine *e, const tad_string_column *col, int64_t *cod
   const size_t off_bytes = up((n + 1) * (off64 ? 8 : 4)), data_bytes = up(col->data_bytes + 8);
   const size_t val_bytes = col->validity ? up((col->validity_offset + n + 7) / 8) : 0, code_bytes = up(n * 8), fr_bytes = up(first_row_cap * 8);
   const size_t stage = host ? off_bytes + data_bytes + val_bytes + code_bytes + fr_bytes : 0;
-  uint64_t slots = encode_strings_small_slots(n);
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    const size_t tb = encode_strings_temp_bytes(n, slots);
+  for (uint64_t slots = factorize_first_slots(n);;) {
+    const size_t tb = factorize_temp_bytes(n, slots);
     if (tb + stage + 64 > e->ws_limit)
       return fail(e, TAD_ERR_GRID_TOO_LARGE, "tad_encode_strings needs %llu bytes of scratch > workspace limit %llu", (unsigned long long)(tb + stage), (unsigned long long)e->ws_limit);
     int rc;
@@ -1581,9 +1591,10 @@ int tad_encode_strings(tad_engine *e, const tad_string_column *col, int64_t *cod
     HIP_TRY(e, hipStreamSynchronize(s));
     HIP_TRY(e, hipGetLastError());
     if (flags & 2u) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: offsets decrease or point beyond data_bytes");
-    if (flags & 1u) {
-      if (attempt == 1 || slots == factorize_table_slots(n)) return fail(e, TAD_ERR_HIP, "tad_encode_strings: the full-size table filled up");
-      slots = factorize_table_slots(n);     // more distinct values than the small table takes: once more with 2 n slots
+    if (flags & 1u) {      // more distinct values than this table takes: once more with the next size (2^20 -> 2^24 -> 2 n slots)
+      const uint64_t next = factorize_next_slots(n, slots);
+      if (next == slots) return fail(e, TAD_ERR_HIP, "tad_encode_strings: the full-size table filled up");
+      slots = next;
       continue;
     }
     if (host) {
@@ -1595,7 +1606,6 @@ int tad_encode_strings(tad_engine *e, const tad_string_column *col, int64_t *cod
     *num_values = nv;
     return TAD_OK;
   }
-  return fail(e, TAD_ERR_HIP, "tad_encode_strings: unreachable");
 }
 
 void tad_points_free(tad_engine *e, tad_points *p) {

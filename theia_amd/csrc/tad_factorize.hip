@@ -12,7 +12,7 @@
 // with an atomic min — the fingerprint sits in the high half, so the minimum is taken among rows of this very tuple.  After the
 // pass every slot names the first row of its tuple.  Ids in order of first appearance (what pandas.factorize gives, so that the
 // GPU path and the pandas path produce identical key ids and key tables): a bitmap of the first rows, a scan of its popcounts,
-// id(first row r) = first rows before r.  A second pass over the rows looks every tuple up again and writes its id.
+// id(first row r) = first rows before r.  The insert pass leaves every row's slot behind (4 bytes); a second pass reads slot -> first row -> id.
 // Pod mode (the UNION ALL of the inbound and the outbound view, :556-565) passes two tuples per row: the table runs over the
 // virtual rows [side a: 0 .. n) ++ [side b: n .. 2n), the side is part of the tuple.
 #include "tad_internal.h"
@@ -26,6 +26,15 @@ __device__ __forceinline__ uint64_t fz_mix(uint64_t x) {   // splitmix64 finalis
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
+}
+
+// A probe LOOKS at a slot with a plain cached load.  On this multi-XCD chip an agent-scope load is a transaction with the memory side for every
+// row (the L2s of the eight XCDs are not coherent with each other, so device-scope accesses bypass them): 1e8 of them were the insert pass
+// (3 of its 4 ms for one key column, profiles/r4_v29_*).  A stale view is harmless here: a slot's fingerprint never changes once claimed, so a
+// non-empty word is trusted for WHICH slot it is (its row half may be stale-high: the atomic min below is then merely redundant), and a word
+// that looks empty is only ever claimed with a compare-and-swap, which is performed at the memory side and returns the truth.
+__device__ __forceinline__ unsigned long long fz_peek(const unsigned long long *slot) {
+  return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 struct FzArgs {
@@ -61,25 +70,46 @@ __device__ __forceinline__ bool fz_same(const FzArgs &A, uint64_t v, const long 
   return true;
 }
 
-// every kept virtual row into the table; on return a slot's low half = the smallest virtual row holding its tuple
-__global__ __launch_bounds__(kFzBlock) void k_fz_insert(FzArgs A, unsigned long long *__restrict__ table, uint64_t mask) {
+static constexpr uint32_t kFzMaxProbe = 32;
+enum : uint32_t { FZ_FLAG_GROW = 1u, FZ_FLAG_BAD_INPUT = 2u };
+
+// The table starts SMALL (round 4, factorize_first_slots: 2^20 slots = 8 MB, then 2^24, then 2 n): most jobs have far fewer keys than rows, a
+// table that fits the L2 / MALL turns every probe from an HBM transaction into a cache hit, and clearing + scanning 2 n slots (2 GB each at 1e8
+// rows) was a third of the old pass.  A pass that finds its table filling up (a probe sequence > 32 slots, or more than half the slots claimed —
+// counted with one atomic per wavefront) raises a flag; every thread leaves at its next row, the later kernels return at once, and the host —
+// which reads the key count at the end anyway — repeats the call with the next size.
+// every kept virtual row into the table; on return a slot's low half = the smallest virtual row holding its tuple, slot_of[v] = v's slot
+__global__ __launch_bounds__(kFzBlock) void k_fz_insert(FzArgs A, unsigned long long *__restrict__ table, uint64_t mask, uint32_t *__restrict__ slot_of,
+                                                        uint32_t *__restrict__ flags, unsigned long long *__restrict__ claims) {
   const uint64_t V = A.n * A.sides;
-  for (uint64_t v = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; v < V; v += (uint64_t)gridDim.x * kFzBlock) {
+  uint32_t claimed = 0;
+  uint32_t round = 0;
+  for (uint64_t v = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; v < V; v += (uint64_t)gridDim.x * kFzBlock, ++round) {
+    // the table is too small: the pass is being abandoned (asked at the memory side, so only every eighth row of a thread)
+    if ((round & 7u) == 0u && __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     if (!fz_kept(A, v)) continue;
     long long t[kFzMaxCols];
     const uint64_t h = fz_hash(A, v, t);
     const unsigned long long mine = ((h >> 32) << 32) | v;     // (v < 2^32 - 1: never the empty word)
+    uint32_t probes = 0;
     for (uint64_t s = h & mask;; s = (s + 1) & mask) {
-      unsigned long long w = __hip_atomic_load(table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long w = fz_peek(table + s);
       if (w == kFzEmpty) {
         w = atomicCAS(table + s, kFzEmpty, mine);
-        if (w == kFzEmpty) break;                               // claimed
+        if (w == kFzEmpty) { ++claimed; slot_of[v] = (uint32_t)s; break; }      // claimed
       }
       if ((w >> 32) == (mine >> 32) && fz_same(A, v, t, w & 0xffffffffull)) {
         if (mine < w) atomicMin(table + s, mine);                // an earlier row of the same tuple (same high half: the min stays in the class)
+        slot_of[v] = (uint32_t)s;
         break;
       }
+      if (++probes > kFzMaxProbe) { atomicOr(flags, FZ_FLAG_GROW); break; }
     }
+  }
+  for (int o = 32; o > 0; o >>= 1) claimed += __shfl_down(claimed, o);     // one atomic per wavefront for the claim count
+  if ((threadIdx.x & 63) == 0 && claimed) {
+    const unsigned long long before = atomicAdd(claims, (unsigned long long)claimed);
+    if (2 * (before + claimed) > mask + 1) atomicOr(flags, FZ_FLAG_GROW);
   }
 }
 
@@ -95,66 +125,107 @@ __global__ __launch_bounds__(kFzBlock) void k_fz_popc(const uint32_t *__restrict
   for (uint64_t i = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; i < words; i += (uint64_t)gridDim.x * kFzBlock) cnt[i] = (uint32_t)__popc(bits[i]);
 }
 
-// id of every row (TAD_KEY_SKIP for rows that are not kept); first_row[id] by the row that is its tuple's first
-__global__ __launch_bounds__(kFzBlock) void k_fz_lookup(FzArgs A, const unsigned long long *__restrict__ table, uint64_t mask, const uint32_t *__restrict__ bits,
-                                                         const unsigned long long *__restrict__ off, uint64_t *__restrict__ key_a, uint64_t *__restrict__ key_b,
-                                                         uint64_t *__restrict__ first_row, uint64_t first_row_cap) {
-  const uint64_t V = A.n * A.sides;
-  for (uint64_t v = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; v < V; v += (uint64_t)gridDim.x * kFzBlock) {
-    uint64_t *out = v >= A.n ? key_b + (v - A.n) : key_a + v;
-    if (!fz_kept(A, v)) { *out = TAD_KEY_SKIP; continue; }
-    long long t[kFzMaxCols];
-    const uint64_t h = fz_hash(A, v, t);
-    uint64_t rep = 0;
-    for (uint64_t s = h & mask;; s = (s + 1) & mask) {
-      const unsigned long long w = table[s];
-      if (w == kFzEmpty) { rep = v; break; }                    // (cannot happen after k_fz_insert; never loop forever)
-      if ((w >> 32) == (h >> 32) && fz_same(A, v, t, w & 0xffffffffull)) { rep = w & 0xffffffffull; break; }
+// id of every row (TAD_KEY_SKIP for rows that are not kept) from its slot; first_row[id] by the row that is its tuple's first
+__global__ __launch_bounds__(kFzBlock) void k_fz_lookup(FzArgs A, const unsigned long long *__restrict__ table, const uint32_t *__restrict__ slot_of,
+                                                         const uint32_t *__restrict__ bits, const unsigned long long *__restrict__ off,
+                                                         uint64_t *__restrict__ key_a, uint64_t *__restrict__ key_b, uint64_t *__restrict__ first_row,
+                                                         uint64_t first_row_cap, const uint32_t *__restrict__ flags) {
+  if (*flags != 0u) return;     // the insert pass gave up: slot_of is incomplete, the host repeats with a larger table
+  // slot -> table word -> bitmap word + offset: three dependent loads per row; four rows per thread keep four chains in flight
+  constexpr int U = 4;
+  const uint64_t V = A.n * A.sides, stride = (uint64_t)gridDim.x * kFzBlock;
+  for (uint64_t v0 = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; v0 < V; v0 += U * stride) {
+    bool kept[U];
+    uint32_t sl[U];
+    uint64_t rep[U];
+    uint32_t bw[U];
+    unsigned long long ow[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t v = v0 + u * stride;
+      kept[u] = v < V && fz_kept(A, v);
+      sl[u] = kept[u] ? slot_of[v] : 0u;
     }
-    const uint64_t id = off[rep >> 5] + (uint64_t)__popc(bits[rep >> 5] & ((1u << (rep & 31ull)) - 1u));
-    *out = id;
-    if (rep == v && id < first_row_cap) first_row[id] = v;
+#pragma unroll
+    for (int u = 0; u < U; ++u) rep[u] = kept[u] ? table[sl[u]] & 0xffffffffull : 0ull;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { bw[u] = bits[rep[u] >> 5]; ow[u] = off[rep[u] >> 5]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t v = v0 + u * stride;
+      if (v >= V) break;
+      uint64_t *out = v >= A.n ? key_b + (v - A.n) : key_a + v;
+      if (!kept[u]) { *out = TAD_KEY_SKIP; continue; }
+      const uint64_t id = ow[u] + (uint64_t)__popc(bw[u] & ((1u << (rep[u] & 31ull)) - 1u));
+      *out = id;
+      if (rep[u] == v && id < first_row_cap) first_row[id] = v;
+    }
   }
 }
 
-uint64_t factorize_table_slots(uint64_t virtual_rows) {
+uint64_t factorize_table_slots(uint64_t virtual_rows) {   // the full size: load factor <= 1/2 whatever the input
   uint64_t s = 1024;
   while (s < 2 * virtual_rows) s <<= 1;
   return s;
 }
-
-// temp layout: table[slots] u64 | bits[words] u32 | cnt[words] u32 | off[words + 1] u64 | scan scratch
-size_t factorize_temp_bytes(uint64_t virtual_rows) {
-  const uint64_t slots = factorize_table_slots(virtual_rows), words = (virtual_rows + 31) / 32;
-  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  return up(slots * 8) + up(words * 4) + up(words * 4) + up((words + 1) * 8) + up(scan_scratch_elems(words ? words : 1) * 8) + 256;
+uint64_t factorize_first_slots(uint64_t virtual_rows) {
+  const uint64_t full = factorize_table_slots(virtual_rows);
+  return full < (1ull << 20) ? full : (1ull << 20);
+}
+uint64_t factorize_next_slots(uint64_t virtual_rows, uint64_t slots) {   // after a pass that asked for more room; == slots: nothing larger exists
+  const uint64_t full = factorize_table_slots(virtual_rows);
+  if (slots >= full) return full;
+  const uint64_t next = slots < (1ull << 24) ? (1ull << 24) : full;
+  return next < full ? next : full;
 }
 
-// num_keys_dev: one u64 on the device
+// temp layout: table[slots] u64 | slot_of[V] u32 | bits[words] u32 | cnt[words] u32 | off[words + 1] u64 | scan scratch | claims u64 + flags u32
+size_t factorize_temp_bytes(uint64_t virtual_rows, uint64_t slots) {
+  const uint64_t words = (virtual_rows + 31) / 32;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  return up(slots * 8) + up(virtual_rows * 4) + up(words * 4) + up(words * 4) + up((words + 1) * 8) + up(scan_scratch_elems(words ? words : 1) * 8) + 256;
+}
+
+struct FzTemp {
+  unsigned long long *table; uint32_t *slot_of, *bits, *cnt; unsigned long long *off, *scratch, *claims; uint32_t *flags;
+};
+static FzTemp fz_temp(void *temp, uint64_t V, uint64_t slots) {
+  const uint64_t words = (V + 31) / 32;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  unsigned char *p = static_cast<unsigned char *>(temp);
+  FzTemp t;
+  t.table = reinterpret_cast<unsigned long long *>(p); p += up(slots * 8);
+  t.slot_of = reinterpret_cast<uint32_t *>(p); p += up(V * 4);
+  t.bits = reinterpret_cast<uint32_t *>(p); p += up(words * 4);
+  t.cnt = reinterpret_cast<uint32_t *>(p); p += up(words * 4);
+  t.off = reinterpret_cast<unsigned long long *>(p); p += up((words + 1) * 8);
+  t.scratch = reinterpret_cast<unsigned long long *>(p); p += up(scan_scratch_elems(words ? words : 1) * 8);
+  t.claims = reinterpret_cast<unsigned long long *>(p);
+  t.flags = reinterpret_cast<uint32_t *>(p + 8);
+  return t;
+}
+static dim3 fz_grid(uint64_t items) { const uint64_t b = (items + kFzBlock - 1) / kFzBlock; return dim3((unsigned)(b < 16384 ? (b ? b : 1) : 16384)); }
+
+// One attempt with a table of `slots` slots: all launches, no synchronisation.  (*flags_dev_out)[0] != 0 afterwards: the table was too small —
+// key ids, first rows and the count were not written; repeat with factorize_next_slots.  num_keys_dev: one u64 on the device.
 void launch_factorize(hipStream_t s, const long long *const *cols_a, const uint8_t *keep_a, const long long *const *cols_b, const uint8_t *keep_b, uint64_t n,
-                      int n_cols, void *temp, uint64_t *key_a, uint64_t *key_b, uint64_t *first_row, uint64_t first_row_cap, unsigned long long *num_keys_dev) {
+                      int n_cols, uint64_t slots, void *temp, uint64_t *key_a, uint64_t *key_b, uint64_t *first_row, uint64_t first_row_cap,
+                      unsigned long long *num_keys_dev, uint32_t **flags_dev_out) {
   FzArgs A{};
   for (int c = 0; c < n_cols; ++c) { A.a[c] = cols_a[c]; A.b[c] = cols_b != nullptr ? cols_b[c] : nullptr; }
   A.keep_a = keep_a; A.keep_b = keep_b; A.n = n; A.n_cols = n_cols; A.sides = cols_b != nullptr ? 2u : 1u;
-  const uint64_t V = n * A.sides;
-  const uint64_t slots = factorize_table_slots(V), words = (V + 31) / 32;
-  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  unsigned char *p = static_cast<unsigned char *>(temp);
-  unsigned long long *table = reinterpret_cast<unsigned long long *>(p); p += up(slots * 8);
-  uint32_t *bits = reinterpret_cast<uint32_t *>(p); p += up(words * 4);
-  uint32_t *cnt = reinterpret_cast<uint32_t *>(p); p += up(words * 4);
-  unsigned long long *off = reinterpret_cast<unsigned long long *>(p); p += up((words + 1) * 8);
-  unsigned long long *scratch = reinterpret_cast<unsigned long long *>(p);
-  hipMemsetAsync(table, 0xFF, slots * 8, s);
-  hipMemsetAsync(bits, 0, words * 4, s);
-  auto grid = [](uint64_t items) { const uint64_t b = (items + kFzBlock - 1) / kFzBlock; return dim3((unsigned)(b < 16384 ? (b ? b : 1) : 16384)); };
-  hipLaunchKernelGGL(k_fz_insert, grid(V), dim3(kFzBlock), 0, s, A, table, slots - 1);
-  hipLaunchKernelGGL(k_fz_mark, grid(slots), dim3(kFzBlock), 0, s, table, slots, bits);
-  hipLaunchKernelGGL(k_fz_popc, grid(words), dim3(kFzBlock), 0, s, bits, words, cnt);
-  launch_scan(s, cnt, off, words, scratch, num_keys_dev);
-  hipLaunchKernelGGL(k_fz_lookup, grid(V), dim3(kFzBlock), 0, s, A, table, slots - 1, bits, off, key_a, key_b, first_row, first_row_cap);
+  const uint64_t V = n * A.sides, words = (V + 31) / 32;
+  const FzTemp t = fz_temp(temp, V, slots);
+  *flags_dev_out = t.flags;
+  hipMemsetAsync(t.table, 0xFF, slots * 8, s);
+  hipMemsetAsync(t.bits, 0, words * 4, s);
+  hipMemsetAsync(t.claims, 0, 16, s);
+  hipLaunchKernelGGL(k_fz_insert, fz_grid(V), dim3(kFzBlock), 0, s, A, t.table, slots - 1, t.slot_of, t.flags, t.claims);
+  hipLaunchKernelGGL(k_fz_mark, fz_grid(slots), dim3(kFzBlock), 0, s, t.table, slots, t.bits);
+  hipLaunchKernelGGL(k_fz_popc, fz_grid(words), dim3(kFzBlock), 0, s, t.bits, words, t.cnt);
+  launch_scan(s, t.cnt, t.off, words, t.scratch, num_keys_dev);
+  hipLaunchKernelGGL(k_fz_lookup, fz_grid(V), dim3(kFzBlock), 0, s, A, t.table, t.slot_of, t.bits, t.off, key_a, key_b, first_row, first_row_cap, t.flags);
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // Arrow string column -> dictionary codes (ABI 10): the step in FRONT of the tuples above.  ClickHouse delivers the GROUP BY columns of
@@ -187,7 +258,7 @@ struct StrArgs {
 };
 
 static constexpr uint32_t kSeMaxProbe = 32;
-enum : uint32_t { SE_FLAG_GROW = 1u, SE_FLAG_BAD_OFFSETS = 2u };
+enum : uint32_t { SE_FLAG_GROW = FZ_FLAG_GROW, SE_FLAG_BAD_OFFSETS = FZ_FLAG_BAD_INPUT };
 
 // [b, b + len) of row v; false if the offsets are not usable
 __device__ __forceinline__ bool se_span(const StrArgs &A, uint64_t v, uint64_t &b, uint32_t &len) {
@@ -233,34 +304,103 @@ __device__ __forceinline__ bool se_same(const uint8_t *p, const uint8_t *q, uint
   return true;
 }
 
+// A block's rows are CONSECUTIVE rows of the column, so their bytes are one contiguous range [off[r0], off[r0 + 256)) of `data`: it is copied
+// into LDS with 16-byte loads (consecutive lanes on consecutive 16 bytes: the column's bytes cross the memory system once, in whole lines),
+// and every lane then hashes and compares its own string from LDS.  Per-lane 8-byte global loads at a ~29-byte stride — the first version —
+// made every wave-level load touch ~15 cache lines, five times over per row, and ran at 0.07 of the HBM peak (profiles/r4_v28_*).
+// A block whose 256 rows hold more than kSeStage bytes (long labels) reads its strings from global memory lane by lane instead.
+static constexpr uint32_t kSeStage = 24 * 1024;
+
+// m (1..8) bytes at byte offset `at` of an 8-byte aligned LDS buffer, bytes beyond m zero
+__device__ __forceinline__ uint64_t se_load_lds(const uint64_t *buf, uint32_t at, uint32_t m) {
+  const uint32_t skip = at & 7u;
+  uint64_t x = buf[at >> 3] >> (skip * 8);
+  if (skip + m > 8) x |= buf[(at >> 3) + 1] << ((8 - skip) * 8);
+  if (m < 8) x &= (1ull << (m * 8)) - 1ull;
+  return x;
+}
+
 // every row into the table; slot_of[v] = the slot of v's string.  flags: SE_FLAG_GROW / SE_FLAG_BAD_OFFSETS; claims: slots claimed
 __global__ __launch_bounds__(kFzBlock) void k_se_insert(StrArgs A, unsigned long long *__restrict__ table, uint64_t mask, uint32_t *__restrict__ slot_of,
                                                         uint32_t *__restrict__ flags, unsigned long long *__restrict__ claims) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_bytes[kSeStage / 8 + 4];
+  __shared__ uint64_t s_lo, s_hi;
+  __shared__ uint32_t s_stop;
   uint32_t claimed = 0;
-  for (uint64_t v = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; v < A.n; v += (uint64_t)gridDim.x * kFzBlock) {
-    if (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;      // someone found the table too small (or the offsets bad)
-    uint64_t b; uint32_t len;
-    if (!se_span(A, v, b, len)) { atomicOr(flags, SE_FLAG_BAD_OFFSETS); break; }
-    const uint8_t *p = A.data + b;
-    const uint64_t h = se_hash(p, len);
-    const unsigned long long mine = ((h >> 32) << 32) | v;
-    uint32_t probes = 0;
-    for (uint64_t s = h & mask;; s = (s + 1) & mask) {
-      unsigned long long w = __hip_atomic_load(table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (w == kFzEmpty) {
-        w = atomicCAS(table + s, kFzEmpty, mine);
-        if (w == kFzEmpty) { ++claimed; slot_of[v] = (uint32_t)s; break; }
+  const uint32_t tid = threadIdx.x;
+  for (uint64_t base = (uint64_t)blockIdx.x * kFzBlock; base < A.n; base += (uint64_t)gridDim.x * kFzBlock) {
+    const uint64_t v = base + tid;
+    const uint32_t rows = A.n - base < kFzBlock ? (uint32_t)(A.n - base) : kFzBlock;
+    uint64_t b = 0; uint32_t len = 0;
+    bool ok = true;
+    if (tid < rows) ok = se_span(A, v, b, len);
+    if (tid == 0) {
+      // the block's byte range from its first and last row's RAW offsets (a null row reads as "" but its bytes may still be there)
+      uint64_t lo, hi;
+      if (A.off64) { const long long *o = static_cast<const long long *>(A.off); lo = (uint64_t)o[base]; hi = (uint64_t)o[base + rows]; }
+      else { const int *o = static_cast<const int *>(A.off); lo = (uint64_t)(uint32_t)o[base]; hi = (uint64_t)(uint32_t)o[base + rows]; }
+      s_lo = lo; s_hi = hi;
+      s_stop = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // someone found the table too small (or the offsets bad)
+    }
+    if (!ok) atomicOr(flags, SE_FLAG_BAD_OFFSETS);      // (the host fails the call; this lane skips its row)
+    __syncthreads();                                    // (also: the previous round's strings are no longer read)
+    if (s_stop != 0u) break;                            // block-uniform
+    const uint64_t lo = s_lo, hi = s_hi;
+    const bool bad_range = hi < lo || hi > A.data_bytes;
+    if (bad_range && tid == 0) atomicOr(flags, SE_FLAG_BAD_OFFSETS);
+    const uintptr_t abs_lo = reinterpret_cast<uintptr_t>(A.data) + lo;
+    const uintptr_t abs_a = abs_lo & ~(uintptr_t)15;    // the aligned 16-byte word that holds the range's first byte
+    const uint64_t span = !bad_range && hi > lo ? (reinterpret_cast<uintptr_t>(A.data) + hi) - abs_a : 0;
+    const bool block_staged = !bad_range && span <= kSeStage;     // block-uniform (from the shared bounds)
+    if (block_staged && span) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(abs_a);
+      uint4 *dst = reinterpret_cast<uint4 *>(s_bytes);
+      for (uint32_t i = tid; (uint64_t)i * 16 < span; i += kFzBlock) dst[i] = src[i];   // (the last word may reach past `hi`: same aligned 16 bytes, same page)
+    }
+    __syncthreads();
+    // a lane reads its string from the stage when it lies inside the staged range (always, for monotone offsets), else from global memory
+    const bool staged = block_staged && b >= lo && b + len <= hi;
+    if (ok && tid < rows) {
+      const uint8_t *p = A.data + b;
+      const uint32_t at = staged ? (uint32_t)((reinterpret_cast<uintptr_t>(A.data) + b) - abs_a) : 0u;      // own string's offset in the stage
+      uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
+      if (staged) {
+        for (uint32_t i = 0; i < len; i += 8) h = fz_mix(h ^ se_load_lds(s_bytes, at + i, len - i < 8 ? len - i : 8)) + 0x632BE59BD9B4E019ull;
+        h = fz_mix(h);
+      } else {
+        h = se_hash(p, len);
       }
-      if ((w >> 32) == (mine >> 32)) {
-        uint64_t rb; uint32_t rlen;
-        const uint64_t rep = w & 0xffffffffull;
-        if (se_span(A, rep, rb, rlen) && rlen == len && se_same(p, A.data + rb, len)) {
-          if (mine < w) atomicMin(table + s, mine);
-          slot_of[v] = (uint32_t)s;
-          break;
+      const unsigned long long mine = ((h >> 32) << 32) | v;
+      uint32_t probes = 0;
+      for (uint64_t s = h & mask;; s = (s + 1) & mask) {
+        unsigned long long w = fz_peek(table + s);
+        if (w == kFzEmpty) {
+          w = atomicCAS(table + s, kFzEmpty, mine);
+          if (w == kFzEmpty) { ++claimed; slot_of[v] = (uint32_t)s; break; }
         }
+        if ((w >> 32) == (mine >> 32)) {
+          uint64_t rb; uint32_t rlen;
+          const uint64_t rep = w & 0xffffffffull;
+          bool same = se_span(A, rep, rb, rlen) && rlen == len;
+          if (same) {
+            const uint8_t *q = A.data + rb;
+            if (staged) {
+              for (uint32_t i = 0; i < len && same; i += 8) {
+                const uint32_t m = len - i < 8 ? len - i : 8;
+                same = se_load_lds(s_bytes, at + i, m) == se_load(q + i, m);
+              }
+            } else {
+              same = se_same(p, q, len);
+            }
+          }
+          if (same) {
+            if (mine < w) atomicMin(table + s, mine);
+            slot_of[v] = (uint32_t)s;
+            break;
+          }
+        }
+        if (++probes > kSeMaxProbe) { atomicOr(flags, SE_FLAG_GROW); break; }
       }
-      if (++probes > kSeMaxProbe) { atomicOr(flags, SE_FLAG_GROW); break; }
     }
   }
   // one atomic per wavefront for the claim count (never one per claim)
@@ -277,56 +417,52 @@ __global__ __launch_bounds__(kFzBlock) void k_se_codes(uint64_t n, const unsigne
                                                        long long *__restrict__ codes, uint64_t *__restrict__ first_row, uint64_t first_row_cap,
                                                        const uint32_t *__restrict__ flags) {
   if (*flags != 0u) return;     // the insert pass gave up (table too small / bad offsets): slot_of is not complete, the host repeats or fails
-  for (uint64_t v = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; v < n; v += (uint64_t)gridDim.x * kFzBlock) {
-    const uint64_t rep = table[slot_of[v]] & 0xffffffffull;
-    const uint64_t id = off[rep >> 5] + (uint64_t)__popc(bits[rep >> 5] & ((1u << (rep & 31ull)) - 1u));
-    codes[v] = (long long)id;
-    if (rep == v && id < first_row_cap) first_row[id] = v;
+  // slot -> table word -> bitmap word + offset: three dependent loads per row; four rows per thread keep four chains in flight
+  constexpr int U = 4;
+  const uint64_t stride = (uint64_t)gridDim.x * kFzBlock;
+  for (uint64_t v0 = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; v0 < n; v0 += U * stride) {
+    uint32_t sl[U];
+    uint64_t rep[U];
+    uint32_t bw[U];
+    unsigned long long ow[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sl[u] = v0 + u * stride < n ? slot_of[v0 + u * stride] : 0u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) rep[u] = v0 + u * stride < n ? table[sl[u]] & 0xffffffffull : 0ull;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { bw[u] = bits[rep[u] >> 5]; ow[u] = off[rep[u] >> 5]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t v = v0 + u * stride;
+      if (v >= n) break;
+      const uint64_t id = ow[u] + (uint64_t)__popc(bw[u] & ((1u << (rep[u] & 31ull)) - 1u));
+      codes[v] = (long long)id;
+      if (rep[u] == v && id < first_row_cap) first_row[id] = v;
+    }
   }
 }
 
-uint64_t encode_strings_small_slots(uint64_t n) {
-  const uint64_t full = factorize_table_slots(n);
-  return full < (1ull << 20) ? full : (1ull << 20);
-}
-
-// temp layout: table[slots] u64 | slot_of[n] u32 | bits[words] u32 | cnt[words] u32 | off[words + 1] u64 | scan scratch | flags u32 + claims u64
-size_t encode_strings_temp_bytes(uint64_t n, uint64_t slots) {
-  const uint64_t words = (n + 31) / 32;
-  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  return up(slots * 8) + up(n * 4) + up(words * 4) + up(words * 4) + up((words + 1) * 8) + up(scan_scratch_elems(words ? words : 1) * 8) + 256;
-}
-
-// One attempt with a table of `slots` slots, all launches, no synchronisation.  (*flags_dev_out)[0] != 0 afterwards: bit 0 (grow) -> repeat with
-// factorize_table_slots(n) slots (codes / first_row / num_values_dev are not written then), bit 1 -> the offsets are malformed.
+// One attempt with a table of `slots` slots (factorize_first_slots / factorize_next_slots; temp: factorize_temp_bytes(n, slots)), all launches, no
+// synchronisation.  (*flags_dev_out)[0] != 0 afterwards: bit 0 (grow) -> repeat with the next size (codes / first_row / num_values_dev are not
+// written then), bit 1 -> the offsets are malformed.
 void launch_encode_strings(hipStream_t s, const void *offsets, int off64, const uint8_t *data, uint64_t data_bytes, const uint8_t *valid, uint64_t valid_off,
                            uint64_t n, uint64_t slots, void *temp, long long *codes, uint64_t *first_row, uint64_t first_row_cap,
                            unsigned long long *num_values_dev, uint32_t **flags_dev_out) {
   StrArgs A{};
   A.off = offsets; A.data = data; A.valid = valid; A.valid_off = valid_off; A.n = n; A.data_bytes = data_bytes; A.off64 = off64;
   const uint64_t words = (n + 31) / 32;
-  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  unsigned char *p = static_cast<unsigned char *>(temp);
-  unsigned long long *table = reinterpret_cast<unsigned long long *>(p); p += up(slots * 8);
-  uint32_t *slot_of = reinterpret_cast<uint32_t *>(p); p += up(n * 4);
-  uint32_t *bits = reinterpret_cast<uint32_t *>(p); p += up(words * 4);
-  uint32_t *cnt = reinterpret_cast<uint32_t *>(p); p += up(words * 4);
-  unsigned long long *off = reinterpret_cast<unsigned long long *>(p); p += up((words + 1) * 8);
-  unsigned long long *scratch = reinterpret_cast<unsigned long long *>(p); p += up(scan_scratch_elems(words ? words : 1) * 8);
-  unsigned long long *claims = reinterpret_cast<unsigned long long *>(p);
-  uint32_t *flags = reinterpret_cast<uint32_t *>(p + 8);
-  *flags_dev_out = flags;
-  hipMemsetAsync(table, 0xFF, slots * 8, s);
-  hipMemsetAsync(bits, 0, words * 4, s);
-  hipMemsetAsync(claims, 0, 16, s);
-  auto grid = [](uint64_t items) { const uint64_t b = (items + kFzBlock - 1) / kFzBlock; return dim3((unsigned)(b < 16384 ? (b ? b : 1) : 16384)); };
-  hipLaunchKernelGGL(k_se_insert, grid(n), dim3(kFzBlock), 0, s, A, table, slots - 1, slot_of, flags, claims);
+  const FzTemp t = fz_temp(temp, n, slots);
+  *flags_dev_out = t.flags;
+  hipMemsetAsync(t.table, 0xFF, slots * 8, s);
+  hipMemsetAsync(t.bits, 0, words * 4, s);
+  hipMemsetAsync(t.claims, 0, 16, s);
+  hipLaunchKernelGGL(k_se_insert, fz_grid(n), dim3(kFzBlock), 0, s, A, t.table, slots - 1, t.slot_of, t.flags, t.claims);
   // (after a raised flag the table is incomplete: the passes below still run — over a bitmap of n bits, harmless — and k_se_codes returns
-  // at once; the host reads flags and the count in ONE synchronisation and repeats the attempt with the full-size table if asked to)
-  hipLaunchKernelGGL(k_fz_mark, grid(slots), dim3(kFzBlock), 0, s, table, slots, bits);
-  hipLaunchKernelGGL(k_fz_popc, grid(words), dim3(kFzBlock), 0, s, bits, words, cnt);
-  launch_scan(s, cnt, off, words, scratch, num_values_dev);
-  hipLaunchKernelGGL(k_se_codes, grid(n), dim3(kFzBlock), 0, s, n, table, slot_of, bits, off, codes, first_row, first_row_cap, flags);
+  // at once; the host reads flags and the count in ONE synchronisation and repeats the attempt with the next table size if asked to)
+  hipLaunchKernelGGL(k_fz_mark, fz_grid(slots), dim3(kFzBlock), 0, s, t.table, slots, t.bits);
+  hipLaunchKernelGGL(k_fz_popc, fz_grid(words), dim3(kFzBlock), 0, s, t.bits, words, t.cnt);
+  launch_scan(s, t.cnt, t.off, words, t.scratch, num_values_dev);
+  hipLaunchKernelGGL(k_se_codes, fz_grid(n), dim3(kFzBlock), 0, s, n, t.table, t.slot_of, t.bits, t.off, codes, first_row, first_row_cap, t.flags);
 }
 
 }  // namespace tad

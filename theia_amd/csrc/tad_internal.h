@@ -425,14 +425,14 @@ void launch_shard_scatter(hipStream_t s, const uint64_t *key, const int64_t *t_e
 
 // ---- ingest: key tuples -> dense ids in order of first appearance (tad_factorize.hip) ----
 static constexpr int kFzMaxCols = 8;
-uint64_t factorize_table_slots(uint64_t virtual_rows);
-size_t factorize_temp_bytes(uint64_t virtual_rows);
+uint64_t factorize_table_slots(uint64_t virtual_rows);                  // the full size (2 n slots)
+uint64_t factorize_first_slots(uint64_t virtual_rows);                  // the first attempt's table: min(full, 2^20)
+uint64_t factorize_next_slots(uint64_t virtual_rows, uint64_t slots);   // 2^20 -> 2^24 -> full
+size_t factorize_temp_bytes(uint64_t virtual_rows, uint64_t slots);
 void launch_factorize(hipStream_t s, const long long *const *cols_a, const uint8_t *keep_a, const long long *const *cols_b, const uint8_t *keep_b, uint64_t n,
-                      int n_cols, void *temp, uint64_t *key_a, uint64_t *key_b, uint64_t *first_row, uint64_t first_row_cap, unsigned long long *num_keys_dev);
-
-// Arrow string column -> dictionary codes in order of first appearance (tad_factorize.hip, ABI 10)
-uint64_t encode_strings_small_slots(uint64_t n);
-size_t encode_strings_temp_bytes(uint64_t n, uint64_t slots);
+                      int n_cols, uint64_t slots, void *temp, uint64_t *key_a, uint64_t *key_b, uint64_t *first_row, uint64_t first_row_cap,
+                      unsigned long long *num_keys_dev, uint32_t **flags_dev_out);
+// Arrow string column -> dictionary codes in order of first appearance (tad_factorize.hip, ABI 10); same table sizes and temp layout
 void launch_encode_strings(hipStream_t s, const void *offsets, int off64, const uint8_t *data, uint64_t data_bytes, const uint8_t *valid, uint64_t valid_off,
                            uint64_t n, uint64_t slots, void *temp, long long *codes, uint64_t *first_row, uint64_t first_row_cap,
                            unsigned long long *num_values_dev, uint32_t **flags_dev_out);

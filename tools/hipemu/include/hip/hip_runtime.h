@@ -33,6 +33,8 @@ typedef struct hipemu_event_s *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __HIP_MEMORY_SCOPE_AGENT 4
 
 struct dim3 {
