@@ -41,7 +41,9 @@ def jdbc_to_http(url):
     raise ValueError("Please provide a valid JDBC url for ClickHouse database")   # anomaly_detection.py:823-829
 
 
-STRING_CHUNK_BYTES = 256 << 20    # string-column bytes handed to one tad_encode_strings call (query_columns(engine=...))
+# string-column bytes handed to one tad_encode_strings call (query_columns(engine=...)): below Arrow's 2 GB limit of int32 offsets, and large
+# because every chunk after a column's first pays a gather that maps its codes into the column's unified dictionary
+STRING_CHUNK_BYTES = 1 << 30
 
 
 class ClickHouseHTTP:
@@ -66,7 +68,7 @@ class ClickHouseHTTP:
         """Run a SELECT, return {column name: numpy array}.  `params`: values of the statement's `{name:Type}` placeholders, sent as
         `param_<name>` URL parameters (the HTTP interface's query parameters: the value never becomes SQL text).
         `engine` (with dict_strings): plain string columns are dictionary-encoded ON THE GPU (TadEngine.encode_strings = tad_encode_strings,
-        include/tad.h) in chunks of ~STRING_CHUNK_BYTES of column bytes instead of by Arrow on one host core per record batch — the same
+        include/tad.h) in chunks of ~STRING_CHUNK_BYTES (1 GB) of column bytes instead of by Arrow on one host core per record batch — the same
         codes and dictionaries (first-appearance order per chunk, unified over the chunks exactly as the batch dictionaries are).  DateTime -> int64 epoch seconds, String -> str — or, with
         dict_strings=True, String -> theia_amd.anomaly_detection.DictColumn (integer codes per row + the distinct values, one
         dictionary per column unified over the record batches): no Python object per row is ever created, which is what makes
@@ -113,7 +115,9 @@ class ClickHouseHTTP:
                 dvals = arr.take(pa.array(first.astype(np.int64))).fill_null("").to_pylist()
                 voc = vocab.setdefault(name, {})
                 remap = np.fromiter((voc.setdefault(v, len(voc)) for v in dvals), dtype=np.int64, count=len(dvals))
-                parts.setdefault(name, []).append(remap[codes] if remap.size else np.zeros(0, dtype=np.int64))
+                if remap.size and not np.array_equal(remap, np.arange(remap.size)):      # (a column's first chunk IS its dictionary: no gather)
+                    codes = remap[codes]
+                parts.setdefault(name, []).append(codes if remap.size else np.zeros(0, dtype=np.int64))
 
             for batch in reader:
                 for name, col in zip(batch.schema.names, batch.columns):
