@@ -65,9 +65,13 @@ __device__ __forceinline__ uint64_t fz_hash(const FzArgs &A, uint64_t v, long lo
 }
 __device__ __forceinline__ bool fz_same(const FzArgs &A, uint64_t v, const long long (&t)[kFzMaxCols], uint64_t rep) {
   if ((v >= A.n) != (rep >= A.n)) return false;
-  for (int c = 0; c < A.n_cols; ++c)
-    if (fz_value(A, rep, c) != t[c]) return false;
-  return true;
+  // every column of the representative row is loaded before any is compared: with an early exit per column the compare was one memory round
+  // trip per key column (rows that match — all but the first of a key — never take the exit anyway)
+  bool same = true;
+#pragma unroll
+  for (int c = 0; c < kFzMaxCols; ++c)
+    if (c < A.n_cols) same = same & (fz_value(A, rep, c) == t[c]);
+  return same;
 }
 
 static constexpr uint32_t kFzMaxProbe = 32;
@@ -279,13 +283,16 @@ __device__ __forceinline__ bool se_span(const StrArgs &A, uint64_t v, uint64_t &
   return true;
 }
 
-// m (1..8) bytes at p as a little-endian word, bytes beyond m zero
+// m (1..8) bytes at p as a little-endian word, bytes beyond m zero.  Two aligned loads without a branch between them (a conditional second load
+// made every chunk of a compare its own memory round trip): when the chunk does not reach into the next word, the first word is loaded twice.
 __device__ __forceinline__ uint64_t se_load(const uint8_t *p, uint32_t m) {
   const uintptr_t a = reinterpret_cast<uintptr_t>(p);
   const uint64_t *w = reinterpret_cast<const uint64_t *>(a & ~(uintptr_t)7);
   const uint32_t skip = (uint32_t)(a & 7);           // bytes of w[0] in front of p
-  uint64_t x = w[0] >> (skip * 8);
-  if (skip + m > 8) x |= w[1] << ((8 - skip) * 8);   // (skip >= 1 here: the shift is < 64)
+  const bool two = skip + m > 8;                      // (skip >= 1 then: the left shift below is < 64)
+  const uint64_t lo = w[0], hi = w[two ? 1 : 0];
+  uint64_t x = lo >> (skip * 8);
+  if (two) x |= hi << ((8 - skip) * 8);
   if (m < 8) x &= (1ull << (m * 8)) - 1ull;
   return x;
 }
@@ -296,12 +303,43 @@ __device__ __forceinline__ uint64_t se_hash(const uint8_t *p, uint32_t len) {
   return fz_mix(h);
 }
 
-__device__ __forceinline__ bool se_same(const uint8_t *p, const uint8_t *q, uint32_t len) {
-  for (uint32_t i = 0; i < len; i += 8) {
-    const uint32_t m = len - i < 8 ? len - i : 8;
-    if (se_load(p + i, m) != se_load(q + i, m)) return false;
+// own(at, m): m bytes of the lane's own string at offset `at`; q: the representative row's bytes in global memory.  What the compare costs is
+// the number of load instructions — 64 lanes, 64 different representatives, 64 different cache lines per instruction, all from L2 — not their
+// latency (3.4 of the insert pass's 5.1 ms, profiles/r4_v33_*; loading the chunks four at a time changed nothing).  So the representative's bytes
+// are fetched as ALIGNED 16-byte words, each exactly once (a 29-byte name is 2-3 loads; chunk by chunk through se_load it was 8: every aligned word
+// twice), and each 8-byte half is compared with the bytes of the own string it covers.
+template <class Own>
+__device__ __forceinline__ bool se_same_as(Own own, const uint8_t *q, uint32_t len) {
+  if (len == 0) return true;                               // (nothing to read: the lengths are equal)
+  const uintptr_t a = reinterpret_cast<uintptr_t>(q);
+  const ulonglong2 *w = reinterpret_cast<const ulonglong2 *>(a & ~(uintptr_t)15);
+  const int skip = (int)(a & 15);                          // bytes of w[0] in front of the string
+  const uint32_t nw = ((uint32_t)skip + len + 15u) >> 4;   // aligned 16-byte words that hold a byte of the string (each inside the buffer's pages)
+  bool same = true;
+  for (uint32_t k0 = 0; k0 < nw && same; k0 += 2) {
+    ulonglong2 v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = w[k0 + u < nw ? k0 + u : k0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (k0 + u >= nw) break;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int start = (int)(16u * (k0 + u)) + 8 * h - skip;        // offset in the string of this 8-byte half's first byte (may be < 0)
+        const int s0 = start < 0 ? 0 : start;
+        const int e0 = start + 8 < (int)len ? start + 8 : (int)len;
+        if (e0 <= s0) continue;                                         // the half lies before or behind the string
+        const uint32_t m = (uint32_t)(e0 - s0);
+        uint64_t x = (h == 0 ? v[u].x : v[u].y) >> (8 * (s0 - start));
+        if (m < 8) x &= (1ull << (m * 8)) - 1ull;
+        same = same && x == own((uint32_t)s0, m);
+      }
+    }
   }
-  return true;
+  return same;
+}
+__device__ __forceinline__ bool se_same(const uint8_t *p, const uint8_t *q, uint32_t len) {
+  return se_same_as([&](uint32_t at, uint32_t m) { return se_load(p + at, m); }, q, len);
 }
 
 // A block's rows are CONSECUTIVE rows of the column, so their bytes are one contiguous range [off[r0], off[r0 + 256)) of `data`: it is copied
@@ -372,6 +410,10 @@ __global__ __launch_bounds__(kFzBlock) void k_se_insert(StrArgs A, unsigned long
       }
       const unsigned long long mine = ((h >> 32) << 32) | v;
       uint32_t probes = 0;
+#if defined(TAD_SE_PROF_NOTABLE)      // measurement builds (tools/build_variants.py): stage + hash only
+      slot_of[v] = (uint32_t)(h & mask);
+      continue;
+#endif
       for (uint64_t s = h & mask;; s = (s + 1) & mask) {
         unsigned long long w = fz_peek(table + s);
         if (w == kFzEmpty) {
@@ -381,17 +423,16 @@ __global__ __launch_bounds__(kFzBlock) void k_se_insert(StrArgs A, unsigned long
         if ((w >> 32) == (mine >> 32)) {
           uint64_t rb; uint32_t rlen;
           const uint64_t rep = w & 0xffffffffull;
+#if defined(TAD_SE_PROF_NOCOMPARE)    // measurement builds: a fingerprint match is taken for equality
+          bool same = true; rb = 0; rlen = len;
+          if (false) {
+#else
           bool same = se_span(A, rep, rb, rlen) && rlen == len;
           if (same) {
+#endif
             const uint8_t *q = A.data + rb;
-            if (staged) {
-              for (uint32_t i = 0; i < len && same; i += 8) {
-                const uint32_t m = len - i < 8 ? len - i : 8;
-                same = se_load_lds(s_bytes, at + i, m) == se_load(q + i, m);
-              }
-            } else {
-              same = se_same(p, q, len);
-            }
+            if (staged) same = se_same_as([&](uint32_t o, uint32_t m) { return se_load_lds(s_bytes, at + o, m); }, q, len);
+            else same = se_same(p, q, len);
           }
           if (same) {
             if (mine < w) atomicMin(table + s, mine);

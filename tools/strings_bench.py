@@ -22,6 +22,7 @@ ap.add_argument("--rows", type=int, default=100_000_000)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--arrow-rows", type=int, default=10_000_000)
 ap.add_argument("--host-rows", type=int, default=20_000_000, help="rows of the host-memory (PCIe-inclusive) run")
+ap.add_argument("--shapes", default="low,high", help="low = 2e4 distinct values, high = rows/50 distinct values")
 args = ap.parse_args()
 n = args.rows
 rng = np.random.default_rng(5)
@@ -37,7 +38,8 @@ def column(n, distinct):
     return vocab.take(pa.array(rng.integers(0, distinct, size=n)))
 
 
-for label, distinct in (("2e4 distinct pod names (small table)", 20_000), ("rows/50 distinct values (table grows)", max(1, n // 50))):
+for label, distinct in [sh for sh, tag in ((("2e4 distinct pod names (small table)", 20_000), "low"), (("rows/50 distinct values (table grows)", max(1, n // 50)), "high"))
+                        if tag in args.shapes.split(",")]:
     arr = column(n, distinct)
     _, obuf, dbuf = arr.buffers()
     offsets = np.frombuffer(obuf, dtype=np.int64)[: n + 1]
