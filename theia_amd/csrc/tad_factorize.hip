@@ -12,7 +12,8 @@
 // with an atomic min — the fingerprint sits in the high half, so the minimum is taken among rows of this very tuple.  After the
 // pass every slot names the first row of its tuple.  Ids in order of first appearance (what pandas.factorize gives, so that the
 // GPU path and the pandas path produce identical key ids and key tables): a bitmap of the first rows, a scan of its popcounts,
-// id(first row r) = first rows before r.  The insert pass leaves every row's slot behind (4 bytes); a second pass reads slot -> first row -> id.
+// id(first row r) = first rows before r.  The insert pass leaves every row's slot behind (4 bytes); after the scan a pass over the SLOTS turns every
+// claimed word into its id, and the pass over the rows is slot -> id.
 // Pod mode (the UNION ALL of the inbound and the outbound view, :556-565) passes two tuples per row: the table runs over the
 // virtual rows [side a: 0 .. n) ++ [side b: n .. 2n), the side is part of the tuple.
 #include "tad_internal.h"
@@ -129,21 +130,33 @@ __global__ __launch_bounds__(kFzBlock) void k_fz_popc(const uint32_t *__restrict
   for (uint64_t i = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; i < words; i += (uint64_t)gridDim.x * kFzBlock) cnt[i] = (uint32_t)__popc(bits[i]);
 }
 
-// id of every row (TAD_KEY_SKIP for rows that are not kept) from its slot; first_row[id] by the row that is its tuple's first
+// After the scan every claimed slot learns its id: table[s] = id (the fingerprint has done its work), first_row[id] = the slot's first row.
+// A pass over the SLOTS — 2^20 of them in the common case — so that the pass over the rows below is slot -> id, one random read instead of
+// three (table word, bitmap word, offset).
+__global__ __launch_bounds__(kFzBlock) void k_fz_ids(unsigned long long *__restrict__ table, uint64_t slots, const uint32_t *__restrict__ bits,
+                                                      const unsigned long long *__restrict__ off, uint64_t *__restrict__ first_row, uint64_t first_row_cap,
+                                                      const uint32_t *__restrict__ flags) {
+  if (*flags != 0u) return;     // the insert pass gave up: the host repeats with a larger table
+  for (uint64_t s = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * kFzBlock) {
+    const unsigned long long w = table[s];
+    if (w == kFzEmpty) continue;
+    const uint64_t rep = w & 0xffffffffull;
+    const uint64_t id = off[rep >> 5] + (uint64_t)__popc(bits[rep >> 5] & ((1u << (rep & 31ull)) - 1u));
+    table[s] = id;
+    if (id < first_row_cap) first_row[id] = rep;
+  }
+}
+
+// id of every row (TAD_KEY_SKIP for rows that are not kept): slot -> id
 __global__ __launch_bounds__(kFzBlock) void k_fz_lookup(FzArgs A, const unsigned long long *__restrict__ table, const uint32_t *__restrict__ slot_of,
-                                                         const uint32_t *__restrict__ bits, const unsigned long long *__restrict__ off,
-                                                         uint64_t *__restrict__ key_a, uint64_t *__restrict__ key_b, uint64_t *__restrict__ first_row,
-                                                         uint64_t first_row_cap, const uint32_t *__restrict__ flags) {
+                                                         uint64_t *__restrict__ key_a, uint64_t *__restrict__ key_b, const uint32_t *__restrict__ flags) {
   if (*flags != 0u) return;     // the insert pass gave up: slot_of is incomplete, the host repeats with a larger table
-  // slot -> table word -> bitmap word + offset: three dependent loads per row; four rows per thread keep four chains in flight
-  constexpr int U = 4;
+  constexpr int U = 4;          // four rows per thread in flight (slot, then the table word)
   const uint64_t V = A.n * A.sides, stride = (uint64_t)gridDim.x * kFzBlock;
   for (uint64_t v0 = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; v0 < V; v0 += U * stride) {
     bool kept[U];
     uint32_t sl[U];
-    uint64_t rep[U];
-    uint32_t bw[U];
-    unsigned long long ow[U];
+    unsigned long long id[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t v = v0 + u * stride;
@@ -151,18 +164,12 @@ __global__ __launch_bounds__(kFzBlock) void k_fz_lookup(FzArgs A, const unsigned
       sl[u] = kept[u] ? slot_of[v] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) rep[u] = kept[u] ? table[sl[u]] & 0xffffffffull : 0ull;
-#pragma unroll
-    for (int u = 0; u < U; ++u) { bw[u] = bits[rep[u] >> 5]; ow[u] = off[rep[u] >> 5]; }
+    for (int u = 0; u < U; ++u) id[u] = kept[u] ? table[sl[u]] : (unsigned long long)TAD_KEY_SKIP;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t v = v0 + u * stride;
       if (v >= V) break;
-      uint64_t *out = v >= A.n ? key_b + (v - A.n) : key_a + v;
-      if (!kept[u]) { *out = TAD_KEY_SKIP; continue; }
-      const uint64_t id = ow[u] + (uint64_t)__popc(bw[u] & ((1u << (rep[u] & 31ull)) - 1u));
-      *out = id;
-      if (rep[u] == v && id < first_row_cap) first_row[id] = v;
+      *(v >= A.n ? key_b + (v - A.n) : key_a + v) = id[u];
     }
   }
 }
@@ -228,7 +235,8 @@ void launch_factorize(hipStream_t s, const long long *const *cols_a, const uint8
   hipLaunchKernelGGL(k_fz_mark, fz_grid(slots), dim3(kFzBlock), 0, s, t.table, slots, t.bits);
   hipLaunchKernelGGL(k_fz_popc, fz_grid(words), dim3(kFzBlock), 0, s, t.bits, words, t.cnt);
   launch_scan(s, t.cnt, t.off, words, t.scratch, num_keys_dev);
-  hipLaunchKernelGGL(k_fz_lookup, fz_grid(V), dim3(kFzBlock), 0, s, A, t.table, t.slot_of, t.bits, t.off, key_a, key_b, first_row, first_row_cap, t.flags);
+  hipLaunchKernelGGL(k_fz_ids, fz_grid(slots), dim3(kFzBlock), 0, s, t.table, slots, t.bits, t.off, first_row, first_row_cap, t.flags);
+  hipLaunchKernelGGL(k_fz_lookup, fz_grid(V), dim3(kFzBlock), 0, s, A, t.table, t.slot_of, key_a, key_b, t.flags);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -452,34 +460,22 @@ __global__ __launch_bounds__(kFzBlock) void k_se_insert(StrArgs A, unsigned long
   }
 }
 
-// code of every row from its slot; first_row[id] by the row that is its string's first
+// code of every row: slot -> id (k_fz_ids has turned the table's words into ids and written the first rows)
 __global__ __launch_bounds__(kFzBlock) void k_se_codes(uint64_t n, const unsigned long long *__restrict__ table, const uint32_t *__restrict__ slot_of,
-                                                       const uint32_t *__restrict__ bits, const unsigned long long *__restrict__ off,
-                                                       long long *__restrict__ codes, uint64_t *__restrict__ first_row, uint64_t first_row_cap,
-                                                       const uint32_t *__restrict__ flags) {
+                                                       long long *__restrict__ codes, const uint32_t *__restrict__ flags) {
   if (*flags != 0u) return;     // the insert pass gave up (table too small / bad offsets): slot_of is not complete, the host repeats or fails
-  // slot -> table word -> bitmap word + offset: three dependent loads per row; four rows per thread keep four chains in flight
   constexpr int U = 4;
   const uint64_t stride = (uint64_t)gridDim.x * kFzBlock;
   for (uint64_t v0 = (uint64_t)blockIdx.x * kFzBlock + threadIdx.x; v0 < n; v0 += U * stride) {
     uint32_t sl[U];
-    uint64_t rep[U];
-    uint32_t bw[U];
-    unsigned long long ow[U];
+    unsigned long long id[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) sl[u] = v0 + u * stride < n ? slot_of[v0 + u * stride] : 0u;
 #pragma unroll
-    for (int u = 0; u < U; ++u) rep[u] = v0 + u * stride < n ? table[sl[u]] & 0xffffffffull : 0ull;
+    for (int u = 0; u < U; ++u) id[u] = v0 + u * stride < n ? table[sl[u]] : 0ull;
 #pragma unroll
-    for (int u = 0; u < U; ++u) { bw[u] = bits[rep[u] >> 5]; ow[u] = off[rep[u] >> 5]; }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t v = v0 + u * stride;
-      if (v >= n) break;
-      const uint64_t id = ow[u] + (uint64_t)__popc(bw[u] & ((1u << (rep[u] & 31ull)) - 1u));
-      codes[v] = (long long)id;
-      if (rep[u] == v && id < first_row_cap) first_row[id] = v;
-    }
+    for (int u = 0; u < U; ++u)
+      if (v0 + u * stride < n) codes[v0 + u * stride] = (long long)id[u];
   }
 }
 
@@ -503,7 +499,8 @@ void launch_encode_strings(hipStream_t s, const void *offsets, int off64, const 
   hipLaunchKernelGGL(k_fz_mark, fz_grid(slots), dim3(kFzBlock), 0, s, t.table, slots, t.bits);
   hipLaunchKernelGGL(k_fz_popc, fz_grid(words), dim3(kFzBlock), 0, s, t.bits, words, t.cnt);
   launch_scan(s, t.cnt, t.off, words, t.scratch, num_values_dev);
-  hipLaunchKernelGGL(k_se_codes, fz_grid(n), dim3(kFzBlock), 0, s, n, t.table, t.slot_of, t.bits, t.off, codes, first_row, first_row_cap, t.flags);
+  hipLaunchKernelGGL(k_fz_ids, fz_grid(slots), dim3(kFzBlock), 0, s, t.table, slots, t.bits, t.off, first_row, first_row_cap, t.flags);
+  hipLaunchKernelGGL(k_se_codes, fz_grid(n), dim3(kFzBlock), 0, s, n, t.table, t.slot_of, codes, t.flags);
 }
 
 }  // namespace tad
