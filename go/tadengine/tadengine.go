@@ -84,6 +84,10 @@ func NewEngine(device int) (*Engine, error) { return NewEngineWithPlan(device, P
 
 // NewEngineWithPlan creates the engine with plan overrides in tad_engine_opts.plan.
 func NewEngineWithPlan(device int, plan Plan) (*Engine, error) {
+	// the header this file was compiled against and the library the process loaded must be the same ABI (struct layouts!)
+	if v := int(C.tad_abi_version()); v != int(C.TAD_ABI_VERSION) {
+		return nil, fmt.Errorf("libtad_mi355x.so ABI %d != tad.h ABI %d", v, int(C.TAD_ABI_VERSION))
+	}
 	opts := C.tad_engine_opts{device: C.int32_t(device), plan: plan.c()}
 	var h *C.tad_engine
 	if rc := C.tad_engine_create(&opts, &h); rc != C.TAD_OK {
@@ -416,6 +420,123 @@ func (e *Engine) EncodeStrings(offsets []int32, data []byte, validity []byte) (c
 		return nil, nil, fmt.Errorf("tad_encode_strings: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
 	}
 	return codes, firstRow[:int(nv)], nil
+}
+
+// AllocDevice / FreeDevice / CopyToDevice / CopyToHost: device buffers for hosts without a HIP binding of their own (what ShardRows and a
+// device-resident Run take).
+func (e *Engine) AllocDevice(bytes uint64) (unsafe.Pointer, error) {
+	var p unsafe.Pointer
+	if rc := C.tad_device_alloc(e.h, C.uint64_t(bytes), &p); rc != C.TAD_OK {
+		return nil, fmt.Errorf("tad_device_alloc: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return p, nil
+}
+
+func (e *Engine) FreeDevice(p unsafe.Pointer) { C.tad_device_free(e.h, p) }
+
+func (e *Engine) CopyToDevice(dst unsafe.Pointer, src []byte) error {
+	if len(src) == 0 {
+		return nil
+	}
+	if rc := C.tad_copy_to_device(e.h, dst, unsafe.Pointer(&src[0]), C.uint64_t(len(src))); rc != C.TAD_OK {
+		return fmt.Errorf("tad_copy_to_device: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return nil
+}
+
+func (e *Engine) CopyToHost(dst []byte, src unsafe.Pointer) error {
+	if len(dst) == 0 {
+		return nil
+	}
+	if rc := C.tad_copy_to_host(e.h, unsafe.Pointer(&dst[0]), src, C.uint64_t(len(dst))); rc != C.TAD_OK {
+		return fmt.Errorf("tad_copy_to_host: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return nil
+}
+
+// State is the per-key running EWMA state of a long-running detector (tad.h: tad_state, SURVEY.md 8f rank 3): Spark's streaming moments
+// (n, avg, m2), the last EWMA value and the last flowEndSeconds of every key, kept in HBM between batches.
+type State struct {
+	e *Engine
+	h *C.tad_state
+}
+
+func (e *Engine) NewState(numKeys uint64) (*State, error) {
+	var h *C.tad_state
+	if rc := C.tad_state_create(e.h, C.uint64_t(numKeys), &h); rc != C.TAD_OK {
+		return nil, fmt.Errorf("tad_state_create: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return &State{e: e, h: h}, nil
+}
+
+func (s *State) Close() {
+	if s.h != nil {
+		C.tad_state_destroy(s.e.h, s.h)
+		s.h = nil
+	}
+}
+
+// RunStream aggregates ONE new batch and continues every key's recurrences over its new points (tad_run_stream): the rows are the points
+// with |x - ewma| > the running stddev_samp.  cols.NumKeys must equal the state's key count; job.Algo must be EWMA.
+func (s *State) RunStream(job Job, cols Columns) ([]Row, error) {
+	n := len(cols.KeyID)
+	if len(cols.FlowEndS) != n || len(cols.Value) != n {
+		return nil, errors.New("tadengine: columns differ in length")
+	}
+	var cj C.tad_job
+	cj.algo = C.tad_algo(job.Algo)
+	cj.agg_flow = C.tad_agg_flow(job.AggFlow)
+	cj.value_op = C.TAD_OP_AUTO
+	var cc C.tad_columns
+	cc.n_rows = C.uint64_t(n)
+	cc.num_keys = C.uint64_t(cols.NumKeys)
+	cc.memory = C.TAD_MEM_HOST
+	bufs := []unsafe.Pointer{cColumn(cols.KeyID), cColumn(cols.FlowEndS), cColumn(cols.Value)}
+	defer func() {
+		for _, p := range bufs {
+			if p != nil {
+				C.free(p)
+			}
+		}
+	}()
+	cc.key_id = (*C.uint64_t)(bufs[0])
+	cc.flow_end_s = (*C.int64_t)(bufs[1])
+	cc.value = (*C.uint64_t)(bufs[2])
+	var res *C.tad_result
+	if rc := C.tad_run_stream(s.e.h, s.h, &cj, &cc, C.TAD_MEM_HOST, &res); rc != C.TAD_OK {
+		msg := C.GoString(C.tad_last_error(s.e.h))
+		if rc == C.TAD_ERR_INVALID_ARGUMENT {
+			return nil, IllegalArgument{msg}
+		}
+		return nil, fmt.Errorf("tad_run_stream: %s (code %d)", msg, int(rc))
+	}
+	defer C.tad_result_free(s.e.h, res)
+	a := int(res.n_rows)
+	rows := make([]Row, a)
+	if a > 0 {
+		k := unsafe.Slice((*uint64)(unsafe.Pointer(res.key_id)), a)
+		t := unsafe.Slice((*int64)(unsafe.Pointer(res.flow_end_s)), a)
+		x := unsafe.Slice((*float64)(unsafe.Pointer(res.throughput)), a)
+		c := unsafe.Slice((*float64)(unsafe.Pointer(res.algo_calc)), a)
+		sd := unsafe.Slice((*float64)(unsafe.Pointer(res.stddev)), a)
+		for i := range rows {
+			rows[i] = Row{k[i], t[i], x[i], c[i], sd[i]}
+		}
+	}
+	return rows, nil
+}
+
+// Export copies the state to the host: per key the point count, Spark's avg and m2, the last EWMA value and the last flowEndSeconds.
+func (s *State) Export(numKeys uint64) (n []uint32, avg, m2, ewma []float64, lastT []int64, err error) {
+	n, avg, m2, ewma, lastT = make([]uint32, numKeys), make([]float64, numKeys), make([]float64, numKeys), make([]float64, numKeys), make([]int64, numKeys)
+	if numKeys == 0 {
+		return
+	}
+	if rc := C.tad_state_export(s.e.h, s.h, (*C.uint32_t)(unsafe.Pointer(&n[0])), (*C.double)(unsafe.Pointer(&avg[0])), (*C.double)(unsafe.Pointer(&m2[0])),
+		(*C.double)(unsafe.Pointer(&ewma[0])), (*C.int64_t)(unsafe.Pointer(&lastT[0]))); rc != C.TAD_OK {
+		err = fmt.Errorf("tad_state_export: %s (code %d)", C.GoString(C.tad_last_error(s.e.h)), int(rc))
+	}
+	return
 }
 
 // Progress feeds Status.CompletedStages / TotalStages (controller.go:426-453).

@@ -161,6 +161,11 @@ def test_encode_strings_slices_nulls_and_strings_that_differ_only_in_their_tail(
         codes, first = engine.encode_strings(sl)
         want_codes, want_first, _ = _want_codes(sl)
         assert (codes == want_codes).all() and (first == want_first).all()
+    # a chunked column is one column
+    chunked = pa.chunked_array([arr.slice(0, 40), arr.slice(40, 3), arr.slice(43)])
+    codes, first = engine.encode_strings(chunked)
+    want_codes, want_first, _ = _want_codes(arr)
+    assert (codes == want_codes).all() and (first == want_first).all()
     # an all-null / all-empty column: one value
     codes, first = engine.encode_strings(pa.array([None, None, ""], pa.string()))
     assert codes.tolist() == [0, 0, 0] and first.tolist() == [0]

@@ -464,6 +464,8 @@ class TadEngine:
         first appears — in the memory the input lives in."""
         keepalive = []
         validity, voff = None, 0
+        if hasattr(column, "combine_chunks") and hasattr(column, "chunks"):     # a pyarrow ChunkedArray: one contiguous column first
+            column = column.combine_chunks() if column.num_chunks != 1 else column.chunk(0)
         if hasattr(column, "buffers") and hasattr(column, "type"):        # a pyarrow Array
             import pyarrow as pa
             t = column.type
