@@ -126,13 +126,14 @@ def cpu_sample(algo, rows, keys, cores):
 
 def pmc_traffic(kernel, name="pmc_latest.json"):
     """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes), or None.  `job_*`: the sum over
-    every kernel of the job (each launches once per job since round 4; the table generator k_synth is not part of it)."""
+    every kernel of the job (each launches once per job since round 4; the table generator and the one-time placement probe are not part of it)."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
         k = d["kernels"][kernel]
-        jf = sum(v["fetch_bytes"] for a, v in d["kernels"].items() if a != "k_synth")
-        jw = sum(v["write_bytes"] for a, v in d["kernels"].items() if a != "k_synth")
+        once = ("k_synth", "k_place_probe")     # the table generator; the placement probe of the record buffer (first job of an engine only)
+        jf = sum(v["fetch_bytes"] for a, v in d["kernels"].items() if a not in once)
+        jw = sum(v["write_bytes"] for a, v in d["kernels"].items() if a not in once)
         return {"bytes": k["fetch_bytes"] + k["write_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
                 "job_bytes": jf + jw, "job_fetch_bytes": jf, "job_write_bytes": jw, "source": d["source"]}
     except Exception:

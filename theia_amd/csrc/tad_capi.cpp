@@ -161,13 +161,15 @@ int ensure(tad_engine *e, DevBuf &b, size_t bytes) {
 // Placement of the record buffer (round 4).  Pass B's time depends on where the buffer it scatters into landed in physical memory — on some boxes
 // 0.605 or 0.675 ms for the same C2 job on two engine instances of one process, 0.60 / 0.69 ms at C4 (profiles/r4_v37_*) — and nothing in the
 // address says which.  A freshly allocated buffer of a big table is therefore timed with pass B's memory pattern (launch_place_probe, which
-// separates the two kinds of placement as clearly as the job does: 0.58 against 0.65 ms) against up to seven other allocations of the same size,
-// made while the earlier ones are still held (so that they land elsewhere); it stops as soon as one candidate is 4 % faster than the slowest
-// seen, the fastest stays, the others are freed.  Once per allocation, i.e. once per engine and table shape: a few probe launches (~0.6 ms each)
+// separates the two kinds of placement as clearly as the job does: 0.58 against 0.65 ms) against up to fifteen other allocations of the same size
+// (24 GB in all: in a fresh process the first ~8 GB allocated after the columns probed slow, what comes after fast — profiles/r4_v37_*),
+// made while the earlier ones are still held (so that they land elsewhere); it stops once a candidate 4 % faster than the slowest has been
+// seen and the next one is no better, the fastest stays, the others are freed.  Once per allocation, i.e. once per engine and table shape: a few probe launches (~0.6 ms each)
 // and host synchronisations inside the first job.  On a box without the effect all candidates time alike and the first one stays.
 #ifndef TAD_PLACEMENT_CANDIDATES
-#define TAD_PLACEMENT_CANDIDATES 8
+#define TAD_PLACEMENT_CANDIDATES 16
 #endif
+static constexpr size_t kPlacementBytes = (size_t)24 << 30;   // ... and at most this much memory held by the candidates together
 int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d_val, uint64_t n, uint64_t slots, uint32_t nparts, int G) {
   if (TAD_PLACEMENT_CANDIDATES < 2 || n < (1ull << 24) || nparts == 0) return TAD_OK;
   hipStream_t s = e->stream;
@@ -194,7 +196,7 @@ int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d
   cand[0] = Cand{e->recs.raw, e->recs.p, 0.f};
   bool ok = probe(cand[0].p, &cand[0].ms);
   nc = 1;
-  while (ok && nc < TAD_PLACEMENT_CANDIDATES) {
+  while (ok && nc < TAD_PLACEMENT_CANDIDATES && (size_t)(nc + 1) * e->recs.cap <= kPlacementBytes) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < e->recs.cap + ((size_t)2 << 30)) break;
     void *q = nullptr;
@@ -202,9 +204,12 @@ int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d
     cand[nc] = Cand{q, q, 0.f};
     ok = probe(q, &cand[nc].ms);
     ++nc;
-    float lo = cand[0].ms, hi = cand[0].ms;
-    for (int i = 1; i < nc; ++i) { lo = cand[i].ms < lo ? cand[i].ms : lo; hi = cand[i].ms > hi ? cand[i].ms : hi; }
-    if (ok && lo <= 0.96f * hi) break;      // both kinds of placement seen: the fast one is what we were looking for
+    // both kinds of placement seen (a candidate 4 % faster than the slowest) AND the newest one no better than the best before it: the
+    // allocations have left the slow stretch (a candidate that straddles its end probes in between and runs the job slow)
+    float lo_prev = cand[0].ms, hi = cand[0].ms;
+    for (int i = 1; i < nc - 1; ++i) lo_prev = cand[i].ms < lo_prev ? cand[i].ms : lo_prev;
+    for (int i = 1; i < nc; ++i) hi = cand[i].ms > hi ? cand[i].ms : hi;
+    if (ok && nc >= 3 && lo_prev <= 0.96f * hi && cand[nc - 1].ms >= 0.99f * lo_prev) break;
   }
   int best = 0;
   if (ok)
