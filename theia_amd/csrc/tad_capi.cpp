@@ -196,7 +196,9 @@ int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d
   cand[0] = Cand{e->recs.raw, e->recs.p, 0.f};
   bool ok = probe(cand[0].p, &cand[0].ms);
   nc = 1;
-  while (ok && nc < TAD_PLACEMENT_CANDIDATES && (size_t)(nc + 1) * e->recs.cap <= kPlacementBytes) {
+  // (the candidates are transient, but they are the engine's memory: together they stay within half the workspace limit)
+  const size_t budget = kPlacementBytes < e->ws_limit / 2 ? kPlacementBytes : (size_t)(e->ws_limit / 2);
+  while (ok && nc < TAD_PLACEMENT_CANDIDATES && (size_t)(nc + 1) * e->recs.cap <= budget) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < e->recs.cap + ((size_t)2 << 30)) break;
     void *q = nullptr;
