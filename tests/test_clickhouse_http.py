@@ -339,3 +339,52 @@ def test_query_columns_encodes_string_columns_on_the_gpu_like_arrow_does(engine,
             assert (gpu[name].codes == host[name].codes).all(), name
             assert gpu[name].values.tolist() == host[name].values.tolist(), name
         assert (gpu["n"] == host["n"]).all()
+
+
+class _EncodeStandIn:
+    """Test double for TadEngine.encode_strings (the GPU entry point is covered by the `-m gpu` test above): same contract — codes in order of
+    first appearance, the first rows — computed with Arrow, so that the CHUNKING of query_columns(engine=...) is covered on the CPU tier."""
+
+    def __init__(self):
+        self.calls = []
+
+    def encode_strings(self, arr):
+        d = pc.dictionary_encode(arr.fill_null(""))
+        codes = d.indices.to_numpy(zero_copy_only=False).astype(np.int64)
+        first = np.full(len(d.dictionary), -1, np.int64)
+        for i in range(codes.size - 1, -1, -1):
+            first[codes[i]] = i
+        self.calls.append(len(arr))
+        return codes, first.astype(np.uint64)
+
+
+import pyarrow.compute as pc  # noqa: E402
+
+
+@pytest.mark.parametrize("chunk", [1 << 30, 4000, 1])
+def test_query_columns_chunks_the_string_columns_for_the_engine(server, monkeypatch, chunk):
+    """Record batches wait until a chunk's worth of column bytes is there, a chunk is one encode call, its codes are mapped into the column's
+    unified dictionary (no gather for a column's first chunk), and the result equals the host path's — codes, values, order."""
+    rng = np.random.default_rng(5)
+    tabs = []
+    for b in range(4):
+        n = 300 + 50 * b
+        tabs.append(pa.table({"p": pa.array(np.char.add("pod-", rng.integers(0, 12 + 9 * b, n).astype(str)).tolist(), pa.string()),
+                              "l": pa.array([None if i % 31 == 0 else "lab%d" % (i % 5) for i in range(n)], pa.string()),
+                              "n": pa.array(rng.integers(0, 60000, n), pa.uint16())}))
+    server.responses["SELECT p, l, n FROM x"] = pa.concat_tables(tabs)
+    client = ch.ClickHouseHTTP(server.url, user="", password="")
+    host = client.query_columns("SELECT p, l, n FROM x", dict_strings=True)
+    monkeypatch.setattr(ch, "STRING_CHUNK_BYTES", chunk)
+    eng = _EncodeStandIn()
+    got = client.query_columns("SELECT p, l, n FROM x", dict_strings=True, engine=eng)
+    for name in ("p", "l"):
+        assert (got[name].codes == host[name].codes).all() and got[name].values.tolist() == host[name].values.tolist(), name
+    assert (got["n"] == host["n"]).all()
+    rows = sum(len(t) for t in tabs)
+    assert sum(eng.calls) == 2 * rows                                     # every row of both string columns went through the engine once
+    assert len(eng.calls) == (2 if chunk == 1 << 30 else 2 * len(tabs) if chunk == 1 else len(eng.calls))
+    # without dict_strings the engine is not consulted
+    eng2 = _EncodeStandIn()
+    plain = client.query_columns("SELECT p, l, n FROM x", engine=eng2)
+    assert eng2.calls == [] and plain["p"].tolist() == host["p"].materialise().tolist()
