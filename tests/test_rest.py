@@ -245,3 +245,31 @@ def test_e2e_retrieve_on_the_engine(engine, golden, algo, agg_type):
         if c is not None:
             c.shutdown()
         server.close()
+
+
+def test_go_format_float_round_trips_and_switches_form_where_strconv_does():
+    """Properties of strconv.FormatFloat(v, 'g', -1, 64) on random doubles: the text parses back to the same bits (shortest digits), the %e form is
+    used exactly when the decimal exponent is < -4 or >= 6, its exponent has a sign and at least two digits, and there is never a trailing '.' or
+    a superfluous zero in the mantissa."""
+    import struct
+    rng = np.random.default_rng(7)
+    raw = rng.integers(0, 1 << 63, size=20000, dtype=np.uint64)
+    vals = [struct.unpack("<d", struct.pack("<Q", int(r)))[0] for r in raw]
+    vals += [float(x) for x in rng.integers(0, 1 << 40, size=2000)] + [x / 8 for x in range(-50, 50)] + [10.0 ** k for k in range(-12, 25)]
+    for v in vals:
+        if v != v or v in (float("inf"), float("-inf")):
+            continue
+        s = rest.go_format_float(v)
+        assert float(s) == v, (v, s)
+        if v == 0:
+            continue
+        from decimal import Decimal
+        x = Decimal(repr(v)).adjusted()      # decimal exponent of the leading digit
+        if "e" in s:
+            mant, ex = s.split("e")
+            assert x < -4 or x >= 6, (v, s)
+            assert ex[0] in "+-" and len(ex) >= 3 and int(ex) == x, (v, s)
+        else:
+            mant = s
+            assert -4 <= x < 6, (v, s)
+        assert not mant.endswith(".") and not (("." in mant) and mant.endswith("0")), (v, s)
