@@ -186,6 +186,11 @@ def test_retrieve_table_per_aggregation_type_and_the_sentinel():
     assert rest.retrieve_table([S(id="j", aggType="svc")])[0][1] == "destinationServicePortName"
     out = rest.table_output(t)
     assert [ln.split() for ln in out.splitlines()] == t
+    # --file: Go's json.MarshalIndent(stats, "", " ")
+    js = rest.retrieve_json([S(id="j", aggType="svc", destinationServicePortName="ns/svc:http", flowEndSeconds="2022-08-11T07:26:54Z", throughput="5e+09",
+                               algoType="EWMA", algoCalc="2.5e+09", anomaly="true")])
+    assert js == ('[\n {\n  "id": "j",\n  "destinationServicePortName": "ns/svc:http",\n  "FlowEndSeconds": "2022-08-11T07:26:54Z",\n  "throughput": "5e+09",\n'
+                  '  "aggType": "svc",\n  "algoType": "EWMA",\n  "AlgoCalc": "2.5e+09",\n  "anomaly": "true"\n }\n]')
 
 
 # ---- the e2e retrieve test (throughputanomalydetection_test.go:191-300) on the engine's rows ----

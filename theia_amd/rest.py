@@ -322,6 +322,13 @@ def retrieve_table(stats):
     return [list(cols)] + [[getattr(s, c) for c in cols] for s in stats]
 
 
+def retrieve_json(stats):
+    """What `theia throughput-anomaly-detection retrieve --file` writes (anomaly_detection_retrieve.go:100-105): json.MarshalIndent(tad.Stats, "", " ") —
+    a one-space indent, fields in struct order, empty ones omitted."""
+    import json
+    return json.dumps([s.to_json() for s in stats], indent=1, separators=(",", ": "), ensure_ascii=False)
+
+
 def table_output(table):
     """TableOutput (pkg/theia/commands/utils.go): columns padded with a tabwriter; enough for a consumer that splits on white space
     (throughputanomalydetection_test.go:276-283 does `strings.Fields`)."""
