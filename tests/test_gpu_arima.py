@@ -11,6 +11,7 @@ TOL = 1e-6   # BASELINE.json north_star: "EWMA/ARIMA scores within 1e-6 relative
 import numpy as np
 import pytest
 
+import arima_gap
 from oracle import arima_oracle as ao
 from oracle import tad_oracle as orc
 
@@ -49,7 +50,8 @@ def test_series_arima_golden_series(engine, golden):
     assert verdict.tolist() == golden["expected_anomaly_list_arima"]
     five = [int(str(float(v))[:5]) for v in got]
     hits = sum(a == b for a, b in zip(five, golden["expected_arima_row_list"]))
-    assert hits >= 80, hits                      # measured 81 / 90, the CPU gate of tests/test_oracle_arima.py (the reference's own two lists agree at 78 / 90)
+    assert hits == 81, hits                      # (the reference's own two lists agree at 78 / 90)
+    arima_gap.check(got, golden, "GPU")          # the same nine misses with the same bits as the CPU gate (tests/arima_gap.py)
     # reported, not gated: distance to the reference's unasserted full-precision list (:288-318)
     full = np.array(golden["expanded_arima_row_list"])
     rel = rel_err(got, full)
