@@ -1,0 +1,130 @@
+// Measurement aid (not part of the library): WHY does pass B of the same job run 0.60 ms on some allocations of its record buffer and 0.67 ms
+// on others of the same process (tad_capi.cpp:place_recs, profiles/r4_v37_record_buffer_placement.log)?
+//
+// A stand-alone process (no Python: starts in a second) that allocates the three columns of a C2-sized table and then NC candidate record
+// buffers, all held at once (as place_recs does), and times on every candidate
+//   pm    pass B's memory pattern as the engine lays it out — PARTITION-major: region (workgroup w, partition p) at p * R + w * r
+//   wm    the same lines in a WORKGROUP-major layout: region (w, p) at w * (nparts * r) + p * r — a workgroup's open lines lie within a few MB
+//   seq   the same reads, one contiguous 8-byte-per-row write stream per workgroup (no scatter at all)
+//   chase a single wavefront's dependent loads across the candidate at strides of 4 KB / 64 KB / 2 MB (TLB reach: ns per access)
+// Every launch is its own dispatch, in a fixed order that the program prints, so that `rocprofv3 --kernel-trace --pmc <counters>` of the very
+// same command lines its counters up with the times:   tools/gpu_placement_r5.sh
+//   hipcc -O3 --offload-arch=gfx950 -o tools/probes/placement_probe tools/probes/placement_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+static constexpr int kThreads = 1024;
+
+__global__ __launch_bounds__(kThreads) void k_fill(ulonglong2 *p, uint64_t n2, uint64_t seed) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * kThreads)
+    p[i] = make_ulonglong2(i * 0x9E3779B97F4A7C15ull + seed, (i + 1) * 0xBF58476D1CE4E5B9ull ^ seed);
+}
+
+// MODE 0: partition-major, 1: workgroup-major, 2: sequential.  n2 = row pairs; 8 lanes (16 rows) fill one 128-byte line
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_pattern(const ulonglong2 *__restrict__ key, const ulonglong2 *__restrict__ te,
+                                                      const ulonglong2 *__restrict__ val, uint64_t n2, unsigned long long *__restrict__ recs,
+                                                      uint64_t slots, uint32_t nparts) {
+  const uint64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
+  const uint64_t region_slots = (slots / nparts) & ~15ull;              // R: a partition's slots
+  const uint64_t share = region_slots / gridDim.x & ~15ull;             // r: this workgroup's slots inside every partition
+  if (share < 16) return;
+  const uint32_t lane8 = threadIdx.x & 7u, grp = threadIdx.x >> 3;
+  for (uint64_t i = lo + threadIdx.x, it = 0; i < hi; i += kThreads, ++it) {
+    const ulonglong2 k = key[i], t = te[i], v = val[i];
+    const uint64_t g = it * (kThreads / 8) + grp;                       // the workgroup's g-th line
+    const uint32_t part = (uint32_t)(g % nparts);
+    const uint64_t line = (g / nparts) % (share / 16);
+    unsigned long long *dst;
+    if (MODE == 0) dst = recs + (uint64_t)part * region_slots + (uint64_t)blockIdx.x * share + line * 16 + lane8 * 2;
+    else if (MODE == 1) dst = recs + ((uint64_t)blockIdx.x * nparts + part) * share + line * 16 + lane8 * 2;
+    else dst = recs + (uint64_t)blockIdx.x * (slots / gridDim.x & ~15ull) + (g % ((slots / gridDim.x & ~15ull) / 16)) * 16 + lane8 * 2;
+    reinterpret_cast<ulonglong2 *>(dst)[0] = make_ulonglong2(k.x ^ t.x ^ v.x, k.y ^ t.y ^ v.y);
+  }
+}
+
+// one wavefront, lane 0: `count` dependent 8-byte loads, `stride` bytes apart, wrapping inside `bytes`
+__global__ __launch_bounds__(64) void k_chase(const unsigned long long *__restrict__ p, uint64_t bytes, uint64_t stride, uint32_t count,
+                                              unsigned long long *out) {
+  if (threadIdx.x != 0) return;
+  uint64_t off = 0, acc = 0;
+  const unsigned long long t0 = wall_clock64();
+  for (uint32_t i = 0; i < count; ++i) {
+    const unsigned long long v = __builtin_nontemporal_load(p + off / 8);
+    acc += v;
+    off = (off + stride + (v & 8ull)) % bytes;        // the next address depends on the loaded value
+  }
+  const unsigned long long t1 = wall_clock64();
+  out[0] = t1 - t0;
+  out[1] = acc;
+}
+
+int main(int argc, char **argv) {
+  const uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 100000000ull;
+  const uint32_t nparts = argc > 2 ? (uint32_t)atoi(argv[2]) : 782;
+  const int nc = argc > 3 ? atoi(argv[3]) : 12;
+  const uint64_t slots = argc > 4 ? strtoull(argv[4], nullptr, 10) : 240000000ull;      // C2's sampled-region buffer: ~2.4x the records
+  const int reps = argc > 5 ? atoi(argv[5]) : 3;
+  const int G = 256;
+  CK(hipSetDevice(0));
+  hipStream_t s;
+  CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  ulonglong2 *col[3];
+  for (int c = 0; c < 3; ++c) {
+    CK(hipMalloc(&col[c], n * 8));
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(kThreads), 0, s, col[c], n / 2, (uint64_t)(c + 1) * 0x1234567ull);
+  }
+  std::vector<unsigned long long *> cand(nc);
+  for (int i = 0; i < nc; ++i) {
+    CK(hipMalloc(&cand[i], slots * 8));
+    CK(hipMemsetAsync(cand[i], 0, slots * 8, s));
+  }
+  unsigned long long *d_out, h_out[2];
+  CK(hipMalloc(&d_out, 16));
+  CK(hipStreamSynchronize(s));
+  size_t free_b = 0, total_b = 0;
+  CK(hipMemGetInfo(&free_b, &total_b));
+  printf("placement_probe: %llu rows, %u partitions, %d candidates of %.2f GB held together; free %.1f of %.1f GB\n", (unsigned long long)n, nparts, nc,
+         slots * 8 / 1e9, free_b / 1e9, total_b / 1e9);
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  auto timed = [&](auto launch) {
+    launch();   // warm
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+      CK(hipEventRecord(a, s));
+      launch();
+      CK(hipEventRecord(b, s));
+      CK(hipEventSynchronize(b));
+      float t = 0; CK(hipEventElapsedTime(&t, a, b));
+      best = t < best ? t : best;
+    }
+    return best;
+  };
+  printf("dispatch order per candidate: (1 + %d) x k_pattern<0>, (1 + %d) x k_pattern<1>, (1 + %d) x k_pattern<2>, 3 x k_chase (4 KB, 64 KB, 2 MB)\n", reps, reps, reps);
+  printf("%-4s %-18s %9s %9s %9s | chase ns/access: %8s %8s %8s\n", "cand", "address", "pm ms", "wm ms", "seq ms", "4KB", "64KB", "2MB");
+  for (int i = 0; i < nc; ++i) {
+    float ms[3];
+    ms[0] = timed([&] { hipLaunchKernelGGL(k_pattern<0>, dim3(G), dim3(kThreads), 0, s, col[0], col[1], col[2], n / 2, cand[i], slots, nparts); });
+    ms[1] = timed([&] { hipLaunchKernelGGL(k_pattern<1>, dim3(G), dim3(kThreads), 0, s, col[0], col[1], col[2], n / 2, cand[i], slots, nparts); });
+    ms[2] = timed([&] { hipLaunchKernelGGL(k_pattern<2>, dim3(G), dim3(kThreads), 0, s, col[0], col[1], col[2], n / 2, cand[i], slots, nparts); });
+    double ns[3];
+    const uint64_t strides[3] = {4096, 65536, 2097152};
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t count = 2048;
+      hipLaunchKernelGGL(k_chase, dim3(1), dim3(64), 0, s, cand[i], slots * 8, strides[k] + 64, count, d_out);
+      CK(hipMemcpyAsync(h_out, d_out, 16, hipMemcpyDeviceToHost, s));
+      CK(hipStreamSynchronize(s));
+      ns[k] = (double)h_out[0] * 10.0 / count;      // wall_clock64: the constant 100 MHz counter
+    }
+    printf("%-4d %-18p %9.4f %9.4f %9.4f | %26.0f %8.0f %8.0f\n", i, (void *)cand[i], ms[0], ms[1], ms[2], ns[0], ns[1], ns[2]);
+    fflush(stdout);
+  }
+  return 0;
+}
