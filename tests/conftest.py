@@ -41,6 +41,18 @@ def _gpu_present():
         return os.path.exists("/dev/kfd")
 
 
+def pytest_collection_modifyitems(config, items):
+    """On a box WITHOUT a GPU every `gpu` test is skipped, whether it takes the `engine` fixture or builds its own engine / C driver
+    (round-4 advisor finding: three of them failed with 'no HIP device available' when the suite ran unfiltered on a CPU box).  On a GPU
+    box nothing is skipped here: a missing library or device stays a failure."""
+    if _gpu_present():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def engine():
     """The HIP engine through the C ABI.  On a GPU box a missing library/device is a FAILURE, never a skip."""

@@ -305,3 +305,95 @@ def test_a_progress_update_cannot_undo_a_completed_state():
         assert after.status.state == ctl.STATE_COMPLETED and after.status.endTime == done.status.endTime
     finally:
         c.shutdown()
+
+
+def test_start_job_for_a_deleted_key_starts_nothing_and_leaves_no_periodic_entry():
+    """round-4 advisor finding: `_jobs[id]` was set before the status named the application — a delete in that window found no id to
+    cancel, start_job then switched the periodic resync on for a dead key and ran the body.  Now: one critical section, and a key
+    that has left the store starts nothing."""
+    ran = []
+    c = ctl.AnomalyDetectorController(run_job=lambda a, t: ran.append(t.name))
+    try:
+        t = tad(jobType="EWMA")
+        key = (NS, t.name)
+        c.start_job(key, t)                                   # never created (= created and deleted before its first sync ran)
+        threading.Event().wait(0.1)
+        assert ran == [] and key not in c._periodic and c._jobs == {} and c._alive == {}
+    finally:
+        c.shutdown()
+
+
+def test_a_resource_recreated_under_the_same_name_waits_for_the_old_body_and_keeps_its_rows():
+    """delete + create of the same name while the old body still runs: the new run has its own token (no inherited tombstone) and
+    does not start before the old body — whose cleanup statement deletes by id — has returned."""
+    release, commands, wrote, bodies = threading.Event(), [], [], []
+
+    class FakeCH:
+        def command(self, sql):
+            commands.append((sql, len(wrote)))
+
+    c = ctl.AnomalyDetectorController(clickhouse=FakeCH())
+
+    def job(args, t):
+        bodies.append(len(bodies))
+        me = bodies[-1]
+        if me == 0:
+            release.wait(10)
+        if c._is_cancelled(t.name[4:]):
+            raise ctl.JobCancelled(t.name[4:])
+        wrote.append(me)
+
+    c._run_job = job
+    try:
+        t = tad(jobType="EWMA", aggFlow="svc")
+        c.create(t)
+        for _ in range(500):
+            if bodies:
+                break
+            threading.Event().wait(0.01)
+        c.delete(NS, t.name)
+        c.create(tad(name=t.name, jobType="EWMA", aggFlow="svc"))    # same name, while body 0 is still blocked
+        threading.Event().wait(0.3)
+        assert bodies == [0] and wrote == []                  # the new run has not started
+        release.set()
+        done = c.wait(NS, t.name, timeout=10)
+        assert done.status.state == ctl.STATE_COMPLETED
+        assert bodies == [0, 1] and wrote == [1]              # body 0 was cancelled, body 1 wrote
+        # both cleanup statements (the delete's and the cancelled body's) were issued BEFORE the new run wrote anything
+        assert [n for _, n in commands] == [0, 0] and all(sql == ctl.cleanup_query(t.name[4:]) for sql, _ in commands)
+        assert not c._is_cancelled(t.name[4:]) and c._alive == {}
+    finally:
+        c.shutdown()
+
+
+def test_a_failing_sync_is_retried_with_exponential_backoff_and_forgotten_on_success():
+    """The reference's queue is workqueue.NewItemExponentialFailureRateLimiter(MinRetryDelay, MaxRetryDelay) (controller.go:95,
+    util.go:40-41: 5 s, 300 s); round 4 retried every 50 ms forever."""
+    assert (ctl.MIN_RETRY_DELAY, ctl.MAX_RETRY_DELAY) == (5.0, 300.0)
+    import time
+    c = ctl.AnomalyDetectorController(run_job=lambda a, t: None, retry_min_delay=0.02, retry_max_delay=0.16)
+    calls, fail = [], [True]
+    real_sync = c.sync
+
+    def sync(key):
+        calls.append(time.monotonic())
+        if fail[0]:
+            raise RuntimeError("engine unavailable")
+        return real_sync(key)
+
+    c.sync = sync
+    try:
+        t = tad(jobType="EWMA")
+        c.create(t)
+        threading.Event().wait(0.75)
+        n = len(calls)
+        gaps = [b - a for a, b in zip(calls, calls[1:])]
+        # 0.02, 0.04, 0.08, 0.16, 0.16, ...: about eight attempts in 0.75 s, where the fixed 50 ms retry made fifteen
+        assert 5 <= n <= 10, n
+        assert gaps[0] >= 0.015 and gaps[2] >= 0.06 and max(gaps) < 0.5, gaps
+        assert all(g >= 0.12 for g in gaps[3:]), gaps
+        fail[0] = False
+        assert c.wait(NS, t.name, timeout=10).status.state == ctl.STATE_COMPLETED
+        assert c._failures == {}                              # Forget
+    finally:
+        c.shutdown()

@@ -70,3 +70,19 @@ def test_the_go_plan_mirrors_tad_plan_field_for_field():
 def test_abi_version_is_checked_before_an_engine_is_created():
     body = GO[GO.index("func NewEngineWithPlan"):]
     assert body.index("C.tad_abi_version()") < body.index("C.tad_engine_create(")
+
+
+def test_go_pointers_stored_in_c_structs_are_pinned():
+    """cgo pointer rules (round-4 advisor finding): a Go struct passed to C may only hold Go pointers to PINNED memory.  Every
+    `<struct var>.<field> = ...unsafe.Pointer(&slice[0])` store must be preceded, in the same function, by `pin.Pin(&slice[0])`;
+    pointers handed over as plain call arguments need nothing."""
+    funcs = re.split(r"\nfunc ", GO)
+    stores = 0
+    for f in funcs:
+        for var, field, sl in re.findall(r"\b(\w+)\.(\w+) = (?:\(\*C\.\w+\)\()?unsafe\.Pointer\(&(\w+)\[0\]\)", f):
+            stores += 1
+            pin = f.find("pin.Pin(&%s[0])" % sl)
+            store = f.find("%s.%s = " % (var, field))
+            assert 0 <= pin < store, (var, field, sl)
+            assert "var pin runtime.Pinner" in f and "defer pin.Unpin()" in f
+    assert stores >= 3          # EncodeStrings: offsets, data, validity

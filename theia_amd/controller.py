@@ -167,6 +167,9 @@ def cleanup_query(job_id):
     return "ALTER TABLE tadetector ON CLUSTER '{cluster}' DELETE WHERE id = ('" + job_id + "');"
 
 
+MIN_RETRY_DELAY, MAX_RETRY_DELAY = 5.0, 300.0      # seconds: controllerutil.MinRetryDelay / MaxRetryDelay (pkg/controller/util.go:40-41)
+
+
 class JobCancelled(Exception):
     """The resource was deleted while its job was running (DeleteSparkApplication, controller.go:387): nothing is written."""
 
@@ -197,16 +200,22 @@ class AnomalyDetectorController:
     `clickhouse`); `progress()` returns (completed, total) stages of the job that is running (default: engine.progress)."""
 
     def __init__(self, clickhouse=None, engine=None, run_job: Optional[Callable] = None, progress: Optional[Callable] = None,
-                 workers=DEFAULT_WORKERS, resync_period=0.05, pushdown=False):
+                 workers=DEFAULT_WORKERS, resync_period=0.05, pushdown=False, retry_min_delay=MIN_RETRY_DELAY, retry_max_delay=MAX_RETRY_DELAY):
         self.clickhouse = clickhouse
         self.engine = engine
         self._run_job = run_job or (lambda args, tad: run_engine_job(args, self.clickhouse, self.engine, pushdown,
                                                                       cancelled=lambda: self._is_cancelled(tad.name[4:])))
+        self._tls = threading.local()             # .run = the run token of the job body this pool thread is executing
         self._progress = progress or (lambda: self.engine.progress() if self.engine is not None else (0, 0))
         self._lock = threading.Lock()
         self._store: Dict[tuple, ThroughputAnomalyDetector] = {}
-        self._jobs: Dict[str, dict] = {}          # job id -> {"state": RUNNING|COMPLETED|FAILED, "error": str} (the SparkApplication's status)
-        self._cancelled: set = set()              # ids of jobs whose resource was deleted while they ran (tombstones, dropped when the job ends)
+        # job id -> the RUN TOKEN of its application: {"id", "state": SUBMITTED|RUNNING|COMPLETED|FAILED, "error", "cancelled"}.  The
+        # tombstone of a resource deleted while its body runs is the token's own "cancelled" flag — per run, not per id: a resource
+        # re-created under the same name gets a new token, so it neither inherits the old tombstone nor has its rows removed by the
+        # old body's cleanup (round-4 advisor finding)
+        self._jobs: Dict[str, dict] = {}
+        self._alive: Dict[str, list] = {}         # job id -> tokens whose body has been submitted and has not returned yet
+        self._failures: Dict[tuple, int] = {}     # key -> consecutive failed syncs (the rate limiter's per-item count; Forget = pop)
         self._queue: "queue.Queue" = queue.Queue()
         self._queued: set = set()                 # keys waiting in the queue (the workqueue's dedup, controller.go:150-160)
         self._active: set = set()                 # keys a worker is processing: one key is never synced by two workers at once
@@ -214,6 +223,7 @@ class AnomalyDetectorController:
         self._periodic: Dict[tuple, bool] = {}
         self._stop = threading.Event()
         self._resync = resync_period
+        self._retry_min, self._retry_max = retry_min_delay, retry_max_delay
         self._last_error = None
         # job bodies run on a bounded pool: `workers` concurrent ClickHouse reads / engine jobs at most (controller.go:199-201's
         # defaultWorkers bound what the reference starts at once; Spark bounded the rest)
@@ -249,9 +259,10 @@ class AnomalyDetectorController:
             tad = self._store.pop((namespace, name))
             self._periodic.pop((namespace, name), None)
             job_id = tad.status.sparkApplication
+            self._failures.pop((namespace, name), None)
             job = self._jobs.get(job_id) if job_id else None
             if job is not None and job["state"] in ("SUBMITTED", "RUNNING"):
-                self._cancelled.add(job_id)          # _execute re-issues the cleanup when the body returns
+                job["cancelled"] = True              # _execute re-issues the cleanup when the body returns
         if job_id:
             self.cleanup(namespace, job_id)
 
@@ -295,8 +306,13 @@ class AnomalyDetectorController:
         return errors
 
     def _is_cancelled(self, job_id):
+        """Asked by a job body right before it writes: has THIS run's resource been deleted?  (From any other thread: is a cancelled
+        body of that id still running?)"""
+        run = getattr(self._tls, "run", None)
         with self._lock:
-            return job_id in self._cancelled
+            if run is not None and run["id"] == job_id:
+                return run["cancelled"]
+            return any(r["cancelled"] for r in self._alive.get(job_id, ()))
 
     def shutdown(self):
         self._stop.set()
@@ -332,11 +348,21 @@ class AnomalyDetectorController:
                 failed = True
             with self._lock:
                 self._active.discard(key)
-                again = key in self._dirty or (failed and key in self._store)
+                dirty = key in self._dirty
                 self._dirty.discard(key)
-            if again:
-                if failed:
-                    time.sleep(min(self._resync, 0.05))
+                retry = failed and key in self._store
+                if retry:
+                    self._failures[key] = n_failed = self._failures.get(key, 0) + 1
+                else:
+                    self._failures.pop(key, None)            # Forget (controller.go:339)
+            if retry:
+                # AddRateLimited: ItemExponentialFailureRateLimiter(MinRetryDelay, MaxRetryDelay) (controller.go:95, util.go:40-41) —
+                # base * 2^(failures - 1), capped; a timer re-adds the key, no worker sleeps on it
+                delay = min(self._retry_min * 2 ** min(n_failed - 1, 30), self._retry_max)
+                t = threading.Timer(delay, self._enqueue, args=(key,))
+                t.daemon = True
+                t.start()
+            elif dirty:
                 self._enqueue(key)
 
     def _resync_loop(self):
@@ -382,30 +408,50 @@ class AnomalyDetectorController:
             self._update_status(key, state=STATE_FAILED, errorMsg="error in creating AnomalyDetector: %s" % exc)
             return
         job_id = tad.name[4:]
+        run = {"id": job_id, "state": "SUBMITTED", "error": "", "cancelled": False}
+        # ONE critical section: the application exists, the status names it and the periodic resync is on — or none of it.  A delete
+        # can only come before (the key has left the store: nothing is started, no periodic entry for a dead key) or after (it finds
+        # the id in the status, sets the token's tombstone and cleans up).
         with self._lock:
-            self._jobs[job_id] = {"state": "SUBMITTED", "error": ""}
-        # the status names the application before its body can run: a delete in between must find the id to stop and clean up
-        self._update_status(key, state=STATE_SCHEDULED, sparkApplication=job_id, startTime=datetime.now(timezone.utc))
-        with self._lock:
-            self._periodic[key] = True               # addPeriodicSync
-        self._pool.submit(self._execute, job_id, args, tad)
-
-    def _execute(self, job_id, args, tad):
-        with self._lock:
-            if job_id not in self._jobs:             # deleted while it waited for a pool slot: never started
-                self._cancelled.discard(job_id)
+            cur = self._store.get(key)
+            if cur is None:
                 return
-            self._jobs[job_id]["state"] = "RUNNING"
-        try:
-            self._run_job(args, tad)
-            outcome = ("COMPLETED", "")
-        except Exception as exc:                     # TadError, ClickHouse errors, ...: the application failed
-            outcome = ("FAILED", str(exc))
+            if self._alive.get(job_id):
+                # the body of a deleted resource of the same name is still running: one body per id at a time — its cleanup
+                # statement (DELETE WHERE id) must not meet this run's rows.  The resync tick brings the key back.
+                self._periodic[key] = True
+                return
+            self._jobs[job_id] = run
+            self._alive.setdefault(job_id, []).append(run)
+            cur.status.state, cur.status.sparkApplication, cur.status.startTime = STATE_SCHEDULED, job_id, datetime.now(timezone.utc)
+            self._periodic[key] = True               # addPeriodicSync
+        self._pool.submit(self._execute, run, args, tad)
+
+    def _execute(self, run, args, tad):
+        job_id = run["id"]
         with self._lock:
-            if job_id in self._jobs:
-                self._jobs[job_id]["state"], self._jobs[job_id]["error"] = outcome
-            deleted = job_id in self._cancelled
-            self._cancelled.discard(job_id)
+            started = not run["cancelled"]           # deleted while it waited for a pool slot: never started
+            if started:
+                run["state"] = "RUNNING"
+        outcome = None
+        if started:
+            self._tls.run = run
+            try:
+                self._run_job(args, tad)
+                outcome = ("COMPLETED", "")
+            except Exception as exc:                 # TadError, ClickHouse errors, ...: the application failed
+                outcome = ("FAILED", str(exc))
+            finally:
+                self._tls.run = None
+        with self._lock:
+            if outcome is not None:
+                run["state"], run["error"] = outcome
+            deleted = started and run["cancelled"]
+            alive = self._alive.get(job_id, [])
+            if run in alive:
+                alive.remove(run)
+            if not alive:
+                self._alive.pop(job_id, None)
         if deleted and self.clickhouse is not None:
             # the resource went away while the body ran: whatever it managed to write before noticing is removed again
             try:

@@ -10,28 +10,15 @@ in the consumer's own format: the strings Go's database/sql produces when it sca
 integers in base 10, float64 through strconv.FormatFloat(v, 'g', -1, 64) — 4005703059 reads "4.005703059e+09", which is where the five-character
 prefixes of the reference's e2e result map come from, test/e2e/throughputanomalydetection_test.go:191-221 — and DateTime as RFC 3339).
 
-Go is not in this image: like theia_amd/controller.py this is the Python statement of host logic a Go host keeps unchanged; the verbs
-take the controller of theia_amd/controller.py where the reference takes its ThroughputAnomalyDetectorQuerier.
+Scope (round 5): ONLY `get_tad_result` and the Go string forms it needs — they pin the throughput prefixes of the reference's e2e result
+map on rows the engine wrote.  The REST verbs (Create / Delete / List), the API type and the CLI's `retrieve` table / `--file` JSON that round 4
+also restated are SURVEY.md section 2 #6 / #7, OUT OF SCOPE, and were removed again.
 """
-import copy
 import math
-from dataclasses import dataclass, field, fields
+from dataclasses import dataclass
 from datetime import datetime, timezone
-from typing import List
 
 import numpy as np
-
-from .controller import STATE_COMPLETED, ThroughputAnomalyDetector
-
-DEFAULT_NAMESPACE = "flow-visibility"      # rest.go:38 defaultNameSpace
-
-# json names of pkg/apis/intelligence/v1alpha1/types.go:108-126 (the capitalised ones are the reference's)
-_STATS_JSON = {"id": "id", "sourceIP": "sourceIP", "sourceTransportPort": "sourceTransportPort", "destinationIP": "destinationIP",
-               "destinationTransportPort": "destinationTransportPort", "flowStartSeconds": "FlowStartSeconds", "podNamespace": "podNamespace",
-               "podLabels": "podLabels", "podName": "podName", "direction": "direction",
-               "destinationServicePortName": "destinationServicePortName", "flowEndSeconds": "FlowEndSeconds", "throughput": "throughput",
-               "aggType": "aggType", "algoType": "algoType", "algoCalc": "AlgoCalc", "anomaly": "anomaly"}
-
 
 @dataclass
 class ThroughputAnomalyDetectorStats:
@@ -53,33 +40,6 @@ class ThroughputAnomalyDetectorStats:
     algoType: str = ""
     algoCalc: str = ""
     anomaly: str = ""
-
-    def to_json(self):
-        """`omitempty` on every field (types.go:109-125)."""
-        return {_STATS_JSON[f.name]: getattr(self, f.name) for f in fields(self) if getattr(self, f.name) != ""}
-
-
-@dataclass
-class ThroughputAnomalyDetectorResult:
-    """The API type the REST verbs return (pkg/apis/intelligence/v1alpha1/types.go:70-98): the spec fields flattened, the status, the stats."""
-    name: str = ""
-    type: str = ""
-    startInterval: object = None
-    endInterval: object = None
-    executorInstances: int = 0
-    nsIgnoreList: List[str] = field(default_factory=list)
-    aggFlow: str = ""
-    podLabel: str = ""
-    podName: str = ""
-    podNameSpace: str = ""
-    externalIp: str = ""
-    servicePortName: str = ""
-    driverCoreRequest: str = ""
-    driverMemory: str = ""
-    executorCoreRequest: str = ""
-    executorMemory: str = ""
-    status: object = None
-    stats: List[ThroughputAnomalyDetectorStats] = field(default_factory=list)
 
 
 # The five SELECTs of rest.go:59-123 (queryMap), column for column.  The reference binds the id with database/sql's `?`; the HTTP
@@ -203,138 +163,3 @@ def get_tad_result(client, job_id, agg_flow="", pod_name=""):
             setattr(s, c, go_string(v))
         stats.append(s)
     return stats
-
-
-class BadRequest(ValueError):
-    """errors.NewBadRequest (rest.go:199, 222-226, 239, 319)."""
-
-
-class NotFound(KeyError):
-    """errors.NewNotFound (rest.go:137)."""
-
-
-class REST:
-    """rest.Storage of the ThroughputAnomalyDetector API (rest.go:41-57, 134-247, 317-327) over the in-process controller."""
-
-    def __init__(self, controller, clickhouse=None, namespace=DEFAULT_NAMESPACE):
-        self.controller = controller
-        self.clickhouse = clickhouse if clickhouse is not None else controller.clickhouse
-        self.namespace = namespace
-
-    @staticmethod
-    def copy_tad(crd):
-        """copyThroughputAnomalyDetector (rest.go:155-181)."""
-        s = crd.spec
-        return ThroughputAnomalyDetectorResult(
-            name=crd.name, type=s.jobType, startInterval=s.startInterval, endInterval=s.endInterval, executorInstances=s.executorInstances,
-            nsIgnoreList=list(s.nsIgnoreList), aggFlow=s.aggFlow, podLabel=s.podLabel, podName=s.podName, podNameSpace=s.podNameSpace,
-            externalIp=s.externalIp, servicePortName=s.servicePortName, driverCoreRequest=s.driverCoreRequest, driverMemory=s.driverMemory,
-            executorCoreRequest=s.executorCoreRequest, executorMemory=s.executorMemory, status=copy.deepcopy(crd.status))
-
-    def _with_result(self, crd, wording):
-        tad = self.copy_tad(crd)
-        if crd.status.state == STATE_COMPLETED:        # "Try to retrieve result from ClickHouse in case TAD is completed"
-            try:
-                tad.stats = get_tad_result(self.clickhouse, crd.status.sparkApplication, tad.aggFlow, tad.podName)
-            except Exception as exc:
-                tad.status.errorMsg += wording % (crd.status.sparkApplication, exc)
-        return tad
-
-    def get(self, name):
-        """REST.Get (rest.go:134-149)."""
-        try:
-            crd = self.controller.get(self.namespace, name)
-        except KeyError:
-            raise NotFound('throughputanomalydetectors "%s" not found' % name)
-        tad = self.copy_tad(crd)
-        if crd.status.state == STATE_COMPLETED:
-            try:
-                tad.stats = get_tad_result(self.clickhouse, crd.status.sparkApplication, tad.aggFlow, tad.podName)
-            except Exception as exc:                   # Get overwrites the message (rest.go:144), List appends (rest.go:202)
-                tad.status.errorMsg = "Failed to get the result for completed Throughput Anomaly Detector with id %s, error: %s" % (
-                    crd.status.sparkApplication, exc)
-        return tad
-
-    def list(self):
-        """REST.List (rest.go:187-208)."""
-        return [self._with_result(crd, "Failed to get the result for Throughput Anomaly Detector with id %s, error: %s")
-                for crd in self.controller.list(self.namespace)]
-
-    def create(self, tad):
-        """REST.Create (rest.go:218-247): a ThroughputAnomalyDetectorResult (or a CRD object) becomes the custom resource."""
-        if not isinstance(tad, (ThroughputAnomalyDetectorResult, ThroughputAnomalyDetector)):
-            raise BadRequest("not a ThroughputAnomalyDetector object: %s" % type(tad).__name__)
-        try:
-            self.controller.get(self.namespace, tad.name)
-            exists = True
-        except KeyError:
-            exists = False
-        if exists:
-            raise BadRequest("ThroughputAnomalyDetection job exists, name: %s" % tad.name)
-        if isinstance(tad, ThroughputAnomalyDetector):
-            job = copy.deepcopy(tad)
-            job.namespace = self.namespace
-        else:
-            from .controller import ThroughputAnomalyDetectorSpec
-            job = ThroughputAnomalyDetector(name=tad.name, namespace=self.namespace, spec=ThroughputAnomalyDetectorSpec(
-                jobType=tad.type, startInterval=tad.startInterval, endInterval=tad.endInterval, nsIgnoreList=list(tad.nsIgnoreList),
-                aggFlow=tad.aggFlow, podLabel=tad.podLabel, podName=tad.podName, podNameSpace=tad.podNameSpace, externalIp=tad.externalIp,
-                servicePortName=tad.servicePortName, executorInstances=tad.executorInstances, driverCoreRequest=tad.driverCoreRequest,
-                driverMemory=tad.driverMemory, executorCoreRequest=tad.executorCoreRequest, executorMemory=tad.executorMemory))
-        try:
-            self.controller.create(job)
-        except Exception as exc:
-            raise BadRequest("error when creating ThroughputAnomalyDetection job: %r, err: %s" % (job, exc))
-        return {"status": "Success"}
-
-    def delete(self, name):
-        """REST.Delete (rest.go:317-327)."""
-        try:
-            self.controller.get(self.namespace, name)
-        except KeyError:
-            raise BadRequest("ThroughputAnomalyDetector job doesn't exist, name: %s" % name)
-        self.controller.delete(self.namespace, name)
-        return {"status": "Success"}
-
-
-NO_ANOMALY = "NO ANOMALY DETECTED"            # the sentinel row's `anomaly` (anomaly_detection.py:395-436)
-
-
-def retrieve_table(stats):
-    """What `theia throughput-anomaly-detection retrieve` prints (anomaly_detection_retrieve.go:94-137): a header and one line per
-    row for the aggregation type of the first row, or the sentinel's line.  Returns a list of rows (lists of strings) or a string."""
-    for s in stats:
-        if s.anomaly == NO_ANOMALY:
-            return "No Anomaly found in id: %s" % s.id
-    if not stats:
-        return []
-    agg = stats[0].aggType
-    if agg == "None":
-        cols = _COLUMNS["tad"]
-    elif agg == "pod":
-        cols = _COLUMNS["podName"] if stats[0].podName != "" else _COLUMNS["podLabel"]
-    elif agg == "external":
-        cols = _COLUMNS["external"]
-    elif agg == "svc":
-        cols = _COLUMNS["svc"]
-    else:
-        return []
-    return [list(cols)] + [[getattr(s, c) for c in cols] for s in stats]
-
-
-def retrieve_json(stats):
-    """What `theia throughput-anomaly-detection retrieve --file` writes (anomaly_detection_retrieve.go:100-105): json.MarshalIndent(tad.Stats, "", " ") —
-    a one-space indent, fields in struct order, empty ones omitted."""
-    import json
-    return json.dumps([s.to_json() for s in stats], indent=1, separators=(",", ": "), ensure_ascii=False)
-
-
-def table_output(table):
-    """TableOutput (pkg/theia/commands/utils.go): columns padded with a tabwriter; enough for a consumer that splits on white space
-    (throughputanomalydetection_test.go:276-283 does `strings.Fields`)."""
-    if isinstance(table, str):
-        return table + "\n"
-    if not table:
-        return ""
-    width = [max(len(r[i]) for r in table) for i in range(len(table[0]))]
-    return "".join("".join(c.ljust(w + 2) for c, w in zip(r, width)).rstrip() + "\n" for r in table)

@@ -24,7 +24,7 @@ for set in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTC
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_UTCL2_BUSY" \
            "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -o x -- $P 100000000 782 12 240000000 1 > $O/probe_pmc$i.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -o x -- $P 100000000 782 12 240000000 1 0 > $O/probe_pmc$i.log 2>&1
   grep -E "^[0-9]+ +0x" $O/probe_pmc$i.log | head -12
 done
 cd $R

@@ -49,6 +49,20 @@ __global__ __launch_bounds__(kThreads) void k_pattern(const ulonglong2 *__restri
   }
 }
 
+// write-only / read-only streams over a candidate (no column reads): is the class a property of the buffer alone?
+__global__ __launch_bounds__(kThreads) void k_wo(ulonglong2 *__restrict__ p, uint64_t n2) {
+  const uint64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += kThreads) p[i] = make_ulonglong2(i, ~i);
+}
+__global__ __launch_bounds__(kThreads) void k_ro(const ulonglong2 *__restrict__ p, uint64_t n2, unsigned long long *out) {
+  const uint64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
+  unsigned long long acc = 0;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += kThreads) { const ulonglong2 v = p[i]; acc += v.x ^ v.y; }
+  if (acc == 0x123456789abcdefull) out[0] = acc;
+}
+
 // one wavefront, lane 0: `count` dependent 8-byte loads, `stride` bytes apart, wrapping inside `bytes`
 __global__ __launch_bounds__(64) void k_chase(const unsigned long long *__restrict__ p, uint64_t bytes, uint64_t stride, uint32_t count,
                                               unsigned long long *out) {
@@ -124,6 +138,30 @@ int main(int argc, char **argv) {
       ns[k] = (double)h_out[0] * 10.0 / count;      // wall_clock64: the constant 100 MHz counter
     }
     printf("%-4d %-18p %9.4f %9.4f %9.4f | %26.0f %8.0f %8.0f\n", i, (void *)cand[i], ms[0], ms[1], ms[2], ns[0], ns[1], ns[2]);
+    fflush(stdout);
+  }
+  if (argc > 6 && atoi(argv[6]) == 0) return 0;      // (the counter passes stop here)
+  // ---- phase 2: what is the class a property of? ----
+  // (a) the buffer alone: write-only and read-only streams over the first 0.8 GB of every candidate;
+  // (b) the base inside the allocation: the partition-major pattern into the same candidate shifted by 256 KB ... 64 MB (slots shrink accordingly);
+  // (c) the pairing with the read streams: the pattern with candidate (i + 1) % nc standing in for the three columns (its first 2.4 GB ... 1.92: two thirds);
+  // (d) stability: the partition-major pattern once more, after everything else
+  printf("phase 2: %-4s %9s %9s | pm shifted by %8s %8s %8s %8s %8s | %12s %9s\n", "cand", "wo ms", "ro ms", "256KB", "1MB", "4MB", "16MB", "64MB", "pm, other src", "pm again");
+  const uint64_t wo_n2 = n / 2;      // 0.8 GB = what pass B writes
+  for (int i = 0; i < nc; ++i) {
+    const float wo = timed([&] { hipLaunchKernelGGL(k_wo, dim3(G), dim3(kThreads), 0, s, reinterpret_cast<ulonglong2 *>(cand[i]), wo_n2); });
+    const float ro = timed([&] { hipLaunchKernelGGL(k_ro, dim3(G), dim3(kThreads), 0, s, reinterpret_cast<const ulonglong2 *>(cand[i]), wo_n2, d_out); });
+    float sh[5];
+    const uint64_t shifts[5] = {256ull << 10, 1ull << 20, 4ull << 20, 16ull << 20, 64ull << 20};
+    for (int k = 0; k < 5; ++k)
+      sh[k] = timed([&] { hipLaunchKernelGGL(k_pattern<0>, dim3(G), dim3(kThreads), 0, s, col[0], col[1], col[2], n / 2, cand[i] + shifts[k] / 8, slots - (128ull << 20) / 8, nparts); });
+    // the next candidate as the source of all three read streams (n rows of 8 bytes each fit three times into 2/3 of it only when slots * 8 >= 3 * n * 8: use n_src rows)
+    const uint64_t n_src = (slots / 3) & ~1ull;
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(cand[(i + 1) % nc]);
+    const float other = timed([&] { hipLaunchKernelGGL(k_pattern<0>, dim3(G), dim3(kThreads), 0, s, src, src + n_src / 2, src + n_src, n_src / 2, cand[i], slots, nparts); });
+    const float again = timed([&] { hipLaunchKernelGGL(k_pattern<0>, dim3(G), dim3(kThreads), 0, s, col[0], col[1], col[2], n / 2, cand[i], slots, nparts); });
+    printf("phase 2: %-4d %9.4f %9.4f | %21.4f %8.4f %8.4f %8.4f %8.4f | %12.4f %9.4f   (source rows %llu of %llu)\n", i, wo, ro, sh[0], sh[1], sh[2], sh[3], sh[4], other, again,
+           (unsigned long long)n_src, (unsigned long long)n);
     fflush(stdout);
   }
   return 0;
