@@ -23,9 +23,14 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (Stage-0 p
 achieved = 24 B/row x rows per launch / the kernel's average duration measured with HIP events on the
 engine's stream (tad_stats.ms_scatter); `traffic` = that kernel's HBM bytes per launch from the committed
 rocprofv3 PMC passes (profiles/pmc_latest.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE;
-separate --pmc runs of this same command).  `cpu_baseline` = the oracle (numpy port of the reference
+separate --pmc runs of this same command).  `roofline.frac` prices the DOMINANT KERNEL; `roofline.frac_whole_run` is SURVEY.md 8d's own definition — (24 B x rows + 40 B x anomalies)
+per job over the WALL time of a step (`ms_per_step`, launch gaps and host round trips included) against the same peak.  `value` is a
+steady-state rate: the second and later job of a shape runs the one-synchronisation form (tad_stats.host_syncs = 1) on buffers that are
+in place; `cold` carries the FIRST job of the shape in the same process — allocations, the placement calibration of the record buffer
+(tad_stats.placement_*) and the three-synchronisation form included.
+`cpu_baseline` = the oracle (numpy port of the reference
 job) timed on this box's host cores on a bounded sample.  ARIMA lines add `arima`: fits/s and the
-FP64 flop rate from the engine's Kalman-step counter (18 flop per step of the recursion the kernel executes; the
+FP64 flop rate from the engine's Kalman-step counter (16 flop per step of the recursion the kernel executes; the
 60-flop-equivalent of SURVEY.md 8d's three-state model beside it).
 """
 import argparse
@@ -309,8 +314,19 @@ def main():
             return g
 
         glob = None
-        for _ in range(warmup):
+        cold = None
+        for w in range(warmup):
+            if w == 0:      # the first job of this shape in this process: allocations, placement calibration, three host synchronisations
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
             stats, glob = step()
+            if w == 0:
+                torch.cuda.synchronize()
+                cold = {"ms_first_step": (time.perf_counter() - tc) * 1e3, "host_syncs_per_job": [st.get("host_syncs") for st in stats],
+                        "stage0_attempts": [st.get("stage0_attempts") for st in stats],
+                        "placement": {k: stats[0].get("placement_" + k) for k in ("candidates", "ms", "kept_ms", "worst_ms")},
+                        "what": "the first step of this shape in the process (untimed warm-up step 1): buffer allocations, the placement "
+                                "calibration of pass B's record buffer and the three-synchronisation form of every job included"}
         if grouped:
             glob = drain() or glob
             dist.barrier()
@@ -342,7 +358,7 @@ def main():
                 drain()
             np.savez(args.dump_rows + ".rank%d.npz" % rank, **{"%s_%s" % (a, f): v for a in algos for f, v in dump[a].items()})
         del key, tend, val
-        return dict(dt=dt, stats=stats, acc=acc, glob=glob, steps=steps, warmup=warmup, n=n, K=K, T=T, agg=agg, algos=algos)
+        return dict(dt=dt, stats=stats, acc=acc, glob=glob, steps=steps, warmup=warmup, n=n, K=K, T=T, agg=agg, algos=algos, cold=cold)
 
     def describe(r, host_input=False, ingest="keys", hint=False):
         """the JSON fields of one measured config (rank 0)"""
@@ -369,12 +385,17 @@ def main():
                         "one 9-double all-gather per job" % world)},
             "roofline": {"bound": "hbm", "kernel": STAGE0_KERNEL.get(st0["stage0_path"], "k_scatter (Stage-0 v1, direct atomics)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": BYTES_PER_ROW * n, "avg_kernel_ms": scatter_ms},
+                         "algorithmic_bytes_per_launch": BYTES_PER_ROW * n, "avg_kernel_ms": scatter_ms,
+                         # SURVEY.md 8d's definition on the run: (24 N + 40 A) per job over the WALL time of a step
+                         "achieved_whole_run": (len(algos) * BYTES_PER_ROW * n + BYTES_PER_ANOMALY * A) / (ms_step * 1e-3) / 1e9,
+                         "frac_whole_run": (len(algos) * BYTES_PER_ROW * n + BYTES_PER_ANOMALY * A) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "pipeline": {"ms_meta": a0["ms_meta"] / steps, "ms_stage0_clear_plus_scatter": a0["ms_stage0"] / steps,
                          "ms_detect_and_emit": sum(a["ms_detect"] for a in r["acc"]) / steps, "ms_device_total": dev_ms,
                          "host_syncs_per_job": [st.get("host_syncs") for st in r["stats"]],
                          "hbm_frac_whole_job": (len(algos) * BYTES_PER_ROW * n + BYTES_PER_ANOMALY * A) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if r.get("cold"):
+            out["cold"] = r["cold"]
         g = r["glob"]
         out["result"] = {"anomalies": g["n_anomalies"], "keys": g["n_keys"], "points": g["n_points"], "rows_used": g["rows_used"],
                          "global_mean": g["global_mean"], "global_sigma": g["global_sigma"]}
@@ -397,7 +418,8 @@ def main():
                                        "frac": flops / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
                                        "algorithmic_flops_per_launch": flops, "avg_kernel_ms": a["ms_detect"] / steps,
                                        "frac_60flop_equivalent": eq60 / FP64_VECTOR_PEAK_TFLOPS,
-                                       "hbm_frac_of_24B_per_row": BYTES_PER_ROW * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                       "hbm_frac_of_24B_per_row": BYTES_PER_ROW * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "frac_whole_run": flops / (ms_step * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
         return out
 
     head = run_config(cfg["algos"], cfg["rows"], cfg["keys"], cfg["buckets"], cfg["agg"], args.steps, args.warmup,
@@ -409,6 +431,8 @@ def main():
                "ms_per_step": d["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
                "dtype": "u64 (aggregates) + f64 (detectors)", "data": "synthetic", "config": d["config"], "roofline": d["roofline"],
                "pipeline": d["pipeline"], "result": d["result"]}
+        if "cold" in d:
+            out["cold"] = d["cold"]
         out["config"]["baseline_config"] = args.config
         if "arima" in d:
             out["arima"] = d["arima"]

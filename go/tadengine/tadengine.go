@@ -148,6 +148,8 @@ type Stats struct {
 	MsTotal                                                  float32
 	Stage0Path                                               int32 // how Stage 0 ran (tad.h: tad_stats.stage0_path), for the controller's logs
 	HostSyncs                                                int32 // 1 = the one-synchronisation form (tad.h: tad_stats.host_syncs, ABI 8)
+	PlacementCandidates                                      int32   // allocations of the record buffer this job timed (tad.h: tad_stats.placement_*, ABI 11) ...
+	PlacementMs                                              float32 // ... and the host time it spent on them: non-zero only in the first big job of an engine
 }
 
 // cColumn copies a Go slice into C memory: cgo forbids handing Go pointers nested in a C struct, and the
@@ -227,7 +229,7 @@ func (e *Engine) Run(job Job, cols Columns) ([]Row, Stats, error) {
 	}
 	st = Stats{uint64(res.stats.rows_in), uint64(res.stats.rows_used), uint64(res.stats.n_keys), uint64(res.stats.n_points),
 		uint64(res.stats.n_anomalies), uint64(res.stats.keys_no_result), uint64(res.stats.arima_nan_fits), float32(res.stats.ms_total),
-		int32(res.stats.stage0_path), int32(res.stats.host_syncs)}
+		int32(res.stats.stage0_path), int32(res.stats.host_syncs), int32(res.stats.placement_candidates), float32(res.stats.placement_ms)}
 	return rows, st, nil
 }
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 10
+#define TAD_ABI_VERSION 11
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -175,6 +175,14 @@ typedef struct {
                               engine's previous one, device-resident in and out, is issued with that job's lattice and row capacity while
                               the device checks both (the lattice against pass A's own derivation, the row total against the block) —
                               a miss discards the output and reruns the 3-synchronisation form (stage0_attempts counts it) */
+  int32_t placement_candidates; /* ABI 11: allocations of pass B's record buffer THIS job timed before it kept one (0 = the buffer was in
+                              place already, or the table is small).  Pass B's rate depends on where that buffer landed in physical memory
+                              (same requests, same hits and misses, slower service by the memory side: profiles/r5_p*_placement_*); a job
+                              that (re)allocates the buffer times pass B's write pattern on it and on further allocations made while the
+                              earlier ones are held, keeps the fastest, frees the rest */
+  float placement_ms;      /* host wall time this job spent doing that (allocations + probe launches), 0 when placement_candidates is 0 */
+  float placement_kept_ms; /* probe time of the allocation kept ... */
+  float placement_worst_ms;/* ... and of the slowest candidate seen: kept ~ worst means this box offered no faster kind */
 } tad_stats;
 
 /* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).

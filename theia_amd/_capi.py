@@ -6,7 +6,7 @@ from . import build as _build
 
 u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
 
-TAD_ABI_VERSION = 10
+TAD_ABI_VERSION = 11
 TAD_KEY_SKIP = (1 << 64) - 1
 TAD_OK = 0
 TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
@@ -76,7 +76,8 @@ class Stats(C.Structure):
                 ("n_anomalies", u64), ("keys_no_result", u64), ("kalman_steps", u64),
                 ("arima_fits", u64), ("arima_nan_fits", u64), ("pts_mean", f64), ("pts_m2", f64), ("t0", i64), ("step", i64), ("n_buckets", u64),
                 ("ms_meta", f32), ("ms_stage0", f32), ("ms_scatter", f32), ("ms_detect", f32),
-                ("ms_total", f32), ("stage0_path", i32), ("stage0_attempts", i32), ("hist_sampled", i32), ("host_syncs", i32)]
+                ("ms_total", f32), ("stage0_path", i32), ("stage0_attempts", i32), ("hist_sampled", i32), ("host_syncs", i32),
+                ("placement_candidates", i32), ("placement_ms", f32), ("placement_kept_ms", f32), ("placement_worst_ms", f32)]
 
 
 class Result(C.Structure):
@@ -123,18 +124,19 @@ SYMBOLS = {
     "tad_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load_library(build_if_missing=True):
-    """dlopen theia_amd/lib/libtad_mi355x.so (building it in-tree first if needed)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get("TAD_LIBRARY_PATH") or _build.LIB_PATH   # override: A/B two builds of the library
+def load_library(build_if_missing=True, path=None):
+    """dlopen theia_amd/lib/libtad_mi355x.so (building it in-tree first if needed).  `path` (or TAD_LIBRARY_PATH) names another build
+    of the library — measurement variants of tools/build_variants.py; one handle per path, so two builds can run in one process."""
+    path = path or os.environ.get("TAD_LIBRARY_PATH") or _build.LIB_PATH   # override: A/B two builds of the library
+    path = os.path.abspath(path)
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
-        if not build_if_missing:
-            raise OSError("libtad_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        if not build_if_missing or path != os.path.abspath(_build.LIB_PATH):
+            raise OSError("%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
         _build.build_library()
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
@@ -142,6 +144,6 @@ def load_library(build_if_missing=True):
         fn.restype = res
         fn.argtypes = args
     if lib.tad_abi_version() != TAD_ABI_VERSION:
-        raise OSError("libtad_mi355x.so ABI %d != binding ABI %d" % (lib.tad_abi_version(), TAD_ABI_VERSION))
-    _lib = lib
+        raise OSError("%s ABI %d != binding ABI %d" % (os.path.basename(path), lib.tad_abi_version(), TAD_ABI_VERSION))
+    _libs[path] = lib
     return lib

@@ -2,6 +2,7 @@
 // CPU fallback in this library (the CPU oracle under oracle/ is test infrastructure and is never
 // linked or called from here).
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -75,6 +76,8 @@ struct tad_engine {
     bool exact_hist = false;   // the sampled histogram proved too optimistic for this table: go straight to the exact one
     bool wide_tiles = false;   // 32-bit tile cells overflowed the list for this table: go straight to 8-byte cells
   } spec;
+  // what place_recs did in the running job (tad_stats.placement_*, ABI 11); reset at the start of every job
+  struct Placement { int candidates = 0; float ms = 0.f, kept_ms = 0.f, worst_ms = 0.f; } placement;
 };
 
 // per-key running state of the streaming EWMA detector: two copies (the count pass writes the candidate next state,
@@ -172,6 +175,7 @@ int ensure(tad_engine *e, DevBuf &b, size_t bytes) {
 static constexpr size_t kPlacementBytes = (size_t)24 << 30;   // ... and at most this much memory held by the candidates together
 int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d_val, uint64_t n, uint64_t slots, uint32_t nparts, int G) {
   if (TAD_PLACEMENT_CANDIDATES < 2 || n < (1ull << 24) || nparts == 0) return TAD_OK;
+  const auto wall0 = std::chrono::steady_clock::now();
   hipStream_t s = e->stream;
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess) return TAD_OK;
@@ -225,6 +229,14 @@ int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d
     if (i != best) hipFree(cand[i].raw);
   e->recs.raw = cand[best].raw;
   e->recs.p = cand[best].p;
+  if (ok) {
+    float worst = cand[0].ms;
+    for (int i = 1; i < nc; ++i) worst = cand[i].ms > worst ? cand[i].ms : worst;
+    e->placement.candidates += nc;
+    e->placement.kept_ms = cand[best].ms;
+    e->placement.worst_ms = worst;
+    e->placement.ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  }
   hipEventDestroy(a);
   hipEventDestroy(b);
   (void)hipGetLastError();
@@ -665,6 +677,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   if (depth == 0) {
     e->done.store(0);
     e->total.store(4);
+    e->placement = tad_engine::Placement{};
   }
 
   JobParams jp;
@@ -1230,6 +1243,10 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     st.stage0_attempts = attempt + 1;
     st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
     st.host_syncs = spec ? 1 : ((hinted || empty) ? 2 : 3);
+    st.placement_candidates = e->placement.candidates;
+    st.placement_ms = e->placement.ms;
+    st.placement_kept_ms = e->placement.kept_ms;
+    st.placement_worst_ms = e->placement.worst_ms;
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     // remember the shape for the next job (only what the device can re-verify: a lattice derived from pass A's sample, the v2 path)
     if (depth == 0 && !points_mode && !stream && !jp.all_points) {

@@ -167,7 +167,13 @@ __device__ __forceinline__ void hist_row(MetaAcc &a, uint32_t *hist, uint64_t k1
 // late in round 3; one in sixteen: pass A 0.106 -> 0.083 ms at C2, regions 2.4x instead of 2x their records (6 sigma of a noisier
 // estimate: address space, never touched), pass B and pass C unchanged once a slice is long enough to keep a partition whole
 // (profiles/r3_v9_passA_sample16_ab.log; with slices of 2x the records every partition split in two and merged through atomics: +0.13 ms).
-static constexpr uint32_t kSampleMask = 15;
+#ifndef TAD_SAMPLE_MASK          // measurement builds (tools/build_variants.py): -DTAD_SAMPLE_MASK=3 samples one iteration in four
+#define TAD_SAMPLE_MASK 15
+#endif
+#ifndef TAD_REGION_UR            // records per lane and batch of pass C's walk over sampled regions (x 64 lanes)
+#define TAD_REGION_UR 12
+#endif
+static constexpr uint32_t kSampleMask = TAD_SAMPLE_MASK;
 
 template <bool VEC, bool HAS2, bool SAMPLE_H>
 __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__restrict__ key,
@@ -1119,7 +1125,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
             b = b > r_end ? r_end : b;
             a = a < lo ? lo : a;             // clip to this slice
             b = b > hi ? hi : b;
-            constexpr int UR = 12;   // a region of the uniform C2 table holds ~500 +- 22 records: one batch of 768 covers it
+            constexpr int UR = TAD_REGION_UR;   // 12: a region of the uniform C2 table holds ~500 +- 22 records: one batch of 768 covers it
             for (unsigned long long i = a + lane; i < b; i += UR * 64) {
               unsigned long long r[UR];
 #pragma unroll

@@ -245,10 +245,10 @@ class TadState:
 class TadEngine:
     """One engine per GPU.  Thread-safe (runs serialise inside the library)."""
 
-    def __init__(self, device=0, stream=None, workspace_limit=0, plan=None):
+    def __init__(self, device=0, stream=None, workspace_limit=0, plan=None, library_path=None):
         """plan: dict of tad_plan overrides (include/tad.h), e.g. {"stage0": "v2", "partition_pass": "sort"}; None = the
-        engine decides everything (production)."""
-        self._lib = capi.load_library()
+        engine decides everything (production).  library_path: another build of the library (A/B measurements, tools/ab_plans.py)."""
+        self._lib = capi.load_library(path=library_path)
         self._h = None
         self.device = int(device)
         self._plan = dict(plan or {})

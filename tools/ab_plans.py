@@ -38,16 +38,19 @@ for f in ("rows", "keys", "buckets"):
 variants = []
 for item in args.variants.split(";"):
     name, _, plan_s = item.partition("=")
-    plan = {}
+    plan, lib = {}, None
     for kv in filter(None, plan_s.split(",")):
+        if kv.startswith("lib:"):
+            lib = kv[4:]
+            continue
         k, _, v = kv.partition("=")
         plan[k] = int(v) if v.lstrip("-").isdigit() else v
-    variants.append((name, plan))
+    variants.append((name, plan, lib))
 
 eng0 = TadEngine(device=0)
 n, K, T = cfg["rows"], cfg["keys"], cfg["buckets"]
 cols = eng0.synth(0, n, K, T)
-engines = [(name, TadEngine(device=0, plan=plan)) for name, plan in variants]
+engines = [(name, TadEngine(device=0, plan=plan, library_path=lib)) for name, plan, lib in variants]
 jobs = [(name, e.prepare(cfg["algo"], cols[0], cols[1], cols[2], K, agg_flow=cfg["agg"], out="device")) for name, e in engines]
 times = {name: [] for name, _ in jobs}
 last = {}
