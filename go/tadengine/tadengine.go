@@ -71,13 +71,14 @@ type Plan struct {
 	OneSync       int32  // 1 = never run a job in the one-synchronisation form
 	TileCells     int32  // 1 = 8-byte tile cells in the settle mode of DBSCAN jobs with max
 	SparseSort    int32  // sparse tables: 1 = always the LSD radix sort, 2 = the partition pass + LDS sort wherever its plan fits (ABI 9)
+	Placement     int32  // 1 = never time / re-allocate pass B's record buffer (ABI 11; Stats.PlacementCandidates says what a job did)
 }
 
 func (p Plan) c() C.tad_plan {
 	return C.tad_plan{stage0: C.int32_t(p.Stage0), partition_pass: C.int32_t(p.PartitionPass), histogram: C.int32_t(p.Histogram),
 		sparse: C.int32_t(p.Sparse), sparse_classes: C.int32_t(p.SparseClasses), ewma_emit: C.int32_t(p.EwmaEmit),
 		ewma_emit_rows: C.uint32_t(p.EwmaEmitRows), one_sync: C.int32_t(p.OneSync), tile_cells: C.int32_t(p.TileCells),
-		sparse_sort: C.int32_t(p.SparseSort)}
+		sparse_sort: C.int32_t(p.SparseSort), placement: C.int32_t(p.Placement)}
 }
 
 func NewEngine(device int) (*Engine, error) { return NewEngineWithPlan(device, Plan{}) }

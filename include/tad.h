@@ -86,6 +86,9 @@ typedef struct {
   int32_t tile_cells;        /* 1 = 8-byte tile cells in the settle mode of DBSCAN jobs with `max` (ABI 8; default: 32-bit cells, value + 1) */
   int32_t sparse_sort;       /* sparse tables (ABI 9; was `reserved`): 1 = always the LSD radix sort, 2 = the partition pass + LDS sort wherever its plan fits
                                 (0: when pass A ran with its key-bin histogram, i.e. >= 2^22 rows) */
+  int32_t placement;         /* ABI 11: 1 = never time / re-allocate pass B's record buffer (tad_stats.placement_*): the calibration holds up to
+                                eight further allocations of the buffer's size (<= 16 GB, <= half the workspace limit) for a few ms in the first
+                                big job of an engine — a host that shares the GPU with other processes may prefer the first allocation as it is */
 } tad_plan;
 
 typedef struct {

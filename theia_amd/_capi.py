@@ -21,13 +21,13 @@ TAD_FLAG_EMIT_ALL_POINTS = 1
 class Plan(C.Structure):
     """tad_plan: plan overrides, every field 0 = the engine decides (tests and A/B measurements set them)."""
     _fields_ = [("stage0", i32), ("partition_pass", i32), ("histogram", i32), ("sparse", i32), ("sparse_classes", i32),
-                ("ewma_emit", i32), ("ewma_emit_rows", u32), ("one_sync", i32), ("tile_cells", i32), ("sparse_sort", i32)]
+                ("ewma_emit", i32), ("ewma_emit_rows", u32), ("one_sync", i32), ("tile_cells", i32), ("sparse_sort", i32), ("placement", i32)]
 
 
 PLAN_VALUES = {   # symbolic values accepted by TadEngine(plan=...) / TadEngine.plan(...)
     "stage0": {"auto": 0, "v1": 1, "v2": 2}, "partition_pass": {"auto": 0, "sort": 1, "wc": 2, "wc_sectors": 3}, "histogram": {"auto": 0, "exact": 1, "sampled": 2},
     "sparse": {"auto": 0, "never": 1, "always": 2}, "sparse_classes": {"auto": 0, "always": 1}, "ewma_emit": {"auto": 0, "staged": 0, "lane": 1}, "one_sync": {"auto": 0, "never": 1}, "tile_cells": {"auto": 0, "wide": 1},
-    "sparse_sort": {"auto": 0, "lsd": 1, "partition": 2},
+    "sparse_sort": {"auto": 0, "lsd": 1, "partition": 2}, "placement": {"auto": 0, "never": 1},
 }
 
 

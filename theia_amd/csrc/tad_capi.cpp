@@ -78,6 +78,9 @@ struct tad_engine {
   } spec;
   // what place_recs did in the running job (tad_stats.placement_*, ABI 11); reset at the start of every job
   struct Placement { int candidates = 0; float ms = 0.f, kept_ms = 0.f, worst_ms = 0.f; } placement;
+  // ... and the (columns, shape) the record buffer in place was timed against: pass B's rate is a property of the PAIR (where the three read
+  // streams lie, where the write stream lies — profiles/r5_b2_*), so a job on other columns re-times the buffer (place_recs)
+  struct PlacedFor { const void *key = nullptr, *te = nullptr, *val = nullptr; uint64_t n = 0; uint32_t nparts = 0; float kept_ms = 0.f; int jobs_since = 0; } placed_for;
 };
 
 // per-key running state of the streaming EWMA detector: two copies (the count pass writes the candidate next state,
@@ -105,7 +108,7 @@ constexpr int kSampleBlockShift = 7;   // (C4 with 1024-key blocks and a sampled
 
 bool plan_ok(const tad_plan &p) {
   return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 3 && p.histogram >= 0 && p.histogram <= 2 && p.sparse >= 0 &&
-         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.one_sync >= 0 && p.one_sync <= 1 && p.tile_cells >= 0 && p.tile_cells <= 1 && p.sparse_sort >= 0 && p.sparse_sort <= 2;
+         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.one_sync >= 0 && p.one_sync <= 1 && p.tile_cells >= 0 && p.tile_cells <= 1 && p.sparse_sort >= 0 && p.sparse_sort <= 2 && p.placement >= 0 && p.placement <= 1;
 }
 constexpr uint32_t kOverflowCap = 1u << 20;  // Stage 0 v2: rows with a value >= 2^49 per run before falling back to v1
 
@@ -161,19 +164,31 @@ int ensure(tad_engine *e, DevBuf &b, size_t bytes) {
   return TAD_OK;
 }
 
-// Placement of the record buffer (round 4).  Pass B's time depends on where the buffer it scatters into landed in physical memory — on some boxes
-// 0.605 or 0.675 ms for the same C2 job on two engine instances of one process, 0.60 / 0.69 ms at C4 (profiles/r4_v37_*) — and nothing in the
-// address says which.  A freshly allocated buffer of a big table is therefore timed with pass B's memory pattern (launch_place_probe, which
-// separates the two kinds of placement as clearly as the job does: 0.58 against 0.65 ms) against up to fifteen other allocations of the same size
-// (24 GB in all: in a fresh process the first ~8 GB allocated after the columns probed slow, what comes after fast — profiles/r4_v37_*),
-// made while the earlier ones are still held (so that they land elsewhere); it stops once a candidate 4 % faster than the slowest has been
-// seen and the next one is no better, the fastest stays, the others are freed.  Once per allocation, i.e. once per engine and table shape: a few probe launches (~0.6 ms each)
-// and host synchronisations inside the first job.  On a box without the effect all candidates time alike and the first one stays.
+// Placement of the record buffer (round 4; what it is a property of: round 5).  Pass B of the same job runs 0.60 ms with some allocations of the
+// buffer it writes and 0.64 or 0.68 ms with others of the same process (C2; some boxes offer only the slow kind).  tools/probes/placement_probe.hip
+// (profiles/r5_p1_*, r5_b1 ... r5_b3_*) narrowed it down:
+//   * not address translation: a dependent-load chase at 4 KB / 64 KB / 2 MB strides costs the same on every candidate, TCP_UTCL1 hits and
+//     misses are equal, and a workgroup-major layout that takes the UTCL1 misses to ZERO keeps the classes (and gains 1.5 %);
+//   * not the scatter: one contiguous 8-byte-per-row write stream per workgroup shows the same classes; shifting the base by 256 KB ... 64 MB
+//     inside an allocation changes nothing;
+//   * not the buffer by itself: a write-only stream (0.19 ms per 0.8 GB) and a read-only stream (0.14 ms) run alike on every candidate;
+//   * it is the PAIR: the same destination changes class when another allocation stands in for the three columns it is read with — concurrent
+//     reads and writes interfere more or less depending on where the two lie relative to each other in PHYSICAL memory.  L2 requests, hits,
+//     misses and EA read / write request counts are identical; what differs is how long the memory side takes (TCC_EA0_RDREQ_LEVEL, TCC tag /
+//     input-buffer stalls).  User space sees no physical address, so no rule can pick the fast kind: the buffer is TIMED against the job's own
+//     columns with pass B's memory pattern (launch_place_probe separates the classes as the job does) and against up to eight further allocations
+//     of the same size (<= 16 GB, <= half the workspace limit) made while the earlier ones are held; the search stops once a candidate 4 %
+//     faster than the slowest has been seen and the next one is no better; the fastest stays, the others are freed.
+// Once per allocation — and again when a job brings OTHER columns or another shape than the buffer was timed against (re-timed with three probe
+// launches; the search over further allocations restarts only if it is 3 % slower than what the last search kept, at most once in 16 jobs).
+// tad_stats.placement_* say what a job did; tad_plan.placement = 1 turns all of it off.
 #ifndef TAD_PLACEMENT_CANDIDATES
-#define TAD_PLACEMENT_CANDIDATES 16
+#define TAD_PLACEMENT_CANDIDATES 9
 #endif
-static constexpr size_t kPlacementBytes = (size_t)24 << 30;   // ... and at most this much memory held by the candidates together
-int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d_val, uint64_t n, uint64_t slots, uint32_t nparts, int G) {
+static constexpr size_t kPlacementBytes = (size_t)16 << 30;   // ... and at most this much memory held by the candidates together
+// `fresh`: the buffer has just been allocated.  Otherwise the buffer was timed against OTHER columns (or another shape): it is timed again, and
+// only if it now runs 3 % slower than what the last calibration kept does the search over further allocations start again (at most once in 16 jobs).
+int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d_val, uint64_t n, uint64_t slots, uint32_t nparts, int G, bool fresh) {
   if (TAD_PLACEMENT_CANDIDATES < 2 || n < (1ull << 24) || nparts == 0) return TAD_OK;
   const auto wall0 = std::chrono::steady_clock::now();
   hipStream_t s = e->stream;
@@ -200,6 +215,20 @@ int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d
   cand[0] = Cand{e->recs.raw, e->recs.p, 0.f};
   bool ok = probe(cand[0].p, &cand[0].ms);
   nc = 1;
+  tad_engine::PlacedFor &pf = e->placed_for;
+  const bool search = fresh || (pf.kept_ms > 0.f && cand[0].ms > 1.03f * pf.kept_ms && pf.jobs_since >= 16) || pf.kept_ms == 0.f;
+  if (!search) {   // the buffer in place serves these columns as well as it served the ones it was chosen for (or the search ran recently)
+    pf.key = d_key; pf.te = d_te; pf.val = d_val; pf.n = n; pf.nparts = nparts;
+    if (ok) {
+      e->placement.candidates += 1;
+      e->placement.kept_ms = e->placement.worst_ms = cand[0].ms;
+      e->placement.ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    (void)hipGetLastError();
+    return TAD_OK;
+  }
   // (the candidates are transient, but they are the engine's memory: together they stay within half the workspace limit)
   const size_t budget = kPlacementBytes < e->ws_limit / 2 ? kPlacementBytes : (size_t)(e->ws_limit / 2);
   while (ok && nc < TAD_PLACEMENT_CANDIDATES && (size_t)(nc + 1) * e->recs.cap <= budget) {
@@ -235,6 +264,7 @@ int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d
     e->placement.candidates += nc;
     e->placement.kept_ms = cand[best].ms;
     e->placement.worst_ms = worst;
+    pf.key = d_key; pf.te = d_te; pf.val = d_val; pf.n = n; pf.nparts = nparts; pf.kept_ms = cand[best].ms; pf.jobs_since = 0;
     e->placement.ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   }
   hipEventDestroy(a);
@@ -969,9 +999,15 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       {
         const void *recs_before = e->recs.p;
         if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
-        // a new buffer of a big table: keep the best of a few placements (place_recs); plain 16-byte aligned columns only (the probe reads them)
-        if (e->recs.p != recs_before && !has2 && columns_aligned16(d_key, d_key2, d_te, d_val))
-          place_recs(e, d_key, d_te, d_val, n, e->recs.cap / 8, pl.nparts, pl.G);
+        // a new buffer of a big table — or other columns / another shape than the buffer in place was timed against: keep the best of a few
+        // placements (place_recs); plain 16-byte aligned columns only (the probe reads them); tad_plan.placement = 1 turns it off
+        const bool fresh = e->recs.p != recs_before;
+        const tad_engine::PlacedFor &pf = e->placed_for;
+        const bool moved = pf.key != d_key || pf.te != d_te || pf.val != d_val || pf.n != n || pf.nparts != pl.nparts;
+        if (fresh) e->placed_for = tad_engine::PlacedFor{};
+        if (plan.placement != 1 && (fresh || moved) && !has2 && columns_aligned16(d_key, d_key2, d_te, d_val))
+          place_recs(e, d_key, d_te, d_val, n, e->recs.cap / 8, pl.nparts, pl.G, fresh);
+        if (e->placed_for.jobs_since < (1 << 20)) e->placed_for.jobs_since++;
       }
       if ((rc = ensure(e, e->ovf, 16 + (size_t)kOverflowCap * sizeof(OverflowRec))) != TAD_OK) return rc;
       unsigned long long *ovf_count = dev_ovf_count(e);     // in the job tail: zeroed with the counters, one fill per attempt

@@ -49,6 +49,43 @@ __global__ __launch_bounds__(kThreads) void k_pattern(const ulonglong2 *__restri
   }
 }
 
+// PHASED: a workgroup alternates a READ phase (B rows of the three columns -> one 8-byte record each, parked in LDS) and a WRITE phase (the B
+// records out, whole 128-byte lines; MODE 0: round robin over the partitions' regions as k_pattern<0>, MODE 2: one contiguous stream).  The 256
+// workgroups start together and do equal work, so their phases stay roughly aligned chip-wide: does separating reads from writes in TIME remove
+// the dependence on where the buffer lies relative to the columns?
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_phased(const ulonglong2 *__restrict__ key, const ulonglong2 *__restrict__ te,
+                                                     const ulonglong2 *__restrict__ val, uint64_t n2, unsigned long long *__restrict__ recs,
+                                                     uint64_t slots, uint32_t nparts, uint32_t batch_pairs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  ulonglong2 *buf = reinterpret_cast<ulonglong2 *>(smem);
+  const uint64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
+  const uint64_t region_slots = (slots / nparts) & ~15ull;
+  const uint64_t share = region_slots / gridDim.x & ~15ull;
+  const uint64_t wg_slots = slots / gridDim.x & ~15ull;
+  if (share < 16) return;
+  const uint32_t lane8 = threadIdx.x & 7u, grp = threadIdx.x >> 3;
+  uint64_t line0 = 0;
+  for (uint64_t b0 = lo; b0 < hi; b0 += batch_pairs) {
+    const uint64_t b1 = b0 + batch_pairs < hi ? b0 + batch_pairs : hi;
+    for (uint64_t i = b0 + threadIdx.x; i < b1; i += kThreads) {          // read phase
+      const ulonglong2 k = key[i], t = te[i], v = val[i];
+      buf[i - b0] = make_ulonglong2(k.x ^ t.x ^ v.x, k.y ^ t.y ^ v.y);
+    }
+    __syncthreads();
+    for (uint64_t i = b0 + threadIdx.x, it = 0; i < b1; i += kThreads, ++it) {   // write phase
+      const uint64_t g = line0 + it * (kThreads / 8) + grp;
+      unsigned long long *dst;
+      if (MODE == 0) dst = recs + (uint64_t)(g % nparts) * region_slots + (uint64_t)blockIdx.x * share + ((g / nparts) % (share / 16)) * 16 + lane8 * 2;
+      else dst = recs + (uint64_t)blockIdx.x * wg_slots + (g % (wg_slots / 16)) * 16 + lane8 * 2;
+      reinterpret_cast<ulonglong2 *>(dst)[0] = buf[i - b0];
+    }
+    line0 += (b1 - b0 + 7) / 8;
+    __syncthreads();
+  }
+}
+
 // write-only / read-only streams over a candidate (no column reads): is the class a property of the buffer alone?
 __global__ __launch_bounds__(kThreads) void k_wo(ulonglong2 *__restrict__ p, uint64_t n2) {
   const uint64_t per = (n2 + gridDim.x - 1) / gridDim.x;
@@ -141,6 +178,20 @@ int main(int argc, char **argv) {
     fflush(stdout);
   }
   if (argc > 6 && atoi(argv[6]) == 0) return 0;      // (the counter passes stop here)
+  // ---- phase 1b: reads and writes separated in time ----
+  printf("phased: %-4s | pm: batch %6s %6s %6s rows | seq: batch %6s %6s %6s rows\n", "cand", "2048", "8192", "16384", "2048", "8192", "16384");
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_phased<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_phased<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  for (int i = 0; i < nc; ++i) {
+    float t[6];
+    const uint32_t bp[3] = {1024, 4096, 8192};        // row PAIRS per batch
+    for (int k = 0; k < 3; ++k) {
+      t[k] = timed([&] { hipLaunchKernelGGL(k_phased<0>, dim3(G), dim3(kThreads), (size_t)bp[k] * 16, s, col[0], col[1], col[2], n / 2, cand[i], slots, nparts, bp[k]); });
+      t[3 + k] = timed([&] { hipLaunchKernelGGL(k_phased<2>, dim3(G), dim3(kThreads), (size_t)bp[k] * 16, s, col[0], col[1], col[2], n / 2, cand[i], slots, nparts, bp[k]); });
+    }
+    printf("phased: %-4d | %16.4f %6.4f %6.4f      | %17.4f %6.4f %6.4f\n", i, t[0], t[1], t[2], t[3], t[4], t[5]);
+    fflush(stdout);
+  }
   // ---- phase 2: what is the class a property of? ----
   // (a) the buffer alone: write-only and read-only streams over the first 0.8 GB of every candidate;
   // (b) the base inside the allocation: the partition-major pattern into the same candidate shifted by 256 KB ... 64 MB (slots shrink accordingly);
