@@ -455,8 +455,10 @@ def main():
             d["baseline_config"] = name
             if name == "c4":     # PMC passes of `bench.py --config c4` (profiles/README.md)
                 d["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(r["stats"][0]["stage0_path"], "k_scatter"),
-                                                       "r4_m7_pmc_c4.json")
-            if name == "c5":
+                                                       "pmc_latest_c4.json")
+            if name == "c5":     # PMC passes of `bench.py --config c5 --algo EWMA` (the Stage 0 both jobs of the step run)
+                d["roofline"]["traffic"] = pmc_traffic({2: "k_partition", 3: "k_partition_wc"}.get(r["stats"][0]["stage0_path"], "k_scatter"),
+                                                       "pmc_latest_c5.json")
                 d["scaling"] = "strong (this is the N = 1 base: `bench.py --config c5 --gpus N` splits the same table over N ranks)"
             elif not args.no_cpu_baseline:
                 cr, ck, sr = cpu_sample(c["algos"][0], c["rows"], c["keys"], cores)
