@@ -97,7 +97,12 @@ def test_exact_values_against_both_reference_lists(golden, golden_exact):
     assert [r["index"] for r in rows] == [59, 60, 62, 72, 73, 74, 75, 77, 80]
     assert [r["index"] for r in rows if r["reference_lists_agree"]] == [80]      # every other miss: the reference's two lists disagree there
     with open(arima_gap.GAP_TABLE) as f:                                          # the table DESIGN.md section 4 quotes is this one
-        assert f.read() == arima_gap.render(rows)
+        table = f.read()
+    assert table == arima_gap.render(rows)
+    import os
+    with open(os.path.join(arima_gap.ROOT, "DESIGN.md")) as f:
+        design = f.read()
+    assert all(("  " + line) in design for line in table.splitlines()), "DESIGN.md section 4 does not quote tests/golden/arima_gap_table.md"
     full = np.array(golden["expanded_arima_row_list"])                            # :288-318, never asserted by the reference
     rel = np.abs(np.array(golden_exact) - full) / full
     assert np.median(rel) < 1e-7 and np.percentile(rel, 90) < 5e-5 and rel.max() < 5e-4   # measured 9.3e-10 / 4.9e-6 / 2.5e-4

@@ -157,10 +157,12 @@ def test_e2e_result_map_on_the_engine(engine, golden, algo, agg_type):
         assert len(stats) >= 2
         a = E2E_ASSERT[agg_type]
         fields = rest.result_columns(spec.get("aggFlow", ""), spec.get("podName", ""))
-        assert len(fields) == a["n"] and fields[a["throughput"]] == "throughput" and fields[a["anomaly"]] == "anomaly"
         for s in stats:
-            f = [getattr(s, name) for name in fields]
-            assert all(v != "" for v in f), f                    # every selected field arrives, so a printed line has a["n"] fields
+            # the e2e splits the printed line on white space (strings.Fields, :276-283): an empty value is no field.  podLabel mode: the test
+            # flows' labels `{test_key:test_value}` are no JSON, remove_meaningless_labels turns them into "" (anomaly_detection.py:107-131),
+            # which is why assert_variable_map counts 9 fields there for the SELECT's 10 columns
+            f = [v for v in (getattr(s, name) for name in fields) if v != ""]
+            assert len(f) == a["n"], f
             assert f[a["throughput"]][:5] in E2E_RESULT_MAP[algo] and f[a["anomaly"]] == "true", f
             assert f[0] == t.name[4:]
         c.delete(NS, t.name)

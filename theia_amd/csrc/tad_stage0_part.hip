@@ -1553,7 +1553,17 @@ static SliceTable slice_table(void *slice_mem, uint64_t slots, const PartPlan &p
 }
 // regions sized from a sampled histogram hold ~2.4x the slots of their records: slices three times as long keep one slice per
 // partition for uniform tables (a split partition merges into the grid with atomics instead of plain stores)
-static uint32_t slice_len_of(bool sampled) { return sampled ? 3 * kSliceRecords : kSliceRecords; }
+// Round 5: ... and never shorter than 1.5x the MEAN partition.  Slices exist to spread a partition swollen by a hot key over many CUs; when every
+// partition is long (C5 on one GPU: 1e9 rows / 1954 partitions = 512k records each) cutting all of them made every tile a pre-zeroed one that its four
+// slices merged into with global atomics (k_part_offsets wrote the 2.25 GB grid once to zero it, pass C 5.6 GB for 2.25 GB of tiles, `profiles/r5_m1_pmc_c5.json`)
+// although the partitions x rounds alone are 15 632 workgroups.  A partition well above the mean is still split.
+static uint32_t slice_len_of(bool sampled, uint64_t slots, uint32_t nparts) {
+  const uint64_t base = sampled ? 3ull * kSliceRecords : kSliceRecords;
+  const uint64_t mean = nparts ? slots / nparts : 0;
+  const uint64_t want = mean + mean / 2;
+  const uint64_t len = want > base ? want : base;
+  return (uint32_t)(len < 0xFFFFFFF0ull ? len : 0xFFFFFFF0ull);
+}
 
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
                          unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n, uint64_t slots, void *slice_mem,
@@ -1566,7 +1576,7 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
   A.G = pl.G; A.partials = sampled ? partials : nullptr; A.n = n; A.chunk = pl.chunk;
   A.offs32 = offs32; A.total = total; A.part_start = part_start;
   A.st = slice_table(slice_mem, slots, pl);
-  A.slice_len = g.val == nullptr ? 0xFFFFFFFFu : slice_len_of(sampled);   // (no grid: the sparse sort reads whole partitions, nothing is split or pre-zeroed)
+  A.slice_len = g.val == nullptr ? 0xFFFFFFFFu : slice_len_of(sampled, slots, pl.nparts);   // (no grid: the sparse sort reads whole partitions, nothing is split or pre-zeroed)
   A.g = g; A.shift_part = pl.shift_part;
   A.spec_partials = partials; A.spec_n = spec_n; A.spec_L = spec_L != nullptr ? *spec_L : Lattice{}; A.spec_ctr = spec_L != nullptr ? spec_ctr : nullptr;
   hipLaunchKernelGGL(k_part_offsets, dim3((pl.nparts + 3) / 4 + (A.spec_ctr != nullptr ? 1 : 0)), dim3(256), 0, s, A);
@@ -1680,7 +1690,7 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   const unsigned long long *rr = static_cast<const unsigned long long *>(recs);
   const uint32_t max_slices = (uint32_t)((size_t)pl.nparts + (size_t)(slots / kSliceRecords) + 1);
   const SliceTable st = slice_table(slice_mem, slots, pl);   // built by k_part_offsets (with the pre-zeroed tiles of split partitions)
-  const uint32_t slice_len = slice_len_of(fin != nullptr);
+  const uint32_t slice_len = slice_len_of(fin != nullptr, slots, pl.nparts);
   // the rounds of a partition run as parallel workgroups on one XCD (measured: C2 pass C 0.39 -> 0.29 ms against sequential rounds)
   const uint32_t par = pl.n_chunks > 1 ? 1u : 0u;
   const bool settle_on = settle.on != 0 && pl.settle_kt != 0;
