@@ -179,15 +179,15 @@ int ensure(tad_engine *e, DevBuf &b, size_t bytes) {
 //     columns with pass B's memory pattern (launch_place_probe separates the classes as the job does) and against up to eight further allocations
 //     of the same size (<= 16 GB, <= half the workspace limit) made while the earlier ones are held; the search stops once a candidate 4 %
 //     faster than the slowest has been seen and the next one is no better; the fastest stays, the others are freed.
-// Once per allocation — and again when a job brings OTHER columns or another shape than the buffer was timed against (re-timed with three probe
-// launches; the search over further allocations restarts only if it is 3 % slower than what the last search kept, at most once in 16 jobs).
+// Once per allocation — and again when a job brings OTHER columns or another shape than the buffer was timed against, at most once in 16 jobs
+// (re-timed with three probe launches; the search over further allocations restarts only if it is 3 % slower than what the last search kept).
 // tad_stats.placement_* say what a job did; tad_plan.placement = 1 turns all of it off.
 #ifndef TAD_PLACEMENT_CANDIDATES
 #define TAD_PLACEMENT_CANDIDATES 9
 #endif
 static constexpr size_t kPlacementBytes = (size_t)16 << 30;   // ... and at most this much memory held by the candidates together
 // `fresh`: the buffer has just been allocated.  Otherwise the buffer was timed against OTHER columns (or another shape): it is timed again, and
-// only if it now runs 3 % slower than what the last calibration kept does the search over further allocations start again (at most once in 16 jobs).
+// only if it now runs 3 % slower than what the last calibration kept does the search over further allocations start again.
 int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d_val, uint64_t n, uint64_t slots, uint32_t nparts, int G, bool fresh) {
   if (TAD_PLACEMENT_CANDIDATES < 2 || n < (1ull << 24) || nparts == 0) return TAD_OK;
   const auto wall0 = std::chrono::steady_clock::now();
@@ -216,9 +216,9 @@ int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d
   bool ok = probe(cand[0].p, &cand[0].ms);
   nc = 1;
   tad_engine::PlacedFor &pf = e->placed_for;
-  const bool search = fresh || (pf.kept_ms > 0.f && cand[0].ms > 1.03f * pf.kept_ms && pf.jobs_since >= 16) || pf.kept_ms == 0.f;
+  const bool search = fresh || pf.kept_ms == 0.f || cand[0].ms > 1.03f * pf.kept_ms;
   if (!search) {   // the buffer in place serves these columns as well as it served the ones it was chosen for (or the search ran recently)
-    pf.key = d_key; pf.te = d_te; pf.val = d_val; pf.n = n; pf.nparts = nparts;
+    pf.key = d_key; pf.te = d_te; pf.val = d_val; pf.n = n; pf.nparts = nparts; pf.jobs_since = 0;
     if (ok) {
       e->placement.candidates += 1;
       e->placement.kept_ms = e->placement.worst_ms = cand[0].ms;
@@ -1005,7 +1005,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         const tad_engine::PlacedFor &pf = e->placed_for;
         const bool moved = pf.key != d_key || pf.te != d_te || pf.val != d_val || pf.n != n || pf.nparts != pl.nparts;
         if (fresh) e->placed_for = tad_engine::PlacedFor{};
-        if (plan.placement != 1 && (fresh || moved) && !has2 && columns_aligned16(d_key, d_key2, d_te, d_val))
+        // (a caller that brings new column buffers with every job must not pay three probe launches per job: re-timed at most once in 16 jobs)
+        if (plan.placement != 1 && (fresh || (moved && pf.jobs_since >= 16)) && !has2 && columns_aligned16(d_key, d_key2, d_te, d_val))
           place_recs(e, d_key, d_te, d_val, n, e->recs.cap / 8, pl.nparts, pl.G, fresh);
         if (e->placed_for.jobs_since < (1 << 20)) e->placed_for.jobs_since++;
       }
