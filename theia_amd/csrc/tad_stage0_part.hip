@@ -803,7 +803,9 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
   uint32_t *gend = gcur + F;  // end of the region (constant)
   uint32_t *nsp = gend + F;   // records spilled to the top of the region, downward from gend (a counter: it cannot wrap)
   uint16_t *jobs = reinterpret_cast<uint16_t *>(nsp + F);
-  __shared__ uint32_t s_njobs;
+  // (the two counters below are written in a tile's APPEND phase and read in its emit phase: one pair per tile parity, so that clearing the
+  //  pair of tile t — after the barrier that ends its emit phase — cannot meet an append of tile t + 1, which starts behind that same barrier)
+  __shared__ uint32_t s_njobs2[2];
   // Records that find their queue full are PARKED here during the append phase and stored in the emit phase (round 4).  They used to be
   // stored straight away — a global store between the LDS appends, for which the compiler drains the prefetched rows of the next tiles
   // (vmcnt counts stores too on gfx9): with ~1 % of the records spilling three quarters of all wavefront-tiles took that drain, which is
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
   constexpr uint32_t kSpillSlots = 288;
   __shared__ unsigned long long s_spill_rec[kSpillSlots];
   __shared__ uint32_t s_spill_at[kSpillSlots];
-  __shared__ uint32_t s_nspill;
+  __shared__ uint32_t s_nspill2[2];
 
   {
     const uint32_t *my = A.offs32 + (size_t)blockIdx.x * F;
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       gcur[p] = ps + my[p];
       gend[p] = last ? (uint32_t)A.part_start[p + 1] : ps + nx[p];
     }
-    if (threadIdx.x == 0) { s_njobs = 0; s_nspill = 0; }
+    if (threadIdx.x == 0) { s_njobs2[0] = s_njobs2[1] = 0; s_nspill2[0] = s_nspill2[1] = 0; }
   }
 
   const uint64_t lo = (uint64_t)blockIdx.x * A.chunk;
@@ -866,6 +868,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
 
   auto process = [&](Rows &r, uint64_t tile) {
     const uint64_t base = lo + tile * TILE;
+    uint32_t &s_njobs = s_njobs2[tile & 1u], &s_nspill = s_nspill2[tile & 1u];
     // ---- append: every record joins its partition's queue (LDS), or spills to the end of the region ----
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
@@ -909,6 +912,10 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
           const uint32_t p = (uint32_t)(k >> A.shift_part);
           const unsigned long long rec = (vrec << A.cell_bits) | cell;
           const uint32_t pos = atomicAdd(&cnt[p], 1u);
+          // the append that makes the queue hold a whole piece registers it for this tile's emit phase (round 5: there used to be a scan over all
+          // queues behind a barrier of its own).  A queue leaves the emit phase with fewer than SEC records, so it crosses SEC at most once per
+          // tile as long as cap < 2 SEC, which the plan guarantees (cap <= 16 with sectors, <= 31 with lines).
+          if (pos == (uint32_t)SEC - 1u) jobs[atomicAdd(&s_njobs, 1u)] = (uint16_t)p;
           if (pos < cap) q[p * cap + pos] = rec;
           else {  // queue full (a burst, or a hot key): top of the region
             const uint32_t k = atomicAdd(&nsp[p], 1u);
@@ -924,28 +931,12 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
     }
     load_tile(r, tile + 2);  // this register set is free again: lands during the rest of this tile and the whole next one
     lds_barrier();
-    // ---- which queues can emit a sector ----
-    for (uint32_t p0 = 0; p0 < F; p0 += kPartThreads) {  // workgroup-uniform trip count: the ballot below needs whole wavefronts
-      const uint32_t p = p0 + threadIdx.x;
-      uint32_t c = p < F ? cnt[p] : 0u;
-      if (c > cap) { c = cap; cnt[p] = cap; }
-      const bool emit = c >= (uint32_t)SEC;
-      const unsigned long long m = __ballot(emit);  // one LDS atomic per wavefront instead of one per queue
-      if (m) {
-        const uint32_t lane = threadIdx.x & 63u;
-        uint32_t first = 0;
-        if (lane == 0) first = atomicAdd(&s_njobs, (uint32_t)__popcll(m));
-        first = __shfl(first, 0);
-        if (emit) jobs[first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
-      }
-    }
-    lds_barrier();
     // ---- emit: SEC consecutive lanes write the queue's whole aligned pieces (one store instruction each); the remainder
     // slides down to the front of the queue ----
     const uint32_t nj = s_njobs;
     for (uint32_t j = threadIdx.x / SEC; j < nj; j += kPartThreads / SEC) {
       const uint32_t p = jobs[j], sl = threadIdx.x & (SEC - 1u);
-      const uint32_t c = cnt[p], g = gcur[p];
+      const uint32_t c0 = cnt[p], c = c0 < cap ? c0 : cap, g = gcur[p];      // (the count runs past cap for the records that spilled)
       unsigned long long *qp = q + p * cap;
       const uint32_t whole = c & ~(uint32_t)(SEC - 1);
       const uint32_t room = gend[p] - g, sp = nsp[p];
@@ -962,7 +953,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       for (uint32_t i = threadIdx.x; i < ns; i += kPartThreads) A.recs[s_spill_at[i]] = s_spill_rec[i];
     }
     lds_barrier();
-    if (threadIdx.x == 0) { s_njobs = 0; s_nspill = 0; }  // next used after the next tile's first barrier
+    if (threadIdx.x == 0) { s_njobs = 0; s_nspill = 0; }  // this parity's pair: next written in the append phase of tile + 2, two barriers from here
   };
 
   Rows R0, R1;
