@@ -179,15 +179,13 @@ int ensure(tad_engine *e, DevBuf &b, size_t bytes) {
 //     columns with pass B's memory pattern (launch_place_probe separates the classes as the job does) and against up to eight further allocations
 //     of the same size (<= 16 GB, <= half the workspace limit) made while the earlier ones are held; the search stops once a candidate 4 %
 //     faster than the slowest has been seen and the next one is no better; the fastest stays, the others are freed.
-// Once per allocation — and again when a job brings OTHER columns or another shape than the buffer was timed against, at most once in 16 jobs
-// (re-timed with three probe launches; the search over further allocations restarts only if it is 3 % slower than what the last search kept).
+// Once per allocation — and again when a job brings OTHER columns or another shape than the buffer was chosen against, at most once in 16 jobs.
 // tad_stats.placement_* say what a job did; tad_plan.placement = 1 turns all of it off.
 #ifndef TAD_PLACEMENT_CANDIDATES
 #define TAD_PLACEMENT_CANDIDATES 9
 #endif
 static constexpr size_t kPlacementBytes = (size_t)16 << 30;   // ... and at most this much memory held by the candidates together
-// `fresh`: the buffer has just been allocated.  Otherwise the buffer was timed against OTHER columns (or another shape): it is timed again, and
-// only if it now runs 3 % slower than what the last calibration kept does the search over further allocations start again.
+// `fresh`: the buffer has just been allocated; otherwise it was chosen against OTHER columns (or another shape) and is the first candidate of a new search.
 int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d_val, uint64_t n, uint64_t slots, uint32_t nparts, int G, bool fresh) {
   if (TAD_PLACEMENT_CANDIDATES < 2 || n < (1ull << 24) || nparts == 0) return TAD_OK;
   const auto wall0 = std::chrono::steady_clock::now();
@@ -216,19 +214,9 @@ int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d
   bool ok = probe(cand[0].p, &cand[0].ms);
   nc = 1;
   tad_engine::PlacedFor &pf = e->placed_for;
-  const bool search = fresh || pf.kept_ms == 0.f || cand[0].ms > 1.03f * pf.kept_ms;
-  if (!search) {   // the buffer in place serves these columns as well as it served the ones it was chosen for (or the search ran recently)
-    pf.key = d_key; pf.te = d_te; pf.val = d_val; pf.n = n; pf.nparts = nparts; pf.jobs_since = 0;
-    if (ok) {
-      e->placement.candidates += 1;
-      e->placement.kept_ms = e->placement.worst_ms = cand[0].ms;
-      e->placement.ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-    }
-    hipEventDestroy(a);
-    hipEventDestroy(b);
-    (void)hipGetLastError();
-    return TAD_OK;
-  }
+  (void)fresh;   // a buffer that served other columns is searched anew like a fresh one: what the probe says about THIS pair cannot be compared with
+                 // the time kept for another pair (a C4 job behind a C2 job re-timed its inherited buffer at 0.645 ms, "as good as" C2's 0.646, and
+                 // ran pass B at 0.688 where engines that searched for C4's columns ran 0.61-0.63: profiles/r5_m3_bench_default_line.json)
   // (the candidates are transient, but they are the engine's memory: together they stay within half the workspace limit)
   const size_t budget = kPlacementBytes < e->ws_limit / 2 ? kPlacementBytes : (size_t)(e->ws_limit / 2);
   while (ok && nc < TAD_PLACEMENT_CANDIDATES && (size_t)(nc + 1) * e->recs.cap <= budget) {
