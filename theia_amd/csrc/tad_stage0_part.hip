@@ -913,8 +913,8 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
           const unsigned long long rec = (vrec << A.cell_bits) | cell;
           const uint32_t pos = atomicAdd(&cnt[p], 1u);
           // the append that makes the queue hold a whole piece registers it for this tile's emit phase (round 5: there used to be a scan over all
-          // queues behind a barrier of its own).  A queue leaves the emit phase with fewer than SEC records, so it crosses SEC at most once per
-          // tile as long as cap < 2 SEC, which the plan guarantees (cap <= 16 with sectors, <= 31 with lines).
+          // queues behind a barrier of its own).  A queue leaves the emit phase with fewer than SEC records, so its count passes SEC - 1 exactly
+          // once in a tile in which it ends up with a whole piece or more (the emit phase writes ALL its whole pieces), and never otherwise.
           if (pos == (uint32_t)SEC - 1u) jobs[atomicAdd(&s_njobs, 1u)] = (uint16_t)p;
           if (pos < cap) q[p * cap + pos] = rec;
           else {  // queue full (a burst, or a hot key): top of the region
