@@ -1049,6 +1049,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
   // (the grid tile of a split partition was zeroed by k_part_offsets: its slices merge with atomics)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_nlist, s_lbase, s_nredo, s_rbase;
+  __shared__ uint32_t s_ovfw[40];   // settle mode: the words of the overflow-key bitmap that cover this round's keys (<= 1024 keys + alignment)
   const uint32_t cell_none = (1u << tg.cell_bits) - 1u;
   const unsigned long long plo = part_start[p], phi = part_start[p + 1];
   const unsigned long long lo = plo + (unsigned long long)(s_idx - first) * tg.slice_len;
@@ -1090,6 +1091,15 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
       flags[c] = FLAG_PRESENT;
     };
     constexpr int U = 8;
+    // Settle mode reads one bit per key of the overflow-key bitmap in its per-key pass: as a global load inside that pass it was a memory round trip on
+    // the critical path of every tile (profiling build, round 5: 10 us of a C4 tile's 40 in that pass).  The words are requested HERE, stay in a
+    // register while the records stream, and go to LDS behind the walk's barrier.
+    uint32_t ovf_w = 0;
+    const uint64_t ovf_k0 = (k0 + (SETTLE ? chunk * tg.kt : 0u)) & ~(uint64_t)31;
+    if (SETTLE && sa.ovf_keys != nullptr && threadIdx.x < 40u) {
+      const uint64_t wi = (ovf_k0 >> 5) + threadIdx.x;
+      if (wi < (g.K + 31) / 32) ovf_w = sa.ovf_keys[wi];
+    }
     if (fin != nullptr) {
       // Regions sized from a sampled histogram: the partition's record space [plo, phi) is tiled by one region per pass-B
       // workgroup; a region holds valid records in [start, fin_lo) and [fin_hi, end) (spilled ones), untouched slack
@@ -1164,6 +1174,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
       // (without the per-key bitmap any record on the overflow list sends the whole job to the redo path)
       skip_cols = !split && (sa.ovf_keys != nullptr || *ovf_count_in == 0ull);
       if (threadIdx.x == 0) { s_nlist = 0; s_nredo = 0; }
+      if (threadIdx.x < 40u) s_ovfw[threadIdx.x] = ovf_w;
       __syncthreads();
       // Four threads per key (adjacent lanes), each over every fourth bucket with its own first value as the shift of its sums;
       // the partials meet in two xor-shuffles (sums re-based onto lane 0's shift: exact algebra, no division).  One thread per key
@@ -1173,13 +1184,14 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         const uint64_t k = k0 + kt0 + kk;
         const bool live = kk < KT && kt0 + kk < KP && k < g.K;
         uint32_t n = 0;
-        double mn = 0.0, mx = 0.0, x0 = 0.0, s1 = 0.0, s2 = 0.0;
+        // (min / max start at +-infinity instead of at the first value: the same result for n > 0 — every value is finite — and unused for n == 0)
+        double mn = __builtin_huge_val(), mx = -__builtin_huge_val(), x0 = 0.0, s1 = 0.0, s2 = 0.0;
         if (live && skip_cols) {
           for (uint32_t b = part; b < nb; b += 4u) {
             const uint32_t c = __umul24(b, KT) + kk;
             if (cell_present(c)) {
               const double x = (double)cell_value(c);
-              if (n == 0) { mn = x; mx = x; x0 = x; }
+              if (n == 0) x0 = x;
               mn = fmin(mn, x);
               mx = fmax(mx, x);
               const double d = x - x0;
@@ -1209,7 +1221,7 @@ __device__ __forceinline__ void tile_aggregate_body(const unsigned long long *__
         if (part != 0 || kk >= KT) continue;
         if (!live) { settled[kk] = 1; continue; }
         // a key with a value on the overflow list is incomplete in the tile: its column is written, the fold completes it, the scan redoes it
-        const bool key_ovf = sa.ovf_keys != nullptr && ((sa.ovf_keys[k >> 5] >> (k & 31u)) & 1u) != 0;
+        const bool key_ovf = sa.ovf_keys != nullptr && ((s_ovfw[(uint32_t)((k - ovf_k0) >> 5)] >> (k & 31u)) & 1u) != 0;
         if (!skip_cols || key_ovf) { sa.st.n_pts[k] = kSettleRedo; settled[kk] = 0; tile_redo[atomicAdd(&s_nredo, 1u)] = (uint32_t)k; continue; }
         const bool slow = n > 0 && (!(mx - mn <= sa.eps) || n < (uint32_t)sa.min_samples);
         sa.st.n_pts[k] = n;
