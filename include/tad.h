@@ -181,10 +181,10 @@ typedef struct {
   int32_t placement_candidates; /* ABI 11: allocations of pass B's record buffer THIS job timed before it kept one (0 = the buffer was in
                               place already, or the table is small).  Pass B's rate depends on where that buffer landed in physical memory
                               (same requests, same hits and misses, slower service by the memory side: profiles/r5_p*_placement_*); a job
-                              that (re)allocates the buffer times pass B's write pattern on it and on further allocations made while the
-                              earlier ones are held, keeps the fastest, frees the rest */
+                              that (re)allocates the buffer — or brings other columns than it was chosen for — times its own pass B into it and
+                              into further allocations made while the earlier ones are held, keeps the fastest, frees the rest */
   float placement_ms;      /* host wall time this job spent doing that (allocations + probe launches), 0 when placement_candidates is 0 */
-  float placement_kept_ms; /* probe time of the allocation kept ... */
+  float placement_kept_ms; /* pass-B time into the allocation kept ... */
   float placement_worst_ms;/* ... and of the slowest candidate seen: kept ~ worst means this box offered no faster kind */
 } tad_stats;
 

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -54,6 +55,7 @@ struct tad_engine {
   bool sp_by_partition = false;   // the running job's sparse Stage 0 went through the partition pass + LDS sort (stage0_path 8 / 9 / 10 instead of 4 / 6 / 7)
   DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
   DevBuf ovf_keys;                                                                // Stage 0 v2, settle mode: bitmap of the keys with a value on the overflow list
+  DevBuf place_scratch;                                                           // place_recs: counters / fin of the calibration runs of pass B
   hipEvent_t ev[8] = {};
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
@@ -175,8 +177,8 @@ int ensure(tad_engine *e, DevBuf &b, size_t bytes) {
 //   * it is the PAIR: the same destination changes class when another allocation stands in for the three columns it is read with — concurrent
 //     reads and writes interfere more or less depending on where the two lie relative to each other in PHYSICAL memory.  L2 requests, hits,
 //     misses and EA read / write request counts are identical; what differs is how long the memory side takes (TCC_EA0_RDREQ_LEVEL, TCC tag /
-//     input-buffer stalls).  User space sees no physical address, so no rule can pick the fast kind: the buffer is TIMED against the job's own
-//     columns with pass B's memory pattern (launch_place_probe separates the classes as the job does) and against up to eight further allocations
+//     input-buffer stalls).  User space sees no physical address, so no rule can pick the fast kind: the JOB'S OWN pass B is timed into the buffer
+//     (its counters redirected to scratch memory; until late in round 5 a stand-in kernel, k_place_probe) and into up to eight further allocations
 //     of the same size (<= 16 GB, <= half the workspace limit) made while the earlier ones are held; the search stops once a candidate 4 %
 //     faster than the slowest has been seen and the next one is no better; the fastest stays, the others are freed.
 // Once per allocation — and again when a job brings OTHER columns or another shape than the buffer was chosen against, at most once in 16 jobs.
@@ -186,7 +188,12 @@ int ensure(tad_engine *e, DevBuf &b, size_t bytes) {
 #endif
 static constexpr size_t kPlacementBytes = (size_t)16 << 30;   // ... and at most this much memory held by the candidates together
 // `fresh`: the buffer has just been allocated; otherwise it was chosen against OTHER columns (or another shape) and is the first candidate of a new search.
-int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d_val, uint64_t n, uint64_t slots, uint32_t nparts, int G, bool fresh) {
+// `run_pass_b(recs)` issues THE JOB'S OWN pass B into a candidate buffer (counters, overflow list and `fin` redirected to scratch memory): what is timed
+// is the kernel that matters with the plan that will run.  Round 4 timed a stand-in (k_place_probe: pass B's memory pattern without its bookkeeping);
+// it ranked the candidates of a C2 job correctly but not those of a C4 job that followed it in one process — kept 0.631 of 0.669 ms by the stand-in,
+// pass B then ran 0.681 where engines of an A/B process ran 0.606 (profiles/r5_m4_bench_default_line.json).
+int place_recs(tad_engine *e, const std::function<void(void *)> &run_pass_b, const void *d_key, const void *d_te, const void *d_val, uint64_t n,
+               uint32_t nparts, bool fresh) {
   if (TAD_PLACEMENT_CANDIDATES < 2 || n < (1ull << 24) || nparts == 0) return TAD_OK;
   const auto wall0 = std::chrono::steady_clock::now();
   hipStream_t s = e->stream;
@@ -197,11 +204,11 @@ int place_recs(tad_engine *e, const void *d_key, const void *d_te, const void *d
   Cand cand[TAD_PLACEMENT_CANDIDATES];
   int nc = 0;
   auto probe = [&](void *p, float *ms) -> bool {
-    launch_place_probe(s, static_cast<const uint64_t *>(d_key), static_cast<const int64_t *>(d_te), static_cast<const uint64_t *>(d_val), n, p, slots, nparts, G);   // warm
+    run_pass_b(p);   // warm
     float best = 1e30f;
     for (int r = 0; r < 2; ++r) {
       if (hipEventRecord(a, s) != hipSuccess) return false;
-      launch_place_probe(s, static_cast<const uint64_t *>(d_key), static_cast<const int64_t *>(d_te), static_cast<const uint64_t *>(d_val), n, p, slots, nparts, G);
+      run_pass_b(p);
       if (hipEventRecord(b, s) != hipSuccess || hipEventSynchronize(b) != hipSuccess) return false;
       float t = 0.f;
       if (hipEventElapsedTime(&t, a, b) != hipSuccess) return false;
@@ -386,7 +393,7 @@ void tad_engine_destroy(tad_engine *e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part_fin, &e->ovf_keys, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
+                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part_fin, &e->ovf_keys, &e->place_scratch, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
   for (DevBuf *b : bufs)
     if (b->p) hipFree(b->raw ? b->raw : b->p);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
@@ -984,6 +991,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       if ((rc = ensure(e, e->part_total, (size_t)pl.nparts * 4)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_start, ((size_t)pl.nparts + 1) * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_offs32, (size_t)pl.G * pl.nparts * 4)) != TAD_OK) return rc;
+      bool want_place = false, place_fresh = false;
       {
         const void *recs_before = e->recs.p;
         if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
@@ -994,8 +1002,8 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         const bool moved = pf.key != d_key || pf.te != d_te || pf.val != d_val || pf.n != n || pf.nparts != pl.nparts;
         if (fresh) e->placed_for = tad_engine::PlacedFor{};
         // (a caller that brings new column buffers with every job must not pay three probe launches per job: re-timed at most once in 16 jobs)
-        if (plan.placement != 1 && (fresh || (moved && pf.jobs_since >= 16)) && !has2 && columns_aligned16(d_key, d_key2, d_te, d_val))
-          place_recs(e, d_key, d_te, d_val, n, e->recs.cap / 8, pl.nparts, pl.G, fresh);
+        want_place = plan.placement != 1 && (fresh || (moved && pf.jobs_since >= 16)) && !has2 && columns_aligned16(d_key, d_key2, d_te, d_val);
+        place_fresh = fresh;
         if (e->placed_for.jobs_since < (1 << 20)) e->placed_for.jobs_since++;
       }
       if ((rc = ensure(e, e->ovf, 16 + (size_t)kOverflowCap * sizeof(OverflowRec))) != TAD_OK) return rc;
@@ -1037,6 +1045,18 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         dbscan_redo_series(g, e->aux.p, &settle.rs_val, &settle.rs_flag, &settle.rs_has, &settle.rs_cap);
         jp.settled = true;
         narrow_tiles = pl.narrow;
+      }
+      if (want_place) {
+        // the calibration runs of pass B write their counters, `fin` and (nothing of) the overflow list to scratch memory: [DevCounters | count | fin]
+        const size_t fin_bytes = fin != nullptr ? (size_t)pl.G * pl.nparts * 8 : 0;
+        if ((rc = ensure(e, e->place_scratch, 128 + fin_bytes)) != TAD_OK) return rc;
+        unsigned char *sc = static_cast<unsigned char *>(e->place_scratch.p);
+        place_recs(e, [&](void *cand) {
+          (void)hipMemsetAsync(sc, 0, 128, s);
+          launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K, rf, L, pl,
+                           offs32, part_start, cand, ovf, reinterpret_cast<unsigned long long *>(sc + 64), 0, reinterpret_cast<DevCounters *>(sc),
+                           fin != nullptr ? reinterpret_cast<uint32_t *>(sc + 128) : nullptr, nullptr);
+        }, d_key, d_te, d_val, n, pl.nparts, place_fresh);
       }
       HIP_TRY(e, hipEventRecord(e->ev[2], s));
       launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,

@@ -364,9 +364,6 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
 uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl);
 // fin != NULL (sampled regions): no fillers; fin[(g * nparts + p) * 2 + {0, 1}] = end of the records written upwards /
 // start of the spilled records written downwards in region (g, p)
-// pass B's memory pattern without its bookkeeping, for timing a candidate placement of the record buffer (tad_capi.cpp:place_recs)
-void launch_place_probe(hipStream_t s, const uint64_t *key, const int64_t *t_end, const uint64_t *value, uint64_t n, void *recs, uint64_t slots,
-                        uint32_t nparts, int G);
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f,
                       Lattice L, const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start,

@@ -1586,42 +1586,6 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
   hipLaunchKernelGGL(k_part_tail, dim3(1), dim3(256), 0, s, A);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Placement probe.  Pass B of the same job on the same columns runs 0.607 ms on some engine instances and 0.643 on others of one process (C2;
-// 0.61 / 0.71 at C4: profiles/r4_v37_*): what differs is where the engine's record buffer landed in physical memory.  When the buffer is
-// (re)allocated the engine therefore times this kernel — pass B's memory pattern without its bookkeeping: every workgroup streams its slice of
-// the three columns and writes whole 128-byte lines, 8 bytes per row, round robin into `nparts` regions of the buffer (its own share of every
-// region, as pass B's (workgroup, partition) regions are) — on up to four candidate allocations and keeps the fastest (tad_capi.cpp:place_recs).
-// The records it writes are garbage and are overwritten by the job.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kPartThreads) void k_place_probe(const ulonglong2 *__restrict__ key, const ulonglong2 *__restrict__ te,
-                                                               const ulonglong2 *__restrict__ val, uint64_t n2, unsigned long long *__restrict__ recs,
-                                                               uint64_t region_slots, uint32_t nparts) {
-  // n2 = row pairs; a workgroup owns the pairs [w * per, (w + 1) * per); a group of 8 lanes (16 rows) fills one 128-byte line
-  const uint64_t per = (n2 + gridDim.x - 1) / gridDim.x;
-  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
-  const uint64_t share = region_slots / gridDim.x & ~15ull;            // this workgroup's slots inside every region
-  if (share < 16) return;
-  const uint32_t lane8 = threadIdx.x & 7u, grp = threadIdx.x >> 3;      // 128 groups per workgroup
-  for (uint64_t i = lo + threadIdx.x, it = 0; i < hi; i += kPartThreads, ++it) {
-    const ulonglong2 k = key[i], t = te[i], v = val[i];
-    const uint64_t g = it * (kPartThreads / 8) + grp;                   // the workgroup's g-th line
-    const uint32_t part = (uint32_t)(g % nparts);
-    const uint64_t line = (g / nparts) % (share / 16);                  // wraps inside the share: the probe never leaves the buffer
-    unsigned long long *dst = recs + (uint64_t)part * region_slots + (uint64_t)blockIdx.x * share + line * 16 + lane8 * 2;
-    reinterpret_cast<ulonglong2 *>(dst)[0] = make_ulonglong2(k.x ^ t.x ^ v.x, k.y ^ t.y ^ v.y);
-  }
-}
-
-// one probe over the whole table into `recs` (`slots` 8-byte records, 16-byte aligned columns); the caller times it
-void launch_place_probe(hipStream_t s, const uint64_t *key, const int64_t *t_end, const uint64_t *value, uint64_t n, void *recs, uint64_t slots,
-                        uint32_t nparts, int G) {
-  if (nparts == 0 || n < 2) return;
-  const uint64_t region_slots = (slots / nparts) & ~15ull;
-  hipLaunchKernelGGL(k_place_probe, dim3(G), dim3(kPartThreads), 0, s, reinterpret_cast<const ulonglong2 *>(key), reinterpret_cast<const ulonglong2 *>(t_end),
-                     reinterpret_cast<const ulonglong2 *>(value), n / 2, static_cast<unsigned long long *>(recs), region_slots, nparts);
-}
-
 void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, const int64_t *t_end,
                       const int64_t *t_start, const uint64_t *value, uint64_t n, uint64_t K, RowFilter f, Lattice L,
                       const PartPlan &pl, const uint32_t *offs32, const unsigned long long *part_start, void *recs,
