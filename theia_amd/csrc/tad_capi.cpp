@@ -994,6 +994,14 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       bool want_place = false, place_fresh = false;
       {
         const void *recs_before = e->recs.p;
+        // a buffer more than twice the size this job needs (a smaller table behind a bigger one) is given back first: the search below then
+        // runs over allocations of THIS job's size
+        if (e->recs.p != nullptr && (size_t)slots * 8 < e->recs.cap / 2 && plan.placement != 1 && e->placed_for.jobs_since >= 16) {
+          HIP_TRY(e, hipStreamSynchronize(s));
+          HIP_TRY(e, hipFree(e->recs.raw ? e->recs.raw : e->recs.p));
+          e->recs = DevBuf{};
+          recs_before = nullptr;
+        }
         if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
         // a new buffer of a big table — or other columns / another shape than the buffer in place was timed against: keep the best of a few
         // placements (place_recs); plain 16-byte aligned columns only (the probe reads them); tad_plan.placement = 1 turns it off
