@@ -178,6 +178,25 @@ int main(int argc, char **argv) {
     fflush(stdout);
   }
   if (argc > 6 && atoi(argv[6]) == 0) return 0;      // (the counter passes stop here)
+  // ---- phase 1c: does the SIZE of the allocation matter?  (round 5: a C4 job found only slow buffers among candidates of a bigger table's size and a
+  // fast one among candidates of its own size.)  The same pattern (the first `slots` slots) on allocations of other sizes, held next to the twelve.
+  {
+    const double gb[] = {0.96, 1.5, 1.92, 2.5, 3.0, 4.0, 6.0, 8.0, 1.92, 1.92};
+    printf("sizes: %-8s %-18s %9s %9s\n", "GB", "address", "pm ms", "seq ms");
+    std::vector<unsigned long long *> extra;
+    for (double g : gb) {
+      const uint64_t bytes = (uint64_t)(g * 1e9) & ~4095ull;
+      const uint64_t use_slots = bytes / 8 < slots ? bytes / 8 : slots;       // (a smaller buffer gets the pattern over all of it)
+      unsigned long long *q = nullptr;
+      if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); printf("sizes: %.2f GB: allocation failed\n", g); continue; }
+      extra.push_back(q);
+      CK(hipMemsetAsync(q, 0, bytes, s));
+      const float pm = timed([&] { hipLaunchKernelGGL(k_pattern<0>, dim3(G), dim3(kThreads), 0, s, col[0], col[1], col[2], n / 2, q, use_slots, nparts); });
+      const float sq = timed([&] { hipLaunchKernelGGL(k_pattern<2>, dim3(G), dim3(kThreads), 0, s, col[0], col[1], col[2], n / 2, q, use_slots, nparts); });
+      printf("sizes: %-8.2f %-18p %9.4f %9.4f\n", g, (void *)q, pm, sq);
+      fflush(stdout);
+    }
+  }
   // ---- phase 1b: reads and writes separated in time ----
   printf("phased: %-4s | pm: batch %6s %6s %6s rows | seq: batch %6s %6s %6s rows\n", "cand", "2048", "8192", "16384", "2048", "8192", "16384");
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_phased<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
