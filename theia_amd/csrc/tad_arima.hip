@@ -61,26 +61,54 @@ struct ArimaWs {
 // ------------------------------------------------------------------------------------------------
 // Box-Cox: llf of scipy 1.10.1 (_morestats.boxcox_llf), bracket() + Brent.optimize() of scipy.optimize
 // ------------------------------------------------------------------------------------------------
-TAD_HD double bc_neg_llf(double lmb, const double *xs, const double *lx, size_t stride, uint32_t n, double sumlog) {
-  // variance of x**lmb / lmb (population), two passes like numpy.var
-  double mean = 0.0;
+// f(i, p[i * stride]) for i = 0 .. n-1 in order, the loads of the NEXT eight elements issued before the current eight are worked on.
+// A lane of k_arima_prep walks its key's column with a stride of K doubles and there are ~1.5 wavefronts per SIMD at C3 (one lane
+// per key, 1e5 keys), so a load placed inside the loop costs a full HBM round trip per element: that, not the arithmetic, was the time.
+template <typename F>
+TAD_HD void stream_col8(const double *__restrict__ p, size_t stride, uint32_t n, F f) {
+  double a[8], b[8];
+  uint32_t i = 0;
+  if (n >= 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = p[(size_t)j * stride];
+  }
+  for (; i + 16 <= n; i += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = p[(size_t)(i + 8 + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f(i + j, a[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = b[j];
+  }
+  if (i + 8 <= n) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f(i + j, a[j]);
+    i += 8;
+  }
+  for (; i < n; ++i) f(i, p[(size_t)i * stride]);
+}
+
+TAD_HD double bc_neg_llf(double lmb, const double *xs, const double *__restrict__ lx, double *__restrict__ tmp, size_t stride, uint32_t n,
+                         double sumlog) {
+  // variance of x**lmb / lmb (population), two passes like numpy.var.  The second pass reads the terms the first one computed back
+  // from `tmp` (a free column of the workspace, same stride) instead of evaluating exp and the division again: the same doubles in
+  // the same order.
+  double mean = 0.0, s = 0.0;
   if (lmb == 0.0) {
-    for (uint32_t i = 0; i < n; ++i) mean += lx[i * stride];
+    stream_col8(lx, stride, n, [&](uint32_t, double l) { mean += l; });
     mean /= (double)n;
-    double s = 0.0;
-    for (uint32_t i = 0; i < n; ++i) { const double d = lx[i * stride] - mean; s += d * d; }
+    stream_col8(lx, stride, n, [&](uint32_t, double l) { const double d = l - mean; s += d * d; });
     return -((lmb - 1.0) * sumlog - (double)n / 2.0 * tad_det_log(s / (double)n));
   }
-  for (uint32_t i = 0; i < n; ++i) mean += tad_det_exp(lmb * lx[i * stride]) / lmb;
+  stream_col8(lx, stride, n, [&](uint32_t i, double l) { const double v = tad_det_exp(lmb * l) / lmb; tmp[(size_t)i * stride] = v; mean += v; });
   mean /= (double)n;
-  double s = 0.0;
-  for (uint32_t i = 0; i < n; ++i) { const double d = tad_det_exp(lmb * lx[i * stride]) / lmb - mean; s += d * d; }
+  stream_col8(tmp, stride, n, [&](uint32_t, double v) { const double d = v - mean; s += d * d; });
   return -((lmb - 1.0) * sumlog - (double)n / 2.0 * tad_det_log(s / (double)n));
 }
 
 // returns false when no valid bracket / not finite (scipy raises -> calculate_arima returns None)
-TAD_HD bool bc_mle_lambda(const double *xs, const double *lx, size_t stride, uint32_t n, double sumlog, double *lam_out) {
-#define BCF(l) bc_neg_llf((l), xs, lx, stride, n, sumlog)
+TAD_HD bool bc_mle_lambda(const double *xs, const double *lx, double *tmp, size_t stride, uint32_t n, double sumlog, double *lam_out) {
+#define BCF(l) bc_neg_llf((l), xs, lx, tmp, stride, n, sumlog)
   const double gold = 1.618034, verysmall = 1e-21, grow_limit = 110.0;
   double xa = -2.0, xb = 2.0;
   double fa = BCF(xa), fb = BCF(xb);
@@ -186,10 +214,9 @@ __global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const do
     uint32_t n = 0;
     bool nonpos = false, allsame = true;
     double x0 = 0.0, sumlog = 0.0;
-    for (uint64_t t = 0; t < g.T; ++t) {
-      const uint64_t c = t * g.K + k;
-      if (g.flag[c] & FLAG_PRESENT) {
-        const double x = (double)g.val[c];
+    auto visit = [&](uint64_t t, uint8_t fl, unsigned long long v) {
+      if (fl & FLAG_PRESENT) {
+        const double x = (double)v;
         if (n == 0) x0 = x;
         if (x != x0) allsame = false;
         if (!(x > 0.0)) nonpos = true;
@@ -200,16 +227,25 @@ __global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const do
         sumlog += l;
         n++;
       }
+    };
+    uint64_t t = 0;
+    for (; t + 8 <= g.T; t += 8) {   // the cells of eight buckets in flight at once (see stream_col8)
+      uint8_t fl[8];
+      unsigned long long v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const uint64_t c = (t + j) * g.K + k; fl[j] = g.flag[c]; v[j] = g.val[c]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) visit(t + j, fl[j], v[j]);
     }
+    for (; t < g.T; ++t) { const uint64_t c = t * g.K + k; visit(t, g.flag[c], g.val[c]); }
     bool ok = n > 3 && !nonpos && !allsame;
     double lam = 0.0;
-    if (ok) ok = bc_mle_lambda(xs, lx, st, n, sumlog, &lam);
+    if (ok) ok = bc_mle_lambda(xs, lx, ys, st, n, sumlog, &lam);   // (ys: scratch for the llf's terms until the transform below fills it)
     ws.lam[k] = lam;
     ws.state[k] = ok ? 0 : 1;
     if (ok) {
       const double sg = sigma[k];
-      for (uint32_t i = 0; i < n; ++i) {
-        const double l = lx[(size_t)i * st];
+      stream_col8(lx, st, n, [&](uint32_t i, double l) {
         const double y = lam == 0.0 ? l : tad_det_expm1(lam * l) / lam;  // scipy.special.boxcox
         ys[(size_t)i * st] = y;
         ws.ysk[(size_t)k * ws.Tpad + i] = y;
@@ -219,7 +255,7 @@ __global__ __launch_bounds__(256) void k_arima_prep(Grid g, ArimaWs ws, const do
           calc[c] = pred;
           if (fabs(xs[(size_t)i * st] - pred) > sg) g.flag[c] = FLAG_PRESENT | FLAG_ANOMALY;
         }
-      }
+      });
     } else if (n > 0) {
       // calculate_arima returned None: arrays_zip/explode of a null array -> the key has no rows at all
       for (uint32_t i = 0; i < n; ++i) g.flag[(uint64_t)tp[(size_t)i * st] * g.K + k] = 0;
@@ -370,14 +406,14 @@ TAD_HD void arima_nll4_collapsed(const double (&xe)[4][3], const double *__restr
 struct Ls2 { double a, b; };
 
 // minimum-norm least squares of Y on two columns = numpy.linalg.pinv(X).dot(Y) with rcond 1e-15, via a
-// one-sided Jacobi rotation.  g11 g12 g22 are the Gram entries; the callback recomputes the rotated
-// column norms and projections from the data (second pass) so that small singular values keep accuracy.
-template <typename RowFn>
-TAD_HD Ls2 pinv2_solve(uint32_t rows, RowFn row) {
+// one-sided Jacobi rotation.  g11 g12 g22 are the Gram entries; the rotated column norms and projections are recomputed from the
+// data (second pass) so that small singular values keep accuracy.  `each(body)` visits the rows in order and calls body(c1, c2, yy).
+template <typename Each>
+TAD_HD Ls2 pinv2_solve(uint32_t rows, Each each) {
   Ls2 r{0.0, 0.0};
   if (rows == 0) return r;
   double g11 = 0.0, g12 = 0.0, g22 = 0.0;
-  for (uint32_t i = 0; i < rows; ++i) { double c1, c2, yy; row(i, c1, c2, yy); g11 += c1 * c1; g12 += c1 * c2; g22 += c2 * c2; }
+  each([&](double c1, double c2, double) { g11 += c1 * c1; g12 += c1 * c2; g22 += c2 * c2; });
   double cs = 1.0, sn = 0.0;
   if (g12 != 0.0) {
     const double zeta = (g22 - g11) / (2.0 * g12);
@@ -386,11 +422,10 @@ TAD_HD Ls2 pinv2_solve(uint32_t rows, RowFn row) {
     sn = cs * tn;
   }
   double s1 = 0.0, s2 = 0.0, b1 = 0.0, b2 = 0.0;
-  for (uint32_t i = 0; i < rows; ++i) {
-    double c1, c2, yy; row(i, c1, c2, yy);
+  each([&](double c1, double c2, double yy) {
     const double r1 = cs * c1 - sn * c2, r2 = sn * c1 + cs * c2;
     s1 += r1 * r1; s2 += r2 * r2; b1 += r1 * yy; b2 += r2 * yy;
-  }
+  });
   const double smax = sqrt(fmax(s1, s2));
   const double cut = 1e-15 * smax;
   const double w1 = sqrt(s1) > cut ? b1 / s1 : 0.0;
@@ -400,44 +435,63 @@ TAD_HD Ls2 pinv2_solve(uint32_t rows, RowFn row) {
   return r;
 }
 
+// Rows i0 .. i1-1 of a strided series in order, f(w0 .. w4) with w_j = y[i + j]: a sliding window of five values in registers, ONE
+// load per row instead of the 6 - 10 the expressions of the passes below name, and the loads of the NEXT four rows issued before the
+// current four are worked on (a pass is a serial chain of adds per lane: with the load inside the chain every row paid an L2 round
+// trip, ~130 cycles per row and SIMD against ~50 of arithmetic).  Indices past n - 1 read y[n - 1]: never used by a row < i1.
+template <typename F>
+TAD_HD void stream_window5(const double *__restrict__ y, size_t stride, uint32_t n, uint32_t i0, uint32_t i1, F f) {
+  if (i0 >= i1) return;
+  const uint32_t last = n - 1;
+  auto Y = [&](uint32_t i) { return y[(size_t)(i < last ? i : last) * stride]; };
+  double w0 = Y(i0), w1 = Y(i0 + 1), w2 = Y(i0 + 2), w3 = Y(i0 + 3), w4 = Y(i0 + 4);
+  double n0 = Y(i0 + 5), n1 = Y(i0 + 6), n2 = Y(i0 + 7), n3 = Y(i0 + 8);
+  uint32_t i = i0;
+  for (; i + 4 <= i1; i += 4) {
+    const double m0 = Y(i + 9), m1 = Y(i + 10), m2 = Y(i + 11), m3 = Y(i + 12);
+    f(w0, w1, w2, w3, w4);
+    f(w1, w2, w3, w4, n0);
+    f(w2, w3, w4, n0, n1);
+    f(w3, w4, n0, n1, n2);
+    w0 = w4; w1 = n0; w2 = n1; w3 = n2; w4 = n3;
+    n0 = m0; n1 = m1; n2 = m2; n3 = m3;
+  }
+  for (; i < i1; ++i) {
+    f(w0, w1, w2, w3, w4);
+    w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = n0; n0 = n1; n1 = n2; n2 = n3;
+  }
+}
+
 TAD_HD void arima_start_params(const double *__restrict__ y, size_t stride, uint32_t n, double *u) {
   const uint32_t m = n - 1;  // number of first differences e_i = y[i+1] - y[i]
   auto e = [&](uint32_t i) { return y[(size_t)(i + 1) * stride] - y[(size_t)i * stride]; };
   double phi0 = 0.0, theta0 = 0.0, var0 = 0.0;
   bool fallback = m <= 2 || m - 2 <= 1;  // lagmat(endog, 2) / lagmat(residuals, 1) raise ValueError
   if (!fallback) {
-    // The passes below visit the rows in order, and row i needs y[i .. i + 4]: a sliding window of five values in registers, ONE
-    // load per row instead of the 6 - 10 the expressions name (k_arima_start is bound by those re-reads: every (key, position)
-    // lane streams its prefix five times).  The same differences of the same values: the bits do not change.
-    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0;
-    uint32_t at = 0xFFFFFFFFu;
-    auto Y = [&](uint32_t i) { return i < n ? y[(size_t)i * stride] : 0.0; };
-    auto window = [&](uint32_t i) {   // afterwards w0 .. w4 = y[i .. i + 4] (0 past the end: never used)
-      if (i == at + 1u && at != 0xFFFFFFFFu) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = Y(i + 4); }
-      else if (i != at) { w0 = Y(i); w1 = Y(i + 1); w2 = Y(i + 2); w3 = Y(i + 3); w4 = Y(i + 4); }
-      at = i;
-    };
+    // Row i of every pass needs y[i .. i + 4] (stream_window5).  The same differences of the same values as the expressions of
+    // the reference name, in the same order: the bits do not change.
     // AR(2) by pinv-OLS: e_t on (e_{t-1}, e_{t-2}), t = 2..m-1
-    const Ls2 ar = pinv2_solve(m - 2, [&](uint32_t i, double &c1, double &c2, double &yy) {
-      window(i);
-      c1 = w2 - w1; c2 = w1 - w0; yy = w3 - w2;   // e(i + 1), e(i), e(i + 2)
+    const Ls2 ar = pinv2_solve(m - 2, [&](auto body) {
+      stream_window5(y, stride, n, 0, m - 2, [&](double w0, double w1, double w2, double w3, double) {
+        body(w2 - w1, w1 - w0, w3 - w2);   // e(i + 1), e(i), e(i + 2)
+      });
     });
     // ARMA(1,1) by pinv-OLS: e_t on (e_{t-1}, res_{t-1}), t = 3..m-1;  res(j) = e(j + 2) - (e(j + 1) a + e(j) b): residual of t = j + 2
     const uint32_t rows = m - 3;
-    const Ls2 am = pinv2_solve(rows, [&](uint32_t i, double &c1, double &c2, double &yy) {
-      window(i);
-      c1 = w3 - w2; c2 = (w3 - w2) - ((w2 - w1) * ar.a + (w1 - w0) * ar.b); yy = w4 - w3;   // e(i + 2), res(i), e(i + 3)
+    const Ls2 am = pinv2_solve(rows, [&](auto body) {
+      stream_window5(y, stride, n, 0, rows, [&](double w0, double w1, double w2, double w3, double w4) {
+        body(w3 - w2, (w3 - w2) - ((w2 - w1) * ar.a + (w1 - w0) * ar.b), w4 - w3);   // e(i + 2), res(i), e(i + 3)
+      });
     });
     phi0 = am.a;
     theta0 = am.b;
     if (rows > 1) {
       double s = 0.0;
-      for (uint32_t i = 1; i < rows; ++i) {
-        window(i);
+      stream_window5(y, stride, n, 1, rows, [&](double w0, double w1, double w2, double w3, double w4) {
         const double resi = (w3 - w2) - ((w2 - w1) * ar.a + (w1 - w0) * ar.b);
         const double r2 = (w4 - w3) - ((w3 - w2) * am.a + resi * am.b);
         s += r2 * r2;
-      }
+      });
       var0 = s / (double)(rows - 1);
     } else {
       double mean = 0.0;
@@ -853,10 +907,24 @@ TAD_HD void lbfgs_deliver(LbfgsLive &L, double f, const double (&g)[3], double f
 // ------------------------------------------------------------------------------------------------
 // k_arima_start — start parameters of every fit (lane = (key, position), 64 consecutive keys per wavefront: coalesced)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_arima_start(Grid g, ArimaWs ws, const uint32_t *__restrict__ n_pts, uint32_t pmax) {
+#ifdef TAD_START_WAVES   // measurement knob (tools/build_variants.py): pin the occupancy the register allocator aims for
+#define TAD_START_ATTR __attribute__((amdgpu_waves_per_eu(TAD_START_WAVES, TAD_START_WAVES)))
+#else
+#define TAD_START_ATTR
+#endif
+__global__ __launch_bounds__(64) TAD_START_ATTR void k_arima_start(Grid g, ArimaWs ws, const uint32_t *__restrict__ n_pts, uint32_t pmax) {
+#ifdef TAD_START_PMAJOR
   const uint32_t kblocks = (uint32_t)((g.K + 63) / 64);
   const uint32_t p = pmax - 1 - blockIdx.x / kblocks;
   const uint64_t k = (uint64_t)(blockIdx.x % kblocks) * 64 + threadIdx.x;
+#else
+  // Key-block major: the pmax - 3 workgroups that walk the SAME 64 keys' series (64 x T x 8 B = 128 KB at T = 250) are consecutive
+  // block ids, so they run together and all but the first of them on an XCD find the rows in its L2.  Position major (every key
+  // block at one position, then the next position) re-streamed the whole [T][K] plane - 200 MB at C3, past every L2 - once per position.
+  const uint32_t npos = pmax - 3;
+  const uint32_t p = pmax - 1 - blockIdx.x % npos;
+  const uint64_t k = (uint64_t)(blockIdx.x / npos) * 64 + threadIdx.x;
+#endif
   if (k >= g.K || ws.state[k] != 0 || n_pts[k] <= p) return;
   double u[3];
   arima_start_params(ws.ys + k, g.K, p, u);

@@ -2,7 +2,7 @@
 """Same-box, same-process A/B of tad_plan overrides (or of two library builds): one engine per variant, ONE table in HBM, the
 variants alternate round by round so that box state (clocks, HBM refresh, neighbours) hits them alike.
 
-usage: python tools/ab_plans.py --config c2|c4 [--rows N --keys K --buckets T] --variants "base=;nosync=one_sync=never" [--rounds 6 --steps 20]
+usage: python tools/ab_plans.py --config c2|c3|c4 [--rows N --keys K --buckets T] --variants "base=;nosync=one_sync=never" [--rounds 6 --steps 20]
        a variant is name=plan (comma-separated tad_plan fields, empty = the engine decides); `lib:<path>` as a plan field loads another
        library build for that variant (TAD_LIBRARY_PATH semantics of tools/build_variants.py, in a subprocess-free way: separate ctypes handle).
 Prints per variant: median / min ms per job over the rounds, and the device-side split (meta / pass B / stage0 / detect) of the last round."""
@@ -19,6 +19,7 @@ from theia_amd import TadEngine  # noqa: E402
 from theia_amd.engine import DeviceArray  # noqa: E402
 
 CONFIGS = {"c2": dict(algo="EWMA", rows=100_000_000, keys=100_000, buckets=250, agg="svc"),
+           "c3": dict(algo="ARIMA", rows=100_000_000, keys=100_000, buckets=250, agg="svc"),
            "c4": dict(algo="DBSCAN", rows=100_000_000, keys=1_000_000, buckets=100, agg="")}
 
 ap = argparse.ArgumentParser()

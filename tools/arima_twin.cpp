@@ -38,7 +38,7 @@ extern "C" int twin_series(const double *x, long n, int maxiter, double *pred, d
   }
   bool ok = n > 3 && !nonpos && !allsame;
   double lam = 0.0;
-  if (ok) ok = bc_mle_lambda(x, lx.data(), 1, (uint32_t)n, sumlog, &lam);
+  if (ok) ok = bc_mle_lambda(x, lx.data(), y.data(), 1, (uint32_t)n, sumlog, &lam);   // (y: scratch for the terms of the llf until it is filled below)
   if (!ok) return 0;
   unsigned long long steps = 0;
   for (long i = 0; i < n; ++i) y[i] = lam == 0.0 ? lx[i] : tad_det_expm1(lam * lx[i]) / lam;
