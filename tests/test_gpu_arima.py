@@ -95,6 +95,21 @@ def test_series_arima_random_shapes(engine):
             assert_same(got, want, "random series %d" % i)
 
 
+def test_series_arima_every_length(engine):
+    """Every history length from 4 to 41: the strided column streams of k_arima_prep (batches of eight, one batch ahead) and the
+    five-value window of k_arima_start (four rows at a time, four ahead) have their seams at 8, 16, 17, 24, ... and at
+    rows = 4, 5, 8, 9, ...  (Series with missing buckets, which the compaction's batches of eight grid cells skip: the job tests below.)"""
+    rng = np.random.default_rng(23)
+    base = np.floor(3e6 * np.exp(rng.normal(0, 0.3, 41))).astype(np.uint64) + 1
+    for n in range(4, 42):
+        x = base[:n].copy()
+        x[n // 2] *= 3
+        want = ao.calculate_arima_exact(x)
+        got = engine.series_arima(x)
+        assert want is not None and got is not None, n
+        assert_same(got, want, "length %d" % n)
+
+
 def check_job(engine, k, t, v, K):
     want = orc.run_job("ARIMA", k, t, v, agg_flow="svc")
     allp = engine.run("ARIMA", k, t, v, K, agg_flow="svc", emit_all=True)
