@@ -12,6 +12,7 @@
 // keys runs with one wavefront per key (k_dbscan_list_wave: series of up to 256 buckets held in registers, pair tests by readlane)
 // or, for longer series, one workgroup per key on SORTED values (k_dbscan_sorted: in one dimension the eps-neighbourhood of a point
 // is a window of the sorted series, so core / noise are window counts — O(n log n), no pair tests).
+#include <type_traits>
 #include <cstdlib>
 
 #include "tad_internal.h"
@@ -383,13 +384,37 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
       reach[i] = false;
       cm[i] = __ballot(core[i]);
     }
+    // reach matters for the present points that are NOT core, and a listed key typically has a handful of those next to ~T core points:
+    // walk whichever set is smaller (wavefront-uniform).  Walking the non-core points asks "is a core point within eps of x_j" of every
+    // lane at once — |x_i - x_j| and |x_j - x_i| are the same double, so it is the same predicate on the same pairs.
+    unsigned long long nm[PPL];
+    int n_core = 0, n_rest = 0;
 #pragma unroll
-    for (int jj = 0; jj < PPL; ++jj)
-      for (unsigned long long m = cm[jj]; m; m &= m - 1) {
-        const double xj = readlane_f64(x[jj], __ffsll((long long)m) - 1);
+    for (int i = 0; i < PPL; ++i) {
+      nm[i] = pm[i] & ~cm[i];
+      n_core += __popcll(cm[i]);
+      n_rest += __popcll(nm[i]);
+    }
+    if (n_rest < n_core) {
 #pragma unroll
-        for (int i = 0; i < PPL; ++i) reach[i] = reach[i] || fabs(x[i] - xj) <= eps;
-      }
+      for (int jj = 0; jj < PPL; ++jj)
+        for (unsigned long long m = nm[jj]; m; m &= m - 1) {
+          const int l = __ffsll((long long)m) - 1;
+          const double xj = readlane_f64(x[jj], l);
+          bool near = false;
+#pragma unroll
+          for (int i = 0; i < PPL; ++i) near = near || (core[i] && fabs(x[i] - xj) <= eps);
+          if (__ballot(near) != 0ull && (int)lane == l) reach[jj] = true;
+        }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < PPL; ++jj)
+        for (unsigned long long m = cm[jj]; m; m &= m - 1) {
+          const double xj = readlane_f64(x[jj], __ffsll((long long)m) - 1);
+#pragma unroll
+          for (int i = 0; i < PPL; ++i) reach[i] = reach[i] || fabs(x[i] - xj) <= eps;
+        }
+    }
     uint32_t noise = 0;
     unsigned long long am[PPL];
 #pragma unroll
@@ -400,46 +425,91 @@ __global__ __launch_bounds__(kDbBlock) void k_dbscan_list_wave(Grid g, double ep
       noise += (uint32_t)__popcll(am[i]);
     }
     if (lane == 0 && n_anom != nullptr) n_anom[k] = noise;
-    // What the job's emit needs of a key with noise points, left next to the list entry: its noise masks and its stddev_samp
-    // (Spark CentralMomentAgg in time order: an IEEE division = the bits of div_by_count; every lane computes the same
-    // recurrence over the present points by readlane) — the series is in registers HERE; k_emit_dbscan_wave used to fetch the
-    // key's whole column (one 64-byte sector per bucket for 8 useful bytes: 238 MB at C4) a second time for these two things.
-    if (sg_e != nullptr && noise) {   // wavefront-uniform
-      // the reciprocals of the counts 1 .. 64 PPL, one IEEE division per lane and register (= RN(1 / count), what div_by_count needs),
-      // picked up by readlane: the step is 5 FMAs instead of a ~30-instruction division on a kernel that is issue-bound
-      // (C4: ~70 % of a noisy key's instructions were this division)
-      double rl[PPL];
+    // What the job's emit needs of a key with noise points, left next to the list entry: its noise masks (the series is in registers
+    // HERE; k_emit_dbscan_wave used to fetch the key's whole column a second time for them) — and its stddev_samp, which
+    // k_dbscan_list_sigma computes with one LANE per entry afterwards.
+    if (am_e != nullptr && noise && lane == 0) {
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) rl[j] = 1.0 / (double)(lane + 64u * (unsigned)j + 1u);
-      double cn = 0.0, avg = 0.0, m2 = 0.0;
-      int ord = 0;   // points seen so far: the next count is ord + 1 -> reciprocal in register ord / 64, lane ord % 64
-#pragma unroll
-      for (int jj = 0; jj < PPL; ++jj)
-        for (unsigned long long m = pm[jj]; m; m &= m - 1, ++ord) {
-          const double xv = readlane_f64(x[jj], __ffsll((long long)m) - 1);
-          double rc = readlane_f64(rl[0], ord & 63);
-#pragma unroll
-          for (int j = 1; j < PPL; ++j)
-            if ((ord >> 6) == j) rc = readlane_f64(rl[j], ord & 63);
-          cn = cn + 1.0;
-          const double d = xv - avg;
-          const double dn = div_by_count(d, cn, rc);     // == d / cn, bit for bit
-          avg = avg + dn;
-          m2 = m2 + d * (d - dn);
-        }
-      if (lane == 0) {
-        sg_e[e] = cn >= 2.0 ? sqrt(m2 / (cn - 1.0)) : 0.0;
-#pragma unroll
-        for (int i = 0; i < PPL; ++i) am_e[(size_t)e * PPL + i] = am[i];
-      }
+      for (int i = 0; i < PPL; ++i) am_e[(size_t)e * PPL + i] = am[i];
     }
   }
 }
 
-// k_emit_dbscan_wave — the DBSCAN job's emit from the detector's WORK LIST instead of a walk over all keys: only listed keys can
-// have noise points, and there are few of them (C4: 1.8 % of the keys, 14 488 rows).  One wavefront per listed key with noise:
-// the noise masks and the key's stddev_samp come from the list entry (k_dbscan_list_wave), the lanes of the noise points fetch
-// their value from the grid; the rows of the key go to off[k] + rank in time order.
+// k_dbscan_list_sigma — stddev_samp of every listed key that has noise points (an output column of its rows), one LANE per list entry.
+// Spark's CentralMomentAgg over the present points in time order (an IEEE division = the bits of div_by_count with RN(1 / count) from
+// an LDS table, as k_key_sigma).  Until round 5 k_dbscan_list_wave ran this recurrence itself, every lane of the key's wavefront
+// computing the same serial chain from readlanes: ~14 instructions x T per KEY, more than the key's pair tests — 60 of that kernel's
+// 86 us at C4, where 70 % of the listed keys have noise.  A lane per entry issues the same chain once per 64 entries: 30 us, of which
+// (probe builds, profiles/r5_d5_* ... r5_d9_*) 5 are the launch over a grid sized from K, 9 the loads — every lane walks its own cache
+// lines — and 14 the chain itself: 7 dependent FP64 operations per present point on one wavefront per SIMD.  What did NOT change it:
+// the division instead of the table (+1.6 us), the batches 1 or 3 ahead, the u64 -> f64 conversions and the table lookup taken out of
+// the step, m2's three operations moved into the next step's stalls.  On a second stream beside the count scan it saved 5 us
+// (profiles/r5_d10_*: two cross-stream dependencies cost what the overlap gives), so it runs on the job's stream.
+static constexpr int kSigmaBlock = 64;   // one wavefront per workgroup: the ~300 wavefronts of C4's list spread over all CUs (256 threads: 54 us)
+__global__ __launch_bounds__(kSigmaBlock) void k_dbscan_list_sigma(Grid g, const uint32_t *__restrict__ list, const unsigned int *__restrict__ count,
+                                                                  const uint32_t *__restrict__ n_anom, double *__restrict__ sg_e,
+                                                                  const unsigned long long *__restrict__ cs_val, const uint8_t *__restrict__ cs_flag,
+                                                                  const uint8_t *__restrict__ cs_has, uint32_t cs_cap, const uint32_t *__restrict__ cs_src,
+                                                                  const unsigned long long *__restrict__ rs_val, const uint8_t *__restrict__ rs_flag) {
+  __shared__ double s_rcp[257];   // (the list_wave path: T <= 256)
+  const uint32_t T = (uint32_t)g.T;
+  const unsigned total = *count;
+  if (blockIdx.x * kSigmaBlock >= total) return;   // (the grid is sized from K, the list is ~2 % of it)
+  for (uint32_t i = threadIdx.x; i <= T; i += kSigmaBlock) s_rcp[i] = 1.0 / (double)i;
+  __syncthreads();
+  for (unsigned e = blockIdx.x * kSigmaBlock + threadIdx.x; e < total; e += gridDim.x * kSigmaBlock) {
+    const uint64_t k = list[e];
+    if (n_anom[k] == 0) continue;
+    // 1 = the series lies contiguous behind this list, 2 = behind the redo list (entry cs_src[e]; cells flagged 2 — their aggregate came
+    // from the overflow list — are read from the grid), 0 = the key's column of the grid                 (as k_dbscan_list_wave)
+    const uint8_t has = (cs_has != nullptr && e < cs_cap) ? cs_has[e] : (uint8_t)0;
+    const size_t src = has == 2 ? (size_t)cs_src[e] * T : (size_t)e * T;
+    const unsigned long long *pv = has == 1 ? cs_val + src : (has == 2 ? rs_val + src : g.val + k);
+    const uint8_t *pf = has == 1 ? cs_flag + src : (has == 2 ? rs_flag + src : g.flag + k);
+    double cn = 0.0, avg = 0.0, m2 = 0.0;
+    uint32_t n = 0;
+    // (OVF: a series from the redo list — a cell flagged 2 has its aggregate in the grid.  Only that instantiation has a global load
+    // inside the step; in the others nothing is younger than the prefetched batch, so the compiler waits with vmcnt(N > 0))
+    auto point = [&](auto ovf, uint32_t t, uint8_t fl, unsigned long long raw) {
+      if (fl & FLAG_PRESENT) {
+        if (decltype(ovf)::value && (fl & 2)) raw = g.val[(uint64_t)t * g.K + k];
+        const double xv = (double)raw;
+        n++;
+        cn = cn + 1.0;
+        const double d = xv - avg;
+        const double dn = div_by_count(d, cn, s_rcp[n]);     // == d / cn, bit for bit
+        avg = avg + dn;
+        m2 = m2 + d * (d - dn);
+      }
+    };
+    // the walk in batches of eight buckets, the next batch requested before the current one is worked on; once with a compile-time stride
+    // of 1 (contiguous series: the eight loads of a batch are adjacent, so they merge into 16-byte ones) and once with the grid's stride
+    auto walk = [&](auto contiguous, auto ovf) {
+      const size_t st = decltype(contiguous)::value ? (size_t)1 : (size_t)g.K;
+      uint8_t fa[8], fb[8];
+      unsigned long long va[8], vb[8];
+      const uint32_t full = T & ~7u;
+      if (full) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fa[j] = pf[(size_t)j * st]; va[j] = pv[(size_t)j * st]; }
+      }
+      for (uint32_t t0 = 0; t0 < full; t0 += 8) {
+        const uint32_t tn = t0 + 8 < full ? t0 + 8 : t0;   // (the last batch loads itself again: no branch around the loads)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fb[j] = pf[(size_t)(tn + j) * st]; vb[j] = pv[(size_t)(tn + j) * st]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) point(ovf, t0 + (uint32_t)j, fa[j], va[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fa[j] = fb[j]; va[j] = vb[j]; }
+      }
+      for (uint32_t t = full; t < T; ++t) point(ovf, t, pf[(size_t)t * st], pv[(size_t)t * st]);
+    };
+    if (has == 1) walk(std::true_type{}, std::false_type{});
+    else if (has == 2) walk(std::true_type{}, std::true_type{});
+    else walk(std::false_type{}, std::false_type{});
+    sg_e[e] = cn >= 2.0 ? sqrt(m2 / (cn - 1.0)) : 0.0;
+  }
+}
 template <int PPL>
 __global__ __launch_bounds__(kDbBlock) void k_emit_dbscan_wave(Grid g, Lattice L, const uint32_t *__restrict__ list,
                                                               const unsigned int *__restrict__ count, const uint32_t *__restrict__ n_anom,
@@ -551,7 +621,10 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
   unsigned long long *rs_val = nullptr; uint8_t *rs_flag = nullptr, *rs_has = nullptr; uint32_t rs_cap = 0;
   if (settled_by_stage0) {   // the list was started by pass C (its counters zeroed before Stage 0), with the listed keys' series contiguous behind it;
     // the keys it could not decide are on the redo list
-    const uint64_t rb = g.K < 1024 ? g.K : 1024;     // (grid-stride over the device-side redo count)
+#ifndef TAD_REDO_BLOCKS   // (measurement knob.  C4, ~1e4 redo keys: 512 workgroups 33.6 us, 1024 30.5, 2048 36.1, 4096 42.4 — more workgroups, more atomics on the list counter)
+#define TAD_REDO_BLOCKS 1024
+#endif
+    const uint64_t rb = g.K < TAD_REDO_BLOCKS ? g.K : TAD_REDO_BLOCKS;     // (grid-stride over the device-side redo count)
     dbscan_redo_series(g, scratch, &rs_val, &rs_flag, &rs_has, &rs_cap);
     hipLaunchKernelGGL(k_dbscan_scan_redo, dim3((unsigned)rb), dim3(kDbBlock), 0, s, g, eps, min_samples, st, dbscan_redo_list(g, scratch), count + 1, list, count,
                        cs_has, cs_cap, rs_val, rs_flag, rs_has, rs_cap, compact_src(g, scratch));
@@ -571,6 +644,13 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
 #define TAD_DBW(PPL) hipLaunchKernelGGL((k_dbscan_list_wave<PPL>), dim3((unsigned)blocks), dim3(kDbBlock), 0, s, g, eps, min_samples, list, count, st.n_anom, wave_list_sg(scratch, g), wave_list_am(scratch, g), cs_val, cs_flag, cs_has, cs_cap, compact_src(g, scratch), rs_val, rs_flag)
     if (g.T <= 64) TAD_DBW(1); else if (g.T <= 128) TAD_DBW(2); else if (g.T <= 192) TAD_DBW(3); else TAD_DBW(4);
 #undef TAD_DBW
+    if (st.n_anom != nullptr) {   // (the list emit is the only reader of the entries' stddev_samp, and it runs for jobs that count here)
+      const uint64_t sblocks = (g.K + kSigmaBlock - 1) / kSigmaBlock;
+      // (on the job's stream: forked onto a second stream beside the count scan it saved 5 us of its 30 — the two cross-stream dependencies
+      // cost what the overlap gives, profiles/r5_d10_*)
+      hipLaunchKernelGGL(k_dbscan_list_sigma, dim3((unsigned)(sblocks < 1024 ? sblocks : 1024)), dim3(kSigmaBlock), 0, s, g, list, count, st.n_anom,
+                         wave_list_sg(scratch, g), cs_val, cs_flag, cs_has, cs_cap, compact_src(g, scratch), rs_val, rs_flag);
+    }
     return 0;
   }
   SortRows rows{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
