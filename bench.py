@@ -24,10 +24,13 @@ achieved = 24 B/row x rows per launch / the kernel's average duration measured w
 engine's stream (tad_stats.ms_scatter); `traffic` = that kernel's HBM bytes per launch from the committed
 rocprofv3 PMC passes (profiles/pmc_latest.json: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE;
 separate --pmc runs of this same command).  `roofline.frac` prices the DOMINANT KERNEL; `roofline.frac_whole_run` is SURVEY.md 8d's own definition — (24 B x rows + 40 B x anomalies)
-per job over the WALL time of a step (`ms_per_step`, launch gaps and host round trips included) against the same peak.  `value` is a
-steady-state rate: the second and later job of a shape runs the one-synchronisation form (tad_stats.host_syncs = 1) on buffers that are
-in place; `cold` carries the FIRST job of the shape in the same process — allocations, the placement calibration of the record buffer
-(tad_stats.placement_*) and the three-synchronisation form included.
+per job over the WALL time of a step (`ms_per_step`, launch gaps and host round trips included) against the same peak.
+`value` is what a controller sees from a warm engine (controller.go:499-523: every CR is a new job on new data): the timed steps go
+ROUND ROBIN over `config.tables` (4) synthetic tables of the workload's shape with different seeds in different device buffers, so
+no step meets the columns of the step before it; `same_columns` is the old loop (one table, every step) beside it, `cold` the FIRST
+job of the engine in the process (allocations included).  `concurrency` (N = 1, default line): aggregate rows/s with 1 / 2 / 4 host
+threads submitting C2 jobs to the ONE engine (job contexts = stream pool, tad.h ABI 12), and the latency of C2 EWMA jobs submitted
+while a C3 ARIMA job runs.
 `cpu_baseline` = the oracle (numpy port of the reference
 job) timed on this box's host cores on a bounded sample.  ARIMA lines add `arima`: fits/s and the
 FP64 flop rate from the engine's Kalman-step counter (16 flop per step of the recursion the kernel executes; the
@@ -136,13 +139,97 @@ def pmc_traffic(kernel, name="pmc_latest.json"):
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
         k = d["kernels"][kernel]
-        once = ("k_synth", "k_place_probe")     # the table generator; the placement probe of the record buffer (first job of an engine only)
+        once = ("k_synth",)     # the table generator is not part of the job
         jf = sum(v["fetch_bytes"] for a, v in d["kernels"].items() if a not in once)
         jw = sum(v["write_bytes"] for a, v in d["kernels"].items() if a not in once)
         return {"bytes": k["fetch_bytes"] + k["write_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
                 "job_bytes": jf + jw, "job_fetch_bytes": jf, "job_write_bytes": jw, "source": d["source"]}
     except Exception:
         return None
+
+
+def concurrency_leg(eng, levels, serial_ms):
+    """Jobs in flight on ONE engine (tad.h ABI 12: job contexts = a pool of streams + workspaces; controller.go:199-201 runs four
+    workers).  (i) c host threads, each submitting C2 EWMA jobs on a table of its own: aggregate rows/s; (ii) C2 EWMA jobs submitted
+    while a C3 ARIMA job (~0.27 s of FP64, low-priority stream) runs: their latency, and what they cost the ARIMA job."""
+    import statistics
+    import threading
+    from theia_amd.engine import SYNTH_SEED
+    c2 = CONFIGS["c2"]
+    n, K, T = c2["rows"], c2["keys"], c2["buckets"]
+    nt = max(levels + [2])
+    tabs = [eng.synth(0, n, K, T, seed=SYNTH_SEED + 977 * (i + 11)) for i in range(nt)]
+    jobs = [eng.prepare("EWMA", t[0], t[1], t[2], K, agg_flow=c2["agg"], out="device") for t in tabs]
+    out = {"what": "c host threads submit C2 EWMA jobs (1e8 rows each, a table per thread) to one engine; value = aggregate rows/s over the "
+                   "wall time of all threads; serial_ms_per_step = this line's ms_per_step", "serial_ms_per_step": serial_ms, "levels": {}}
+    steps = 12
+    for c in levels:
+        ctxs = set()
+        for j in jobs[:c]:          # every context that will be used has its buffers
+            j.run().close()
+        bar = threading.Barrier(c + 1)
+
+        def work(i):
+            bar.wait()
+            for _ in range(steps):
+                r = jobs[i].run()
+                ctxs.add(r.stats["job_context"])
+                r.close()
+        if c > 1:       # warm the c contexts: c jobs at once
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(c)]
+            for th in ths:
+                th.start()
+            bar.wait()
+            for th in ths:
+                th.join()
+            bar = threading.Barrier(c + 1)
+            ctxs.clear()
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(c)]
+        for th in ths:
+            th.start()
+        bar.wait()
+        t0 = time.perf_counter()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t0
+        out["levels"][str(c)] = {"value": c * steps * n / dt, "ms_per_job_wall": dt * 1e3 / steps, "ms_per_job_amortised": dt * 1e3 / (steps * c),
+                                 "job_contexts_used": sorted(ctxs)}
+    base = out["levels"].get("1", {}).get("value")
+    if base:
+        for c, v in out["levels"].items():
+            v["vs_one_in_flight"] = v["value"] / base
+    # (ii) a short job next to a long one
+    arima = eng.prepare("ARIMA", tabs[0][0], tabs[0][1], tabs[0][2], K, agg_flow=c2["agg"], out="device")
+    t0 = time.perf_counter()
+    arima.run().close()          # alone (also: allocates the ARIMA workspace)
+    t0 = time.perf_counter()
+    arima.run().close()
+    alone_s = time.perf_counter() - t0
+    lat, box = [], {}
+
+    def long_job():
+        t = time.perf_counter()
+        r = arima.run()
+        box["s"] = time.perf_counter() - t
+        box["ctx"] = r.stats["job_context"]
+        r.close()
+    th = threading.Thread(target=long_job)
+    th.start()
+    time.sleep(0.03)
+    while th.is_alive():
+        t = time.perf_counter()
+        r = jobs[1].run()
+        lat.append((time.perf_counter() - t) * 1e3)
+        r.close()
+    th.join()
+    if lat:
+        lat = lat[:-1] or lat        # the last one may have outlived the ARIMA job
+    out["short_job_beside_long_job"] = {
+        "what": "C2 EWMA jobs submitted back to back by one thread while a C3 ARIMA job (same shape, another table) runs on another context's "
+                "low-priority stream",
+        "ewma_jobs": len(lat), "ewma_ms_p50": statistics.median(lat) if lat else None, "ewma_ms_max": max(lat) if lat else None,
+        "ewma_ms_alone": serial_ms, "arima_s_alone": alone_s, "arima_s_with_ewma_stream": box.get("s"), "arima_job_context": box.get("ctx")}
+    return out
 
 
 def launch_ranks(n):
@@ -185,6 +272,11 @@ def main():
                     help="with ONE rank: create the process group anyway and run the job's all-gather / all-to-all(v) through it "
                          "(backend nccl = RCCL on device tensors) — the single-GPU check of the N>1 RCCL path")
     ap.add_argument("--plan", default="", help="tad_plan overrides for A/B runs, e.g. histogram=exact,partition_pass=sort (default: the engine decides)")
+    ap.add_argument("--tables", type=int, default=4, help="synthetic tables of the workload's shape the timed steps go round robin over "
+                                                           "(different seeds, different device buffers); 1 = the same columns every step")
+    ap.add_argument("--c5-shape", default="", help="N > 1: run the other_configs.c5 leg (BASELINE configs[4], key- and row-sharded) on a table of "
+                                                     "ROWS,KEYS,BUCKETS in total instead of 1e9,1e6,250, whatever the headline is (reduced-size tests)")
+    ap.add_argument("--concurrency", default="1,2,4", help="N = 1 default line: host threads submitting C2 jobs to the one engine (job contexts); '' = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU sample (0 = chosen from the host's core count)")
@@ -202,6 +294,7 @@ def main():
     import torch.distributed as dist
     from theia_amd import TadEngine
     from theia_amd import distributed as td
+    from theia_amd.engine import SYNTH_SEED
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -227,6 +320,11 @@ def main():
         else:
             dist.init_process_group(backend)
     coll_dev = dev if (grouped and backend == "nccl") else None
+    ranks_seen = 1
+    if grouped:     # evidence that the collectives of this line really crossed `world` processes: every rank contributes its rank id
+        ids = [torch.zeros(1, dtype=torch.int64, device=coll_dev if coll_dev is not None else "cpu") for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=coll_dev if coll_dev is not None else "cpu"))
+        ranks_seen = len({int(x.item()) for x in ids})
 
     cfg = dict(CONFIGS[args.config])
     strong = args.config == "c5"
@@ -246,38 +344,43 @@ def main():
     eng = TadEngine(device=dev.index, plan=plan)
     reducer = td.JobReducer(device=coll_dev)
 
-    def make_table(n, K, T, ingest):
+    def make_table(n, K, T, ingest, index=0):
         key = torch.empty(n, dtype=torch.int64, device=dev)
         tend = torch.empty(n, dtype=torch.int64, device=dev)
         val = torch.empty(n, dtype=torch.int64, device=dev)
         # ingest=keys: local key ids 0..K-1 of this rank's shard (global key = local * world + rank);
         # ingest=rows: an arbitrary slice of the rows, global key ids over all K * world keys
-        eng.synth(rank * n, n, K * (world if ingest == "rows" else 1), T, into=(key, tend, val))
+        # index > 0: another table of the same shape (another seed, other buffers) for the fresh-columns loop
+        eng.synth(rank * n, n, K * (world if ingest == "rows" else 1), T, seed=SYNTH_SEED + 977 * index, into=(key, tend, val))
         return key, tend, val
 
-    def run_config(algos, n, K, T, agg, steps, warmup, ingest="keys", host_input=False, hint=False):
-        """W warm-up steps, then exactly `steps` timed steps between synchronisation points; one step = one job per algo."""
-        key, tend, val = make_table(n, K, T, ingest)
+    def run_config(algos, n, K, T, agg, steps, warmup, ingest="keys", host_input=False, hint=False, tables=1, same_columns_steps=0):
+        """W warm-up steps, then exactly `steps` timed steps between synchronisation points; one step = one job per algo.  With
+        tables > 1 step i runs on table i mod tables (different rows in different device buffers: no step meets the columns of the
+        step before it); same_columns_steps > 0 adds a second timed loop on table 0 alone."""
+        tabs = [make_table(n, K, T, ingest, i) for i in range(tables)]
         lattice = (1660202814, 60, T) if hint else None
         if host_input:
-            hkey, htend, hval = (x.cpu().pin_memory() for x in (key, tend, val))
+            htabs = [tuple(x.cpu().pin_memory() for x in tab) for tab in tabs]
         pending = [None]
+        rccl = {"allgather_us": [], "alltoall_ms": [], "alltoall_bytes": 0, "exchanges": 0}
 
         dump = {}
 
         prepared = {}   # the device-resident job of a step, its two C structs built once (TadEngine.prepare): a step = the bare tad_run call
 
-        def one_job(algo, k_, t_, v_):
+        def one_job(algo, ti, k_, t_, v_):
             if host_input:
-                return eng.run(algo, hkey, htend, hval, K, agg_flow=agg, lattice=lattice, out="host")
+                return eng.run(algo, *htabs[ti], K, agg_flow=agg, lattice=lattice, out="host")
             if dump.get("on") or ingest == "rows":
                 return eng.run(algo, k_, t_, v_, K, agg_flow=agg, lattice=lattice, out="host" if dump.get("on") else "device")
-            if algo not in prepared:
-                prepared[algo] = eng.prepare(algo, k_, t_, v_, K, agg_flow=agg, lattice=lattice, out="device")
-            return prepared[algo].run()
+            if (algo, ti) not in prepared:
+                prepared[(algo, ti)] = eng.prepare(algo, k_, t_, v_, K, agg_flow=agg, lattice=lattice, out="device")
+            return prepared[(algo, ti)].run()
 
-        def step():
+        def step(ti=0):
             stats, glob = [], None
+            key, tend, val = tabs[ti]
             if ingest == "rows":
                 # Stage 0 on the local slice -> partial points; all-to-all(v) to the owners (RCCL over xGMI); the owners run the
                 # job(s) on the partials (re-aggregating sums of sums is bit-exact)
@@ -285,20 +388,27 @@ def main():
                 ptr = pts.device_pointers()
                 cols = [torch.as_tensor(td.DeviceColumn(ptr[f], pts.n_points), device=dev) for f in ("key_id", "flow_end_s", "value")]
                 # bucketed by owner on the GPU (tad_shard_rows), shipped with one all-to-all(v) per column
+                tx = time.perf_counter()
                 lk, lt, lv = td.exchange_rows_device(eng, cols[0], cols[1], cols[2], world, rank,
                                                      host_collective=(coll_dev is None and grouped))
+                torch.cuda.synchronize()
+                rccl["alltoall_ms"].append((time.perf_counter() - tx) * 1e3)
+                rccl["alltoall_bytes"] = 24 * int(pts.n_points)      # sent by this rank per exchange (three 8-byte columns per partial point)
+                rccl["exchanges"] += 1
                 pts.close()
             else:
                 lk, lt, lv = key, tend, val
             for algo in algos:
-                res = one_job(algo, lk, lt, lv)
+                res = one_job(algo, ti, lk, lt, lv)
                 st = res.stats
                 # RCCL over xGMI: one 9-double all-gather (counters + moments) per job, started now and collected after the
                 # NEXT job has been issued, so its latency hides behind that job; the last one is collected inside the timed region
                 if grouped:
                     nxt = reducer.start(st)
                     if pending[0] is not None:
+                        tg = time.perf_counter()
                         glob = pending[0].result()
+                        rccl["allgather_us"].append((time.perf_counter() - tg) * 1e6)
                     pending[0] = nxt
                 if dump.get("on"):
                     h = res.to_host()
@@ -309,56 +419,81 @@ def main():
             return stats, glob
 
         def drain():
-            g = pending[0].result() if pending[0] is not None else None
+            g = None
+            if pending[0] is not None:
+                tg = time.perf_counter()
+                g = pending[0].result()
+                rccl["allgather_us"].append((time.perf_counter() - tg) * 1e6)
             pending[0] = None
             return g
+
+        def timed_loop(count, table_of):
+            acc = [{"ms_meta": 0.0, "ms_stage0": 0.0, "ms_scatter": 0.0, "ms_detect": 0.0, "ms_total": 0.0} for _ in algos]
+            glob, stats = None, None
+            if grouped:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(count):
+                stats, g2 = step(table_of(i))
+                glob = g2 or glob
+                for a, st in zip(acc, stats):
+                    for f in a:
+                        a[f] += st[f]
+            if grouped:
+                glob = drain() or glob          # the last job's reduction completes inside the timed region
+            torch.cuda.synchronize()
+            if grouped:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            dt_rank = dt
+            if grouped:
+                tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
+                lo = tt.clone()
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                dt, dt_rank = float(tt.item()), float(lo.item())
+            return dt, dt_rank, acc, stats, glob
 
         glob = None
         cold = None
         for w in range(warmup):
-            if w == 0:      # the first job of this shape in this process: allocations, placement calibration, three host synchronisations
+            if w == 0:      # the first job of this shape in this process: allocations, three host synchronisations
                 torch.cuda.synchronize()
                 tc = time.perf_counter()
-            stats, glob = step()
+            stats, glob = step(w % tables)
             if w == 0:
                 torch.cuda.synchronize()
                 cold = {"ms_first_step": (time.perf_counter() - tc) * 1e3, "host_syncs_per_job": [st.get("host_syncs") for st in stats],
                         "stage0_attempts": [st.get("stage0_attempts") for st in stats],
-                        "placement": {k: stats[0].get("placement_" + k) for k in ("candidates", "ms", "kept_ms", "worst_ms")},
-                        "what": "the first step of this shape in the process (untimed warm-up step 1): buffer allocations, the placement "
-                                "calibration of pass B's record buffer and the three-synchronisation form of every job included"}
+                        "what": "the first step of this shape in the process (untimed warm-up step 1): the job context's buffer allocations "
+                                "included (the library's code objects are loaded by tad_engine_create)"}
+        for ti in range(min(warmup, 1) * tables):      # every table's prepared job exists before the timed region (a struct build, no GPU work)
+            if not host_input and ingest == "keys" and all((a, ti) in prepared for a in algos):
+                continue
+            step(ti)
         if grouped:
             glob = drain() or glob
-            dist.barrier()
-        torch.cuda.synchronize()
-        acc = [{"ms_meta": 0.0, "ms_stage0": 0.0, "ms_scatter": 0.0, "ms_detect": 0.0, "ms_total": 0.0} for _ in algos]
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            stats, g2 = step()
-            glob = g2 or glob
-            for a, st in zip(acc, stats):
-                for f in a:
-                    a[f] += st[f]
-        if grouped:
-            glob = drain() or glob          # the last job's reduction completes inside the timed region
-        torch.cuda.synchronize()
-        if grouped:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if grouped:
-            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        else:
+        rccl["allgather_us"].clear()
+        rccl["alltoall_ms"].clear()
+        dt, dt_min_rank, acc, stats, g2 = timed_loop(steps, lambda i: i % tables)
+        glob = g2 or glob
+        same = None
+        if same_columns_steps:
+            sdt, _, _, _, _ = timed_loop(same_columns_steps, lambda i: 0)
+            same = {"ms_per_step": sdt * 1e3 / same_columns_steps, "steps": same_columns_steps,
+                    "what": "the same loop on ONE table (every step meets the previous step's columns): the rounds-1-5 headline loop"}
+        if not grouped:
             glob = td.JobReducer().reduce(stats[-1])
         if args.dump_rows:
             dump["on"] = True
-            step()
+            step(0)
             if grouped:
                 drain()
             np.savez(args.dump_rows + ".rank%d.npz" % rank, **{"%s_%s" % (a, f): v for a in algos for f, v in dump[a].items()})
-        del key, tend, val
-        return dict(dt=dt, stats=stats, acc=acc, glob=glob, steps=steps, warmup=warmup, n=n, K=K, T=T, agg=agg, algos=algos, cold=cold)
+        del tabs
+        return dict(dt=dt, dt_min_rank=dt_min_rank, stats=stats, acc=acc, glob=glob, steps=steps, warmup=warmup, n=n, K=K, T=T, agg=agg, algos=algos, cold=cold,
+                    tables=tables, same=same, rccl=rccl)
 
     def describe(r, host_input=False, ingest="keys", hint=False):
         """the JSON fields of one measured config (rank 0)"""
@@ -394,8 +529,27 @@ def main():
                          "host_syncs_per_job": [st.get("host_syncs") for st in r["stats"]],
                          "hbm_frac_whole_job": (len(algos) * BYTES_PER_ROW * n + BYTES_PER_ANOMALY * A) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        out["config"]["tables"] = r.get("tables", 1)
+        out["config"]["columns"] = ("step i runs on table i mod %d: tables of this shape with different seeds in different device buffers — no step "
+                                    "meets the columns of the step before it" % r["tables"]) if r.get("tables", 1) > 1 else "one table, every step"
         if r.get("cold"):
             out["cold"] = r["cold"]
+        if r.get("same"):
+            out["same_columns"] = dict(r["same"], ratio_to_ms_per_step=r["same"]["ms_per_step"] / ms_step)
+        if grouped:
+            import statistics
+            rc = r["rccl"]
+            out["rccl"] = {"backend": "%s (%s)" % (backend, "RCCL, device tensors" if backend == "nccl" else "host tensors: ranks share GPUs"),
+                           "world": world, "ranks_seen": ranks_seen,
+                           "allgather_us_p50": statistics.median(rc["allgather_us"]) if rc["allgather_us"] else None,
+                           "allgather_what": "host wait for the 9-double all-gather of a job (counters + moments), collected after the NEXT job "
+                                             "was issued; %d collected in the timed region" % len(rc["allgather_us"]),
+                           "alltoall_bytes": rc["alltoall_bytes"] if ingest == "rows" else 0,
+                           "alltoall_ms": statistics.median(rc["alltoall_ms"]) if rc["alltoall_ms"] else None,
+                           "alltoall_what": "tad_shard_rows + one all-to-all(v) per column of the partial points (24 B each), wall time on rank 0"
+                                            if ingest == "rows" else "none: rows arrive key-sharded",
+                           "per_rank_ms_per_step": {"min": r["dt_min_rank"] * 1e3 / steps, "max": ms_step,
+                                                    "what": "timed region of the fastest and of the slowest rank (key-size imbalance)"}}
         g = r["glob"]
         out["result"] = {"anomalies": g["n_anomalies"], "keys": g["n_keys"], "points": g["n_points"], "rows_used": g["rows_used"],
                          "global_mean": g["global_mean"], "global_sigma": g["global_sigma"]}
@@ -422,8 +576,11 @@ def main():
                                        "frac_whole_run": flops / (ms_step * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
         return out
 
+    # the fresh-columns loop wherever four tables of the shape are cheap (<= 1e8 rows: 9.6 GB); C5 keeps one table
+    multi = args.tables > 1 and not strong and not args.host_input and args.ingest == "keys" and cfg["rows"] <= 100_000_000 and not args.dump_rows
     head = run_config(cfg["algos"], cfg["rows"], cfg["keys"], cfg["buckets"], cfg["agg"], args.steps, args.warmup,
-                      ingest=args.ingest, host_input=args.host_input, hint=args.hint_lattice)
+                      ingest=args.ingest, host_input=args.host_input, hint=args.hint_lattice, tables=args.tables if multi else 1,
+                      same_columns_steps=max(1, args.steps // 2) if multi else 0)
     out = None
     if rank == 0:
         d = describe(head, args.host_input, args.ingest, args.hint_lattice)
@@ -431,8 +588,9 @@ def main():
                "ms_per_step": d["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
                "dtype": "u64 (aggregates) + f64 (detectors)", "data": "synthetic", "config": d["config"], "roofline": d["roofline"],
                "pipeline": d["pipeline"], "result": d["result"]}
-        if "cold" in d:
-            out["cold"] = d["cold"]
+        for f in ("cold", "same_columns", "rccl"):
+            if f in d:
+                out[f] = d[f]
         out["config"]["baseline_config"] = args.config
         if "arima" in d:
             out["arima"] = d["arima"]
@@ -469,6 +627,32 @@ def main():
                     d["cpu_baseline"] = {"error": repr(exc)[:200]}
             others[name] = d
         out["other_configs"] = others
+    if world > 1 and (headline_is_c2 or args.c5_shape) and not args.no_other_configs and not args.host_input and args.ingest == "keys":
+        # BASELINE.json configs[4], the only config it names for 8 GPUs: the 1e9-row / 1e6-key table split over the N ranks (strong
+        # scaling), one step = EWMA then ARIMA on the rank's shard — key-sharded (no data-path collective) and row-sharded
+        # (tad_aggregate + one all-to-all(v) of the partial points to the key owners: the shuffle of anomaly_detection.py:664-684)
+        c = dict(CONFIGS["c5"])
+        if args.c5_shape:
+            c["rows"], c["keys"], c["buckets"] = (int(x) for x in args.c5_shape.split(","))
+        c5 = {}
+        for ing in ("keys", "rows"):
+            try:
+                r = run_config(c["algos"], c["rows"] // world, c["keys"] // world, c["buckets"], c["agg"], 1, 1, ingest=ing)
+                if rank == 0:
+                    d = describe(r, ingest=ing)
+                    d["baseline_config"] = "c5"
+                    d["scaling"] = "strong: %d rows / %d keys in total, 1/%d of them per rank" % (c["rows"], c["keys"], world)
+                    c5[ing] = d
+            except Exception as exc:      # the headline line must still be printed
+                c5[ing] = {"baseline_config": "c5", "error": repr(exc)[:300]}
+                torch.cuda.empty_cache()
+        if rank == 0:
+            out["other_configs"] = {"c5": c5}
+    if world == 1 and headline_is_c2 and args.concurrency and not args.no_other_configs and not args.host_input and args.ingest == "keys":
+        try:
+            out["concurrency"] = concurrency_leg(eng, [int(x) for x in args.concurrency.split(",") if x], out["ms_per_step"])
+        except Exception as exc:
+            out["concurrency"] = {"error": repr(exc)[:300]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             algo = cfg["algos"][-1] if len(cfg["algos"]) > 1 else cfg["algos"][0]

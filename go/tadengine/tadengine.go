@@ -54,10 +54,11 @@ type IllegalArgument struct{ Msg string }
 func (e IllegalArgument) Error() string { return e.Msg }
 
 // Engine owns one GPU.  Run may be called from the controller's 4 workers concurrently
-// (controller.go:199-201); calls on one engine serialise inside the library.
+// (controller.go:199-201): each call takes one of the engine's job contexts (own HIP stream and workspace, tad.h ABI 12), so up
+// to MaxJobsInFlight jobs overlap on the GPU; further callers wait inside the library.
 type Engine struct{ h *C.tad_engine }
 
-// Plan mirrors tad_plan (tad.h, ABI 10): plan overrides of an engine, every field 0 = the engine decides — what the controller
+// Plan mirrors tad_plan (tad.h, ABI 12): plan overrides of an engine, every field 0 = the engine decides — what the controller
 // uses.  Tests and A/B measurements force a strategy with it; the library reads no environment variable.  A Go struct, not
 // C.tad_plan: cgo types are private to this package, callers in other packages could not construct one.
 type Plan struct {
@@ -68,28 +69,28 @@ type Plan struct {
 	SparseClasses int32  // 1 = always run a sparse table as length classes of keys
 	EwmaEmit      int32  // 1 = lane-per-key emit for the EWMA job
 	EwmaEmitRows  uint32 // LDS rows per wavefront of the staged EWMA emit (<= 4096)
-	OneSync       int32  // 1 = never run a job in the one-synchronisation form
 	TileCells     int32  // 1 = 8-byte tile cells in the settle mode of DBSCAN jobs with max
 	SparseSort    int32  // sparse tables: 1 = always the LSD radix sort, 2 = the partition pass + LDS sort wherever its plan fits (ABI 9)
-	Placement     int32  // 1 = never time / re-allocate pass B's record buffer (ABI 11; Stats.PlacementCandidates says what a job did)
 }
 
 func (p Plan) c() C.tad_plan {
 	return C.tad_plan{stage0: C.int32_t(p.Stage0), partition_pass: C.int32_t(p.PartitionPass), histogram: C.int32_t(p.Histogram),
 		sparse: C.int32_t(p.Sparse), sparse_classes: C.int32_t(p.SparseClasses), ewma_emit: C.int32_t(p.EwmaEmit),
-		ewma_emit_rows: C.uint32_t(p.EwmaEmitRows), one_sync: C.int32_t(p.OneSync), tile_cells: C.int32_t(p.TileCells),
-		sparse_sort: C.int32_t(p.SparseSort), placement: C.int32_t(p.Placement)}
+		ewma_emit_rows: C.uint32_t(p.EwmaEmitRows), tile_cells: C.int32_t(p.TileCells), sparse_sort: C.int32_t(p.SparseSort)}
 }
 
 func NewEngine(device int) (*Engine, error) { return NewEngineWithPlan(device, Plan{}) }
 
-// NewEngineWithPlan creates the engine with plan overrides in tad_engine_opts.plan.
-func NewEngineWithPlan(device int, plan Plan) (*Engine, error) {
+// NewEngineWithPlan creates the engine with plan overrides in tad_engine_opts.plan and the default number of job contexts (4).
+func NewEngineWithPlan(device int, plan Plan) (*Engine, error) { return NewEngineWithOptions(device, plan, 0) }
+
+// NewEngineWithOptions: maxJobsInFlight = tad_engine_opts.max_jobs_in_flight (0 = 4, the controller's worker count; 1 = jobs serialise).
+func NewEngineWithOptions(device int, plan Plan, maxJobsInFlight int) (*Engine, error) {
 	// the header this file was compiled against and the library the process loaded must be the same ABI (struct layouts!)
 	if v := int(C.tad_abi_version()); v != int(C.TAD_ABI_VERSION) {
 		return nil, fmt.Errorf("libtad_mi355x.so ABI %d != tad.h ABI %d", v, int(C.TAD_ABI_VERSION))
 	}
-	opts := C.tad_engine_opts{device: C.int32_t(device), plan: plan.c()}
+	opts := C.tad_engine_opts{device: C.int32_t(device), plan: plan.c(), max_jobs_in_flight: C.int32_t(maxJobsInFlight)}
 	var h *C.tad_engine
 	if rc := C.tad_engine_create(&opts, &h); rc != C.TAD_OK {
 		return nil, fmt.Errorf("tad_engine_create: %s (code %d)", C.GoString(C.tad_last_error(nil)), int(rc))
@@ -148,9 +149,8 @@ type Stats struct {
 	ArimaNanFits                                             uint64 // ARIMA fits voided by a non-finite likelihood (tad.h: tad_stats.arima_nan_fits)
 	MsTotal                                                  float32
 	Stage0Path                                               int32 // how Stage 0 ran (tad.h: tad_stats.stage0_path), for the controller's logs
-	HostSyncs                                                int32 // 1 = the one-synchronisation form (tad.h: tad_stats.host_syncs, ABI 8)
-	PlacementCandidates                                      int32   // allocations of the record buffer this job timed (tad.h: tad_stats.placement_*, ABI 11) ...
-	PlacementMs                                              float32 // ... and the host time it spent on them: non-zero only in the first big job of an engine
+	HostSyncs                                                int32 // host synchronisations of the job (tad.h: tad_stats.host_syncs): 3, or 2 with a lattice hint
+	JobContext                                               int32 // which of the engine's job contexts ran it (tad.h: tad_stats.job_context, ABI 12)
 }
 
 // cColumn copies a Go slice into C memory: cgo forbids handing Go pointers nested in a C struct, and the
@@ -230,7 +230,7 @@ func (e *Engine) Run(job Job, cols Columns) ([]Row, Stats, error) {
 	}
 	st = Stats{uint64(res.stats.rows_in), uint64(res.stats.rows_used), uint64(res.stats.n_keys), uint64(res.stats.n_points),
 		uint64(res.stats.n_anomalies), uint64(res.stats.keys_no_result), uint64(res.stats.arima_nan_fits), float32(res.stats.ms_total),
-		int32(res.stats.stage0_path), int32(res.stats.host_syncs), int32(res.stats.placement_candidates), float32(res.stats.placement_ms)}
+		int32(res.stats.stage0_path), int32(res.stats.host_syncs), int32(res.stats.job_context)}
 	return rows, st, nil
 }
 
@@ -550,9 +550,22 @@ func (s *State) Export(numKeys uint64) (n []uint32, avg, m2, ewma []float64, las
 	return
 }
 
-// Progress feeds Status.CompletedStages / TotalStages (controller.go:426-453).
+// Progress feeds Status.CompletedStages / TotalStages (controller.go:426-453): the sum over the jobs in flight.
 func (e *Engine) Progress() (done, total int) {
 	var d, t C.int32_t
 	C.tad_progress(e.h, &d, &t)
 	return int(d), int(t)
 }
+
+// JobProgress is Progress for ONE job: the one whose Job.ID is id (Status.SparkApplication, controller.go:622); total == 0 when no
+// such job is in flight.
+func (e *Engine) JobProgress(id string) (done, total int) {
+	cid := C.CString(id)
+	defer C.free(unsafe.Pointer(cid))
+	var d, t C.int32_t
+	C.tad_job_progress(e.h, cid, &d, &t)
+	return int(d), int(t)
+}
+
+// JobsInFlight: job contexts busy right now.
+func (e *Engine) JobsInFlight() int { return int(C.tad_jobs_in_flight(e.h)) }

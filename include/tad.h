@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAD_ABI_VERSION 11
+#define TAD_ABI_VERSION 12
 #define TAD_KEY_SKIP UINT64_MAX /* row (or its second key) does not take part */
 
 /* ---- error codes (0 = ok, negative = failure; text via tad_last_error) ---- */
@@ -67,7 +67,7 @@ typedef enum { TAD_MEM_HOST = 0, TAD_MEM_DEVICE = 1 } tad_mem;
 #define TAD_FLAG_EMIT_ALL_POINTS 1u /* result = every point (plotDF before the filter of :394),
                                        with its verdict in tad_result.anomaly; for inspection/tests */
 
-typedef struct tad_engine tad_engine; /* opaque; one per GPU */
+typedef struct tad_engine tad_engine; /* opaque; one per GPU; runs up to max_jobs_in_flight jobs concurrently (ABI 12) */
 
 /* Plan overrides (ABI 7).  Every field 0 = the engine decides from the shape of the batch, which is what a production host
  * passes.  A non-zero field forces one of the strategies the engine would otherwise choose between: the parity tests run
@@ -82,20 +82,28 @@ typedef struct {
   int32_t sparse_classes;    /* 1 = always run a sparse table as length classes of keys */
   int32_t ewma_emit;         /* 1 = lane-per-key emit for the EWMA job instead of the LDS-staged one */
   uint32_t ewma_emit_rows;   /* LDS rows per wavefront of the staged EWMA emit (<= 4096); 0 = sized from the row count */
-  int32_t one_sync;          /* 1 = never run a job in the one-synchronisation form (ABI 8; see tad_stats.host_syncs) */
+  int32_t reserved0;         /* must be 0 (ABI 8-11: one_sync — the one-synchronisation form of a job was removed in ABI 12: a placement-neutral
+                                A/B put it at 1.0 % of a C2 / C4 job, profiles/r6_a1_ab1_*.log) */
   int32_t tile_cells;        /* 1 = 8-byte tile cells in the settle mode of DBSCAN jobs with `max` (ABI 8; default: 32-bit cells, value + 1) */
   int32_t sparse_sort;       /* sparse tables (ABI 9; was `reserved`): 1 = always the LSD radix sort, 2 = the partition pass + LDS sort wherever its plan fits
                                 (0: when pass A ran with its key-bin histogram, i.e. >= 2^22 rows) */
-  int32_t placement;         /* ABI 11: 1 = never time / re-allocate pass B's record buffer (tad_stats.placement_*): the calibration holds up to
-                                eight further allocations of the buffer's size (<= 16 GB, <= half the workspace limit) for a few ms in the first
-                                big job of an engine — a host that shares the GPU with other processes may prefer the first allocation as it is */
+  int32_t reserved1;         /* must be 0 (ABI 11: placement — the placement search of pass B's record buffer was removed in ABI 12: 7-21 ms per
+                                search to win <= 0.04 ms per job on the SAME column buffers; a controller brings new columns with every job,
+                                profiles/r6_a1_cold_*.log) */
 } tad_plan;
 
 typedef struct {
   int32_t device;            /* HIP device ordinal */
   void *stream;              /* hipStream_t to run on, or NULL: the engine creates its own */
-  uint64_t workspace_limit;  /* bytes of HBM the engine may use for its grid; 0 = 3/4 of free */
+  uint64_t workspace_limit;  /* bytes of HBM ONE job may use for its grid and Stage-0 buffers; 0 = 3/4 of what is free at create.  Per job in
+                                flight: contexts keep their (grow-only) buffers between jobs, and when an allocation fails the idle contexts'
+                                buffers are given back to the device before the job fails */
   tad_plan plan;             /* all zero in production */
+  int32_t max_jobs_in_flight;/* ABI 12: job contexts (own HIP stream, events, workspace) the engine may create — tad_run calls from that many
+                                threads run concurrently on the GPU, further callers wait for a context.  0 = 4 (controller.go:199-201 runs four
+                                workers; Spark ran one pod per job), 1 = jobs serialise (ABI <= 11), max 16.  Forced to 1 when `stream` is
+                                given.  Contexts are created on demand: a serial caller only ever uses the first */
+  int32_t reserved;          /* must be 0 */
 } tad_engine_opts;
 
 /* Mirrors the job's argument vector (anomaly_detection.py:781-870). */
@@ -173,19 +181,9 @@ typedef struct {
   int32_t stage0_attempts; /* times Stage 0 ran before it settled: 1 normally; more after a wrong lattice hint, a sampled lattice or
                               a sampled histogram that proved too optimistic (every fallback is exact), an overflow-list fallback */
   int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/8 of pass A's reads) */
-  int32_t host_syncs;      /* ABI 8: host synchronisations of the attempt that produced the result.  3 = lattice derivation, row count,
-                              result; 1 = the one-synchronisation form: a job of the same shape (rows, keys, algorithm, filters) as the
-                              engine's previous one, device-resident in and out, is issued with that job's lattice and row capacity while
-                              the device checks both (the lattice against pass A's own derivation, the row total against the block) —
-                              a miss discards the output and reruns the 3-synchronisation form (stage0_attempts counts it) */
-  int32_t placement_candidates; /* ABI 11: allocations of pass B's record buffer THIS job timed before it kept one (0 = the buffer was in
-                              place already, or the table is small).  Pass B's rate depends on where that buffer landed in physical memory
-                              (same requests, same hits and misses, slower service by the memory side: profiles/r5_p*_placement_*); a job
-                              that (re)allocates the buffer — or brings other columns than it was chosen for — times its own pass B into it and
-                              into further allocations made while the earlier ones are held, keeps the fastest, frees the rest */
-  float placement_ms;      /* host wall time this job spent doing that (allocations + probe launches), 0 when placement_candidates is 0 */
-  float placement_kept_ms; /* pass-B time into the allocation kept ... */
-  float placement_worst_ms;/* ... and of the slowest candidate seen: kept ~ worst means this box offered no faster kind */
+  int32_t host_syncs;      /* host synchronisations of the attempt that produced the result: 3 = lattice derivation, row count, result;
+                              2 with a lattice hint (or an empty batch) */
+  int32_t job_context;     /* ABI 12: index of the job context (stream + workspace) that ran the job; 0 for a serial caller */
 } tad_stats;
 
 /* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).
@@ -216,8 +214,10 @@ int tad_engine_set_plan(tad_engine *e, const tad_plan *plan);
 const char *tad_last_error(tad_engine *e);
 
 /* ---- the job: replaces the SparkApplication run (anomaly_detection.py:647-710) ----
- * Callable from several OS threads (controller.go:199-201 runs 4 workers): runs on one engine
- * serialise on an internal mutex.  out_memory selects host or device result arrays. */
+ * Callable from several OS threads (controller.go:199-201 runs 4 workers): each call takes one of the engine's job contexts and runs
+ * on that context's stream, so up to max_jobs_in_flight jobs overlap on the GPU (a short EWMA job does not queue behind a long ARIMA
+ * job: ARIMA jobs run on a low-priority stream); callers beyond that wait for a context.  Results are bit-identical to a serial run
+ * (contexts share no buffers).  out_memory selects host or device result arrays. */
 int tad_run(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory,
             tad_result **out);
 void tad_result_free(tad_engine *e, tad_result *r);
@@ -315,8 +315,12 @@ int tad_run_stream(tad_engine *e, tad_state *s, const tad_job *job, const tad_co
                    tad_result **out);
 
 /* Stage counter for Status.CompletedStages / TotalStages (controller.go:426-453); callable while
- * tad_run executes on another thread. */
+ * tad_run executes on another thread.  tad_progress: the sum over the jobs in flight (with none: the job that finished last).
+ * tad_job_progress (ABI 12): the job whose tad_job.id equals `id`; *total = 0 when no such job is in flight (finished or not yet
+ * admitted).  tad_jobs_in_flight: contexts busy right now. */
 int tad_progress(tad_engine *e, int32_t *done, int32_t *total);
+int tad_job_progress(tad_engine *e, const char *id, int32_t *done, int32_t *total);
+int tad_jobs_in_flight(tad_engine *e);
 
 /* ---- per-series entry points: the reference's pure functions, one key, values in time order.
  * Same device kernels as tad_run (a 1-key series table).  x, out arrays are HOST memory. ---- */

@@ -124,6 +124,26 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     assert "other_configs" not in d
 
 
+def test_bench_gpus_2_default_line_carries_c5_and_rccl_evidence():
+    """What the driver's `bench.py --gpus N` must put on the line at N > 1 (reduced sizes here, two ranks on one GPU over gloo): the
+    weak-scaled headline, BASELINE configs[4] (C5: EWMA then ARIMA, strong scaling) key-sharded AND row-sharded in other_configs, and
+    the evidence that the collectives crossed ranks: ranks seen, all-gather wait, all-to-all bytes / time, per-rank step times."""
+    d = _self_launched(["--rows", "2000000", "--keys", "2000", "--steps", "3", "--warmup", "1", "--c5-shape", "600000,600,60"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["tables"] == 4
+    rc = d["rccl"]
+    assert rc["world"] == 2 and rc["ranks_seen"] == 2 and rc["allgather_us_p50"] > 0 and rc["alltoall_bytes"] == 0
+    assert 0 < rc["per_rank_ms_per_step"]["min"] <= rc["per_rank_ms_per_step"]["max"] == d["ms_per_step"]
+    c5 = d["other_configs"]["c5"]
+    for ing in ("keys", "rows"):
+        c = c5[ing]
+        assert "error" not in c, c
+        assert c["config"]["algo"] == "EWMA+ARIMA" and c["result"]["keys"] == 600 and c["rccl"]["ranks_seen"] == 2
+        assert c["scaling"].startswith("strong") and c["config"]["rows_per_gpu"] == 300000
+    assert c5["rows"]["rccl"]["alltoall_bytes"] > 0 and c5["rows"]["rccl"]["alltoall_ms"] > 0 and c5["keys"]["rccl"]["alltoall_bytes"] == 0
+    assert "row-sharded x2" in c5["rows"]["config"]["parallelism"]
+    assert c5["rows"]["result"]["rows_used"] == c5["keys"]["result"]["rows_used"] == 600000
+
+
 def test_bench_c5_gpus_2_row_sharded_starts_two_ranks_by_itself():
     d = _self_launched(["--config", "c5", "--rows", "300000", "--keys", "300", "--buckets", "60", "--steps", "1", "--warmup", "0",
                         "--ingest", "rows"])

@@ -433,27 +433,33 @@ def test_device_resident_inputs_and_outputs(engine):
 
 
 def test_concurrent_runs_from_four_threads(engine):
-    # controller.go:199-201 runs 4 workers; cgo pins an OS thread per call.  Runs on one engine serialise inside the
-    # library: four threads with different jobs must each get exactly their own result.
+    # controller.go:199-201 runs 4 workers; cgo pins an OS thread per call.  Since ABI 12 each call runs on a job context of its own
+    # (stream + workspace): four threads with different jobs — three detectors mixed — run concurrently and must each get exactly
+    # their own result, bit for bit what a serial run gives.
     import threading
     from oracle import arima_oracle as ao
     series = [(orc.synth_rows(77 * i, 40, 1, 40)[2]) for i in range(4)]
     series_want = [ao.calculate_arima_exact(x) for x in series]
     series_got = [None] * 4
     jobs = []
-    for i, algo in enumerate(["EWMA", "DBSCAN", "EWMA", "DBSCAN"]):
-        k, t, v = orc.synth_rows(1000 * i, 60000 + 7000 * i, 50 + 10 * i, 40)
-        jobs.append((algo, k, t, v, 50 + 10 * i, orc.run_job(algo, k, t, v, agg_flow="svc")))
+    for i, algo in enumerate(["EWMA", "DBSCAN", "ARIMA", "DBSCAN"]):
+        rows, K = (60000 + 7000 * i, 50 + 10 * i) if algo != "ARIMA" else (6000, 12)
+        k, t, v = orc.synth_rows(1000 * i, rows, K, 40)
+        jobs.append((algo, k, t, v, K, orc.run_job(algo, k, t, v, agg_flow="svc")))
     out = [None] * 4
-    errs = []
+    errs, seen_ctx, in_flight = [], set(), []
 
     def work(i):
         try:
             algo, k, t, v, K, _ = jobs[i]
             for _ in range(3):
                 out[i] = engine.run(algo, k, t, v, K, agg_flow="svc", job_id="job-%d" % i)
-                assert engine.progress()[1] == 4
-                # the per-series entry points share the engine's buffers: tad_series_arima must return ITS predictions
+                seen_ctx.add(out[i].stats["job_context"])
+                done, total = engine.progress()          # the sum over the jobs in flight (or the job that finished last)
+                assert total % 4 == 0 and 0 <= done <= total
+                assert engine.job_progress("job-%d" % i) == (0, 0)     # this thread's job has returned: not in flight
+                in_flight.append(engine.jobs_in_flight())
+                # the per-series entry points take a context of their own: tad_series_arima must return ITS predictions
                 series_got[i] = engine.series_arima(series[i])
         except Exception as exc:  # noqa: BLE001
             errs.append(exc)
@@ -464,12 +470,53 @@ def test_concurrent_runs_from_four_threads(engine):
     for th in threads:
         th.join()
     assert not errs, errs
+    assert seen_ctx <= {0, 1, 2, 3} and max(in_flight) <= 4 and engine.jobs_in_flight() == 0
     for i in range(4):
         assert np.array_equal(np.asarray(series_got[i]), np.asarray(series_want[i]), equal_nan=True), i
         want = jobs[i][5]
         assert out[i].id == "job-%d" % i and out[i].n_rows == want["n_anomalies"]
-        for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+        for f in ("key_id", "flow_end_s", "throughput", "stddev"):
             assert (out[i][f] == want[f]).all(), (i, f)
+        assert np.array_equal(out[i]["algo_calc"], want["algo_calc"], equal_nan=True), i
+
+
+def test_job_contexts_serial_caller_stays_on_context_zero_and_pool_is_bounded(engine):
+    """A serial caller always gets context 0 (warm buffers); max_jobs_in_flight = 1 restores the serialising engine; a job in flight is
+    visible through tad_job_progress / tad_jobs_in_flight from another thread."""
+    import threading
+    from theia_amd import TadEngine
+    k, t, v = orc.synth_rows(5, 30000, 40, 40)
+    for _ in range(3):
+        assert engine.run("EWMA", k, t, v, 40, agg_flow="svc").stats["job_context"] == 0
+    one = TadEngine(device=0, max_jobs_in_flight=1)
+    try:
+        ctx = []
+
+        def work():
+            for _ in range(4):
+                ctx.append(one.run("DBSCAN", k, t, v, 40, agg_flow="svc").stats["job_context"])
+        ths = [threading.Thread(target=work) for _ in range(3)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert ctx == [0] * 12
+    finally:
+        one.close()
+    with pytest.raises(Exception):
+        TadEngine(device=0, max_jobs_in_flight=17)
+    # a long job (ARIMA, a few thousand fits) watched from the main thread
+    ka, ta, va = orc.synth_rows(9, 40000, 200, 120)
+    seen = []
+    th = threading.Thread(target=lambda: engine.run("ARIMA", ka, ta, va, 200, agg_flow="svc", job_id="watched"))
+    th.start()
+    while th.is_alive():
+        d, tot = engine.job_progress("watched")
+        if tot:
+            seen.append((d, tot, engine.jobs_in_flight()))
+    th.join()
+    assert engine.job_progress("watched") == (0, 0) and engine.job_progress("no-such-job") == (0, 0)
+    assert seen and all(tot == 4 and 0 <= d <= 4 for d, tot, _ in seen) and max(n for _, _, n in seen) >= 1
 
 
 # ------------------------------------------------------------------ (d) full-size properties (BASELINE C2 / C4)

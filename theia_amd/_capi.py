@@ -6,7 +6,7 @@ from . import build as _build
 
 u64, i64, i32, u32, f64, f32 = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_float
 
-TAD_ABI_VERSION = 11
+TAD_ABI_VERSION = 12
 TAD_KEY_SKIP = (1 << 64) - 1
 TAD_OK = 0
 TAD_ERR_INVALID_ARGUMENT, TAD_ERR_NO_DEVICE, TAD_ERR_OUT_OF_MEMORY, TAD_ERR_HIP = -1, -2, -3, -4
@@ -21,13 +21,13 @@ TAD_FLAG_EMIT_ALL_POINTS = 1
 class Plan(C.Structure):
     """tad_plan: plan overrides, every field 0 = the engine decides (tests and A/B measurements set them)."""
     _fields_ = [("stage0", i32), ("partition_pass", i32), ("histogram", i32), ("sparse", i32), ("sparse_classes", i32),
-                ("ewma_emit", i32), ("ewma_emit_rows", u32), ("one_sync", i32), ("tile_cells", i32), ("sparse_sort", i32), ("placement", i32)]
+                ("ewma_emit", i32), ("ewma_emit_rows", u32), ("reserved0", i32), ("tile_cells", i32), ("sparse_sort", i32), ("reserved1", i32)]
 
 
 PLAN_VALUES = {   # symbolic values accepted by TadEngine(plan=...) / TadEngine.plan(...)
     "stage0": {"auto": 0, "v1": 1, "v2": 2}, "partition_pass": {"auto": 0, "sort": 1, "wc": 2, "wc_sectors": 3}, "histogram": {"auto": 0, "exact": 1, "sampled": 2},
-    "sparse": {"auto": 0, "never": 1, "always": 2}, "sparse_classes": {"auto": 0, "always": 1}, "ewma_emit": {"auto": 0, "staged": 0, "lane": 1}, "one_sync": {"auto": 0, "never": 1}, "tile_cells": {"auto": 0, "wide": 1},
-    "sparse_sort": {"auto": 0, "lsd": 1, "partition": 2}, "placement": {"auto": 0, "never": 1},
+    "sparse": {"auto": 0, "never": 1, "always": 2}, "sparse_classes": {"auto": 0, "always": 1}, "ewma_emit": {"auto": 0, "staged": 0, "lane": 1}, "tile_cells": {"auto": 0, "wide": 1},
+    "sparse_sort": {"auto": 0, "lsd": 1, "partition": 2},
 }
 
 
@@ -55,7 +55,7 @@ class StringColumn(C.Structure):
 
 
 class EngineOpts(C.Structure):
-    _fields_ = [("device", i32), ("stream", C.c_void_p), ("workspace_limit", u64), ("plan", Plan)]
+    _fields_ = [("device", i32), ("stream", C.c_void_p), ("workspace_limit", u64), ("plan", Plan), ("max_jobs_in_flight", i32), ("reserved", i32)]
 
 
 class Job(C.Structure):
@@ -77,7 +77,7 @@ class Stats(C.Structure):
                 ("arima_fits", u64), ("arima_nan_fits", u64), ("pts_mean", f64), ("pts_m2", f64), ("t0", i64), ("step", i64), ("n_buckets", u64),
                 ("ms_meta", f32), ("ms_stage0", f32), ("ms_scatter", f32), ("ms_detect", f32),
                 ("ms_total", f32), ("stage0_path", i32), ("stage0_attempts", i32), ("hist_sampled", i32), ("host_syncs", i32),
-                ("placement_candidates", i32), ("placement_ms", f32), ("placement_kept_ms", f32), ("placement_worst_ms", f32)]
+                ("job_context", i32)]
 
 
 class Result(C.Structure):
@@ -110,6 +110,8 @@ SYMBOLS = {
     "tad_factorize": (C.c_int, [C.c_void_p, C.POINTER(KeyColumns), C.c_void_p, C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]),
     "tad_encode_strings": (C.c_int, [C.c_void_p, C.POINTER(StringColumn), C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]),
     "tad_progress": (C.c_int, [C.c_void_p, C.POINTER(i32), C.POINTER(i32)]),
+    "tad_job_progress": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(i32), C.POINTER(i32)]),
+    "tad_jobs_in_flight": (C.c_int, [C.c_void_p]),
     "tad_series_ewma": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_void_p]),
     "tad_series_ewma_anomaly": (C.c_int, [C.c_void_p, C.c_void_p, u64, f64, C.c_int, f64, C.c_void_p]),
     "tad_series_stddev": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.POINTER(C.c_int), C.POINTER(f64)]),

@@ -1,13 +1,20 @@
 // tad_capi.cpp — the C ABI of include/tad.h on top of the gfx950 kernels.  HIP only: there is no
 // CPU fallback in this library (the CPU oracle under oracle/ is test infrastructure and is never
 // linked or called from here).
+//
+// Threading (controller.go:199-201 runs four workers, Spark ran one pod per job): an engine owns a small POOL of job
+// contexts.  A context is everything one job in flight needs — a HIP stream (two: normal and low priority), its events, its pinned
+// read-back blocks and its grow-only workspace buffers — so jobs submitted from different threads run concurrently on the GPU, each
+// on its own stream, and never touch each other's memory.  tad_run takes an idle context (creating one up to
+// tad_engine_opts.max_jobs_in_flight, else waiting), runs, and gives it back.  Serial callers always get context 0 and see the
+// behaviour of the single-mutex engine of ABI <= 11.
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -22,7 +29,6 @@ namespace {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
-  void *raw = nullptr;   // what hipMalloc returned (p is aligned up inside it, see ensure)
 };
 
 struct FreeBlock {
@@ -34,16 +40,39 @@ thread_local std::string g_static_err;
 
 }  // namespace
 
+struct JobCtx;
+
 struct tad_engine {
   int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  uint64_t ws_limit = 0;
-  tad_plan plan{};    // plan overrides (tests / A-B measurements); all zero = the engine decides.  Read under mu.
-  std::mutex mu;      // serialises runs on this engine (controller.go:199-201 has 4 workers)
-  std::mutex err_mu;  // protects err
+  uint64_t ws_limit = 0;       // per job in flight
+  int max_ctx = 1;
+  hipStream_t user_stream = nullptr;   // tad_engine_opts.stream: context 0 runs on it (and the pool has that one context)
+  int prio_normal = 0, prio_low = 0;   // hipDeviceGetStreamPriorityRange: ARIMA jobs (seconds of FP64) run on the low-priority stream of their
+                                       // context so that the short HBM-bound jobs of other contexts are dispatched ahead of their workgroups
+  std::mutex mu;               // protects plan, ctxs, the busy flags and last_done / last_total
+  std::condition_variable cv;  // a context became idle
+  tad_plan plan{};             // plan overrides (tests / A-B measurements); all zero = the engine decides
+  std::vector<JobCtx *> ctxs;
+  int32_t last_done = 0, last_total = 0;   // progress of the job that finished last (tad_progress with nothing in flight)
+  std::mutex err_mu;           // protects err
   std::string err;
+  std::mutex pool_mu;          // protects free_blocks
+  std::vector<FreeBlock> free_blocks;  // recycled device result blocks (a result may be freed from any thread)
+};
+
+// One job in flight.  Everything below is touched by the thread that holds the context only (busy == true), except done / total / id.
+struct JobCtx {
+  tad_engine *eng = nullptr;
+  int index = 0;               // position in eng->ctxs (tad_stats.job_context)
+  bool busy = false;           // under eng->mu
+  int device = 0;
+  hipStream_t stream = nullptr;        // the stream of the running job: stream_normal or stream_low
+  hipStream_t stream_normal = nullptr, stream_low = nullptr;
+  bool own_streams = false;
+  uint64_t ws_limit = 0;
+  tad_plan plan{};             // the engine's plan when the job was admitted
   std::atomic<int32_t> done{0}, total{0};
+  char id[64] = {};            // tad_job.id of the running job (tad_job_progress); under eng->mu
   // grow-only device scratch
   DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2;   // counters: the job tail (kTailBytes)
   DevBuf in_key, in_key2, in_te, in_ts, in_val;
@@ -55,9 +84,7 @@ struct tad_engine {
   bool sp_by_partition = false;   // the running job's sparse Stage 0 went through the partition pass + LDS sort (stage0_path 8 / 9 / 10 instead of 4 / 6 / 7)
   DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
   DevBuf ovf_keys;                                                                // Stage 0 v2, settle mode: bitmap of the keys with a value on the overflow list
-  DevBuf place_scratch;                                                           // place_recs: counters / fin of the calibration runs of pass B
   hipEvent_t ev[8] = {};
-  std::vector<FreeBlock> free_blocks;  // recycled device result blocks
   MetaPartial *meta_host = nullptr;    // pinned
   // The job's tail — what the host reads when a job's kernels are done — is ONE block on the device (e->counters: DevCounters |
   // row total | overflow-list count | pad to 128 B | kMomentBlocks moment partials) and ONE pinned block here: one copy per job.
@@ -65,61 +92,51 @@ struct tad_engine {
   DevCounters *ctr_host = nullptr;           // = tail_host
   unsigned long long *total_host = nullptr;  // = tail_host + 64
   Moments *moments_host = nullptr;           // = tail_host + 128
-  // Speculation state of the one-synchronisation job (run_job_locked): the lattice and the row count of the last job of this shape.
-  struct Spec {
+  // what the last job of this context learnt about its table, reused when the next job has the same shape (nothing speculative: both only
+  // skip an attempt that is known to fail)
+  struct Learnt {
     bool valid = false;
     uint64_t n = 0, K = 0;
     bool has2 = false;
-    int algo = 0, agg = 0, op = 0;
-    uint32_t flags = 0;
-    int64_t start = 0, end = 0;
-    Lattice L{};
-    uint64_t rows = 0;
+    int algo = 0, op = 0;
     bool exact_hist = false;   // the sampled histogram proved too optimistic for this table: go straight to the exact one
     bool wide_tiles = false;   // 32-bit tile cells overflowed the list for this table: go straight to 8-byte cells
-  } spec;
-  // what place_recs did in the running job (tad_stats.placement_*, ABI 11); reset at the start of every job
-  struct Placement { int candidates = 0; float ms = 0.f, kept_ms = 0.f, worst_ms = 0.f; } placement;
-  // ... and the (columns, shape) the record buffer in place was timed against: pass B's rate is a property of the PAIR (where the three read
-  // streams lie, where the write stream lies — profiles/r5_b2_*), so a job on other columns re-times the buffer (place_recs)
-  struct PlacedFor { const void *key = nullptr, *te = nullptr, *val = nullptr; uint64_t n = 0; uint32_t nparts = 0; float kept_ms = 0.f; int jobs_since = 0; } placed_for;
+  } learnt;
 };
 
 // per-key running state of the streaming EWMA detector: two copies (the count pass writes the candidate next state,
 // it becomes current only when the batch succeeds)
 namespace {
-constexpr size_t kTailCtr = 0, kTailTotal = 64, kTailOvfCount = 72, kTailTickets = 80, kTailMoments = 128;   // tickets: one u32 (k_part_offsets)
+constexpr size_t kTailCtr = 0, kTailTotal = 64, kTailOvfCount = 72, kTailMoments = 128;
 constexpr size_t kTailBytes = kTailMoments + sizeof(Moments) * kMomentBlocks;
-inline DevCounters *dev_ctr(tad_engine *e) { return static_cast<DevCounters *>(e->counters.p); }
-inline unsigned long long *dev_total(tad_engine *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailTotal); }
-inline unsigned long long *dev_ovf_count(tad_engine *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailOvfCount); }
-inline unsigned int *dev_ticket(tad_engine *e, int i) { return reinterpret_cast<unsigned int *>(static_cast<unsigned char *>(e->counters.p) + kTailTickets) + i; }
-inline Moments *dev_moments(tad_engine *e) { return reinterpret_cast<Moments *>(static_cast<unsigned char *>(e->counters.p) + kTailMoments); }
+inline unsigned long long *dev_total(JobCtx *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailTotal); }
+inline unsigned long long *dev_ovf_count(JobCtx *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailOvfCount); }
+inline Moments *dev_moments(JobCtx *e) { return reinterpret_cast<Moments *>(static_cast<unsigned char *>(e->counters.p) + kTailMoments); }
 }  // namespace
 
 struct tad_state {
   uint64_t K = 0;
   void *block[2] = {nullptr, nullptr};
   int cur = 0;
+  mutable std::mutex mu;     // batches of one state are serial (tad_run_stream from two threads on one state)
 };
 
 namespace {
 
 constexpr int kMetaBlocks = 2048;
 constexpr int kSampleBlockShift = 7;   // (C4 with 1024-key blocks and a sampled histogram: pass A 0.21 -> 0.10 ms but pass C 0.68 -> 0.86 ms, profiles/r3_v2_c4_keyblock_ab.log)
+constexpr int kDefaultJobsInFlight = 4;   // controller.go:199-201 / pkg/controller/util.go:43: four workers
+constexpr int kMaxJobsInFlight = 16;
 
 bool plan_ok(const tad_plan &p) {
   return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 3 && p.histogram >= 0 && p.histogram <= 2 && p.sparse >= 0 &&
-         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.one_sync >= 0 && p.one_sync <= 1 && p.tile_cells >= 0 && p.tile_cells <= 1 && p.sparse_sort >= 0 && p.sparse_sort <= 2 && p.placement >= 0 && p.placement <= 1;
+         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.tile_cells >= 0 && p.tile_cells <= 1 && p.sparse_sort >= 0 && p.sparse_sort <= 2 && p.reserved0 == 0 && p.reserved1 == 0;
 }
 constexpr uint32_t kOverflowCap = 1u << 20;  // Stage 0 v2: rows with a value >= 2^49 per run before falling back to v1
 
-int fail(tad_engine *e, int code, const char *fmt, ...) {
+int vfail(tad_engine *e, int code, const char *fmt, va_list ap) {
   char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
   if (e) {
     std::lock_guard<std::mutex> lk(e->err_mu);
     e->err = buf;
@@ -127,6 +144,27 @@ int fail(tad_engine *e, int code, const char *fmt, ...) {
     g_static_err = buf;
   }
   return code;
+}
+int fail(tad_engine *e, int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  const int rc = vfail(e, code, fmt, ap);
+  va_end(ap);
+  return rc;
+}
+int fail(JobCtx *c, int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  const int rc = vfail(c ? c->eng : nullptr, code, fmt, ap);
+  va_end(ap);
+  return rc;
+}
+int fail(std::nullptr_t, int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  const int rc = vfail(nullptr, code, fmt, ap);
+  va_end(ap);
+  return rc;
 }
 
 #define HIP_TRY(e, call)                                                                         \
@@ -137,136 +175,193 @@ int fail(tad_engine *e, int code, const char *fmt, ...) {
                   "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
   } while (0)
 
-// Big buffers start on a kBigAlign boundary of the address space (measurement builds change it: -DTAD_BIG_ALIGN_LOG2=30).
-#ifndef TAD_BIG_ALIGN_LOG2
-#define TAD_BIG_ALIGN_LOG2 0
-#endif
-int ensure(tad_engine *e, DevBuf &b, size_t bytes) {
+// every grow-only buffer of a context, for trimming and teardown
+template <typename F> void for_each_buf(JobCtx *c, F f) {
+  DevBuf *bufs[] = {&c->grid_val, &c->grid_flag, &c->sigma, &c->n_pts, &c->n_anom, &c->off, &c->scan_scratch, &c->calc, &c->counters, &c->meta, &c->aux,
+                    &c->key_mean, &c->key_m2, &c->rcp_table, &c->binhist, &c->part_total, &c->part_start, &c->part_offs32, &c->recs, &c->ovf, &c->slices,
+                    &c->sp_comp_a, &c->sp_comp_b, &c->sp_val_a, &c->sp_val_b, &c->sp_temp, &c->sp_first, &c->sp_times, &c->sp_cls, &c->part_fin, &c->ovf_keys,
+                    &c->in_key, &c->in_key2, &c->in_te, &c->in_ts, &c->in_val};
+  for (DevBuf *b : bufs) f(*b);
+}
+
+// give the workspace of a context back to the device (the context is idle and held by the caller, or is being destroyed)
+void drop_buffers(JobCtx *c) {
+  for_each_buf(c, [](DevBuf &b) {
+    if (b.p) hipFree(b.p);
+    b = DevBuf{};
+  });
+  c->rcp_n = 0;
+}
+
+// An allocation failed: the idle contexts of the engine and the recycled result blocks give their memory back, then the caller retries once.
+// (Contexts are grow-only for speed; the sum over a pool may exceed what a single big job plus the others' leftovers can share.)
+void trim_idle(tad_engine *eng, JobCtx *self) {
+  std::vector<JobCtx *> held;
+  {
+    std::lock_guard<std::mutex> lk(eng->mu);
+    for (JobCtx *c : eng->ctxs)
+      if (c != self && !c->busy) { c->busy = true; held.push_back(c); }
+  }
+  for (JobCtx *c : held) drop_buffers(c);
+  {
+    std::lock_guard<std::mutex> lk(eng->pool_mu);
+    for (auto &fb : eng->free_blocks) hipFree(fb.p);
+    eng->free_blocks.clear();
+  }
+  (void)hipGetLastError();
+  {
+    std::lock_guard<std::mutex> lk(eng->mu);
+    for (JobCtx *c : held) c->busy = false;
+  }
+  eng->cv.notify_all();
+}
+
+int ensure(JobCtx *e, DevBuf &b, size_t bytes) {
   if (bytes <= b.cap) return TAD_OK;
   if (b.p) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipFree(b.raw ? b.raw : b.p));
-    b.p = b.raw = nullptr;
-    b.cap = 0;
+    HIP_TRY(e, hipFree(b.p));
+    b = DevBuf{};
   }
   size_t want = bytes + bytes / 8 + 256;
-  const size_t align = (TAD_BIG_ALIGN_LOG2 > 0 && want >= ((size_t)64 << 20)) ? ((size_t)1 << TAD_BIG_ALIGN_LOG2) : 0;
-  hipError_t r = hipMalloc(&b.raw, want + align);
+  hipError_t r = hipMalloc(&b.p, want);
   if (r != hipSuccess) {
     want = bytes;
-    r = hipMalloc(&b.raw, want + align);
+    r = hipMalloc(&b.p, want);
   }
-  if (r != hipSuccess)
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    trim_idle(e->eng, e);
+    r = hipMalloc(&b.p, want);
+  }
+  if (r != hipSuccess) {
+    b.p = nullptr;
+    (void)hipGetLastError();
     return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(r));
-  b.p = align ? reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(b.raw) + align - 1) & ~(uintptr_t)(align - 1)) : b.raw;
+  }
   b.cap = want;
-#if defined(TAD_TRACE_ALLOC)      // measurement builds: where the big buffers land
-  if (want >= ((size_t)64 << 20)) fprintf(stderr, "tad alloc engine %p buf +%zu: %zu MB at %p (raw %p)\n", (void *)e, (size_t)((char *)&b - (char *)e), want >> 20, b.p, b.raw);
-#endif
   return TAD_OK;
 }
 
-// Placement of the record buffer (round 4; what it is a property of: round 5).  Pass B of the same job runs 0.60 ms with some allocations of the
-// buffer it writes and 0.64 or 0.68 ms with others of the same process (C2; some boxes offer only the slow kind).  tools/probes/placement_probe.hip
-// (profiles/r5_p1_*, r5_b1 ... r5_b3_*) narrowed it down:
-//   * not address translation: a dependent-load chase at 4 KB / 64 KB / 2 MB strides costs the same on every candidate, TCP_UTCL1 hits and
-//     misses are equal, and a workgroup-major layout that takes the UTCL1 misses to ZERO keeps the classes (and gains 1.5 %);
-//   * not the scatter: one contiguous 8-byte-per-row write stream per workgroup shows the same classes; shifting the base by 256 KB ... 64 MB
-//     inside an allocation changes nothing;
-//   * not the buffer by itself: a write-only stream (0.19 ms per 0.8 GB) and a read-only stream (0.14 ms) run alike on every candidate;
-//   * it is the PAIR: the same destination changes class when another allocation stands in for the three columns it is read with — concurrent
-//     reads and writes interfere more or less depending on where the two lie relative to each other in PHYSICAL memory.  L2 requests, hits,
-//     misses and EA read / write request counts are identical; what differs is how long the memory side takes (TCC_EA0_RDREQ_LEVEL, TCC tag /
-//     input-buffer stalls).  User space sees no physical address, so no rule can pick the fast kind: the JOB'S OWN pass B is timed into the buffer
-//     (its counters redirected to scratch memory; until late in round 5 a stand-in kernel, k_place_probe) and into up to eight further allocations
-//     of the same size (<= 16 GB, <= half the workspace limit) made while the earlier ones are held; the search stops once a candidate 4 %
-//     faster than the slowest has been seen and the next one is no better; the fastest stays, the others are freed.
-// Once per allocation — and again when a job brings OTHER columns or another shape than the buffer was chosen against, at most once in 16 jobs.
-// tad_stats.placement_* say what a job did; tad_plan.placement = 1 turns all of it off.
-#ifndef TAD_PLACEMENT_CANDIDATES
-#define TAD_PLACEMENT_CANDIDATES 9
-#endif
-static constexpr size_t kPlacementBytes = (size_t)16 << 30;   // ... and at most this much memory held by the candidates together
-// `fresh`: the buffer has just been allocated; otherwise it was chosen against OTHER columns (or another shape) and is the first candidate of a new search.
-// `run_pass_b(recs)` issues THE JOB'S OWN pass B into a candidate buffer (counters, overflow list and `fin` redirected to scratch memory): what is timed
-// is the kernel that matters with the plan that will run.  Round 4 timed a stand-in (k_place_probe: pass B's memory pattern without its bookkeeping);
-// it ranked the candidates of a C2 job correctly but not those of a C4 job that followed it in one process — kept 0.631 of 0.669 ms by the stand-in,
-// pass B then ran 0.681 where engines of an A/B process ran 0.606 (profiles/r5_m4_bench_default_line.json).
-int place_recs(tad_engine *e, const std::function<void(void *)> &run_pass_b, const void *d_key, const void *d_te, const void *d_val, uint64_t n,
-               uint32_t nparts, bool fresh) {
-  if (TAD_PLACEMENT_CANDIDATES < 2 || n < (1ull << 24) || nparts == 0) return TAD_OK;
-  const auto wall0 = std::chrono::steady_clock::now();
-  hipStream_t s = e->stream;
-  hipEvent_t a, b;
-  if (hipEventCreate(&a) != hipSuccess) return TAD_OK;
-  if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return TAD_OK; }
-  struct Cand { void *raw, *p; float ms; };
-  Cand cand[TAD_PLACEMENT_CANDIDATES];
-  int nc = 0;
-  auto probe = [&](void *p, float *ms) -> bool {
-    run_pass_b(p);   // warm
-    float best = 1e30f;
-    for (int r = 0; r < 2; ++r) {
-      if (hipEventRecord(a, s) != hipSuccess) return false;
-      run_pass_b(p);
-      if (hipEventRecord(b, s) != hipSuccess || hipEventSynchronize(b) != hipSuccess) return false;
-      float t = 0.f;
-      if (hipEventElapsedTime(&t, a, b) != hipSuccess) return false;
-      best = t < best ? t : best;
-    }
-    *ms = best;
-    return true;
-  };
-  cand[0] = Cand{e->recs.raw, e->recs.p, 0.f};
-  bool ok = probe(cand[0].p, &cand[0].ms);
-  nc = 1;
-  tad_engine::PlacedFor &pf = e->placed_for;
-  (void)fresh;   // a buffer that served other columns is searched anew like a fresh one: what the probe says about THIS pair cannot be compared with
-                 // the time kept for another pair (a C4 job behind a C2 job re-timed its inherited buffer at 0.645 ms, "as good as" C2's 0.646, and
-                 // ran pass B at 0.688 where engines that searched for C4's columns ran 0.61-0.63: profiles/r5_m3_bench_default_line.json)
-  // (the candidates are transient, but they are the engine's memory: together they stay within half the workspace limit)
-  const size_t budget = kPlacementBytes < e->ws_limit / 2 ? kPlacementBytes : (size_t)(e->ws_limit / 2);
-  while (ok && nc < TAD_PLACEMENT_CANDIDATES && (size_t)(nc + 1) * e->recs.cap <= budget) {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < e->recs.cap + ((size_t)2 << 30)) break;
-    void *q = nullptr;
-    if (hipMalloc(&q, e->recs.cap) != hipSuccess) { (void)hipGetLastError(); break; }
-    cand[nc] = Cand{q, q, 0.f};
-    ok = probe(q, &cand[nc].ms);
-    ++nc;
-    // both kinds of placement seen (a candidate 4 % faster than the slowest) AND the newest one no better than the best before it: the
-    // allocations have left the slow stretch (a candidate that straddles its end probes in between and runs the job slow)
-    float lo_prev = cand[0].ms, hi = cand[0].ms;
-    for (int i = 1; i < nc - 1; ++i) lo_prev = cand[i].ms < lo_prev ? cand[i].ms : lo_prev;
-    for (int i = 1; i < nc; ++i) hi = cand[i].ms > hi ? cand[i].ms : hi;
-    if (ok && nc >= 3 && lo_prev <= 0.96f * hi && cand[nc - 1].ms >= 0.99f * lo_prev) break;
+// Resolve one kernel of every translation unit: the lazy loader brings the unit's code object onto the device.
+void preload_code_objects() {
+  const void *anchors[] = {code_anchor_arima(), code_anchor_dbscan(), code_anchor_drop(), code_anchor_factorize(), code_anchor_kernels(), code_anchor_shard(), code_anchor_sparse(), code_anchor_stage0_part(), code_anchor_synth()};
+  for (const void *k : anchors) {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, k);
   }
-  int best = 0;
-  if (ok)
-    for (int i = 1; i < nc; ++i)
-      if (cand[i].ms < 0.99f * cand[best].ms) best = i;     // (within 1 %: the earlier allocation stays)
-#if defined(TAD_TRACE_ALLOC)
-  for (int i = 0; i < nc; ++i) fprintf(stderr, "tad placement engine %p candidate %d at %p: %.4f ms%s\n", (void *)e, i, cand[i].p, cand[i].ms, i == best ? "  <- kept" : "");
-#endif
-  hipStreamSynchronize(s);
-  for (int i = 0; i < nc; ++i)
-    if (i != best) hipFree(cand[i].raw);
-  e->recs.raw = cand[best].raw;
-  e->recs.p = cand[best].p;
-  if (ok) {
-    float worst = cand[0].ms;
-    for (int i = 1; i < nc; ++i) worst = cand[i].ms > worst ? cand[i].ms : worst;
-    e->placement.candidates += nc;
-    e->placement.kept_ms = cand[best].ms;
-    e->placement.worst_ms = worst;
-    pf.key = d_key; pf.te = d_te; pf.val = d_val; pf.n = n; pf.nparts = nparts; pf.kept_ms = cand[best].ms; pf.jobs_since = 0;
-    e->placement.ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-  }
-  hipEventDestroy(a);
-  hipEventDestroy(b);
   (void)hipGetLastError();
-  return TAD_OK;
 }
+
+// ---- the pool ----
+JobCtx *ctx_create(tad_engine *eng, bool first) {
+  JobCtx *c = new (std::nothrow) JobCtx();
+  if (!c) return nullptr;
+  c->eng = eng;
+  c->device = eng->device;
+  c->ws_limit = eng->ws_limit;
+  bool ok = true;
+  if (first && eng->user_stream) {
+    c->stream_normal = c->stream_low = eng->user_stream;
+  } else {
+    c->own_streams = true;
+    ok = hipStreamCreateWithPriority(&c->stream_normal, hipStreamNonBlocking, eng->prio_normal) == hipSuccess;
+    if (ok && eng->prio_low != eng->prio_normal) ok = hipStreamCreateWithPriority(&c->stream_low, hipStreamNonBlocking, eng->prio_low) == hipSuccess;
+    else c->stream_low = c->stream_normal;
+  }
+  c->stream = c->stream_normal;
+  for (auto &ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->meta_host), sizeof(MetaPartial) * kMetaBlocks, hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->tail_host), kTailBytes, hipHostMallocDefault) == hipSuccess;
+  if (ok) {
+    memset(c->tail_host, 0, kTailBytes);
+    c->ctr_host = reinterpret_cast<DevCounters *>(c->tail_host + kTailCtr);
+    c->total_host = reinterpret_cast<unsigned long long *>(c->tail_host + kTailTotal);
+    c->moments_host = reinterpret_cast<Moments *>(c->tail_host + kTailMoments);
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    for (auto &ev : c->ev) if (ev) hipEventDestroy(ev);
+    if (c->meta_host) hipHostFree(c->meta_host);
+    if (c->tail_host) hipHostFree(c->tail_host);
+    if (c->own_streams) {
+      if (c->stream_low && c->stream_low != c->stream_normal) hipStreamDestroy(c->stream_low);
+      if (c->stream_normal) hipStreamDestroy(c->stream_normal);
+    }
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+void ctx_destroy(JobCtx *c) {
+  if (c->stream_normal) hipStreamSynchronize(c->stream_normal);
+  if (c->stream_low && c->stream_low != c->stream_normal) hipStreamSynchronize(c->stream_low);
+  drop_buffers(c);
+  for (auto &ev : c->ev) if (ev) hipEventDestroy(ev);
+  if (c->meta_host) hipHostFree(c->meta_host);
+  if (c->tail_host) hipHostFree(c->tail_host);
+  if (c->own_streams) {
+    if (c->stream_low && c->stream_low != c->stream_normal) hipStreamDestroy(c->stream_low);
+    if (c->stream_normal) hipStreamDestroy(c->stream_normal);
+  }
+  delete c;
+}
+
+// An idle context (the lowest-numbered one: a serial caller always gets context 0 and its warm buffers), a new one while the pool may
+// grow, else wait.  low_priority: the job's kernels go to the context's low-priority stream (ARIMA).
+struct Lease {
+  tad_engine *eng;
+  JobCtx *c = nullptr;
+  Lease(tad_engine *eng_, const char *id = nullptr, bool low_priority = false) : eng(eng_) {
+    std::unique_lock<std::mutex> lk(eng->mu);
+    for (;;) {
+      for (JobCtx *x : eng->ctxs)
+        if (!x->busy) { c = x; break; }
+      if (c) break;
+      if ((int)eng->ctxs.size() < eng->max_ctx) {
+        lk.unlock();      // (stream / pinned-memory creation outside the lock)
+        hipSetDevice(eng->device);
+        JobCtx *n = ctx_create(eng, false);
+        lk.lock();
+        if (n) { n->index = (int)eng->ctxs.size(); eng->ctxs.push_back(n); c = n; break; }
+        if (eng->ctxs.empty()) return;   // cannot happen (context 0 is made by tad_engine_create); c stays NULL
+      }
+      eng->cv.wait(lk);
+    }
+    c->busy = true;
+    c->plan = eng->plan;
+    c->done.store(0);
+    c->total.store(0);
+    memset(c->id, 0, sizeof c->id);
+    if (id) strncpy(c->id, id, sizeof c->id - 1);
+    c->stream = low_priority ? c->stream_low : c->stream_normal;
+  }
+  ~Lease() {
+    if (!c) return;
+    {
+      std::lock_guard<std::mutex> lk(eng->mu);
+      if (c->total.load() != 0) { eng->last_done = c->done.load(); eng->last_total = c->total.load(); }
+      c->busy = false;
+      c->id[0] = 0;
+    }
+    eng->cv.notify_one();
+  }
+  Lease(const Lease &) = delete;
+  Lease &operator=(const Lease &) = delete;
+};
+
+// recycled device result blocks (engine-wide: a result is freed by whoever holds it)
+void release_block(tad_engine *eng, void *p, size_t cap) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(eng->pool_mu);
+    if (eng->free_blocks.size() < 16) { eng->free_blocks.push_back({p, cap}); return; }
+  }
+  hipSetDevice(eng->device);
+  hipFree(p);
+}
+inline void release_block(JobCtx *e, void *p, size_t cap) { release_block(e->eng, p, cap); }
 
 Lattice make_lattice(int64_t t0, int64_t step, uint64_t nb) {
   Lattice L;
@@ -315,18 +410,27 @@ void carve(void *base, uint64_t rows, bool with_anomaly, OutRows *o) {
   o->anomaly = with_anomaly ? p : nullptr;
 }
 
-int alloc_device_block(tad_engine *e, size_t bytes, ResultBlock *rb) {
-  for (size_t i = 0; i < e->free_blocks.size(); ++i) {
-    if (e->free_blocks[i].cap >= bytes && e->free_blocks[i].cap <= 2 * bytes + (1 << 20)) {
-      rb->base = e->free_blocks[i].p;
-      rb->cap = e->free_blocks[i].cap;
-      e->free_blocks.erase(e->free_blocks.begin() + i);
-      return TAD_OK;
+int alloc_device_block(JobCtx *e, size_t bytes, ResultBlock *rb) {
+  {
+    std::lock_guard<std::mutex> lk(e->eng->pool_mu);
+    std::vector<FreeBlock> &fb = e->eng->free_blocks;
+    for (size_t i = 0; i < fb.size(); ++i) {
+      if (fb[i].cap >= bytes && fb[i].cap <= 2 * bytes + (1 << 20)) {
+        rb->base = fb[i].p;
+        rb->cap = fb[i].cap;
+        fb.erase(fb.begin() + i);
+        return TAD_OK;
+      }
     }
   }
   void *p = nullptr;
   hipError_t r = hipMalloc(&p, bytes);
-  if (r != hipSuccess) return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipMalloc(result, %zu) failed: %s", bytes, hipGetErrorString(r));
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    trim_idle(e->eng, e);
+    r = hipMalloc(&p, bytes);
+  }
+  if (r != hipSuccess) { (void)hipGetLastError(); return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipMalloc(result, %zu) failed: %s", bytes, hipGetErrorString(r)); }
   rb->base = p;
   rb->cap = bytes;
   return TAD_OK;
@@ -362,28 +466,34 @@ int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
   const int dev = opts ? opts->device : 0;
   if (dev < 0 || dev >= ndev) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "device %d out of range (have %d)", dev, ndev);
   if (opts && !plan_ok(opts->plan)) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_engine_create: a tad_plan field is out of range");
+  if (opts && (opts->max_jobs_in_flight < 0 || opts->max_jobs_in_flight > kMaxJobsInFlight || opts->reserved != 0))
+    return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_engine_create: max_jobs_in_flight must be 0 (default %d) .. %d", kDefaultJobsInFlight, kMaxJobsInFlight);
   tad_engine *e = new (std::nothrow) tad_engine();
   if (!e) return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
   e->device = dev;
   if (hipSetDevice(dev) != hipSuccess) { delete e; return fail(nullptr, TAD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", dev); }
-  if (opts && opts->stream) {
-    e->stream = static_cast<hipStream_t>(opts->stream);
-  } else {
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(nullptr, TAD_ERR_HIP, "hipStreamCreate failed"); }
-    e->own_stream = true;
+  e->user_stream = opts ? static_cast<hipStream_t>(opts->stream) : nullptr;
+  // a caller's stream orders the engine's work with the caller's own: one context, on that stream
+  e->max_ctx = e->user_stream ? 1 : ((opts && opts->max_jobs_in_flight) ? opts->max_jobs_in_flight : kDefaultJobsInFlight);
+  {
+    int least = 0, greatest = 0;   // numerically lower = higher priority
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    e->prio_low = least;
+    e->prio_normal = greatest < least ? least - 1 : least;   // one step above the lowest: ordinary (default) priority where the range has three levels
+    if (e->prio_normal < greatest) e->prio_normal = greatest;
   }
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
   e->ws_limit = (opts && opts->workspace_limit) ? opts->workspace_limit : (uint64_t)(free_b / 4 * 3);
   if (opts) e->plan = opts->plan;
-  for (auto &ev : e->ev) hipEventCreate(&ev);
-  hipHostMalloc(reinterpret_cast<void **>(&e->meta_host), sizeof(MetaPartial) * kMetaBlocks, hipHostMallocDefault);
-  hipHostMalloc(reinterpret_cast<void **>(&e->tail_host), kTailBytes, hipHostMallocDefault);
-  if (!e->meta_host || !e->tail_host) { tad_engine_destroy(e); return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "pinned host allocation failed"); }
-  memset(e->tail_host, 0, kTailBytes);
-  e->ctr_host = reinterpret_cast<DevCounters *>(e->tail_host + kTailCtr);
-  e->total_host = reinterpret_cast<unsigned long long *>(e->tail_host + kTailTotal);
-  e->moments_host = reinterpret_cast<Moments *>(e->tail_host + kTailMoments);
+  JobCtx *c0 = ctx_create(e, true);
+  if (!c0) { delete e; return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "stream / pinned host allocation failed"); }
+  e->ctxs.push_back(c0);
+  // The code objects of the library load lazily, on the first launch out of each translation unit: ~3.5 ms of the first job of a process
+  // (profiles/r6_a1_cold_hip_api_stats.csv: 1.5 ms inside hipLaunchKernel, 1.9 ms inside hipFuncSetAttribute).  Touch one kernel of every
+  // unit here, where the ~100 ms of runtime initialisation are being paid anyway.
+  preload_code_objects();
+  (void)hipGetLastError();
   *out = e;
   return TAD_OK;
 }
@@ -391,17 +501,12 @@ int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
 void tad_engine_destroy(tad_engine *e) {
   if (!e) return;
   hipSetDevice(e->device);
-  if (e->stream) hipStreamSynchronize(e->stream);
-  DevBuf *bufs[] = {&e->grid_val, &e->grid_flag, &e->sigma, &e->n_pts, &e->n_anom, &e->off, &e->scan_scratch,
-                    &e->calc, &e->counters, &e->meta, &e->aux, &e->key_mean, &e->key_m2, &e->rcp_table, &e->binhist, &e->part_total, &e->part_start, &e->part_offs32, &e->recs, &e->ovf, &e->slices, &e->sp_comp_a, &e->sp_comp_b, &e->sp_val_a, &e->sp_val_b, &e->sp_temp, &e->sp_first, &e->sp_times, &e->sp_cls, &e->part_fin, &e->ovf_keys, &e->place_scratch, &e->in_key, &e->in_key2, &e->in_te, &e->in_ts, &e->in_val};
-  for (DevBuf *b : bufs)
-    if (b->p) hipFree(b->raw ? b->raw : b->p);
+  {
+    std::unique_lock<std::mutex> lk(e->mu);   // (destroying an engine with jobs in flight is a caller bug; wait for them rather than crash)
+    e->cv.wait(lk, [&] { for (JobCtx *c : e->ctxs) if (c->busy) return false; return true; });
+  }
+  for (JobCtx *c : e->ctxs) ctx_destroy(c);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
-  for (auto &ev : e->ev)
-    if (ev) hipEventDestroy(ev);
-  if (e->meta_host) hipHostFree(e->meta_host);
-  if (e->tail_host) hipHostFree(e->tail_host);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
 
@@ -410,48 +515,53 @@ int tad_engine_set_plan(tad_engine *e, const tad_plan *plan) {
   tad_plan p{};
   if (plan) p = *plan;
   if (!plan_ok(p)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_engine_set_plan: a tad_plan field is out of range");
-  std::lock_guard<std::mutex> lk(e->mu);   // takes effect with the next job
+  std::lock_guard<std::mutex> lk(e->mu);   // jobs admitted from now on see it; jobs in flight keep the plan they were admitted with
   e->plan = p;
   return TAD_OK;
 }
 
 int tad_progress(tad_engine *e, int32_t *done, int32_t *total) {
   if (!e) return TAD_ERR_INVALID_ARGUMENT;
-  if (done) *done = e->done.load();
-  if (total) *total = e->total.load();
+  std::lock_guard<std::mutex> lk(e->mu);
+  int32_t d = 0, t = 0;
+  bool any = false;
+  for (JobCtx *c : e->ctxs)
+    if (c->busy && c->total.load() != 0) { d += c->done.load(); t += c->total.load(); any = true; }
+  if (!any) { d = e->last_done; t = e->last_total; }
+  if (done) *done = d;
+  if (total) *total = t;
   return TAD_OK;
 }
 
-// the caller holds e->mu (or e is NULL)
-static void result_free_locked(tad_engine *e, tad_result *r) {
-  if (!r) return;
-  ResultPriv *rp = reinterpret_cast<ResultPriv *>(r);
-  if (rp->block) {
-    if (r->memory == TAD_MEM_DEVICE && e) {
-      if (e->free_blocks.size() < 8) e->free_blocks.push_back({rp->block, rp->block_cap});
-      else { hipSetDevice(e->device); hipFree(rp->block); }
-    } else if (r->memory == TAD_MEM_DEVICE) {
-      hipFree(rp->block);
-    } else {
-      free(rp->block);
+int tad_job_progress(tad_engine *e, const char *id, int32_t *done, int32_t *total) {
+  if (!e || !id) return TAD_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (JobCtx *c : e->ctxs)
+    if (c->busy && c->total.load() != 0 && strncmp(c->id, id, sizeof c->id) == 0) {
+      if (done) *done = c->done.load();
+      if (total) *total = c->total.load();
+      return TAD_OK;
     }
-  }
-  delete rp;
+  if (done) *done = 0;     // no job with this id is in flight (finished, or not started yet): total = 0
+  if (total) *total = 0;
+  return TAD_OK;
+}
+
+int tad_jobs_in_flight(tad_engine *e) {
+  if (!e) return 0;
+  std::lock_guard<std::mutex> lk(e->mu);
+  int n = 0;
+  for (JobCtx *c : e->ctxs) n += c->busy ? 1 : 0;
+  return n;
 }
 
 void tad_result_free(tad_engine *e, tad_result *r) {
   if (!r) return;
   ResultPriv *rp = reinterpret_cast<ResultPriv *>(r);
   if (rp->block) {
-    if (r->memory == TAD_MEM_DEVICE && e) {
-      std::lock_guard<std::mutex> lk(e->mu);
-      if (e->free_blocks.size() < 8) e->free_blocks.push_back({rp->block, rp->block_cap});
-      else { hipSetDevice(e->device); hipFree(rp->block); }
-    } else if (r->memory == TAD_MEM_DEVICE) {
-      hipFree(rp->block);
-    } else {
-      free(rp->block);
-    }
+    if (r->memory == TAD_MEM_DEVICE && e) release_block(e, rp->block, rp->block_cap);
+    else if (r->memory == TAD_MEM_DEVICE) hipFree(rp->block);
+    else free(rp->block);
   }
   delete rp;
 }
@@ -476,7 +586,7 @@ struct JobParams {
 
 // reciprocals of the point counts 1..T for the exact-division FMA sequence (tad_internal.h:div_by_count);
 // 1.0 / n on the host is IEEE division = the correctly rounded reciprocal the sequence needs.
-int ensure_rcp_table(tad_engine *e, uint64_t T) {
+int ensure_rcp_table(JobCtx *e, uint64_t T) {
   const uint64_t want = T + 2;
   if (want <= e->rcp_n) return TAD_OK;
   uint64_t cap = want < 1024 ? 1024 : want + want / 4;
@@ -491,7 +601,7 @@ int ensure_rcp_table(tad_engine *e, uint64_t T) {
   return TAD_OK;
 }
 
-int ensure_key_buffers(tad_engine *e, uint64_t K) {
+int ensure_key_buffers(JobCtx *e, uint64_t K) {
   int rc;
   const uint64_t k = K ? K : 1;
   if ((rc = ensure(e, e->sigma, k * sizeof(double))) != TAD_OK) return rc;
@@ -507,7 +617,7 @@ int ensure_key_buffers(tad_engine *e, uint64_t K) {
 
 // Runs sigma + detector + scan on grid g.  On return *rows = number of rows emit will write.
 // stats_done: Stage 0 v2's tile pass already produced sigma / n_pts / (EWMA) n_anom / moments inputs / counters.
-int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_t *rows, bool stats_done = false, bool defer_tail = false) {
+int detect_and_count(JobCtx *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_t *rows, bool stats_done = false) {
   hipStream_t s = e->stream;
   int rc;
   if ((rc = ensure_key_buffers(e, g.K)) != TAD_OK) return rc;
@@ -554,7 +664,6 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
   else if (!ewma || jp.all_points) launch_count_flags(s, g, jp.all_points, n_anom);  // ARIMA / DROP all_points: skips no-result keys
   launch_scan_moments(s, cnt, off, g.K, static_cast<unsigned long long *>(e->scan_scratch.p), dev_total(e), n_pts,
                       static_cast<const double *>(e->key_mean.p), static_cast<const double *>(e->key_m2.p), dev_moments(e), db_fused ? ctr : nullptr);
-  if (defer_tail) return TAD_OK;   // the one-synchronisation job: the tail is fetched once, after the emit
   HIP_TRY(e, hipMemcpyAsync(e->tail_host, e->counters.p, kTailBytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipStreamSynchronize(s));
   HIP_TRY(e, hipGetLastError());
@@ -562,18 +671,18 @@ int detect_and_count(tad_engine *e, Grid g, JobParams &jp, DevCounters *ctr, uin
   return TAD_OK;
 }
 
-void emit_rows(tad_engine *e, Grid g, Lattice L, const JobParams &jp, OutRows out, uint64_t rows = 0, EmitGuard guard = EmitGuard{nullptr, 0, nullptr}) {
+void emit_rows(JobCtx *e, Grid g, Lattice L, const JobParams &jp, OutRows out, uint64_t rows = 0) {
   const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : (jp.algo == TAD_ALGO_DROP ? 3 : (jp.lazy_sigma ? 4 : 2)));
   // DBSCAN job: only keys of the detector's work list (still in e->aux) can have rows
   if (kind == 4 && !jp.all_points &&
-      launch_emit_dbscan_list(e->stream, g, L, e->aux.p, static_cast<const uint32_t *>(e->n_anom.p), static_cast<const unsigned long long *>(e->off.p), out, guard))
+      launch_emit_dbscan_list(e->stream, g, L, e->aux.p, static_cast<const uint32_t *>(e->n_anom.p), static_cast<const unsigned long long *>(e->off.p), out))
     return;
   launch_emit(e->stream, g, L, kind, jp.all_points, jp.alpha, static_cast<const double *>(e->sigma.p),
               static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(kind == 3 ? e->key_mean.p : e->calc.p),
-              static_cast<const unsigned long long *>(e->off.p), out, rows, e->plan.ewma_emit, e->plan.ewma_emit_rows, guard);
+              static_cast<const unsigned long long *>(e->off.p), out, rows, e->plan.ewma_emit, e->plan.ewma_emit_rows);
 }
 
-int make_result(tad_engine *e, uint64_t rows, bool with_anomaly, tad_mem out_memory, ResultPriv **out, OutRows *dev_rows,
+int make_result(JobCtx *e, uint64_t rows, bool with_anomaly, tad_mem out_memory, ResultPriv **out, OutRows *dev_rows,
                 ResultBlock *dev_block) {
   ResultPriv *rp = new (std::nothrow) ResultPriv();
   if (!rp) return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
@@ -589,7 +698,7 @@ int make_result(tad_engine *e, uint64_t rows, bool with_anomaly, tad_mem out_mem
 }
 
 // after emit: hand the device block to the caller, or copy it to a host block
-int finish_result(tad_engine *e, ResultPriv *rp, uint64_t rows, bool with_anomaly, ResultBlock dev_block, OutRows dev_rows) {
+int finish_result(JobCtx *e, ResultPriv *rp, uint64_t rows, bool with_anomaly, ResultBlock dev_block, OutRows dev_rows) {
   if (rp->pub.memory == TAD_MEM_DEVICE) {
     rp->block = dev_block.base;
     rp->block_cap = dev_block.cap;
@@ -603,10 +712,10 @@ int finish_result(tad_engine *e, ResultPriv *rp, uint64_t rows, bool with_anomal
   }
   const size_t bytes = result_bytes(rows, with_anomaly);
   void *h = malloc(bytes);
-  if (!h) { e->free_blocks.push_back({dev_block.base, dev_block.cap}); return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu result bytes", bytes); }
+  if (!h) { release_block(e, dev_block.base, dev_block.cap); return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu result bytes", bytes); }
   hipError_t r = hipMemcpyAsync(h, dev_block.base, bytes, hipMemcpyDeviceToHost, e->stream);
   if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
-  e->free_blocks.push_back({dev_block.base, dev_block.cap});
+  release_block(e, dev_block.base, dev_block.cap);
   if (r != hipSuccess) { free(h); return fail(e, TAD_ERR_HIP, "result copy failed: %s", hipGetErrorString(r)); }
   OutRows ho;
   carve(h, rows, with_anomaly, &ho);
@@ -621,7 +730,7 @@ int finish_result(tad_engine *e, ResultPriv *rp, uint64_t rows, bool with_anomal
   return TAD_OK;
 }
 
-int stage_column(tad_engine *e, DevBuf &buf, const void *src, uint64_t n, tad_mem mem, const void **dev) {
+int stage_column(JobCtx *e, DevBuf &buf, const void *src, uint64_t n, tad_mem mem, const void **dev) {
   if (!src) { *dev = nullptr; return TAD_OK; }
   if (mem == TAD_MEM_DEVICE) { *dev = src; return TAD_OK; }
   int rc = ensure(e, buf, n * 8);
@@ -651,16 +760,17 @@ StreamState state_view(const tad_state *st, int which) {
   return v;
 }
 
-int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
+int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
                    tad_state *stream, int depth);
-int run_sparse_classes(tad_engine *e, const tad_job *job, const JobParams &jp, bool op_max, uint64_t n_rows_in, uint64_t rows_used, uint64_t K, Lattice L,
+int run_sparse_classes(JobCtx *e, const tad_job *job, const JobParams &jp, bool op_max, uint64_t n_rows_in, uint64_t rows_used, uint64_t K, Lattice L,
                        uint64_t P, uint32_t tmax, tad_mem out_memory, tad_result **out);
-int sparse_points_direct(tad_engine *e, uint64_t n_rows_in, uint64_t rows_used, Lattice L, uint64_t P, DevCounters *ctr, tad_mem out_memory,
+int sparse_points_direct(JobCtx *e, uint64_t n_rows_in, uint64_t rows_used, Lattice L, uint64_t P, DevCounters *ctr, tad_mem out_memory,
                          tad_points **points_out);
 
 // The job (points_out == nullptr), Stage 0 alone (points_out != nullptr), or one streaming batch (stream != nullptr).
-int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
+int run_job(tad_engine *eng, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
             tad_state *stream = nullptr) {
+  tad_engine *e = eng;
   const bool points_mode = points_out != nullptr;
   if (stream && e && job && cols) {
     if (job->algo != TAD_ALGO_EWMA) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: only the EWMA detector has a streaming form");
@@ -689,12 +799,16 @@ int run_job(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem 
       job->drop_nsigma < 0.0 || job->drop_min_samples < 0)
     return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run: detector parameter out of range");
 
-  std::lock_guard<std::mutex> lk(e->mu);
-  return run_job_locked(e, job, cols, out_memory, out, points_out, stream, 0);
+  // one job context = one job in flight; a streaming state is advanced by one batch at a time
+  std::unique_lock<std::mutex> state_lk;
+  if (stream) state_lk = std::unique_lock<std::mutex>(stream->mu);
+  Lease lease(eng, job->id, !points_mode && job->algo == TAD_ALGO_ARIMA);
+  if (!lease.c) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_run: no job context available");
+  return run_job_locked(lease.c, job, cols, out_memory, out, points_out, stream, 0);
 }
 
-// the validated job with e->mu held; depth > 0: a length class of a skewed sparse table run as a job of its own
-int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
+// the validated job on the context the caller holds; depth > 0: a length class of a skewed sparse table run as a job of its own
+int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_mem out_memory, tad_result **out, tad_points **points_out,
                    tad_state *stream, int depth) {
   const bool points_mode = points_out != nullptr;
   HIP_TRY(e, hipSetDevice(e->device));
@@ -702,7 +816,6 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   if (depth == 0) {
     e->done.store(0);
     e->total.store(4);
-    e->placement = tad_engine::Placement{};
   }
 
   JobParams jp;
@@ -739,7 +852,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   Lattice L = make_lattice(cols->t0, lat_mode == 0 ? cols->step : 1, cols->n_buckets);
   bool empty = (n == 0 || K == 0);
   // Stage 0 strategy: v2 (partition + LDS tiles) for big batches, v1 (direct atomics) otherwise / as fallback.
-  const tad_plan plan = e->plan;   // (e->mu is held)
+  const tad_plan plan = e->plan;   // (the engine's plan when the job was admitted)
   const bool force_v1 = plan.stage0 == 1;
   const bool force_v2 = plan.stage0 == 2;
   const bool has2 = cols->key_id2 != nullptr;
@@ -750,21 +863,16 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
   // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  tad_plan.histogram = 1 disables it.
   bool force_exact_hist = plan.histogram == 1;
   bool sparse_lsd = plan.sparse_sort == 1;   // set when the partition + LDS-sort form of the sparse Stage 0 met a heavy key bin or a value too wide for its records
-  // The one-synchronisation form.  A job normally synchronises with the host three times: for the lattice (pass A's partials), for
-  // the row count (the result block is sized from it) and at the end.  A job of the SAME SHAPE as the engine's previous one — rows,
-  // keys, algorithm, filters; device-resident in and out — is instead issued in one go with that job's lattice and a result block
-  // sized from that job's rows, while the device checks both: k_lattice_check derives the lattice from this job's pass A exactly as
-  // the host would, the emit kernels compare the row total with the block.  A miss (DEV_ERR_SPEC, or any other device error) throws
-  // the output away and the job runs again in the three-synchronisation form, which also refreshes the remembered shape.
-  const tad_engine::Spec &sp = e->spec;
-  bool spec_ok = depth == 0 && plan.one_sync != 1 && !points_mode && !stream && out_memory == TAD_MEM_DEVICE && cols->memory == TAD_MEM_DEVICE &&
-                 !jp.all_points && cols->n_buckets == 0 && (jp.algo == TAD_ALGO_EWMA || jp.algo == TAD_ALGO_DBSCAN) && sp.valid && sp.n == n &&
-                 sp.K == K && sp.has2 == has2 && sp.algo == (int)job->algo && sp.agg == (int)job->agg_flow && sp.op == (int)op_max && sp.flags == job->flags &&
-                 sp.start == job->start_time && sp.end == job->end_time;
-  if (spec_ok && sp.exact_hist) force_exact_hist = true;
-  if (spec_ok && sp.wide_tiles) force_wide_tiles = true;
+  // what the context's last job learnt about a table of this shape: skip the attempt that is known to fail
+  {
+    const JobCtx::Learnt &lt = e->learnt;
+    if (depth == 0 && lt.valid && lt.n == n && lt.K == K && lt.has2 == has2 && lt.algo == (int)job->algo && lt.op == (int)op_max) {
+      if (lt.exact_hist) force_exact_hist = true;
+      if (lt.wide_tiles) force_wide_tiles = true;
+    }
+  }
   // retries: wrong hint -> derive (0 -> 1); sampled lattice too coarse / saw no live row -> exact (1 -> 2); overflow list
-  // full -> Stage 0 v1; a missed speculation -> the plain form.  Each transition happens at most once, so 8 attempts cover every path.
+  // full -> Stage 0 v1.  Each transition happens at most once, so 8 attempts cover every path.
   for (int attempt = 0; attempt < 11; ++attempt) {
     const bool hinted = lat_mode == 0;
     HIP_TRY(e, hipMemsetAsync(ctr, 0, kTailMoments, s));    // counters, row total, overflow-list count
@@ -795,10 +903,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       launch_meta(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, n, rf,
                   static_cast<MetaPartial *>(e->meta.p), meta_blocks);
     }
-    const bool spec = spec_ok && v2 && lat_mode == 1 && !empty;
-    if (spec) {   // the remembered lattice, verified on the device against this job's own pass A (an extra workgroup of k_part_offsets)
-      L = sp.L;
-    } else if (!hinted && !empty) {
+    if (!hinted && !empty) {
       HIP_TRY(e, hipMemcpyAsync(e->meta_host, e->meta.p, sizeof(MetaPartial) * meta_blocks, hipMemcpyDeviceToHost, s));
       HIP_TRY(e, hipStreamSynchronize(s));
       int64_t tmin = 0, tmax = 0, tref = 0;
@@ -974,7 +1079,6 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     Grid g{static_cast<unsigned long long *>(e->grid_val.p), static_cast<uint8_t *>(e->grid_flag.p), empty ? 0 : K, L.nb, nullptr};
     if (sparse) g = sparse_grid;
     if (v2 && !part_plan_tiles(K, L.nb, has2, &pl)) v2 = false;  // tile does not fit LDS: direct scatter
-    if (spec && (!v2 || sparse)) { e->spec.valid = false; spec_ok = false; continue; }   // (cannot happen: the remembered job ran this very plan; the lattice check lives in the v2 path)
     const bool stats_done = false;
     if (sparse) {
       // the rank grid is already filled
@@ -991,29 +1095,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       if ((rc = ensure(e, e->part_total, (size_t)pl.nparts * 4)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_start, ((size_t)pl.nparts + 1) * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->part_offs32, (size_t)pl.G * pl.nparts * 4)) != TAD_OK) return rc;
-      bool want_place = false, place_fresh = false;
-      {
-        const void *recs_before = e->recs.p;
-        // a buffer more than twice the size this job needs (a smaller table behind a bigger one) is given back first: the search below then
-        // runs over allocations of THIS job's size
-        if (e->recs.p != nullptr && (size_t)slots * 8 < e->recs.cap / 2 && plan.placement != 1 && e->placed_for.jobs_since >= 16) {
-          HIP_TRY(e, hipStreamSynchronize(s));
-          HIP_TRY(e, hipFree(e->recs.raw ? e->recs.raw : e->recs.p));
-          e->recs = DevBuf{};
-          recs_before = nullptr;
-        }
-        if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
-        // a new buffer of a big table — or other columns / another shape than the buffer in place was timed against: keep the best of a few
-        // placements (place_recs); plain 16-byte aligned columns only (the probe reads them); tad_plan.placement = 1 turns it off
-        const bool fresh = e->recs.p != recs_before;
-        const tad_engine::PlacedFor &pf = e->placed_for;
-        const bool moved = pf.key != d_key || pf.te != d_te || pf.val != d_val || pf.n != n || pf.nparts != pl.nparts;
-        if (fresh) e->placed_for = tad_engine::PlacedFor{};
-        // (a caller that brings new column buffers with every job must not pay three probe launches per job: re-timed at most once in 16 jobs)
-        want_place = plan.placement != 1 && (fresh || (moved && pf.jobs_since >= 16)) && !has2 && columns_aligned16(d_key, d_key2, d_te, d_val);
-        place_fresh = fresh;
-        if (e->placed_for.jobs_since < (1 << 20)) e->placed_for.jobs_since++;
-      }
+      if ((rc = ensure(e, e->recs, (size_t)slots * 8)) != TAD_OK) return rc;
       if ((rc = ensure(e, e->ovf, 16 + (size_t)kOverflowCap * sizeof(OverflowRec))) != TAD_OK) return rc;
       unsigned long long *ovf_count = dev_ovf_count(e);     // in the job tail: zeroed with the counters, one fill per attempt
       OverflowRec *ovf = reinterpret_cast<OverflowRec *>(static_cast<unsigned char *>(e->ovf.p) + 16);
@@ -1023,7 +1105,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
       launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start,
-                          hist_sampled, static_cast<const MetaPartial *>(e->meta.p), n, slots, e->slices.p, g, spec ? &L : nullptr, meta_blocks, ctr);
+                          hist_sampled, static_cast<const MetaPartial *>(e->meta.p), n, slots, e->slices.p, g);
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
       // DBSCAN job: pass C in settle mode — key rounds, the detector's per-key pass on the LDS tile, grid columns of unsettled keys only.
@@ -1053,18 +1135,6 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         dbscan_redo_series(g, e->aux.p, &settle.rs_val, &settle.rs_flag, &settle.rs_has, &settle.rs_cap);
         jp.settled = true;
         narrow_tiles = pl.narrow;
-      }
-      if (want_place) {
-        // the calibration runs of pass B write their counters, `fin` and (nothing of) the overflow list to scratch memory: [DevCounters | count | fin]
-        const size_t fin_bytes = fin != nullptr ? (size_t)pl.G * pl.nparts * 8 : 0;
-        if ((rc = ensure(e, e->place_scratch, 128 + fin_bytes)) != TAD_OK) return rc;
-        unsigned char *sc = static_cast<unsigned char *>(e->place_scratch.p);
-        place_recs(e, [&](void *cand) {
-          (void)hipMemsetAsync(sc, 0, 128, s);
-          launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K, rf, L, pl,
-                           offs32, part_start, cand, ovf, reinterpret_cast<unsigned long long *>(sc + 64), 0, reinterpret_cast<DevCounters *>(sc),
-                           fin != nullptr ? reinterpret_cast<uint32_t *>(sc + 128) : nullptr, nullptr);
-        }, d_key, d_te, d_val, n, pl.nparts, place_fresh);
       }
       HIP_TRY(e, hipEventRecord(e->ev[2], s));
       launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts,
@@ -1117,11 +1187,9 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       rows = *e->total_host;
       for (int b = 0; b < kMomentBlocks; ++b) e->moments_host[b] = Moments{0.0, 0.0, 0.0};
     } else {
-      if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done, spec)) != TAD_OK) return rc;
-      if (spec) rows = sp.rows + sp.rows / 8 + 4096;    // the CAPACITY of the result block until the tail arrives
+      if ((rc = detect_and_count(e, g, jp, ctr, &rows, stats_done)) != TAD_OK) return rc;
     }
-    DevCounters c = *e->ctr_host;
-    if (spec) c = DevCounters{};                         // (not fetched yet: checked after the emit)
+    const DevCounters c = *e->ctr_host;
     if (c.err & DEV_ERR_KEY_RANGE)
       return fail(e, TAD_ERR_KEY_RANGE, "a key id is >= num_keys (%llu) and is not TAD_KEY_SKIP", (unsigned long long)K);
     if (c.err & DEV_ERR_LATE_ROW)
@@ -1155,27 +1223,27 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
                            reinterpret_cast<long long *>(d + r * 8), reinterpret_cast<unsigned long long *>(d + r * 16));
       {
         const hipError_t er = hipEventRecord(e->ev[4], s);
-        if (er != hipSuccess) { e->free_blocks.push_back({blk.base, blk.cap}); delete pp; return fail(e, TAD_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er)); }
+        if (er != hipSuccess) { release_block(e, blk.base, blk.cap); delete pp; return fail(e, TAD_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er)); }
       }
       unsigned char *base = d;
       if (out_memory == TAD_MEM_HOST) {
         void *h = malloc(bytes);
-        if (!h) { e->free_blocks.push_back({blk.base, blk.cap}); delete pp; return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu bytes of points", bytes); }
+        if (!h) { release_block(e, blk.base, blk.cap); delete pp; return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu bytes of points", bytes); }
         hipError_t hr = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
         if (hr == hipSuccess) hr = hipStreamSynchronize(s);
-        e->free_blocks.push_back({blk.base, blk.cap});
+        release_block(e, blk.base, blk.cap);
         if (hr != hipSuccess) { free(h); delete pp; return fail(e, TAD_ERR_HIP, "points copy failed: %s", hipGetErrorString(hr)); }
         base = static_cast<unsigned char *>(h);
         pp->block = h; pp->block_cap = bytes;
       } else {
         const hipError_t hr = hipStreamSynchronize(s);
-        if (hr != hipSuccess) { e->free_blocks.push_back({blk.base, blk.cap}); delete pp; return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(hr)); }
+        if (hr != hipSuccess) { release_block(e, blk.base, blk.cap); delete pp; return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(hr)); }
         pp->block = blk.base; pp->block_cap = blk.cap;
       }
       {
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
-          if (out_memory == TAD_MEM_HOST) free(pp->block); else e->free_blocks.push_back({pp->block, pp->block_cap});
+          if (out_memory == TAD_MEM_HOST) free(pp->block); else release_block(e, pp->block, pp->block_cap);
           delete pp;
           return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le));
         }
@@ -1221,31 +1289,19 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
       launch_stream(s, g, L, jp.alpha, jp.all_points, true, state_view(stream, stream->cur), state_view(stream, stream->cur ^ 1),
                     nullptr, static_cast<const unsigned long long *>(e->off.p), dev_rows, ctr);
     else if (rows)
-      emit_rows(e, g, L, jp, dev_rows, spec ? sp.rows : rows, spec ? EmitGuard{dev_total(e), rows, ctr} : EmitGuard{nullptr, 0, nullptr});
+      emit_rows(e, g, L, jp, dev_rows, rows);
     {
       const hipError_t er = hipEventRecord(e->ev[4], s);
       if (er != hipSuccess) {
-        e->free_blocks.push_back({dev_block.base, dev_block.cap});
+        release_block(e, dev_block.base, dev_block.cap);
         delete rp;
         return fail(e, TAD_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er));
       }
     }
     if ((rc = finish_result(e, rp, rows, jp.all_points, dev_block, dev_rows)) != TAD_OK) { delete rp; return rc; }
-    hipError_t le = spec ? hipMemcpyAsync(e->tail_host, e->counters.p, kTailBytes, hipMemcpyDeviceToHost, s) : hipSuccess;   // the job's ONE round trip
-    if (le == hipSuccess) le = hipStreamSynchronize(s);
+    hipError_t le = hipStreamSynchronize(s);
     if (le == hipSuccess) le = hipGetLastError();
-    if (le != hipSuccess) { result_free_locked(e, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
-    if (spec) {
-      c = *e->ctr_host;
-      if (c.err != 0 || *e->total_host > rows) {   // the lattice or the capacity did not hold, or Stage 0 raised something: the plain form sorts it out
-        result_free_locked(e, &rp->pub);
-        e->spec.valid = false;
-        spec_ok = false;
-        continue;
-      }
-      rows = *e->total_host;
-      rp->pub.n_rows = rows;
-    }
+    if (le != hipSuccess) { tad_result_free(e->eng, &rp->pub); return fail(e, TAD_ERR_HIP, "kernel failure: %s", hipGetErrorString(le)); }
 
     tad_stats &st = rp->pub.stats;
     st.rows_in = n;
@@ -1282,7 +1338,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
         if (out_memory == TAD_MEM_DEVICE) {
           tmp.resize(rows);
           const hipError_t cr = hipMemcpy(tmp.data(), rp->pub.anomaly, rows, hipMemcpyDeviceToHost);
-          if (cr != hipSuccess) { result_free_locked(e, &rp->pub); return fail(e, TAD_ERR_HIP, "verdict copy failed: %s", hipGetErrorString(cr)); }
+          if (cr != hipSuccess) { tad_result_free(e->eng, &rp->pub); return fail(e, TAD_ERR_HIP, "verdict copy failed: %s", hipGetErrorString(cr)); }
           a = tmp.data();
         }
         for (uint64_t i = 0; i < rows; ++i) st.n_anomalies += a[i];
@@ -1295,18 +1351,13 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
     st.stage0_path = sparse ? (sp_part ? 8 : 4) : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
     st.stage0_attempts = attempt + 1;
     st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
-    st.host_syncs = spec ? 1 : ((hinted || empty) ? 2 : 3);
-    st.placement_candidates = e->placement.candidates;
-    st.placement_ms = e->placement.ms;
-    st.placement_kept_ms = e->placement.kept_ms;
-    st.placement_worst_ms = e->placement.worst_ms;
+    st.host_syncs = (hinted || empty) ? 2 : 3;
+    st.job_context = e->index;
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
-    // remember the shape for the next job (only what the device can re-verify: a lattice derived from pass A's sample, the v2 path)
-    if (depth == 0 && !points_mode && !stream && !jp.all_points) {
-      tad_engine::Spec &w = e->spec;
-      w.valid = v2 && !sparse && lat_mode == 1 && !force_v1_retry && !empty;
-      w.n = n; w.K = K; w.has2 = has2; w.algo = (int)job->algo; w.agg = (int)job->agg_flow; w.op = (int)op_max; w.flags = job->flags;
-      w.start = job->start_time; w.end = job->end_time; w.L = L; w.rows = rows; w.exact_hist = force_exact_hist && plan.histogram != 1;
+    if (depth == 0 && !points_mode && !stream) {
+      JobCtx::Learnt &w = e->learnt;
+      w.valid = true; w.n = n; w.K = K; w.has2 = has2; w.algo = (int)job->algo; w.op = (int)op_max;
+      w.exact_hist = force_exact_hist && plan.histogram != 1;
       w.wide_tiles = force_wide_tiles && plan.tile_cells != 1;
     }
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);
@@ -1320,7 +1371,7 @@ int run_job_locked(tad_engine *e, const tad_job *job, const tad_columns *cols, t
 
 // Stage 0 alone on a sparse table whose rank grid does not fit: the sorted unique points (e->sp_comp_a / e->sp_val_a) are
 // the answer — three columns out, counters and moments from the same pass (tad_sparse.hip:k_sparse_points_out).
-int sparse_points_direct(tad_engine *e, uint64_t n_rows_in, uint64_t rows_used, Lattice L, uint64_t P, DevCounters *ctr, tad_mem out_memory,
+int sparse_points_direct(JobCtx *e, uint64_t n_rows_in, uint64_t rows_used, Lattice L, uint64_t P, DevCounters *ctr, tad_mem out_memory,
                          tad_points **points_out) {
   hipStream_t s = e->stream;
   int rc;
@@ -1340,20 +1391,20 @@ int sparse_points_direct(tad_engine *e, uint64_t n_rows_in, uint64_t rows_used, 
   void *h = nullptr;
   if (hr == hipSuccess && out_memory == TAD_MEM_HOST) {
     h = malloc(bytes);
-    if (!h) { e->free_blocks.push_back({blk.base, blk.cap}); delete pp; return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu bytes of points", bytes); }
+    if (!h) { release_block(e, blk.base, blk.cap); delete pp; return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory for %zu bytes of points", bytes); }
     hr = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
   }
   if (hr == hipSuccess) hr = hipStreamSynchronize(s);
   if (hr == hipSuccess) hr = hipGetLastError();
   if (hr != hipSuccess) {
-    e->free_blocks.push_back({blk.base, blk.cap});
+    release_block(e, blk.base, blk.cap);
     free(h);
     delete pp;
     return fail(e, TAD_ERR_HIP, "sparse Stage 0, points: %s", hipGetErrorString(hr));
   }
   unsigned char *base = d;
   if (out_memory == TAD_MEM_HOST) {
-    e->free_blocks.push_back({blk.base, blk.cap});
+    release_block(e, blk.base, blk.cap);
     base = static_cast<unsigned char *>(h);
     pp->block = h; pp->block_cap = bytes;
   } else {
@@ -1395,7 +1446,7 @@ int sparse_points_direct(tad_engine *e, uint64_t n_rows_in, uint64_t rows_used, 
 // moments are Chan-merged in class order (telemetry).  On entry the sorted unique points are in e->sp_comp_a / e->sp_val_a
 // (P of them), e->sp_first[k] = first point of key k; the class jobs reuse every engine buffer, so the parent's state moves
 // to a block of its own first.
-int run_sparse_classes(tad_engine *e, const tad_job *job, const JobParams &jp, bool op_max, uint64_t n_rows_in, uint64_t rows_used, uint64_t K, Lattice L,
+int run_sparse_classes(JobCtx *e, const tad_job *job, const JobParams &jp, bool op_max, uint64_t n_rows_in, uint64_t rows_used, uint64_t K, Lattice L,
                        uint64_t P, uint32_t tmax, tad_mem out_memory, tad_result **out) {
   hipStream_t s = e->stream;
   int rc;
@@ -1423,8 +1474,8 @@ int run_sparse_classes(tad_engine *e, const tad_job *job, const JobParams &jp, b
   struct Cls { uint64_t keys, points, key0, pt0; tad_result *res; };
   std::vector<Cls> cls;
   auto release = [&]() {
-    for (Cls &c : cls) if (c.res) { result_free_locked(e, c.res); c.res = nullptr; }
-    e->free_blocks.push_back({blk.base, blk.cap});
+    for (Cls &c : cls) if (c.res) { tad_result_free(e->eng, c.res); c.res = nullptr; }
+    release_block(e, blk.base, blk.cap);
   };
   uint64_t key0 = 0, pt0 = 0;
   for (uint32_t c = 0; c < nclass; ++c) {
@@ -1490,7 +1541,7 @@ int run_sparse_classes(tad_engine *e, const tad_job *job, const JobParams &jp, b
   if (hr == hipSuccess) hr = hipStreamSynchronize(s);
   if (hr == hipSuccess) hr = hipGetLastError();
   if (hr != hipSuccess) {
-    e->free_blocks.push_back({dev_block.base, dev_block.cap});
+    release_block(e, dev_block.base, dev_block.cap);
     delete rp;
     release();
     return fail(e, TAD_ERR_HIP, "length classes, merge: %s", hipGetErrorString(hr));
@@ -1549,10 +1600,12 @@ int tad_run_stream(tad_engine *e, tad_state *st, const tad_job *job, const tad_c
   return run_job(e, job, cols, out_memory, out, nullptr, st);
 }
 
-int tad_state_create(tad_engine *e, uint64_t num_keys, tad_state **out) {
-  if (!e || !out || num_keys == 0) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_state_create: bad arguments");
+int tad_state_create(tad_engine *eng, uint64_t num_keys, tad_state **out) {
+  if (!eng || !out || num_keys == 0) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_state_create: bad arguments");
   *out = nullptr;
-  std::lock_guard<std::mutex> lk(e->mu);
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_state_create: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   tad_state *st = new (std::nothrow) tad_state();
   if (!st) return fail(e, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
@@ -1573,16 +1626,19 @@ int tad_state_create(tad_engine *e, uint64_t num_keys, tad_state **out) {
 
 void tad_state_destroy(tad_engine *e, tad_state *st) {
   if (!st) return;
-  if (e) { std::lock_guard<std::mutex> lk(e->mu); hipSetDevice(e->device); hipStreamSynchronize(e->stream); }
+  { std::lock_guard<std::mutex> lk(st->mu); }   // a batch on this state has returned (it synchronises its stream before it does)
+  if (e) hipSetDevice(e->device);
   for (int i = 0; i < 2; ++i) if (st->block[i]) hipFree(st->block[i]);
   delete st;
 }
 
-int tad_state_export(tad_engine *e, const tad_state *st, uint32_t *n, double *avg, double *m2, double *ewma, int64_t *last_t) {
-  if (!e || !st) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_state_export: bad arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+int tad_state_export(tad_engine *eng, const tad_state *st, uint32_t *n, double *avg, double *m2, double *ewma, int64_t *last_t) {
+  if (!eng || !st) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_state_export: bad arguments");
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_state_export: no job context available");
+  std::lock_guard<std::mutex> state_lk(st->mu);
   HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
   const StreamState v = state_view(st, st->cur);
   if (n) HIP_TRY(e, hipMemcpy(n, v.n, st->K * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (avg) HIP_TRY(e, hipMemcpy(avg, v.avg, st->K * sizeof(double), hipMemcpyDeviceToHost));
@@ -1597,16 +1653,18 @@ int tad_aggregate(tad_engine *e, const tad_job *job, const tad_columns *cols, ta
   return run_job(e, job, cols, out_memory, nullptr, out);
 }
 
-int tad_shard_rows(tad_engine *e, const tad_columns *cols, uint32_t world, uint64_t *out_key_id, int64_t *out_flow_end_s,
+int tad_shard_rows(tad_engine *eng, const tad_columns *cols, uint32_t world, uint64_t *out_key_id, int64_t *out_flow_end_s,
                    uint64_t *out_value, uint64_t *counts) {
-  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: engine is NULL");
-  if (!cols || !counts || !shard_world_ok(world)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: bad arguments (1 <= world <= 1024)");
+  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: engine is NULL");
+  if (!cols || !counts || !shard_world_ok(world)) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: bad arguments (1 <= world <= 1024)");
   if (cols->memory != TAD_MEM_DEVICE || cols->key_id2 || cols->flow_start_s)
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: device columns with one key per row only");
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: device columns with one key per row only");
   const uint64_t n = cols->n_rows;
   if (n && (!cols->key_id || !cols->flow_end_s || !cols->value || !out_key_id || !out_flow_end_s || !out_value))
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: key_id, flow_end_s, value and the three outputs are required");
-  std::lock_guard<std::mutex> lk(e->mu);
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: key_id, flow_end_s, value and the three outputs are required");
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_shard_rows: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   hipStream_t s = e->stream;
   int rc;
@@ -1627,20 +1685,22 @@ int tad_shard_rows(tad_engine *e, const tad_columns *cols, uint32_t world, uint6
   return TAD_OK;
 }
 
-int tad_factorize(tad_engine *e, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row, uint64_t first_row_cap,
+int tad_factorize(tad_engine *eng, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row, uint64_t first_row_cap,
                   uint64_t *num_keys) {
-  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: engine is NULL");
+  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: engine is NULL");
   if (!kc || !num_keys || kc->n_cols < 1 || kc->n_cols > kFzMaxCols || !kc->cols_a || (kc->n_rows && !key_id) || (kc->cols_b && kc->n_rows && !key_id2) ||
       (first_row_cap && !first_row))
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: bad arguments (1..%d key columns, key_id / key_id2 / first_row buffers)", kFzMaxCols);
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: bad arguments (1..%d key columns, key_id / key_id2 / first_row buffers)", kFzMaxCols);
   const uint64_t n = kc->n_rows;
   const uint32_t sides = kc->cols_b ? 2 : 1;
   *num_keys = 0;
   if (n == 0) return TAD_OK;
-  if (n * sides >= 0xFFFFFFFFull) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: %llu virtual rows do not fit 32-bit row indices", (unsigned long long)(n * sides));
+  if (n * sides >= 0xFFFFFFFFull) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: %llu virtual rows do not fit 32-bit row indices", (unsigned long long)(n * sides));
   for (int c = 0; c < kc->n_cols; ++c)
-    if (!kc->cols_a[c] || (kc->cols_b && !kc->cols_b[c])) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: key column %d is NULL", c);
-  std::lock_guard<std::mutex> lk(e->mu);
+    if (!kc->cols_a[c] || (kc->cols_b && !kc->cols_b[c])) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: key column %d is NULL", c);
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_factorize: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   hipStream_t s = e->stream;
   const bool host = kc->memory == TAD_MEM_HOST;
@@ -1701,16 +1761,18 @@ int tad_factorize(tad_engine *e, const tad_key_columns *kc, uint64_t *key_id, ui
   }
 }
 
-int tad_encode_strings(tad_engine *e, const tad_string_column *col, int64_t *codes, uint64_t *first_row, uint64_t first_row_cap, uint64_t *num_values) {
-  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: engine is NULL");
+int tad_encode_strings(tad_engine *eng, const tad_string_column *col, int64_t *codes, uint64_t *first_row, uint64_t first_row_cap, uint64_t *num_values) {
+  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: engine is NULL");
   if (!col || !num_values || (col->offset_bits != 32 && col->offset_bits != 64) || (col->n_rows && (!col->offsets || !codes)) || (first_row_cap && !first_row) ||
       (col->data_bytes && !col->data))
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: bad arguments (offsets of 32 or 64 bits, data, codes / first_row buffers)");
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: bad arguments (offsets of 32 or 64 bits, data, codes / first_row buffers)");
   const uint64_t n = col->n_rows;
   *num_values = 0;
   if (n == 0) return TAD_OK;
-  if (n >= 0xFFFFFFFFull) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: %llu rows do not fit 32-bit row indices", (unsigned long long)n);
-  std::lock_guard<std::mutex> lk(e->mu);
+  if (n >= 0xFFFFFFFFull) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: %llu rows do not fit 32-bit row indices", (unsigned long long)n);
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_encode_strings: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   hipStream_t s = e->stream;
   const bool host = col->memory == TAD_MEM_HOST;
@@ -1771,15 +1833,9 @@ void tad_points_free(tad_engine *e, tad_points *p) {
   if (!p) return;
   PointsPriv *pp = reinterpret_cast<PointsPriv *>(p);
   if (pp->block) {
-    if (p->memory == TAD_MEM_DEVICE && e) {
-      std::lock_guard<std::mutex> lk(e->mu);
-      if (e->free_blocks.size() < 8) e->free_blocks.push_back({pp->block, pp->block_cap});
-      else { hipSetDevice(e->device); hipFree(pp->block); }
-    } else if (p->memory == TAD_MEM_DEVICE) {
-      hipFree(pp->block);
-    } else {
-      free(pp->block);
-    }
+    if (p->memory == TAD_MEM_DEVICE && e) release_block(e, pp->block, pp->block_cap);
+    else if (p->memory == TAD_MEM_DEVICE) hipFree(pp->block);
+    else free(pp->block);
   }
   delete pp;
 }
@@ -1792,7 +1848,7 @@ void tad_points_free(tad_engine *e, tad_points *p) {
 namespace {
 
 // Fill the engine's grid with one series: K = 1, T = n, every point present.
-int series_grid(tad_engine *e, const uint64_t *x, uint64_t n, Grid *g) {
+int series_grid(JobCtx *e, const uint64_t *x, uint64_t n, Grid *g) {
   int rc;
   if ((rc = ensure(e, e->grid_val, (n ? n : 1) * 8)) != TAD_OK) return rc;
   if ((rc = ensure(e, e->grid_flag, n ? n : 1)) != TAD_OK) return rc;
@@ -1811,7 +1867,7 @@ int series_grid(tad_engine *e, const uint64_t *x, uint64_t n, Grid *g) {
 }
 
 // Emit every point of a one-key grid with given sigma; copies verdicts / calc to the host.
-int series_emit_all(tad_engine *e, Grid g, const JobParams &jp, bool has_sigma, double sigma, double *calc_out, uint8_t *verdict_out) {
+int series_emit_all(JobCtx *e, Grid g, const JobParams &jp, bool has_sigma, double sigma, double *calc_out, uint8_t *verdict_out) {
   const uint64_t n = g.T;
   int rc;
   if ((rc = ensure(e, e->sigma, sizeof(double))) != TAD_OK) return rc;
@@ -1833,7 +1889,7 @@ int series_emit_all(tad_engine *e, Grid g, const JobParams &jp, bool has_sigma, 
   if (calc_out && n) r = hipMemcpyAsync(calc_out, o.algo_calc, n * 8, hipMemcpyDeviceToHost, e->stream);
   if (r == hipSuccess && verdict_out && n) r = hipMemcpyAsync(verdict_out, o.anomaly, n, hipMemcpyDeviceToHost, e->stream);
   if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
-  e->free_blocks.push_back({blk.base, blk.cap});
+  release_block(e, blk.base, blk.cap);
   if (r != hipSuccess) return fail(e, TAD_ERR_HIP, "series copy failed: %s", hipGetErrorString(r));
   return TAD_OK;
 }
@@ -1855,9 +1911,11 @@ JobParams series_params(tad_algo algo, double alpha, double eps, int min_samples
 
 extern "C" {
 
-int tad_series_ewma(tad_engine *e, const uint64_t *x, uint64_t n, double alpha, double *out) {
-  if (!e || (n && (!x || !out))) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_ewma: bad arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+int tad_series_ewma(tad_engine *eng, const uint64_t *x, uint64_t n, double alpha, double *out) {
+  if (!eng || (n && (!x || !out))) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_ewma: bad arguments");
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_ewma: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   Grid g;
   int rc = series_grid(e, x, n, &g);
@@ -1865,10 +1923,12 @@ int tad_series_ewma(tad_engine *e, const uint64_t *x, uint64_t n, double alpha, 
   return series_emit_all(e, g, series_params(TAD_ALGO_EWMA, alpha, 0, 0, 0), false, 0.0, out, nullptr);
 }
 
-int tad_series_ewma_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, double alpha, int has_stddev, double stddev,
+int tad_series_ewma_anomaly(tad_engine *eng, const uint64_t *x, uint64_t n, double alpha, int has_stddev, double stddev,
                             uint8_t *verdict) {
-  if (!e || (n && (!x || !verdict))) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_ewma_anomaly: bad arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+  if (!eng || (n && (!x || !verdict))) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_ewma_anomaly: bad arguments");
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_ewma_anomaly: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   Grid g;
   int rc = series_grid(e, x, n, &g);
@@ -1876,9 +1936,11 @@ int tad_series_ewma_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, double
   return series_emit_all(e, g, series_params(TAD_ALGO_EWMA, alpha, 0, 0, 0), has_stddev != 0, stddev, nullptr, verdict);
 }
 
-int tad_series_stddev(tad_engine *e, const uint64_t *x, uint64_t n, int *has_stddev, double *stddev) {
-  if (!e || !has_stddev || !stddev || (n && !x)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_stddev: bad arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+int tad_series_stddev(tad_engine *eng, const uint64_t *x, uint64_t n, int *has_stddev, double *stddev) {
+  if (!eng || !has_stddev || !stddev || (n && !x)) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_stddev: bad arguments");
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_stddev: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   *has_stddev = 0;
   *stddev = 0.0;
@@ -1899,10 +1961,12 @@ int tad_series_stddev(tad_engine *e, const uint64_t *x, uint64_t n, int *has_std
   return TAD_OK;
 }
 
-int tad_series_dbscan_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, double eps, int min_samples, uint8_t *verdict) {
-  if (!e || (n && (!x || !verdict)) || eps < 0.0 || min_samples < 0)
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_dbscan_anomaly: bad arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+int tad_series_dbscan_anomaly(tad_engine *eng, const uint64_t *x, uint64_t n, double eps, int min_samples, uint8_t *verdict) {
+  if (!eng || (n && (!x || !verdict)) || eps < 0.0 || min_samples < 0)
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_dbscan_anomaly: bad arguments");
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_dbscan_anomaly: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   Grid g;
   int rc = series_grid(e, x, n, &g);
@@ -1913,11 +1977,13 @@ int tad_series_dbscan_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, doub
   return series_emit_all(e, g, jp, false, 0.0, nullptr, verdict);
 }
 
-int tad_series_drop(tad_engine *e, const uint64_t *x, uint64_t n, double nsigma, int min_samples, int *has_result,
+int tad_series_drop(tad_engine *eng, const uint64_t *x, uint64_t n, double nsigma, int min_samples, int *has_result,
                     double *mean, double *stddev, uint8_t *verdict) {
-  if (!e || !has_result || !mean || !stddev || (n && (!x || !verdict)) || nsigma < 0.0 || min_samples < 0)
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_drop: bad arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+  if (!eng || !has_result || !mean || !stddev || (n && (!x || !verdict)) || nsigma < 0.0 || min_samples < 0)
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_drop: bad arguments");
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_drop: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   *has_result = 0;
   *mean = 0.0;
@@ -1947,8 +2013,8 @@ int tad_series_drop(tad_engine *e, const uint64_t *x, uint64_t n, double nsigma,
 
 namespace {
 
-// calculate_arima / calculate_arima_anomaly on one series; the caller holds e->mu.  pred_out (n doubles) may be NULL.
-int series_arima_locked(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
+// calculate_arima / calculate_arima_anomaly on one series, on the context the caller holds.  pred_out (n doubles) may be NULL.
+int series_arima_locked(JobCtx *e, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
                         uint8_t *verdict, uint64_t *n_verdict, double *pred_out) {
   HIP_TRY(e, hipSetDevice(e->device));
   *n_verdict = 1;
@@ -1988,13 +2054,15 @@ int series_arima_locked(tad_engine *e, const uint64_t *x, uint64_t n, int maxite
 
 extern "C" {
 
-int tad_series_arima(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int *has_result, double *out) {
-  if (!e || !has_result || (n && (!x || !out)) || maxiter < 0) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima: bad arguments");
+int tad_series_arima(tad_engine *eng, const uint64_t *x, uint64_t n, int maxiter, int *has_result, double *out) {
+  if (!eng || !has_result || (n && (!x || !out)) || maxiter < 0) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima: bad arguments");
   uint64_t nv = 0;
   std::vector<uint8_t> verdict(n ? n : 1);
   std::vector<double> pred(n ? n : 1);
   // ONE critical section: the predictions are read from the engine's calc buffer before any other thread can run
-  std::lock_guard<std::mutex> lk(e->mu);
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_arima: no job context available");
   const int rc = series_arima_locked(e, x, n, maxiter, 0, 0.0, verdict.data(), &nv, pred.data());
   if (rc != TAD_OK) return rc;
   *has_result = (nv == n && n > 3) ? 1 : 0;
@@ -2002,19 +2070,23 @@ int tad_series_arima(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, 
   return TAD_OK;
 }
 
-int tad_series_arima_anomaly(tad_engine *e, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
+int tad_series_arima_anomaly(tad_engine *eng, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
                              uint8_t *verdict, uint64_t *n_verdict) {
-  if (!e || !n_verdict || !verdict || (n && !x) || maxiter < 0)
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima_anomaly: bad arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+  if (!eng || !n_verdict || !verdict || (n && !x) || maxiter < 0)
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima_anomaly: bad arguments");
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_arima_anomaly: no job context available");
   return series_arima_locked(e, x, n, maxiter, has_stddev, stddev, verdict, n_verdict, nullptr);
 }
 
-int tad_synth_generate(tad_engine *e, uint64_t seed, uint64_t first_row, uint64_t n_rows, uint64_t num_keys,
+int tad_synth_generate(tad_engine *eng, uint64_t seed, uint64_t first_row, uint64_t n_rows, uint64_t num_keys,
                        uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s, uint64_t *value) {
-  if (!e || num_keys == 0 || n_buckets == 0 || (n_rows && (!key_id || !flow_end_s || !value)))
-    return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_synth_generate: bad arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+  if (!eng || num_keys == 0 || n_buckets == 0 || (n_rows && (!key_id || !flow_end_s || !value)))
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_synth_generate: bad arguments");
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_synth_generate: no job context available");
   HIP_TRY(e, hipSetDevice(e->device));
   launch_synth(e->stream, seed, first_row, n_rows, num_keys, n_buckets, key_id, flow_end_s, value);
   HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -2033,8 +2105,7 @@ int tad_device_alloc(tad_engine *e, uint64_t bytes, void **ptr) {
 int tad_device_free(tad_engine *e, void *ptr) {
   if (!e) return TAD_ERR_INVALID_ARGUMENT;
   HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  if (ptr) HIP_TRY(e, hipFree(ptr));
+  if (ptr) HIP_TRY(e, hipFree(ptr));     // (every entry point synchronises its stream before it returns: nothing of the engine's is pending on caller memory)
   return TAD_OK;
 }
 
@@ -2048,7 +2119,6 @@ int tad_copy_to_device(tad_engine *e, void *dst, const void *src, uint64_t bytes
 int tad_copy_to_host(tad_engine *e, void *dst, const void *src, uint64_t bytes) {
   if (!e || (bytes && (!dst || !src))) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_copy_to_host: bad arguments");
   HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
   HIP_TRY(e, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return TAD_OK;
 }

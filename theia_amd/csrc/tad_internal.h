@@ -31,7 +31,7 @@ struct Grid {
 
 enum : uint32_t { DEV_ERR_KEY_RANGE = 1u, DEV_ERR_OFF_LATTICE = 2u, DEV_ERR_OVERFLOW_LIST = 4u, DEV_ERR_LATE_ROW = 8u,
                   DEV_ERR_REGION_FULL = 16u,   // Stage 0 v2 with a SAMPLED histogram: a (workgroup, partition) region was sized too small
-                  DEV_ERR_SPEC = 32u,          // the one-synchronisation job: the speculated lattice / result capacity did not hold (the job is redone)
+                  // (32u was DEV_ERR_SPEC of the one-synchronisation job, ABI 8-11: removed in round 6, see docs/HISTORY.md)
                   DEV_ERR_SPARSE_ROUND = 64u };  // sparse Stage 0 through the partition pass: one key bin holds more records than a workgroup sorts in LDS (the LSD sort takes over)
 enum : uint8_t { FLAG_PRESENT = 1, FLAG_ANOMALY = 2 };
 
@@ -59,14 +59,6 @@ struct DevCounters {
 struct RowFilter {
   int64_t start_time;  // 0 = unset
   int64_t end_time;    // 0 = unset
-};
-
-// The one-synchronisation job sizes the result block from the last job's row count before this job's count exists on the host:
-// the emit kernels read the total on the device and write nothing when it does not fit (cap == 0: no guard).
-struct EmitGuard {
-  const unsigned long long *total;
-  unsigned long long cap;
-  DevCounters *ctr;
 };
 
 struct OutRows {
@@ -235,8 +227,7 @@ void launch_scan_moments(hipStream_t s, const uint32_t *cnt, unsigned long long 
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
                  const unsigned long long *off, OutRows out, uint64_t rows_hint = 0,   // rows_hint: off[K] if the caller knows it
-                 int ewma_emit = 0, uint32_t ewma_emit_rows = 0,   // tad_plan: 1 = lane-per-key k_emit for the EWMA job; LDS rows per wavefront of the staged emit
-                 EmitGuard guard = EmitGuard{nullptr, 0, nullptr});
+                 int ewma_emit = 0, uint32_t ewma_emit_rows = 0);  // tad_plan: 1 = lane-per-key k_emit for the EWMA job; LDS rows per wavefront of the staged emit
 void launch_emit_points(hipStream_t s, Grid g, Lattice lat, const unsigned long long *off, unsigned long long *out_key,
                         long long *out_t, unsigned long long *out_val);
 // streaming EWMA: per-key running state (tad_state); k_stream continues the recurrences over the new grid
@@ -303,7 +294,7 @@ int launch_dbscan(hipStream_t s, Grid g, double eps, int min_samples, void *scra
 // DBSCAN job (statistics from the scan, sigma computed at emit): the rows from the work list launch_dbscan left in `scratch`,
 // one wavefront per listed key.  false: not applicable (series longer than a wavefront's registers hold) -> launch_emit(kind 4)
 bool launch_emit_dbscan_list(hipStream_t s, Grid g, Lattice lat, const void *scratch, const uint32_t *n_anom, const unsigned long long *off,
-                             OutRows out, EmitGuard guard = EmitGuard{nullptr, 0, nullptr});
+                             OutRows out);
 
 // drop detector (tad_drop.hip): sigma / n_pts / key_mean / key_m2 / counters + FLAG_ANOMALY; ws = K * T doubles
 void launch_drop(hipStream_t s, Grid g, double n_sigma, int min_samples, double *ws, double *sigma, uint32_t *n_pts,
@@ -355,11 +346,10 @@ bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 // offs32[G][nparts] (exclusive per-workgroup prefix inside each partition), total[nparts], part_start[nparts + 1]
 // sampled: the histogram is a sample -> region capacities (estimate + 6 sigma + margin); partials carry the sampling ratios
 // TWO launches (k_part_offsets, k_part_tail): also build the slice table of pass C in slice_mem (slice_table_bytes(slots, pl)) and zero
-// the grid tile of every partition that will be split into several slices.  spec_L != NULL (the one-synchronisation job): one extra
-// workgroup checks the speculated lattice against pass A's spec_n partials (DEV_ERR_SPEC into spec_ctr when they differ).
+// the grid tile of every partition that will be split into several slices.
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
                          unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n, uint64_t slots, void *slice_mem,
-                         Grid g, const Lattice *spec_L = nullptr, int spec_n = 0, DevCounters *spec_ctr = nullptr);
+                         Grid g);
 // upper bound of the record slots pass B may be given when the regions are sized from a sampled histogram
 uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl);
 // fin != NULL (sampled regions): no fillers; fin[(g * nparts + p) * 2 + {0, 1}] = end of the records written upwards /
@@ -440,5 +430,17 @@ void launch_encode_strings(hipStream_t s, const void *offsets, int off64, const 
 void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_rows,
                   uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,
                   uint64_t *value);
+
+// ---- code-object preload (tad_capi.cpp:preload_code_objects) ----
+// HIP loads a translation unit's code object on the first use of one of its kernels (~0.4 ms each, inside the first job otherwise).
+const void *code_anchor_arima();
+const void *code_anchor_dbscan();
+const void *code_anchor_drop();
+const void *code_anchor_factorize();
+const void *code_anchor_kernels();
+const void *code_anchor_shard();
+const void *code_anchor_sparse();
+const void *code_anchor_stage0_part();
+const void *code_anchor_synth();
 
 }  // namespace tad

@@ -606,23 +606,15 @@ void launch_scan_moments(hipStream_t s, const uint32_t *cnt, unsigned long long 
 // KIND 2: verdict bits, algoCalc = 0.0 (DBSCAN placeholder, :312-322).
 // ------------------------------------------------------------------------------------------------
 // COOP: one wavefront per key (walk_series_coop); all lanes run the recurrences, lane 0 stores the rows.
-// the result block was sized before the row count was known on the host: write nothing when the rows do not fit (workgroup-uniform)
-__device__ __forceinline__ bool emit_blocked(const EmitGuard &guard, bool reporter) {
-  if (guard.cap == 0 || *guard.total <= guard.cap) return false;
-  if (reporter) atomicOr(&guard.ctr->err, DEV_ERR_SPEC);
-  return true;
-}
-
 template <int KIND, bool ALL, bool COOP = false>
 __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha,
                                                  const double *__restrict__ sigma,
                                                  const uint32_t *__restrict__ n_pts,
                                                  const double *__restrict__ calc,
-                                                 const unsigned long long *__restrict__ off, OutRows out, EmitGuard guard) {
+                                                 const unsigned long long *__restrict__ off, OutRows out) {
   const uint64_t gtid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint64_t k = COOP ? gtid >> 6 : gtid;
   const bool writer = !COOP || (threadIdx.x & 63) == 0;
-  if (emit_blocked(guard, gtid == 0)) return;
   if (k >= g.K) return;
   unsigned long long pos = off[k];
   const unsigned long long end = off[k + 1];
@@ -723,9 +715,8 @@ __global__ __launch_bounds__(kBlock) void k_emit(Grid g, Lattice L, double alpha
 static constexpr int kStageMarkTBits = 26;   // marker = lane << 26 | t
 __global__ __launch_bounds__(64) void k_emit_staged(Grid g, Lattice L, double alpha, const double *__restrict__ sigma,
                                                     const uint32_t *__restrict__ n_pts,
-                                                    const unsigned long long *__restrict__ off, OutRows out, uint32_t cap, EmitGuard guard) {
+                                                    const unsigned long long *__restrict__ off, OutRows out, uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_stage[];
-  if (emit_blocked(guard, blockIdx.x == 0 && threadIdx.x == 0)) return;
   double *s_e = reinterpret_cast<double *>(smem_stage);                       // [cap]
   double *s_sg = s_e + cap;                                                   // [64]
   uint32_t *s_m = reinterpret_cast<uint32_t *>(s_sg + 64);                    // [cap]
@@ -799,12 +790,12 @@ static uint32_t emit_stage_rows(uint64_t K, uint64_t rows_hint, int ewma_emit, u
 
 void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, double alpha,
                  const double *sigma, const uint32_t *n_pts, const double *calc,
-                 const unsigned long long *off, OutRows out, uint64_t rows_hint, int ewma_emit, uint32_t ewma_emit_rows, EmitGuard guard) {
+                 const unsigned long long *off, OutRows out, uint64_t rows_hint, int ewma_emit, uint32_t ewma_emit_rows) {
   if (g.K == 0) return;
   if (coop_shape(g)) {   // long series on few keys: a wavefront per key (no staged variant: the rows of a key are written by one lane in time order)
     const int cblocks = (int)((g.K * 64 + kBlock - 1) / kBlock);
 #define TAD_LAUNCH_EMIT_C(KIND, ALL) \
-  hipLaunchKernelGGL((k_emit<KIND, ALL, true>), dim3(cblocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out, guard)
+  hipLaunchKernelGGL((k_emit<KIND, ALL, true>), dim3(cblocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out)
     if (all_points) {
       if (kind == 0) TAD_LAUNCH_EMIT_C(0, true); else if (kind == 1) TAD_LAUNCH_EMIT_C(1, true); else if (kind == 3) TAD_LAUNCH_EMIT_C(3, true); else TAD_LAUNCH_EMIT_C(2, true);
     } else {
@@ -817,13 +808,13 @@ void launch_emit(hipStream_t s, Grid g, Lattice lat, int kind, bool all_points, 
   if (kind == 0 && !all_points && g.T < (1ull << kStageMarkTBits)) {
     if (const uint32_t cap = emit_stage_rows(g.K, rows_hint, ewma_emit, ewma_emit_rows)) {
       const unsigned blocks64 = (unsigned)((g.K + 63) / 64);
-      hipLaunchKernelGGL(k_emit_staged, dim3(blocks64), dim3(64), (size_t)cap * 12 + 64 * 8, s, g, lat, alpha, sigma, n_pts, off, out, cap, guard);
+      hipLaunchKernelGGL(k_emit_staged, dim3(blocks64), dim3(64), (size_t)cap * 12 + 64 * 8, s, g, lat, alpha, sigma, n_pts, off, out, cap);
       return;
     }
   }
   const int blocks = (int)((g.K + kBlock - 1) / kBlock);
 #define TAD_LAUNCH_EMIT(KIND, ALL) \
-  hipLaunchKernelGGL((k_emit<KIND, ALL>), dim3(blocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out, guard)
+  hipLaunchKernelGGL((k_emit<KIND, ALL>), dim3(blocks), dim3(kBlock), 0, s, g, lat, alpha, sigma, n_pts, calc, off, out)
   if (all_points) {
     if (kind == 0) TAD_LAUNCH_EMIT(0, true); else if (kind == 1) TAD_LAUNCH_EMIT(1, true); else if (kind == 3) TAD_LAUNCH_EMIT(3, true); else TAD_LAUNCH_EMIT(2, true);
   } else {
@@ -971,5 +962,8 @@ void launch_ewma_values(hipStream_t s, Grid g, double alpha, double *calc) {
   const int blocks = (int)((g.K + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_ewma_values, dim3(blocks), dim3(kBlock), 0, s, g, alpha, calc);
 }
+
+// one kernel of this translation unit: tad_engine_create resolves it so that the unit's code object is loaded before the first job
+const void *code_anchor_kernels() { return reinterpret_cast<const void *>(&k_meta); }
 
 }  // namespace tad

@@ -102,4 +102,7 @@ void launch_shard_scatter(hipStream_t s, const uint64_t *key, const int64_t *t_e
                      cursor, out_key, out_t, out_val);
 }
 
+// one kernel of this translation unit: tad_engine_create resolves it so that the unit's code object is loaded before the first job
+const void *code_anchor_shard() { return reinterpret_cast<const void *>(&k_shard_count); }
+
 }  // namespace tad

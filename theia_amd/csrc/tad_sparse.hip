@@ -1299,4 +1299,7 @@ void launch_class_gather(hipStream_t s, OutRows src, uint64_t R, const uint32_t 
   hipLaunchKernelGGL(k_class_gather, dim3((unsigned)((R + kSpBlock - 1) / kSpBlock)), dim3(kSpBlock), 0, s, src, R, keymap, off, first_row, dst);
 }
 
+// one kernel of this translation unit: tad_engine_create resolves it so that the unit's code object is loaded before the first job
+const void *code_anchor_sparse() { return reinterpret_cast<const void *>(&k_sparse_first); }
+
 }  // namespace tad

@@ -293,47 +293,6 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
 }
 
 // ------------------------------------------------------------------------------------------------
-// The one-synchronisation job (tad_capi.cpp): the host issues the whole job with the lattice of the LAST job of the same shape
-// instead of waiting for pass A's partials; this kernel derives the lattice from the partials exactly as the host would (min,
-// max, gcd of the sampled differences, gcd with the span and the reference offset) and raises DEV_ERR_SPEC when it is not the
-// speculated one — the host then discards the job's output and redoes it with the host-derived lattice.  It runs as ONE EXTRA WORKGROUP
-// of k_part_offsets (which never reads the lattice), next to that kernel's own work: no launch, nothing on the critical path.  (Every row is still
-// checked against the lattice by pass B: a speculated lattice that merely CONTAINS the rows would give the same anomaly rows,
-// but not the same tad_stats; equality with the derivation keeps the two paths indistinguishable.)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lattice_check_block(const MetaPartial *__restrict__ partials, int n_partials, const Lattice &L, DevCounters *ctr) {
-  PMeta m{0, 0, 0, 0, 0};
-  for (int b = threadIdx.x; b < n_partials; b += 256) {
-    const MetaPartial p = partials[b];
-    PMeta o{p.tmin, p.tmax, p.tref, p.g, p.used};
-    m = pmeta_merge(m, o);
-  }
-  for (int d = 32; d >= 1; d >>= 1) {
-    PMeta o;
-    o.tmin = __shfl_down((long long)m.tmin, d);
-    o.tmax = __shfl_down((long long)m.tmax, d);
-    o.tref = __shfl_down((long long)m.tref, d);
-    o.g = __shfl_down((unsigned long long)m.g, d);
-    o.used = __shfl_down((unsigned long long)m.used, d);
-    m = pmeta_merge(m, o);
-  }
-  __shared__ PMeta s_m[4];
-  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  for (int w = 1; w < 4; ++w) m = pmeta_merge(m, s_m[w]);
-  bool same = m.used != 0;
-  if (same) {
-    const uint64_t span = (uint64_t)m.tmax - (uint64_t)m.tmin;
-    uint64_t step = p_gcd_u64(p_gcd_u64(m.g, span), (uint64_t)m.tref - (uint64_t)m.tmin);
-    if (step == 0) step = 1;
-    same = L.t0 == m.tmin && (uint64_t)L.step == step && L.nb == span / step + 1;
-  }
-  if (!same) atomicOr(&ctr->err, DEV_ERR_SPEC);
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // offsets: cnt[g][p] (row reduce of the bins) -> column-wise exclusive prefix over g -> part_start[p]
 // ------------------------------------------------------------------------------------------------
 // Capacity of a (workgroup, partition) region from a SAMPLED count s at sampling ratio 1 / scale: the estimate s * scale
@@ -365,11 +324,6 @@ struct OffsetsArgs {
   uint32_t slice_len;
   Grid g;                        // the grid tile of a partition that will be split into several slices is zeroed here
   int shift_part;
-  // the one-synchronisation job: the speculated lattice, checked by one extra workgroup against pass A's partials (spec_ctr NULL = off)
-  const MetaPartial *spec_partials;
-  int spec_n;
-  Lattice spec_L;
-  DevCounters *spec_ctr;
 };
 
 // TWO launches for everything between pass A and pass B (round 4; five before: k_part_rows, k_part_colscan — 256 dependent steps per
@@ -380,10 +334,6 @@ struct OffsetsArgs {
 // (A ticket that let the last workgroup of the first kernel do the tail was measured: the device-scope fences and the agent-scope
 // loads it needs made the one kernel slower — 40 us — than the two.)
 __global__ __launch_bounds__(256) void k_part_offsets(OffsetsArgs A) {
-  if (blockIdx.x == gridDim.x - 1 && A.spec_ctr != nullptr) {   // the extra workgroup: lattice check of the one-synchronisation job
-    lattice_check_block(A.spec_partials, A.spec_n, A.spec_L, A.spec_ctr);
-    return;
-  }
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t p = blockIdx.x * 4u + wave;
   const uint32_t per = (uint32_t)(A.G + 63) / 64u;                 // workgroups per lane (4 at G = 256)
@@ -1570,7 +1520,7 @@ static uint32_t slice_len_of(bool sampled, uint64_t slots, uint32_t nparts) {
 
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
                          unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n, uint64_t slots, void *slice_mem,
-                         Grid g, const Lattice *spec_L, int spec_n, DevCounters *spec_ctr) {
+                         Grid g) {
   static_assert(kMaxParts <= 8 * 256, "k_part_tail holds 8 partitions per thread");
   OffsetsArgs A;
   A.binhist = binhist; A.nbins = pl.nbins; A.bins_per_part = pl.bins_per_part; A.nparts = pl.nparts;
@@ -1581,8 +1531,7 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
   A.st = slice_table(slice_mem, slots, pl);
   A.slice_len = g.val == nullptr ? 0xFFFFFFFFu : slice_len_of(sampled, slots, pl.nparts);   // (no grid: the sparse sort reads whole partitions, nothing is split or pre-zeroed)
   A.g = g; A.shift_part = pl.shift_part;
-  A.spec_partials = partials; A.spec_n = spec_n; A.spec_L = spec_L != nullptr ? *spec_L : Lattice{}; A.spec_ctr = spec_L != nullptr ? spec_ctr : nullptr;
-  hipLaunchKernelGGL(k_part_offsets, dim3((pl.nparts + 3) / 4 + (A.spec_ctr != nullptr ? 1 : 0)), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(k_part_offsets, dim3((pl.nparts + 3) / 4), dim3(256), 0, s, A);
   hipLaunchKernelGGL(k_part_tail, dim3(1), dim3(256), 0, s, A);
 }
 
@@ -1679,5 +1628,8 @@ void launch_tile_aggregate(hipStream_t s, const void *recs, const unsigned long 
   else { if (op_max) TAD_TA(true, false); else TAD_TA(false, false); }
 #undef TAD_TA
 }
+
+// one kernel of this translation unit: tad_engine_create resolves it so that the unit's code object is loaded before the first job
+const void *code_anchor_stage0_part() { return reinterpret_cast<const void *>(&k_part_tail); }
 
 }  // namespace tad

@@ -243,9 +243,10 @@ class TadState:
 
 
 class TadEngine:
-    """One engine per GPU.  Thread-safe (runs serialise inside the library)."""
+    """One engine per GPU.  Thread-safe: up to max_jobs_in_flight jobs (0 = the library's default, 4) run concurrently, each on its own
+    job context (HIP stream + workspace) inside the library; further callers wait."""
 
-    def __init__(self, device=0, stream=None, workspace_limit=0, plan=None, library_path=None):
+    def __init__(self, device=0, stream=None, workspace_limit=0, plan=None, library_path=None, max_jobs_in_flight=0):
         """plan: dict of tad_plan overrides (include/tad.h), e.g. {"stage0": "v2", "partition_pass": "sort"}; None = the
         engine decides everything (production).  library_path: another build of the library (A/B measurements, tools/ab_plans.py)."""
         self._lib = capi.load_library(path=library_path)
@@ -253,7 +254,8 @@ class TadEngine:
         self.device = int(device)
         self._plan = dict(plan or {})
         opts = capi.EngineOpts(device=int(device), stream=C.c_void_p(stream) if stream else None,
-                               workspace_limit=int(workspace_limit), plan=capi.make_plan(**self._plan))
+                               workspace_limit=int(workspace_limit), plan=capi.make_plan(**self._plan),
+                               max_jobs_in_flight=int(max_jobs_in_flight))
         h = C.c_void_p()
         rc = self._lib.tad_engine_create(C.byref(opts), C.byref(h))
         if rc != capi.TAD_OK:
@@ -309,6 +311,15 @@ class TadEngine:
         d, t = capi.i32(), capi.i32()
         self._lib.tad_progress(self._h, C.byref(d), C.byref(t))
         return d.value, t.value
+
+    def job_progress(self, job_id):
+        """(done, total) of the job in flight whose id is job_id; (0, 0) when there is none"""
+        d, t = capi.i32(), capi.i32()
+        self._lib.tad_job_progress(self._h, job_id.encode()[:63], C.byref(d), C.byref(t))
+        return d.value, t.value
+
+    def jobs_in_flight(self):
+        return int(self._lib.tad_jobs_in_flight(self._h))
 
     # ---- the job (anomaly_detection.py:647-710) ----
     def run(self, algo, key_id, flow_end_s, value, num_keys, agg_flow="", value_op="auto", key_id2=None,

@@ -2,7 +2,7 @@
 """Same-box, same-process A/B of tad_plan overrides (or of two library builds): one engine per variant, ONE table in HBM, the
 variants alternate round by round so that box state (clocks, HBM refresh, neighbours) hits them alike.
 
-usage: python tools/ab_plans.py --config c2|c3|c4 [--rows N --keys K --buckets T] --variants "base=;nosync=one_sync=never" [--rounds 6 --steps 20]
+usage: python tools/ab_plans.py --config c2|c3|c4 [--rows N --keys K --buckets T] --variants "auto=;exact=histogram=exact" [--rounds 6 --steps 20]
        a variant is name=plan (comma-separated tad_plan fields, empty = the engine decides); `lib:<path>` as a plan field loads another
        library build for that variant (TAD_LIBRARY_PATH semantics of tools/build_variants.py, in a subprocess-free way: separate ctypes handle).
 Prints per variant: median / min ms per job over the rounds, and the device-side split (meta / pass B / stage0 / detect) of the last round."""
@@ -27,7 +27,7 @@ ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
 ap.add_argument("--rows", type=int)
 ap.add_argument("--keys", type=int)
 ap.add_argument("--buckets", type=int)
-ap.add_argument("--variants", default="auto=;nosync=one_sync=never")
+ap.add_argument("--variants", default="auto=;exact=histogram=exact")
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--steps", type=int, default=20)
 args = ap.parse_args()
@@ -55,7 +55,7 @@ engines = [(name, TadEngine(device=0, plan=plan, library_path=lib)) for name, pl
 jobs = [(name, e.prepare(cfg["algo"], cols[0], cols[1], cols[2], K, agg_flow=cfg["agg"], out="device")) for name, e in engines]
 times = {name: [] for name, _ in jobs}
 last = {}
-for name, j in jobs:          # warm-up: buffers, the remembered shape of the one-synchronisation form
+for name, j in jobs:          # warm-up: buffers
     for _ in range(3):
         j.run().close()
 for r in range(args.rounds):

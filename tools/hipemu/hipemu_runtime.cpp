@@ -307,6 +307,8 @@ hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t) { std
 hipError_t hipMemset(void *dst, int value, size_t bytes) { std::memset(dst, value, bytes); return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *s) { *s = new hipemu_stream_s{0}; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
+hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 1; *greatest = -1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
@@ -321,3 +323,4 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
 hipError_t hipGetLastError() { return hipSuccess; }
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : (e == hipErrorOutOfMemory ? "out of memory" : "error"); }
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipFuncGetAttributes(hipFuncAttributes *attr, const void *) { attr->numRegs = 0; attr->sharedSizeBytes = 0; return hipSuccess; }

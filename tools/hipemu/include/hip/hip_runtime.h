@@ -178,6 +178,8 @@ hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t s);
 hipError_t hipMemset(void *dst, int value, size_t bytes);
 hipError_t hipStreamCreate(hipStream_t *s);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int priority);
+hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();
@@ -189,5 +191,7 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipGetLastError();
 const char *hipGetErrorString(hipError_t e);
 hipError_t hipFuncSetAttribute(const void *fn, hipFuncAttribute attr, int value);
+struct hipFuncAttributes { int numRegs; size_t sharedSizeBytes; };
+hipError_t hipFuncGetAttributes(hipFuncAttributes *attr, const void *fn);
 template <typename T> inline hipError_t hipMalloc(T **p, size_t bytes) { return hipMalloc(reinterpret_cast<void **>(p), bytes); }
 template <typename T> inline hipError_t hipHostMalloc(T **p, size_t bytes, unsigned flags) { return hipHostMalloc(reinterpret_cast<void **>(p), bytes, flags); }
