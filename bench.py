@@ -205,30 +205,37 @@ def concurrency_leg(eng, levels, serial_ms):
     t0 = time.perf_counter()
     arima.run().close()
     alone_s = time.perf_counter() - t0
-    lat, box = [], {}
+    def beside(gap_s):
+        lat, box = [], {}
 
-    def long_job():
-        t = time.perf_counter()
-        r = arima.run()
-        box["s"] = time.perf_counter() - t
-        box["ctx"] = r.stats["job_context"]
-        r.close()
-    th = threading.Thread(target=long_job)
-    th.start()
-    time.sleep(0.03)
-    while th.is_alive():
-        t = time.perf_counter()
-        r = jobs[1].run()
-        lat.append((time.perf_counter() - t) * 1e3)
-        r.close()
-    th.join()
-    if lat:
-        lat = lat[:-1] or lat        # the last one may have outlived the ARIMA job
+        def long_job():
+            t = time.perf_counter()
+            r = arima.run()
+            box["s"] = time.perf_counter() - t
+            box["ctx"], box["relaunches"] = r.stats["job_context"], r.stats["arima_relaunches"]
+            r.close()
+        th = threading.Thread(target=long_job)
+        th.start()
+        time.sleep(0.03)
+        while th.is_alive():
+            t = time.perf_counter()
+            r = jobs[1].run()
+            lat.append((time.perf_counter() - t) * 1e3)
+            r.close()
+            if gap_s:
+                time.sleep(gap_s)
+        th.join()
+        if len(lat) > 1:
+            lat = lat[:-1]        # the last one may have outlived the ARIMA job
+        q = sorted(lat)
+        return {"ewma_jobs": len(lat), "ewma_ms_p50": statistics.median(lat) if lat else None, "ewma_ms_p90": q[int(0.9 * (len(q) - 1))] if q else None,
+                "ewma_ms_max": max(lat) if lat else None, "arima_s": box.get("s"), "arima_relaunches": box.get("relaunches"), "arima_job_context": box.get("ctx")}
     out["short_job_beside_long_job"] = {
-        "what": "C2 EWMA jobs submitted back to back by one thread while a C3 ARIMA job (same shape, another table) runs on another context's "
-                "low-priority stream",
-        "ewma_jobs": len(lat), "ewma_ms_p50": statistics.median(lat) if lat else None, "ewma_ms_max": max(lat) if lat else None,
-        "ewma_ms_alone": serial_ms, "arima_s_alone": alone_s, "arima_s_with_ewma_stream": box.get("s"), "arima_job_context": box.get("ctx")}
+        "what": "C2 EWMA jobs submitted by one thread while a C3 ARIMA job (same shape, another table) runs on another context's low-priority "
+                "stream: every 20 ms (`paced`), and back to back (`saturated`: the fit time-slices with them, 2 ms at most per wait).  The fit "
+                "kernel retires its wavefronts while a whole-CU job is in flight (tad_stats.arima_relaunches) — without that the EWMA job waited "
+                "for the fit's whole grid: 212 ms (profiles/r6_a2_bench_default_line.json)",
+        "ewma_ms_alone": serial_ms, "arima_s_alone": alone_s, "paced": beside(0.02), "saturated": beside(0.0)}
     return out
 
 

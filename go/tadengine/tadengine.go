@@ -151,6 +151,7 @@ type Stats struct {
 	Stage0Path                                               int32 // how Stage 0 ran (tad.h: tad_stats.stage0_path), for the controller's logs
 	HostSyncs                                                int32 // host synchronisations of the job (tad.h: tad_stats.host_syncs): 3, or 2 with a lattice hint
 	JobContext                                               int32 // which of the engine's job contexts ran it (tad.h: tad_stats.job_context, ABI 12)
+	ArimaRelaunches                                          int32 // times the ARIMA fit yielded to other jobs' whole-CU kernels and was relaunched (tad_stats.arima_relaunches)
 }
 
 // cColumn copies a Go slice into C memory: cgo forbids handing Go pointers nested in a C struct, and the
@@ -230,7 +231,7 @@ func (e *Engine) Run(job Job, cols Columns) ([]Row, Stats, error) {
 	}
 	st = Stats{uint64(res.stats.rows_in), uint64(res.stats.rows_used), uint64(res.stats.n_keys), uint64(res.stats.n_points),
 		uint64(res.stats.n_anomalies), uint64(res.stats.keys_no_result), uint64(res.stats.arima_nan_fits), float32(res.stats.ms_total),
-		int32(res.stats.stage0_path), int32(res.stats.host_syncs), int32(res.stats.job_context)}
+		int32(res.stats.stage0_path), int32(res.stats.host_syncs), int32(res.stats.job_context), int32(res.stats.arima_relaunches)}
 	return rows, st, nil
 }
 

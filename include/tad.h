@@ -184,6 +184,9 @@ typedef struct {
   int32_t host_syncs;      /* host synchronisations of the attempt that produced the result: 3 = lattice derivation, row count, result;
                               2 with a lattice hint (or an empty batch) */
   int32_t job_context;     /* ABI 12: index of the job context (stream + workspace) that ran the job; 0 for a serial caller */
+  int32_t arima_relaunches;/* ABI 12: times this job's ARIMA fit kernel was relaunched after its wavefronts had retired early to make room for
+                              another job's whole-CU workgroups (pass B / pass C need 1024 threads and up to 156 KB of LDS per workgroup and
+                              cannot be placed beside the fit's long-lived wavefronts); 0 when the job ran alone.  Results do not depend on it */
 } tad_stats;
 
 /* Anomalous points only (anomaly_detection.py:394), ordered by (key_id, flow_end_s).
@@ -293,6 +296,26 @@ typedef struct {
 } tad_string_column;
 int tad_encode_strings(tad_engine *e, const tad_string_column *col, int64_t *codes, uint64_t *first_row, uint64_t first_row_cap,
                        uint64_t *num_values);
+
+/* ---- ingest, columnar (ABI 12): Arrow record batches in host memory -> the 8-byte device columns of tad_factorize / tad_run ----
+ * ClickHouse's HTTP interface (the reference's JDBC URL points at it, anomaly_detection.py:730-731) streams the raw rows as Arrow record
+ * batches; with `toLowCardinality(col)` and output_format_arrow_low_cardinality_as_dictionary = 1 the string columns arrive as Arrow
+ * DICTIONARY arrays, a dictionary per batch.  The host maps each batch's dictionary (its distinct values only) into the column's job-wide
+ * one and evaluates the SQL's string predicates (anomaly_detection.py:507-614) on the distinct values; the rows are touched on the GPU:
+ * tad_widen_column: dst[i] = table ? table[src[i]] : src[i], for i < n.  src holds n integers of src_bits (8 / 16 / 32 / 64) bits, sign-extended
+ *   when src_signed, in HOST (staged by the call) or DEVICE memory; table (int64[table_len], DEVICE) and dst (int64[n], DEVICE).  Covers the
+ *   dictionary indices of a batch (table = the batch's remap), UInt32 DateTime and UInt16 port columns (table NULL) and gathers of a device
+ *   column at the rows tad_factorize reports in first_row (src = first_row, table = the column).  An index outside the table is
+ *   TAD_ERR_INVALID_ARGUMENT.
+ * tad_mask_rows: keep[i] = AND over t < n_terms of (masks[t][codes[t][i]] != 0), ANDed into the previous keep[i] when combine != 0.  codes[t]
+ *   (int64[n]), masks[t] (uint8[mask_len[t]]) and keep (uint8[n]) are DEVICE memory; the pointer arrays themselves are host memory.  n_terms <= 8.
+ * tad_host_alloc / tad_host_free: page-locked host memory (a reader receives the HTTP body straight into it; copies from it run at PCIe rate). */
+int tad_widen_column(tad_engine *e, const void *src, int32_t src_bits, int32_t src_signed, tad_mem src_memory, uint64_t n, const int64_t *table,
+                     uint64_t table_len, int64_t *dst);
+int tad_mask_rows(tad_engine *e, uint64_t n, int32_t n_terms, const int64_t *const *codes, const uint8_t *const *masks, const uint64_t *mask_len,
+                  int32_t combine, uint8_t *keep);
+int tad_host_alloc(tad_engine *e, uint64_t bytes, void **ptr);
+int tad_host_free(tad_engine *e, void *ptr);
 
 /* ---- streaming EWMA: per-key running state kept in HBM between batches ----
  * The batch job re-reads the whole window and judges every point against the stddev_samp of the WHOLE series

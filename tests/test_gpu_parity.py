@@ -519,6 +519,49 @@ def test_job_contexts_serial_caller_stays_on_context_zero_and_pool_is_bounded(en
     assert seen and all(tot == 4 and 0 <= d <= 4 for d, tot, _ in seen) and max(n for _, _, n in seen) >= 1
 
 
+def test_arima_fit_yields_to_whole_cu_jobs_and_resumes_bit_exact(engine):
+    """An ARIMA job in flight while other threads run jobs on the partition path (pass B / pass C workgroups need whole CUs): the engine
+    raises its pause word, the fit kernel's wavefronts stop taking keys and retire, the host relaunches the kernel — the per-position
+    cursors carry on.  The ARIMA rows must be the serial run's, bit for bit, whatever the interleaving; so must the other jobs' rows."""
+    import threading
+    from theia_amd import TadEngine
+    eng = TadEngine(device=0, plan={"stage0": "v2"})      # (small tables: the partition path forced, so that every job claims whole CUs)
+    try:
+        ka, ta, va = orc.synth_rows(21, 60000, 300, 60)
+        want_a = orc.run_job("ARIMA", ka, ta, va, agg_flow="svc")
+        ke, te, ve = orc.synth_rows(22, 80000, 100, 50)
+        want_e = orc.run_job("EWMA", ke, te, ve, agg_flow="svc")
+        stop, errs, relaunches = threading.Event(), [], []
+
+        def short_jobs():
+            try:
+                while not stop.is_set():
+                    r = eng.run("EWMA", ke, te, ve, 100, agg_flow="svc")
+                    assert r.n_rows == want_e["n_anomalies"] and (r["algo_calc"] == want_e["algo_calc"]).all()
+            except Exception as exc:  # noqa: BLE001
+                errs.append(exc)
+        ths = [threading.Thread(target=short_jobs) for _ in range(2)]
+        for th in ths:
+            th.start()
+        try:
+            for _ in range(3):
+                r = eng.run("ARIMA", ka, ta, va, 300, agg_flow="svc")
+                relaunches.append(r.stats["arima_relaunches"])
+                assert r.n_rows == want_a["n_anomalies"] > 0
+                for f in ("key_id", "flow_end_s", "throughput", "stddev"):
+                    assert (r[f] == want_a[f]).all(), f
+                assert np.array_equal(r["algo_calc"], want_a["algo_calc"], equal_nan=True)
+        finally:
+            stop.set()
+            for th in ths:
+                th.join()
+        assert not errs, errs
+        assert max(relaunches) >= 1, relaunches      # the yield path ran (two threads of back-to-back whole-CU jobs beside three ARIMA jobs)
+        assert eng.run("ARIMA", ka, ta, va, 300, agg_flow="svc").stats["arima_relaunches"] == 0      # alone: never
+    finally:
+        eng.close()
+
+
 # ------------------------------------------------------------------ (d) full-size properties (BASELINE C2 / C4)
 @pytest.mark.parametrize("algo,N,K,T,agg", [("EWMA", 100_000_000, 100_000, 250, "svc"), ("DBSCAN", 100_000_000, 1_000_000, 100, "")])
 def test_full_size_properties(engine, algo, N, K, T, agg):

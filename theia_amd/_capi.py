@@ -77,7 +77,7 @@ class Stats(C.Structure):
                 ("arima_fits", u64), ("arima_nan_fits", u64), ("pts_mean", f64), ("pts_m2", f64), ("t0", i64), ("step", i64), ("n_buckets", u64),
                 ("ms_meta", f32), ("ms_stage0", f32), ("ms_scatter", f32), ("ms_detect", f32),
                 ("ms_total", f32), ("stage0_path", i32), ("stage0_attempts", i32), ("hist_sampled", i32), ("host_syncs", i32),
-                ("job_context", i32)]
+                ("job_context", i32), ("arima_relaunches", i32)]
 
 
 class Result(C.Structure):
@@ -109,6 +109,10 @@ SYMBOLS = {
     "tad_shard_rows": (C.c_int, [C.c_void_p, C.POINTER(Columns), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tad_factorize": (C.c_int, [C.c_void_p, C.POINTER(KeyColumns), C.c_void_p, C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]),
     "tad_encode_strings": (C.c_int, [C.c_void_p, C.POINTER(StringColumn), C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]),
+    "tad_widen_column": (C.c_int, [C.c_void_p, C.c_void_p, i32, i32, C.c_int, u64, C.c_void_p, u64, C.c_void_p]),
+    "tad_mask_rows": (C.c_int, [C.c_void_p, u64, i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(u64), i32, C.c_void_p]),
+    "tad_host_alloc": (C.c_int, [C.c_void_p, u64, C.POINTER(C.c_void_p)]),
+    "tad_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tad_progress": (C.c_int, [C.c_void_p, C.POINTER(i32), C.POINTER(i32)]),
     "tad_job_progress": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(i32), C.POINTER(i32)]),
     "tad_jobs_in_flight": (C.c_int, [C.c_void_p]),

@@ -55,6 +55,7 @@ struct ArimaWs {
   uint8_t *state;  // [K] 0 = ok, 1 = no result
   double *hist;    // [wavefronts of k_arima_fit][kHistDoubles][64] every lane's L-BFGS (s, y) history (struct Lbfgs)
   unsigned long long *cursor;   // [T] next key of series position p not yet handed to a lane (k_arima_fit)
+  unsigned int *yielded;        // [1] set by a wavefront of k_arima_fit that stopped taking keys because the engine asked it to (ArimaPause)
   uint32_t Tpad;
 };
 
@@ -962,11 +963,13 @@ __device__ unsigned long long g_arima_prof[8];
 
 __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double *__restrict__ sigma,
                                                const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax, uint32_t chunk,
-                                               double *__restrict__ calc, DevCounters *ctr, double *buf, double *park) {
+                                               double *__restrict__ calc, DevCounters *ctr, double *buf, double *park, const int *pause) {
   const uint32_t nchunks = (uint32_t)((g.K + chunk - 1) / chunk);   // wavefronts per position
   const uint32_t p = pmax - 1 - blockIdx.x / nchunks;           // heaviest (longest history) positions first
   const unsigned lane = threadIdx.x;
   bool dry = false;                                             // wave-uniform: position p has no key left to hand out
+  bool yielded = false;                                         // wave-uniform: ... or the engine asked the fit to make room (see ArimaPause)
+  unsigned polls = 0;
   uint64_t k = 0;
   bool busy = false;
   unsigned long long steps = 0, fits = 0, nanfits = 0;
@@ -989,6 +992,18 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     while (!dry) {
       const unsigned long long m = __ballot(!busy);
       if (m == 0) break;
+      // Cooperative yield.  The fit is ~0.25 s of two-wavefront-per-SIMD work whose wavefronts live for tens of ms; a workgroup of another
+      // job's pass B needs a WHOLE CU (1024 threads, 156 KB of LDS) and would wait until this grid is exhausted whatever the stream priorities
+      // (measured: 212 ms, profiles/r6_a2_*).  `pause` is a word in page-locked host memory the engine raises while such a job is in flight:
+      // every 16th time a lane runs out of work the wavefront looks at it (one uncached read over the host link, ~1 % of the fit) and, if it
+      // is raised, takes no further key — its busy lanes finish their fits (<= a few ms), the wavefront retires, the host relaunches the
+      // kernel when the word is clear again.  The per-position cursors carry on where they stopped; results do not depend on which lane
+      // fits which key.
+      if (pause != nullptr && (++polls & 15u) == 0u && __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+        yielded = true;
+        dry = true;
+        break;
+      }
       unsigned long long first = 0;
       if (lane == 0) first = atomicAdd(&ws.cursor[p], (unsigned long long)__popcll(m));
       first = __shfl(first, 0);
@@ -1097,6 +1112,7 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     TAD_PROF_ADD(0, t_a, t_b); TAD_PROF_ADD(1, t_b, t_c); TAD_PROF_ADD(2, t_c, t_d); TAD_PROF_ADD(3, 0ull, 1ull);
   }
   for (int d = 32; d >= 1; d >>= 1) { steps += __shfl_down(steps, d); fits += __shfl_down(fits, d); nanfits += __shfl_down(nanfits, d); }
+  if (threadIdx.x == 0 && yielded) atomicOr(ws.yielded, 1u);
   if (threadIdx.x == 0 && fits) {
     atomicAdd(&ctr->kalman_steps, steps);
     atomicAdd(&ctr->arima_fits, fits);
@@ -1117,10 +1133,10 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAD_ARIMA_WAVES, TAD_ARIMA_WAVES))) void k_arima_fit(
     Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,
-    uint32_t chunk, double *__restrict__ calc, DevCounters *ctr) {
+    uint32_t chunk, double *__restrict__ calc, DevCounters *ctr, const int *pause) {
   __shared__ double buf[64 * (kStage + 1)];
   __shared__ double park[64 * kParkDoubles];
-  arima_fit_body(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf, park);
+  arima_fit_body(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf, park, pause);
 }
 
 static uint32_t arima_tpad(uint64_t T) { return (uint32_t)((T + kStage - 1) / kStage * kStage); }
@@ -1132,13 +1148,10 @@ size_t arima_workspace_bytes(Grid g) {
   const size_t cells = (size_t)g.K * g.T;
   return cells * (8 * 3 + 8 * 3 + 4) + (size_t)g.K * arima_tpad(g.T) * 8 + (size_t)g.K * 9 + 1024 +
          (size_t)arima_fit_blocks(g) * (kHistDoubles * 64 * 8) + 512 +   // + the L-BFGS history block of every wavefront of k_arima_fit (30 KB each)
-         (size_t)g.T * 8 + 512;                                          // + the per-position key cursors
+         (size_t)g.T * 8 + 512 + 512 + 64;                               // + the per-position key cursors + the yield word (each region 512-byte aligned)
 }
 
-int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc,
-                 DevCounters *ctr, void *workspace, size_t workspace_bytes) {
-  if (g.K == 0 || g.T == 0) return 0;
-  if (workspace_bytes < arima_workspace_bytes(g)) return -1;
+static ArimaWs arima_carve(Grid g, void *workspace) {
   const size_t cells = (size_t)g.K * g.T;
   unsigned char *w = static_cast<unsigned char *>(workspace);
   ArimaWs ws;
@@ -1154,24 +1167,46 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
   auto align512 = [](unsigned char *q) { return reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(q) + 511) & ~(uintptr_t)511); };
   w = align512(w);   // (tpos is 4 bytes per cell: with an odd cell count everything after it was 4-byte aligned only — fatal for the 64-bit atomics on the cursors)
   ws.hist = reinterpret_cast<double *>(w); w = align512(w + (size_t)arima_fit_blocks(g) * (kHistDoubles * 64 * 8));
-  ws.cursor = reinterpret_cast<unsigned long long *>(w);
+  ws.cursor = reinterpret_cast<unsigned long long *>(w); w = align512(w + (size_t)g.T * 8);
+  ws.yielded = reinterpret_cast<unsigned int *>(w);
+  return ws;
+}
+
+// (Re)launch the fit over whatever keys the per-position cursors have not handed out yet; *yielded (device, in the workspace) says afterwards
+// whether a wavefront stopped early because `pause` was raised.
+int launch_arima_fit(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc, DevCounters *ctr, void *workspace,
+                     const int *pause, const unsigned int **yielded) {
+  if (yielded) *yielded = nullptr;
+  if (g.K == 0 || g.T <= 3) return 0;
+  const ArimaWs ws = arima_carve(g, workspace);
+  const uint64_t blocks = arima_fit_blocks(g);
+  if (blocks > 0x7FFFFFFFull) return -1;
+  hipMemsetAsync(ws.yielded, 0, 4, s);
+  hipLaunchKernelGGL(k_arima_fit, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, kArimaChunk, calc, ctr, pause);
+  if (yielded) *yielded = ws.yielded;
+  return 0;
+}
+
+int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc,
+                 DevCounters *ctr, void *workspace, size_t workspace_bytes, const int *pause, const unsigned int **yielded) {
+  if (yielded) *yielded = nullptr;
+  if (g.K == 0 || g.T == 0) return 0;
+  if (workspace_bytes < arima_workspace_bytes(g)) return -1;
+  const ArimaWs ws = arima_carve(g, workspace);
   hipLaunchKernelGGL(k_arima_prep, dim3((unsigned)((g.K + 255) / 256)), dim3(256), 0, s, g, ws, sigma, calc, ctr);
   if (g.T > 3) {
     const uint64_t kblocks = (g.K + 63) / 64;
     if (kblocks * (g.T - 3) > 0x7FFFFFFFull) return -1;
     hipLaunchKernelGGL(k_arima_start, dim3((unsigned)(kblocks * (g.T - 3))), dim3(64), 0, s, g, ws, n_pts, (uint32_t)g.T);
-    const uint32_t chunk = kArimaChunk;
     hipMemsetAsync(ws.cursor, 0, (size_t)g.T * 8, s);
-    const uint64_t blocks = arima_fit_blocks(g);
-    if (blocks > 0x7FFFFFFFull) return -1;
-    hipLaunchKernelGGL(k_arima_fit, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, chunk, calc, ctr);
+    if (launch_arima_fit(s, g, sigma, n_pts, maxiter, calc, ctr, workspace, pause, yielded) != 0) return -1;
 #if defined(TAD_ARIMA_PROF)
     {
       unsigned long long h[8] = {0};
       hipStreamSynchronize(s);
       hipMemcpyFromSymbol(h, HIP_SYMBOL(g_arima_prof), sizeof h);
       fprintf(stderr, "arima prof: wavefront cycles in likelihood pass %llu | optimiser step %llu | refill %llu | optimiser cycles %llu | wavefronts %llu\n",
-              h[0], h[1], h[2], h[3], (unsigned long long)blocks);
+              h[0], h[1], h[2], h[3], (unsigned long long)arima_fit_blocks(g));
       unsigned long long z[8] = {0};
       hipMemcpyToSymbol(HIP_SYMBOL(g_arima_prof), z, sizeof z);
     }

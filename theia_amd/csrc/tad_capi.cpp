@@ -18,6 +18,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "tad_internal.h"
@@ -56,13 +57,20 @@ struct tad_engine {
   int32_t last_done = 0, last_total = 0;   // progress of the job that finished last (tad_progress with nothing in flight)
   std::mutex err_mu;           // protects err
   std::string err;
+  // Whole-CU jobs vs. the ARIMA fit.  A workgroup of pass B / pass C needs a whole CU; the fit kernel of an ARIMA job in flight on another
+  // context keeps every CU populated with long-lived wavefronts, so such a workgroup would wait for the fit's whole grid (212 ms measured)
+  // whatever the stream priorities.  *pause_word (page-locked, device-visible) counts the jobs in flight that are in a whole-CU phase; the fit
+  // polls it and retires its wavefronts while it is non-zero (tad_arima.hip), its host loop relaunches it afterwards (detect_and_count).
+  int *pause_word = nullptr;
   std::mutex pool_mu;          // protects free_blocks
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks (a result may be freed from any thread)
 };
 
 // One job in flight.  Everything below is touched by the thread that holds the context only (busy == true), except done / total / id.
+struct PauseHold;
 struct JobCtx {
   tad_engine *eng = nullptr;
+  PauseHold *hold = nullptr;   // the running job's claim on whole CUs (run_job); NULL for the small entry points
   int index = 0;               // position in eng->ctxs (tad_stats.job_context)
   bool busy = false;           // under eng->mu
   int device = 0;
@@ -81,6 +89,7 @@ struct JobCtx {
   DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
   DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
   DevBuf sp_cls;                                                                  // Stage 0 sparse, length classes: per-key class arrays
+  int arima_relaunches = 0;       // times the running job's ARIMA fit was relaunched after it had yielded to whole-CU jobs (tad_stats.arima_relaunches)
   bool sp_by_partition = false;   // the running job's sparse Stage 0 went through the partition pass + LDS sort (stage0_path 8 / 9 / 10 instead of 4 / 6 / 7)
   DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
   DevBuf ovf_keys;                                                                // Stage 0 v2, settle mode: bitmap of the keys with a value on the overflow list
@@ -245,7 +254,7 @@ int ensure(JobCtx *e, DevBuf &b, size_t bytes) {
 
 // Resolve one kernel of every translation unit: the lazy loader brings the unit's code object onto the device.
 void preload_code_objects() {
-  const void *anchors[] = {code_anchor_arima(), code_anchor_dbscan(), code_anchor_drop(), code_anchor_factorize(), code_anchor_kernels(), code_anchor_shard(), code_anchor_sparse(), code_anchor_stage0_part(), code_anchor_synth()};
+  const void *anchors[] = {code_anchor_arima(), code_anchor_dbscan(), code_anchor_drop(), code_anchor_factorize(), code_anchor_ingest(), code_anchor_kernels(), code_anchor_shard(), code_anchor_sparse(), code_anchor_stage0_part(), code_anchor_synth()};
   for (const void *k : anchors) {
     hipFuncAttributes attr;
     (void)hipFuncGetAttributes(&attr, k);
@@ -336,6 +345,7 @@ struct Lease {
     memset(c->id, 0, sizeof c->id);
     if (id) strncpy(c->id, id, sizeof c->id - 1);
     c->stream = low_priority ? c->stream_low : c->stream_normal;
+    c->hold = nullptr;
   }
   ~Lease() {
     if (!c) return;
@@ -344,12 +354,34 @@ struct Lease {
       if (c->total.load() != 0) { eng->last_done = c->done.load(); eng->last_total = c->total.load(); }
       c->busy = false;
       c->id[0] = 0;
+      c->hold = nullptr;
     }
     eng->cv.notify_one();
   }
   Lease(const Lease &) = delete;
   Lease &operator=(const Lease &) = delete;
 };
+
+}  // namespace
+
+// A job's claim on whole CUs: raised when its Stage 0 takes the partition path, dropped while its own ARIMA fit runs, dropped for good when
+// the job returns.
+struct PauseHold {
+  tad_engine *eng;
+  bool held = false;
+  explicit PauseHold(tad_engine *e) : eng(e) {}
+  void acquire() {
+    if (!held && eng->pause_word) { __atomic_fetch_add(eng->pause_word, 1, __ATOMIC_SEQ_CST); held = true; }
+  }
+  void release() {
+    if (held) { __atomic_fetch_sub(eng->pause_word, 1, __ATOMIC_SEQ_CST); held = false; }
+  }
+  ~PauseHold() { release(); }
+  PauseHold(const PauseHold &) = delete;
+  PauseHold &operator=(const PauseHold &) = delete;
+};
+
+namespace {
 
 // recycled device result blocks (engine-wide: a result is freed by whoever holds it)
 void release_block(tad_engine *eng, void *p, size_t cap) {
@@ -486,8 +518,10 @@ int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
   hipMemGetInfo(&free_b, &total_b);
   e->ws_limit = (opts && opts->workspace_limit) ? opts->workspace_limit : (uint64_t)(free_b / 4 * 3);
   if (opts) e->plan = opts->plan;
+  if (hipHostMalloc(reinterpret_cast<void **>(&e->pause_word), 64, hipHostMallocDefault) == hipSuccess) *e->pause_word = 0;
+  else { (void)hipGetLastError(); e->pause_word = nullptr; }     // (without it ARIMA fits never yield: the behaviour of ABI <= 11)
   JobCtx *c0 = ctx_create(e, true);
-  if (!c0) { delete e; return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "stream / pinned host allocation failed"); }
+  if (!c0) { if (e->pause_word) hipHostFree(e->pause_word); delete e; return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "stream / pinned host allocation failed"); }
   e->ctxs.push_back(c0);
   // The code objects of the library load lazily, on the first launch out of each translation unit: ~3.5 ms of the first job of a process
   // (profiles/r6_a1_cold_hip_api_stats.csv: 1.5 ms inside hipLaunchKernel, 1.9 ms inside hipFuncSetAttribute).  Touch one kernel of every
@@ -507,6 +541,7 @@ void tad_engine_destroy(tad_engine *e) {
   }
   for (JobCtx *c : e->ctxs) ctx_destroy(c);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
+  if (e->pause_word) hipHostFree(e->pause_word);
   delete e;
 }
 
@@ -655,8 +690,27 @@ int detect_and_count(JobCtx *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_
     if ((rc = ensure(e, e->calc, g.K * g.T * sizeof(double))) != TAD_OK) return rc;
     const size_t wsb = arima_workspace_bytes(g);
     if ((rc = ensure(e, e->aux, wsb)) != TAD_OK) return rc;
-    if (launch_arima(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, wsb) != 0)
+    // The fit yields to whole-CU jobs of other contexts (PauseHold): it stops taking keys while the engine's pause word is raised and is
+    // relaunched here — after the word has cleared, or after 2 ms at the latest, so that a steady stream of short jobs time-slices with the
+    // fit instead of starving it.  This job's own claim is dropped for the duration (it would pause itself) and taken back for the emit.
+    const bool held = e->hold && e->hold->held;
+    if (held) e->hold->release();
+    const unsigned int *yielded_dev = nullptr;
+    if (launch_arima(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, wsb, e->eng->pause_word, &yielded_dev) != 0)
       return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
+    while (yielded_dev != nullptr && e->eng->pause_word != nullptr) {
+      unsigned int y = 0;
+      HIP_TRY(e, hipMemcpyAsync(&y, yielded_dev, 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(e, hipStreamSynchronize(s));
+      if (y == 0) break;
+      const auto t0 = std::chrono::steady_clock::now();
+      while (__atomic_load_n(e->eng->pause_word, __ATOMIC_ACQUIRE) != 0 && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2))
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+      if (launch_arima_fit(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, e->eng->pause_word, &yielded_dev) != 0)
+        return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
+      e->arima_relaunches++;
+    }
+    if (held) e->hold->acquire();
   }
   const uint32_t *cnt = n_anom;
   if (jp.all_points && jp.algo != TAD_ALGO_ARIMA && !drop) cnt = n_pts;
@@ -804,6 +858,8 @@ int run_job(tad_engine *eng, const tad_job *job, const tad_columns *cols, tad_me
   if (stream) state_lk = std::unique_lock<std::mutex>(stream->mu);
   Lease lease(eng, job->id, !points_mode && job->algo == TAD_ALGO_ARIMA);
   if (!lease.c) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_run: no job context available");
+  PauseHold hold(eng);     // (declared after the lease: dropped before the context goes back to the pool)
+  lease.c->hold = &hold;
   return run_job_locked(lease.c, job, cols, out_memory, out, points_out, stream, 0);
 }
 
@@ -816,6 +872,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
   if (depth == 0) {
     e->done.store(0);
     e->total.store(4);
+    e->arima_relaunches = 0;
   }
 
   JobParams jp;
@@ -880,6 +937,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
     bool narrow_tiles = false;
     PartPlan pl{};
     bool v2 = !empty && !force_v1 && !force_v1_retry && (force_v2 || n >= (1ull << 22)) && part_plan_bins(n, K, has2, &pl);
+    if (v2 && e->hold) e->hold->acquire();   // pass B / pass C workgroups need whole CUs: ARIMA fits of other jobs in flight make room (PauseHold)
     if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
     int meta_blocks = 0;
     bool hist_sampled = false;
@@ -1353,6 +1411,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
     st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
     st.host_syncs = (hinted || empty) ? 2 : 3;
     st.job_context = e->index;
+    st.arima_relaunches = e->arima_relaunches;
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     if (depth == 0 && !points_mode && !stream) {
       JobCtx::Learnt &w = e->learnt;
@@ -2091,6 +2150,84 @@ int tad_synth_generate(tad_engine *eng, uint64_t seed, uint64_t first_row, uint6
   launch_synth(e->stream, seed, first_row, n_rows, num_keys, n_buckets, key_id, flow_end_s, value);
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   HIP_TRY(e, hipGetLastError());
+  return TAD_OK;
+}
+
+// ---- columnar ingest: Arrow buffers in host memory -> 8-byte device columns ----
+int tad_widen_column(tad_engine *eng, const void *src, int32_t src_bits, int32_t src_signed, tad_mem src_memory, uint64_t n, const int64_t *table,
+                     uint64_t table_len, int64_t *dst) {
+  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_widen_column: engine is NULL");
+  if ((src_bits != 8 && src_bits != 16 && src_bits != 32 && src_bits != 64) || (n && (!src || !dst)) || (table_len && !table))
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_widen_column: bad arguments (src of 8 / 16 / 32 / 64 bits, src / dst buffers, table)");
+  if (n == 0) return TAD_OK;
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_widen_column: no job context available");
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  const size_t bytes = (size_t)n * (size_t)(src_bits / 8);
+  if (src_memory == TAD_MEM_HOST && src_bits == 64 && table == nullptr) {      // nothing to convert: the copy is the column
+    HIP_TRY(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    return TAD_OK;
+  }
+  int rc;
+  if ((rc = ensure(e, e->counters, kTailBytes)) != TAD_OK) return rc;
+  unsigned int *err = reinterpret_cast<unsigned int *>(e->counters.p);
+  HIP_TRY(e, hipMemsetAsync(err, 0, 4, s));
+  const void *d_src = src;
+  if (src_memory == TAD_MEM_HOST) {
+    if ((rc = ensure(e, e->in_key, bytes)) != TAD_OK) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->in_key.p, src, bytes, hipMemcpyHostToDevice, s));
+    d_src = e->in_key.p;
+  }
+  launch_widen(s, d_src, src_bits, src_signed != 0, n, reinterpret_cast<const long long *>(table), table ? table_len : 0, reinterpret_cast<long long *>(dst), err);
+  unsigned int herr = 0;
+  HIP_TRY(e, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  HIP_TRY(e, hipGetLastError());
+  if (herr) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_widen_column: an index lies outside the table of %llu entries", (unsigned long long)table_len);
+  return TAD_OK;
+}
+
+int tad_mask_rows(tad_engine *eng, uint64_t n, int32_t n_terms, const int64_t *const *codes, const uint8_t *const *masks, const uint64_t *mask_len,
+                  int32_t combine, uint8_t *keep) {
+  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_mask_rows: engine is NULL");
+  if (n_terms < 0 || n_terms > kMaskMaxTerms || (n_terms && (!codes || !masks || !mask_len)) || (n && !keep))
+    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_mask_rows: bad arguments (0..%d terms, keep buffer)", kMaskMaxTerms);
+  for (int t = 0; t < n_terms; ++t)
+    if (n && (!codes[t] || !masks[t])) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_mask_rows: term %d is NULL", t);
+  if (n == 0) return TAD_OK;
+  Lease lease(eng);
+  JobCtx *e = lease.c;
+  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_mask_rows: no job context available");
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t s = e->stream;
+  int rc;
+  if ((rc = ensure(e, e->counters, kTailBytes)) != TAD_OK) return rc;
+  unsigned int *err = reinterpret_cast<unsigned int *>(e->counters.p);
+  HIP_TRY(e, hipMemsetAsync(err, 0, 4, s));
+  launch_mask_rows(s, n, n_terms, reinterpret_cast<const long long *const *>(codes), masks, mask_len, combine != 0, keep, err);
+  unsigned int herr = 0;
+  HIP_TRY(e, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  HIP_TRY(e, hipGetLastError());
+  if (herr) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_mask_rows: a code lies outside its mask");
+  return TAD_OK;
+}
+
+int tad_host_alloc(tad_engine *e, uint64_t bytes, void **ptr) {
+  if (!e || !ptr) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_host_alloc: bad arguments");
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipError_t r = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+  if (r != hipSuccess) { (void)hipGetLastError(); return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(r)); }
+  return TAD_OK;
+}
+
+int tad_host_free(tad_engine *e, void *ptr) {
+  if (!e) return TAD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (ptr) HIP_TRY(e, hipHostFree(ptr));
   return TAD_OK;
 }
 

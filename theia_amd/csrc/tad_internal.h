@@ -301,8 +301,14 @@ void launch_drop(hipStream_t s, Grid g, double n_sigma, int min_samples, double 
                  double *key_mean, double *key_m2, DevCounters *ctr);
 
 // ARIMA(1,1,1) walk-forward on Box-Cox data: calc[T][K] + FLAG_ANOMALY.
+// pause (NULL = never yield): a word in page-locked host memory; while it is non-zero the wavefronts of k_arima_fit stop taking keys and retire
+// (other jobs' whole-CU workgroups cannot be placed beside them).  *yielded (device memory inside the workspace) is non-zero afterwards when that
+// happened: the caller waits for `pause` to clear and calls launch_arima_fit until *yielded stays zero — the per-position cursors in the
+// workspace carry on where the wavefronts stopped.
 int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter,
-                 double *calc, DevCounters *ctr, void *workspace, size_t workspace_bytes);
+                 double *calc, DevCounters *ctr, void *workspace, size_t workspace_bytes, const int *pause = nullptr, const unsigned int **yielded = nullptr);
+int launch_arima_fit(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc, DevCounters *ctr, void *workspace,
+                     const int *pause, const unsigned int **yielded);
 size_t arima_workspace_bytes(Grid g);
 
 // ---- Stage 0 v2: partition rows by key range, aggregate tiles in LDS (tad_stage0_part.hip) ----
@@ -431,12 +437,19 @@ void launch_synth(hipStream_t s, uint64_t seed, uint64_t first_row, uint64_t n_r
                   uint64_t num_keys, uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s,
                   uint64_t *value);
 
+// ---- columnar ingest (tad_ingest.hip) ----
+constexpr int kMaskMaxTerms = 8;
+void launch_widen(hipStream_t s, const void *src, int bits, bool is_signed, uint64_t n, const long long *table, uint64_t table_len, long long *dst, unsigned int *err);
+void launch_mask_rows(hipStream_t s, uint64_t n, int n_terms, const long long *const *codes, const uint8_t *const *masks, const uint64_t *mask_len, bool combine,
+                      uint8_t *keep, unsigned int *err);
+
 // ---- code-object preload (tad_capi.cpp:preload_code_objects) ----
 // HIP loads a translation unit's code object on the first use of one of its kernels (~0.4 ms each, inside the first job otherwise).
 const void *code_anchor_arima();
 const void *code_anchor_dbscan();
 const void *code_anchor_drop();
 const void *code_anchor_factorize();
+const void *code_anchor_ingest();
 const void *code_anchor_kernels();
 const void *code_anchor_shard();
 const void *code_anchor_sparse();

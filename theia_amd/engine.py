@@ -58,6 +58,31 @@ class DeviceArray:
             pass
 
 
+class HostBuffer:
+    """Page-locked host memory owned by an engine (tad_host_alloc): a reader receives an HTTP body straight into `view`, and
+    copies from it to the device run at PCIe rate.  Kept and reused by the ingest client between jobs (pinning is slow)."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        ptr = C.c_void_p()
+        engine._check(engine._lib.tad_host_alloc(engine._h, self.nbytes, C.byref(ptr)))
+        self.ptr = ptr.value
+        self.view = memoryview((C.c_ubyte * self.nbytes).from_address(self.ptr)).cast("B")
+
+    def free(self):
+        if self.ptr is not None and self.engine._h is not None:
+            self.view = None
+            self.engine._lib.tad_host_free(self.engine._h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def _as_column(x, dtype, n_expected=None):
     """-> (pointer, n, is_device, keepalive)"""
     if x is None:
@@ -403,6 +428,50 @@ class TadEngine:
         del keep1, keep2, keep3
         self._check(rc)
         return outs, [int(c) for c in counts]
+
+    # ---- columnar ingest: Arrow buffers -> 8-byte device columns (tad_widen_column / tad_mask_rows) ----
+    def widen_into(self, dst, dst_offset, src_ptr, bits, signed, n, src_device=False, table=None):
+        """dst[dst_offset + i] = table[src[i]] (table: DeviceArray of int64) or src[i] widened, for i < n.  dst: DeviceArray of 8-byte
+        elements; src_ptr: address of n integers of `bits` bits in host memory (or device memory with src_device)."""
+        if dst_offset < 0 or dst_offset + n > dst.n:
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "widen_into: rows %d..%d do not fit a column of %d" % (dst_offset, dst_offset + n, dst.n))
+        self._check(self._lib.tad_widen_column(self._h, src_ptr, int(bits), 1 if signed else 0, capi.TAD_MEM_DEVICE if src_device else capi.TAD_MEM_HOST,
+                                               int(n), table.ptr if table is not None else None, table.n if table is not None else 0,
+                                               dst.ptr + 8 * int(dst_offset)))
+
+    def gather(self, column, rows):
+        """column[rows] for a device column (DeviceArray of 8-byte elements) and device row numbers (DeviceArray u64) -> numpy array"""
+        out = DeviceArray(self, max(rows.n, 1), column.dtype)
+        out.n = rows.n
+        if rows.n:
+            self._check(self._lib.tad_widen_column(self._h, rows.ptr, 64, 0, capi.TAD_MEM_DEVICE, rows.n, column.ptr, column.n, out.ptr))
+        host = out.to_host()
+        out.free()
+        return host
+
+    def mask_rows(self, n, terms, keep=None):
+        """terms: list of (codes DeviceArray int64[n], mask numpy bool[D]) -> DeviceArray uint8-as-bytes keep[n] = AND of mask[codes[i]] (ANDed into
+        `keep` when one is given).  The masks are per DISTINCT value (the host evaluated the SQL's string predicates on the dictionaries)."""
+        if not 0 <= len(terms) <= 8:
+            raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "mask_rows: at most 8 terms")
+        combine = keep is not None
+        if keep is None:
+            keep = DeviceArray(self, (n + 7) // 8 + 1, np.uint64)     # n bytes, allocated in 8-byte elements
+        masks = []
+        for _, m in terms:
+            a = np.ascontiguousarray(np.asarray(m, dtype=bool).astype(np.uint8))
+            masks.append((DeviceArray.from_host(self, np.frombuffer(a.tobytes() + b"\0" * (-a.size % 8 or 8), dtype=np.uint64)), a.size))
+        k = len(terms)
+        codes_p = (C.c_void_p * max(k, 1))(*[c.ptr for c, _ in terms])
+        masks_p = (C.c_void_p * max(k, 1))(*[d.ptr for d, _ in masks])
+        lens = (capi.u64 * max(k, 1))(*[ln for _, ln in masks])
+        if k == 0 and not combine:      # no predicate: every row is kept
+            self._check(self._lib.tad_copy_to_device(self._h, keep.ptr, np.ones(((n + 7) // 8 + 1) * 8, dtype=np.uint8).ctypes.data, ((n + 7) // 8 + 1) * 8))
+        elif k:
+            self._check(self._lib.tad_mask_rows(self._h, int(n), k, codes_p, masks_p, lens, 1 if combine else 0, keep.ptr))
+        for d, _ in masks:
+            d.free()
+        return keep
 
     # ---- ingest: key tuples -> dense ids in order of first appearance (tad_factorize) ----
     def factorize(self, cols_a, keep_a=None, cols_b=None, keep_b=None, max_keys=None):
