@@ -112,6 +112,22 @@ def test_edge_cases(engine):
         engine.factorize([alld], None, [alld, alld])
 
 
+def test_millions_of_distinct_keys_on_the_full_size_table(engine):
+    """Per-connection keys (mode None): nearly every row is a key of its own.  The full-size table (2 n slots) must take them all — with millions
+    of keys at load 0.48 linear-probing clusters longer than the small tables' probe limit (32) are certain, and round 6's 5e7-connection
+    ingest failed on exactly that (`tad_factorize: the full-size table filled up`)."""
+    rng = np.random.default_rng(99)
+    n = 4_000_000
+    a = rng.integers(0, 1 << 40, size=n).astype(np.int64)
+    b = rng.integers(0, 65536, size=n).astype(np.int64)
+    a[n // 2:] = a[:n - n // 2]            # the second half repeats the first half's keys in order: ids 0 .. n/2 - 1 twice
+    b[n // 2:] = b[:n - n // 2]
+    k1, _, fr = engine.factorize([a, b])
+    uniq = n // 2                           # (random 56-bit tuples: no accidental duplicates at this size)
+    assert fr.size == uniq and (fr == np.arange(uniq, dtype=np.uint64)).all()
+    assert (k1[:uniq] == np.arange(uniq, dtype=np.uint64)).all() and (k1[n // 2:] == k1[:n - n // 2]).all()
+
+
 # ---- tad_encode_strings (ABI 10): an Arrow string column -> dictionary codes in order of first appearance ----
 def _want_codes(arr):
     """pyarrow's own dictionary encode (first-appearance order), nulls as ''."""

@@ -416,6 +416,100 @@ def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_fl
     return PreparedColumns(mode, key_id, None, flow_end, flow_start, value, table, _epoch(start_time), _epoch(end_time))
 
 
+def prepare_columns_device(flows, start_time="", end_time="", ns_ignore_list=(), agg_flow="", pod_label="", external_ip="",
+                           svc_port_name="", pod_name="", pod_namespace="", engine=None):
+    """prepare_columns for a table that is already in HBM (theia_amd.clickhouse.fetch_flows_device: 8-byte integer columns as DeviceArray,
+    string columns as DeviceDictColumn = device codes + host dictionary).  The same predicates and GROUP BY keys (ref:507-614): every string
+    predicate is evaluated on the column's DISTINCT values here and applied to the rows on the GPU (tad_mask_rows); the key tuples are
+    factorised on the GPU (tad_factorize) and the key table is read back at the rows where the keys first appear (tad_widen_column as a
+    gather).  No per-row work on the host; nothing but the key table and the masks over distinct values crosses PCIe."""
+    from .engine import DeviceArray
+    eng = engine or get_engine()
+    flow_end, value = flows["flowEndSeconds"], flows["throughput"]
+    n = flow_end.n
+    common = []          # (codes, bool mask over the distinct values): terms every side's keep mask carries
+    if ns_ignore_list:   # ref:549-553, 576-580
+        ign = np.asarray(list(ns_ignore_list), dtype=str)
+        for name in ("sourcePodNamespace", "destinationPodNamespace"):
+            col = flows[name]
+            common.append((col.codes, ~np.isin(col.values, ign)))
+
+    def key_table_of(first_rows, cols):
+        """distinct keys' column values: cols = list of DeviceDictColumn | DeviceArray, first_rows = DeviceArray u64 of row numbers"""
+        out = []
+        for c in cols:
+            if hasattr(c, "values"):
+                codes = eng.gather(c.codes, first_rows).astype(np.int64)
+                out.append(c.values[codes] if c.values.size else np.zeros(codes.size, dtype=str))
+            else:
+                out.append(eng.gather(c, first_rows).astype(np.int64))
+        return out
+
+    if agg_flow == "pod":
+        by_name = bool(pod_name) and not pod_label
+        ident = "PodName" if by_name else "PodLabels"
+        mode = "podname" if by_name else "pod"
+        sides = []
+        for side, direction in (("destination", "inbound"), ("source", "outbound")):
+            col, ns = flows[side + ident], flows[side + "PodNamespace"]
+            if pod_label:                                      # ref:516-527
+                rx = _like_regex("%" + pod_label + "%")
+                ok = np.fromiter((rx.match(u) is not None for u in col.values), dtype=bool, count=col.values.size)
+            elif pod_name:                                     # ref:528-543
+                ok = col.values == pod_name
+            else:                                              # ref:544-548
+                ok = col.values != ""
+            terms = [(col.codes, ok)] + common
+            if (pod_label or pod_name) and pod_namespace:
+                terms.append((ns.codes, ns.values == pod_namespace))
+            sides.append((eng.mask_rows(n, terms), ns, col, direction))
+        if n == 0:
+            return PreparedColumns(mode, flow_end, flow_end, flow_end, None, value, {k: np.zeros(0, dtype=str) for k in KEY_COLUMNS[mode]}, 0, 0)
+        key_id, key_id2, first = eng.factorize([sides[0][1].codes, sides[0][2].codes], sides[0][0], [sides[1][1].codes, sides[1][2].codes], sides[1][0])
+        first_h = first.to_host()
+        side_b = first_h >= np.uint64(n)
+        rows = DeviceArray.from_host(eng, (first_h - np.where(side_b, np.uint64(n), np.uint64(0))).astype(np.uint64))
+        rows.n = first_h.size
+        ta, tb = key_table_of(rows, [sides[0][1], sides[0][2]]), key_table_of(rows, [sides[1][1], sides[1][2]])
+        uniq = [np.where(side_b, b, a).astype(str) for a, b in zip(ta, tb)]
+        uniq.append(np.where(side_b, sides[1][3], sides[0][3]))
+        for k in (sides[0][0], sides[1][0], rows, first):
+            k.free()
+        # the pod SQL carries no flowStartSeconds / flowEndSeconds predicate (ref:556-565)
+        return PreparedColumns(mode, key_id, key_id2, flow_end, None, value, dict(zip(KEY_COLUMNS[mode], uniq)), 0, 0)
+
+    terms = list(common)
+    if agg_flow == "external":
+        ft = np.zeros(65536, dtype=bool)
+        ft[3] = True                                           # ref:590 `flowType = 3`: the integer column is its own code
+        terms.append((flows["flowType"], ft))
+        ip = flows["destinationIP"]
+        if external_ip:
+            terms.append((ip.codes, ip.values == external_ip))  # ref:591-593
+        cols = [ip]
+    elif agg_flow == "svc":
+        svc = flows["destinationServicePortName"]
+        terms.append((svc.codes, (svc.values == svc_port_name) if svc_port_name else (svc.values != "")))   # ref:594-601
+        cols = [svc]
+    elif not agg_flow:
+        cols = [flows["sourceIP"], flows["sourceTransportPort"], flows["destinationIP"], flows["destinationTransportPort"],
+                flows["protocolIdentifier"], flows["flowStartSeconds"]]
+    else:
+        raise ValueError("aggregated flow type should be 'pod' or 'external' or 'svc'")
+    mode = agg_flow or ""
+    flow_start = flows["flowStartSeconds"] if start_time else None
+    if n == 0:
+        return PreparedColumns(mode, flow_end, None, flow_end, flow_start, value, {k: np.zeros(0, dtype=str) for k in KEY_COLUMNS[mode]},
+                               _epoch(start_time), _epoch(end_time))
+    keep = eng.mask_rows(n, terms) if terms else None
+    key_id, _, first = eng.factorize([c.codes if hasattr(c, "values") else c for c in cols], keep)
+    uniq = key_table_of(first, cols)
+    for k in (keep, first):
+        if k is not None:
+            k.free()
+    return PreparedColumns(mode, key_id, None, flow_end, flow_start, value, dict(zip(KEY_COLUMNS[mode], uniq)), _epoch(start_time), _epoch(end_time))
+
+
 # ------------------------------------------------------------------------------------------------
 # the job (ref:647-710) and the result rows (ref:352-421, 500-503)
 # ------------------------------------------------------------------------------------------------
@@ -488,10 +582,13 @@ def result_columns(prep, res, algo_type, agg_flow, tad_id):
 
 def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_ignore_list, agg_flow=None,
                       pod_label=None, external_ip=None, svc_port_name=None, pod_name=None, pod_namespace=None,
-                      engine=None, pushdown=False, columnar=False):
+                      engine=None, pushdown=False, columnar=False, connections=0):
     """ref:647-710.  `flows` stands where the reference has the JDBC address: a column dict, a path for load_flows,
     or a theia_amd.clickhouse.ClickHouseHTTP client (then the rows come over ClickHouse's HTTP interface as Arrow
     batches; pushdown=True lets ClickHouse run the reference's GROUP BY and ships aggregated points instead).
+    connections > 0 (with a ClickHouse client): the device ingest — that many parallel dictionary-encoded reads straight into HBM
+    (theia_amd.clickhouse.fetch_flows_device + prepare_columns_device); falls back to the single-connection read when the table
+    changes between the count query and the reads.
     Returns (stats dict, list of result rows) — or, with columnar=True, (stats dict, dict of result columns)."""
     if algo_type not in VALID_ALGOS:
         raise ValueError("Algorithm should be in {}".format(" or ".join(VALID_ALGOS)))
@@ -507,6 +604,21 @@ def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_i
         if pushdown:
             flows = ch.fetch_points(flows, generate_tad_sql_query(*args), agg_flow, pod_name or "")
             start_time, end_time, ns_ignore_list = "", "", ()   # ClickHouse has applied them already
+        elif connections:
+            client, eng = flows, engine or get_engine()
+            try:
+                dev = ch.fetch_flows_device(client, eng, *args, connections=connections)
+            except RuntimeError as exc:
+                logger.warning("device ingest abandoned (%s): single-connection read", exc)
+                flows = ch.fetch_flows(client, *args, engine=eng)
+            else:
+                prep = prepare_columns_device(dev, *args, engine=eng)
+                res = eng.run(algo_type, prep.key_id, prep.flow_end_s, prep.value, max(prep.num_keys, 1), agg_flow=agg_flow,
+                              key_id2=prep.key_id2, flow_start_s=prep.flow_start_s, start_time=prep.start_time,
+                              end_time=prep.end_time, job_id=str(tad_id_input or ""))
+                if columnar:
+                    return res.stats, result_columns(prep, res, algo_type, agg_flow, tad_id_input)
+                return res.stats, result_rows(prep, res, algo_type, agg_flow, tad_id_input)
         else:
             flows = ch.fetch_flows(flows, *args, engine=engine or get_engine())   # string columns dictionary-encoded on the GPU
     eng = engine or get_engine()

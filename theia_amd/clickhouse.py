@@ -240,11 +240,29 @@ _RAW_COLUMNS = {
 }
 
 
+# the string columns of default.flows the job reads (create_table.sh:31-85: all plain `String`)
+STRING_COLUMNS = ("sourceIP", "destinationIP", "sourcePodNamespace", "destinationPodNamespace", "sourcePodLabels", "destinationPodLabels",
+                  "sourcePodName", "destinationPodName", "destinationServicePortName")
+# settings of the dictionary read: LowCardinality columns leave ClickHouse as Arrow DICTIONARY arrays (a dictionary per block), and blocks are
+# large so that a block's dictionary (the distinct values the host looks at) is small against its rows
+DICTIONARY_SETTINGS = {"output_format_arrow_low_cardinality_as_dictionary": 1, "output_format_arrow_string_as_string": 1, "max_block_size": 4194304}
+
+
+def shard_expr(agg_flow, shards):
+    """`cityHash64(...) % shards`: which of `shards` parallel reads a row belongs to (the same expression shards the rows
+    over GPUs).  Hashing the connection tuple spreads every mode's rows evenly; which read delivers a row does not enter the result (the
+    engine's Stage 0 is commutative)."""
+    return "cityHash64(sourceIP, sourceTransportPort, destinationIP, destinationTransportPort, flowStartSeconds, flowEndSeconds) %% %d" % int(shards)
+
+
 def rows_query(start_time, end_time, ns_ignore_list, agg_flow=None, pod_label=None, external_ip=None, svc_port_name=None,
-               pod_name=None, pod_namespace=None):
+               pod_name=None, pod_namespace=None, dictionary=False, shard=None, count_only=False):
     """SELECT of the raw rows the job needs: the WHERE clause of the reference SQL (anomaly_detection.py:507-614) without
     its GROUP BY.  Pod mode keeps a row if EITHER side passes its condition (the UNION ALL of :556-565 reads each
-    side separately); the host applies the per-side predicates again when it builds the two keys."""
+    side separately); the host applies the per-side predicates again when it builds the two keys.
+    dictionary: string columns as `toLowCardinality(c) AS c` (with DICTIONARY_SETTINGS they arrive as Arrow dictionary arrays), and only
+    the columns the mode's job reads.  shard = (g, G): the rows of read g of G (`AND cityHash64(...) % G = g`).  count_only: the rows per
+    shard instead of the rows (`SELECT <shard expr> AS shard, count() AS rows ... GROUP BY shard`; shard = (None, G))."""
     mode = agg_flow if agg_flow in ("pod", "external", "svc") else ""
     where = []
     if ns_ignore_list:
@@ -275,9 +293,29 @@ def rows_query(start_time, end_time, ns_ignore_list, agg_flow=None, pod_label=No
         elif mode == "svc":
             where.append("destinationServicePortName = '{}'".format(svc_port_name) if svc_port_name
                          else "destinationServicePortName <> ''")
-    sql = "SELECT {} FROM {}".format(", ".join(_RAW_COLUMNS[mode]), FLOWS_TABLE)
+    columns = list(_RAW_COLUMNS[mode])
+    if dictionary:
+        # only what prepare_columns_device reads: pod mode has no time filter (flowStartSeconds unused) and keys on names OR labels; the
+        # other modes need flowStartSeconds for the start_time filter (mode None: it is part of the key) and the namespaces for ns-ignore
+        if mode == "pod":
+            by_name = bool(pod_name) and not pod_label
+            columns = [c for c in columns if c != "flowStartSeconds" and not c.endswith("PodName" if not by_name else "PodLabels")]
+        else:
+            if not start_time and mode != "":
+                columns = [c for c in columns if c != "flowStartSeconds"]
+            if not ns_ignore_list:
+                columns = [c for c in columns if not c.endswith("PodNamespace")]
+        columns = ["toLowCardinality({0}) AS {0}".format(c) if c in STRING_COLUMNS else c for c in columns]
+    if shard is not None and not count_only:
+        where.append("{} = {}".format(shard_expr(mode, shard[1]), int(shard[0])))
+    if count_only:
+        sql = "SELECT {} AS shard, count() AS rows FROM {}".format(shard_expr(mode, shard[1]), FLOWS_TABLE)
+    else:
+        sql = "SELECT {} FROM {}".format(", ".join(columns), FLOWS_TABLE)
     if where:
         sql += " WHERE " + " AND ".join(where)
+    if count_only:
+        sql += " GROUP BY shard"
     return sql
 
 
@@ -295,6 +333,201 @@ def fetch_flows(client, start_time="", end_time="", ns_ignore_list=(), agg_flow=
     if "throughput" in flows:
         flows["throughput"] = np.asarray(flows["throughput"]).astype(np.uint64)
     return flows
+
+
+class DeviceDictColumn:
+    """A string column on the device: codes int64[n] in HBM (DeviceArray) + the distinct values on the host (numpy str[D]).  What
+    fetch_flows_device delivers for every string column; theia_amd.anomaly_detection.prepare_columns_device evaluates the SQL's predicates
+    on `values` and applies them to the rows with tad_mask_rows."""
+
+    def __init__(self, codes, values):
+        self.codes = codes
+        self.values = np.asarray(values).astype(str)
+
+    def __len__(self):
+        return self.codes.n
+
+
+class _Vocabulary:
+    """The job-wide dictionary of one string column, shared by the reader threads: a record batch's dictionary (its distinct values) is
+    mapped into it with one vectorised lookup; values it has not seen are appended in order of appearance."""
+
+    def __init__(self):
+        import threading
+        import pyarrow as pa
+        self.arr = pa.array([], pa.string())
+        self.lock = threading.Lock()
+
+    @property
+    def values(self):
+        return self.arr.to_pylist()
+
+    def remap(self, batch_dictionary):
+        """pyarrow string array (the batch's dictionary, nulls read as '') -> int64[len]: position of every value in the job-wide dictionary"""
+        import pyarrow as pa
+        import pyarrow.compute as pc
+        d = batch_dictionary.fill_null("")
+        with self.lock:
+            pos = pc.index_in(d, value_set=self.arr) if len(self.arr) else pa.nulls(len(d), pa.int32())
+            if pos.null_count:
+                self.arr = pa.concat_arrays([self.arr, pc.unique(d.filter(pc.is_null(pos)))])
+                pos = pc.index_in(d, value_set=self.arr)
+        return np.ascontiguousarray(pos.to_numpy(zero_copy_only=False), dtype=np.int64)
+
+
+def fetch_flows_device(client, engine, start_time="", end_time="", ns_ignore_list=(), agg_flow="", pod_label="", external_ip="",
+                       svc_port_name="", pod_name="", pod_namespace="", connections=8, pinned=None, timings=None):
+    """The raw-rows read, straight into HBM (the reference pulls the GROUP BY result through ONE JDBC connection,
+    anomaly_detection.py:655-662 — its own bottleneck, not reproduced):
+
+      * `connections` parallel reads, read g taking the rows with `cityHash64(...) % G = g` (rows_query(shard=...)); one count query
+        first gives every read its place in the device columns, so the readers write disjoint row ranges and nothing is concatenated;
+      * string columns as Arrow DICTIONARY arrays (toLowCardinality + DICTIONARY_SETTINGS): per record batch the host looks at the
+        batch's dictionary only (_Vocabulary.remap), the rows' indices go to the device as they are and become job-wide codes there
+        (tad_widen_column with the batch's remap as table);
+      * every response is received into ONE buffer (page-locked when `pinned`: a pool kept by the client between jobs) and parsed in
+        place — Arrow IPC is zero-copy over a buffer — so the column buffers are copied host -> device exactly once.
+
+    Returns {column: DeviceArray (8-byte integers) | DeviceDictColumn} with `n` rows, in shard-major row order.  Raises if the table
+    changed between the count and the reads (the caller falls back to fetch_flows)."""
+    import threading
+    import time
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    from .engine import DeviceArray, HostBuffer
+    G = max(1, int(connections))
+    args = (start_time, end_time, list(ns_ignore_list), agg_flow, pod_label, external_ip, svc_port_name, pod_name, pod_namespace)
+    t_begin = time.perf_counter()
+    counts = client.query_columns(rows_query(*args, dictionary=True, shard=(None, G), count_only=True))
+    rows_of = np.zeros(G, dtype=np.int64)
+    if counts:
+        rows_of[np.asarray(counts["shard"]).astype(np.int64)] = np.asarray(counts["rows"]).astype(np.int64)
+    offsets = np.concatenate([[0], np.cumsum(rows_of)])
+    n = int(offsets[-1])
+    sql0 = rows_query(*args, dictionary=True, shard=(0, G))
+    names = [c.split(" AS ")[-1] for c in sql0[len("SELECT "):sql0.index(" FROM ")].split(", ")]
+    is_string = {c: c in STRING_COLUMNS for c in names}
+    columns = {c: DeviceArray(engine, max(n, 1), np.int64 if c != "throughput" else np.uint64) for c in names}
+    for c in columns.values():
+        c.n = n
+    vocab = {c: _Vocabulary() for c in names if is_string[c]}
+    errors = []
+    t_count = time.perf_counter()
+    stage = {"read_s": 0.0, "parse_upload_s": 0.0, "bytes": 0}
+    lock = threading.Lock()
+    pool = client.__dict__.setdefault("_pinned_pool", []) if pinned else None
+
+    def take_buffer(cap):
+        if not pinned:
+            b = bytearray(max(cap, 1))
+            return b, memoryview(b)
+        with lock:
+            for i, b in enumerate(pool):
+                if b.nbytes >= cap:
+                    pool.pop(i)
+                    return b, b.view
+        b = HostBuffer(engine, max(cap, 1))
+        return b, b.view
+
+    def read_body(resp):
+        """the whole response body in ONE buffer (page-locked when asked): (memoryview of the body, its owner)"""
+        length = resp.headers.get("Content-Length")
+        buf, view = take_buffer(int(length) if length is not None else (64 << 20))
+        got = 0
+        while True:
+            if got == len(view):
+                if length is not None:
+                    break
+                nbuf, nview = take_buffer(2 * len(view))      # chunked transfer and the guess was too small
+                nview[:got] = view[:got]
+                if pinned:
+                    with lock:
+                        pool.append(buf)
+                buf, view = nbuf, nview
+            k = resp.readinto(view[got:])
+            if not k:
+                break
+            got += k
+        return view[:got], buf
+
+    def reader(g):
+        try:
+            t0 = time.perf_counter()
+            settings = dict(DICTIONARY_SETTINGS)
+            with client._request(settings, (rows_query(*args, dictionary=True, shard=(g, G)) + " FORMAT ArrowStream").encode()) as resp:
+                body, owner = read_body(resp)
+            t1 = time.perf_counter()
+            at = int(offsets[g])
+            end = int(offsets[g + 1])
+            if len(body):
+                for batch in ipc.open_stream(pa.py_buffer(body)):
+                    k = batch.num_rows
+                    if at + k > end:
+                        raise RuntimeError("shard %d of %d delivered more rows than its count query announced (%d)" % (g, G, end - int(offsets[g])))
+                    for name, col in zip(batch.schema.names, batch.columns):
+                        if name not in columns:
+                            continue
+                        t = col.type
+                        if pa.types.is_dictionary(t):
+                            idx = col.indices
+                            if idx.null_count:
+                                raise RuntimeError("column %s: null dictionary indices" % name)
+                            d = col.dictionary
+                            if not pa.types.is_string(d.type):
+                                d = d.cast(pa.string())
+                            table = DeviceArray.from_host(engine, vocab[name].remap(d))
+                            bits = idx.type.bit_width
+                            engine.widen_into(columns[name], at, idx.buffers()[1].address + idx.offset * (bits // 8), bits,
+                                              pa.types.is_signed_integer(idx.type), k, table=table)
+                            table.free()
+                        elif is_string[name]:      # a server that ignored the dictionary settings: encode on the GPU, map like a batch dictionary
+                            codes, first = engine.encode_strings(col)
+                            dvals = col.take(pa.array(first.astype(np.int64))).fill_null("")
+                            table = DeviceArray.from_host(engine, vocab[name].remap(dvals))
+                            engine.widen_into(columns[name], at, codes.ctypes.data, 64, True, k, table=table)
+                            table.free()
+                        else:
+                            if pa.types.is_timestamp(t) or pa.types.is_date(t):
+                                col = col.cast(pa.timestamp("s")).cast(pa.int64()) if not (pa.types.is_timestamp(t) and t.unit == "s") else col.cast(pa.int64())
+                                t = col.type
+                            if col.null_count:
+                                raise RuntimeError("column %s: nulls in an integer column" % name)
+                            bits = t.bit_width
+                            engine.widen_into(columns[name], at, col.buffers()[1].address + col.offset * (bits // 8), bits,
+                                              pa.types.is_signed_integer(t), k)
+                    at += k
+            if at != end:
+                raise RuntimeError("shard %d of %d delivered %d rows, its count query announced %d" % (g, G, at - int(offsets[g]), end - int(offsets[g])))
+            t2 = time.perf_counter()
+            with lock:
+                stage["read_s"] = max(stage["read_s"], t1 - t0)
+                stage["parse_upload_s"] = max(stage["parse_upload_s"], t2 - t1)
+                stage["bytes"] += len(body)
+                if pinned:
+                    pool.append(owner)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=reader, args=(g,)) for g in range(G)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        for c in columns.values():
+            c.free()
+        raise errors[0]
+    out = {}
+    for c in names:
+        if is_string[c]:
+            vals = vocab[c].values
+            out[c] = DeviceDictColumn(columns[c], np.asarray(vals, dtype=object).astype(str) if vals else np.zeros(0, dtype=str))
+        else:
+            out[c] = columns[c]
+    if timings is not None:
+        timings.update({"count_query_s": t_count - t_begin, "slowest_read_s": stage["read_s"], "slowest_parse_upload_s": stage["parse_upload_s"],
+                        "total_s": time.perf_counter() - t_begin, "bytes": stage["bytes"], "rows": n, "connections": G})
+    return out
 
 
 def fetch_points(client, sql, agg_flow="", pod_name=""):

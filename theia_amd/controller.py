@@ -174,7 +174,7 @@ class JobCancelled(Exception):
     """The resource was deleted while its job was running (DeleteSparkApplication, controller.go:387): nothing is written."""
 
 
-def run_engine_job(args, client, engine=None, pushdown=False, cancelled=None):
+def run_engine_job(args, client, engine=None, pushdown=False, cancelled=None, connections=0):
     """The job body the SparkApplication ran (anomaly_detection.py:647-726) on the GPU engine: parse the argument vector, read
     through `client` (theia_amd.clickhouse.ClickHouseHTTP), detect, append the rows to `tadetector`.  Returns the row count.
     `cancelled()` is asked right before the rows are written: a deleted job must not leave rows nobody tracks."""
@@ -188,7 +188,8 @@ def run_engine_job(args, client, engine=None, pushdown=False, cancelled=None):
     _, cols = ad.anomaly_detection(opt["--algo"], client, opt.get("--start_time", ""), opt.get("--end_time", ""), tad_id,
                                    json.loads(opt["--ns-ignore-list"]) if "--ns-ignore-list" in opt else [], opt.get("--agg-flow", ""),
                                    opt.get("--pod-label", ""), opt.get("--external-ip", ""), opt.get("--svc-port-name", ""),
-                                   opt.get("--pod-name", ""), opt.get("--pod-namespace", ""), engine=engine, pushdown=pushdown, columnar=True)
+                                   opt.get("--pod-name", ""), opt.get("--pod-namespace", ""), engine=engine, pushdown=pushdown, columnar=True,
+                                   connections=connections)
     if cancelled is not None and cancelled():
         raise JobCancelled(tad_id)
     return ad.store_result_columns(client, cols)
@@ -200,13 +201,15 @@ class AnomalyDetectorController:
     `clickhouse`); `progress()` returns (completed, total) stages of the job that is running (default: engine.progress)."""
 
     def __init__(self, clickhouse=None, engine=None, run_job: Optional[Callable] = None, progress: Optional[Callable] = None,
-                 workers=DEFAULT_WORKERS, resync_period=0.05, pushdown=False, retry_min_delay=MIN_RETRY_DELAY, retry_max_delay=MAX_RETRY_DELAY):
+                 workers=DEFAULT_WORKERS, resync_period=0.05, pushdown=False, retry_min_delay=MIN_RETRY_DELAY, retry_max_delay=MAX_RETRY_DELAY,
+                 connections=0):
         self.clickhouse = clickhouse
         self.engine = engine
+        # connections > 0: the device ingest (that many parallel dictionary-encoded reads straight into HBM, theia_amd.clickhouse.fetch_flows_device)
         self._run_job = run_job or (lambda args, tad: run_engine_job(args, self.clickhouse, self.engine, pushdown,
-                                                                      cancelled=lambda: self._is_cancelled(tad.name[4:])))
+                                                                      cancelled=lambda: self._is_cancelled(tad.name[4:]), connections=connections))
         self._tls = threading.local()             # .run = the run token of the job body this pool thread is executing
-        self._progress = progress or (lambda: self.engine.progress() if self.engine is not None else (0, 0))
+        self._progress = progress or self._engine_progress
         self._lock = threading.Lock()
         self._store: Dict[tuple, ThroughputAnomalyDetector] = {}
         # job id -> the RUN TOKEN of its application: {"id", "state": SUBMITTED|RUNNING|COMPLETED|FAILED, "error", "cancelled"}.  The
@@ -362,7 +365,7 @@ class AnomalyDetectorController:
                 t = threading.Timer(delay, self._enqueue, args=(key,))
                 t.daemon = True
                 t.start()
-            elif dirty:
+            if dirty:       # client-go re-adds an item marked dirty during processing on Done(), independently of AddRateLimited
                 self._enqueue(key)
 
     def _resync_loop(self):
@@ -447,17 +450,22 @@ class AnomalyDetectorController:
             if outcome is not None:
                 run["state"], run["error"] = outcome
             deleted = started and run["cancelled"]
-            alive = self._alive.get(job_id, [])
-            if run in alive:
-                alive.remove(run)
-            if not alive:
-                self._alive.pop(job_id, None)
-        if deleted and self.clickhouse is not None:
-            # the resource went away while the body ran: whatever it managed to write before noticing is removed again
-            try:
-                self.clickhouse.command(cleanup_query(job_id))
-            except Exception as exc:
-                self._last_error = exc
+        try:
+            if deleted and self.clickhouse is not None:
+                # the resource went away while the body ran: whatever it managed to write before noticing is removed again — BEFORE the
+                # run leaves _alive: start_job waits for that, so a resource re-created under the same name cannot insert rows that this
+                # DELETE WHERE id would take with it (round-5 advisor finding)
+                try:
+                    self.clickhouse.command(cleanup_query(job_id))
+                except Exception as exc:
+                    self._last_error = exc
+        finally:
+            with self._lock:
+                alive = self._alive.get(job_id, [])
+                if run in alive:
+                    alive.remove(run)
+                if not alive:
+                    self._alive.pop(job_id, None)
 
     def check_job_status(self, key, tad):
         """checkSparkApplicationStatus (controller.go:455-497)."""
@@ -478,13 +486,31 @@ class AnomalyDetectorController:
                 self._periodic[key] = False
         return state
 
+    def _engine_progress(self, job_id=None):
+        """(completed, total) stages of job `job_id` — the reference asks the Spark monitoring service of THAT application
+        (controller.go:426-453); several jobs may be in flight on the engine (tad.h ABI 12: job contexts), so the engine is asked by id
+        (tad_job_progress); a job that is not in flight any more reports what the engine finished last (tad_progress)."""
+        if self.engine is None:
+            return (0, 0)
+        if job_id and hasattr(self.engine, "job_progress"):
+            done, total = self.engine.job_progress(job_id)
+            if total:
+                return done, total
+        return self.engine.progress()
+
+    def _progress_of(self, tad):
+        try:
+            return self._progress(tad.status.sparkApplication)
+        except TypeError:                            # a caller-supplied progress() without arguments
+            return self._progress()
+
     def update_progress(self, key, tad):
         """updateProgress (controller.go:426-453)."""
         state = self.check_job_status(key, tad)
         if state != "RUNNING":
             return
         try:
-            done, total = self._progress()
+            done, total = self._progress_of(tad)
         except Exception:                            # the monitoring endpoint may not be up: not requeued (controller.go:437-443)
             return
         self._update_status(key, only_if_state=(STATE_SCHEDULED, STATE_RUNNING), state=STATE_RUNNING, completedStages=int(done),
@@ -498,7 +524,7 @@ class AnomalyDetectorController:
             self._update_status(key, state=STATE_FAILED, errorMsg="Spark Application should be started before updating results")
             return
         try:
-            done, total = self._progress()
+            done, total = self._progress_of(tad)
             self._update_status(key, completedStages=int(done), totalStages=int(total))
         except Exception:
             pass

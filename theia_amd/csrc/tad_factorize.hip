@@ -84,8 +84,10 @@ enum : uint32_t { FZ_FLAG_GROW = 1u, FZ_FLAG_BAD_INPUT = 2u };
 // counted with one atomic per wavefront) raises a flag; every thread leaves at its next row, the later kernels return at once, and the host —
 // which reads the key count at the end anyway — repeats the call with the next size.
 // every kept virtual row into the table; on return a slot's low half = the smallest virtual row holding its tuple, slot_of[v] = v's slot
+// max_probe: kFzMaxProbe on the small tables; unlimited on the full-size one (2 n slots: it cannot fill up, and with tens of millions of distinct
+// keys a linear-probing cluster longer than 32 DOES occur — 5e7 keys at load 0.37: ~400 expected — which round 6's 5e7-connection ingest met)
 __global__ __launch_bounds__(kFzBlock) void k_fz_insert(FzArgs A, unsigned long long *__restrict__ table, uint64_t mask, uint32_t *__restrict__ slot_of,
-                                                        uint32_t *__restrict__ flags, unsigned long long *__restrict__ claims) {
+                                                        uint32_t *__restrict__ flags, unsigned long long *__restrict__ claims, uint32_t max_probe) {
   const uint64_t V = A.n * A.sides;
   uint32_t claimed = 0;
   uint32_t round = 0;
@@ -108,13 +110,13 @@ __global__ __launch_bounds__(kFzBlock) void k_fz_insert(FzArgs A, unsigned long 
         slot_of[v] = (uint32_t)s;
         break;
       }
-      if (++probes > kFzMaxProbe) { atomicOr(flags, FZ_FLAG_GROW); break; }
+      if (++probes > max_probe) { atomicOr(flags, FZ_FLAG_GROW); break; }
     }
   }
   for (int o = 32; o > 0; o >>= 1) claimed += __shfl_down(claimed, o);     // one atomic per wavefront for the claim count
   if ((threadIdx.x & 63) == 0 && claimed) {
     const unsigned long long before = atomicAdd(claims, (unsigned long long)claimed);
-    if (2 * (before + claimed) > mask + 1) atomicOr(flags, FZ_FLAG_GROW);
+    if (max_probe != 0xFFFFFFFFu && 2 * (before + claimed) > mask + 1) atomicOr(flags, FZ_FLAG_GROW);
   }
 }
 
@@ -231,7 +233,8 @@ void launch_factorize(hipStream_t s, const long long *const *cols_a, const uint8
   hipMemsetAsync(t.table, 0xFF, slots * 8, s);
   hipMemsetAsync(t.bits, 0, words * 4, s);
   hipMemsetAsync(t.claims, 0, 16, s);
-  hipLaunchKernelGGL(k_fz_insert, fz_grid(V), dim3(kFzBlock), 0, s, A, t.table, slots - 1, t.slot_of, t.flags, t.claims);
+  hipLaunchKernelGGL(k_fz_insert, fz_grid(V), dim3(kFzBlock), 0, s, A, t.table, slots - 1, t.slot_of, t.flags, t.claims,
+                     slots >= factorize_table_slots(V) ? 0xFFFFFFFFu : kFzMaxProbe);
   hipLaunchKernelGGL(k_fz_mark, fz_grid(slots), dim3(kFzBlock), 0, s, t.table, slots, t.bits);
   hipLaunchKernelGGL(k_fz_popc, fz_grid(words), dim3(kFzBlock), 0, s, t.bits, words, t.cnt);
   launch_scan(s, t.cnt, t.off, words, t.scratch, num_keys_dev);
@@ -368,7 +371,7 @@ __device__ __forceinline__ uint64_t se_load_lds(const uint64_t *buf, uint32_t at
 
 // every row into the table; slot_of[v] = the slot of v's string.  flags: SE_FLAG_GROW / SE_FLAG_BAD_OFFSETS; claims: slots claimed
 __global__ __launch_bounds__(kFzBlock) void k_se_insert(StrArgs A, unsigned long long *__restrict__ table, uint64_t mask, uint32_t *__restrict__ slot_of,
-                                                        uint32_t *__restrict__ flags, unsigned long long *__restrict__ claims) {
+                                                        uint32_t *__restrict__ flags, unsigned long long *__restrict__ claims, uint32_t max_probe) {
   __shared__ __attribute__((aligned(16))) uint64_t s_bytes[kSeStage / 8 + 4];
   __shared__ uint64_t s_lo, s_hi;
   __shared__ uint32_t s_stop;
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(kFzBlock) void k_se_insert(StrArgs A, unsigned long
             break;
           }
         }
-        if (++probes > kSeMaxProbe) { atomicOr(flags, SE_FLAG_GROW); break; }
+        if (++probes > max_probe) { atomicOr(flags, SE_FLAG_GROW); break; }
       }
     }
   }
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(kFzBlock) void k_se_insert(StrArgs A, unsigned long
   for (int o = 32; o > 0; o >>= 1) claimed += __shfl_down(claimed, o);
   if ((threadIdx.x & 63) == 0 && claimed) {
     const unsigned long long before = atomicAdd(claims, (unsigned long long)claimed);
-    if (2 * (before + claimed) > mask + 1) atomicOr(flags, SE_FLAG_GROW);
+    if (max_probe != 0xFFFFFFFFu && 2 * (before + claimed) > mask + 1) atomicOr(flags, SE_FLAG_GROW);
   }
 }
 
@@ -493,7 +496,8 @@ void launch_encode_strings(hipStream_t s, const void *offsets, int off64, const 
   hipMemsetAsync(t.table, 0xFF, slots * 8, s);
   hipMemsetAsync(t.bits, 0, words * 4, s);
   hipMemsetAsync(t.claims, 0, 16, s);
-  hipLaunchKernelGGL(k_se_insert, fz_grid(n), dim3(kFzBlock), 0, s, A, t.table, slots - 1, t.slot_of, t.flags, t.claims);
+  hipLaunchKernelGGL(k_se_insert, fz_grid(n), dim3(kFzBlock), 0, s, A, t.table, slots - 1, t.slot_of, t.flags, t.claims,
+                     slots >= factorize_table_slots(n) ? 0xFFFFFFFFu : kSeMaxProbe);
   // (after a raised flag the table is incomplete: the passes below still run — over a bitmap of n bits, harmless — and k_se_codes returns
   // at once; the host reads flags and the count in ONE synchronisation and repeats the attempt with the next table size if asked to)
   hipLaunchKernelGGL(k_fz_mark, fz_grid(slots), dim3(kFzBlock), 0, s, t.table, slots, t.bits);

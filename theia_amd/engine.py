@@ -466,7 +466,8 @@ class TadEngine:
         masks_p = (C.c_void_p * max(k, 1))(*[d.ptr for d, _ in masks])
         lens = (capi.u64 * max(k, 1))(*[ln for _, ln in masks])
         if k == 0 and not combine:      # no predicate: every row is kept
-            self._check(self._lib.tad_copy_to_device(self._h, keep.ptr, np.ones(((n + 7) // 8 + 1) * 8, dtype=np.uint8).ctypes.data, ((n + 7) // 8 + 1) * 8))
+            ones = np.ones(((n + 7) // 8 + 1) * 8, dtype=np.uint8)
+            self._check(self._lib.tad_copy_to_device(self._h, keep.ptr, ones.ctypes.data, ones.size))
         elif k:
             self._check(self._lib.tad_mask_rows(self._h, int(n), k, codes_p, masks_p, lens, 1 if combine else 0, keep.ptr))
         for d, _ in masks:
