@@ -707,6 +707,8 @@ HELP_MESSAGE = """
             and results appended over its HTTP interface with CH_USERNAME / CH_PASSWORD.  Default
             jdbc:clickhouse://clickhouse-clickhouse.flow-visibility.svc:8123 when --flows is not given.
         -G, --pushdown-groupby: let ClickHouse run the GROUP BY (the reference's SQL) and ship aggregated points.
+        -C, --connections (optional): read the raw rows over this many parallel connections straight into GPU memory,
+            string columns as Arrow dictionaries (LowCardinality); default 0 = one connection, host decode.
         -F, --flows=PATH: read the flow table from a file instead (.npz / .parquet / .csv, columns of default.flows).
         -o, --out=PATH: append the tadetector rows as JSON lines to PATH instead of inserting them ('-' = stdout).
         -s, --start_time=None / -e, --end_time=None: 'YYYY-MM-DD hh:mm:ss' UTC.
@@ -721,16 +723,16 @@ def main(argv=None):
     """ref:729-900: same options, same exit codes (2 on a bad argument)."""
     argv = sys.argv[1:] if argv is None else argv
     try:
-        opts, _ = getopt.getopt(argv, "ha:d:s:e:i:n:f:l:x:p:N:P:F:o:G",
+        opts, _ = getopt.getopt(argv, "ha:d:s:e:i:n:f:l:x:p:N:P:F:o:GC:",
                                 ["help", "algo=", "db_jdbc_url=", "start_time=", "end_time=", "id=", "ns_ignore_list=",
                                  "ns-ignore-list=", "agg-flow=", "pod-label=", "external-ip=", "svc-port-name=", "pod-name=",
-                                 "pod-namespace=", "flows=", "out=", "pushdown-groupby"])
+                                 "pod-namespace=", "flows=", "out=", "pushdown-groupby", "connections="])
     except getopt.GetoptError as exc:
         logger.error("ERROR of getopt.getopt: %s", exc)
         logger.info(HELP_MESSAGE)
         sys.exit(2)
     a = {"algo": "", "start": "", "end": "", "id": None, "ns": [], "agg": "", "label": "", "ip": "", "svc": "",
-         "name": "", "namespace": "", "flows": "", "out": "", "db": "", "pushdown": False}
+         "name": "", "namespace": "", "flows": "", "out": "", "db": "", "pushdown": False, "connections": 0}
 
     def bad(msg):
         logger.error(msg)
@@ -751,6 +753,10 @@ def main(argv=None):
             a["db"] = arg
         elif opt in ("-G", "--pushdown-groupby"):
             a["pushdown"] = True
+        elif opt in ("-C", "--connections"):
+            if not arg.isdigit() or not 0 <= int(arg) <= 64:
+                bad("connections should be an integer between 0 and 64.")
+            a["connections"] = int(arg)
         elif opt in ("-s", "--start_time", "-e", "--end_time"):
             which = "start" if opt in ("-s", "--start_time") else "end"
             try:
@@ -793,7 +799,8 @@ def main(argv=None):
     to_db = client is not None and not a["out"]
     try:
         _, rows = anomaly_detection(a["algo"], a["flows"] or client, a["start"], a["end"], tad_id, a["ns"], a["agg"],
-                                    a["label"], a["ip"], a["svc"], a["name"], a["namespace"], pushdown=a["pushdown"], columnar=to_db)
+                                    a["label"], a["ip"], a["svc"], a["name"], a["namespace"], pushdown=a["pushdown"], columnar=to_db,
+                                    connections=a["connections"] if client is not None and not a["flows"] else 0)
     except (TadError, ValueError, OSError) as exc:
         logger.error("Anomaly Detection failed: %s", exc)
         sys.exit(1)

@@ -55,7 +55,9 @@ struct ArimaWs {
   uint8_t *state;  // [K] 0 = ok, 1 = no result
   double *hist;    // [wavefronts of k_arima_fit][kHistDoubles][64] every lane's L-BFGS (s, y) history (struct Lbfgs)
   unsigned long long *cursor;   // [T] next key of series position p not yet handed to a lane (k_arima_fit)
-  unsigned int *yielded;        // [1] set by a wavefront of k_arima_fit that stopped taking keys because the engine asked it to (ArimaPause)
+  unsigned int *yielded;        // [1] set by a wavefront of k_arima_fit that stopped because the engine asked it to (cooperative yield)
+  unsigned int *saved;          // [wavefronts of k_arima_fit] 1: the wavefront suspended its fits in `save` and resumes them at the next launch
+  double *save;                 // [wavefronts of k_arima_fit][kSaveDoubles][64] the suspended lanes' optimiser state (the history block stays where it is)
   uint32_t Tpad;
 };
 
@@ -739,6 +741,7 @@ TAD_HD void lbfgs_direction(Lbfgs &o) {
 // pass has the registers to itself and nothing of the step's state is spilled to scratch memory (a reload from there costs a
 // memory round trip; as members of one long-lived struct the fields also stayed live around the loop on the idle-lane path).
 static constexpr int kParkDoubles = 29;
+static constexpr int kSaveDoubles = 7 + kParkDoubles;   // a suspended lane (k_arima_fit's cooperative yield): busy, key, x[3], fc, col | head + the parked state
 TAD_HD inline void lbfgs_park(const Lbfgs &o) {
   double *m = o.park;
   const size_t st = o.pstride;
@@ -963,13 +966,13 @@ __device__ unsigned long long g_arima_prof[8];
 
 __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double *__restrict__ sigma,
                                                const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax, uint32_t chunk,
-                                               double *__restrict__ calc, DevCounters *ctr, double *buf, double *park, const int *pause) {
+                                               double *__restrict__ calc, DevCounters *ctr, double *buf, double *park, const int *pause, uint32_t grace) {
   const uint32_t nchunks = (uint32_t)((g.K + chunk - 1) / chunk);   // wavefronts per position
   const uint32_t p = pmax - 1 - blockIdx.x / nchunks;           // heaviest (longest history) positions first
   const unsigned lane = threadIdx.x;
   bool dry = false;                                             // wave-uniform: position p has no key left to hand out
-  bool yielded = false;                                         // wave-uniform: ... or the engine asked the fit to make room (see ArimaPause)
-  unsigned polls = 0;
+  bool yielded = false;                                         // wave-uniform: ... or the engine asked the fit to make room (cooperative yield)
+  unsigned polls = 0, iter = 0;
   uint64_t k = 0;
   bool busy = false;
   unsigned long long steps = 0, fits = 0, nanfits = 0;
@@ -992,14 +995,9 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     while (!dry) {
       const unsigned long long m = __ballot(!busy);
       if (m == 0) break;
-      // Cooperative yield.  The fit is ~0.25 s of two-wavefront-per-SIMD work whose wavefronts live for tens of ms; a workgroup of another
-      // job's pass B needs a WHOLE CU (1024 threads, 156 KB of LDS) and would wait until this grid is exhausted whatever the stream priorities
-      // (measured: 212 ms, profiles/r6_a2_*).  `pause` is a word in page-locked host memory the engine raises while such a job is in flight:
-      // every 16th time a lane runs out of work the wavefront looks at it (one uncached read over the host link, ~1 % of the fit) and, if it
-      // is raised, takes no further key — its busy lanes finish their fits (<= a few ms), the wavefront retires, the host relaunches the
-      // kernel when the word is clear again.  The per-position cursors carry on where they stopped; results do not depend on which lane
-      // fits which key.
-      if (pause != nullptr && (++polls & 15u) == 0u && __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+      // Cooperative yield (see the main loop): no key is handed out while the engine's pause word is raised.  Asked on a wavefront's first
+      // refill (a workgroup that starts while the word is raised retires at once) and every 16th after it; the main loop asks every cycle.
+      if (pause != nullptr && iter >= grace && (polls++ & 15u) == 0u && __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
         yielded = true;
         dry = true;
         break;
@@ -1077,8 +1075,39 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     }
   };
 
+  // Resume: this wavefront suspended its fits at the last launch (below) — every lane takes its key and optimiser state back; the (s, y)
+  // history never left this wavefront's block of global memory.
+  unsigned int *const saved_flag = ws.saved + blockIdx.x;
+  double *const save = ws.save + (size_t)blockIdx.x * (kSaveDoubles * 64) + lane;      // lanes interleaved: coalesced
+  // (every lane reads the flag before lane 0 clears it: the shuffle is where the lanes meet)
+  unsigned int was_saved = *saved_flag;
+  was_saved = (unsigned int)__shfl((int)was_saved, 0);
+  if (was_saved != 0u) {      // wave-uniform
+    busy = save[0] != 0.0;
+    k = (uint64_t)__double_as_longlong(save[64]);
+    o.x[0] = save[2 * 64]; o.x[1] = save[3 * 64]; o.x[2] = save[4 * 64];
+    o.fc = save[5 * 64];
+    const long long ch = __double_as_longlong(save[6 * 64]);
+    o.col = (int)(ch >> 32); o.head = (int)(ch & 0xffffffffll);
+    o.done = !busy;
+#pragma unroll 1      // (cold code: one double at a time keeps the kernel's register peak where the optimiser step put it)
+    for (int i = 0; i < kParkDoubles; ++i) o.park[(size_t)i * o.pstride] = save[(size_t)(7 + i) * 64];
+    if (lane == 0) *saved_flag = 0u;
+  }
   refill();
   while (__any(busy)) {
+    // Cooperative yield.  The fit is ~0.25 s of two-wavefront-per-SIMD work whose wavefronts live for tens of ms; a workgroup of another
+    // job's pass B needs a WHOLE CU (1024 threads, 156 KB of LDS) and would wait until this grid is exhausted whatever the stream priorities
+    // (measured: 212 ms, profiles/r6_a2_*).  `pause` is a word in page-locked host memory the engine raises while such a job is in flight.
+    // It is read at the top of every cycle (a system-scope load over the host link whose latency hides behind the likelihood pass) and
+    // acted on at the end of the cycle, where a fit's whole state is (key, x, fc, the history's shape) in registers, 29 parked doubles in
+    // LDS and the history in this wavefront's own global block: the lanes write the first two to `save`, the wavefront retires — within
+    // one likelihood pass (tens of us) of the word being raised, not after its longest fit (up to ~10 ms) — and the host relaunches the
+    // kernel when the word clears (tad_capi.cpp): the same wavefront index takes the same lanes back, so which lane fits which key, and
+    // every bit of every result, is what an undisturbed run gives.  `grace`: cycles during which the word is ignored (a relaunch that was
+    // forced after the host's 2 ms wait must make progress although short jobs keep arriving).
+    int paused_now = 0;
+    if (pause != nullptr) paused_now = __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     TAD_PROF_T(t_a);
     double xe[4][3], dx[3], nll[4], fc0 = 0.0;
 #pragma unroll
@@ -1107,6 +1136,19 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
       }
     }
     TAD_PROF_T(t_c);
+    if (paused_now != 0 && iter >= grace) {      // wave-uniform: suspend
+      save[0] = busy ? 1.0 : 0.0;
+      save[64] = __longlong_as_double((long long)k);
+      save[2 * 64] = o.x[0]; save[3 * 64] = o.x[1]; save[4 * 64] = o.x[2];
+      save[5 * 64] = o.fc;
+      save[6 * 64] = __longlong_as_double(((long long)o.col << 32) | (long long)(unsigned int)o.head);
+#pragma unroll 1
+      for (int i = 0; i < kParkDoubles; ++i) save[(size_t)(7 + i) * 64] = o.park[(size_t)i * o.pstride];
+      if (lane == 0) *saved_flag = 1u;
+      yielded = true;
+      break;
+    }
+    ++iter;
     refill();
     TAD_PROF_T(t_d);
     TAD_PROF_ADD(0, t_a, t_b); TAD_PROF_ADD(1, t_b, t_c); TAD_PROF_ADD(2, t_c, t_d); TAD_PROF_ADD(3, 0ull, 1ull);
@@ -1133,10 +1175,10 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAD_ARIMA_WAVES, TAD_ARIMA_WAVES))) void k_arima_fit(
     Grid g, ArimaWs ws, const double *__restrict__ sigma, const uint32_t *__restrict__ n_pts, int maxiter, uint32_t pmax,
-    uint32_t chunk, double *__restrict__ calc, DevCounters *ctr, const int *pause) {
+    uint32_t chunk, double *__restrict__ calc, DevCounters *ctr, const int *pause, uint32_t grace) {
   __shared__ double buf[64 * (kStage + 1)];
   __shared__ double park[64 * kParkDoubles];
-  arima_fit_body(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf, park, pause);
+  arima_fit_body(g, ws, sigma, n_pts, maxiter, pmax, chunk, calc, ctr, buf, park, pause, grace);
 }
 
 static uint32_t arima_tpad(uint64_t T) { return (uint32_t)((T + kStage - 1) / kStage * kStage); }
@@ -1148,7 +1190,8 @@ size_t arima_workspace_bytes(Grid g) {
   const size_t cells = (size_t)g.K * g.T;
   return cells * (8 * 3 + 8 * 3 + 4) + (size_t)g.K * arima_tpad(g.T) * 8 + (size_t)g.K * 9 + 1024 +
          (size_t)arima_fit_blocks(g) * (kHistDoubles * 64 * 8) + 512 +   // + the L-BFGS history block of every wavefront of k_arima_fit (30 KB each)
-         (size_t)g.T * 8 + 512 + 512 + 64;                               // + the per-position key cursors + the yield word (each region 512-byte aligned)
+         (size_t)g.T * 8 + 512 + 512 + 64 +                              // + the per-position key cursors + the yield word (each region 512-byte aligned)
+         (size_t)arima_fit_blocks(g) * (4 + kSaveDoubles * 64 * 8) + 1024;   // + the suspend flag and save block of every wavefront of k_arima_fit (18 KB each)
 }
 
 static ArimaWs arima_carve(Grid g, void *workspace) {
@@ -1168,21 +1211,23 @@ static ArimaWs arima_carve(Grid g, void *workspace) {
   w = align512(w);   // (tpos is 4 bytes per cell: with an odd cell count everything after it was 4-byte aligned only — fatal for the 64-bit atomics on the cursors)
   ws.hist = reinterpret_cast<double *>(w); w = align512(w + (size_t)arima_fit_blocks(g) * (kHistDoubles * 64 * 8));
   ws.cursor = reinterpret_cast<unsigned long long *>(w); w = align512(w + (size_t)g.T * 8);
-  ws.yielded = reinterpret_cast<unsigned int *>(w);
+  ws.yielded = reinterpret_cast<unsigned int *>(w); w = align512(w + 64);
+  ws.saved = reinterpret_cast<unsigned int *>(w); w = align512(w + (size_t)arima_fit_blocks(g) * 4);
+  ws.save = reinterpret_cast<double *>(w);
   return ws;
 }
 
 // (Re)launch the fit over whatever keys the per-position cursors have not handed out yet; *yielded (device, in the workspace) says afterwards
 // whether a wavefront stopped early because `pause` was raised.
 int launch_arima_fit(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc, DevCounters *ctr, void *workspace,
-                     const int *pause, const unsigned int **yielded) {
+                     const int *pause, const unsigned int **yielded, uint32_t grace) {
   if (yielded) *yielded = nullptr;
   if (g.K == 0 || g.T <= 3) return 0;
   const ArimaWs ws = arima_carve(g, workspace);
   const uint64_t blocks = arima_fit_blocks(g);
   if (blocks > 0x7FFFFFFFull) return -1;
   hipMemsetAsync(ws.yielded, 0, 4, s);
-  hipLaunchKernelGGL(k_arima_fit, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, kArimaChunk, calc, ctr, pause);
+  hipLaunchKernelGGL(k_arima_fit, dim3((unsigned)blocks), dim3(64), 0, s, g, ws, sigma, n_pts, maxiter, (uint32_t)g.T, kArimaChunk, calc, ctr, pause, grace);
   if (yielded) *yielded = ws.yielded;
   return 0;
 }
@@ -1199,7 +1244,8 @@ int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_p
     if (kblocks * (g.T - 3) > 0x7FFFFFFFull) return -1;
     hipLaunchKernelGGL(k_arima_start, dim3((unsigned)(kblocks * (g.T - 3))), dim3(64), 0, s, g, ws, n_pts, (uint32_t)g.T);
     hipMemsetAsync(ws.cursor, 0, (size_t)g.T * 8, s);
-    if (launch_arima_fit(s, g, sigma, n_pts, maxiter, calc, ctr, workspace, pause, yielded) != 0) return -1;
+    hipMemsetAsync(ws.saved, 0, (size_t)arima_fit_blocks(g) * 4, s);
+    if (launch_arima_fit(s, g, sigma, n_pts, maxiter, calc, ctr, workspace, pause, yielded, 0) != 0) return -1;
 #if defined(TAD_ARIMA_PROF)
     {
       unsigned long long h[8] = {0};

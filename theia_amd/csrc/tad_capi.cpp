@@ -690,9 +690,9 @@ int detect_and_count(JobCtx *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_
     if ((rc = ensure(e, e->calc, g.K * g.T * sizeof(double))) != TAD_OK) return rc;
     const size_t wsb = arima_workspace_bytes(g);
     if ((rc = ensure(e, e->aux, wsb)) != TAD_OK) return rc;
-    // The fit yields to whole-CU jobs of other contexts (PauseHold): it stops taking keys while the engine's pause word is raised and is
-    // relaunched here — after the word has cleared, or after 2 ms at the latest, so that a steady stream of short jobs time-slices with the
-    // fit instead of starving it.  This job's own claim is dropped for the duration (it would pause itself) and taken back for the emit.
+    // The fit yields to whole-CU jobs of other contexts (PauseHold): its wavefronts suspend their fits while the engine's pause word is raised
+    // and the kernel is relaunched here — after the word has cleared, or after 2 ms at the latest, so that a steady stream of short jobs
+    // time-slices with the fit instead of starving it.  This job's own claim is dropped for the duration (it would pause itself) and taken back for the emit.
     const bool held = e->hold && e->hold->held;
     if (held) e->hold->release();
     const unsigned int *yielded_dev = nullptr;
@@ -706,7 +706,9 @@ int detect_and_count(JobCtx *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_
       const auto t0 = std::chrono::steady_clock::now();
       while (__atomic_load_n(e->eng->pause_word, __ATOMIC_ACQUIRE) != 0 && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2))
         std::this_thread::sleep_for(std::chrono::microseconds(50));
-      if (launch_arima_fit(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, e->eng->pause_word, &yielded_dev) != 0)
+      // still raised after 2 ms (short jobs arrive back to back): this launch runs 24 optimiser cycles (~1 ms) before it looks at the word
+      const uint32_t grace = __atomic_load_n(e->eng->pause_word, __ATOMIC_ACQUIRE) != 0 ? 24u : 0u;
+      if (launch_arima_fit(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, e->eng->pause_word, &yielded_dev, grace) != 0)
         return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
       e->arima_relaunches++;
     }
@@ -1000,7 +1002,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
     uint64_t cells = empty ? 0 : K * L.nb;
     const bool cells_overflow = !empty && L.nb != 0 && cells / L.nb != K;
     // (ARIMA: predictions + 60 B per cell of workspace, arima_workspace_bytes; DROP: one double per cell)
-    uint64_t need = cells * 9 + (jp.algo == TAD_ALGO_ARIMA ? cells * 76 + (1ull << 22) : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
+    uint64_t need = cells * 9 + (jp.algo == TAD_ALGO_ARIMA ? cells * 80 + (1ull << 22) : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
     // Sparse tables (few points per key on a fine lattice: second-resolution timestamps, per-connection keys): the dense
     // K x T grid would be mostly empty or not fit at all — sort the rows by (key, time) instead and lay each key's points
     // out by rank (tad_sparse.hip).  Chosen when the rows could fill at most 1/8 of a large grid, or the grid does not fit.
@@ -1085,7 +1087,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
       const uint64_t P = runs_tmax[0];    // the filtered-out slots sort last and the reduction drops them
       const unsigned int tmax = (unsigned int)runs_tmax[1];
       cells = K * (uint64_t)tmax;
-      need = cells * 17 + (jp.algo == TAD_ALGO_ARIMA ? cells * 76 + (1ull << 22) : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
+      need = cells * 17 + (jp.algo == TAD_ALGO_ARIMA ? cells * 80 + (1ull << 22) : (jp.algo == TAD_ALGO_DROP ? cells * 8 : 0));
       // Skewed series lengths (one key with a day of seconds next to many short-lived ones): K x Tmax does not fit although the
       // points do.  The keys are split into length classes that run as jobs of their own (run_sparse_classes).
       if (P && depth == 0 && (need > e->ws_limit || plan.sparse_classes == 1)) {

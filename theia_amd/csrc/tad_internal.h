@@ -301,14 +301,15 @@ void launch_drop(hipStream_t s, Grid g, double n_sigma, int min_samples, double 
                  double *key_mean, double *key_m2, DevCounters *ctr);
 
 // ARIMA(1,1,1) walk-forward on Box-Cox data: calc[T][K] + FLAG_ANOMALY.
-// pause (NULL = never yield): a word in page-locked host memory; while it is non-zero the wavefronts of k_arima_fit stop taking keys and retire
-// (other jobs' whole-CU workgroups cannot be placed beside them).  *yielded (device memory inside the workspace) is non-zero afterwards when that
-// happened: the caller waits for `pause` to clear and calls launch_arima_fit until *yielded stays zero — the per-position cursors in the
-// workspace carry on where the wavefronts stopped.
+// pause (NULL = never yield): a word in page-locked host memory; while it is non-zero the wavefronts of k_arima_fit SUSPEND their fits at the end
+// of the running optimiser cycle (state saved per wavefront in the workspace) and retire — other jobs' whole-CU workgroups cannot be placed
+// beside them.  *yielded (device memory inside the workspace) is non-zero afterwards when that happened: the caller waits for `pause` to clear
+// and calls launch_arima_fit until *yielded stays zero — every wavefront takes its own lanes back, the per-position cursors carry on.
+// grace: optimiser cycles during which a (re)launched wavefront ignores the word (progress under a steady stream of short jobs).
 int launch_arima(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter,
                  double *calc, DevCounters *ctr, void *workspace, size_t workspace_bytes, const int *pause = nullptr, const unsigned int **yielded = nullptr);
 int launch_arima_fit(hipStream_t s, Grid g, const double *sigma, const uint32_t *n_pts, int maxiter, double *calc, DevCounters *ctr, void *workspace,
-                     const int *pause, const unsigned int **yielded);
+                     const int *pause, const unsigned int **yielded, uint32_t grace);
 size_t arima_workspace_bytes(Grid g);
 
 // ---- Stage 0 v2: partition rows by key range, aggregate tiles in LDS (tad_stage0_part.hip) ----
