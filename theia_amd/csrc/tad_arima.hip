@@ -997,7 +997,7 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
       if (m == 0) break;
       // Cooperative yield (see the main loop): no key is handed out while the engine's pause word is raised.  Asked on a wavefront's first
       // refill (a workgroup that starts while the word is raised retires at once) and every 16th after it; the main loop asks every cycle.
-      if (pause != nullptr && iter >= grace && (polls++ & 15u) == 0u && __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+      if (pause != nullptr && iter >= grace && (polls++ & 15u) == 0u && __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         yielded = true;
         dry = true;
         break;
@@ -1098,16 +1098,16 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
   while (__any(busy)) {
     // Cooperative yield.  The fit is ~0.25 s of two-wavefront-per-SIMD work whose wavefronts live for tens of ms; a workgroup of another
     // job's pass B needs a WHOLE CU (1024 threads, 156 KB of LDS) and would wait until this grid is exhausted whatever the stream priorities
-    // (measured: 212 ms, profiles/r6_a2_*).  `pause` is a word in page-locked host memory the engine raises while such a job is in flight.
-    // It is read at the top of every cycle (a system-scope load over the host link whose latency hides behind the likelihood pass) and
-    // acted on at the end of the cycle, where a fit's whole state is (key, x, fc, the history's shape) in registers, 29 parked doubles in
+    // (measured: 212 ms, profiles/r6_a2_*).  `pause` is a word in DEVICE memory the engine raises while such a job is in flight (a 4-byte
+    // fill on its signal stream).  It is read at the top of every cycle (an agent-scope load: the XCDs' L2s are not coherent with each other,
+    // the load goes to the memory side; a page-locked HOST word polled at this rate doubled the kernel's time) and acted on at the end of the cycle, where a fit's whole state is (key, x, fc, the history's shape) in registers, 29 parked doubles in
     // LDS and the history in this wavefront's own global block: the lanes write the first two to `save`, the wavefront retires — within
     // one likelihood pass (tens of us) of the word being raised, not after its longest fit (up to ~10 ms) — and the host relaunches the
     // kernel when the word clears (tad_capi.cpp): the same wavefront index takes the same lanes back, so which lane fits which key, and
     // every bit of every result, is what an undisturbed run gives.  `grace`: cycles during which the word is ignored (a relaunch that was
     // forced after the host's 2 ms wait must make progress although short jobs keep arriving).
     int paused_now = 0;
-    if (pause != nullptr) paused_now = __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (pause != nullptr) paused_now = __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     TAD_PROF_T(t_a);
     double xe[4][3], dx[3], nll[4], fc0 = 0.0;
 #pragma unroll

@@ -48,7 +48,7 @@ struct tad_engine {
   uint64_t ws_limit = 0;       // per job in flight
   int max_ctx = 1;
   hipStream_t user_stream = nullptr;   // tad_engine_opts.stream: context 0 runs on it (and the pool has that one context)
-  int prio_normal = 0, prio_low = 0;   // hipDeviceGetStreamPriorityRange: ARIMA jobs (seconds of FP64) run on the low-priority stream of their
+  int prio_normal = 0, prio_low = 0, prio_high = 0;   // hipDeviceGetStreamPriorityRange: ARIMA jobs (seconds of FP64) run on the low-priority stream of their
                                        // context so that the short HBM-bound jobs of other contexts are dispatched ahead of their workgroups
   std::mutex mu;               // protects plan, ctxs, the busy flags and last_done / last_total
   std::condition_variable cv;  // a context became idle
@@ -59,9 +59,16 @@ struct tad_engine {
   std::string err;
   // Whole-CU jobs vs. the ARIMA fit.  A workgroup of pass B / pass C needs a whole CU; the fit kernel of an ARIMA job in flight on another
   // context keeps every CU populated with long-lived wavefronts, so such a workgroup would wait for the fit's whole grid (212 ms measured)
-  // whatever the stream priorities.  *pause_word (page-locked, device-visible) counts the jobs in flight that are in a whole-CU phase; the fit
-  // polls it and retires its wavefronts while it is non-zero (tad_arima.hip), its host loop relaunches it afterwards (detect_and_count).
-  int *pause_word = nullptr;
+  // whatever the stream priorities.  pause_count = jobs in flight that are in a whole-CU phase; *pause_dev (DEVICE memory) is 0 / non-zero
+  // accordingly, written on the 0 <-> 1 transitions by a 4-byte fill on signal_stream (one stream, under pause_mu: the writes cannot
+  // pass each other).  The fit polls it every optimiser cycle and suspends while it is raised (tad_arima.hip); its host loop relaunches it
+  // (detect_and_count).  The word lives in device memory because 2048 wavefronts polling a page-locked HOST word once per cycle (1.6e7
+  // reads/s over the host link) doubled the fit's time (C3 266 -> 492 ms, profiles/r6_a4_*); an agent-scope load from HBM costs nothing
+  // measurable.
+  std::mutex pause_mu;
+  int pause_count = 0;         // under pause_mu (read without it by the fit's host loop: a hint, re-checked by the kernel)
+  int *pause_dev = nullptr;
+  hipStream_t signal_stream = nullptr;
   std::mutex pool_mu;          // protects free_blocks
   std::vector<FreeBlock> free_blocks;  // recycled device result blocks (a result may be freed from any thread)
 };
@@ -371,10 +378,16 @@ struct PauseHold {
   bool held = false;
   explicit PauseHold(tad_engine *e) : eng(e) {}
   void acquire() {
-    if (!held && eng->pause_word) { __atomic_fetch_add(eng->pause_word, 1, __ATOMIC_SEQ_CST); held = true; }
+    if (held || !eng->pause_dev) return;
+    std::lock_guard<std::mutex> lk(eng->pause_mu);
+    if (eng->pause_count++ == 0) (void)hipMemsetAsync(eng->pause_dev, 1, 4, eng->signal_stream);
+    held = true;
   }
   void release() {
-    if (held) { __atomic_fetch_sub(eng->pause_word, 1, __ATOMIC_SEQ_CST); held = false; }
+    if (!held) return;
+    std::lock_guard<std::mutex> lk(eng->pause_mu);
+    if (--eng->pause_count == 0) (void)hipMemsetAsync(eng->pause_dev, 0, 4, eng->signal_stream);
+    held = false;
   }
   ~PauseHold() { release(); }
   PauseHold(const PauseHold &) = delete;
@@ -513,15 +526,27 @@ int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
     e->prio_low = least;
     e->prio_normal = greatest < least ? least - 1 : least;   // one step above the lowest: ordinary (default) priority where the range has three levels
     if (e->prio_normal < greatest) e->prio_normal = greatest;
+    e->prio_high = greatest;
   }
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
   e->ws_limit = (opts && opts->workspace_limit) ? opts->workspace_limit : (uint64_t)(free_b / 4 * 3);
   if (opts) e->plan = opts->plan;
-  if (hipHostMalloc(reinterpret_cast<void **>(&e->pause_word), 64, hipHostMallocDefault) == hipSuccess) *e->pause_word = 0;
-  else { (void)hipGetLastError(); e->pause_word = nullptr; }     // (without it ARIMA fits never yield: the behaviour of ABI <= 11)
+  // the pause word and the stream its writes go through (highest priority: a 4-byte fill must not queue behind anything)
+  if (hipMalloc(reinterpret_cast<void **>(&e->pause_dev), 256) != hipSuccess || hipMemset(e->pause_dev, 0, 256) != hipSuccess ||
+      hipStreamCreateWithPriority(&e->signal_stream, hipStreamNonBlocking, e->prio_high) != hipSuccess) {
+    (void)hipGetLastError();     // (without it ARIMA fits never yield: the behaviour of ABI <= 11)
+    if (e->pause_dev) hipFree(e->pause_dev);
+    e->pause_dev = nullptr;
+    e->signal_stream = nullptr;
+  }
   JobCtx *c0 = ctx_create(e, true);
-  if (!c0) { if (e->pause_word) hipHostFree(e->pause_word); delete e; return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "stream / pinned host allocation failed"); }
+  if (!c0) {
+    if (e->signal_stream) hipStreamDestroy(e->signal_stream);
+    if (e->pause_dev) hipFree(e->pause_dev);
+    delete e;
+    return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "stream / pinned host allocation failed");
+  }
   e->ctxs.push_back(c0);
   // The code objects of the library load lazily, on the first launch out of each translation unit: ~3.5 ms of the first job of a process
   // (profiles/r6_a1_cold_hip_api_stats.csv: 1.5 ms inside hipLaunchKernel, 1.9 ms inside hipFuncSetAttribute).  Touch one kernel of every
@@ -541,7 +566,8 @@ void tad_engine_destroy(tad_engine *e) {
   }
   for (JobCtx *c : e->ctxs) ctx_destroy(c);
   for (auto &fb : e->free_blocks) hipFree(fb.p);
-  if (e->pause_word) hipHostFree(e->pause_word);
+  if (e->signal_stream) { hipStreamSynchronize(e->signal_stream); hipStreamDestroy(e->signal_stream); }
+  if (e->pause_dev) hipFree(e->pause_dev);
   delete e;
 }
 
@@ -696,19 +722,19 @@ int detect_and_count(JobCtx *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_
     const bool held = e->hold && e->hold->held;
     if (held) e->hold->release();
     const unsigned int *yielded_dev = nullptr;
-    if (launch_arima(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, wsb, e->eng->pause_word, &yielded_dev) != 0)
+    if (launch_arima(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, wsb, e->eng->pause_dev, &yielded_dev) != 0)
       return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
-    while (yielded_dev != nullptr && e->eng->pause_word != nullptr) {
+    while (yielded_dev != nullptr && e->eng->pause_dev != nullptr) {
       unsigned int y = 0;
       HIP_TRY(e, hipMemcpyAsync(&y, yielded_dev, 4, hipMemcpyDeviceToHost, s));
       HIP_TRY(e, hipStreamSynchronize(s));
       if (y == 0) break;
       const auto t0 = std::chrono::steady_clock::now();
-      while (__atomic_load_n(e->eng->pause_word, __ATOMIC_ACQUIRE) != 0 && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2))
+      while (__atomic_load_n(&e->eng->pause_count, __ATOMIC_ACQUIRE) != 0 && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2))
         std::this_thread::sleep_for(std::chrono::microseconds(50));
       // still raised after 2 ms (short jobs arrive back to back): this launch runs 24 optimiser cycles (~1 ms) before it looks at the word
-      const uint32_t grace = __atomic_load_n(e->eng->pause_word, __ATOMIC_ACQUIRE) != 0 ? 24u : 0u;
-      if (launch_arima_fit(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, e->eng->pause_word, &yielded_dev, grace) != 0)
+      const uint32_t grace = __atomic_load_n(&e->eng->pause_count, __ATOMIC_ACQUIRE) != 0 ? 24u : 0u;
+      if (launch_arima_fit(s, g, sigma, n_pts, jp.maxiter, static_cast<double *>(e->calc.p), ctr, e->aux.p, e->eng->pause_dev, &yielded_dev, grace) != 0)
         return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
       e->arima_relaunches++;
     }

@@ -301,7 +301,7 @@ void launch_drop(hipStream_t s, Grid g, double n_sigma, int min_samples, double 
                  double *key_mean, double *key_m2, DevCounters *ctr);
 
 // ARIMA(1,1,1) walk-forward on Box-Cox data: calc[T][K] + FLAG_ANOMALY.
-// pause (NULL = never yield): a word in page-locked host memory; while it is non-zero the wavefronts of k_arima_fit SUSPEND their fits at the end
+// pause (NULL = never yield): a word in device memory; while it is non-zero the wavefronts of k_arima_fit SUSPEND their fits at the end
 // of the running optimiser cycle (state saved per wavefront in the workspace) and retire — other jobs' whole-CU workgroups cannot be placed
 // beside them.  *yielded (device memory inside the workspace) is non-zero afterwards when that happened: the caller waits for `pause` to clear
 // and calls launch_arima_fit until *yielded stays zero — every wavefront takes its own lanes back, the per-position cursors carry on.

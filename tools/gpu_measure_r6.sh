@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 measurement call (the committed library): the full -m gpu suite, the default bench line (C2 headline + C4 + C3 + C5 at N = 1 with
-# the CPU baselines), same-process A/B of the one-synchronisation form, rocprofv3 kernel-trace stats of C2 / C4 / C3 and of the sparse path
-# (small shapes and 1e8 rows), HBM PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, no tracing flags) for C2, C4 and the sparse scale run,
-# tad_factorize / tad_encode_strings at 1e8 rows, the job through ClickHouse's HTTP interface (2e7 rows).   usage: tools/gpu_measure_r5.sh <tag> [notests]
+# Round-6 measurement call (the committed library): the full -m gpu suite, the default bench line (C2 headline over 4 tables + same_columns + cold +
+# concurrency + C4 + C3 + C5 at N = 1 with the CPU baselines), the host-input line, the cold probe, rocprofv3 kernel-trace stats of C2 / C4 / C3 / C5 at
+# N = 1 and of the sparse path, HBM PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, no tracing flags) for C2, C4, C5 and the sparse scale run,
+# tad_factorize / tad_encode_strings at 1e8 rows, the device ingest end to end at 1e8 rows.   usage: tools/gpu_measure_r6.sh <tag> [notests]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1
 mkdir -p $O
@@ -10,15 +10,14 @@ cd $R
 if [ "$2" != notests ]; then ( timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6 ) > $O/pytest.log 2>&1; fi
 timeout 900 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err
 timeout 120 python bench.py --host-input --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs > $O/bench_host_input.json 2>/dev/null
-timeout 300 python tools/ab_plans.py --config c2 > $O/ab_c2_one_sync.log 2>&1
-timeout 300 python tools/ab_plans.py --config c4 > $O/ab_c4_one_sync.log 2>&1
+timeout 300 python tools/cold_probe.py --config c2 > $O/cold_c2.log 2>&1
+timeout 300 python tools/cold_probe.py --config c4 > $O/cold_c4.log 2>&1
 timeout 400 python tools/sparse_bench.py --steps 5 --rows 100000000 --sorts lsd,auto > $O/sparse_bench.log 2>&1
 timeout 600 python tools/factorize_bench.py > $O/factorize_bench.log 2>&1
 timeout 600 python tools/strings_bench.py > $O/strings_bench.log 2>&1
-timeout 400 python tools/ingest_e2e.py --rows 20000000 --mode pod > $O/ingest_e2e_pod.log 2>&1
-( cd /tmp; timeout 120 $R/tools/probes/placement_probe > $O/placement_probe.log 2>&1 )
+timeout 600 python tools/ingest_e2e.py --rows 100000000 --mode pod --connections 8 --compare-host 2000000 > $O/ingest_e2e_pod.log 2>&1
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-other-configs"
+B="python $R/bench.py --no-cpu-baseline --no-other-configs --tables 1"
 kt() {  # name, command...
   n=$1; shift
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$n -o $n -- "$@" > $O/kt_$n.log 2>&1
@@ -53,9 +52,9 @@ python - <<PY
 import json
 for n in ("c2", "c4", "c5", "sparse"):
     k = json.load(open("$O/pmc_%s.json" % n))["kernels"]
-    job = {a: b for a, b in k.items() if a not in ("k_synth", "k_place_probe")}     # (the table generator and the one-time placement probe are not the job)
+    job = {a: b for a, b in k.items() if a not in ("k_synth",)}     # (the table generator is not the job)
     print(n, "bytes fetched %.2f GB written %.2f GB per job (one launch of every kernel of the job)" % (sum(v["fetch_bytes"] for v in job.values()) / 1e9, sum(v["write_bytes"] for v in job.values()) / 1e9), {a: (round(b["fetch_bytes"] / 1e6), round(b["write_bytes"] / 1e6)) for a, b in k.items() if b["fetch_bytes"] + b["write_bytes"] > 2e7})
 PY
 rm -f $O/pmc_c*_fetch.csv $O/pmc_c*_write.csv $O/pmc_sparse_*.csv $O/kt_*.log $O/pmc_*.log
-cat $O/pytest.log $O/ab_c2_one_sync.log $O/ab_c4_one_sync.log $O/sparse_bench.log $O/factorize_bench.log $O/strings_bench.log $O/ingest_e2e_pod.log 2>/dev/null; python -c "
+cat $O/pytest.log $O/cold_c2.log $O/cold_c4.log $O/sparse_bench.log $O/factorize_bench.log $O/strings_bench.log $O/ingest_e2e_pod.log 2>/dev/null; python -c "
 import json; d=json.loads(open('$O/bench_default_line.json').read().strip().splitlines()[-1]); print('C2', d['ms_per_step'], d['roofline']['frac'], d['pipeline']['hbm_frac_whole_job']); [print(k, v.get('ms_per_step'), v.get('roofline',{}).get('frac')) for k,v in d.get('other_configs',{}).items()]; print(json.loads(open('$O/bench_host_input.json').read().strip().splitlines()[-1])['ms_per_step'])"
