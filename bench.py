@@ -232,9 +232,10 @@ def concurrency_leg(eng, levels, serial_ms):
                 "ewma_ms_max": max(lat) if lat else None, "arima_s": box.get("s"), "arima_relaunches": box.get("relaunches"), "arima_job_context": box.get("ctx")}
     out["short_job_beside_long_job"] = {
         "what": "C2 EWMA jobs submitted by one thread while a C3 ARIMA job (same shape, another table) runs on another context's low-priority "
-                "stream: every 20 ms (`paced`), and back to back (`saturated`: the fit time-slices with them, 2 ms at most per wait).  The fit "
-                "kernel retires its wavefronts while a whole-CU job is in flight (tad_stats.arima_relaunches) — without that the EWMA job waited "
-                "for the fit's whole grid: 212 ms (profiles/r6_a2_bench_default_line.json)",
+                "stream: every 20 ms (`paced`), and back to back (`saturated`: the fit time-slices with them — 2 ms at most per wait, then ~1 ms "
+                "of fit whatever arrives).  While a whole-CU job is in flight the fit kernel suspends its fits at the end of the running optimiser "
+                "cycle and its wavefronts retire; the host relaunches it and every wavefront takes its lanes back (tad_stats.arima_relaunches; "
+                "results bit-identical).  Without that the EWMA job waited for the fit's whole grid: 212 ms (profiles/r6_a2_bench_default_line.json)",
         "ewma_ms_alone": serial_ms, "arima_s_alone": alone_s, "paced": beside(0.02), "saturated": beside(0.0)}
     return out
 

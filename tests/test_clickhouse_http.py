@@ -192,6 +192,68 @@ def test_rows_query_where_clause():
     assert "(destinationPodName = 'p1' AND destinationPodNamespace = 'ns1') OR (sourcePodName = 'p1' AND sourcePodNamespace = 'ns1')" in q
 
 
+def test_rows_query_dictionary_shard_and_count_variants():
+    """The statements of the device ingest (fetch_flows_device): only the columns the mode's job reads, string columns as
+    toLowCardinality(col) AS col (so that ClickHouse sends Arrow dictionaries), a shard predicate per parallel read, and the count query that
+    gives every read its place in the device columns.  The WHERE clause is the reference's (anomaly_detection.py:507-614) in every variant."""
+    plain = ch.rows_query("", "", ["kube-system"], "pod", "", "", "", "", "")
+    where = plain[plain.index(" WHERE "):]
+    q = ch.rows_query("", "", ["kube-system"], "pod", "", "", "", "", "", dictionary=True, shard=(2, 8))
+    assert q == ("SELECT toLowCardinality(sourcePodNamespace) AS sourcePodNamespace, toLowCardinality(destinationPodNamespace) AS destinationPodNamespace, "
+                 "toLowCardinality(sourcePodLabels) AS sourcePodLabels, toLowCardinality(destinationPodLabels) AS destinationPodLabels, flowEndSeconds, throughput "
+                 "FROM default.flows" + where + " AND cityHash64(sourceIP, sourceTransportPort, destinationIP, destinationTransportPort, flowStartSeconds, "
+                 "flowEndSeconds) % 8 = 2")
+    by_name = ch.rows_query("", "", [], "pod", "", "", "", "p1", "ns1", dictionary=True, shard=(0, 2))
+    assert "sourcePodName" in by_name and "PodLabels" not in by_name[:by_name.index(" FROM ")]
+    c = ch.rows_query("", "", ["kube-system"], "pod", "", "", "", "", "", dictionary=True, shard=(None, 8), count_only=True)
+    assert c == ("SELECT cityHash64(sourceIP, sourceTransportPort, destinationIP, destinationTransportPort, flowStartSeconds, flowEndSeconds) % 8 AS shard, "
+                 "count() AS rows FROM default.flows" + where + " GROUP BY shard")
+    # svc without a time window or ns-ignore list: three columns; with them: flowStartSeconds and the namespaces come along
+    q = ch.rows_query("", "", [], "svc", "", "", "", "", "", dictionary=True, shard=(0, 1))
+    assert q[len("SELECT "):q.index(" FROM ")] == "toLowCardinality(destinationServicePortName) AS destinationServicePortName, flowEndSeconds, throughput"
+    q = ch.rows_query("2022-01-01 00:00:00", "", ["a"], "svc", "", "", "", "", "", dictionary=True, shard=(0, 1))
+    cols = q[len("SELECT "):q.index(" FROM ")]
+    assert "flowStartSeconds" in cols and "toLowCardinality(sourcePodNamespace) AS sourcePodNamespace" in cols
+    # mode None: flowStartSeconds is part of the key; ports and protocol stay integers
+    q = ch.rows_query("", "", [], "", "", "", "", "", "", dictionary=True, shard=(1, 4))
+    cols = q[len("SELECT "):q.index(" FROM ")].split(", ")
+    assert cols == ["toLowCardinality(sourceIP) AS sourceIP", "sourceTransportPort", "toLowCardinality(destinationIP) AS destinationIP",
+                    "destinationTransportPort", "protocolIdentifier", "flowStartSeconds", "flowEndSeconds", "throughput"]
+    assert q.endswith(" WHERE cityHash64(sourceIP, sourceTransportPort, destinationIP, destinationTransportPort, flowStartSeconds, flowEndSeconds) % 4 = 1")
+    assert ch.rows_query("", "", [], "svc", "", "", "", "", "") == ch.rows_query("", "", [], "svc", "", "", "", "", "", dictionary=False, shard=None)
+
+
+def test_vocabulary_maps_batch_dictionaries_into_one_in_order_of_appearance():
+    v = ch._Vocabulary()
+    assert v.remap(pa.array(["b", "a", None])).tolist() == [0, 1, 2] and v.values == ["b", "a", ""]
+    assert v.remap(pa.array(["a", "c", "b", ""])).tolist() == [1, 3, 0, 2] and v.values == ["b", "a", "", "c"]
+    assert v.remap(pa.array([], pa.string())).tolist() == []
+    assert v.remap(pa.array(["d", "d", "a"])).tolist() == [4, 4, 1] and v.values == ["b", "a", "", "c", "d"]      # a dictionary with a repeated value
+    import threading
+    w = ch._Vocabulary()
+    outs = {}
+
+    def work(i):
+        outs[i] = [w.remap(pa.array(["v%d" % ((i * 7 + j) % 50) for j in range(30)])) for _ in range(20)]
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    vals = w.values
+    assert sorted(vals) == sorted(set(vals)) and len(vals) == 50           # every value once, whatever the interleaving
+    for i in range(6):
+        want = ["v%d" % ((i * 7 + j) % 50) for j in range(30)]
+        assert all([vals[c] for c in r.tolist()] == want for r in outs[i])
+
+
+def test_cli_connections_option_is_validated():
+    for bad in ("x", "-1", "65"):
+        with pytest.raises(SystemExit) as ei:
+            ad.main(["--algo", "EWMA", "--connections", bad])
+        assert ei.value.code == 2
+
+
 def test_insert_columns_arrow(server):
     client = ch.ClickHouseHTTP(server.url, user="", password="")
     flows = jo.synth_flows(3000)

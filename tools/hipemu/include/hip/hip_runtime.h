@@ -120,8 +120,6 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 // compiler-level wavefront barrier on the device (no instruction); here the lanes really have to meet
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::wave_op(hipemu::OP_BALLOT, 1u, 0, reinterpret_cast<uintptr_t>(__FILE__) * 1000003u + (unsigned)__LINE__))
 #define __builtin_amdgcn_readlane(v, l) __shfl((int)(v), (int)(l))
-#define __builtin_amdgcn_readfirstlane(v) (v)   /* the product only applies it to values that ARE the same in all lanes (to tell the compiler so) */
-#define __builtin_amdgcn_alignbit(h, l, s) ((unsigned int)((((unsigned long long)(unsigned int)(h) << 32) | (unsigned int)(l)) >> ((s) & 31u)))
 static inline long long __double_as_longlong(double v) { long long r; __builtin_memcpy(&r, &v, 8); return r; }
 static inline double __longlong_as_double(long long v) { double r; __builtin_memcpy(&r, &v, 8); return r; }
 #define __builtin_amdgcn_frexp_mant(x) hipemu::frexp_mant(x)
