@@ -12,8 +12,8 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtad_mi355x.so")
-SOURCES = ["tad_kernels.hip", "tad_stage0_part.hip", "tad_dbscan.hip", "tad_arima.hip", "tad_drop.hip", "tad_synth.hip", "tad_shard.hip", "tad_sparse.hip", "tad_factorize.hip", "tad_ingest.hip", "tad_capi.cpp"]
-HEADERS = [os.path.join(CSRC, "tad_internal.h"), os.path.join(CSRC, "tad_detmath.h"), os.path.join(REPO_ROOT, "include", "tad.h")]
+SOURCES = ["tad_kernels.hip", "tad_stage0_part.hip", "tad_dbscan.hip", "tad_arima.hip", "tad_drop.hip", "tad_synth.hip", "tad_shard.hip", "tad_sparse.hip", "tad_factorize.hip", "tad_ingest.hip", "tad_engine.cpp", "tad_capi.cpp", "tad_capi_ingest.cpp", "tad_capi_series.cpp"]
+HEADERS = [os.path.join(CSRC, "tad_internal.h"), os.path.join(CSRC, "tad_engine.h"), os.path.join(CSRC, "tad_detmath.h"), os.path.join(REPO_ROOT, "include", "tad.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-unused-value", "-Wno-unused-result"]
 

@@ -1107,7 +1107,10 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     // every bit of every result, is what an undisturbed run gives.  `grace`: cycles during which the word is ignored (a relaunch that was
     // forced after the host's 2 ms wait must make progress although short jobs keep arriving).
     int paused_now = 0;
-    if (pause != nullptr) paused_now = __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if !defined(TAD_ARIMA_POLL_MASK)       // measurement knob (tools/build_variants.py): poll every (mask + 1)-th cycle; 0xFFFFFFFF = never
+#define TAD_ARIMA_POLL_MASK 0u
+#endif
+    if (pause != nullptr && (iter & TAD_ARIMA_POLL_MASK) == 0u) paused_now = __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     TAD_PROF_T(t_a);
     double xe[4][3], dx[3], nll[4], fc0 = 0.0;
 #pragma unroll

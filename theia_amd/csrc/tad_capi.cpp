@@ -1,649 +1,11 @@
-// tad_capi.cpp — the C ABI of include/tad.h on top of the gfx950 kernels.  HIP only: there is no
-// CPU fallback in this library (the CPU oracle under oracle/ is test infrastructure and is never
-// linked or called from here).
-//
-// Threading (controller.go:199-201 runs four workers, Spark ran one pod per job): an engine owns a small POOL of job
-// contexts.  A context is everything one job in flight needs — a HIP stream (two: normal and low priority), its events, its pinned
-// read-back blocks and its grow-only workspace buffers — so jobs submitted from different threads run concurrently on the GPU, each
-// on its own stream, and never touch each other's memory.  tad_run takes an idle context (creating one up to
-// tad_engine_opts.max_jobs_in_flight, else waiting), runs, and gives it back.  Serial callers always get context 0 and see the
-// behaviour of the single-mutex engine of ABI <= 11.
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <new>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "tad_internal.h"
+// tad_capi.cpp — the job of include/tad.h: tad_run / tad_aggregate / tad_run_stream on a job context (tad_engine.h).  Replaces one run of
+// anomaly_detection() (plugins/anomaly-detection/anomaly_detection.py:647-710): Stage 0 GROUP BY -> per-key sigma -> detector -> compaction.
+#include "tad_engine.h"
 
 using namespace tad;
+using namespace tadh;
 
-namespace {
-
-struct DevBuf {
-  void *p = nullptr;
-  size_t cap = 0;
-};
-
-struct FreeBlock {
-  void *p;
-  size_t cap;
-};
-
-thread_local std::string g_static_err;
-
-}  // namespace
-
-struct JobCtx;
-
-struct tad_engine {
-  int device = 0;
-  uint64_t ws_limit = 0;       // per job in flight
-  int max_ctx = 1;
-  hipStream_t user_stream = nullptr;   // tad_engine_opts.stream: context 0 runs on it (and the pool has that one context)
-  int prio_normal = 0, prio_low = 0, prio_high = 0;   // hipDeviceGetStreamPriorityRange: ARIMA jobs (seconds of FP64) run on the low-priority stream of their
-                                       // context so that the short HBM-bound jobs of other contexts are dispatched ahead of their workgroups
-  std::mutex mu;               // protects plan, ctxs, the busy flags and last_done / last_total
-  std::condition_variable cv;  // a context became idle
-  tad_plan plan{};             // plan overrides (tests / A-B measurements); all zero = the engine decides
-  std::vector<JobCtx *> ctxs;
-  int32_t last_done = 0, last_total = 0;   // progress of the job that finished last (tad_progress with nothing in flight)
-  std::mutex err_mu;           // protects err
-  std::string err;
-  // Whole-CU jobs vs. the ARIMA fit.  A workgroup of pass B / pass C needs a whole CU; the fit kernel of an ARIMA job in flight on another
-  // context keeps every CU populated with long-lived wavefronts, so such a workgroup would wait for the fit's whole grid (212 ms measured)
-  // whatever the stream priorities.  pause_count = jobs in flight that are in a whole-CU phase; *pause_dev (DEVICE memory) is 0 / non-zero
-  // accordingly, written on the 0 <-> 1 transitions by a 4-byte fill on signal_stream (one stream, under pause_mu: the writes cannot
-  // pass each other).  The fit polls it every optimiser cycle and suspends while it is raised (tad_arima.hip); its host loop relaunches it
-  // (detect_and_count).  The word lives in device memory because 2048 wavefronts polling a page-locked HOST word once per cycle (1.6e7
-  // reads/s over the host link) doubled the fit's time (C3 266 -> 492 ms, profiles/r6_a4_*); an agent-scope load from HBM costs nothing
-  // measurable.
-  std::mutex pause_mu;
-  int pause_count = 0;         // under pause_mu (read without it by the fit's host loop: a hint, re-checked by the kernel)
-  int *pause_dev = nullptr;
-  hipStream_t signal_stream = nullptr;
-  std::mutex pool_mu;          // protects free_blocks
-  std::vector<FreeBlock> free_blocks;  // recycled device result blocks (a result may be freed from any thread)
-};
-
-// One job in flight.  Everything below is touched by the thread that holds the context only (busy == true), except done / total / id.
-struct PauseHold;
-struct JobCtx {
-  tad_engine *eng = nullptr;
-  PauseHold *hold = nullptr;   // the running job's claim on whole CUs (run_job); NULL for the small entry points
-  int index = 0;               // position in eng->ctxs (tad_stats.job_context)
-  bool busy = false;           // under eng->mu
-  int device = 0;
-  hipStream_t stream = nullptr;        // the stream of the running job: stream_normal or stream_low
-  hipStream_t stream_normal = nullptr, stream_low = nullptr;
-  bool own_streams = false;
-  uint64_t ws_limit = 0;
-  tad_plan plan{};             // the engine's plan when the job was admitted
-  std::atomic<int32_t> done{0}, total{0};
-  char id[64] = {};            // tad_job.id of the running job (tad_job_progress); under eng->mu
-  // grow-only device scratch
-  DevBuf grid_val, grid_flag, sigma, n_pts, n_anom, off, scan_scratch, calc, counters, meta, aux, key_mean, key_m2;   // counters: the job tail (kTailBytes)
-  DevBuf in_key, in_key2, in_te, in_ts, in_val;
-  DevBuf rcp_table;           // rcp_table[n] = RN(1/n), n = 0..rcp_n-1
-  uint64_t rcp_n = 0;
-  DevBuf binhist, part_total, part_start, part_offs32, recs, ovf, slices;  // Stage 0 v2 (ovf: 8-byte count + overflow records)
-  DevBuf sp_comp_a, sp_comp_b, sp_val_a, sp_val_b, sp_temp, sp_first, sp_times;  // Stage 0 sparse (sort + rank grid)
-  DevBuf sp_cls;                                                                  // Stage 0 sparse, length classes: per-key class arrays
-  int arima_relaunches = 0;       // times the running job's ARIMA fit was relaunched after it had yielded to whole-CU jobs (tad_stats.arima_relaunches)
-  bool sp_by_partition = false;   // the running job's sparse Stage 0 went through the partition pass + LDS sort (stage0_path 8 / 9 / 10 instead of 4 / 6 / 7)
-  DevBuf part_fin;                                                                // Stage 0 v2, sampled histogram: final cursors of the (workgroup, partition) regions
-  DevBuf ovf_keys;                                                                // Stage 0 v2, settle mode: bitmap of the keys with a value on the overflow list
-  hipEvent_t ev[8] = {};
-  MetaPartial *meta_host = nullptr;    // pinned
-  // The job's tail — what the host reads when a job's kernels are done — is ONE block on the device (e->counters: DevCounters |
-  // row total | overflow-list count | pad to 128 B | kMomentBlocks moment partials) and ONE pinned block here: one copy per job.
-  unsigned char *tail_host = nullptr;        // pinned, kTailBytes
-  DevCounters *ctr_host = nullptr;           // = tail_host
-  unsigned long long *total_host = nullptr;  // = tail_host + 64
-  Moments *moments_host = nullptr;           // = tail_host + 128
-  // what the last job of this context learnt about its table, reused when the next job has the same shape (nothing speculative: both only
-  // skip an attempt that is known to fail)
-  struct Learnt {
-    bool valid = false;
-    uint64_t n = 0, K = 0;
-    bool has2 = false;
-    int algo = 0, op = 0;
-    bool exact_hist = false;   // the sampled histogram proved too optimistic for this table: go straight to the exact one
-    bool wide_tiles = false;   // 32-bit tile cells overflowed the list for this table: go straight to 8-byte cells
-  } learnt;
-};
-
-// per-key running state of the streaming EWMA detector: two copies (the count pass writes the candidate next state,
-// it becomes current only when the batch succeeds)
-namespace {
-constexpr size_t kTailCtr = 0, kTailTotal = 64, kTailOvfCount = 72, kTailMoments = 128;
-constexpr size_t kTailBytes = kTailMoments + sizeof(Moments) * kMomentBlocks;
-inline unsigned long long *dev_total(JobCtx *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailTotal); }
-inline unsigned long long *dev_ovf_count(JobCtx *e) { return reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(e->counters.p) + kTailOvfCount); }
-inline Moments *dev_moments(JobCtx *e) { return reinterpret_cast<Moments *>(static_cast<unsigned char *>(e->counters.p) + kTailMoments); }
-}  // namespace
-
-struct tad_state {
-  uint64_t K = 0;
-  void *block[2] = {nullptr, nullptr};
-  int cur = 0;
-  mutable std::mutex mu;     // batches of one state are serial (tad_run_stream from two threads on one state)
-};
-
-namespace {
-
-constexpr int kMetaBlocks = 2048;
-constexpr int kSampleBlockShift = 7;   // (C4 with 1024-key blocks and a sampled histogram: pass A 0.21 -> 0.10 ms but pass C 0.68 -> 0.86 ms, profiles/r3_v2_c4_keyblock_ab.log)
-constexpr int kDefaultJobsInFlight = 4;   // controller.go:199-201 / pkg/controller/util.go:43: four workers
-constexpr int kMaxJobsInFlight = 16;
-
-bool plan_ok(const tad_plan &p) {
-  return p.stage0 >= 0 && p.stage0 <= 2 && p.partition_pass >= 0 && p.partition_pass <= 3 && p.histogram >= 0 && p.histogram <= 2 && p.sparse >= 0 &&
-         p.sparse <= 2 && p.sparse_classes >= 0 && p.sparse_classes <= 1 && p.ewma_emit >= 0 && p.ewma_emit <= 1 && p.ewma_emit_rows <= 4096 && p.tile_cells >= 0 && p.tile_cells <= 1 && p.sparse_sort >= 0 && p.sparse_sort <= 2 && p.reserved0 == 0 && p.reserved1 == 0;
-}
-constexpr uint32_t kOverflowCap = 1u << 20;  // Stage 0 v2: rows with a value >= 2^49 per run before falling back to v1
-
-int vfail(tad_engine *e, int code, const char *fmt, va_list ap) {
-  char buf[512];
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  if (e) {
-    std::lock_guard<std::mutex> lk(e->err_mu);
-    e->err = buf;
-  } else {
-    g_static_err = buf;
-  }
-  return code;
-}
-int fail(tad_engine *e, int code, const char *fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  const int rc = vfail(e, code, fmt, ap);
-  va_end(ap);
-  return rc;
-}
-int fail(JobCtx *c, int code, const char *fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  const int rc = vfail(c ? c->eng : nullptr, code, fmt, ap);
-  va_end(ap);
-  return rc;
-}
-int fail(std::nullptr_t, int code, const char *fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  const int rc = vfail(nullptr, code, fmt, ap);
-  va_end(ap);
-  return rc;
-}
-
-#define HIP_TRY(e, call)                                                                         \
-  do {                                                                                           \
-    hipError_t err__ = (call);                                                                   \
-    if (err__ != hipSuccess)                                                                     \
-      return fail((e), err__ == hipErrorOutOfMemory ? TAD_ERR_OUT_OF_MEMORY : TAD_ERR_HIP,       \
-                  "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
-  } while (0)
-
-// every grow-only buffer of a context, for trimming and teardown
-template <typename F> void for_each_buf(JobCtx *c, F f) {
-  DevBuf *bufs[] = {&c->grid_val, &c->grid_flag, &c->sigma, &c->n_pts, &c->n_anom, &c->off, &c->scan_scratch, &c->calc, &c->counters, &c->meta, &c->aux,
-                    &c->key_mean, &c->key_m2, &c->rcp_table, &c->binhist, &c->part_total, &c->part_start, &c->part_offs32, &c->recs, &c->ovf, &c->slices,
-                    &c->sp_comp_a, &c->sp_comp_b, &c->sp_val_a, &c->sp_val_b, &c->sp_temp, &c->sp_first, &c->sp_times, &c->sp_cls, &c->part_fin, &c->ovf_keys,
-                    &c->in_key, &c->in_key2, &c->in_te, &c->in_ts, &c->in_val};
-  for (DevBuf *b : bufs) f(*b);
-}
-
-// give the workspace of a context back to the device (the context is idle and held by the caller, or is being destroyed)
-void drop_buffers(JobCtx *c) {
-  for_each_buf(c, [](DevBuf &b) {
-    if (b.p) hipFree(b.p);
-    b = DevBuf{};
-  });
-  c->rcp_n = 0;
-}
-
-// An allocation failed: the idle contexts of the engine and the recycled result blocks give their memory back, then the caller retries once.
-// (Contexts are grow-only for speed; the sum over a pool may exceed what a single big job plus the others' leftovers can share.)
-void trim_idle(tad_engine *eng, JobCtx *self) {
-  std::vector<JobCtx *> held;
-  {
-    std::lock_guard<std::mutex> lk(eng->mu);
-    for (JobCtx *c : eng->ctxs)
-      if (c != self && !c->busy) { c->busy = true; held.push_back(c); }
-  }
-  for (JobCtx *c : held) drop_buffers(c);
-  {
-    std::lock_guard<std::mutex> lk(eng->pool_mu);
-    for (auto &fb : eng->free_blocks) hipFree(fb.p);
-    eng->free_blocks.clear();
-  }
-  (void)hipGetLastError();
-  {
-    std::lock_guard<std::mutex> lk(eng->mu);
-    for (JobCtx *c : held) c->busy = false;
-  }
-  eng->cv.notify_all();
-}
-
-int ensure(JobCtx *e, DevBuf &b, size_t bytes) {
-  if (bytes <= b.cap) return TAD_OK;
-  if (b.p) {
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    HIP_TRY(e, hipFree(b.p));
-    b = DevBuf{};
-  }
-  size_t want = bytes + bytes / 8 + 256;
-  hipError_t r = hipMalloc(&b.p, want);
-  if (r != hipSuccess) {
-    want = bytes;
-    r = hipMalloc(&b.p, want);
-  }
-  if (r != hipSuccess) {
-    (void)hipGetLastError();
-    trim_idle(e->eng, e);
-    r = hipMalloc(&b.p, want);
-  }
-  if (r != hipSuccess) {
-    b.p = nullptr;
-    (void)hipGetLastError();
-    return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(r));
-  }
-  b.cap = want;
-  return TAD_OK;
-}
-
-// Resolve one kernel of every translation unit: the lazy loader brings the unit's code object onto the device.
-void preload_code_objects() {
-  const void *anchors[] = {code_anchor_arima(), code_anchor_dbscan(), code_anchor_drop(), code_anchor_factorize(), code_anchor_ingest(), code_anchor_kernels(), code_anchor_shard(), code_anchor_sparse(), code_anchor_stage0_part(), code_anchor_synth()};
-  for (const void *k : anchors) {
-    hipFuncAttributes attr;
-    (void)hipFuncGetAttributes(&attr, k);
-  }
-  (void)hipGetLastError();
-}
-
-// ---- the pool ----
-JobCtx *ctx_create(tad_engine *eng, bool first) {
-  JobCtx *c = new (std::nothrow) JobCtx();
-  if (!c) return nullptr;
-  c->eng = eng;
-  c->device = eng->device;
-  c->ws_limit = eng->ws_limit;
-  bool ok = true;
-  if (first && eng->user_stream) {
-    c->stream_normal = c->stream_low = eng->user_stream;
-  } else {
-    c->own_streams = true;
-    ok = hipStreamCreateWithPriority(&c->stream_normal, hipStreamNonBlocking, eng->prio_normal) == hipSuccess;
-    if (ok && eng->prio_low != eng->prio_normal) ok = hipStreamCreateWithPriority(&c->stream_low, hipStreamNonBlocking, eng->prio_low) == hipSuccess;
-    else c->stream_low = c->stream_normal;
-  }
-  c->stream = c->stream_normal;
-  for (auto &ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
-  ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->meta_host), sizeof(MetaPartial) * kMetaBlocks, hipHostMallocDefault) == hipSuccess;
-  ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->tail_host), kTailBytes, hipHostMallocDefault) == hipSuccess;
-  if (ok) {
-    memset(c->tail_host, 0, kTailBytes);
-    c->ctr_host = reinterpret_cast<DevCounters *>(c->tail_host + kTailCtr);
-    c->total_host = reinterpret_cast<unsigned long long *>(c->tail_host + kTailTotal);
-    c->moments_host = reinterpret_cast<Moments *>(c->tail_host + kTailMoments);
-  }
-  if (!ok) {
-    (void)hipGetLastError();
-    for (auto &ev : c->ev) if (ev) hipEventDestroy(ev);
-    if (c->meta_host) hipHostFree(c->meta_host);
-    if (c->tail_host) hipHostFree(c->tail_host);
-    if (c->own_streams) {
-      if (c->stream_low && c->stream_low != c->stream_normal) hipStreamDestroy(c->stream_low);
-      if (c->stream_normal) hipStreamDestroy(c->stream_normal);
-    }
-    delete c;
-    return nullptr;
-  }
-  return c;
-}
-
-void ctx_destroy(JobCtx *c) {
-  if (c->stream_normal) hipStreamSynchronize(c->stream_normal);
-  if (c->stream_low && c->stream_low != c->stream_normal) hipStreamSynchronize(c->stream_low);
-  drop_buffers(c);
-  for (auto &ev : c->ev) if (ev) hipEventDestroy(ev);
-  if (c->meta_host) hipHostFree(c->meta_host);
-  if (c->tail_host) hipHostFree(c->tail_host);
-  if (c->own_streams) {
-    if (c->stream_low && c->stream_low != c->stream_normal) hipStreamDestroy(c->stream_low);
-    if (c->stream_normal) hipStreamDestroy(c->stream_normal);
-  }
-  delete c;
-}
-
-// An idle context (the lowest-numbered one: a serial caller always gets context 0 and its warm buffers), a new one while the pool may
-// grow, else wait.  low_priority: the job's kernels go to the context's low-priority stream (ARIMA).
-struct Lease {
-  tad_engine *eng;
-  JobCtx *c = nullptr;
-  Lease(tad_engine *eng_, const char *id = nullptr, bool low_priority = false) : eng(eng_) {
-    std::unique_lock<std::mutex> lk(eng->mu);
-    for (;;) {
-      for (JobCtx *x : eng->ctxs)
-        if (!x->busy) { c = x; break; }
-      if (c) break;
-      if ((int)eng->ctxs.size() < eng->max_ctx) {
-        lk.unlock();      // (stream / pinned-memory creation outside the lock)
-        hipSetDevice(eng->device);
-        JobCtx *n = ctx_create(eng, false);
-        lk.lock();
-        if (n) { n->index = (int)eng->ctxs.size(); eng->ctxs.push_back(n); c = n; break; }
-        if (eng->ctxs.empty()) return;   // cannot happen (context 0 is made by tad_engine_create); c stays NULL
-      }
-      eng->cv.wait(lk);
-    }
-    c->busy = true;
-    c->plan = eng->plan;
-    c->done.store(0);
-    c->total.store(0);
-    memset(c->id, 0, sizeof c->id);
-    if (id) strncpy(c->id, id, sizeof c->id - 1);
-    c->stream = low_priority ? c->stream_low : c->stream_normal;
-    c->hold = nullptr;
-  }
-  ~Lease() {
-    if (!c) return;
-    {
-      std::lock_guard<std::mutex> lk(eng->mu);
-      if (c->total.load() != 0) { eng->last_done = c->done.load(); eng->last_total = c->total.load(); }
-      c->busy = false;
-      c->id[0] = 0;
-      c->hold = nullptr;
-    }
-    eng->cv.notify_one();
-  }
-  Lease(const Lease &) = delete;
-  Lease &operator=(const Lease &) = delete;
-};
-
-}  // namespace
-
-// A job's claim on whole CUs: raised when its Stage 0 takes the partition path, dropped while its own ARIMA fit runs, dropped for good when
-// the job returns.
-struct PauseHold {
-  tad_engine *eng;
-  bool held = false;
-  explicit PauseHold(tad_engine *e) : eng(e) {}
-  void acquire() {
-    if (held || !eng->pause_dev) return;
-    std::lock_guard<std::mutex> lk(eng->pause_mu);
-    if (eng->pause_count++ == 0) (void)hipMemsetAsync(eng->pause_dev, 1, 4, eng->signal_stream);
-    held = true;
-  }
-  void release() {
-    if (!held) return;
-    std::lock_guard<std::mutex> lk(eng->pause_mu);
-    if (--eng->pause_count == 0) (void)hipMemsetAsync(eng->pause_dev, 0, 4, eng->signal_stream);
-    held = false;
-  }
-  ~PauseHold() { release(); }
-  PauseHold(const PauseHold &) = delete;
-  PauseHold &operator=(const PauseHold &) = delete;
-};
-
-namespace {
-
-// recycled device result blocks (engine-wide: a result is freed by whoever holds it)
-void release_block(tad_engine *eng, void *p, size_t cap) {
-  if (!p) return;
-  {
-    std::lock_guard<std::mutex> lk(eng->pool_mu);
-    if (eng->free_blocks.size() < 16) { eng->free_blocks.push_back({p, cap}); return; }
-  }
-  hipSetDevice(eng->device);
-  hipFree(p);
-}
-inline void release_block(JobCtx *e, void *p, size_t cap) { release_block(e->eng, p, cap); }
-
-Lattice make_lattice(int64_t t0, int64_t step, uint64_t nb) {
-  Lattice L;
-  L.t0 = t0;
-  L.step = step < 1 ? 1 : step;
-  L.nb = nb;
-  L.magic = 0;
-  if (L.step == 1) {
-    L.mode = 0;
-  } else {
-    // ceil(2^64 / step) = floor((2^64 - 1) / step) + 1 (step >= 2 never divides 2^64 - 1 + 1 exactly
-    // unless it is a power of two, for which floor((2^64-1)/step) + 1 = 2^64/step as well)
-    L.magic = UINT64_MAX / (uint64_t)L.step + 1;
-    // the multiply-high quotient is exact for dividends < 2^32 and divisors < 2^32
-    const bool small = (uint64_t)L.step < (1ull << 32) &&
-                       (nb == 0 || (nb - 1) <= (UINT32_MAX / (uint64_t)L.step));
-    L.mode = small ? 1 : 2;
-  }
-  return L;
-}
-
-uint64_t host_gcd(uint64_t a, uint64_t b) {
-  while (b) { uint64_t r = a % b; a = b; b = r; }
-  return a;
-}
-
-struct ResultBlock {
-  void *base = nullptr;
-  size_t cap = 0;
-};
-
-// every column starts on a 32-byte boundary (stride = rows rounded up to 4): k_emit stores four rows at a time
-size_t result_bytes(uint64_t rows, bool with_anomaly) {
-  const uint64_t r = ((rows ? rows : 1) + 3) & ~3ull;
-  return (size_t)r * 8 * 5 + (with_anomaly ? (size_t)((r + 15) & ~15ull) : 0);
-}
-
-void carve(void *base, uint64_t rows, bool with_anomaly, OutRows *o) {
-  const uint64_t r = ((rows ? rows : 1) + 3) & ~3ull;
-  unsigned char *p = static_cast<unsigned char *>(base);
-  o->key_id = reinterpret_cast<unsigned long long *>(p); p += r * 8;
-  o->flow_end_s = reinterpret_cast<long long *>(p); p += r * 8;
-  o->throughput = reinterpret_cast<double *>(p); p += r * 8;
-  o->algo_calc = reinterpret_cast<double *>(p); p += r * 8;
-  o->stddev = reinterpret_cast<double *>(p); p += r * 8;
-  o->anomaly = with_anomaly ? p : nullptr;
-}
-
-int alloc_device_block(JobCtx *e, size_t bytes, ResultBlock *rb) {
-  {
-    std::lock_guard<std::mutex> lk(e->eng->pool_mu);
-    std::vector<FreeBlock> &fb = e->eng->free_blocks;
-    for (size_t i = 0; i < fb.size(); ++i) {
-      if (fb[i].cap >= bytes && fb[i].cap <= 2 * bytes + (1 << 20)) {
-        rb->base = fb[i].p;
-        rb->cap = fb[i].cap;
-        fb.erase(fb.begin() + i);
-        return TAD_OK;
-      }
-    }
-  }
-  void *p = nullptr;
-  hipError_t r = hipMalloc(&p, bytes);
-  if (r != hipSuccess) {
-    (void)hipGetLastError();
-    trim_idle(e->eng, e);
-    r = hipMalloc(&p, bytes);
-  }
-  if (r != hipSuccess) { (void)hipGetLastError(); return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipMalloc(result, %zu) failed: %s", bytes, hipGetErrorString(r)); }
-  rb->base = p;
-  rb->cap = bytes;
-  return TAD_OK;
-}
-
-struct ResultPriv {  // lives right behind the public struct
-  tad_result pub;
-  void *block;
-  size_t block_cap;
-};
-
-}  // namespace
-
-extern "C" {
-
-int tad_abi_version(void) { return TAD_ABI_VERSION; }
-
-const char *tad_last_error(tad_engine *e) {
-  if (!e) return g_static_err.c_str();
-  std::lock_guard<std::mutex> lk(e->err_mu);
-  static thread_local std::string copy;
-  copy = e->err;
-  return copy.c_str();
-}
-
-int tad_engine_create(const tad_engine_opts *opts, tad_engine **out) {
-  if (!out) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_engine_create: out is NULL");
-  *out = nullptr;
-  int ndev = 0;
-  hipError_t r = hipGetDeviceCount(&ndev);
-  if (r != hipSuccess || ndev == 0)
-    return fail(nullptr, TAD_ERR_NO_DEVICE, "no HIP device available (%s)", r != hipSuccess ? hipGetErrorString(r) : "count = 0");
-  const int dev = opts ? opts->device : 0;
-  if (dev < 0 || dev >= ndev) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "device %d out of range (have %d)", dev, ndev);
-  if (opts && !plan_ok(opts->plan)) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_engine_create: a tad_plan field is out of range");
-  if (opts && (opts->max_jobs_in_flight < 0 || opts->max_jobs_in_flight > kMaxJobsInFlight || opts->reserved != 0))
-    return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_engine_create: max_jobs_in_flight must be 0 (default %d) .. %d", kDefaultJobsInFlight, kMaxJobsInFlight);
-  tad_engine *e = new (std::nothrow) tad_engine();
-  if (!e) return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "out of host memory");
-  e->device = dev;
-  if (hipSetDevice(dev) != hipSuccess) { delete e; return fail(nullptr, TAD_ERR_NO_DEVICE, "hipSetDevice(%d) failed", dev); }
-  e->user_stream = opts ? static_cast<hipStream_t>(opts->stream) : nullptr;
-  // a caller's stream orders the engine's work with the caller's own: one context, on that stream
-  e->max_ctx = e->user_stream ? 1 : ((opts && opts->max_jobs_in_flight) ? opts->max_jobs_in_flight : kDefaultJobsInFlight);
-  {
-    int least = 0, greatest = 0;   // numerically lower = higher priority
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
-    e->prio_low = least;
-    e->prio_normal = greatest < least ? least - 1 : least;   // one step above the lowest: ordinary (default) priority where the range has three levels
-    if (e->prio_normal < greatest) e->prio_normal = greatest;
-    e->prio_high = greatest;
-  }
-  size_t free_b = 0, total_b = 0;
-  hipMemGetInfo(&free_b, &total_b);
-  e->ws_limit = (opts && opts->workspace_limit) ? opts->workspace_limit : (uint64_t)(free_b / 4 * 3);
-  if (opts) e->plan = opts->plan;
-  // the pause word and the stream its writes go through (highest priority: a 4-byte fill must not queue behind anything)
-  if (hipMalloc(reinterpret_cast<void **>(&e->pause_dev), 256) != hipSuccess || hipMemset(e->pause_dev, 0, 256) != hipSuccess ||
-      hipStreamCreateWithPriority(&e->signal_stream, hipStreamNonBlocking, e->prio_high) != hipSuccess) {
-    (void)hipGetLastError();     // (without it ARIMA fits never yield: the behaviour of ABI <= 11)
-    if (e->pause_dev) hipFree(e->pause_dev);
-    e->pause_dev = nullptr;
-    e->signal_stream = nullptr;
-  }
-  JobCtx *c0 = ctx_create(e, true);
-  if (!c0) {
-    if (e->signal_stream) hipStreamDestroy(e->signal_stream);
-    if (e->pause_dev) hipFree(e->pause_dev);
-    delete e;
-    return fail(nullptr, TAD_ERR_OUT_OF_MEMORY, "stream / pinned host allocation failed");
-  }
-  e->ctxs.push_back(c0);
-  // The code objects of the library load lazily, on the first launch out of each translation unit: ~3.5 ms of the first job of a process
-  // (profiles/r6_a1_cold_hip_api_stats.csv: 1.5 ms inside hipLaunchKernel, 1.9 ms inside hipFuncSetAttribute).  Touch one kernel of every
-  // unit here, where the ~100 ms of runtime initialisation are being paid anyway.
-  preload_code_objects();
-  (void)hipGetLastError();
-  *out = e;
-  return TAD_OK;
-}
-
-void tad_engine_destroy(tad_engine *e) {
-  if (!e) return;
-  hipSetDevice(e->device);
-  {
-    std::unique_lock<std::mutex> lk(e->mu);   // (destroying an engine with jobs in flight is a caller bug; wait for them rather than crash)
-    e->cv.wait(lk, [&] { for (JobCtx *c : e->ctxs) if (c->busy) return false; return true; });
-  }
-  for (JobCtx *c : e->ctxs) ctx_destroy(c);
-  for (auto &fb : e->free_blocks) hipFree(fb.p);
-  if (e->signal_stream) { hipStreamSynchronize(e->signal_stream); hipStreamDestroy(e->signal_stream); }
-  if (e->pause_dev) hipFree(e->pause_dev);
-  delete e;
-}
-
-int tad_engine_set_plan(tad_engine *e, const tad_plan *plan) {
-  if (!e) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_engine_set_plan: engine is NULL");
-  tad_plan p{};
-  if (plan) p = *plan;
-  if (!plan_ok(p)) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_engine_set_plan: a tad_plan field is out of range");
-  std::lock_guard<std::mutex> lk(e->mu);   // jobs admitted from now on see it; jobs in flight keep the plan they were admitted with
-  e->plan = p;
-  return TAD_OK;
-}
-
-int tad_progress(tad_engine *e, int32_t *done, int32_t *total) {
-  if (!e) return TAD_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
-  int32_t d = 0, t = 0;
-  bool any = false;
-  for (JobCtx *c : e->ctxs)
-    if (c->busy && c->total.load() != 0) { d += c->done.load(); t += c->total.load(); any = true; }
-  if (!any) { d = e->last_done; t = e->last_total; }
-  if (done) *done = d;
-  if (total) *total = t;
-  return TAD_OK;
-}
-
-int tad_job_progress(tad_engine *e, const char *id, int32_t *done, int32_t *total) {
-  if (!e || !id) return TAD_ERR_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lk(e->mu);
-  for (JobCtx *c : e->ctxs)
-    if (c->busy && c->total.load() != 0 && strncmp(c->id, id, sizeof c->id) == 0) {
-      if (done) *done = c->done.load();
-      if (total) *total = c->total.load();
-      return TAD_OK;
-    }
-  if (done) *done = 0;     // no job with this id is in flight (finished, or not started yet): total = 0
-  if (total) *total = 0;
-  return TAD_OK;
-}
-
-int tad_jobs_in_flight(tad_engine *e) {
-  if (!e) return 0;
-  std::lock_guard<std::mutex> lk(e->mu);
-  int n = 0;
-  for (JobCtx *c : e->ctxs) n += c->busy ? 1 : 0;
-  return n;
-}
-
-void tad_result_free(tad_engine *e, tad_result *r) {
-  if (!r) return;
-  ResultPriv *rp = reinterpret_cast<ResultPriv *>(r);
-  if (rp->block) {
-    if (r->memory == TAD_MEM_DEVICE && e) release_block(e, rp->block, rp->block_cap);
-    else if (r->memory == TAD_MEM_DEVICE) hipFree(rp->block);
-    else free(rp->block);
-  }
-  delete rp;
-}
-
-// ------------------------------------------------------------------------------------------------
-// the detector pipeline over a filled grid (shared by tad_run and the tad_series_* entry points)
-// ------------------------------------------------------------------------------------------------
-}  // extern "C"
-
-namespace {
-
-struct JobParams {
-  tad_algo algo;
-  double alpha, eps;
-  int min_samples, maxiter;
-  double drop_nsigma;
-  int drop_min_samples;
-  bool all_points;
-  bool lazy_sigma = false;   // set by detect_and_count: the stddev column is computed by the emit kernel (DBSCAN jobs)
-  bool settled = false;      // set by Stage 0: pass C ran in settle mode (SettleArgs) — the DBSCAN scan only walks the keys it marked
-};
+namespace tadh {
 
 // reciprocals of the point counts 1..T for the exact-division FMA sequence (tad_internal.h:div_by_count);
 // 1.0 / n on the host is IEEE division = the correctly rounded reciprocal the sequence needs.
@@ -678,6 +40,10 @@ int ensure_key_buffers(JobCtx *e, uint64_t K) {
 
 // Runs sigma + detector + scan on grid g.  On return *rows = number of rows emit will write.
 // stats_done: Stage 0 v2's tile pass already produced sigma / n_pts / (EWMA) n_anom / moments inputs / counters.
+}  // namespace tadh
+
+namespace {
+
 int detect_and_count(JobCtx *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_t *rows, bool stats_done = false) {
   hipStream_t s = e->stream;
   int rc;
@@ -753,7 +119,11 @@ int detect_and_count(JobCtx *e, Grid g, JobParams &jp, DevCounters *ctr, uint64_
   return TAD_OK;
 }
 
-void emit_rows(JobCtx *e, Grid g, Lattice L, const JobParams &jp, OutRows out, uint64_t rows = 0) {
+}  // namespace
+
+namespace tadh {
+
+void emit_rows(JobCtx *e, Grid g, Lattice L, const JobParams &jp, OutRows out, uint64_t rows) {
   const int kind = jp.algo == TAD_ALGO_EWMA ? 0 : (jp.algo == TAD_ALGO_ARIMA ? 1 : (jp.algo == TAD_ALGO_DROP ? 3 : (jp.lazy_sigma ? 4 : 2)));
   // DBSCAN job: only keys of the detector's work list (still in e->aux) can have rows
   if (kind == 4 && !jp.all_points &&
@@ -763,6 +133,10 @@ void emit_rows(JobCtx *e, Grid g, Lattice L, const JobParams &jp, OutRows out, u
               static_cast<const uint32_t *>(e->n_pts.p), static_cast<const double *>(kind == 3 ? e->key_mean.p : e->calc.p),
               static_cast<const unsigned long long *>(e->off.p), out, rows, e->plan.ewma_emit, e->plan.ewma_emit_rows);
 }
+
+}  // namespace tadh
+
+namespace {
 
 int make_result(JobCtx *e, uint64_t rows, bool with_anomaly, tad_mem out_memory, ResultPriv **out, OutRows *dev_rows,
                 ResultBlock *dev_block) {
@@ -821,12 +195,6 @@ int stage_column(JobCtx *e, DevBuf &buf, const void *src, uint64_t n, tad_mem me
   *dev = buf.p;
   return TAD_OK;
 }
-
-struct PointsPriv {  // tad_points + its storage
-  tad_points pub;
-  void *block;
-  size_t block_cap;
-};
 
 size_t state_bytes(uint64_t K) { return (size_t)K * (4 + 8 * 4 + 1) + 64; }
 
@@ -1740,552 +1108,5 @@ int tad_aggregate(tad_engine *e, const tad_job *job, const tad_columns *cols, ta
   return run_job(e, job, cols, out_memory, nullptr, out);
 }
 
-int tad_shard_rows(tad_engine *eng, const tad_columns *cols, uint32_t world, uint64_t *out_key_id, int64_t *out_flow_end_s,
-                   uint64_t *out_value, uint64_t *counts) {
-  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: engine is NULL");
-  if (!cols || !counts || !shard_world_ok(world)) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: bad arguments (1 <= world <= 1024)");
-  if (cols->memory != TAD_MEM_DEVICE || cols->key_id2 || cols->flow_start_s)
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: device columns with one key per row only");
-  const uint64_t n = cols->n_rows;
-  if (n && (!cols->key_id || !cols->flow_end_s || !cols->value || !out_key_id || !out_flow_end_s || !out_value))
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_shard_rows: key_id, flow_end_s, value and the three outputs are required");
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_shard_rows: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  hipStream_t s = e->stream;
-  int rc;
-  if ((rc = ensure(e, e->scan_scratch, (size_t)world * 16)) != TAD_OK) return rc;
-  unsigned long long *d_counts = static_cast<unsigned long long *>(e->scan_scratch.p);
-  unsigned long long *d_cursor = d_counts + world;
-  HIP_TRY(e, hipMemsetAsync(d_counts, 0, (size_t)world * 8, s));
-  launch_shard_count(s, cols->key_id, n, world, d_counts);
-  std::vector<unsigned long long> h(world), off(world);
-  HIP_TRY(e, hipMemcpyAsync(h.data(), d_counts, (size_t)world * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(e, hipStreamSynchronize(s));
-  unsigned long long run = 0;
-  for (uint32_t d = 0; d < world; ++d) { off[d] = run; run += h[d]; counts[d] = h[d]; }
-  HIP_TRY(e, hipMemcpyAsync(d_cursor, off.data(), (size_t)world * 8, hipMemcpyHostToDevice, s));
-  launch_shard_scatter(s, cols->key_id, cols->flow_end_s, cols->value, n, world, d_cursor, out_key_id, out_flow_end_s, out_value);
-  HIP_TRY(e, hipStreamSynchronize(s));   // `off` goes out of scope; the caller may hand the buffers to a collective on another stream
-  HIP_TRY(e, hipGetLastError());
-  return TAD_OK;
-}
-
-int tad_factorize(tad_engine *eng, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row, uint64_t first_row_cap,
-                  uint64_t *num_keys) {
-  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: engine is NULL");
-  if (!kc || !num_keys || kc->n_cols < 1 || kc->n_cols > kFzMaxCols || !kc->cols_a || (kc->n_rows && !key_id) || (kc->cols_b && kc->n_rows && !key_id2) ||
-      (first_row_cap && !first_row))
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: bad arguments (1..%d key columns, key_id / key_id2 / first_row buffers)", kFzMaxCols);
-  const uint64_t n = kc->n_rows;
-  const uint32_t sides = kc->cols_b ? 2 : 1;
-  *num_keys = 0;
-  if (n == 0) return TAD_OK;
-  if (n * sides >= 0xFFFFFFFFull) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: %llu virtual rows do not fit 32-bit row indices", (unsigned long long)(n * sides));
-  for (int c = 0; c < kc->n_cols; ++c)
-    if (!kc->cols_a[c] || (kc->cols_b && !kc->cols_b[c])) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: key column %d is NULL", c);
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_factorize: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  hipStream_t s = e->stream;
-  const bool host = kc->memory == TAD_MEM_HOST;
-  // host inputs are staged behind the table block in the same scratch: columns, masks, outputs
-  const size_t col_bytes = (n * 8 + 255) & ~(size_t)255, mask_bytes = (n + 255) & ~(size_t)255, fr_bytes = (first_row_cap * 8 + 255) & ~(size_t)255;
-  const size_t stage = host ? (size_t)kc->n_cols * sides * col_bytes + 2 * mask_bytes + sides * col_bytes + fr_bytes : 0;
-  // the table starts small and grows when the device says so (tad_factorize.hip): 2^20 -> 2^24 -> 2 n slots
-  for (uint64_t slots = factorize_first_slots(n * sides);;) {
-    const size_t tb = factorize_temp_bytes(n * sides, slots);
-    if (tb + stage + 64 > e->ws_limit)
-      return fail(e, TAD_ERR_GRID_TOO_LARGE, "tad_factorize needs %llu bytes of scratch > workspace limit %llu", (unsigned long long)(tb + stage), (unsigned long long)e->ws_limit);
-    int rc;
-    if ((rc = ensure(e, e->sp_temp, tb + stage + 64)) != TAD_OK) return rc;
-    unsigned char *base = static_cast<unsigned char *>(e->sp_temp.p);
-    unsigned long long *nk_dev = reinterpret_cast<unsigned long long *>(base + tb);
-    const long long *ca[kFzMaxCols] = {}, *cb[kFzMaxCols] = {};
-    const uint8_t *ka = kc->keep_a, *kb = kc->keep_b;
-    uint64_t *d_key = key_id, *d_key2 = key_id2, *d_fr = first_row;
-    if (host) {
-      unsigned char *p = base + tb + 64;
-      for (int c = 0; c < kc->n_cols; ++c) {
-        HIP_TRY(e, hipMemcpyAsync(p, kc->cols_a[c], n * 8, hipMemcpyHostToDevice, s)); ca[c] = reinterpret_cast<const long long *>(p); p += col_bytes;
-        if (sides == 2) { HIP_TRY(e, hipMemcpyAsync(p, kc->cols_b[c], n * 8, hipMemcpyHostToDevice, s)); cb[c] = reinterpret_cast<const long long *>(p); p += col_bytes; }
-      }
-      if (ka) { HIP_TRY(e, hipMemcpyAsync(p, ka, n, hipMemcpyHostToDevice, s)); ka = p; }
-      p += mask_bytes;
-      if (kb) { HIP_TRY(e, hipMemcpyAsync(p, kb, n, hipMemcpyHostToDevice, s)); kb = p; }
-      p += mask_bytes;
-      d_key = reinterpret_cast<uint64_t *>(p); p += col_bytes;
-      if (sides == 2) { d_key2 = reinterpret_cast<uint64_t *>(p); p += col_bytes; }
-      d_fr = reinterpret_cast<uint64_t *>(p);
-    } else {
-      for (int c = 0; c < kc->n_cols; ++c) { ca[c] = reinterpret_cast<const long long *>(kc->cols_a[c]); if (sides == 2) cb[c] = reinterpret_cast<const long long *>(kc->cols_b[c]); }
-    }
-    uint32_t *flags_dev = nullptr;
-    launch_factorize(s, ca, ka, sides == 2 ? cb : nullptr, kb, n, kc->n_cols, slots, base, d_key, d_key2, d_fr, first_row_cap, nk_dev, &flags_dev);
-    unsigned long long nk = 0;
-    uint32_t flags = 0;
-    HIP_TRY(e, hipMemcpyAsync(&nk, nk_dev, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(e, hipMemcpyAsync(&flags, flags_dev, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(e, hipStreamSynchronize(s));
-    HIP_TRY(e, hipGetLastError());
-    if (flags != 0) {      // more keys than this table takes: once more with the next size (a host batch is staged again: the block may have moved)
-      const uint64_t next = factorize_next_slots(n * sides, slots);
-      if (next == slots) return fail(e, TAD_ERR_HIP, "tad_factorize: the full-size table filled up");
-      slots = next;
-      continue;
-    }
-    if (host) {
-      HIP_TRY(e, hipMemcpyAsync(key_id, d_key, n * 8, hipMemcpyDeviceToHost, s));
-      if (sides == 2) HIP_TRY(e, hipMemcpyAsync(key_id2, d_key2, n * 8, hipMemcpyDeviceToHost, s));
-      const uint64_t m = nk < first_row_cap ? nk : first_row_cap;
-      if (m) HIP_TRY(e, hipMemcpyAsync(first_row, d_fr, m * 8, hipMemcpyDeviceToHost, s));
-      HIP_TRY(e, hipStreamSynchronize(s));
-    }
-    *num_keys = nk;
-    return TAD_OK;
-  }
-}
-
-int tad_encode_strings(tad_engine *eng, const tad_string_column *col, int64_t *codes, uint64_t *first_row, uint64_t first_row_cap, uint64_t *num_values) {
-  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: engine is NULL");
-  if (!col || !num_values || (col->offset_bits != 32 && col->offset_bits != 64) || (col->n_rows && (!col->offsets || !codes)) || (first_row_cap && !first_row) ||
-      (col->data_bytes && !col->data))
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: bad arguments (offsets of 32 or 64 bits, data, codes / first_row buffers)");
-  const uint64_t n = col->n_rows;
-  *num_values = 0;
-  if (n == 0) return TAD_OK;
-  if (n >= 0xFFFFFFFFull) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: %llu rows do not fit 32-bit row indices", (unsigned long long)n);
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_encode_strings: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  hipStream_t s = e->stream;
-  const bool host = col->memory == TAD_MEM_HOST;
-  const int off64 = col->offset_bits == 64;
-  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  // host inputs are staged behind the table block: offsets, bytes (+ 8 of slack: the last aligned word), validity, codes, first rows
-  const size_t off_bytes = up((n + 1) * (off64 ? 8 : 4)), data_bytes = up(col->data_bytes + 8);
-  const size_t val_bytes = col->validity ? up((col->validity_offset + n + 7) / 8) : 0, code_bytes = up(n * 8), fr_bytes = up(first_row_cap * 8);
-  const size_t stage = host ? off_bytes + data_bytes + val_bytes + code_bytes + fr_bytes : 0;
-  for (uint64_t slots = factorize_first_slots(n);;) {
-    const size_t tb = factorize_temp_bytes(n, slots);
-    if (tb + stage + 64 > e->ws_limit)
-      return fail(e, TAD_ERR_GRID_TOO_LARGE, "tad_encode_strings needs %llu bytes of scratch > workspace limit %llu", (unsigned long long)(tb + stage), (unsigned long long)e->ws_limit);
-    int rc;
-    if ((rc = ensure(e, e->sp_temp, tb + stage + 64)) != TAD_OK) return rc;
-    unsigned char *base = static_cast<unsigned char *>(e->sp_temp.p);
-    unsigned long long *nv_dev = reinterpret_cast<unsigned long long *>(base + tb);
-    const void *d_off = col->offsets;
-    const uint8_t *d_data = col->data, *d_valid = col->validity;
-    long long *d_codes = reinterpret_cast<long long *>(codes);
-    uint64_t *d_fr = first_row;
-    if (host) {
-      unsigned char *p = base + tb + 64;
-      HIP_TRY(e, hipMemcpyAsync(p, col->offsets, (n + 1) * (off64 ? 8 : 4), hipMemcpyHostToDevice, s)); d_off = p; p += off_bytes;
-      if (col->data_bytes) HIP_TRY(e, hipMemcpyAsync(p, col->data, col->data_bytes, hipMemcpyHostToDevice, s));
-      d_data = p; p += data_bytes;
-      if (col->validity) { HIP_TRY(e, hipMemcpyAsync(p, col->validity, (col->validity_offset + n + 7) / 8, hipMemcpyHostToDevice, s)); d_valid = p; p += val_bytes; }
-      d_codes = reinterpret_cast<long long *>(p); p += code_bytes;
-      d_fr = reinterpret_cast<uint64_t *>(p);
-    }
-    uint32_t *flags_dev = nullptr;
-    launch_encode_strings(s, d_off, off64, d_data, col->data_bytes, d_valid, col->validity_offset, n, slots, base, d_codes, d_fr, first_row_cap, nv_dev, &flags_dev);
-    unsigned long long nv = 0;
-    uint32_t flags = 0;
-    HIP_TRY(e, hipMemcpyAsync(&nv, nv_dev, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(e, hipMemcpyAsync(&flags, flags_dev, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(e, hipStreamSynchronize(s));
-    HIP_TRY(e, hipGetLastError());
-    if (flags & 2u) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_encode_strings: offsets decrease or point beyond data_bytes");
-    if (flags & 1u) {      // more distinct values than this table takes: once more with the next size (2^20 -> 2^24 -> 2 n slots)
-      const uint64_t next = factorize_next_slots(n, slots);
-      if (next == slots) return fail(e, TAD_ERR_HIP, "tad_encode_strings: the full-size table filled up");
-      slots = next;
-      continue;
-    }
-    if (host) {
-      HIP_TRY(e, hipMemcpyAsync(codes, d_codes, n * 8, hipMemcpyDeviceToHost, s));
-      const uint64_t m = nv < first_row_cap ? nv : first_row_cap;
-      if (m) HIP_TRY(e, hipMemcpyAsync(first_row, d_fr, m * 8, hipMemcpyDeviceToHost, s));
-      HIP_TRY(e, hipStreamSynchronize(s));
-    }
-    *num_values = nv;
-    return TAD_OK;
-  }
-}
-
-void tad_points_free(tad_engine *e, tad_points *p) {
-  if (!p) return;
-  PointsPriv *pp = reinterpret_cast<PointsPriv *>(p);
-  if (pp->block) {
-    if (p->memory == TAD_MEM_DEVICE && e) release_block(e, pp->block, pp->block_cap);
-    else if (p->memory == TAD_MEM_DEVICE) hipFree(pp->block);
-    else free(pp->block);
-  }
-  delete pp;
-}
-
-// ------------------------------------------------------------------------------------------------
-// per-series entry points (a one-key table; same kernels)
-// ------------------------------------------------------------------------------------------------
-}  // extern "C"
-
-namespace {
-
-// Fill the engine's grid with one series: K = 1, T = n, every point present.
-int series_grid(JobCtx *e, const uint64_t *x, uint64_t n, Grid *g) {
-  int rc;
-  if ((rc = ensure(e, e->grid_val, (n ? n : 1) * 8)) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->grid_flag, n ? n : 1)) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->counters, kTailBytes)) != TAD_OK) return rc;
-  if (n) {
-    HIP_TRY(e, hipMemcpyAsync(e->grid_val.p, x, n * 8, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->grid_flag.p, FLAG_PRESENT, n, e->stream));
-  }
-  HIP_TRY(e, hipMemsetAsync(e->counters.p, 0, sizeof(DevCounters), e->stream));
-  g->val = static_cast<unsigned long long *>(e->grid_val.p);
-  g->flag = static_cast<uint8_t *>(e->grid_flag.p);
-  g->K = 1;
-  g->T = n;
-  g->times = nullptr;
-  return TAD_OK;
-}
-
-// Emit every point of a one-key grid with given sigma; copies verdicts / calc to the host.
-int series_emit_all(JobCtx *e, Grid g, const JobParams &jp, bool has_sigma, double sigma, double *calc_out, uint8_t *verdict_out) {
-  const uint64_t n = g.T;
-  int rc;
-  if ((rc = ensure(e, e->sigma, sizeof(double))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->n_pts, sizeof(uint32_t))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->off, 2 * sizeof(unsigned long long))) != TAD_OK) return rc;
-  const uint32_t npts = has_sigma ? (uint32_t)(n < 2 ? 2 : n) : (uint32_t)(n < 1 ? 0 : 1);  // n_pts >= 2 <=> sigma is defined
-  const unsigned long long off[2] = {0ull, (unsigned long long)n};
-  HIP_TRY(e, hipMemcpyAsync(e->sigma.p, &sigma, sizeof sigma, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->n_pts.p, &npts, sizeof npts, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->off.p, off, sizeof off, hipMemcpyHostToDevice, e->stream));
-  ResultBlock blk;
-  if ((rc = alloc_device_block(e, result_bytes(n, true), &blk)) != TAD_OK) return rc;
-  OutRows o;
-  carve(blk.base, n, true, &o);
-  JobParams all = jp;
-  all.all_points = true;
-  emit_rows(e, g, make_lattice(0, 1, n), all, o);
-  hipError_t r = hipSuccess;
-  if (calc_out && n) r = hipMemcpyAsync(calc_out, o.algo_calc, n * 8, hipMemcpyDeviceToHost, e->stream);
-  if (r == hipSuccess && verdict_out && n) r = hipMemcpyAsync(verdict_out, o.anomaly, n, hipMemcpyDeviceToHost, e->stream);
-  if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
-  release_block(e, blk.base, blk.cap);
-  if (r != hipSuccess) return fail(e, TAD_ERR_HIP, "series copy failed: %s", hipGetErrorString(r));
-  return TAD_OK;
-}
-
-JobParams series_params(tad_algo algo, double alpha, double eps, int min_samples, int maxiter) {
-  JobParams jp;
-  jp.algo = algo;
-  jp.alpha = alpha == 0.0 ? 0.5 : alpha;
-  jp.eps = eps == 0.0 ? 250000000.0 : eps;
-  jp.min_samples = min_samples == 0 ? 4 : min_samples;
-  jp.maxiter = maxiter == 0 ? 50 : maxiter;
-  jp.drop_nsigma = 3.0;
-  jp.drop_min_samples = 3;
-  jp.all_points = true;
-  return jp;
-}
-
-}  // namespace
-
-extern "C" {
-
-int tad_series_ewma(tad_engine *eng, const uint64_t *x, uint64_t n, double alpha, double *out) {
-  if (!eng || (n && (!x || !out))) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_ewma: bad arguments");
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_ewma: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  Grid g;
-  int rc = series_grid(e, x, n, &g);
-  if (rc != TAD_OK || n == 0) return rc;
-  return series_emit_all(e, g, series_params(TAD_ALGO_EWMA, alpha, 0, 0, 0), false, 0.0, out, nullptr);
-}
-
-int tad_series_ewma_anomaly(tad_engine *eng, const uint64_t *x, uint64_t n, double alpha, int has_stddev, double stddev,
-                            uint8_t *verdict) {
-  if (!eng || (n && (!x || !verdict))) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_ewma_anomaly: bad arguments");
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_ewma_anomaly: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  Grid g;
-  int rc = series_grid(e, x, n, &g);
-  if (rc != TAD_OK || n == 0) return rc;
-  return series_emit_all(e, g, series_params(TAD_ALGO_EWMA, alpha, 0, 0, 0), has_stddev != 0, stddev, nullptr, verdict);
-}
-
-int tad_series_stddev(tad_engine *eng, const uint64_t *x, uint64_t n, int *has_stddev, double *stddev) {
-  if (!eng || !has_stddev || !stddev || (n && !x)) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_stddev: bad arguments");
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_stddev: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  *has_stddev = 0;
-  *stddev = 0.0;
-  Grid g;
-  int rc = series_grid(e, x, n, &g);
-  if (rc != TAD_OK || n == 0) return rc;
-  if ((rc = ensure(e, e->sigma, sizeof(double))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->n_pts, sizeof(uint32_t))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->n_anom, sizeof(uint32_t))) != TAD_OK) return rc;
-  if ((rc = ensure_rcp_table(e, g.T)) != TAD_OK) return rc;
-  launch_key_sigma(e->stream, g, 0.5, false, static_cast<const double *>(e->rcp_table.p), static_cast<double *>(e->sigma.p), static_cast<uint32_t *>(e->n_pts.p),
-                   static_cast<uint32_t *>(e->n_anom.p), static_cast<DevCounters *>(e->counters.p), nullptr, nullptr);
-  double sg = 0.0;
-  HIP_TRY(e, hipMemcpyAsync(&sg, e->sigma.p, sizeof sg, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  *has_stddev = n >= 2;
-  *stddev = sg;
-  return TAD_OK;
-}
-
-int tad_series_dbscan_anomaly(tad_engine *eng, const uint64_t *x, uint64_t n, double eps, int min_samples, uint8_t *verdict) {
-  if (!eng || (n && (!x || !verdict)) || eps < 0.0 || min_samples < 0)
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_dbscan_anomaly: bad arguments");
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_dbscan_anomaly: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  Grid g;
-  int rc = series_grid(e, x, n, &g);
-  if (rc != TAD_OK || n == 0) return rc;
-  JobParams jp = series_params(TAD_ALGO_DBSCAN, 0, eps, min_samples, 0);
-  if ((rc = ensure(e, e->aux, dbscan_scratch_bytes(g))) != TAD_OK) return rc;
-  if (launch_dbscan(e->stream, g, jp.eps, jp.min_samples, e->aux.p) != 0) return fail(e, TAD_ERR_HIP, "DBSCAN launch failed");
-  return series_emit_all(e, g, jp, false, 0.0, nullptr, verdict);
-}
-
-int tad_series_drop(tad_engine *eng, const uint64_t *x, uint64_t n, double nsigma, int min_samples, int *has_result,
-                    double *mean, double *stddev, uint8_t *verdict) {
-  if (!eng || !has_result || !mean || !stddev || (n && (!x || !verdict)) || nsigma < 0.0 || min_samples < 0)
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_drop: bad arguments");
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_drop: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  *has_result = 0;
-  *mean = 0.0;
-  *stddev = 0.0;
-  const int ms = min_samples == 0 ? 3 : min_samples;
-  if (n == 0 || n < (uint64_t)ms || n < 2) return TAD_OK;   // drop_detection_udf.py:44-45
-  Grid g;
-  int rc = series_grid(e, x, n, &g);
-  if (rc != TAD_OK) return rc;
-  if ((rc = ensure_key_buffers(e, 1)) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->calc, n * sizeof(double))) != TAD_OK) return rc;
-  launch_drop(e->stream, g, nsigma == 0.0 ? 3.0 : nsigma, ms, static_cast<double *>(e->calc.p), static_cast<double *>(e->sigma.p),
-              static_cast<uint32_t *>(e->n_pts.p), static_cast<double *>(e->key_mean.p), static_cast<double *>(e->key_m2.p),
-              static_cast<DevCounters *>(e->counters.p));
-  std::vector<uint8_t> flags(n);
-  HIP_TRY(e, hipMemcpyAsync(mean, e->key_mean.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(stddev, e->sigma.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(flags.data(), g.flag, n, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  HIP_TRY(e, hipGetLastError());
-  *has_result = 1;
-  for (uint64_t i = 0; i < n; ++i) verdict[i] = (flags[i] & FLAG_ANOMALY) ? 1 : 0;
-  return TAD_OK;
-}
-
-}  // extern "C"
-
-namespace {
-
-// calculate_arima / calculate_arima_anomaly on one series, on the context the caller holds.  pred_out (n doubles) may be NULL.
-int series_arima_locked(JobCtx *e, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
-                        uint8_t *verdict, uint64_t *n_verdict, double *pred_out) {
-  HIP_TRY(e, hipSetDevice(e->device));
-  *n_verdict = 1;
-  verdict[0] = 0;
-  if (n <= 3) return TAD_OK;  // anomaly_detection.py:232-234 -> None -> [False] (:284-287)
-  Grid g;
-  int rc = series_grid(e, x, n, &g);
-  if (rc != TAD_OK) return rc;
-  JobParams jp = series_params(TAD_ALGO_ARIMA, 0, 0, 0, maxiter);
-  if ((rc = ensure(e, e->sigma, sizeof(double))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->n_pts, sizeof(uint32_t))) != TAD_OK) return rc;
-  if ((rc = ensure(e, e->calc, n * sizeof(double))) != TAD_OK) return rc;
-  // sigma as given by the caller; n_pts carries the real length for ARIMA
-  const double sg = has_stddev ? stddev : __builtin_inf();  // no sigma -> no point can exceed it
-  const uint32_t npts = (uint32_t)n;
-  HIP_TRY(e, hipMemcpyAsync(e->sigma.p, &sg, sizeof sg, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->n_pts.p, &npts, sizeof npts, hipMemcpyHostToDevice, e->stream));
-  const size_t wsb = arima_workspace_bytes(g);
-  if ((rc = ensure(e, e->aux, wsb)) != TAD_OK) return rc;
-  DevCounters *ctr = static_cast<DevCounters *>(e->counters.p);
-  if (launch_arima(e->stream, g, static_cast<const double *>(e->sigma.p), static_cast<const uint32_t *>(e->n_pts.p), jp.maxiter,
-                   static_cast<double *>(e->calc.p), ctr, e->aux.p, wsb) != 0)
-    return fail(e, TAD_ERR_HIP, "ARIMA launch failed");
-  HIP_TRY(e, hipMemcpyAsync(e->ctr_host, ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
-  std::vector<uint8_t> flags(n);
-  HIP_TRY(e, hipMemcpyAsync(flags.data(), g.flag, n, hipMemcpyDeviceToHost, e->stream));
-  if (pred_out) HIP_TRY(e, hipMemcpyAsync(pred_out, e->calc.p, n * 8, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  HIP_TRY(e, hipGetLastError());
-  if (e->ctr_host->keys_no_result) return TAD_OK;  // calculate_arima returned None
-  *n_verdict = n;
-  for (uint64_t i = 0; i < n; ++i) verdict[i] = (flags[i] & FLAG_ANOMALY) ? 1 : 0;
-  return TAD_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int tad_series_arima(tad_engine *eng, const uint64_t *x, uint64_t n, int maxiter, int *has_result, double *out) {
-  if (!eng || !has_result || (n && (!x || !out)) || maxiter < 0) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima: bad arguments");
-  uint64_t nv = 0;
-  std::vector<uint8_t> verdict(n ? n : 1);
-  std::vector<double> pred(n ? n : 1);
-  // ONE critical section: the predictions are read from the engine's calc buffer before any other thread can run
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_arima: no job context available");
-  const int rc = series_arima_locked(e, x, n, maxiter, 0, 0.0, verdict.data(), &nv, pred.data());
-  if (rc != TAD_OK) return rc;
-  *has_result = (nv == n && n > 3) ? 1 : 0;
-  if (*has_result) memcpy(out, pred.data(), n * 8);
-  return TAD_OK;
-}
-
-int tad_series_arima_anomaly(tad_engine *eng, const uint64_t *x, uint64_t n, int maxiter, int has_stddev, double stddev,
-                             uint8_t *verdict, uint64_t *n_verdict) {
-  if (!eng || !n_verdict || !verdict || (n && !x) || maxiter < 0)
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_series_arima_anomaly: bad arguments");
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_series_arima_anomaly: no job context available");
-  return series_arima_locked(e, x, n, maxiter, has_stddev, stddev, verdict, n_verdict, nullptr);
-}
-
-int tad_synth_generate(tad_engine *eng, uint64_t seed, uint64_t first_row, uint64_t n_rows, uint64_t num_keys,
-                       uint64_t n_buckets, uint64_t *key_id, int64_t *flow_end_s, uint64_t *value) {
-  if (!eng || num_keys == 0 || n_buckets == 0 || (n_rows && (!key_id || !flow_end_s || !value)))
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_synth_generate: bad arguments");
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_synth_generate: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  launch_synth(e->stream, seed, first_row, n_rows, num_keys, n_buckets, key_id, flow_end_s, value);
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  HIP_TRY(e, hipGetLastError());
-  return TAD_OK;
-}
-
-// ---- columnar ingest: Arrow buffers in host memory -> 8-byte device columns ----
-int tad_widen_column(tad_engine *eng, const void *src, int32_t src_bits, int32_t src_signed, tad_mem src_memory, uint64_t n, const int64_t *table,
-                     uint64_t table_len, int64_t *dst) {
-  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_widen_column: engine is NULL");
-  if ((src_bits != 8 && src_bits != 16 && src_bits != 32 && src_bits != 64) || (n && (!src || !dst)) || (table_len && !table))
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_widen_column: bad arguments (src of 8 / 16 / 32 / 64 bits, src / dst buffers, table)");
-  if (n == 0) return TAD_OK;
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_widen_column: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  hipStream_t s = e->stream;
-  const size_t bytes = (size_t)n * (size_t)(src_bits / 8);
-  if (src_memory == TAD_MEM_HOST && src_bits == 64 && table == nullptr) {      // nothing to convert: the copy is the column
-    HIP_TRY(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(e, hipStreamSynchronize(s));
-    return TAD_OK;
-  }
-  int rc;
-  if ((rc = ensure(e, e->counters, kTailBytes)) != TAD_OK) return rc;
-  unsigned int *err = reinterpret_cast<unsigned int *>(e->counters.p);
-  HIP_TRY(e, hipMemsetAsync(err, 0, 4, s));
-  const void *d_src = src;
-  if (src_memory == TAD_MEM_HOST) {
-    if ((rc = ensure(e, e->in_key, bytes)) != TAD_OK) return rc;
-    HIP_TRY(e, hipMemcpyAsync(e->in_key.p, src, bytes, hipMemcpyHostToDevice, s));
-    d_src = e->in_key.p;
-  }
-  launch_widen(s, d_src, src_bits, src_signed != 0, n, reinterpret_cast<const long long *>(table), table ? table_len : 0, reinterpret_cast<long long *>(dst), err);
-  unsigned int herr = 0;
-  HIP_TRY(e, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(e, hipStreamSynchronize(s));
-  HIP_TRY(e, hipGetLastError());
-  if (herr) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_widen_column: an index lies outside the table of %llu entries", (unsigned long long)table_len);
-  return TAD_OK;
-}
-
-int tad_mask_rows(tad_engine *eng, uint64_t n, int32_t n_terms, const int64_t *const *codes, const uint8_t *const *masks, const uint64_t *mask_len,
-                  int32_t combine, uint8_t *keep) {
-  if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_mask_rows: engine is NULL");
-  if (n_terms < 0 || n_terms > kMaskMaxTerms || (n_terms && (!codes || !masks || !mask_len)) || (n && !keep))
-    return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_mask_rows: bad arguments (0..%d terms, keep buffer)", kMaskMaxTerms);
-  for (int t = 0; t < n_terms; ++t)
-    if (n && (!codes[t] || !masks[t])) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_mask_rows: term %d is NULL", t);
-  if (n == 0) return TAD_OK;
-  Lease lease(eng);
-  JobCtx *e = lease.c;
-  if (!e) return fail(eng, TAD_ERR_OUT_OF_MEMORY, "tad_mask_rows: no job context available");
-  HIP_TRY(e, hipSetDevice(e->device));
-  hipStream_t s = e->stream;
-  int rc;
-  if ((rc = ensure(e, e->counters, kTailBytes)) != TAD_OK) return rc;
-  unsigned int *err = reinterpret_cast<unsigned int *>(e->counters.p);
-  HIP_TRY(e, hipMemsetAsync(err, 0, 4, s));
-  launch_mask_rows(s, n, n_terms, reinterpret_cast<const long long *const *>(codes), masks, mask_len, combine != 0, keep, err);
-  unsigned int herr = 0;
-  HIP_TRY(e, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(e, hipStreamSynchronize(s));
-  HIP_TRY(e, hipGetLastError());
-  if (herr) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_mask_rows: a code lies outside its mask");
-  return TAD_OK;
-}
-
-int tad_host_alloc(tad_engine *e, uint64_t bytes, void **ptr) {
-  if (!e || !ptr) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_host_alloc: bad arguments");
-  HIP_TRY(e, hipSetDevice(e->device));
-  hipError_t r = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
-  if (r != hipSuccess) { (void)hipGetLastError(); return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(r)); }
-  return TAD_OK;
-}
-
-int tad_host_free(tad_engine *e, void *ptr) {
-  if (!e) return TAD_ERR_INVALID_ARGUMENT;
-  HIP_TRY(e, hipSetDevice(e->device));
-  if (ptr) HIP_TRY(e, hipHostFree(ptr));
-  return TAD_OK;
-}
-
-int tad_device_alloc(tad_engine *e, uint64_t bytes, void **ptr) {
-  if (!e || !ptr) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_device_alloc: bad arguments");
-  HIP_TRY(e, hipSetDevice(e->device));
-  hipError_t r = hipMalloc(ptr, bytes ? bytes : 1);
-  if (r != hipSuccess) return fail(e, TAD_ERR_OUT_OF_MEMORY, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(r));
-  return TAD_OK;
-}
-
-int tad_device_free(tad_engine *e, void *ptr) {
-  if (!e) return TAD_ERR_INVALID_ARGUMENT;
-  HIP_TRY(e, hipSetDevice(e->device));
-  if (ptr) HIP_TRY(e, hipFree(ptr));     // (every entry point synchronises its stream before it returns: nothing of the engine's is pending on caller memory)
-  return TAD_OK;
-}
-
-int tad_copy_to_device(tad_engine *e, void *dst, const void *src, uint64_t bytes) {
-  if (!e || (bytes && (!dst || !src))) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_copy_to_device: bad arguments");
-  HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
-  return TAD_OK;
-}
-
-int tad_copy_to_host(tad_engine *e, void *dst, const void *src, uint64_t bytes) {
-  if (!e || (bytes && (!dst || !src))) return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_copy_to_host: bad arguments");
-  HIP_TRY(e, hipSetDevice(e->device));
-  HIP_TRY(e, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
-  return TAD_OK;
-}
 
 }  // extern "C"
