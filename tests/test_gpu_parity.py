@@ -503,6 +503,22 @@ def test_job_contexts_serial_caller_stays_on_context_zero_and_pool_is_bounded(en
         assert ctx == [0] * 12
     finally:
         one.close()
+    two = TadEngine(device=0, max_jobs_in_flight=2)           # eight threads, two contexts: nobody ever sees a third
+    try:
+        ctx, bar = [], threading.Barrier(8)
+
+        def burst():
+            bar.wait()
+            for _ in range(3):
+                ctx.append(two.run("EWMA", k, t, v, 40, agg_flow="svc").stats["job_context"])
+        ths = [threading.Thread(target=burst) for _ in range(8)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert len(ctx) == 24 and set(ctx) <= {0, 1}
+    finally:
+        two.close()
     with pytest.raises(Exception):
         TadEngine(device=0, max_jobs_in_flight=17)
     # a long job (ARIMA, a few thousand fits) watched from the main thread

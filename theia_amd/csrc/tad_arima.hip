@@ -1099,7 +1099,7 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     // Cooperative yield.  The fit is ~0.25 s of two-wavefront-per-SIMD work whose wavefronts live for tens of ms; a workgroup of another
     // job's pass B needs a WHOLE CU (1024 threads, 156 KB of LDS) and would wait until this grid is exhausted whatever the stream priorities
     // (measured: 212 ms, profiles/r6_a2_*).  `pause` is a word in DEVICE memory the engine raises while such a job is in flight (a 4-byte
-    // fill on its signal stream).  It is read at the top of every cycle (an agent-scope load: the XCDs' L2s are not coherent with each other,
+    // fill on its signal stream).  It is read at the top of every fourth cycle (an agent-scope load: the XCDs' L2s are not coherent with each other,
     // the load goes to the memory side; a page-locked HOST word polled at this rate doubled the kernel's time) and acted on at the end of the cycle, where a fit's whole state is (key, x, fc, the history's shape) in registers, 29 parked doubles in
     // LDS and the history in this wavefront's own global block: the lanes write the first two to `save`, the wavefront retires — within
     // one likelihood pass (tens of us) of the word being raised, not after its longest fit (up to ~10 ms) — and the host relaunches the
@@ -1107,8 +1107,8 @@ __device__ __forceinline__ void arima_fit_body(Grid g, ArimaWs ws, const double 
     // every bit of every result, is what an undisturbed run gives.  `grace`: cycles during which the word is ignored (a relaunch that was
     // forced after the host's 2 ms wait must make progress although short jobs keep arriving).
     int paused_now = 0;
-#if !defined(TAD_ARIMA_POLL_MASK)       // measurement knob (tools/build_variants.py): poll every (mask + 1)-th cycle; 0xFFFFFFFF = never
-#define TAD_ARIMA_POLL_MASK 0u
+#if !defined(TAD_ARIMA_POLL_MASK)       // poll every (mask + 1)-th cycle (measurement builds, tools/build_variants.py: 0 = every cycle, 0xFFFFFFFF = never).
+#define TAD_ARIMA_POLL_MASK 3u          // C3, same process: every cycle 276.4 ms, every 4th 275.0, every 16th 275.3, never 275.2 (profiles/r6_p1_ab_c3_poll.log)
 #endif
     if (pause != nullptr && (iter & TAD_ARIMA_POLL_MASK) == 0u) paused_now = __hip_atomic_load(pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     TAD_PROF_T(t_a);

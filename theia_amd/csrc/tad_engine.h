@@ -50,6 +50,7 @@ struct tad_engine {
   std::condition_variable cv;  // a context became idle
   tad_plan plan{};             // plan overrides (tests / A-B measurements); all zero = the engine decides
   std::vector<JobCtx *> ctxs;
+  int creating = 0;            // contexts being created outside the lock (counted against max_ctx)
   int32_t last_done = 0, last_total = 0;   // progress of the job that finished last (tad_progress with nothing in flight)
   std::mutex err_mu;           // protects err
   std::string err;
@@ -209,11 +210,13 @@ struct Lease {
       for (JobCtx *x : eng->ctxs)
         if (!x->busy) { c = x; break; }
       if (c) break;
-      if ((int)eng->ctxs.size() < eng->max_ctx) {
+      if ((int)eng->ctxs.size() + eng->creating < eng->max_ctx) {
+        ++eng->creating;
         lk.unlock();      // (stream / pinned-memory creation outside the lock)
         hipSetDevice(eng->device);
         JobCtx *n = ctx_create(eng, false);
         lk.lock();
+        --eng->creating;
         if (n) { n->index = (int)eng->ctxs.size(); eng->ctxs.push_back(n); c = n; break; }
         if (eng->ctxs.empty()) return;   // cannot happen (context 0 is made by tad_engine_create); c stays NULL
       }
