@@ -436,6 +436,67 @@ func (e *Engine) EncodeStrings(offsets []int32, data []byte, validity []byte) (c
 
 // AllocDevice / FreeDevice / CopyToDevice / CopyToHost: device buffers for hosts without a HIP binding of their own (what ShardRows and a
 // device-resident Run take).
+// ---- columnar ingest (tad.h ABI 12): Arrow buffers -> the engine's 8-byte device columns ----
+
+// AllocHost returns page-locked host memory (tad_host_alloc): a reader receives ClickHouse's ArrowStream body straight into it and copies from
+// it to the device run at PCIe rate.  Keep and reuse the buffers between jobs: pinning is slow.
+func (e *Engine) AllocHost(bytes uint64) (unsafe.Pointer, error) {
+	var p unsafe.Pointer
+	if rc := C.tad_host_alloc(e.h, C.uint64_t(bytes), &p); rc != C.TAD_OK {
+		return nil, fmt.Errorf("tad_host_alloc: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return p, nil
+}
+
+func (e *Engine) FreeHost(p unsafe.Pointer) { C.tad_host_free(e.h, p) }
+
+// WidenColumn writes dst[i] = table[src[i]] (table != nil: the dictionary indices of one Arrow record batch through the batch's remap into the
+// column's job-wide dictionary; or a gather of a device column at Factorize's first rows) or src[i] widened (UInt32 DateTime, UInt16 ports)
+// for i < n.  src: n integers of srcBits (8 / 16 / 32 / 64) bits in C / page-locked host memory (srcOnDevice false) or device memory; table and
+// dst: device memory (int64).  Pointers are plain C pointers: nothing of Go's heap crosses the boundary.
+func (e *Engine) WidenColumn(src unsafe.Pointer, srcBits int, srcSigned, srcOnDevice bool, n uint64, table unsafe.Pointer, tableLen uint64, dst unsafe.Pointer) error {
+	signed, mem := C.int32_t(0), C.tad_mem(C.TAD_MEM_HOST)
+	if srcSigned {
+		signed = 1
+	}
+	if srcOnDevice {
+		mem = C.TAD_MEM_DEVICE
+	}
+	if rc := C.tad_widen_column(e.h, src, C.int32_t(srcBits), signed, mem, C.uint64_t(n), (*C.int64_t)(table), C.uint64_t(tableLen), (*C.int64_t)(dst)); rc != C.TAD_OK {
+		return fmt.Errorf("tad_widen_column: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return nil
+}
+
+// MaskRows writes keep[i] = AND over t of masks[t][codes[t][i]] (ANDed into the previous keep[i] when combine): the SQL's string predicates
+// (anomaly_detection.py:507-614), evaluated by the host on the DISTINCT values of each column, applied to the rows on the GPU.  codes[t]
+// (int64[n]), masks[t] (uint8[maskLen[t]]) and keep (uint8[n]) are device pointers; at most 8 terms.
+func (e *Engine) MaskRows(n uint64, codes, masks []unsafe.Pointer, maskLen []uint64, combine bool, keep unsafe.Pointer) error {
+	k := len(codes)
+	if k > 8 || len(masks) != k || len(maskLen) != k {
+		return errors.New("tadengine: MaskRows takes at most 8 terms, one mask and one length per code column")
+	}
+	// the two pointer arrays live in C memory for the call (cgo may not pass Go memory that holds pointers)
+	carr := (*[8]unsafe.Pointer)(C.malloc(C.size_t(8 * unsafe.Sizeof(unsafe.Pointer(nil)))))
+	marr := (*[8]unsafe.Pointer)(C.malloc(C.size_t(8 * unsafe.Sizeof(unsafe.Pointer(nil)))))
+	larr := (*[8]C.uint64_t)(C.malloc(C.size_t(8 * 8)))
+	defer C.free(unsafe.Pointer(carr))
+	defer C.free(unsafe.Pointer(marr))
+	defer C.free(unsafe.Pointer(larr))
+	for t := 0; t < k; t++ {
+		carr[t], marr[t], larr[t] = codes[t], masks[t], C.uint64_t(maskLen[t])
+	}
+	comb := C.int32_t(0)
+	if combine {
+		comb = 1
+	}
+	if rc := C.tad_mask_rows(e.h, C.uint64_t(n), C.int32_t(k), (**C.int64_t)(unsafe.Pointer(&carr[0])), (**C.uint8_t)(unsafe.Pointer(&marr[0])),
+		&larr[0], comb, (*C.uint8_t)(keep)); rc != C.TAD_OK {
+		return fmt.Errorf("tad_mask_rows: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+	}
+	return nil
+}
+
 func (e *Engine) AllocDevice(bytes uint64) (unsafe.Pointer, error) {
 	var p unsafe.Pointer
 	if rc := C.tad_device_alloc(e.h, C.uint64_t(bytes), &p); rc != C.TAD_OK {
