@@ -275,7 +275,7 @@ class PreparedColumns:
         self.flow_end_s = flow_end_s      # i64[N]
         self.flow_start_s = flow_start_s  # i64[N] or None (pod mode: the SQL has no time filter)
         self.value = value                # u64[N] throughput
-        self.key_table = key_table        # dict column name -> array[num_keys]
+        self.key_table = key_table        # dict column name -> array[num_keys] (device ingest: DeviceKeyColumn, decoded on demand)
         self.start_time = start_time      # epoch seconds handed to the engine (0 = unset)
         self.end_time = end_time
 
@@ -416,14 +416,57 @@ def prepare_columns(flows, start_time="", end_time="", ns_ignore_list=(), agg_fl
     return PreparedColumns(mode, key_id, None, flow_end, flow_start, value, table, _epoch(start_time), _epoch(end_time))
 
 
+class DeviceKeyColumn:
+    """One column of the key table of a device-ingested job, decoded ON DEMAND: `col[kid]` gathers the column's values at the rows where the
+    requested keys first appear (tad_widen_column as a gather) and looks the strings up in the host dictionary.  A table in mode None has a
+    key per connection — tens of millions — of which only the keys with anomalous points are ever shown: reading the whole key table back
+    was 0.84 s of a 1.0 s ingest at 5e7 keys (profiles/r6_i2_ingest_e2e_default_c8.log).  `sides`: [(column, constant)] per side of the
+    key tuple (pod mode: inbound, outbound); a column is a DeviceDictColumn, a DeviceArray of integers, or None when `constant` is the value
+    (pod mode's `direction`).  first: DeviceArray u64[num_keys], the virtual row (side * n + row) where every key first appears."""
+
+    def __init__(self, engine, n_rows, first, sides):
+        self.engine, self.n_rows, self.first, self.sides = engine, int(n_rows), first, sides
+
+    def __len__(self):
+        return self.first.n
+
+    def __getitem__(self, kid):
+        from .engine import DeviceArray
+        kid = np.ascontiguousarray(np.asarray(kid).astype(np.uint64))
+        if kid.size == 0:
+            return np.zeros(0, dtype=str)
+        uniq, inv = np.unique(kid, return_inverse=True)      # every key once (a key has many result rows)
+        dk = DeviceArray.from_host(self.engine, uniq)
+        vrow = self.engine.gather(self.first, dk)
+        dk.free()
+        side = (vrow >= np.uint64(self.n_rows)).astype(np.int64) if len(self.sides) > 1 else np.zeros(uniq.size, dtype=np.int64)
+        rows = DeviceArray.from_host(self.engine, (vrow - side.astype(np.uint64) * np.uint64(self.n_rows)).astype(np.uint64))
+        out = None
+        for sidx, (col, const) in enumerate(self.sides):
+            if col is None:
+                vals = np.full(uniq.size, const)
+            elif hasattr(col, "values"):
+                codes = self.engine.gather(col.codes, rows).astype(np.int64)
+                vals = col.values[codes] if col.values.size else np.zeros(codes.size, dtype=str)
+            else:
+                vals = self.engine.gather(col, rows).astype(np.int64)
+            out = vals if out is None else np.where(side == sidx, vals, out)
+        rows.free()
+        return np.asarray(out)[inv]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self[np.arange(len(self), dtype=np.uint64)]
+        return a if dtype is None else a.astype(dtype)
+
+
 def prepare_columns_device(flows, start_time="", end_time="", ns_ignore_list=(), agg_flow="", pod_label="", external_ip="",
                            svc_port_name="", pod_name="", pod_namespace="", engine=None):
     """prepare_columns for a table that is already in HBM (theia_amd.clickhouse.fetch_flows_device: 8-byte integer columns as DeviceArray,
     string columns as DeviceDictColumn = device codes + host dictionary).  The same predicates and GROUP BY keys (ref:507-614): every string
     predicate is evaluated on the column's DISTINCT values here and applied to the rows on the GPU (tad_mask_rows); the key tuples are
-    factorised on the GPU (tad_factorize) and the key table is read back at the rows where the keys first appear (tad_widen_column as a
-    gather).  No per-row work on the host; nothing but the key table and the masks over distinct values crosses PCIe."""
-    from .engine import DeviceArray
+    factorised on the GPU (tad_factorize); the key table stays on the device and is decoded on demand — for the keys that have result rows —
+    at the rows where the keys first appear (DeviceKeyColumn).  No per-row work on the host; nothing but the masks over distinct values and
+    the result's keys crosses PCIe."""
     eng = engine or get_engine()
     flow_end, value = flows["flowEndSeconds"], flows["throughput"]
     n = flow_end.n
@@ -433,17 +476,6 @@ def prepare_columns_device(flows, start_time="", end_time="", ns_ignore_list=(),
         for name in ("sourcePodNamespace", "destinationPodNamespace"):
             col = flows[name]
             common.append((col.codes, ~np.isin(col.values, ign)))
-
-    def key_table_of(first_rows, cols):
-        """distinct keys' column values: cols = list of DeviceDictColumn | DeviceArray, first_rows = DeviceArray u64 of row numbers"""
-        out = []
-        for c in cols:
-            if hasattr(c, "values"):
-                codes = eng.gather(c.codes, first_rows).astype(np.int64)
-                out.append(c.values[codes] if c.values.size else np.zeros(codes.size, dtype=str))
-            else:
-                out.append(eng.gather(c, first_rows).astype(np.int64))
-        return out
 
     if agg_flow == "pod":
         by_name = bool(pod_name) and not pod_label
@@ -466,17 +498,13 @@ def prepare_columns_device(flows, start_time="", end_time="", ns_ignore_list=(),
         if n == 0:
             return PreparedColumns(mode, flow_end, flow_end, flow_end, None, value, {k: np.zeros(0, dtype=str) for k in KEY_COLUMNS[mode]}, 0, 0)
         key_id, key_id2, first = eng.factorize([sides[0][1].codes, sides[0][2].codes], sides[0][0], [sides[1][1].codes, sides[1][2].codes], sides[1][0])
-        first_h = first.to_host()
-        side_b = first_h >= np.uint64(n)
-        rows = DeviceArray.from_host(eng, (first_h - np.where(side_b, np.uint64(n), np.uint64(0))).astype(np.uint64))
-        rows.n = first_h.size
-        ta, tb = key_table_of(rows, [sides[0][1], sides[0][2]]), key_table_of(rows, [sides[1][1], sides[1][2]])
-        uniq = [np.where(side_b, b, a).astype(str) for a, b in zip(ta, tb)]
-        uniq.append(np.where(side_b, sides[1][3], sides[0][3]))
-        for k in (sides[0][0], sides[1][0], rows, first):
+        table = {KEY_COLUMNS[mode][0]: DeviceKeyColumn(eng, n, first, [(sides[0][1], None), (sides[1][1], None)]),
+                 KEY_COLUMNS[mode][1]: DeviceKeyColumn(eng, n, first, [(sides[0][2], None), (sides[1][2], None)]),
+                 KEY_COLUMNS[mode][2]: DeviceKeyColumn(eng, n, first, [(None, sides[0][3]), (None, sides[1][3])])}
+        for k in (sides[0][0], sides[1][0]):
             k.free()
         # the pod SQL carries no flowStartSeconds / flowEndSeconds predicate (ref:556-565)
-        return PreparedColumns(mode, key_id, key_id2, flow_end, None, value, dict(zip(KEY_COLUMNS[mode], uniq)), 0, 0)
+        return PreparedColumns(mode, key_id, key_id2, flow_end, None, value, table, 0, 0)
 
     terms = list(common)
     if agg_flow == "external":
@@ -503,11 +531,10 @@ def prepare_columns_device(flows, start_time="", end_time="", ns_ignore_list=(),
                                _epoch(start_time), _epoch(end_time))
     keep = eng.mask_rows(n, terms) if terms else None
     key_id, _, first = eng.factorize([c.codes if hasattr(c, "values") else c for c in cols], keep)
-    uniq = key_table_of(first, cols)
-    for k in (keep, first):
-        if k is not None:
-            k.free()
-    return PreparedColumns(mode, key_id, None, flow_end, flow_start, value, dict(zip(KEY_COLUMNS[mode], uniq)), _epoch(start_time), _epoch(end_time))
+    table = {name: DeviceKeyColumn(eng, n, first, [(c, None)]) for name, c in zip(KEY_COLUMNS[mode], cols)}
+    if keep is not None:
+        keep.free()
+    return PreparedColumns(mode, key_id, None, flow_end, flow_start, value, table, _epoch(start_time), _epoch(end_time))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -564,7 +591,8 @@ def result_columns(prep, res, algo_type, agg_flow, tad_id):
     n = res.n_rows
     cols = {}
     for name in KEY_COLUMNS[prep.mode]:
-        vals = np.asarray(prep.key_table[name])[kid]
+        col = prep.key_table[name]
+        vals = col[kid] if isinstance(col, DeviceKeyColumn) else np.asarray(col)[kid]
         if name == "podLabels":
             uniq, inv = np.unique(vals.astype(str), return_inverse=True)
             vals = np.asarray([remove_meaningless_labels(u) for u in uniq], dtype=object)[inv]
