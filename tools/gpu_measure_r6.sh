@@ -16,6 +16,7 @@ timeout 400 python tools/sparse_bench.py --steps 5 --rows 100000000 --sorts lsd,
 timeout 600 python tools/factorize_bench.py > $O/factorize_bench.log 2>&1
 timeout 600 python tools/strings_bench.py > $O/strings_bench.log 2>&1
 timeout 600 python tools/ingest_e2e.py --rows 100000000 --mode pod --connections 8 --compare-host 2000000 > $O/ingest_e2e_pod.log 2>&1
+timeout 600 python tools/ingest_e2e.py --rows 50000000 --mode default --connections 8 > $O/ingest_e2e_default.log 2>&1
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-other-configs --tables 1"
 kt() {  # name, command...
@@ -56,5 +57,5 @@ for n in ("c2", "c4", "c5", "sparse"):
     print(n, "bytes fetched %.2f GB written %.2f GB per job (one launch of every kernel of the job)" % (sum(v["fetch_bytes"] for v in job.values()) / 1e9, sum(v["write_bytes"] for v in job.values()) / 1e9), {a: (round(b["fetch_bytes"] / 1e6), round(b["write_bytes"] / 1e6)) for a, b in k.items() if b["fetch_bytes"] + b["write_bytes"] > 2e7})
 PY
 rm -f $O/pmc_c*_fetch.csv $O/pmc_c*_write.csv $O/pmc_sparse_*.csv $O/kt_*.log $O/pmc_*.log
-cat $O/pytest.log $O/cold_c2.log $O/cold_c4.log $O/sparse_bench.log $O/factorize_bench.log $O/strings_bench.log $O/ingest_e2e_pod.log 2>/dev/null; python -c "
+cat $O/pytest.log $O/cold_c2.log $O/cold_c4.log $O/sparse_bench.log $O/factorize_bench.log $O/strings_bench.log $O/ingest_e2e_pod.log $O/ingest_e2e_default.log 2>/dev/null; python -c "
 import json; d=json.loads(open('$O/bench_default_line.json').read().strip().splitlines()[-1]); print('C2', d['ms_per_step'], d['roofline']['frac'], d['pipeline']['hbm_frac_whole_job']); [print(k, v.get('ms_per_step'), v.get('roofline',{}).get('frac')) for k,v in d.get('other_configs',{}).items()]; print(json.loads(open('$O/bench_host_input.json').read().strip().splitlines()[-1])['ms_per_step'])"
