@@ -134,7 +134,7 @@ def cpu_sample(algo, rows, keys, cores):
 
 def pmc_traffic(kernel, name="pmc_latest.json"):
     """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes), or None.  `job_*`: the sum over
-    every kernel of the job (each launches once per job since round 4; the table generator and the one-time placement probe are not part of it)."""
+    every kernel of the job (each launches once per job; the table generator is not part of it)."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """FETCH_SIZE / WRITE_SIZE counter_collection.csv (two separate rocprofv3 --pmc passes) -> profiles/pmc_latest.json.
-FETCH_SIZE (KiB) is doubled: on gfx950 it tallies 64 B per 128-B request (MI355X_MICROARCH.md §HBM); the doubling is
-calibrated here on k_synth-free kernels by k_meta_hist, whose reads are exactly 16 B/row.
+FETCH_SIZE (KiB) is doubled: on gfx950 it tallies 64 B per 128-B request (MI355X_MICROARCH.md §HBM).  Calibrated by load width with
+tools/probes/fetch_calibrate.hip (profiles/r6_c2_fetch_calibrate.log): 4, 8 and 16 bytes per lane and the time-major 8-byte walk all
+report exactly half their bytes.
 usage: tools/pmc_to_json.py <fetch.csv> <write.csv> <label> > profiles/pmc_latest.json"""
 import collections
 import csv
