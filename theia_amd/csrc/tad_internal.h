@@ -1,4 +1,4 @@
-// tad_internal.h — shared between the C-ABI host code (tad_capi.cpp) and the gfx950 kernels.
+// tad_internal.h — shared between the C-ABI host code (tad_engine.cpp, tad_capi*.cpp) and the gfx950 kernels.
 // Product code.  Nothing here may include or call anything under oracle/.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -444,7 +444,7 @@ void launch_widen(hipStream_t s, const void *src, int bits, bool is_signed, uint
 void launch_mask_rows(hipStream_t s, uint64_t n, int n_terms, const long long *const *codes, const uint8_t *const *masks, const uint64_t *mask_len, bool combine,
                       uint8_t *keep, unsigned int *err);
 
-// ---- code-object preload (tad_capi.cpp:preload_code_objects) ----
+// ---- code-object preload (tad_engine.cpp:preload_code_objects) ----
 // HIP loads a translation unit's code object on the first use of one of its kernels (~0.4 ms each, inside the first job otherwise).
 const void *code_anchor_arima();
 const void *code_anchor_dbscan();
