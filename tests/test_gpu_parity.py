@@ -297,6 +297,25 @@ def test_job_sampled_histogram_too_optimistic_falls_back_to_exact(engine, stage0
         assert res2.stats["stage0_attempts"] == 1 and res2.stats["hist_sampled"] == 1
 
 
+def test_key_out_of_range_in_a_row_the_sampled_histogram_skips_is_an_error(engine, stage0):
+    """TAD_ERR_KEY_RANGE is the contract for a key id >= num_keys.  With a sampled histogram pass A reads one row in sixteen, so the check must
+    also live in pass B, which reads every row: until round 6 a bad key outside the sample was silently dropped."""
+    from theia_amd import TadError, _capi
+    n, K, T = 6_000_000, 3000, 50
+    k, t, v = orc.synth_rows(0, n, K, T)
+    ok = engine.run("EWMA", k, t, v, K, agg_flow="svc")
+    chunk = (((n + 255) // 256) + 1) & ~1
+    bad = k.copy()
+    bad[5 * chunk + 12_000] = np.uint64(K)           # the second 8192-row iteration of workgroup 5's chunk: never sampled
+    with pytest.raises(TadError) as ei:
+        engine.run("EWMA", bad, t, v, K, agg_flow="svc")
+    assert ei.value.code == _capi.TAD_ERR_KEY_RANGE
+    if stage0 != "v1":
+        assert ok.stats["hist_sampled"] == 1            # (the good table did go through the sampled histogram)
+    bad[5 * chunk + 12_000] = np.uint64(_capi.TAD_KEY_SKIP)      # ... and TAD_KEY_SKIP there is no error
+    assert engine.run("EWMA", bad, t, v, K, agg_flow="svc").stats["rows_used"] == n - 1
+
+
 @pytest.mark.parametrize("n_rows,K,T", [(1_500_000, 40_000, 2000), (300_000, 50, 20_000), (2_000_000, 300_000, 100)])
 def test_job_wide_grids_take_several_rounds_per_partition(engine, stage0, n_rows, K, T):
     # grids whose KP x T block does not fit one LDS tile (many buckets) or that would need more than 2048 partitions

@@ -678,6 +678,8 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
           const uint32_t p = (uint32_t)(k >> A.shift_part);
           r_cell[slot] = cell;
           r_pr[slot] = (p << 16) | atomicAdd(&off[p], 1u);
+        } else if (kept && k != TAD_KEY_SKIP) {
+          err |= DEV_ERR_KEY_RANGE;   // pass A reports it too, but only for the rows it reads: with a sampled histogram that is one row in sixteen
         }
       }
     }
@@ -876,6 +878,8 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
               else A.recs[at] = rec;                                       // a hot key: more spills in one tile than the buffer holds
             } else err |= DEV_ERR_REGION_FULL;                             // sampled regions only: the region is full
           }
+        } else if (kept && k != TAD_KEY_SKIP) {
+          err |= DEV_ERR_KEY_RANGE;   // pass A reports it too, but only for the rows it reads: with a sampled histogram that is one row in sixteen
         }
       }
     }
