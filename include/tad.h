@@ -124,6 +124,20 @@ typedef struct {
   char id[64];               /* --id, echoed into the result (tadetector.id, :503) */
 } tad_job;
 
+/* By-product of tad_factorize_hist (ABI 12): how many of each Stage-0 workgroup's rows fall into each key bin — what pass A of tad_run would
+ * otherwise count with a second read of the key column when it sizes pass B's regions exactly (many-key tables: DBSCAN on 1e6 keys spends
+ * 0.19 ms and 0.89 GB of its 1.55 ms there).  The factorisation has every row's id in registers when it writes key_id; counting there is
+ * free.  `bins` is DEVICE memory of TAD_KEY_HIST_BYTES bytes supplied by the caller; the other fields are filled in by tad_factorize_hist
+ * and checked by tad_run against its own plan — a histogram that does not belong to the batch (other row count, key count, sides) or that
+ * the job cannot use (a time-window filter drops rows the histogram counted; a small batch has no pass A) is ignored. */
+#define TAD_KEY_HIST_BYTES ((uint64_t)256 * 16384 * 4)
+typedef struct {
+  uint64_t n_rows, num_keys;   /* the batch it was taken from */
+  uint64_t chunk_rows;         /* rows per workgroup */
+  uint32_t workgroups, nbins, shift, sides;
+  uint32_t *bins;              /* DEVICE [workgroups][nbins]: rows of workgroup g whose key id >> shift == b */
+} tad_key_hist;
+
 /* One columnar batch of flow rows (the columns the SQL of :507-614 touches, after the host's
  * dictionary encoding).  All arrays have n_rows entries; memory says where they live. */
 typedef struct {
@@ -141,6 +155,7 @@ typedef struct {
   int64_t t0;
   int64_t step;
   uint64_t n_buckets;
+  const tad_key_hist *key_hist; /* optional (NULL): tad_factorize_hist's by-product for THIS batch (ABI 12) */
 } tad_columns;
 
 /* Per-run counters and stage timings (for CompletedStages/TotalStages-style progress and bench). */
@@ -180,7 +195,8 @@ typedef struct {
                                   instead of the LSD radix sort (big sparse tables: the columns are read once, 8-byte records move through HBM once) */
   int32_t stage0_attempts; /* times Stage 0 ran before it settled: 1 normally; more after a wrong lattice hint, a sampled lattice or
                               a sampled histogram that proved too optimistic (every fallback is exact), an overflow-list fallback */
-  int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/8 of pass A's reads) */
+  int32_t hist_sampled;    /* 1: pass B's regions were sized from a SAMPLE of the key column (1/16 of pass A's reads); 2 (ABI 12): from the
+                              caller's tad_key_hist (exact; pass A only sampled the time lattice); 0: from pass A's own exact histogram */
   int32_t host_syncs;      /* host synchronisations of the attempt that produced the result: 3 = lattice derivation, row count, result;
                               2 with a lattice hint (or an empty batch) */
   int32_t job_context;     /* ABI 12: index of the job context (stream + workspace) that ran the job; 0 for a serial caller */
@@ -273,6 +289,11 @@ typedef struct {
 } tad_key_columns;
 int tad_factorize(tad_engine *e, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row,
                   uint64_t first_row_cap, uint64_t *num_keys);
+/* ... and the same with the key-bin histogram of the ids as a by-product (tad_key_hist above): hist->bins must point to TAD_KEY_HIST_BYTES
+ * bytes of DEVICE memory (whatever kc->memory is); the other fields are outputs.  hist->n_rows == 0 afterwards: no histogram (empty batch,
+ * or more than 2^32 - 1 row slots). */
+int tad_factorize_hist(tad_engine *e, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row,
+                       uint64_t first_row_cap, uint64_t *num_keys, tad_key_hist *hist);
 
 /* ---- ingest, one step earlier (ABI 10): an Arrow string column -> dictionary codes on the GPU ----
  * ClickHouse delivers the job's GROUP BY columns (sourcePodName, destinationPodName, pod labels, namespaces, destinationIP,

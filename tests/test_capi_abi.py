@@ -39,14 +39,14 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 def test_ctypes_struct_layout_matches_the_c_compiler(tmp_path):
     from theia_amd import _capi
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include "tad.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    prog.write_text('#include <stdio.h>\n#include "tad.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                     'sizeof(tad_plan),sizeof(tad_engine_opts),sizeof(tad_job),sizeof(tad_columns),sizeof(tad_stats),sizeof(tad_result),sizeof(tad_points),'
-                    'sizeof(tad_key_columns),sizeof(tad_string_column));return 0;}\n')
+                    'sizeof(tad_key_columns),sizeof(tad_string_column),sizeof(tad_key_hist));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     mine = [ctypes.sizeof(c) for c in (_capi.Plan, _capi.EngineOpts, _capi.Job, _capi.Columns, _capi.Stats, _capi.Result, _capi.Points, _capi.KeyColumns,
-                                       _capi.StringColumn)]
+                                       _capi.StringColumn, _capi.KeyHist)]
     assert sizes == mine
 
 

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import job_oracle as jo
+from oracle import tad_oracle as orc
 from theia_amd import _capi as capi
 from theia_amd import anomaly_detection as ad
 from theia_amd.engine import DeviceArray
@@ -126,6 +127,80 @@ def test_millions_of_distinct_keys_on_the_full_size_table(engine):
     uniq = n // 2                           # (random 56-bit tuples: no accidental duplicates at this size)
     assert fr.size == uniq and (fr == np.arange(uniq, dtype=np.uint64)).all()
     assert (k1[:uniq] == np.arange(uniq, dtype=np.uint64)).all() and (k1[n // 2:] == k1[:n - n // 2]).all()
+
+
+# ---- tad_factorize_hist (ABI 12): the key-bin histogram of the ids as a by-product, for the Stage 0 of the job that follows ----
+@pytest.mark.parametrize("algo,agg,sides,plan", [
+    ("DBSCAN", "", 1, {}), ("DBSCAN", "", 1, {"tile_cells": "wide"}), ("DBSCAN", "", 1, {"partition_pass": "sort"}),
+    ("DBSCAN", "", 1, {"partition_pass": "wc_sectors"}), ("DBSCAN", "svc", 1, {}), ("DBSCAN", "", 1, {"histogram": "exact"}),
+    ("EWMA", "svc", 1, {}), ("EWMA", "pod", 2, {}), ("DBSCAN", "pod", 2, {})])
+def test_job_with_the_factorisation_histogram_equals_the_job_without(engine, algo, agg, sides, plan):
+    """tad_run sizes pass B's regions from tad_factorize_hist's by-product instead of reading the key column again: the same rows, bit for bit,
+    as the job that counts for itself — for the settle-mode variants of the DBSCAN job (tile cells, partition passes, operators), the EWMA job
+    and pod mode's two keys per row; the histogram itself equals numpy's count per (workgroup, bin)."""
+    from theia_amd import TadEngine
+    rng = np.random.default_rng(17)
+    n, card = 4_300_000, 100_000                  # >= 2^22 rows: the partition path on its own; ~3e5 keys x 20 buckets: a dense grid
+    raw = [rng.integers(0, card, size=n).astype(np.int64), rng.integers(0, 3, size=n).astype(np.int64)]
+    keep = rng.random(n) < 0.9
+    rawb = [rng.integers(0, card, size=n).astype(np.int64), rng.integers(0, 3, size=n).astype(np.int64)] if sides == 2 else None
+    keepb = (rng.random(n) < 0.8) if sides == 2 else None
+    out = engine.factorize(raw, keep, rawb, keepb, with_hist=True)
+    k1, k2, first, hist = out
+    K = first.size
+    assert hist.valid and hist.c.n_rows == n and hist.c.num_keys == K and hist.c.sides == sides and hist.c.workgroups == 256
+    bins = np.frombuffer(hist.bins.to_host().tobytes(), dtype=np.uint32)[:256 * hist.c.nbins].reshape(256, hist.c.nbins)
+    g = np.arange(n) // hist.c.chunk_rows
+    want = np.zeros((256, hist.c.nbins), dtype=np.int64)
+    for kk in (k1, k2) if sides == 2 else (k1,):
+        live = kk != SKIP
+        np.add.at(want, (g[live], (kk[live] >> np.uint64(hist.c.shift)).astype(np.int64)), 1)
+    assert (bins == want).all() and hist.c.nbins == -(-K // (1 << hist.c.shift))
+    _, t, v = orc.synth_rows(3, n, 1000, 20)
+    eng = TadEngine(device=0, plan=plan)
+    try:
+        a = eng.run(algo, k1, t, v, K, agg_flow=agg, key_id2=k2)
+        b = eng.run(algo, k1, t, v, K, agg_flow=agg, key_id2=k2, key_hist=hist)
+        assert b.stats["hist_sampled"] == 2 and a.stats["hist_sampled"] in (0, 1) and b.stats["stage0_path"] in (2, 3)
+        assert a.n_rows == b.n_rows and a.stats["n_points"] == b.stats["n_points"] and a.stats["rows_used"] == b.stats["rows_used"]
+        for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+            assert (a[f] == b[f]).all(), f
+        # a histogram that does not belong to the batch (one row fewer) or a job with a time window: ignored, same rows
+        c = eng.run(algo, k1[:-1], t[:-1], v[:-1], K, agg_flow=agg, key_id2=None if k2 is None else k2[:-1], key_hist=hist)
+        assert c.stats["hist_sampled"] != 2
+        if agg != "pod":
+            d = eng.run(algo, k1, t, v, K, agg_flow=agg, end_time=int(t.max()), key_hist=hist)
+            assert d.stats["hist_sampled"] != 2 and d.stats["rows_used"] < a.stats["rows_used"]
+    finally:
+        eng.close()
+        hist.free()
+
+
+def test_sparse_table_through_the_partition_sort_with_the_factorisation_histogram(engine):
+    """A table whose grid would be mostly empty (6e5 keys x 60 buckets for 4.3e6 rows) takes the sparse Stage 0 through pass A / pass B
+    (stage0_path 8): the key-bin histogram it plans its sort rounds from may be the factorisation's too."""
+    rng = np.random.default_rng(18)
+    n = 4_300_000
+    raw = [rng.integers(0, 200_000, size=n).astype(np.int64), rng.integers(0, 3, size=n).astype(np.int64)]
+    k1, _, first, hist = engine.factorize(raw, rng.random(n) < 0.9, with_hist=True)
+    _, t, v = orc.synth_rows(3, n, 1000, 60)
+    a = engine.run("EWMA", k1, t, v, first.size, agg_flow="svc")
+    b = engine.run("EWMA", k1, t, v, first.size, agg_flow="svc", key_hist=hist)
+    assert a.stats["stage0_path"] == b.stats["stage0_path"] == 8 and b.stats["hist_sampled"] == 2 and a.stats["hist_sampled"] == 0
+    assert a.n_rows == b.n_rows > 0 and a.stats["n_points"] == b.stats["n_points"]
+    for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+        assert (a[f] == b[f]).all(), f
+    hist.free()
+
+
+def test_factorisation_histogram_of_a_small_or_empty_batch(engine):
+    k1, _, first, hist = engine.factorize([np.arange(1000, dtype=np.int64) % 7], with_hist=True)
+    assert first.size == 7 and hist.valid and hist.c.nbins == 7 and hist.c.shift == 0      # (a job this small never reads it: no pass A below 2^22 rows)
+    _, t, v = orc.synth_rows(0, 1000, 7, 10)
+    assert engine.run("EWMA", k1, t, v, 7, agg_flow="svc", key_hist=hist).stats["hist_sampled"] == 0
+    k1, _, first, hist2 = engine.factorize([np.zeros(10, dtype=np.int64)], np.zeros(10, bool), with_hist=True)
+    assert first.size == 0 and not hist2.valid
+    hist.free(); hist2.free()
 
 
 # ---- tad_encode_strings (ABI 10): an Arrow string column -> dictionary codes in order of first appearance ----

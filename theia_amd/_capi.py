@@ -65,10 +65,19 @@ class Job(C.Structure):
                 ("flags", u32), ("id", C.c_char * 64)]
 
 
+TAD_KEY_HIST_BYTES = 256 * 16384 * 4
+
+
+class KeyHist(C.Structure):
+    """tad_key_hist: tad_factorize_hist's by-product (key-bin histogram per Stage-0 workgroup); bins is device memory of TAD_KEY_HIST_BYTES."""
+    _fields_ = [("n_rows", u64), ("num_keys", u64), ("chunk_rows", u64), ("workgroups", u32), ("nbins", u32), ("shift", u32), ("sides", u32),
+                ("bins", C.c_void_p)]
+
+
 class Columns(C.Structure):
     _fields_ = [("n_rows", u64), ("key_id", C.c_void_p), ("key_id2", C.c_void_p),
                 ("flow_end_s", C.c_void_p), ("flow_start_s", C.c_void_p), ("value", C.c_void_p),
-                ("num_keys", u64), ("memory", C.c_int), ("t0", i64), ("step", i64), ("n_buckets", u64)]
+                ("num_keys", u64), ("memory", C.c_int), ("t0", i64), ("step", i64), ("n_buckets", u64), ("key_hist", C.POINTER(KeyHist))]
 
 
 class Stats(C.Structure):
@@ -108,6 +117,7 @@ SYMBOLS = {
     "tad_points_free": (None, [C.c_void_p, C.POINTER(Points)]),
     "tad_shard_rows": (C.c_int, [C.c_void_p, C.POINTER(Columns), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tad_factorize": (C.c_int, [C.c_void_p, C.POINTER(KeyColumns), C.c_void_p, C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]),
+    "tad_factorize_hist": (C.c_int, [C.c_void_p, C.POINTER(KeyColumns), C.c_void_p, C.c_void_p, C.c_void_p, u64, C.POINTER(u64), C.POINTER(KeyHist)]),
     "tad_encode_strings": (C.c_int, [C.c_void_p, C.POINTER(StringColumn), C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]),
     "tad_widen_column": (C.c_int, [C.c_void_p, C.c_void_p, i32, i32, C.c_int, u64, C.c_void_p, u64, C.c_void_p]),
     "tad_mask_rows": (C.c_int, [C.c_void_p, u64, i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(u64), i32, C.c_void_p]),
@@ -145,7 +155,10 @@ def load_library(build_if_missing=True, path=None):
             raise OSError("%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
         _build.build_library()
     lib = C.CDLL(path)
+    shipped = path == os.path.abspath(_build.LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
+        if not shipped and not hasattr(lib, name):     # an older build loaded for an A/B measurement may lack the newest entry points
+            continue
         fn = getattr(lib, name)  # AttributeError here = the library does not export the header's symbol
         fn.restype = res
         fn.argtypes = args

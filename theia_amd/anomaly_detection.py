@@ -268,7 +268,7 @@ def _ilike_contains(col, needle):
 class PreparedColumns:
     """What tad_run needs for one job: the encoded columns + the dictionary to decode results."""
 
-    def __init__(self, mode, key_id, key_id2, flow_end_s, flow_start_s, value, key_table, start_time, end_time):
+    def __init__(self, mode, key_id, key_id2, flow_end_s, flow_start_s, value, key_table, start_time, end_time, key_hist=None):
         self.mode = mode                  # key of KEY_COLUMNS
         self.key_id = key_id              # u64[N], TAD_KEY_SKIP where the predicates reject the row
         self.key_id2 = key_id2            # pod mode: the row's outbound key (ref:556-565), else None
@@ -278,6 +278,7 @@ class PreparedColumns:
         self.key_table = key_table        # dict column name -> array[num_keys] (device ingest: DeviceKeyColumn, decoded on demand)
         self.start_time = start_time      # epoch seconds handed to the engine (0 = unset)
         self.end_time = end_time
+        self.key_hist = key_hist          # device ingest: tad_factorize_hist's by-product for these very columns (engine.run(key_hist=...))
 
     @property
     def num_keys(self):
@@ -497,14 +498,15 @@ def prepare_columns_device(flows, start_time="", end_time="", ns_ignore_list=(),
             sides.append((eng.mask_rows(n, terms), ns, col, direction))
         if n == 0:
             return PreparedColumns(mode, flow_end, flow_end, flow_end, None, value, {k: np.zeros(0, dtype=str) for k in KEY_COLUMNS[mode]}, 0, 0)
-        key_id, key_id2, first = eng.factorize([sides[0][1].codes, sides[0][2].codes], sides[0][0], [sides[1][1].codes, sides[1][2].codes], sides[1][0])
+        key_id, key_id2, first, hist = eng.factorize([sides[0][1].codes, sides[0][2].codes], sides[0][0], [sides[1][1].codes, sides[1][2].codes], sides[1][0],
+                                                     with_hist=True)
         table = {KEY_COLUMNS[mode][0]: DeviceKeyColumn(eng, n, first, [(sides[0][1], None), (sides[1][1], None)]),
                  KEY_COLUMNS[mode][1]: DeviceKeyColumn(eng, n, first, [(sides[0][2], None), (sides[1][2], None)]),
                  KEY_COLUMNS[mode][2]: DeviceKeyColumn(eng, n, first, [(None, sides[0][3]), (None, sides[1][3])])}
         for k in (sides[0][0], sides[1][0]):
             k.free()
         # the pod SQL carries no flowStartSeconds / flowEndSeconds predicate (ref:556-565)
-        return PreparedColumns(mode, key_id, key_id2, flow_end, None, value, table, 0, 0)
+        return PreparedColumns(mode, key_id, key_id2, flow_end, None, value, table, 0, 0, key_hist=hist)
 
     terms = list(common)
     if agg_flow == "external":
@@ -530,11 +532,11 @@ def prepare_columns_device(flows, start_time="", end_time="", ns_ignore_list=(),
         return PreparedColumns(mode, flow_end, None, flow_end, flow_start, value, {k: np.zeros(0, dtype=str) for k in KEY_COLUMNS[mode]},
                                _epoch(start_time), _epoch(end_time))
     keep = eng.mask_rows(n, terms) if terms else None
-    key_id, _, first = eng.factorize([c.codes if hasattr(c, "values") else c for c in cols], keep)
+    key_id, _, first, hist = eng.factorize([c.codes if hasattr(c, "values") else c for c in cols], keep, with_hist=True)
     table = {name: DeviceKeyColumn(eng, n, first, [(c, None)]) for name, c in zip(KEY_COLUMNS[mode], cols)}
     if keep is not None:
         keep.free()
-    return PreparedColumns(mode, key_id, None, flow_end, flow_start, value, table, _epoch(start_time), _epoch(end_time))
+    return PreparedColumns(mode, key_id, None, flow_end, flow_start, value, table, _epoch(start_time), _epoch(end_time), key_hist=hist)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -643,7 +645,7 @@ def anomaly_detection(algo_type, flows, start_time, end_time, tad_id_input, ns_i
                 prep = prepare_columns_device(dev, *args, engine=eng)
                 res = eng.run(algo_type, prep.key_id, prep.flow_end_s, prep.value, max(prep.num_keys, 1), agg_flow=agg_flow,
                               key_id2=prep.key_id2, flow_start_s=prep.flow_start_s, start_time=prep.start_time,
-                              end_time=prep.end_time, job_id=str(tad_id_input or ""))
+                              end_time=prep.end_time, job_id=str(tad_id_input or ""), key_hist=prep.key_hist)
                 if columnar:
                     return res.stats, result_columns(prep, res, algo_type, agg_flow, tad_id_input)
                 return res.stats, result_rows(prep, res, algo_type, agg_flow, tad_id_input)

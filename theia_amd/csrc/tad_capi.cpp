@@ -337,6 +337,14 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
     if ((rc = ensure(e, e->meta, sizeof(MetaPartial) * kMetaBlocks)) != TAD_OK) return rc;
     int meta_blocks = 0;
     bool hist_sampled = false;
+    // The caller's key-bin histogram (tad_factorize_hist's by-product): pass A then only samples the time lattice and pass B's regions are
+    // sized EXACTLY from the caller's counts.  Taken when it provably describes this batch and this job: same rows, keys, sides and row
+    // chunking, no time-window filter (the histogram counted every kept row), the lattice still derived from a sample (lat_mode 1 or a hint).
+    const tad_key_hist *kh = cols->key_hist;
+    bool use_kh = v2 && depth == 0 && kh != nullptr && kh->bins != nullptr && lat_mode != 2 && kh->n_rows == n && kh->num_keys == K &&
+                  kh->sides == (has2 ? 2u : 1u) && kh->workgroups == (uint32_t)pl.G && kh->nbins == pl.nbins && kh->shift == (uint32_t)pl.shift_bin &&
+                  kh->chunk_rows == pl.chunk && rf.end_time == 0 && !(d_ts != nullptr && rf.start_time != 0);
+    const uint32_t *binhist = nullptr;
     if (v2) {
       // pass A: lattice partials + per-workgroup key-bin histogram in one read of the key/time columns
       if ((rc = ensure(e, e->binhist, (size_t)pl.G * pl.nbins * 4)) != TAD_OK) return rc;
@@ -346,10 +354,14 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
                                       // over the regions cost more than the sampled pass A saves: sample only when a region of a
                                       // 128-key block is expected to hold a few hundred records
                                       // (lat_mode 2 re-derives the lattice with k_meta, which reuses the partials buffer the sampling ratios live in)
-                                      !force_exact_hist && lat_mode != 2 && sampled_slots_bound(n * (has2 ? 2 : 1), pl) < (1ull << 32) &&
+                                      use_kh ||       // (the sampled pass: its histogram lands in e->binhist and is not used)
+                                      (!force_exact_hist && lat_mode != 2 && sampled_slots_bound(n * (has2 ? 2 : 1), pl) < (1ull << 32) &&
                                           (plan.histogram == 2 ||      // (A/B: sampled wherever it is possible at all)
-                                           n * (has2 ? 2 : 1) / ((uint64_t)pl.G * ((K >> kSampleBlockShift) ? (K >> kSampleBlockShift) : 1)) >= 384));
+                                           n * (has2 ? 2 : 1) / ((uint64_t)pl.G * ((K >> kSampleBlockShift) ? (K >> kSampleBlockShift) : 1)) >= 384)));
       meta_blocks = pl.G;
+      binhist = static_cast<const uint32_t *>(e->binhist.p);
+      if (use_kh && hist_sampled) { binhist = kh->bins; hist_sampled = false; }   // exact counts, from the caller
+      else use_kh = false;          // (pass A could not sample — unaligned columns — and counted every row itself)
     }
     if (!hinted && !empty && (!v2 || lat_mode == 2)) {
       meta_blocks = (int)((n + 255) / 256);
@@ -448,12 +460,12 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
         if ((rc = ensure(e, e->slices, slice_table_bytes(slots, spl))) != TAD_OK) return rc;
         uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
         unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
-        launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), spl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start, false,
+        launch_part_offsets(s, binhist, spl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start, false,
                             static_cast<const MetaPartial *>(e->meta.p), n, slots, e->slices.p, Grid{});
         // (no overflow list: a value that does not fit the record raises DEV_ERR_OVERFLOW_LIST and the LSD sort redoes the job)
         launch_partition(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
                          rf, L, spl, offs32, part_start, e->recs.p, nullptr, dev_ovf_count(e), 0, ctr, nullptr, nullptr);
-        launch_sparse_sort(s, e->recs.p, part_start, static_cast<const uint32_t *>(e->binhist.p), spl, K, L.step, op_max,
+        launch_sparse_sort(s, e->recs.p, part_start, binhist, spl, K, L.step, op_max,
                            ucomp, static_cast<unsigned long long *>(e->sp_comp_b.p), static_cast<unsigned long long *>(e->sp_val_b.p),
                            reinterpret_cast<uint32_t *>(uval), e->sp_temp.p, d_runs, ctr);
       } else if (launch_sparse_group(s, (const uint64_t *)d_key, (const uint64_t *)d_key2, (const int64_t *)d_te, (const int64_t *)d_ts, (const uint64_t *)d_val, n, K,
@@ -558,7 +570,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
       uint32_t *offs32 = static_cast<uint32_t *>(e->part_offs32.p);
       unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
-      launch_part_offsets(s, static_cast<const uint32_t *>(e->binhist.p), pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start,
+      launch_part_offsets(s, binhist, pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start,
                           hist_sampled, static_cast<const MetaPartial *>(e->meta.p), n, slots, e->slices.p, g);
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
@@ -731,7 +743,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
       hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
       st.stage0_path = sparse ? (sp_part ? 8 : 4) : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
       st.stage0_attempts = attempt + 1;
-      st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
+      st.hist_sampled = (v2 && hist_sampled) ? 1 : (use_kh ? 2 : 0);
       e->done.store(4);
       *points_out = &pp->pub;
       return TAD_OK;
@@ -804,7 +816,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
     hipEventElapsedTime(&st.ms_detect, e->ev[5], e->ev[4]);
     st.stage0_path = sparse ? (sp_part ? 8 : 4) : (v2 ? (pl.wc_cap ? 3 : 2) : 1);
     st.stage0_attempts = attempt + 1;
-    st.hist_sampled = (v2 && hist_sampled) ? 1 : 0;
+    st.hist_sampled = (v2 && hist_sampled) ? 1 : (use_kh ? 2 : 0);
     st.host_syncs = (hinted || empty) ? 2 : 3;
     st.job_context = e->index;
     st.arima_relaunches = e->arima_relaunches;

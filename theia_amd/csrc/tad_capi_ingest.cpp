@@ -39,8 +39,11 @@ int tad_shard_rows(tad_engine *eng, const tad_columns *cols, uint32_t world, uin
   return TAD_OK;
 }
 
-int tad_factorize(tad_engine *eng, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row, uint64_t first_row_cap,
-                  uint64_t *num_keys) {
+}  // extern "C"
+
+// tad_factorize / tad_factorize_hist
+static int factorize_impl(tad_engine *eng, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row, uint64_t first_row_cap,
+                          uint64_t *num_keys, tad_key_hist *hist) {
   if (!eng) return fail(nullptr, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: engine is NULL");
   if (!kc || !num_keys || kc->n_cols < 1 || kc->n_cols > kFzMaxCols || !kc->cols_a || (kc->n_rows && !key_id) || (kc->cols_b && kc->n_rows && !key_id2) ||
       (first_row_cap && !first_row))
@@ -48,6 +51,15 @@ int tad_factorize(tad_engine *eng, const tad_key_columns *kc, uint64_t *key_id, 
   const uint64_t n = kc->n_rows;
   const uint32_t sides = kc->cols_b ? 2 : 1;
   *num_keys = 0;
+  uint32_t *hist_bins = nullptr;
+  PartPlan hpl{};
+  if (hist != nullptr) {
+    hist_bins = hist->bins;
+    hist->n_rows = hist->num_keys = hist->chunk_rows = 0;
+    hist->workgroups = hist->nbins = hist->shift = hist->sides = 0;
+    // pass B's row chunking does not depend on the key count (part_plan_bins): the kernel needs it before the count exists on the host
+    if (hist_bins == nullptr || !part_plan_bins(n, 1, sides == 2, &hpl)) hist_bins = nullptr;
+  }
   if (n == 0) return TAD_OK;
   if (n * sides >= 0xFFFFFFFFull) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_factorize: %llu virtual rows do not fit 32-bit row indices", (unsigned long long)(n * sides));
   for (int c = 0; c < kc->n_cols; ++c)
@@ -90,7 +102,8 @@ int tad_factorize(tad_engine *eng, const tad_key_columns *kc, uint64_t *key_id, 
       for (int c = 0; c < kc->n_cols; ++c) { ca[c] = reinterpret_cast<const long long *>(kc->cols_a[c]); if (sides == 2) cb[c] = reinterpret_cast<const long long *>(kc->cols_b[c]); }
     }
     uint32_t *flags_dev = nullptr;
-    launch_factorize(s, ca, ka, sides == 2 ? cb : nullptr, kb, n, kc->n_cols, slots, base, d_key, d_key2, d_fr, first_row_cap, nk_dev, &flags_dev);
+    launch_factorize(s, ca, ka, sides == 2 ? cb : nullptr, kb, n, kc->n_cols, slots, base, d_key, d_key2, d_fr, first_row_cap, nk_dev, &flags_dev,
+                     hist_bins, hpl.G, hpl.chunk);
     unsigned long long nk = 0;
     uint32_t flags = 0;
     HIP_TRY(e, hipMemcpyAsync(&nk, nk_dev, 8, hipMemcpyDeviceToHost, s));
@@ -111,8 +124,25 @@ int tad_factorize(tad_engine *eng, const tad_key_columns *kc, uint64_t *key_id, 
       HIP_TRY(e, hipStreamSynchronize(s));
     }
     *num_keys = nk;
+    if (hist_bins != nullptr && nk != 0 && part_plan_bins(n, nk, sides == 2, &hpl)) {   // what the kernel derived from the device-side count
+      hist->n_rows = n; hist->num_keys = nk; hist->chunk_rows = hpl.chunk;
+      hist->workgroups = (uint32_t)hpl.G; hist->nbins = hpl.nbins; hist->shift = (uint32_t)hpl.shift_bin; hist->sides = sides;
+    }
     return TAD_OK;
   }
+}
+
+extern "C" {
+
+int tad_factorize(tad_engine *eng, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row, uint64_t first_row_cap,
+                  uint64_t *num_keys) {
+  return factorize_impl(eng, kc, key_id, key_id2, first_row, first_row_cap, num_keys, nullptr);
+}
+
+int tad_factorize_hist(tad_engine *eng, const tad_key_columns *kc, uint64_t *key_id, uint64_t *key_id2, uint64_t *first_row, uint64_t first_row_cap,
+                       uint64_t *num_keys, tad_key_hist *hist) {
+  if (eng && !hist) return fail(eng, TAD_ERR_INVALID_ARGUMENT, "tad_factorize_hist: hist is NULL");
+  return factorize_impl(eng, kc, key_id, key_id2, first_row, first_row_cap, num_keys, hist);
 }
 
 int tad_encode_strings(tad_engine *eng, const tad_string_column *col, int64_t *codes, uint64_t *first_row, uint64_t first_row_cap, uint64_t *num_values) {

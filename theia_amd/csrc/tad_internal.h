@@ -317,6 +317,7 @@ struct OverflowRec {  // a row whose value needs more than 49 bits: applied to t
   unsigned long long val;
   unsigned long long gcell;  // bucket * K + key
 };
+constexpr uint32_t kMaxBins = 16384;   // pass-A histogram bins (key >> shift_bin); also the rule k_fz_lookup_hist applies on the device
 struct PartPlan {
   int shift_bin;       // pass-A histogram bin = key >> shift_bin
   uint32_t nbins;
@@ -428,7 +429,7 @@ uint64_t factorize_next_slots(uint64_t virtual_rows, uint64_t slots);   // 2^20 
 size_t factorize_temp_bytes(uint64_t virtual_rows, uint64_t slots);
 void launch_factorize(hipStream_t s, const long long *const *cols_a, const uint8_t *keep_a, const long long *const *cols_b, const uint8_t *keep_b, uint64_t n,
                       int n_cols, uint64_t slots, void *temp, uint64_t *key_a, uint64_t *key_b, uint64_t *first_row, uint64_t first_row_cap,
-                      unsigned long long *num_keys_dev, uint32_t **flags_dev_out);
+                      unsigned long long *num_keys_dev, uint32_t **flags_dev_out, uint32_t *hist_bins = nullptr, int hist_workgroups = 0, uint64_t hist_chunk = 0);
 // Arrow string column -> dictionary codes in order of first appearance (tad_factorize.hip, ABI 10); same table sizes and temp layout
 void launch_encode_strings(hipStream_t s, const void *offsets, int off64, const uint8_t *data, uint64_t data_bytes, const uint8_t *valid, uint64_t valid_off,
                            uint64_t n, uint64_t slots, void *temp, long long *codes, uint64_t *first_row, uint64_t first_row_cap,

@@ -1296,7 +1296,6 @@ __global__ __launch_bounds__(256) void k_apply_overflow(const OverflowRec *__res
 // host side
 // ------------------------------------------------------------------------------------------------
 
-static constexpr uint32_t kMaxBins = 16384;
 
 bool part_plan_bins(uint64_t n, uint64_t K, bool has2, PartPlan *pl) {
   if (K == 0 || n == 0 || n * (has2 ? 2 : 1) >= (1ull << 32)) return false;

@@ -106,6 +106,23 @@ def _as_column(x, dtype, n_expected=None):
     return a.ctypes.data, a.size, False, a
 
 
+class KeyHistogram:
+    """tad_factorize_hist's by-product: the key-bin histogram of a batch per Stage-0 workgroup, in HBM.  Hand it to TadEngine.run(key_hist=...)
+    with the SAME batch: Stage 0 then sizes pass B's regions from it instead of reading the key column a second time."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.bins = DeviceArray(engine, capi.TAD_KEY_HIST_BYTES // 8, np.uint64)
+        self.c = capi.KeyHist(bins=self.bins.ptr)
+
+    @property
+    def valid(self):
+        return self.c.n_rows != 0
+
+    def free(self):
+        self.bins.free()
+
+
 class PreparedJob:
     """TadEngine.prepare(...): one job over one set of live columns, ready to be submitted any number of times."""
 
@@ -349,7 +366,7 @@ class TadEngine:
     # ---- the job (anomaly_detection.py:647-710) ----
     def run(self, algo, key_id, flow_end_s, value, num_keys, agg_flow="", value_op="auto", key_id2=None,
             flow_start_s=None, start_time=0, end_time=0, lattice=None, emit_all=False, out="host", job_id="",
-            alpha=0.0, eps=0.0, min_samples=0, maxiter=0, drop_nsigma=0.0, drop_min_samples=0, _prepare_only=False):
+            alpha=0.0, eps=0.0, min_samples=0, maxiter=0, drop_nsigma=0.0, drop_min_samples=0, key_hist=None, _prepare_only=False):
         if algo not in capi.TAD_ALGO:
             raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "algo must be EWMA, ARIMA, DBSCAN or DROP")
         if agg_flow not in capi.TAD_AGG:
@@ -372,9 +389,11 @@ class TadEngine:
                             num_keys=int(num_keys), memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
         if lattice is not None:
             cols.t0, cols.step, cols.n_buckets = int(lattice[0]), int(lattice[1]), int(lattice[2])
+        if key_hist is not None and key_hist.valid:
+            cols.key_hist = C.pointer(key_hist.c)
         if _prepare_only:
             return PreparedJob(self, job, cols, capi.TAD_MEM_DEVICE if out == "device" else capi.TAD_MEM_HOST,
-                               (keep1, keep2, keep3, keep4, keep5))
+                               (keep1, keep2, keep3, keep4, keep5, key_hist))
         res = C.POINTER(capi.Result)()
         rc = self._lib.tad_run(self._h, C.byref(job), C.byref(cols),
                                capi.TAD_MEM_DEVICE if out == "device" else capi.TAD_MEM_HOST, C.byref(res))
@@ -475,11 +494,12 @@ class TadEngine:
         return keep
 
     # ---- ingest: key tuples -> dense ids in order of first appearance (tad_factorize) ----
-    def factorize(self, cols_a, keep_a=None, cols_b=None, keep_b=None, max_keys=None):
+    def factorize(self, cols_a, keep_a=None, cols_b=None, keep_b=None, max_keys=None, with_hist=False):
         """cols_a: list of 1..8 equally long int64 arrays (numpy on the host, or DeviceArray / device pointers all on the device) —
         the key tuple of every row; keep_a: bool / uint8 mask (None = every row); cols_b / keep_b: the second tuple of every row
         (pod mode).  Returns (key_id u64[n], key_id2 u64[n] or None, first_row u64[num_keys]) — ids in order of first appearance over
-        the virtual rows [side a ++ side b], TAD_KEY_SKIP where the mask is 0 — in the memory the inputs live in."""
+        the virtual rows [side a ++ side b], TAD_KEY_SKIP where the mask is 0 — in the memory the inputs live in.  with_hist: a fourth
+        return value, the KeyHistogram of the ids (tad_factorize_hist) for TadEngine.run(key_hist=...) on the same batch."""
         ncol = len(cols_a)
         if not 1 <= ncol <= 8 or (cols_b is not None and len(cols_b) != ncol):
             raise TadError(capi.TAD_ERR_INVALID_ARGUMENT, "factorize: 1..8 key columns, the same number on both sides")
@@ -519,22 +539,29 @@ class TadEngine:
         kc = capi.KeyColumns(n_rows=n, n_cols=ncol, cols_a=arr_a, keep_a=ka, cols_b=arr_b, keep_b=kb,
                              memory=capi.TAD_MEM_DEVICE if dev else capi.TAD_MEM_HOST)
         nk = capi.u64()
+        hist = KeyHistogram(self) if with_hist else None
+
+        def call(k1, k2, fr):
+            if hist is not None:
+                return self._lib.tad_factorize_hist(self._h, C.byref(kc), k1, k2, fr, cap, C.byref(nk), C.byref(hist.c))
+            return self._lib.tad_factorize(self._h, C.byref(kc), k1, k2, fr, cap, C.byref(nk))
         if dev:
             key1 = DeviceArray(self, n, np.uint64)
             key2 = DeviceArray(self, n, np.uint64) if pb is not None else None
             first = DeviceArray(self, max(cap, 1), np.uint64)
-            rc = self._lib.tad_factorize(self._h, C.byref(kc), key1.ptr, key2.ptr if key2 is not None else None, first.ptr, cap, C.byref(nk))
+            rc = call(key1.ptr, key2.ptr if key2 is not None else None, first.ptr)
             del keepalive
             self._check(rc)
             first.n = min(int(nk.value), cap)
-            return key1, key2, first
+            return (key1, key2, first, hist) if with_hist else (key1, key2, first)
         key1 = np.empty(n, dtype=np.uint64)
         key2 = np.empty(n, dtype=np.uint64) if pb is not None else None
         first = np.empty(max(cap, 1), dtype=np.uint64)
-        rc = self._lib.tad_factorize(self._h, C.byref(kc), key1.ctypes.data, key2.ctypes.data if key2 is not None else None, first.ctypes.data, cap, C.byref(nk))
+        rc = call(key1.ctypes.data, key2.ctypes.data if key2 is not None else None, first.ctypes.data)
         del keepalive
         self._check(rc)
-        return key1, key2, first[:min(int(nk.value), cap)]
+        first = first[:min(int(nk.value), cap)]
+        return (key1, key2, first, hist) if with_hist else (key1, key2, first)
 
     # ---- ingest, one step earlier: an Arrow string column -> dictionary codes (tad_encode_strings) ----
     def encode_strings(self, column, max_values=None):
