@@ -133,6 +133,21 @@ type Columns struct {
 	FlowStartS  []int64 // nil unless StartTime is set
 	Value       []uint64
 	NumKeys     uint64
+	KeyHist     *KeyHist // optional: FactorizeHist's by-product for THIS batch (Stage 0 then does not count the key column again)
+}
+
+// KeyHist is tad_key_hist (tad.h, ABI 12): the key-bin histogram of a factorised batch per Stage-0 workgroup.  The bins live in device
+// memory (TAD_KEY_HIST_BYTES, allocated by FactorizeHist, released by Free); the struct itself is C memory so that tad_columns may point to it.
+type KeyHist struct{ c *C.tad_key_hist }
+
+func (h *KeyHist) Valid() bool { return h != nil && h.c != nil && h.c.n_rows != 0 }
+
+func (h *KeyHist) Free(e *Engine) {
+	if h != nil && h.c != nil {
+		C.tad_device_free(e.h, unsafe.Pointer(h.c.bins))
+		C.free(unsafe.Pointer(h.c))
+		h.c = nil
+	}
 }
 
 // Row is the mode-independent part of one tadetector row (create_table.sh:363-384).
@@ -206,6 +221,9 @@ func (e *Engine) Run(job Job, cols Columns) ([]Row, Stats, error) {
 	cc.flow_end_s = (*C.int64_t)(bufs[2])
 	cc.flow_start_s = (*C.int64_t)(bufs[3])
 	cc.value = (*C.uint64_t)(bufs[4])
+	if cols.KeyHist.Valid() {
+		cc.key_hist = cols.KeyHist.c // C memory: no Go pointer inside the struct handed to C
+	}
 
 	var res *C.tad_result
 	rc := C.tad_run(e.h, &cj, &cc, C.TAD_MEM_HOST, &res)
@@ -313,8 +331,19 @@ func (e *Engine) ShardRows(key, flowEnd, value unsafe.Pointer, n uint64, world u
 // every row in pod mode (the outbound view of the UNION ALL, :556-565), ids into the second return value.  firstRow[k] = the virtual
 // row (i for side a, n + i for side b) where key k first appears: the caller reads the key's column values there.
 func (e *Engine) Factorize(colsA [][]int64, keepA []byte, colsB [][]int64, keepB []byte) (keyID, keyID2, firstRow []uint64, err error) {
+	keyID, keyID2, firstRow, _, err = e.factorize(colsA, keepA, colsB, keepB, false)
+	return
+}
+
+// FactorizeHist is Factorize plus the key-bin histogram of the ids (tad_factorize_hist): put it into Columns.KeyHist of the job over the
+// same rows and Stage 0 sizes its partition regions from it instead of reading the key column a second time.  Free it after the job.
+func (e *Engine) FactorizeHist(colsA [][]int64, keepA []byte, colsB [][]int64, keepB []byte) (keyID, keyID2, firstRow []uint64, hist *KeyHist, err error) {
+	return e.factorize(colsA, keepA, colsB, keepB, true)
+}
+
+func (e *Engine) factorize(colsA [][]int64, keepA []byte, colsB [][]int64, keepB []byte, withHist bool) (keyID, keyID2, firstRow []uint64, hist *KeyHist, err error) {
 	if len(colsA) < 1 || len(colsA) > 8 || (colsB != nil && len(colsB) != len(colsA)) {
-		return nil, nil, nil, errors.New("tadengine: 1..8 key columns, the same number on both sides")
+		return nil, nil, nil, nil, errors.New("tadengine: 1..8 key columns, the same number on both sides")
 	}
 	n := len(colsA[0])
 	sides := 1
@@ -355,14 +384,14 @@ func (e *Engine) Factorize(colsA [][]int64, keepA []byte, colsB [][]int64, keepB
 	kc.memory = C.TAD_MEM_HOST
 	pa := ptrs(colsA)
 	if pa == nil || (keepA != nil && len(keepA) != n) || (keepB != nil && len(keepB) != n) {
-		return nil, nil, nil, errors.New("tadengine: key columns and masks differ in length")
+		return nil, nil, nil, nil, errors.New("tadengine: key columns and masks differ in length")
 	}
 	kc.cols_a = (**C.int64_t)(unsafe.Pointer(pa))
 	kc.keep_a = (*C.uint8_t)(mask(keepA))
 	if colsB != nil {
 		pb := ptrs(colsB)
 		if pb == nil {
-			return nil, nil, nil, errors.New("tadengine: key columns differ in length")
+			return nil, nil, nil, nil, errors.New("tadengine: key columns differ in length")
 		}
 		kc.cols_b = (**C.int64_t)(unsafe.Pointer(pb))
 		kc.keep_b = (*C.uint8_t)(mask(keepB))
@@ -377,15 +406,31 @@ func (e *Engine) Factorize(colsA [][]int64, keepA []byte, colsB [][]int64, keepB
 		}
 	}
 	if n == 0 {
-		return keyID, keyID2, firstRow[:0], nil
+		return keyID, keyID2, firstRow[:0], nil, nil
 	}
 	var nk C.uint64_t
+	if withHist {
+		hist = &KeyHist{c: (*C.tad_key_hist)(C.calloc(1, C.size_t(unsafe.Sizeof(C.tad_key_hist{}))))}
+		var bins unsafe.Pointer
+		if rc := C.tad_device_alloc(e.h, C.uint64_t(C.TAD_KEY_HIST_BYTES), &bins); rc != C.TAD_OK {
+			C.free(unsafe.Pointer(hist.c))
+			return nil, nil, nil, nil, fmt.Errorf("tad_device_alloc: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+		}
+		hist.c.bins = (*C.uint32_t)(bins)
+		if rc := C.tad_factorize_hist(e.h, &kc, (*C.uint64_t)(unsafe.Pointer(&keyID[0])), k2, (*C.uint64_t)(unsafe.Pointer(&firstRow[0])),
+			C.uint64_t(len(firstRow)), &nk, hist.c); rc != C.TAD_OK {
+			hist.Free(e)
+			return nil, nil, nil, nil, fmt.Errorf("tad_factorize_hist: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+		}
+		return keyID, keyID2, firstRow[:int(nk)], hist, nil
+	}
 	if rc := C.tad_factorize(e.h, &kc, (*C.uint64_t)(unsafe.Pointer(&keyID[0])), k2, (*C.uint64_t)(unsafe.Pointer(&firstRow[0])),
 		C.uint64_t(len(firstRow)), &nk); rc != C.TAD_OK {
-		return nil, nil, nil, fmt.Errorf("tad_factorize: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
+		return nil, nil, nil, nil, fmt.Errorf("tad_factorize: %s (code %d)", C.GoString(C.tad_last_error(e.h)), int(rc))
 	}
-	return keyID, keyID2, firstRow[:int(nk)], nil
+	return keyID, keyID2, firstRow[:int(nk)], nil, nil
 }
+
 
 // EncodeStrings turns one string column of a batch — in Arrow's layout, what clickhouse-go's column-oriented block API and the
 // Arrow Go reader both hand out: n+1 offsets into a byte slice — into dictionary codes on the GPU (tad.h: tad_encode_strings, ABI 10):

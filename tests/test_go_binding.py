@@ -27,7 +27,7 @@ def test_every_c_function_the_go_file_calls_is_declared():
     for must in ("tad_abi_version", "tad_engine_create", "tad_engine_destroy", "tad_engine_set_plan", "tad_last_error", "tad_run", "tad_result_free",
                  "tad_aggregate", "tad_points_free", "tad_shard_rows", "tad_factorize", "tad_encode_strings", "tad_progress", "tad_state_create",
                  "tad_state_destroy", "tad_run_stream", "tad_state_export", "tad_device_alloc", "tad_device_free", "tad_copy_to_device",
-                 "tad_copy_to_host", "tad_job_progress", "tad_jobs_in_flight", "tad_widen_column", "tad_mask_rows", "tad_host_alloc", "tad_host_free"):
+                 "tad_copy_to_host", "tad_job_progress", "tad_jobs_in_flight", "tad_widen_column", "tad_mask_rows", "tad_host_alloc", "tad_host_free", "tad_factorize_hist"):
         assert must in called, must
     for t in set(re.findall(r"C\.(tad_[a-z0-9_]+)\b(?!\()", GO)):
         assert t in types or t in declared, t
