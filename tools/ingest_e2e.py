@@ -146,7 +146,7 @@ for run in range(args.runs):
     prep = ad.prepare_columns_device(dev, *pos, engine=eng)
     t2 = time.perf_counter()
     res = eng.run("EWMA", prep.key_id, prep.flow_end_s, prep.value, max(prep.num_keys, 1), agg_flow=agg, key_id2=prep.key_id2,
-                  flow_start_s=prep.flow_start_s, start_time=prep.start_time, end_time=prep.end_time, out="device")
+                  flow_start_s=prep.flow_start_s, start_time=prep.start_time, end_time=prep.end_time, out="device", key_hist=prep.key_hist)
     t3 = time.perf_counter()
     out_cols = ad.result_columns(prep, res, "EWMA", agg, "e2e")
     t4 = time.perf_counter()
@@ -187,7 +187,7 @@ if args.compare_host:
         shards[g] = (0, empty.getvalue())
     dev = ch.fetch_flows_device(client, eng, *pos, connections=G, pinned=not args.no_pinned)
     prep_d = ad.prepare_columns_device(dev, *pos, engine=eng)
-    res_d = eng.run("EWMA", prep_d.key_id, prep_d.flow_end_s, prep_d.value, max(prep_d.num_keys, 1), agg_flow=agg, key_id2=prep_d.key_id2)
+    res_d = eng.run("EWMA", prep_d.key_id, prep_d.flow_end_s, prep_d.value, max(prep_d.num_keys, 1), agg_flow=agg, key_id2=prep_d.key_id2, key_hist=prep_d.key_hist)
     rows_d = ad.result_rows(prep_d, res_d, "EWMA", agg, "e2e")
     import json
     canon = lambda rows: sorted(json.dumps(r, sort_keys=True) for r in rows)
