@@ -165,6 +165,15 @@ def test_job_with_the_factorisation_histogram_equals_the_job_without(engine, alg
         assert a.n_rows == b.n_rows and a.stats["n_points"] == b.stats["n_points"] and a.stats["rows_used"] == b.stats["rows_used"]
         for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
             assert (a[f] == b[f]).all(), f
+        # a STALE histogram — right shape, another batch's counts (here: the key column reversed) — must cost an attempt, never memory or rows:
+        # pass B writes nothing past a region, reports it, and the job counts for itself
+        kr = np.ascontiguousarray(k1[::-1])
+        kr2 = None if k2 is None else np.ascontiguousarray(k2[::-1])
+        e1 = eng.run(algo, kr, t, v, K, agg_flow=agg, key_id2=kr2)
+        e2 = eng.run(algo, kr, t, v, K, agg_flow=agg, key_id2=kr2, key_hist=hist)
+        assert e2.stats["hist_sampled"] != 2 and e2.stats["stage0_attempts"] == e1.stats["stage0_attempts"] + 1 and e1.n_rows == e2.n_rows
+        for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+            assert (e1[f] == e2[f]).all(), f
         # a histogram that does not belong to the batch (one row fewer) or a job with a time window: ignored, same rows
         c = eng.run(algo, k1[:-1], t[:-1], v[:-1], K, agg_flow=agg, key_id2=None if k2 is None else k2[:-1], key_hist=hist)
         assert c.stats["hist_sampled"] != 2
@@ -176,9 +185,10 @@ def test_job_with_the_factorisation_histogram_equals_the_job_without(engine, alg
         hist.free()
 
 
-def test_sparse_table_through_the_partition_sort_with_the_factorisation_histogram(engine):
+def test_sparse_table_through_the_partition_sort_counts_for_itself(engine):
     """A table whose grid would be mostly empty (6e5 keys x 60 buckets for 4.3e6 rows) takes the sparse Stage 0 through pass A / pass B
-    (stage0_path 8): the key-bin histogram it plans its sort rounds from may be the factorisation's too."""
+    (stage0_path 8).  Its LDS sort rounds are planned from the histogram with sizes it relies on, so a caller's histogram is not used
+    there: the job redoes pass A with its own count (one more attempt) and gives the same rows."""
     rng = np.random.default_rng(18)
     n = 4_300_000
     raw = [rng.integers(0, 200_000, size=n).astype(np.int64), rng.integers(0, 3, size=n).astype(np.int64)]
@@ -186,7 +196,8 @@ def test_sparse_table_through_the_partition_sort_with_the_factorisation_histogra
     _, t, v = orc.synth_rows(3, n, 1000, 60)
     a = engine.run("EWMA", k1, t, v, first.size, agg_flow="svc")
     b = engine.run("EWMA", k1, t, v, first.size, agg_flow="svc", key_hist=hist)
-    assert a.stats["stage0_path"] == b.stats["stage0_path"] == 8 and b.stats["hist_sampled"] == 2 and a.stats["hist_sampled"] == 0
+    assert a.stats["stage0_path"] == b.stats["stage0_path"] == 8 and b.stats["hist_sampled"] == 0 and a.stats["hist_sampled"] == 0
+    assert a.stats["stage0_attempts"] == 1 and b.stats["stage0_attempts"] == 2
     assert a.n_rows == b.n_rows > 0 and a.stats["n_points"] == b.stats["n_points"]
     for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
         assert (a[f] == b[f]).all(), f

@@ -315,6 +315,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
   // the estimate with 6 sigma of slack; a region that still turns out too small (keys arriving in bursts the sample missed)
   // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  tad_plan.histogram = 1 disables it.
   bool force_exact_hist = plan.histogram == 1;
+  bool kh_rejected = false;   // the caller's key-bin histogram did not describe the batch (a region overflowed): the job counts for itself
   bool sparse_lsd = plan.sparse_sort == 1;   // set when the partition + LDS-sort form of the sparse Stage 0 met a heavy key bin or a value too wide for its records
   // what the context's last job learnt about a table of this shape: skip the attempt that is known to fail
   {
@@ -341,7 +342,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
     // sized EXACTLY from the caller's counts.  Taken when it provably describes this batch and this job: same rows, keys, sides and row
     // chunking, no time-window filter (the histogram counted every kept row), the lattice still derived from a sample (lat_mode 1 or a hint).
     const tad_key_hist *kh = cols->key_hist;
-    bool use_kh = v2 && depth == 0 && kh != nullptr && kh->bins != nullptr && lat_mode != 2 && kh->n_rows == n && kh->num_keys == K &&
+    bool use_kh = v2 && depth == 0 && !kh_rejected && kh != nullptr && kh->bins != nullptr && lat_mode != 2 && kh->n_rows == n && kh->num_keys == K &&
                   kh->sides == (has2 ? 2u : 1u) && kh->workgroups == (uint32_t)pl.G && kh->nbins == pl.nbins && kh->shift == (uint32_t)pl.shift_bin &&
                   kh->chunk_rows == pl.chunk && rf.end_time == 0 && !(d_ts != nullptr && rf.start_time != 0);
     const uint32_t *binhist = nullptr;
@@ -419,6 +420,11 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
                    (plan.sparse != 1 && (cells_overflow || need > e->ws_limit || (cells >= (1ull << 24) && slots_all < cells / 8))));
     Grid sparse_grid{};
     bool sp_part = false;
+    if (sparse && use_kh) {
+      // the sparse sort plans LDS rounds of exactly known sizes from the histogram (k_ss_plan): only pass A's own count is trusted with that
+      kh_rejected = true;
+      continue;
+    }
     if (sparse) {
       // Big sparse tables (pass A ran with its key-bin histogram): the dense path's partition pass brings every key block's rows together as
       // 8-byte records, a workgroup per key sub-range sorts them in LDS (tad_sparse.hip: launch_sparse_sort) — the columns are read once and
@@ -661,6 +667,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
     if (c.err & DEV_ERR_LATE_ROW)
       return fail(e, TAD_ERR_INVALID_ARGUMENT, "tad_run_stream: a row is not newer than the last flowEndSeconds of its key's state; state unchanged");
     if (c.err & DEV_ERR_REGION_FULL) {   // a region sized from the sampled histogram was too small: exact histogram
+      if (use_kh) { kh_rejected = true; continue; }     // ... or the caller's histogram is not this batch's: pass A counts
       if (!force_exact_hist) { force_exact_hist = true; continue; }
       return fail(e, TAD_ERR_HIP, "internal error: a partition region overflowed with an exact histogram");
     }

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
   uint32_t *off = reinterpret_cast<uint32_t *>(smem + (size_t)S * 10);  // F + 1 entries
   uint32_t *gcur = off + (F + 1);  // next global record slot of (this workgroup, partition)
   uint32_t *delta = gcur + F;
-  uint32_t *gend = delta + F;      // end of the region (sampled regions: capacity, checked; exact regions: never reached)
+  uint32_t *gend = delta + F;      // end of the region: capacity, checked (exact counts of THIS batch never reach it; a caller's stale tad_key_hist can)
   __shared__ uint32_t s_wave[kPartThreads / 64];
   __shared__ uint32_t s_full;
 
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
       const uint32_t ps = (uint32_t)A.part_start[p];
       gcur[p] = ps + my_offs[p];
-      gend[p] = A.fin == nullptr ? 0xFFFFFFFFu : (last ? (uint32_t)A.part_start[p + 1] : ps + nx[p]);
+      gend[p] = last ? (uint32_t)A.part_start[p + 1] : ps + nx[p];
       off[p] = 0;
     }
     if (threadIdx.x == 0) s_full = 0;
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
     for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
       const uint32_t o = off[p], c = off[p + 1] - o;
       const uint32_t gc = gcur[p];
-      const bool full = c > gend[p] - gc;   // only with regions sized from a sampled histogram
+      const bool full = c > gend[p] - gc;   // regions sized from a sampled histogram, or from counts that are not this batch's
       delta[p] = full ? 0xFFFFFFFFu : gc - o;  // global slot of the partition's first record of this tile, minus its tile position
       if (!full) gcur[p] = gc + c;
       else s_full = 1;
@@ -721,8 +721,15 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
   if (A.fin != nullptr) {
     uint32_t *fo = A.fin + (size_t)blockIdx.x * F * 2;
     for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) { fo[2 * p] = gcur[p]; fo[2 * p + 1] = gend[p]; }
-    if (s_full) err |= DEV_ERR_REGION_FULL;
+  } else {
+    // exact regions are read whole by pass C: counts of this batch fill them to the last slot; counts that are not this batch's (a caller's
+    // tad_key_hist) may leave slots over, which become `no cell` fillers like the line padding of the write-combining pass
+    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads)
+      for (uint32_t g = gcur[p]; g < gend[p]; ++g) A.recs[g] = ~0ull;
   }
+  // a region that was too small: sampled histogram — or exact counts that are not this batch's (a caller's tad_key_hist): the records were
+  // left out, never written past the region; the host redoes the job with its own count
+  if (s_full) err |= DEV_ERR_REGION_FULL;
   block_count_rows(used, err, A.ctr);
 }
 
@@ -930,9 +937,11 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       else err |= DEV_ERR_REGION_FULL;
       uint32_t *fo = A.fin + ((size_t)blockIdx.x * F + p) * 2;
       fo[0] = g; fo[1] = e;
-    } else {
+    } else if (c <= e - g && g <= e) {
       for (uint32_t i = 0; i < c; ++i) A.recs[g + i] = q[p * cap + i];
       for (g += c; g < e; ++g) A.recs[g] = ~0ull;
+    } else {
+      err |= DEV_ERR_REGION_FULL;   // exact counts that are not this batch's (a caller's tad_key_hist): nothing is written past the region
     }
   }
   block_count_rows(used, err, A.ctr);

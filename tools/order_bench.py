@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""The C2 / C4 job on the SAME rows in the orders a caller can bring them in.  The synthetic table has its rows in arbitrary order; the
+`flows` table is `ORDER BY (timeInserted, flowEndSeconds)` (create_table.sh:85), so a read without ORDER BY delivers them roughly by time,
+and a pre-aggregated view (`pod_view_table`, create_table.sh:115) or a `GROUP BY` result delivers them by key.  Integer sum / max do not
+depend on the order, so every order must give the arbitrary order's rows bit for bit; what changes is which queues of pass B fill.
+
+usage: python tools/order_bench.py [--config c2|c4] [--rows N] [--jobs 10]"""
+import argparse
+import os
+import statistics
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from theia_amd import TadEngine  # noqa: E402
+
+CONFIGS = {"c2": dict(algo="EWMA", rows=100_000_000, keys=100_000, buckets=250, agg="svc"),
+           "c4": dict(algo="DBSCAN", rows=100_000_000, keys=1_000_000, buckets=100, agg="")}
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+ap.add_argument("--rows", type=int, default=0)
+ap.add_argument("--jobs", type=int, default=10)
+args = ap.parse_args()
+cfg = CONFIGS[args.config]
+n, K, T = args.rows or cfg["rows"], cfg["keys"], cfg["buckets"]
+dev = torch.device("cuda", 0)
+eng = TadEngine(0)
+key = torch.empty(n, dtype=torch.int64, device=dev)
+tend = torch.empty(n, dtype=torch.int64, device=dev)
+val = torch.empty(n, dtype=torch.int64, device=dev)
+eng.synth(0, n, K, T, into=(key, tend, val))
+
+
+def order(name):
+    if name == "arbitrary":
+        return None
+    if name == "by time":
+        return torch.sort(tend, stable=True).indices
+    if name == "by time, 64 K-row blocks shuffled within":     # rows of a block arrive together, blocks in time order
+        o = torch.sort(tend, stable=True).indices
+        blk = torch.arange(n, device=dev) >> 16
+        return o[torch.sort(blk * (1 << 20) + torch.randint(0, 1 << 20, (n,), device=dev)).indices]
+    if name == "by key":
+        return torch.sort(key, stable=True).indices
+    if name == "by (key, time)":
+        return torch.sort(key * 4096 + (tend - tend.min()) // 60, stable=True).indices
+    if name == "by (time, key)":
+        return torch.sort(((tend - tend.min()) // 60) * (1 << 21) + key, stable=True).indices
+    raise ValueError(name)
+
+
+want = None
+print("%s: %d rows, %d keys, %d buckets, %s" % (args.config, n, K, T, cfg["algo"]))
+for name in ("arbitrary", "by time", "by time, 64 K-row blocks shuffled within", "by key", "by (key, time)", "by (time, key)"):
+    o = order(name)
+    k, t, v = (key, tend, val) if o is None else (key[o].contiguous(), tend[o].contiguous(), val[o].contiguous())
+    del o
+    torch.cuda.synchronize()
+    res = eng.run(cfg["algo"], k, t, v, K, agg_flow=cfg["agg"])
+    got = {f: res[f].copy() for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev")}
+    st0 = res.stats
+    res.close()
+    if want is None:
+        want = got
+    same = all(got[f].shape == want[f].shape and (got[f] == want[f]).all() for f in want)
+    ms, pa, pb, s0, det = [], [], [], [], []
+    for _ in range(args.jobs):
+        t0 = time.perf_counter()
+        r = eng.run(cfg["algo"], k, t, v, K, agg_flow=cfg["agg"], out="device")
+        st = r.stats
+        r.close()
+        ms.append((time.perf_counter() - t0) * 1e3)
+        pa.append(st["ms_meta"]); pb.append(st["ms_scatter"]); s0.append(st["ms_stage0"]); det.append(st["ms_detect"])
+    md = statistics.median
+    print("  %-42s %7.3f ms/job (pass A %.3f, stage 0 %.3f [pass B %.3f], detect %.3f) path %d attempts %d/%d hist_sampled %d | %d rows %s"
+          % (name, md(ms), md(pa), md(s0), md(pb), md(det), st["stage0_path"], st0["stage0_attempts"], st["stage0_attempts"],
+             st["hist_sampled"], got["key_id"].size, "== arbitrary order's" if same else "DIFFER from the arbitrary order's"))
+    del k, t, v
+eng.close()
