@@ -337,6 +337,43 @@ def test_job_hot_key_partition_is_split_across_workgroups(engine, stage0, agg):
     check_job(engine, "EWMA", k, t, v, 300, agg_flow=agg)
 
 
+@pytest.mark.parametrize("order", ["by_key", "by_time_key", "first_appearance_ids", "runs_of_one_key"])
+@pytest.mark.parametrize("agg", ["svc", ""])
+def test_job_rows_in_the_orders_a_caller_brings_them(engine, stage0, order, agg):
+    """The synthetic table has its rows in arbitrary order.  A GROUP BY result or a view ordered by its key arrives sorted by key, a read of
+    `flows` (ORDER BY (timeInserted, flowEndSeconds), create_table.sh:85) by time, and any dictionary encoder hands out ids in order of first
+    appearance (the first rows of the table then carry ascending ids).  Whole wavefronts of pass A / pass B then meet on ONE histogram bin /
+    partition and are handled together (k_partition_wc: one slice of the region's top per wavefront); integer sum / max do not depend on the
+    row order, so every order gives the oracle's rows bit for bit.  Many keys x few buckets: 157 partitions of 128 keys at 2e4 keys."""
+    rng = np.random.default_rng(23)
+    n, K, T = 600_000, 20_000, 24
+    k, t, v = orc.synth_rows(5, n, K, T)
+    v = np.where(rng.random(n) < 0.0005, rng.integers(2**50, 2**64 - 1, size=n, dtype=np.uint64), v)   # the overflow list stays in play
+    if order == "by_key":
+        o = np.argsort(k, kind="stable")
+    elif order == "by_time_key":
+        o = np.lexsort((k, t))
+    elif order == "runs_of_one_key":     # 48-row runs of one key between arbitrary rows: part of a wavefront on one partition, part not
+        o = np.arange(n)
+        srt = np.argsort(k[: n // 2], kind="stable")
+        blocks = srt[: (srt.size // 48) * 48].reshape(-1, 48)
+        rest = np.setdiff1d(o, blocks.ravel())
+        rest = rest[rng.permutation(rest.size)]
+        cut = np.sort(rng.integers(0, rest.size, size=blocks.shape[0]))
+        o = np.concatenate([np.concatenate([blocks[i], rest[(cut[i - 1] if i else 0):cut[i]]]) for i in range(blocks.shape[0])] + [rest[cut[-1]:]])
+        assert o.size == n and np.unique(o).size == n
+    else:
+        o = np.arange(n)
+        _, first = np.unique(k, return_index=True)           # keys ascending -> their first rows
+        newid = np.empty(K, dtype=np.uint64)
+        present = np.unique(k)
+        newid[present[np.argsort(first, kind="stable")]] = np.arange(present.size, dtype=np.uint64)
+        k = newid[k]
+        assert k[0] == 0 and k[:1000].max() < 1000
+    k, t, v = np.ascontiguousarray(k[o]), np.ascontiguousarray(t[o]), np.ascontiguousarray(v[o])
+    check_job(engine, "EWMA", k, t, v, K, agg_flow=agg)
+
+
 @pytest.mark.parametrize("op", ["sum", "max"])
 def test_aggregate_points_and_reaggregation_of_partials(engine, op):
     # tad_aggregate = Stage 0 alone.  (1) its points equal the oracle's GROUP BY bit for bit (values as uint64, wrap

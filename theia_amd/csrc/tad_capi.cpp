@@ -315,13 +315,17 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
   // the estimate with 6 sigma of slack; a region that still turns out too small (keys arriving in bursts the sample missed)
   // raises DEV_ERR_REGION_FULL and the job is redone with the exact histogram.  tad_plan.histogram = 1 disables it.
   bool force_exact_hist = plan.histogram == 1;
+  bool learnt_exact_hist = false, probing_sampled_hist = false;   // (JobCtx::Learnt: the exact histogram on the last job's word / the sample on probation)
   bool kh_rejected = false;   // the caller's key-bin histogram did not describe the batch (a region overflowed): the job counts for itself
   bool sparse_lsd = plan.sparse_sort == 1;   // set when the partition + LDS-sort form of the sparse Stage 0 met a heavy key bin or a value too wide for its records
   // what the context's last job learnt about a table of this shape: skip the attempt that is known to fail
   {
     const JobCtx::Learnt &lt = e->learnt;
     if (depth == 0 && lt.valid && lt.n == n && lt.K == K && lt.has2 == has2 && lt.algo == (int)job->algo && lt.op == (int)op_max) {
-      if (lt.exact_hist) force_exact_hist = true;
+      if (lt.exact_hist) {
+        if (lt.exact_uses >= lt.exact_backoff) probing_sampled_hist = true;   // time to try the sample again
+        else { force_exact_hist = true; learnt_exact_hist = true; }
+      }
       if (lt.wide_tiles) force_wide_tiles = true;
     }
   }
@@ -830,8 +834,12 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
     hipEventElapsedTime(&st.ms_total, e->ev[0], e->ev[4]);
     if (depth == 0 && !points_mode && !stream) {
       JobCtx::Learnt &w = e->learnt;
+      const bool exact_now = force_exact_hist && plan.histogram != 1;
+      if (learnt_exact_hist) w.exact_uses++;                                           // same table shape, the exact histogram once more
+      else if (probing_sampled_hist) { w.exact_uses = 0; w.exact_backoff = exact_now ? (w.exact_backoff < 64 ? w.exact_backoff * 2 : 64) : 8; }
+      else { w.exact_uses = 0; w.exact_backoff = 8; }
       w.valid = true; w.n = n; w.K = K; w.has2 = has2; w.algo = (int)job->algo; w.op = (int)op_max;
-      w.exact_hist = force_exact_hist && plan.histogram != 1;
+      w.exact_hist = exact_now;
       w.wide_tiles = force_wide_tiles && plan.tile_cells != 1;
     }
     strncpy(rp->pub.id, job->id, sizeof rp->pub.id - 1);

@@ -112,7 +112,9 @@ struct JobCtx {
     uint64_t n = 0, K = 0;
     bool has2 = false;
     int algo = 0, op = 0;
-    bool exact_hist = false;   // the sampled histogram proved too optimistic for this table: go straight to the exact one
+    bool exact_hist = false;   // the sampled histogram proved too optimistic for this table: go straight to the exact one ...
+    uint32_t exact_uses = 0, exact_backoff = 8;   // ... for `exact_backoff` jobs, then the sample is tried again (a sorted table may be followed by
+                                                  // hashed ones of the same shape); a probe that fails doubles the interval, up to 64
     bool wide_tiles = false;   // 32-bit tile cells overflowed the list for this table: go straight to 8-byte cells
   } learnt;
 };

@@ -124,16 +124,40 @@ struct MetaAcc {
   uint32_t err;
 };
 
+#ifndef TAD_WAVE_AGG             // measurement builds: -DTAD_WAVE_AGG=0 takes the wavefront aggregation out of pass A and pass B
+#define TAD_WAVE_AGG 1
+#endif
+#ifndef TAD_WAVE_AGG_MIN
+#define TAD_WAVE_AGG_MIN 8
+#endif
+// lanes of a wavefront on one partition / one histogram bin from which they are handled together: 8 records = one 64-byte sector (hashed keys
+// put 8 of 64 lanes on one of ~800 partitions with probability < 1e-9; a table of very few keys takes this path all the time, and may)
+static constexpr int kWaveAggMin = TAD_WAVE_AGG_MIN;
+
+// one count for a key bin.  Sorted rows put a whole wavefront on one bin — 64 atomics on one LDS word; the lanes that share the first
+// active lane's bin add their number at once when they are many (hashed keys never are).
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin) {
+#if TAD_WAVE_AGG
+  const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin);
+  const unsigned long long grp = __ballot(bin == b0);
+  if (__popcll(grp) >= kWaveAggMin && bin == b0) {
+    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u)) == 0) atomicAdd(&hist[b0], (uint32_t)__popcll(grp));
+    return;
+  }
+#endif
+  atomicAdd(&hist[bin], 1u);
+}
+
 __device__ __forceinline__ void meta_row(MetaAcc &a, uint32_t *hist, uint64_t k1, uint64_t k2, int64_t te, bool kept,
                                          uint64_t K, int shift_bin) {
   if (!kept) return;
   bool counted = false;
   if (k1 != TAD_KEY_SKIP) {
-    if (k1 < K) { atomicAdd(&hist[(uint32_t)(k1 >> shift_bin)], 1u); counted = true; }
+    if (k1 < K) { hist_add(hist, (uint32_t)(k1 >> shift_bin)); counted = true; }
     else a.err |= DEV_ERR_KEY_RANGE;
   }
   if (k2 != TAD_KEY_SKIP) {
-    if (k2 < K) { atomicAdd(&hist[(uint32_t)(k2 >> shift_bin)], 1u); counted = true; }
+    if (k2 < K) { hist_add(hist, (uint32_t)(k2 >> shift_bin)); counted = true; }
     else a.err |= DEV_ERR_KEY_RANGE;
   }
   if (!counted) return;
@@ -154,11 +178,11 @@ __device__ __forceinline__ void meta_row(MetaAcc &a, uint32_t *hist, uint64_t k1
 // a row whose time is not sampled: histogram only
 __device__ __forceinline__ void hist_row(MetaAcc &a, uint32_t *hist, uint64_t k1, uint64_t k2, uint64_t K, int shift_bin) {
   if (k1 != TAD_KEY_SKIP) {
-    if (k1 < K) atomicAdd(&hist[(uint32_t)(k1 >> shift_bin)], 1u);
+    if (k1 < K) hist_add(hist, (uint32_t)(k1 >> shift_bin));
     else a.err |= DEV_ERR_KEY_RANGE;
   }
   if (k2 != TAD_KEY_SKIP) {
-    if (k2 < K) atomicAdd(&hist[(uint32_t)(k2 >> shift_bin)], 1u);
+    if (k2 < K) hist_add(hist, (uint32_t)(k2 >> shift_bin));
     else a.err |= DEV_ERR_KEY_RANGE;
   }
 }
@@ -870,6 +894,29 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
           }
           const uint32_t p = (uint32_t)(k >> A.shift_part);
           const unsigned long long rec = (vrec << A.cell_bits) | cell;
+#if TAD_WAVE_AGG
+          // Rows that arrive sorted (a GROUP BY result, a view ordered by its key; the first rows of any table whose ids were handed out in
+          // order of first appearance) send most lanes of a wavefront to ONE partition: 64 atomics on one LDS word, a queue of ~20 slots
+          // for hundreds of records.  The lanes that share the first active lane's partition take, when they are many, one slice of the
+          // region's top together — one atomic, consecutive slots, one coalesced store; hashed keys never meet the condition.
+          {
+            uint32_t p0 = __builtin_amdgcn_readfirstlane(p);
+            unsigned long long grp = __ballot(p == p0);
+            if (__popcll(grp) < kWaveAggMin) {   // (the first lane may hold the odd row out — an old key among new ones: ask the last lane too)
+              p0 = __builtin_amdgcn_readlane(p, 63 - __clzll(__ballot(true)));
+              grp = __ballot(p == p0);
+            }
+            if (__popcll(grp) >= kWaveAggMin && p == p0) {
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u));
+              uint32_t k0 = 0;
+              if (rank == 0) k0 = atomicAdd(&nsp[p0], (uint32_t)__popcll(grp));
+              k0 = __builtin_amdgcn_readfirstlane(k0) + rank;
+              if (k0 < gend[p0] - gcur[p0]) A.recs[gend[p0] - 1u - k0] = rec;
+              else err |= DEV_ERR_REGION_FULL;
+              continue;
+            }
+          }
+#endif
           const uint32_t pos = atomicAdd(&cnt[p], 1u);
           // the append that makes the queue hold a whole piece registers it for this tile's emit phase (round 5: there used to be a scan over all
           // queues behind a barrier of its own).  A queue leaves the emit phase with fewer than SEC records, so its count passes SEC - 1 exactly
@@ -880,7 +927,15 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
             const uint32_t k = atomicAdd(&nsp[p], 1u);
             if (k < gend[p] - gcur[p]) {                                  // (gcur only moves in the emit phase)
               const uint32_t at = gend[p] - 1u - k;
+#if TAD_WAVE_AGG
+              const unsigned long long spl = __ballot(true);      // one update of the parking counter per wavefront, not per record
+              const uint32_t srank = __builtin_amdgcn_mbcnt_hi((uint32_t)(spl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)spl, 0u));
+              uint32_t sl = 0;
+              if (srank == 0) sl = atomicAdd(&s_nspill, (uint32_t)__popcll(spl));
+              sl = __builtin_amdgcn_readfirstlane(sl) + srank;
+#else
               const uint32_t sl = atomicAdd(&s_nspill, 1u);
+#endif
               if (sl < kSpillSlots) { s_spill_rec[sl] = rec; s_spill_at[sl] = at; }   // stored in the emit phase
               else A.recs[at] = rec;                                       // a hot key: more spills in one tile than the buffer holds
             } else err |= DEV_ERR_REGION_FULL;                             // sampled regions only: the region is full
