@@ -270,18 +270,20 @@ def test_job_sparse_live_rows_in_an_unsampled_stretch(engine, stage0):
 
 
 def test_job_sampled_histogram_too_optimistic_falls_back_to_exact(engine, stage0):
-    # Stage-0 v2 sizes pass B's (workgroup, partition) regions from a SAMPLE of the key column (one 8192-row iteration in
-    # sixteen of every workgroup's chunk + the chunk ends; eight until late in round 3).  Here 16 keys occur ONLY in stretches the sample skips: their
-    # regions are sized for nothing, pass B finds them full (DEV_ERR_REGION_FULL) and the job must be redone with the exact
-    # histogram — same rows as the oracle, bit for bit.
+    # Stage-0 v2 sizes pass B's (workgroup, partition) regions from a SAMPLE of the key column: of every 8192-row iteration of a workgroup's
+    # chunk the 4 x 128 rows of ONE wavefront (wavefront it % 16 in iteration it), plus the chunk ends.  Here 16 keys occur ONLY in rows the
+    # sample skips: their regions are sized for nothing, pass B finds them full (DEV_ERR_REGION_FULL) and the job must be redone with the
+    # exact histogram — same rows as the oracle, bit for bit.
     if stage0 == "v1":
         pytest.skip("the direct scatter has no histogram")
     n, K, T = 26_000_000, 2000, 60
     k, t, v = orc.synth_rows_parallel(n, K, T)
     chunk = (((n + 255) // 256) + 1) & ~1
-    it = (np.arange(n, dtype=np.int64) % chunk) // 8192
+    pair = (np.arange(n, dtype=np.int64) % chunk) // 2         # a lane loads two rows; lane l of iteration it: pairs it * 4096 + u * 1024 + l
+    it = pair // 4096
+    wave = (pair % 1024) // 64
     nit = (chunk + 8191) // 8192
-    hidden = (it % 8 >= 2) & (it % 8 <= 6) & (it < nit - 3)
+    hidden = (wave == (it + 5) % 16) & (it < nit - 3)           # a sixteenth of the rows, none of them in the sample
     k = np.where(hidden, k % np.uint64(16), np.uint64(16) + k % np.uint64(K - 16))
     want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
     res = engine.run("EWMA", k, t, v, K, agg_flow="svc")

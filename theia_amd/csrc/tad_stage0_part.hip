@@ -127,12 +127,16 @@ struct MetaAcc {
 #ifndef TAD_WAVE_AGG             // measurement builds: -DTAD_WAVE_AGG=0 takes the wavefront aggregation out of pass A and pass B
 #define TAD_WAVE_AGG 1
 #endif
+#ifndef TAD_ADAPTIVE_QUEUES       // measurement builds: -DTAD_ADAPTIVE_QUEUES=0 gives every partition's queue the same depth
+#define TAD_ADAPTIVE_QUEUES 1
+#endif
 #ifndef TAD_WAVE_AGG_MIN
 #define TAD_WAVE_AGG_MIN 8
 #endif
 // lanes of a wavefront on one partition / one histogram bin from which they are handled together: 8 records = one 64-byte sector (hashed keys
 // put 8 of 64 lanes on one of ~800 partitions with probability < 1e-9; a table of very few keys takes this path all the time, and may)
 static constexpr int kWaveAggMin = TAD_WAVE_AGG_MIN;
+static constexpr size_t kWcFixedBytes = 18;   // LDS of k_partition_wc per partition beside its queue: cnt, gcur, gend, nsp u32, jobs u16 (+ 4 bytes: cnt has F + 1 words)
 
 // one count for a key bin.  Sorted rows put a whole wavefront on one bin — 64 atomics on one LDS word; the lanes that share the first
 // active lane's bin add their number at once when they are many (hashed keys never are).
@@ -231,8 +235,11 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
     uint64_t i = threadIdx.x;
     uint32_t it = 0;
     for (; i + (U - 1) * kPartThreads < npair; i += U * kPartThreads, ++it) {
-      const bool with_t = !sample_t || (it & kSampleMask) == 0 || (i - threadIdx.x) + 2 * U * kPartThreads >= npair;  // workgroup-uniform
-      if (SAMPLE_H && !with_t) continue;   // sampled histogram: the unsampled iterations are not read at all
+      // wavefront-uniform.  The sample of an iteration is ONE of its sixteen wavefronts' rows (4 x 128 rows of the 8192), a different one every
+      // iteration — 1/16 of the bytes in 1 KB pieces, no stretch of 2048 rows unseen.  (Until round 6 it was every sixteenth iteration whole:
+      // rows sorted by key then hid entire partitions between two samples and every such job paid the exact retry.)
+      const bool with_t = !sample_t || (it & kSampleMask) == ((threadIdx.x >> 6) & kSampleMask) || (i - threadIdx.x) + 2 * U * kPartThreads >= npair;
+      if (SAMPLE_H && !with_t) continue;   // sampled histogram: the unsampled rows are not read at all
       seen += 2 * U;
       ulonglong2 k[U], k2[U];
       longlong2 t[U];
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
 // store instruction) and slides its remainder down.  A record that finds its queue full goes straight to the END of
 // the region (downward cursor, rare); at the end of the kernel the leftovers (< 8 per partition) and `no cell`
 // fillers close the gap, so pass C reads the same contiguous partitions as before and skips the fillers.
-// LDS: q[F * cap] u64 | cnt[F] | gcur[F] | gend[F] u32 | jobs[F] u16.  Tiles are small (RPT rows per thread, 2 * RPT
+// LDS: q[F * cap] u64 | cnt[F + 1] | gcur[F] | gend[F] | nsp[F] u32 | jobs[F] u16.  Tiles are small (RPT rows per thread, 2 * RPT
 // with a second key), two register sets alternate so that every load has more than a tile to land.
 // ------------------------------------------------------------------------------------------------
 
@@ -781,11 +788,18 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
   constexpr uint32_t TILE = (uint32_t)RPT * kPartThreads;
   const uint32_t F = A.nparts;
   unsigned long long *q = reinterpret_cast<unsigned long long *>(smem);
+  // cnt[p]: records in partition p's queue (low half; it runs past the queue's depth for the records that spilled, < 2^16 within a tile) under
+  // the queue's first slot in q (high half, constant): the append's one atomic returns both.  F + 1 words: a queue's depth is the next
+  // word's offset minus its own.
   uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + (size_t)F * cap * 8);
-  uint32_t *gcur = cnt + F;   // next sector of (this workgroup, partition), upward
+  uint32_t *gcur = cnt + F + 1;   // next sector of (this workgroup, partition), upward
   uint32_t *gend = gcur + F;  // end of the region (constant)
   uint32_t *nsp = gend + F;   // records spilled to the top of the region, downward from gend (a counter: it cannot wrap)
   uint16_t *jobs = reinterpret_cast<uint16_t *>(nsp + F);
+#if TAD_ADAPTIVE_QUEUES
+  __shared__ uint32_t s_red[3 * (kPartThreads / 64)];
+  __shared__ float s_redf[kPartThreads / 64];
+#endif
   // (the two counters below are written in a tile's APPEND phase and read in its emit phase: one pair per tile parity, so that clearing the
   //  pair of tile t — after the barrier that ends its emit phase — cannot meet an append of tile t + 1, which starts behind that same barrier)
   __shared__ uint32_t s_njobs2[2];
@@ -804,12 +818,63 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
     const bool last = (int)blockIdx.x + 1 == G;
     for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
       const uint32_t ps = (uint32_t)A.part_start[p];
-      cnt[p] = 0;
       nsp[p] = 0;
       gcur[p] = ps + my[p];
       gend[p] = last ? (uint32_t)A.part_start[p + 1] : ps + nx[p];
     }
     if (threadIdx.x == 0) { s_njobs2[0] = s_njobs2[1] = 0; s_nspill2[0] = s_nspill2[1] = 0; }
+  }
+  // Queue depths follow the workgroup's histogram row.  A queue keeps SEC - 1 slots for its leftovers; behind them it needs room for a
+  // tile's arrivals, ~Poisson(lambda_p) with lambda_p = the tile's record slots x the partition's share of this workgroup's records
+  // (region size = pass A's count, or its capacity estimate).  The pool is shared out as lambda_p + z sqrt(lambda_p) with ONE z for all
+  // partitions — equal overflow probability everywhere, which is what minimises the records that find their queue full.  Hashed keys:
+  // every queue as deep as the others, as before.  Keys that come and go with time, ids in order of first appearance, a hot key: the
+  // partitions a workgroup really feeds get the LDS of those it never touches, and their records leave as whole lines instead of one
+  // by one over the region's top.  Depths only steer WHERE a record waits: the records written, and everything downstream, do not change.
+  {
+#if TAD_ADAPTIVE_QUEUES
+    constexpr float kTileSlots = (float)(TILE * (HAS2 ? 2u : 1u));
+    const uint32_t pool = F * cap;
+    uint32_t *tmp = reinterpret_cast<uint32_t *>(q);     // (the queues are empty until the first append)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t rsum = 0, ract = 0, rmax = 0;      // (a thread reads the regions it wrote itself: same stride as the loop above)
+    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) { const uint32_t r = gend[p] - gcur[p]; rsum += r; ract += r != 0u; rmax = r > rmax ? r : rmax; }
+    for (int d = 32; d >= 1; d >>= 1) { rsum += __shfl_down(rsum, d); ract += __shfl_down(ract, d); const uint32_t o = __shfl_down(rmax, d); rmax = o > rmax ? o : rmax; }
+    if (lane == 0) { s_red[wave] = rsum; s_red[kPartThreads / 64 + wave] = ract; s_red[2 * (kPartThreads / 64) + wave] = rmax; }
+    lds_barrier();
+    rsum = 0; ract = 0; rmax = 0;
+    for (int w = 0; w < kPartThreads / 64; ++w) {
+      rsum += s_red[w]; ract += s_red[kPartThreads / 64 + w];
+      rmax = s_red[2 * (kPartThreads / 64) + w] > rmax ? s_red[2 * (kPartThreads / 64) + w] : rmax;
+    }
+    // ... when there is something to follow: a workgroup that feeds every partition about alike (no region above 1.5 x the mean, at least
+    // three quarters of them in use) keeps the equal depths — rounding lambda + z sqrt(lambda) to whole slots would give half of C4's
+    // queues 17 slots and the other half 18 for counts that differ by their Poisson noise (measured: pass B + 2.7 %)
+    const bool skewed = (unsigned long long)rmax * F * 2u > (unsigned long long)rsum * 3u || ract * 4u < F * 3u;
+    const float per_rec = rsum ? kTileSlots / (float)rsum : 0.0f;
+    float sq = 0.0f;
+    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) sq += sqrtf((float)(gend[p] - gcur[p]) * per_rec);
+    for (int d = 32; d >= 1; d >>= 1) sq += __shfl_down(sq, d);
+    if (lane == 0) s_redf[wave] = sq;
+    lds_barrier();
+    sq = 0.0f;
+    for (int w = 0; w < kPartThreads / 64; ++w) sq += s_redf[w];      // (fixed order: every thread gets the same bits)
+    // what is left after the leftovers' slots; half a slot per queue for the rounding below, two slots for the float sums
+    const float room = (float)pool - ((float)(SEC - 1) + 0.5f) * (float)ract - 2.0f;
+    const float z = room > kTileSlots && sq > 0.0f ? (room - kTileSlots) / sq : 0.0f;
+    const float shrink = room > kTileSlots ? 1.0f : (room > 0.0f ? room / kTileSlots : 0.0f);
+    for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
+      const uint32_t r = gend[p] - gcur[p];
+      const float lam = (float)r * per_rec;
+      tmp[p] = r ? (uint32_t)(SEC - 1) + (uint32_t)(lam * shrink + z * sqrtf(lam) + 0.5f) : 0u;
+    }
+    lds_barrier();
+    lds_exclusive_scan(tmp, F, s_red);
+    const bool ok = skewed && tmp[F] <= pool;                          // (the sum fits by the arithmetic above: a safety net, not a code path)
+    for (uint32_t p = threadIdx.x; p <= F; p += kPartThreads) cnt[p] = (ok ? tmp[p] : p * cap) << 16;   // (cnt lies behind the queues: no overlap with tmp)
+#else
+    for (uint32_t p = threadIdx.x; p <= F; p += kPartThreads) cnt[p] = (p * cap) << 16;
+#endif
   }
 
   const uint64_t lo = (uint64_t)blockIdx.x * A.chunk;
@@ -917,12 +982,13 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
             }
           }
 #endif
-          const uint32_t pos = atomicAdd(&cnt[p], 1u);
+          const uint32_t word = atomicAdd(&cnt[p], 1u);
+          const uint32_t pos = word & 0xFFFFu, qo = word >> 16, qc = (cnt[p + 1] >> 16) - qo;
           // the append that makes the queue hold a whole piece registers it for this tile's emit phase (round 5: there used to be a scan over all
           // queues behind a barrier of its own).  A queue leaves the emit phase with fewer than SEC records, so its count passes SEC - 1 exactly
           // once in a tile in which it ends up with a whole piece or more (the emit phase writes ALL its whole pieces), and never otherwise.
           if (pos == (uint32_t)SEC - 1u) jobs[atomicAdd(&s_njobs, 1u)] = (uint16_t)p;
-          if (pos < cap) q[p * cap + pos] = rec;
+          if (pos < qc) q[qo + pos] = rec;
           else {  // queue full (a burst, or a hot key): top of the region
             const uint32_t k = atomicAdd(&nsp[p], 1u);
             if (k < gend[p] - gcur[p]) {                                  // (gcur only moves in the emit phase)
@@ -952,8 +1018,9 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
     const uint32_t nj = s_njobs;
     for (uint32_t j = threadIdx.x / SEC; j < nj; j += kPartThreads / SEC) {
       const uint32_t p = jobs[j], sl = threadIdx.x & (SEC - 1u);
-      const uint32_t c0 = cnt[p], c = c0 < cap ? c0 : cap, g = gcur[p];      // (the count runs past cap for the records that spilled)
-      unsigned long long *qp = q + p * cap;
+      const uint32_t word = cnt[p], qo = word >> 16, qcap = (cnt[p + 1] >> 16) - qo;
+      const uint32_t c0 = word & 0xFFFFu, c = c0 < qcap ? c0 : qcap, g = gcur[p];      // (the count runs past the queue's depth for the records that spilled)
+      unsigned long long *qp = q + qo;
       const uint32_t whole = c & ~(uint32_t)(SEC - 1);
       const uint32_t room = gend[p] - g, sp = nsp[p];
       const bool fits = sp <= room && whole <= room - sp;   // always with exact regions; a region sized from a sampled histogram may be full
@@ -962,7 +1029,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       const bool mv = whole + sl < c;
       const unsigned long long tail = mv ? qp[whole + sl] : 0ull;
       if (mv) qp[sl] = tail;  // (one wavefront, LDS in order: every lane has read before any lane writes)
-      if (sl == 0) { cnt[p] = c - whole; gcur[p] = g + whole; }
+      if (sl == 0) { cnt[p] = (qo << 16) | (c - whole); gcur[p] = g + whole; }
     }
     {   // the parked spills of this tile
       const uint32_t ns = s_nspill < kSpillSlots ? s_nspill : kSpillSlots;
@@ -983,17 +1050,18 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
   // ---- close the regions: leftovers, then (exact regions) `no cell` fillers up to the spilled records; sampled regions keep
   // their slack untouched and record where the valid records end / the spilled ones start ----
   for (uint32_t p = threadIdx.x; p < F; p += kPartThreads) {
-    const uint32_t c = cnt[p] < cap ? cnt[p] : cap;
+    const uint32_t word = cnt[p], qo = word >> 16, qcap = (cnt[p + 1] >> 16) - qo;
+    const uint32_t c = (word & 0xFFFFu) < qcap ? (word & 0xFFFFu) : qcap;
     uint32_t g = gcur[p];
     const uint32_t room = gend[p] - g;
     const uint32_t e = gend[p] - (nsp[p] < room ? nsp[p] : room);   // first spilled record
     if (A.fin != nullptr) {
-      if (c <= e - g && g <= e) { for (uint32_t i = 0; i < c; ++i) A.recs[g + i] = q[p * cap + i]; g += c; }
+      if (c <= e - g && g <= e) { for (uint32_t i = 0; i < c; ++i) A.recs[g + i] = q[qo + i]; g += c; }
       else err |= DEV_ERR_REGION_FULL;
       uint32_t *fo = A.fin + ((size_t)blockIdx.x * F + p) * 2;
       fo[0] = g; fo[1] = e;
     } else if (c <= e - g && g <= e) {
-      for (uint32_t i = 0; i < c; ++i) A.recs[g + i] = q[p * cap + i];
+      for (uint32_t i = 0; i < c; ++i) A.recs[g + i] = q[qo + i];
       for (g += c; g < e; ++g) A.recs[g] = ~0ull;
     } else {
       err |= DEV_ERR_REGION_FULL;   // exact counts that are not this batch's (a caller's tad_key_hist): nothing is written past the region
@@ -1507,9 +1575,9 @@ void part_plan_wc(uint64_t slots, bool aligned, bool has2, int partition_pass, P
   pl->pad_slots = 0;
   if (partition_pass == 1) return;
   if (!aligned || pl->nparts == 0) return;
-  const size_t per = kLdsBudget / pl->nparts;
-  if (per < 18 + 8 * 9) return;
-  uint32_t cap = (uint32_t)((per - 18) / 8);
+  const size_t per = (kLdsBudget - 16) / pl->nparts;
+  if (per < kWcFixedBytes + 8 * 9) return;
+  uint32_t cap = (uint32_t)((per - kWcFixedBytes) / 8);
   if (cap > 64) cap = 64;
   // Whole 128-byte lines: 15 leftovers + room for a tile's arrivals.  Round 3 asked for 22 slots (at C4's 977 partitions = 18 slots lines measured
   // 0.99 against 0.80 ms for 64-byte sectors); that loss was the global store of the ~1 % spilled records between the LDS appends draining the
@@ -1622,7 +1690,7 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   // fast path: 16-byte loads, no time-window filter, bucket by one multiply-high
   const bool generic = !vec || L.mode == 2 || f.end_time != 0 || (f.start_time != 0 && t_start != nullptr);
   if (pl.wc_cap) {  // write-combining variant (the plan checked the alignment)
-    const size_t wlds = ((size_t)pl.nparts * (8 * (size_t)pl.wc_cap + 18) + 15) & ~(size_t)15;
+    const size_t wlds = ((size_t)pl.nparts * (8 * (size_t)pl.wc_cap + kWcFixedBytes) + 4 + 15) & ~(size_t)15;
 #define TAD_WC(RPT, SEC, H2, GEN)                                                                                       \
   do {                                                                                                                \
     allow_big_lds(reinterpret_cast<const void *>(k_partition_wc<RPT, SEC, H2, GEN>), kLdsBudget);                      \
