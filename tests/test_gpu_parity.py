@@ -299,6 +299,24 @@ def test_job_sampled_histogram_too_optimistic_falls_back_to_exact(engine, stage0
         assert res2.stats["stage0_attempts"] == 1 and res2.stats["hist_sampled"] == 1
 
 
+@pytest.mark.parametrize("window", ["end_80", "start_end_60", "one_bucket"])
+def test_job_time_window_through_the_sampled_histogram(engine, stage0, window):
+    """`theia tad run --start-time / --end-time` (anomaly_detection.py:581-586) on a table big enough for the sampled pass A: the window is
+    applied to the sampled rows (histogram of the KEPT rows, lattice of the kept rows) and to every row in pass B.  A window that keeps one bucket in fifty leaves the sample little to see: whatever path the
+    engine settles on, the rows are the oracle's."""
+    n, K, T = 6_000_000, 3000, 50
+    k, t, v = orc.synth_rows(0, n, K, T)
+    ts = t - 30
+    lo, hi = int(t.min()), int(t.max())
+    kw = {"end_80": dict(end_time=lo + (hi - lo) * 4 // 5),
+          "start_end_60": dict(flow_start_s=ts, start_time=lo + (hi - lo) // 5, end_time=lo + (hi - lo) * 4 // 5),
+          "one_bucket": dict(flow_start_s=ts, start_time=lo + 60 * 20 - 30, end_time=lo + 60 * 21)}[window]
+    res, want = check_job(engine, "EWMA", k, t, v, K, agg_flow="svc", **kw)
+    assert 0 < res.stats["rows_used"] < n
+    if stage0 != "v1" and window != "one_bucket":
+        assert res.stats["hist_sampled"] == 1 and res.stats["stage0_attempts"] == 1
+
+
 def test_key_out_of_range_in_a_row_the_sampled_histogram_skips_is_an_error(engine, stage0):
     """TAD_ERR_KEY_RANGE is the contract for a key id >= num_keys.  With a sampled histogram pass A reads one row in sixteen, so the check must
     also live in pass B, which reads every row: until round 6 a bad key outside the sample was silently dropped."""

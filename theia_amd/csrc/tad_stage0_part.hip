@@ -231,7 +231,9 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
     // Without a time-window filter the time column is only needed for (min, max, sampled gcd): read it for one
     // iteration in sixteen plus both ends of the chunk (time-ordered tables have their extremes there) and let the
     // partition pass, which checks every row against the lattice, catch a missed extreme (-> exact re-derivation).
-    const bool sample_t = f.end_time == 0 && !has_ts;
+    // (a job with a time window tests its rows here too: with a sampled histogram the sampled rows — a window narrower than the sample's
+    //  reach shows as `no live row` or as a region found full, and the job is redone exactly; with an exact histogram every row, as it must)
+    const bool sample_t = SAMPLE_H || (f.end_time == 0 && !has_ts);
     uint64_t i = threadIdx.x;
     uint32_t it = 0;
     for (; i + (U - 1) * kPartThreads < npair; i += U * kPartThreads, ++it) {
@@ -924,6 +926,8 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       bool kept = true;
       if (GENERIC && (A.f.end_time != 0 || has_ts)) {
         const uint64_t i = row_index(base, j);
+        // (the start times prefetched with the tile's other columns — 16 more registers per row set — measured slower: pass B 0.870 against 0.830 ms
+        //  with a start_time, 0.742 against 0.696 with an end_time alone, profiles/r6_s14_*)
         const int64_t ts = (has_ts && i < hi) ? A.t_start[i] : 0;
         kept = p_time_kept(te, ts, has_ts, A.f);
       }
@@ -1608,8 +1612,8 @@ bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
                       MetaPartial *partials, uint32_t *binhist, DevCounters *ctr, bool sample_hist) {
   const bool vec = aligned16(key) && aligned16(key2) && aligned16(t_end);
   const bool has2 = key2 != nullptr;
-  // the histogram can only be sampled where the time column is (no time-window filter, 16-byte loads)
-  const bool sh = sample_hist && vec && f.end_time == 0 && !(t_start != nullptr && f.start_time != 0);
+  // the histogram is sampled with 16-byte loads only; a time-window filter (anomaly_detection.py:581-586) is applied to the sampled rows
+  const bool sh = sample_hist && vec && (t_start == nullptr || f.start_time == 0 || aligned16(t_start));
 #define TAD_MH(V, H2, SH)                                                                                              \
   do {                                                                                                                 \
     allow_big_lds(reinterpret_cast<const void *>(k_meta_hist<V, H2, SH>), kLdsBudget);                                 \

@@ -129,6 +129,8 @@ for frac in (0.1, 0.01):
 
 # the job with a time window (theia tad run --start-time / --end-time -> anomaly_detection.py:581-586): every row is tested, pass A reads the
 # time column in full, the generic forms of pass A / pass B run
+eng.close()
+eng = TadEngine(0, library_path=args.library)      # (a fresh engine: the contexts of the one above remember the sorted tables of this shape)
 tstart = tend - 30
 t_lo, t_hi = int(tend.min()), int(tend.max())
 for name, kw in (("no window", {}),
