@@ -23,6 +23,10 @@ ap.add_argument("--rows", type=int, default=0, help="rows of the scale run (0 = 
 ap.add_argument("--only-scale", action="store_true")
 ap.add_argument("--algos", default="EWMA,DBSCAN")
 ap.add_argument("--sorts", default="auto", help="comma list of tad_plan.sparse_sort values for the scale run: auto, lsd, partition")
+ap.add_argument("--order", default="arbitrary", choices=["arbitrary", "time"],
+                help="scale run: rows in arbitrary order, or sorted by flowEndSeconds with the ids handed out in order of first appearance "
+                     "(what a read of `flows`, ORDER BY (timeInserted, flowEndSeconds), followed by a dictionary encode delivers)")
+ap.add_argument("--lifetime", type=int, default=86400, help="scale run: seconds of the day within which a connection's points fall")
 args = ap.parse_args()
 
 
@@ -53,11 +57,22 @@ def connection_table(rows, seed):
     K = max(1, rows // 100)
     P = rows // 3
     pk = rng.integers(0, K, size=P, dtype=np.int64).astype(np.uint64)
-    pt = 1660202814 + rng.integers(0, 86400, size=P, dtype=np.int64)
+    life = max(1, min(args.lifetime, 86400))
+    born = rng.integers(0, 86400 - life + 1, size=K, dtype=np.int64)
+    pt = 1660202814 + born[pk.astype(np.int64)] + rng.integers(0, life, size=P, dtype=np.int64)
     k, t = np.repeat(pk, 3), np.repeat(pt, 3)
     v = (1_000_000_000 + (mix64(k + np.uint64(3)) % np.uint64(3_000_000_000))).astype(np.uint64) + rng.integers(0, 2_000_000, size=k.size, dtype=np.int64).astype(np.uint64)
     order = rng.permutation(k.size)
-    return k[order], t[order], v[order], K
+    k, t, v = k[order], t[order], v[order]
+    if args.order == "time":
+        o = np.argsort(t, kind="stable")
+        k, t, v = k[o], t[o], v[o]
+        _, first = np.unique(k, return_index=True)
+        present = np.unique(k)
+        newid = np.zeros(K, dtype=np.uint64)
+        newid[present.astype(np.int64)[np.argsort(first, kind="stable")]] = np.arange(present.size, dtype=np.uint64)
+        k = newid[k.astype(np.int64)]
+    return k, t, v, K
 
 
 def time_jobs(label, eng, k, t, v, K):
@@ -71,9 +86,9 @@ def time_jobs(label, eng, k, t, v, K):
             st = r.stats
             r.close()
         ms = (time.perf_counter() - t0) / args.steps * 1e3
-        print("%s | %s: %d rows, %d points, %d anomalies, stage0_path %d: %.3f ms/job (stage0 %.3f ms = %.2e rows/s = %.0f GB/s on the 24 B/row "
+        print("%s | %s: %d rows, %d points, %d anomalies, stage0_path %d, attempts %d: %.3f ms/job (stage0 %.3f ms = %.2e rows/s = %.0f GB/s on the 24 B/row "
               "of the columns = %.3f of the 8 TB/s peak; detect %.3f) = %.2e rows/s per job"
-              % (label, algo, k.size, st["n_points"], st["n_anomalies"], st["stage0_path"], ms, st["ms_stage0"], k.size / st["ms_stage0"] * 1e3,
+              % (label, algo, k.size, st["n_points"], st["n_anomalies"], st["stage0_path"], st["stage0_attempts"], ms, st["ms_stage0"], k.size / st["ms_stage0"] * 1e3,
                  24 * k.size / st["ms_stage0"] / 1e6, 24 * k.size / st["ms_stage0"] / 1e6 / 8000.0, st["ms_detect"], k.size / ms * 1e3), flush=True)
     for a in (dk, dt, dv):
         a.free()
@@ -90,5 +105,6 @@ if args.rows:
     k, t, v, K = connection_table(args.rows, seed=7)
     for sort in args.sorts.split(","):
         eng = TadEngine(device=0, plan={} if sort == "auto" else {"sparse_sort": sort})
-        time_jobs("per-connection keys [sparse_sort %s]: %d connections x ~33 second-resolution points x 3 rows" % (sort, K), eng, k, t, v, K)
+        time_jobs("per-connection keys [sparse_sort %s, rows in %s order, lifetime %d s]: %d connections x ~33 second-resolution points x 3 rows"
+                  % (sort, args.order, args.lifetime, K), eng, k, t, v, K)
         eng.close()
