@@ -30,7 +30,10 @@ ROUND ROBIN over `config.tables` (4) synthetic tables of the workload's shape wi
 no step meets the columns of the step before it; `same_columns` is the old loop (one table, every step) beside it, `cold` the FIRST
 job of the engine in the process (allocations included).  `concurrency` (N = 1, default line): aggregate rows/s with 1 / 2 / 4 host
 threads submitting C2 jobs to the ONE engine (job contexts = stream pool, tad.h ABI 12), and the latency of C2 EWMA jobs submitted
-while a C3 ARIMA job runs.
+while a C3 ARIMA job runs.  `row_orders` (N = 1, default line): the C2 job on the SAME rows in the orders a caller can bring them in —
+ids handed out in order of first appearance (any dictionary encoder), rows by time (`flows` is ORDER BY (timeInserted, flowEndSeconds),
+create_table.sh:85), by key (a GROUP BY result), keys alive for a tenth of the table — and with an --end-time window; the synthetic
+table's rows are in arbitrary order with hashed ids.
 `cpu_baseline` = the oracle (numpy port of the reference
 job) timed on this box's host cores on a bounded sample.  ARIMA lines add `arima`: fits/s and the
 FP64 flop rate from the engine's Kalman-step counter (16 flop per step of the recursion the kernel executes; the
@@ -240,6 +243,75 @@ def concurrency_leg(eng, levels, serial_ms):
     return out
 
 
+def row_orders_leg(eng, dev):
+    """The C2 job on one table in the orders a caller can bring its rows in (tools/order_bench.py has the longer list).  Integer sum / max do
+    not depend on the order, so every permutation must give the arbitrary order's rows bit for bit (checked); what changes is which queues
+    of pass B fill.  Median ms per job over 10 jobs each, device-resident columns, result on the device."""
+    import statistics
+    import torch
+    c2 = CONFIGS["c2"]
+    n, K, T = c2["rows"], c2["keys"], c2["buckets"]
+    key = torch.empty(n, dtype=torch.int64, device=dev)
+    tend = torch.empty(n, dtype=torch.int64, device=dev)
+    val = torch.empty(n, dtype=torch.int64, device=dev)
+    eng.synth(0, n, K, T, into=(key, tend, val))
+    out = {"what": "C2 EWMA job, 1e8 rows, median ms per job of 10; `identical`: the result rows equal the arbitrary order's bit for bit"}
+    fields = ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev")
+
+    def time_job(k, t, v, **kw):
+        torch.cuda.synchronize()      # (the columns were written on torch's stream, the engine reads them on its own)
+        ms, st = [], None
+        for i in range(12):
+            t0 = time.perf_counter()
+            r = eng.run("EWMA", k, t, v, K, agg_flow=c2["agg"], out="device", **kw)
+            st = r.stats
+            r.close()
+            if i >= 2:
+                ms.append((time.perf_counter() - t0) * 1e3)
+        return {"ms_per_job": statistics.median(ms), "pass_b_ms": st["ms_scatter"], "stage0_attempts": st["stage0_attempts"], "hist_sampled": st["hist_sampled"]}
+
+    def rows_of(k, t, v):
+        torch.cuda.synchronize()
+        r = eng.run("EWMA", k, t, v, K, agg_flow=c2["agg"])
+        got = {f: r[f].copy() for f in fields}
+        r.close()
+        return got
+    want = rows_of(key, tend, val)
+    out["arbitrary"] = time_job(key, tend, val)
+    # ids in order of first appearance: the same series under other ids
+    first = torch.full((K,), n, dtype=torch.int64, device=dev).scatter_reduce(0, key, torch.arange(n, device=dev), "amin")
+    newid = torch.empty(K, dtype=torch.int64, device=dev)
+    newid[torch.sort(first).indices] = torch.arange(K, device=dev)
+    k2 = newid[key].contiguous()
+    got = rows_of(k2, tend, val)
+    old = torch.sort(newid).indices.cpu().numpy()[got["key_id"].astype(np.int64)]
+    perm = old.argsort(kind="stable")
+    same = got["key_id"].size == want["key_id"].size and (old[perm] == want["key_id"].astype(np.int64)).all() and \
+        all((got[f][perm] == want[f]).all() for f in fields[1:])
+    out["ids_by_first_appearance"] = dict(time_job(k2, tend, val), identical=bool(same))
+    del k2, first, newid
+    for name, o in (("by_time", torch.sort(tend, stable=True).indices), ("by_key", torch.sort(key, stable=True).indices)):
+        k, t, v = key[o].contiguous(), tend[o].contiguous(), val[o].contiguous()
+        del o
+        got = rows_of(k, t, v)
+        same = all(got[f].shape == want[f].shape and (got[f] == want[f]).all() for f in fields)
+        out[name] = dict(time_job(k, t, v), identical=bool(same))
+        del k, t, v
+    # keys that live for a tenth of the table, rows in time order: every workgroup of pass B sees a narrow range of ids
+    i = torch.arange(n, device=dev)
+    W = K // 10
+    k_live = ((i.double() * ((K - W) / n)).long() + (key * 2654435761 % W)) % K
+    t_live = tend.min() + 60 * ((i.double() * (T / n)).long())
+    del i
+    out["keys_alive_for_a_tenth_in_time_order"] = time_job(k_live, t_live, val)
+    del k_live, t_live
+    t_lo, t_hi = int(tend.min()), int(tend.max())
+    out["end_time_keeps_80_percent"] = time_job(key, tend, val, end_time=t_lo + (t_hi - t_lo) * 4 // 5)
+    del key, tend, val
+    torch.cuda.empty_cache()
+    return out
+
+
 def launch_ranks(n):
     """Run this same command line as `n` ranks of one node (python -m torch.distributed.run, one process per GPU) and return
     the launcher's exit code."""
@@ -284,6 +356,7 @@ def main():
                                                            "(different seeds, different device buffers); 1 = the same columns every step")
     ap.add_argument("--c5-shape", default="", help="N > 1: run the other_configs.c5 leg (BASELINE configs[4], key- and row-sharded) on a table of "
                                                      "ROWS,KEYS,BUCKETS in total instead of 1e9,1e6,250, whatever the headline is (reduced-size tests)")
+    ap.add_argument("--no-row-orders", action="store_true", help="N = 1 default line: skip the row_orders leg")
     ap.add_argument("--concurrency", default="1,2,4", help="N = 1 default line: host threads submitting C2 jobs to the one engine (job contexts); '' = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -662,6 +735,14 @@ def main():
             out["concurrency"] = concurrency_leg(eng, [int(x) for x in args.concurrency.split(",") if x], out["ms_per_step"])
         except Exception as exc:
             out["concurrency"] = {"error": repr(exc)[:300]}
+    if world == 1 and headline_is_c2 and not args.no_other_configs and not args.host_input and args.ingest == "keys" and not args.no_row_orders:
+        try:
+            eng_o = TadEngine(device=dev.index, plan=plan)     # (an engine of its own: its contexts learn from the sorted tables)
+            out["row_orders"] = row_orders_leg(eng_o, dev)
+            eng_o.close()
+        except Exception as exc:
+            out["row_orders"] = {"error": repr(exc)[:300]}
+            torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             algo = cfg["algos"][-1] if len(cfg["algos"]) > 1 else cfg["algos"][0]

@@ -2,7 +2,7 @@
 # Round-6 measurement call (the committed library): the full -m gpu suite, the default bench line (C2 headline over 4 tables + same_columns + cold +
 # concurrency + C4 + C3 + C5 at N = 1 with the CPU baselines), the host-input line, the cold probe, rocprofv3 kernel-trace stats of C2 / C4 / C3 / C5 at
 # N = 1 and of the sparse path, HBM PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, no tracing flags) for C2, C4, C5 and the sparse scale run,
-# tad_factorize / tad_encode_strings at 1e8 rows, the device ingest end to end at 1e8 rows.   usage: tools/gpu_measure_r6.sh <tag> [notests]
+# tad_factorize / tad_encode_strings at 1e8 rows, the row orders / key lifetimes / time windows of tools/order_bench.py, the device ingest end to end at 1e8 rows.   usage: tools/gpu_measure_r6.sh <tag> [notests]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1
 mkdir -p $O
@@ -14,6 +14,10 @@ timeout 300 python tools/cold_probe.py --config c2 > $O/cold_c2.log 2>&1
 timeout 300 python tools/cold_probe.py --config c4 > $O/cold_c4.log 2>&1
 timeout 400 python tools/sparse_bench.py --steps 5 --rows 100000000 --sorts lsd,auto > $O/sparse_bench.log 2>&1
 timeout 600 python tools/factorize_bench.py > $O/factorize_bench.log 2>&1
+( timeout 300 python tools/order_bench.py --config c2 2>&1 | grep -v amdgpu.ids ) > $O/order_c2.log
+( timeout 300 python tools/order_bench.py --config c4 2>&1 | grep -v amdgpu.ids ) > $O/order_c4.log
+( timeout 300 python tools/hist_byproduct_bench.py 2>&1 | grep -v amdgpu.ids ) > $O/hist_byproduct_c4.log
+( timeout 300 python tools/skew_check.py 100000000 0.0 0.1 0.5 2>&1 | grep -v amdgpu.ids ) > $O/hot_key.log
 timeout 600 python tools/strings_bench.py > $O/strings_bench.log 2>&1
 timeout 600 python tools/ingest_e2e.py --rows 100000000 --mode pod --connections 8 --compare-host 2000000 > $O/ingest_e2e_pod.log 2>&1
 timeout 600 python tools/ingest_e2e.py --rows 50000000 --mode default --connections 8 > $O/ingest_e2e_default.log 2>&1
@@ -57,5 +61,5 @@ for n in ("c2", "c4", "c5", "sparse"):
     print(n, "bytes fetched %.2f GB written %.2f GB per job (one launch of every kernel of the job)" % (sum(v["fetch_bytes"] for v in job.values()) / 1e9, sum(v["write_bytes"] for v in job.values()) / 1e9), {a: (round(b["fetch_bytes"] / 1e6), round(b["write_bytes"] / 1e6)) for a, b in k.items() if b["fetch_bytes"] + b["write_bytes"] > 2e7})
 PY
 rm -f $O/pmc_c*_fetch.csv $O/pmc_c*_write.csv $O/pmc_sparse_*.csv $O/kt_*.log $O/pmc_*.log
-cat $O/pytest.log $O/cold_c2.log $O/cold_c4.log $O/sparse_bench.log $O/factorize_bench.log $O/strings_bench.log $O/ingest_e2e_pod.log $O/ingest_e2e_default.log 2>/dev/null; python -c "
+cat $O/pytest.log $O/cold_c2.log $O/cold_c4.log $O/order_c2.log $O/order_c4.log $O/hist_byproduct_c4.log $O/hot_key.log $O/sparse_bench.log $O/factorize_bench.log $O/strings_bench.log $O/ingest_e2e_pod.log $O/ingest_e2e_default.log 2>/dev/null; python -c "
 import json; d=json.loads(open('$O/bench_default_line.json').read().strip().splitlines()[-1]); print('C2', d['ms_per_step'], d['roofline']['frac'], d['pipeline']['hbm_frac_whole_job']); [print(k, v.get('ms_per_step'), v.get('roofline',{}).get('frac')) for k,v in d.get('other_configs',{}).items()]; print(json.loads(open('$O/bench_host_input.json').read().strip().splitlines()[-1])['ms_per_step'])"

@@ -105,7 +105,7 @@ for frac in (0.1, 0.01):
     for name, o in (("in time order", None), ("the same rows shuffled", torch.sort(torch.randint(0, 1 << 40, (n,), device=dev)).indices)):
         k, t, v = (k_live, t_live, val) if o is None else (k_live[o].contiguous(), t_live[o].contiguous(), val[o].contiguous())
         del o
-        assert int(k.max()) < K and int(k.min()) >= 0
+        torch.cuda.synchronize()      # (the columns were written on torch's stream, the engine reads them on its own)
         r = eng.run(cfg["algo"], k, t, v, K, agg_flow=cfg["agg"])
         res[name] = {f: r[f].copy() for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev")}
         st0 = r.stats
