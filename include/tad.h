@@ -129,7 +129,10 @@ typedef struct {
  * 0.19 ms and 0.89 GB of its 1.55 ms there).  The factorisation has every row's id in registers when it writes key_id; counting there is
  * free.  `bins` is DEVICE memory of TAD_KEY_HIST_BYTES bytes supplied by the caller; the other fields are filled in by tad_factorize_hist
  * and checked by tad_run against its own plan — a histogram that does not belong to the batch (other row count, key count, sides) or that
- * the job cannot use (a time-window filter drops rows the histogram counted; a small batch has no pass A) is ignored. */
+ * the job cannot use (a time-window filter drops rows the histogram counted; a small batch has no pass A) is ignored.  A histogram of the right
+ * shape whose COUNTS are another batch's (a stale one) costs an attempt, never memory or rows: pass B writes nothing past a region, reports the
+ * region it found full, and the job is redone with pass A's own count (tad_stats.stage0_attempts).  The counts must be those tad_factorize_hist
+ * wrote: their sum is not checked against n_rows. */
 #define TAD_KEY_HIST_BYTES ((uint64_t)256 * 16384 * 4)
 typedef struct {
   uint64_t n_rows, num_keys;   /* the batch it was taken from */

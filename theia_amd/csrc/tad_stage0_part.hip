@@ -979,7 +979,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
               const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u));
               uint32_t k0 = 0;
               if (rank == 0) k0 = atomicAdd(&nsp[p0], (uint32_t)__popcll(grp));
-              k0 = __builtin_amdgcn_readfirstlane(k0) + rank;
+              k0 = (uint32_t)__shfl((int)k0, (int)__builtin_ctzll(grp)) + rank;   // (from the group's OWN first lane: right whichever lanes execute this together)
               if (k0 < gend[p0] - gcur[p0]) A.recs[gend[p0] - 1u - k0] = rec;
               else err |= DEV_ERR_REGION_FULL;
               continue;
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
               const uint32_t srank = __builtin_amdgcn_mbcnt_hi((uint32_t)(spl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)spl, 0u));
               uint32_t sl = 0;
               if (srank == 0) sl = atomicAdd(&s_nspill, (uint32_t)__popcll(spl));
-              sl = __builtin_amdgcn_readfirstlane(sl) + srank;
+              sl = (uint32_t)__shfl((int)sl, (int)__builtin_ctzll(spl)) + srank;
 #else
               const uint32_t sl = atomicAdd(&s_nspill, 1u);
 #endif

@@ -120,6 +120,14 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 // compiler-level wavefront barrier on the device (no instruction); here the lanes really have to meet
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::wave_op(hipemu::OP_BALLOT, 1u, 0, reinterpret_cast<uintptr_t>(__FILE__) * 1000003u + (unsigned)__LINE__))
 #define __builtin_amdgcn_readlane(v, l) __shfl((int)(v), (int)(l))
+// value of the lowest active lane (the lanes that reach the call site); lanes below this one within a ballot mask
+template <typename T> inline T hipemu_readfirstlane(T v, HIPEMU_SITE) {
+  const unsigned long long m = hipemu::wave_op(hipemu::OP_BALLOT, 1u, 0, HIPEMU_KEY);
+  return hipemu::from_bits<T>(hipemu::wave_op(hipemu::OP_SHFL, hipemu::to_bits(v), __builtin_ctzll(m), HIPEMU_KEY ^ 0x9E3779B9u));
+}
+#define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
+#define __builtin_amdgcn_mbcnt_lo(mask, acc) ((acc) + (unsigned)__builtin_popcount((unsigned)(mask) & (unsigned)(((threadIdx.x & 63u) >= 32u) ? 0xFFFFFFFFu : ((1u << (threadIdx.x & 31u)) - 1u))))
+#define __builtin_amdgcn_mbcnt_hi(mask, acc) ((acc) + (unsigned)__builtin_popcount((unsigned)(mask) & (unsigned)(((threadIdx.x & 63u) < 32u) ? 0u : ((1u << (threadIdx.x & 31u)) - 1u))))
 static inline long long __double_as_longlong(double v) { long long r; __builtin_memcpy(&r, &v, 8); return r; }
 static inline double __longlong_as_double(long long v) { double r; __builtin_memcpy(&r, &v, 8); return r; }
 #define __builtin_amdgcn_frexp_mant(x) hipemu::frexp_mant(x)
