@@ -299,6 +299,34 @@ def test_job_sampled_histogram_too_optimistic_falls_back_to_exact(engine, stage0
         assert res2.stats["stage0_attempts"] == 1 and res2.stats["hist_sampled"] == 1
 
 
+def test_exact_histogram_learnt_from_a_sorted_table_expires(stage0):
+    """A table sorted by key fails the sampled histogram (one wasted attempt) and the job context remembers that tables of this shape need the
+    exact pass A.  Hashed tables of the same shape that follow must not pay the slower pass for ever: after eight jobs the sample is tried
+    again, works, and stays.  Every job gives the oracle's rows."""
+    if stage0 != "v2wc":
+        pytest.skip("one Stage-0 strategy is enough: the memory is the job context's")
+    from theia_amd import TadEngine
+    n, K, T = 6_000_000, 3000, 50
+    k, t, v = orc.synth_rows(0, n, K, T)
+    o = np.argsort(k, kind="stable")
+    want = orc.run_job("EWMA", k, t, v, agg_flow="svc")
+    eng = TadEngine(device=0)
+    try:
+        def run(kk, tt, vv):
+            r = eng.run("EWMA", kk, tt, vv, K, agg_flow="svc")
+            assert r.n_rows == want["n_anomalies"]
+            for f in ("key_id", "flow_end_s", "throughput", "algo_calc", "stddev"):
+                assert (r[f] == want[f]).all(), f
+            return r.stats["stage0_attempts"], r.stats["hist_sampled"]
+        first = run(np.ascontiguousarray(k[o]), np.ascontiguousarray(t[o]), np.ascontiguousarray(v[o]))
+        assert first == (2, 0)                               # the sample was too optimistic for the sorted rows: exact on the retry
+        seen = [run(k, t, v) for _ in range(11)]
+        assert seen[:8] == [(1, 0)] * 8                      # on the sorted table's word: straight to the exact histogram
+        assert seen[8:] == [(1, 1)] * 3                      # the probe: the sample works for the hashed table, and is kept
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("window", ["end_80", "start_end_60", "one_bucket"])
 def test_job_time_window_through_the_sampled_histogram(engine, stage0, window):
     """`theia tad run --start-time / --end-time` (anomaly_detection.py:581-586) on a table big enough for the sampled pass A: the window is
