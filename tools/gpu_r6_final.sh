@@ -7,7 +7,7 @@ cd $R
 ( timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 ) > $O/pytest.log 2>&1
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) > $O/smoke.log 2>&1
 S=$(date +%s.%N); timeout 900 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err; E=$(date +%s.%N)
-echo "bench.py wall seconds: $(echo "$E - $S" | bc)" > $O/bench_wall.log
+echo "bench.py wall seconds: $(python -c "print($E - $S)")" > $O/bench_wall.log
 cat $O/pytest.log $O/smoke.log $O/bench_wall.log
 python - <<PY
 import json
