@@ -782,8 +782,14 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
 
 // SEC = records per emitted piece: 8 (one 64-byte sector) when LDS leaves only 9..12 queue slots per partition, 16 (one
 // whole 128-byte line — streaming speed in the micro-benchmark) when there are few enough partitions for >= 22 slots.
-template <int RPT, int SEC, bool HAS2, bool GENERIC>
+// TS (with GENERIC): the job has a start_time and a 16-byte aligned flowStartSeconds column — it is loaded with the tile's other columns, one
+// more unconditional 16-byte load per row pair.  (Loaded in the append phase, as the generic variant without TS still does for an unaligned
+// column, the load sits between the LDS appends and is waited for together with the prefetched rows of the next tile: pass B 0.80 against
+// 0.66 ms.  A first form prefetched it behind a run-time test inside load_tile: the compiler then cannot count the loads in flight and waits
+// for all of them everywhere — slower even for jobs without a start_time, profiles/r6_s14_*.)
+template <int RPT, int SEC, bool HAS2, bool GENERIC, bool TS = false>
 __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint32_t cap, int G) {
+  static_assert(!TS || GENERIC, "a start_time filter is a generic job");
   static_assert(RPT == 2 || RPT == 4, "rows per thread: one or two 16-byte loads per column");
   static_assert(SEC == 8 || SEC == 16, "emit one 64-byte sector or one 128-byte line");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -881,7 +887,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
 
   const uint64_t lo = (uint64_t)blockIdx.x * A.chunk;
   const uint64_t hi = lo + A.chunk < A.n ? lo + A.chunk : A.n;
-  const bool has_ts = GENERIC && A.t_start != nullptr && A.f.start_time != 0;
+  const bool has_ts = TS || (GENERIC && A.t_start != nullptr && A.f.start_time != 0);
   const uint32_t KP = A.kp_mask + 1u;
   const uint32_t cell_none = (1u << A.cell_bits) - 1u;
   const unsigned long long value_limit = A.value_limit;
@@ -889,7 +895,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
   const uint64_t nfull = hi > lo ? (hi - lo) / TILE : 0;
   const uint64_t ntiles = hi > lo ? (hi - lo + TILE - 1) / TILE : 0;
 
-  struct Rows { uint64_t k[RPT], k2[HAS2 ? RPT : 1], v[RPT]; int64_t t[RPT]; };
+  struct Rows { uint64_t k[RPT], k2[HAS2 ? RPT : 1], v[RPT]; int64_t t[RPT], ts[TS ? RPT : 1]; };
   auto row_index = [&](uint64_t base, int j) -> uint64_t { return base + (uint64_t)(j >> 1) * (2 * kPartThreads) + 2 * threadIdx.x + (j & 1); };
   auto load_tile = [&](Rows &r, uint64_t tile) {  // workgroup-uniform branches only
     const uint64_t base = lo + tile * TILE;
@@ -902,6 +908,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(A.value + i);
         r.k[j] = k.x; r.k[j + 1] = k.y; r.t[j] = t.x; r.t[j + 1] = t.y; r.v[j] = v.x; r.v[j + 1] = v.y;
         if (HAS2) { const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(A.key2 + i); r.k2[j] = k2.x; r.k2[j + 1] = k2.y; }
+        if (TS) { const longlong2 ts = *reinterpret_cast<const longlong2 *>(A.t_start + i); r.ts[TS ? j : 0] = ts.x; r.ts[TS ? j + 1 : 0] = ts.y; }
       }
     } else if (tile < ntiles) {
 #pragma unroll
@@ -912,6 +919,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
         r.t[j] = in ? A.t_end[i] : 0;
         r.v[j] = in ? A.value[i] : 0;
         if (HAS2) r.k2[j] = in ? A.key2[i] : TAD_KEY_SKIP;
+        if (TS) r.ts[TS ? j : 0] = in ? A.t_start[i] : 0;
       }
     }
   };
@@ -926,9 +934,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
       bool kept = true;
       if (GENERIC && (A.f.end_time != 0 || has_ts)) {
         const uint64_t i = row_index(base, j);
-        // (the start times prefetched with the tile's other columns — 16 more registers per row set — measured slower: pass B 0.870 against 0.830 ms
-        //  with a start_time, 0.742 against 0.696 with an end_time alone, profiles/r6_s14_*)
-        const int64_t ts = (has_ts && i < hi) ? A.t_start[i] : 0;
+        const int64_t ts = TS ? r.ts[TS ? j : 0] : ((has_ts && i < hi) ? A.t_start[i] : 0);
         kept = p_time_kept(te, ts, has_ts, A.f);
       }
       uint32_t bucket = 0;
@@ -1695,17 +1701,20 @@ void launch_partition(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
   const bool generic = !vec || L.mode == 2 || f.end_time != 0 || (f.start_time != 0 && t_start != nullptr);
   if (pl.wc_cap) {  // write-combining variant (the plan checked the alignment)
     const size_t wlds = ((size_t)pl.nparts * (8 * (size_t)pl.wc_cap + kWcFixedBytes) + 4 + 15) & ~(size_t)15;
-#define TAD_WC(RPT, SEC, H2, GEN)                                                                                       \
+    const bool ts16 = generic && t_start != nullptr && f.start_time != 0 && aligned16(t_start);   // start times prefetched with the tile
+#define TAD_WC1(RPT, SEC, H2, GEN, TS)                                                                                  \
   do {                                                                                                                \
-    allow_big_lds(reinterpret_cast<const void *>(k_partition_wc<RPT, SEC, H2, GEN>), kLdsBudget);                      \
-    hipLaunchKernelGGL((k_partition_wc<RPT, SEC, H2, GEN>), dim3(pl.G), dim3(kPartThreads), wlds, s, A, pl.wc_cap, pl.G); \
+    allow_big_lds(reinterpret_cast<const void *>(k_partition_wc<RPT, SEC, H2, GEN, TS>), kLdsBudget);                  \
+    hipLaunchKernelGGL((k_partition_wc<RPT, SEC, H2, GEN, TS>), dim3(pl.G), dim3(kPartThreads), wlds, s, A, pl.wc_cap, pl.G); \
   } while (0)
+#define TAD_WC(RPT, SEC, H2, GEN) do { if (GEN && ts16) TAD_WC1(RPT, SEC, H2, GEN, GEN); else TAD_WC1(RPT, SEC, H2, GEN, false); } while (0)
 #define TAD_WC_SEC(RPT, H2, GEN) do { if (pl.wc_sec == 16) TAD_WC(RPT, 16, H2, GEN); else TAD_WC(RPT, 8, H2, GEN); } while (0)
     if (pl.wc_rpt == 4 && !has2) { if (generic) TAD_WC_SEC(4, false, true); else TAD_WC_SEC(4, false, false); }
     else if (has2) { if (generic) TAD_WC_SEC(2, true, true); else TAD_WC_SEC(2, true, false); }
     else { if (generic) TAD_WC_SEC(2, false, true); else TAD_WC_SEC(2, false, false); }
 #undef TAD_WC_SEC
 #undef TAD_WC
+#undef TAD_WC1
     return;
   }
   int rpt = pl.rpt;
