@@ -581,7 +581,7 @@ int run_job_locked(JobCtx *e, const tad_job *job, const tad_columns *cols, tad_m
       unsigned long long *part_start = static_cast<unsigned long long *>(e->part_start.p);
       if ((rc = ensure(e, e->slices, slice_table_bytes(slots, pl))) != TAD_OK) return rc;
       launch_part_offsets(s, binhist, pl, offs32, static_cast<uint32_t *>(e->part_total.p), part_start,
-                          hist_sampled, static_cast<const MetaPartial *>(e->meta.p), n, slots, e->slices.p, g);
+                          hist_sampled, static_cast<const MetaPartial *>(e->meta.p), n, slots, e->slices.p, g, ctr);
       // (per-key statistics run as their own kernel: fusing them into the tile pass measured slower on MI355X — one
       // wavefront per tile walks a 250-step FP64 dependency chain while the CU's other wavefronts have nothing left to do)
       // DBSCAN job: pass C in settle mode — key rounds, the detector's per-key pass on the LDS tile, grid columns of unsettled keys only.

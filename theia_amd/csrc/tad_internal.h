@@ -357,7 +357,7 @@ bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 // the grid tile of every partition that will be split into several slices.
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
                          unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n, uint64_t slots, void *slice_mem,
-                         Grid g);
+                         Grid g, DevCounters *ctr = nullptr);   // ctr (sampled): DEV_ERR_REGION_FULL when a partition sits in a few large regions
 // upper bound of the record slots pass B may be given when the regions are sized from a sampled histogram
 uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl);
 // fin != NULL (sampled regions): no fillers; fin[(g * nparts + p) * 2 + {0, 1}] = end of the records written upwards /

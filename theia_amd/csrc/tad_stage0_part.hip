@@ -140,28 +140,29 @@ static constexpr size_t kWcFixedBytes = 18;   // LDS of k_partition_wc per parti
 
 // one count for a key bin.  Sorted rows put a whole wavefront on one bin — 64 atomics on one LDS word; the lanes that share the first
 // active lane's bin add their number at once when they are many (hashed keys never are).
-__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin) {
+// weight: the rows this one stands for (1, or the sampling interval for a row of a sampled stretch: a sampled histogram holds ESTIMATED rows)
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, uint32_t weight) {
 #if TAD_WAVE_AGG
   const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin);
   const unsigned long long grp = __ballot(bin == b0);
   if (__popcll(grp) >= kWaveAggMin && bin == b0) {
-    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u)) == 0) atomicAdd(&hist[b0], (uint32_t)__popcll(grp));
+    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u)) == 0) atomicAdd(&hist[b0], (uint32_t)__popcll(grp) * weight);
     return;
   }
 #endif
-  atomicAdd(&hist[bin], 1u);
+  atomicAdd(&hist[bin], weight);
 }
 
 __device__ __forceinline__ void meta_row(MetaAcc &a, uint32_t *hist, uint64_t k1, uint64_t k2, int64_t te, bool kept,
-                                         uint64_t K, int shift_bin) {
+                                         uint64_t K, int shift_bin, uint32_t weight = 1u) {
   if (!kept) return;
   bool counted = false;
   if (k1 != TAD_KEY_SKIP) {
-    if (k1 < K) { hist_add(hist, (uint32_t)(k1 >> shift_bin)); counted = true; }
+    if (k1 < K) { hist_add(hist, (uint32_t)(k1 >> shift_bin), weight); counted = true; }
     else a.err |= DEV_ERR_KEY_RANGE;
   }
   if (k2 != TAD_KEY_SKIP) {
-    if (k2 < K) { hist_add(hist, (uint32_t)(k2 >> shift_bin)); counted = true; }
+    if (k2 < K) { hist_add(hist, (uint32_t)(k2 >> shift_bin), weight); counted = true; }
     else a.err |= DEV_ERR_KEY_RANGE;
   }
   if (!counted) return;
@@ -182,11 +183,11 @@ __device__ __forceinline__ void meta_row(MetaAcc &a, uint32_t *hist, uint64_t k1
 // a row whose time is not sampled: histogram only
 __device__ __forceinline__ void hist_row(MetaAcc &a, uint32_t *hist, uint64_t k1, uint64_t k2, uint64_t K, int shift_bin) {
   if (k1 != TAD_KEY_SKIP) {
-    if (k1 < K) hist_add(hist, (uint32_t)(k1 >> shift_bin));
+    if (k1 < K) hist_add(hist, (uint32_t)(k1 >> shift_bin), 1u);
     else a.err |= DEV_ERR_KEY_RANGE;
   }
   if (k2 != TAD_KEY_SKIP) {
-    if (k2 < K) hist_add(hist, (uint32_t)(k2 >> shift_bin));
+    if (k2 < K) hist_add(hist, (uint32_t)(k2 >> shift_bin), 1u);
     else a.err |= DEV_ERR_KEY_RANGE;
   }
 }
@@ -240,8 +241,15 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
       // wavefront-uniform.  The sample of an iteration is ONE of its sixteen wavefronts' rows (4 x 128 rows of the 8192), a different one every
       // iteration — 1/16 of the bytes in 1 KB pieces, no stretch of 2048 rows unseen.  (Until round 6 it was every sixteenth iteration whole:
       // rows sorted by key then hid entire partitions between two samples and every such job paid the exact retry.)
-      const bool with_t = !sample_t || (it & kSampleMask) == ((threadIdx.x >> 6) & kSampleMask) || (i - threadIdx.x) + 2 * U * kPartThreads >= npair;
+      // The chunk's last two iterations (and its ragged tail) are read WHOLE — a time-ordered table has its extremes there.  Their rows count
+      // once; a row of the sampled stretches stands for kSampleMask + 1 rows: the histogram holds estimated rows that add up to the chunk's.
+      // (Until late in round 6 every row counted once and the estimate was count x rows / seen: the whole-read end pulled that scale
+      // down to ~9, and a partition whose rows all sit in the sampled stretch — keys that leave while the chunk is being read, in any
+      // time-ordered table — was under-estimated by almost half: its region overflowed and the job was redone with the exact histogram.)
+      const bool zone = (i - threadIdx.x) + 2 * U * kPartThreads >= npair;                                  // workgroup-uniform
+      const bool with_t = !sample_t || zone || (it & kSampleMask) == ((threadIdx.x >> 6) & kSampleMask);
       if (SAMPLE_H && !with_t) continue;   // sampled histogram: the unsampled rows are not read at all
+      const uint32_t weight = SAMPLE_H && !zone ? kSampleMask + 1u : 1u;
       seen += 2 * U;
       ulonglong2 k[U], k2[U];
       longlong2 t[U];
@@ -257,8 +265,8 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
         for (int u = 0; u < U; ++u) {
           const uint64_t r = lo + 2 * (i + u * kPartThreads);
           const int64_t ts0 = has_ts ? t_start[r] : 0, ts1 = has_ts ? t_start[r + 1] : 0;
-          meta_row(acc, hist, k[u].x, k2[u].x, t[u].x, p_time_kept(t[u].x, ts0, has_ts, f), K, shift_bin);
-          meta_row(acc, hist, k[u].y, k2[u].y, t[u].y, p_time_kept(t[u].y, ts1, has_ts, f), K, shift_bin);
+          meta_row(acc, hist, k[u].x, k2[u].x, t[u].x, p_time_kept(t[u].x, ts0, has_ts, f), K, shift_bin, weight);
+          meta_row(acc, hist, k[u].y, k2[u].y, t[u].y, p_time_kept(t[u].y, ts1, has_ts, f), K, shift_bin, weight);
         }
       } else {
 #pragma unroll
@@ -328,14 +336,20 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
 // ------------------------------------------------------------------------------------------------
 // offsets: cnt[g][p] (row reduce of the bins) -> column-wise exclusive prefix over g -> part_start[p]
 // ------------------------------------------------------------------------------------------------
-// Capacity of a (workgroup, partition) region from a SAMPLED count s at sampling ratio 1 / scale: the estimate s * scale
-// (std dev ~ sqrt(estimate * scale) for hashed keys) + 6 sigma + a floor for partitions the sample missed.  Too small
-// -> pass B raises DEV_ERR_REGION_FULL and the host reruns with the exact histogram; too large costs address space only
-// (nothing is written to or read from the slack).
-__device__ __forceinline__ uint32_t sampled_capacity(uint32_t s, double scale) {
-  const double est = (double)s * scale;
-  return (uint32_t)(est + 6.0 * sqrt(est * scale) + 8.0 * scale + 16.0);
+// Capacity of a (workgroup, partition) region from pass A's ESTIMATED record count (rows of the whole-read stretches once, rows of the
+// sampled stretches x the sampling interval): the estimate (std dev < sqrt(estimate * interval) for hashed keys) + 5.5 sigma + a floor for
+// partitions the sample missed.  Too small -> pass B raises DEV_ERR_REGION_FULL and the host reruns with the exact histogram.  Too large is
+// not free either: pass C's walk follows the address span of a partition's regions (6 sigma + 144: k_tile_aggregate 302-309 us at C2
+// against 295 with the ~17 % smaller regions of the estimator before — profiles/r6_s24_*).
+__device__ __forceinline__ uint32_t sampled_capacity(uint32_t est) {
+  constexpr double scale = (double)(kSampleMask + 1);
+  return (uint32_t)((double)est + 5.5 * sqrt((double)est * scale) + 6.0 * scale);
 }
+// Pass C walks sampled regions one wavefront per region.  A partition whose records sit in a FEW large regions (rows sorted by key: two
+// regions of 1e5 records) would be walked by one or two wavefronts — 1.4 ms of pass C at C2.  Such a table is sent to the exact histogram
+// (contiguous partitions, all sixteen wavefronts streaming) before pass B starts: k_part_offsets raises DEV_ERR_REGION_FULL, pass B returns
+// at once, pass C finds no slices (k_part_tail), the host redoes the job as it does for a region that overflowed.
+static constexpr uint32_t kBigSampledRegion = 8192;      // records; and more than 8x the partition's mean region
 
 // Work unit of pass C = a SLICE of at most slice_len record slots of one partition (k_tile_aggregate).
 struct SliceTable {
@@ -357,6 +371,7 @@ struct OffsetsArgs {
   uint32_t slice_len;
   Grid g;                        // the grid tile of a partition that will be split into several slices is zeroed here
   int shift_part;
+  DevCounters *ctr;              // sampled regions: DEV_ERR_REGION_FULL for a table the sampled layout does not suit (NULL: no check)
 };
 
 // TWO launches for everything between pass A and pass B (round 4; five before: k_part_rows, k_part_colscan — 256 dependent steps per
@@ -377,14 +392,7 @@ __global__ __launch_bounds__(256) void k_part_offsets(OffsetsArgs A) {
       const uint32_t *row = A.binhist + (size_t)gi * A.nbins;
       uint32_t c = 0;
       for (uint32_t b = b0; b < b1; ++b) c += row[b];
-      if (A.partials != nullptr) {
-        const uint64_t lo = (uint64_t)gi * A.chunk;
-        const uint64_t rows = lo < A.n ? (lo + A.chunk < A.n ? A.chunk : A.n - lo) : 0;
-        const uint64_t seen = A.partials[gi].seen;
-        double scale = seen ? (double)rows / (double)seen : 1.0;
-        if (scale < 1.0) scale = 1.0;
-        c = sampled_capacity(c, scale);
-      }
+      if (A.partials != nullptr) c = sampled_capacity(c);
       return (c + A.round_mask) & ~A.round_mask;
     };
     constexpr uint32_t kKeep = 4;                      // G <= 256: the lane's counts stay in registers between the two loops
@@ -419,6 +427,19 @@ __global__ __launch_bounds__(256) void k_part_offsets(OffsetsArgs A) {
       }
     }
     if (lane == 0) A.total[p] = tot;   // v2 requires n_rows * 2 < 2^32 (checked on the host)
+    if (A.partials != nullptr && A.ctr != nullptr) {   // sampled regions: is this partition concentrated in a few large ones?
+      bool big = false;
+      if (per <= kKeep) {
+#pragma unroll
+        for (uint32_t j = 0; j < kKeep; ++j) big |= kept[j] > kBigSampledRegion && (unsigned long long)kept[j] * (unsigned)A.G > 8ull * tot;
+      } else {
+        for (uint32_t j = 0; j < per; ++j) {
+          const uint32_t gi = lane * per + j;
+          if (gi < (uint32_t)A.G) { const uint32_t c = count_of(gi); big |= c > kBigSampledRegion && (unsigned long long)c * (unsigned)A.G > 8ull * tot; }
+        }
+      }
+      if (__any(big) && lane == 0) atomicOr(&A.ctr->err, DEV_ERR_REGION_FULL);
+    }
     if (tot > A.slice_len) {           // split partition: its slices merge into the pre-zeroed tile
       const uint32_t KP = 1u << A.shift_part;
       const uint64_t k0 = (uint64_t)p << A.shift_part, cells_all = (uint64_t)KP * A.g.T;
@@ -475,7 +496,9 @@ __global__ __launch_bounds__(256) void k_part_tail(OffsetsArgs A) {
       srun += k;
     }
   }
-  if (threadIdx.x == 0) { A.part_start[F] = rtot; *A.st.n_slices = stot; }
+  // (a table k_part_offsets sends to the exact histogram: no slices — pass C's workgroups return where they look their slice up, pass B returns
+  //  on the flag itself; a test of its own at the top of pass C was an exposed memory round trip per workgroup, + 0.01-0.03 ms at C2)
+  if (threadIdx.x == 0) { A.part_start[F] = rtot; *A.st.n_slices = (A.ctr != nullptr && (A.ctr->err & DEV_ERR_REGION_FULL)) ? 0u : stot; }
 }
 
 // rows_used / error bits of a workgroup: ONE atomic per workgroup.  One per wavefront was 4096 atomics on one address at the very
@@ -580,6 +603,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(PartArgs A) {
 
   // no global load may sit inside the tile loop: vmcnt retires in order, so waiting for one fresh load would
   // also wait for every prefetched row behind it
+  if (A.fin != nullptr && (A.ctr->err & DEV_ERR_REGION_FULL)) return;   // k_part_offsets: this table is redone with the exact histogram
   const uint32_t *my_offs = A.offs32 + (size_t)blockIdx.x * F;
   {
     const uint32_t *nx = A.offs32 + (size_t)(blockIdx.x + 1) * F;
@@ -820,6 +844,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition_wc(PartArgs A, uint3
   __shared__ uint32_t s_spill_at[kSpillSlots];
   __shared__ uint32_t s_nspill2[2];
 
+  if (A.fin != nullptr && (A.ctr->err & DEV_ERR_REGION_FULL)) return;   // k_part_offsets: this table is redone with the exact histogram
   {
     const uint32_t *my = A.offs32 + (size_t)blockIdx.x * F;
     const uint32_t *nx = A.offs32 + (size_t)(blockIdx.x + 1) * F;
@@ -1665,7 +1690,7 @@ static uint32_t slice_len_of(bool sampled, uint64_t slots, uint32_t nparts) {
 
 void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan &pl, uint32_t *offs32, uint32_t *total,
                          unsigned long long *part_start, bool sampled, const MetaPartial *partials, uint64_t n, uint64_t slots, void *slice_mem,
-                         Grid g) {
+                         Grid g, DevCounters *ctr) {
   static_assert(kMaxParts <= 8 * 256, "k_part_tail holds 8 partitions per thread");
   OffsetsArgs A;
   A.binhist = binhist; A.nbins = pl.nbins; A.bins_per_part = pl.bins_per_part; A.nparts = pl.nparts;
@@ -1675,7 +1700,7 @@ void launch_part_offsets(hipStream_t s, const uint32_t *binhist, const PartPlan 
   A.offs32 = offs32; A.total = total; A.part_start = part_start;
   A.st = slice_table(slice_mem, slots, pl);
   A.slice_len = g.val == nullptr ? 0xFFFFFFFFu : slice_len_of(sampled, slots, pl.nparts);   // (no grid: the sparse sort reads whole partitions, nothing is split or pre-zeroed)
-  A.g = g; A.shift_part = pl.shift_part;
+  A.g = g; A.shift_part = pl.shift_part; A.ctr = sampled ? ctr : nullptr;
   hipLaunchKernelGGL(k_part_offsets, dim3((pl.nparts + 3) / 4), dim3(256), 0, s, A);
   hipLaunchKernelGGL(k_part_tail, dim3(1), dim3(256), 0, s, A);
 }
