@@ -336,14 +336,19 @@ __global__ __launch_bounds__(kPartThreads) void k_meta_hist(const uint64_t *__re
 // ------------------------------------------------------------------------------------------------
 // offsets: cnt[g][p] (row reduce of the bins) -> column-wise exclusive prefix over g -> part_start[p]
 // ------------------------------------------------------------------------------------------------
-// Capacity of a (workgroup, partition) region from pass A's ESTIMATED record count (rows of the whole-read stretches once, rows of the
-// sampled stretches x the sampling interval): the estimate (std dev < sqrt(estimate * interval) for hashed keys) + 5.5 sigma + a floor for
-// partitions the sample missed.  Too small -> pass B raises DEV_ERR_REGION_FULL and the host reruns with the exact histogram.  Too large is
-// not free either: pass C's walk follows the address span of a partition's regions (6 sigma + 144: k_tile_aggregate 302-309 us at C2
-// against 295 with the ~17 % smaller regions of the estimator before — profiles/r6_s24_*).
+// Capacity of a (workgroup, partition) region from pass A's ESTIMATED record count est = 16 S + E (S rows of the partition in the sampled
+// stretches, each standing for 16; E rows in the whole-read end, counted once): est + 5.5 sqrt(16 est) + 192.  Too small -> pass B raises
+// DEV_ERR_REGION_FULL and the host reruns with the exact histogram.  The danger is the LOW tail of S (~Poisson(n / 16)): a low S makes the
+// estimate and the slack computed from it small together, so the constant decides, not the multiple of sigma — with 5.5 sigma + 96 a C2
+// region (S ~ 29) overflowed when S <= 7: 5e-7 per region, one job in ten (and deterministically the C2 job with a start_time + end_time
+// window); with + 192, S <= 2 or less: < 1e-3 per job for regions of 60 .. 2000 records (binomial tails, profiles/r6_s28_*).  Too large is
+// not free either: pass C's walk follows the address span of a partition's regions (k_tile_aggregate 302-309 us at C2 for these ~1180-slot
+// regions against 295 for the ~980 of the biased estimate before, profiles/r6_s24_*) — the price of an estimate that holds for keys that
+// come and go.
+static constexpr double kCapSigmas = 5.5, kCapIntervals = 12.0;    // (sampled_slots_bound on the host sums these capacities: keep the two in step)
 __device__ __forceinline__ uint32_t sampled_capacity(uint32_t est) {
   constexpr double scale = (double)(kSampleMask + 1);
-  return (uint32_t)((double)est + 5.5 * sqrt((double)est * scale) + 6.0 * scale);
+  return (uint32_t)((double)est + kCapSigmas * sqrt((double)est * scale) + kCapIntervals * scale);
 }
 // Pass C walks sampled regions one wavefront per region.  A partition whose records sit in a FEW large regions (rows sorted by key: two
 // regions of 1e5 records) would be walked by one or two wavefronts — 1.4 ms of pass C at C2.  Such a table is sent to the exact histogram
@@ -1661,8 +1666,9 @@ bool launch_meta_hist(hipStream_t s, const uint64_t *key, const uint64_t *key2, 
 
 // 6 sigma of every region summed by Cauchy-Schwarz over R = G * nparts regions whose estimates total <= slots
 uint64_t sampled_slots_bound(uint64_t slots, const PartPlan &pl) {
-  const double R = (double)pl.G * (double)pl.nparts, scale = (double)(kSampleMask + 2);   // sampling ratio 1/16 plus the chunk ends
-  return slots + (uint64_t)(6.0 * sqrt(scale * R * (double)slots) + R * (8.0 * scale + 16.0 + 16.0)) + 1024;
+  const double R = (double)pl.G * (double)pl.nparts, scale = (double)(kSampleMask + 2);   // (the sampling interval, and one to spare)
+  static_assert(kCapSigmas <= 6.0, "the bound below sums 6 sigma per region");
+  return slots + (uint64_t)(6.0 * sqrt(scale * R * (double)slots) + R * (kCapIntervals * scale + 16.0)) + 1024;   // sampled_capacity's constant + the rounding to 16, per region
 }
 
 // slice table inside slice_mem: slice_part[max_slices] | slice_first[nparts] | n_slices

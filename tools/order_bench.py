@@ -146,15 +146,18 @@ for name, kw in (("no window", {}),
                  ("end_time keeps 80 % of the buckets", dict(end_time=t_lo + (t_hi - t_lo) * 4 // 5)),
                  ("start_time + end_time keep the middle 60 %", dict(flow_start_s=tstart, start_time=t_lo + (t_hi - t_lo) // 5, end_time=t_lo + (t_hi - t_lo) * 4 // 5))):
     ms, pa, pb, s0 = [], [], [], []
+    first = None
     for i in range(args.jobs + 2):
         t0 = time.perf_counter()
         r = eng.run(cfg["algo"], key, tend, val, K, agg_flow=cfg["agg"], out="device", **kw)
         st = r.stats
         r.close()
+        if first is None:
+            first = (st["stage0_attempts"], st["hist_sampled"])
         if i >= 2:
             ms.append((time.perf_counter() - t0) * 1e3)
             pa.append(st["ms_meta"]); pb.append(st["ms_scatter"]); s0.append(st["ms_stage0"])
     md = statistics.median
-    print("  %-46s %7.3f ms/job (pass A %.3f, stage 0 %.3f [pass B %.3f]) rows used %d of %d, %d anomalies, attempts %d hist_sampled %d"
-          % (name, md(ms), md(pa), md(s0), md(pb), st["rows_used"], n, st["n_anomalies"], st["stage0_attempts"], st["hist_sampled"]))
+    print("  %-46s %7.3f ms/job (pass A %.3f, stage 0 %.3f [pass B %.3f]) rows used %d of %d, %d anomalies, attempts %d hist_sampled %d (first job: %d, %d)"
+          % (name, md(ms), md(pa), md(s0), md(pb), st["rows_used"], n, st["n_anomalies"], st["stage0_attempts"], st["hist_sampled"], first[0], first[1]))
 eng.close()
