@@ -223,3 +223,46 @@ def test_c5_whole_table_on_one_gpu(engine):
             assert (an_all[a:b] == (np.abs(pvf[a:b] - want) > sigma[i])).all()
     for d in (dk, dt, dv):
         d.free()
+
+
+def test_full_size_first_jobs_go_through_on_the_sampled_histogram():
+    """Every job of a controller is the FIRST on its table (controller.go:499-523), so what the sampled pass A costs when it is wrong is paid by
+    every job it is wrong for.  On the C2 table — hashed, with an `--end-time`, with `--start-time` + `--end-time` (regions of ~300 records: the
+    low tail of the sampled count, where `sampled_capacity`'s constant decides) — and on a time-ordered table whose keys are alive for a tenth
+    of it (keys that LEAVE while a workgroup's chunk is read: the estimate must not be biased against them), a fresh engine's first job
+    settles on the sample in ONE attempt; rows sorted by key are sent to the exact histogram (two attempts, the first one cut short)."""
+    import torch
+    from theia_amd import TadEngine
+    N, K, T = SHAPES["c2"]
+    dev = torch.device("cuda", 0)
+    key = torch.empty(N, dtype=torch.int64, device=dev)
+    tend = torch.empty(N, dtype=torch.int64, device=dev)
+    val = torch.empty(N, dtype=torch.int64, device=dev)
+    eng = TadEngine(device=0)
+    eng.synth(0, N, K, T, into=(key, tend, val))
+    eng.close()
+    lo, hi = int(tend.min()), int(tend.max())
+    i = torch.arange(N, device=dev)
+    W = K // 10
+    k_live = ((i.double() * ((K - W) / N)).long() + (key * 2654435761 % W)) % K
+    t_live = lo + 60 * ((i.double() * (T / N)).long())
+    del i
+    tstart = tend - 30
+    by_key = torch.sort(key, stable=True).indices
+    cases = [("hashed", (key, tend, val), {}, (1, 1)),
+             ("end_time", (key, tend, val), dict(end_time=lo + (hi - lo) * 4 // 5), (1, 1)),
+             ("start_and_end_time", (key, tend, val), dict(flow_start_s=tstart, start_time=lo + (hi - lo) // 5, end_time=lo + (hi - lo) * 4 // 5), (1, 1)),
+             ("keys_alive_for_a_tenth_in_time_order", (k_live, t_live, val), {}, (1, 1)),
+             ("rows_by_key", (key[by_key].contiguous(), tend[by_key].contiguous(), val[by_key].contiguous()), {}, (2, 0))]
+    torch.cuda.synchronize()      # (the columns were written on torch's stream, the engine reads them on its own)
+    rows = {}
+    for name, (k, t, v), kw, want in cases:
+        eng = TadEngine(device=0)
+        try:
+            r = eng.run("EWMA", k, t, v, K, agg_flow="svc", out="device", **kw)
+            assert (r.stats["stage0_attempts"], r.stats["hist_sampled"]) == want, (name, r.stats["stage0_attempts"], r.stats["hist_sampled"])
+            rows[name] = r.n_rows
+            r.close()
+        finally:
+            eng.close()
+    assert rows["rows_by_key"] == rows["hashed"]        # (the same rows in another order: the same anomalies)
