@@ -327,6 +327,20 @@ def test_exact_histogram_learnt_from_a_sorted_table_expires(stage0):
         eng.close()
 
 
+def test_job_two_keys_per_row_through_the_sampled_histogram(engine, stage0):
+    """Pod mode's UNION ALL (anomaly_detection.py:556-565: a row counts for its source pod and for its destination pod) on a table big enough
+    for the sampled pass A: both keys of a sampled row are weighted alike, a tenth of the second keys are TAD_KEY_SKIP."""
+    n, K, T = 6_000_000, 3000, 50
+    k, t, v = orc.synth_rows(0, n, K, T)
+    rng = np.random.default_rng(31)
+    k2 = (k * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(K)
+    k2 = np.where(rng.random(n) < 0.1, SKIP, k2)
+    res, want = check_job(engine, "EWMA", k, t, v, K, agg_flow="pod", key_id2=k2)
+    assert res.stats["rows_used"] == n + int((k2 != SKIP).sum())
+    if stage0 != "v1":
+        assert res.stats["hist_sampled"] == 1 and res.stats["stage0_attempts"] == 1
+
+
 @pytest.mark.parametrize("window", ["end_80", "start_end_60", "one_bucket"])
 def test_job_time_window_through_the_sampled_histogram(engine, stage0, window):
     """`theia tad run --start-time / --end-time` (anomaly_detection.py:581-586) on a table big enough for the sampled pass A: the window is
